@@ -1,0 +1,293 @@
+"""Pure-PyTorch fp32 CPU restatement of the steps/pytorchnn hot path.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Every function is stateless and
+works on a flat ``state_dict`` (name -> tensor) whose key names are the
+reference's, so a checkpoint written by either side can
+be fed to the other.  Citations are ``/root/reference/steps/pytorchnn/<file>:line``.
+
+Noise (eps) is always an explicit argument: ``None`` means eval mode / mean
+weights, a tensor means "this is the N(0,1) draw the layer would have made".
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------
+# variational weights + KL
+# ----------------------------------------------------------------------------
+
+
+def sampled_weight(mu, lgstd, eps):
+    """W = mu + exp(lgstd) * eps   (model.py:1083-1107; eval -> W = mu)."""
+    if eps is None:
+        return mu
+    return mu + torch.exp(lgstd) * eps
+
+
+def bayes_linear(x, mu, lgstd, eps=None):
+    """BayesLinear.forward, bias=False default (model.py:1050,1127-1129)."""
+    return F.linear(x, sampled_weight(mu, lgstd, eps))
+
+
+def kl_mean_form(mu, lgstd):
+    """mean(mu^2 - 2 lgstd + exp(2 lgstd)) / 2 -- no '-1', mean not sum
+    (model.py:1115, :762-765, :1255)."""
+    return torch.mean(mu ** 2.0 - lgstd * 2.0 + torch.exp(lgstd * 2.0)) / 2.0
+
+
+def kl_mean_form_minus1(mu, lgstd):
+    """GPNN flavour, with the '-1' (model.py:1816-1826)."""
+    return torch.mean(mu ** 2 - lgstd * 2.0 + torch.exp(lgstd * 2.0) - 1) / 2.0
+
+
+# ----------------------------------------------------------------------------
+# Transformer pieces
+# ----------------------------------------------------------------------------
+
+
+def positional_table(max_len, d_model):
+    """Sinusoidal table (max_len, 1, d) (model.py:97-103)."""
+    pe = torch.zeros(max_len, d_model)
+    pos = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.unsqueeze(1)
+
+
+def causal_mask(T):
+    """Additive float mask, -inf above the diagonal (model.py:1258-1262)."""
+    m = torch.full((T, T), float("-inf"))
+    return torch.triu(m, diagonal=1)
+
+
+def attention_core(q, k, v, nhead, mask):
+    """q,k,v: (T,B,d) already projected.  Head index = b*nhead + head
+    (model.py:889-920).  Returns (T,B,d) before o_net."""
+    T, B, d = q.shape
+    hd = d // nhead
+    q = q * (float(hd) ** -0.5)
+    q = q.contiguous().view(T, B * nhead, hd).transpose(0, 1)
+    k = k.contiguous().view(-1, B * nhead, hd).transpose(0, 1)
+    v = v.contiguous().view(-1, B * nhead, hd).transpose(0, 1)
+    s = torch.bmm(q, k.transpose(1, 2))
+    if mask is not None:
+        s = s + mask.unsqueeze(0)
+    p = torch.softmax(s, dim=-1)
+    o = torch.bmm(p, v)
+    return o.transpose(0, 1).contiguous().view(T, B, d)
+
+
+def mha(x, sd, pre, nhead, mask, eps=None):
+    """MultiheadAttention (fused qkv_net, model.py:871-928) or
+    BayesMultiheadAttention (separate q/k/v nets, Bayesian o_net,
+    model.py:971-1019), chosen by which keys exist under ``pre``."""
+    if pre + "qkv_net.weight" in sd:
+        qkv = F.linear(x, sd[pre + "qkv_net.weight"], sd[pre + "qkv_net.bias"])
+        q, k, v = qkv.chunk(3, dim=-1)
+    elif pre + "in_proj_weight" in sd:  # nn.MultiheadAttention (TransformerModel baseline)
+        qkv = F.linear(x, sd[pre + "in_proj_weight"], sd[pre + "in_proj_bias"])
+        q, k, v = qkv.chunk(3, dim=-1)
+    else:
+        q = F.linear(x, sd[pre + "q_net.weight"], sd[pre + "q_net.bias"])
+        k = F.linear(x, sd[pre + "k_net.weight"], sd[pre + "k_net.bias"])
+        v = F.linear(x, sd[pre + "v_net.weight"], sd[pre + "v_net.bias"])
+    a = attention_core(q, k, v, nhead, mask)
+    if pre + "o_net.weight_mean" in sd:
+        return bayes_linear(a, sd[pre + "o_net.weight_mean"], sd[pre + "o_net.weight_lgstd"], eps)
+    if pre + "out_proj.weight" in sd:
+        return F.linear(a, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
+    return F.linear(a, sd[pre + "o_net.weight"], sd[pre + "o_net.bias"])
+
+
+def gp_mixture(z, coef, acts):
+    """sum_i act_i(z) * coef[i]  (model.py:1885-1899)."""
+    out = 0
+    for i, a in enumerate(acts):
+        out = out + getattr(F, a)(z) * coef[i]
+    return out
+
+
+def encoder_layer(x, sd, pre, nhead, mask, eps=None):
+    """Post-LN block (model.py:1037-1046, 1162-1176, 2274-2295).  ``eps`` is the
+    single draw this layer makes: for the FFN position it belongs to linear2,
+    for the MHA position to o_net.  A layer with ``gpnn.*`` keys is the
+    GaussTransformerEncoderLayer: gpnn replaces GELU(linear1(x)); under
+    train.py GPNN.sample stays False so its forward is deterministic."""
+    d = x.shape[-1]
+    att_eps = eps if pre + "self_attn.o_net.weight_mean" in sd else None
+    a = mha(x, sd, pre + "self_attn.", nhead, mask, att_eps)
+    x = F.layer_norm(x + a, (d,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])
+    if pre + "gpnn.weights_mean" in sd:
+        z = F.linear(x, sd[pre + "gpnn.weights_mean"], sd[pre + "gpnn.bias_mean"])
+        h = gp_mixture(z, sd[pre + "gpnn.coef_mean"], ["tanh", "sigmoid", "relu", "gelu"])
+    else:
+        h = F.gelu(F.linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"]))
+    if pre + "linear2.weight_mean" in sd:
+        f = bayes_linear(h, sd[pre + "linear2.weight_mean"], sd[pre + "linear2.weight_lgstd"], eps)
+    else:
+        f = F.linear(h, sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
+    return F.layer_norm(x + f, (d,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])
+
+
+def transformer_lm(src, sd, nhead, eps=None):
+    """BayesTransformerModel / TransformerModel / GaussTransformerModel forward
+    with dropout off (model.py:1274-1309, 159-171).  src (T,B) int64 -> logits
+    (T,B,V).  ``eps``: the one N(0,1) draw of the Bayesian tensor (layer-0
+    linear2 / o_net, or embed for 'EMB'); None = eval."""
+    T = src.shape[0]
+    d = sd["encoder.weight"].shape[1]
+    x = F.embedding(src, sd["encoder.weight"]) * math.sqrt(d)
+    if "embed_mean" in sd:  # 'EMB' (model.py:1286-1290)
+        x = F.linear(x, sampled_weight(sd["embed_mean"], sd["embed_lgstd"], eps))
+    x = x + sd["pos_encoder.pe"][:T]
+    mask = causal_mask(T)
+    # nn.TransformerEncoder keys are transformerlayers.layers.N.*, ours .N.*
+    base = "transformerlayers.layers." if any(k.startswith("transformerlayers.layers.") for k in sd) \
+        else "transformerlayers."
+    i = 0
+    while (base + "%d.norm1.weight" % i) in sd:
+        x = encoder_layer(x, sd, base + "%d." % i, nhead, mask, eps if i == 0 else None)
+        i += 1
+    if "embed_mean" in sd:  # model.py:1302-1304 (mean weights, transposed)
+        x = F.linear(x, sd["embed_mean"].t())
+    return F.linear(x, sd["decoder.weight"], sd["decoder.bias"])
+
+
+def kl_transformer(sd, bayes_pos):
+    """Which tensor's KL train.py adds (train.py:340-356)."""
+    if bayes_pos == "FFN":
+        p = "transformerlayers.0.linear2."
+        return kl_mean_form(sd[p + "weight_mean"], sd[p + "weight_lgstd"])
+    if bayes_pos == "MHA":
+        p = "transformerlayers.0.self_attn.o_net."
+        return kl_mean_form(sd[p + "weight_mean"], sd[p + "weight_lgstd"])
+    if bayes_pos == "EMB":
+        return kl_mean_form(sd["embed_mean"], sd["embed_lgstd"])
+    return torch.zeros(())
+
+
+# ----------------------------------------------------------------------------
+# LSTM pieces
+# ----------------------------------------------------------------------------
+
+LSTM_EPS_ORDER = ("weight_hh_lgstd_1", "weight_ih_lgstd_1", "bias_hh_lgstd_1", "bias_ih_lgstd_1",
+                  "weight_hh_lgstd_2", "weight_ih_lgstd_2", "bias_hh_lgstd_2", "bias_ih_lgstd_2")
+
+
+def bayes2lstm_weights(sd, pre, pos, eps8=None):
+    """flat_parameters (model.py:705-732): noise only on gate rows
+    [(pos-1)H, pos*H) of all 8 tensors; eps8 follows LSTM_EPS_ORDER
+    (draw order of model.py:668-703)."""
+    out = {}
+    for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+        for layer in (1, 2):
+            out["%s_%d" % (name, layer)] = sd["%s%s_mean_%d" % (pre, name, layer)].clone()
+    if 1 <= pos <= 4 and eps8 is not None:
+        for key, eps in zip(LSTM_EPS_ORDER, eps8):
+            lg = sd[pre + key]
+            H = lg.shape[0]
+            tgt = key.replace("_lgstd", "")
+            out[tgt][(pos - 1) * H:pos * H] += torch.exp(lg) * eps
+    return out
+
+
+def lstm_layer(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    """One layer over T steps; gates i,f,g,o; c'=sig(f)c+sig(i)tanh(g);
+    h'=sig(o)tanh(c')  (what _VF.lstm computes, model.py:812)."""
+    outs = []
+    xw = F.linear(x, w_ih, b_ih)
+    for t in range(x.shape[0]):
+        g = xw[t] + F.linear(h, w_hh, b_hh)
+        i, f, gg, o = g.chunk(4, dim=-1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        outs.append(h)
+    return torch.stack(outs, 0), h, c
+
+
+def bayes_rnn_lm(x, hidden, sd, pos, eps8=None):
+    """BayesRNNModel.forward, dropout off (model.py:217-222).  x (T,B) int64,
+    hidden = (h0,c0) each (2,B,H).  Returns logits (T,B,V), (hT,cT)."""
+    emb = F.embedding(x, sd["encoder.weight"])
+    w = bayes2lstm_weights(sd, "rnn.", pos, eps8)
+    h0, c0 = hidden
+    y, h1, c1 = lstm_layer(emb, h0[0], c0[0], w["weight_ih_1"], w["weight_hh_1"], w["bias_ih_1"], w["bias_hh_1"])
+    y, h2, c2 = lstm_layer(y, h0[1], c0[1], w["weight_ih_2"], w["weight_hh_2"], w["bias_ih_2"], w["bias_hh_2"])
+    logits = F.linear(y, sd["decoder.weight"], sd["decoder.bias"])
+    return logits, (torch.stack([h1, h2]), torch.stack([c1, c2]))
+
+
+def rnn_lm(x, hidden, sd):
+    """RNNModel with nn.LSTM, eval mode (model.py:61-66): keys rnn.weight_ih_l{k}."""
+    y = F.embedding(x, sd["encoder.weight"])
+    h0, c0 = hidden
+    hs, cs = [], []
+    layer = 0
+    while "rnn.weight_ih_l%d" % layer in sd:
+        y, h, c = lstm_layer(y, h0[layer], c0[layer], sd["rnn.weight_ih_l%d" % layer], sd["rnn.weight_hh_l%d" % layer],
+                             sd["rnn.bias_ih_l%d" % layer], sd["rnn.bias_hh_l%d" % layer])
+        hs.append(h)
+        cs.append(c)
+        layer += 1
+    logits = F.linear(y, sd["decoder.weight"], sd["decoder.bias"])
+    return logits, (torch.stack(hs), torch.stack(cs))
+
+
+def kl_bayes2lstm(sd, pre, pos):
+    """Bayes2LSTM.kl_divergence, pos 1..4 (model.py:734-765): layer-1 tensors
+    only; weights and biases each get their own mean."""
+    if not (1 <= pos <= 4):
+        return torch.zeros(())
+    H = sd[pre + "weight_hh_lgstd_1"].shape[0]
+    r = slice((pos - 1) * H, pos * H)
+    wm = torch.cat([sd[pre + "weight_hh_mean_1"][r], sd[pre + "weight_ih_mean_1"][r]], -1)
+    wl = torch.cat([sd[pre + "weight_hh_lgstd_1"], sd[pre + "weight_ih_lgstd_1"]], -1)
+    bm = torch.cat([sd[pre + "bias_hh_mean_1"][r], sd[pre + "bias_ih_mean_1"][r]], -1)
+    bl = torch.cat([sd[pre + "bias_hh_lgstd_1"], sd[pre + "bias_ih_lgstd_1"]], -1)
+    return kl_mean_form(wm, wl) + kl_mean_form(bm, bl)
+
+
+# ----------------------------------------------------------------------------
+# loss / step / scoring
+# ----------------------------------------------------------------------------
+
+
+def cross_entropy_mean(logits, targets):
+    """nn.CrossEntropyLoss() on (M,V) (train.py:233,332)."""
+    return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), targets.reshape(-1))
+
+
+def token_nll(logits, targets):
+    """Per-token NLL (M,), the quantity PPL and n-best scores are sums of."""
+    return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), targets.reshape(-1), reduction="none")
+
+
+def sentence_score(logits, targets):
+    """len * CE_mean = sum of token NLL (compute_sentence_scores_bayes_jianwei.py:168-170)."""
+    return targets.numel() * cross_entropy_mean(logits, targets)
+
+
+def clip_and_sgd(params, grads, bufs, lr, clip, momentum=0.9):
+    """clip_grad_norm_(params, clip) then SGD(momentum, wd=0)
+    (train.py:419-420,466).  ``bufs`` entries may be None (first step).
+    Distinct tensors only (a tied weight appears once).  In place."""
+    total = torch.sqrt(sum((g.detach() ** 2).sum() for g in grads))
+    coef = torch.clamp(clip / (total + 1e-6), max=1.0)
+    for i, (p, g) in enumerate(zip(params, grads)):
+        g = g * coef
+        if bufs[i] is None:
+            bufs[i] = g.clone()
+        else:
+            bufs[i].mul_(momentum).add_(g)
+        p.data.add_(bufs[i], alpha=-lr)
+    return total
+
+
+def transformer_train_loss(src, targets, sd, nhead, bayes_pos, eps, kl_scale):
+    """loss = CE_mean + KL * seq_len/len(train_data) (train.py:332-412)."""
+    logits = transformer_lm(src, sd, nhead, eps)
+    mle = cross_entropy_mean(logits, targets)
+    kl = kl_transformer(sd, bayes_pos) * kl_scale
+    return mle + kl, mle, kl

@@ -1,0 +1,36 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name, device="cpu"):
+    """-> (dict of plain entries as torch tensors, state_dict, grad dict)."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    plain, sd, grad = {}, {}, {}
+    for k in z.files:
+        v = z[k]
+        t = torch.from_numpy(v).to(device) if v.dtype.kind in "fiu" else v
+        if k.startswith("sd/"):
+            sd[k[3:]] = t
+        elif k.startswith("grad/"):
+            grad[k[5:]] = t
+        else:
+            plain[k] = t
+    return plain, sd, grad
+
+
+@pytest.fixture
+def golden():
+    return load_golden

@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/ by RUNNING THE REFERENCE.
+
+Run only in the build container (the reference never travels to the GPU box):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python3 /root/repo/tests/golden/make_golden.py
+
+It imports /root/reference/steps/pytorchnn/{model,data}.py read-only, drives the
+reference classes on tiny seeded inputs and stores inputs + state_dict +
+outputs as .npz (data only; no reference source is copied).  eps recovery
+follows SURVEY.md Appendix D: re-seed, replay the same ``zeros().normal_()``
+draws the layer makes, re-seed again, run the layer.
+"""
+import contextlib
+import io
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+REF = "/root/reference/steps/pytorchnn"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+with contextlib.redirect_stdout(io.StringIO()):
+    import model as ref  # noqa: E402
+    import data as refdata  # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def pack_sd(m):
+    # pos_encoder.pe is a deterministic (5000,1,d) table: keep 64 rows so fixtures stay small
+    return {"sd/" + k: (npy(v)[:64] if k.endswith("pos_encoder.pe") else npy(v)) for k, v in m.state_dict().items()}
+
+
+def grads(m):
+    return {"grad/" + k: npy(p.grad) for k, p in m.named_parameters() if p.grad is not None}
+
+
+def save(name, **kw):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def zero_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+
+
+# ---------------------------------------------------------------- F1 BayesLinear
+def f1_bayes_linear():
+    torch.manual_seed(11)
+    lin = ref.BayesLinear(24, 10)
+    x = torch.randn(7, 3, 24, requires_grad=True)
+    g = torch.randn(7, 3, 10)
+    kl_scale = 0.37
+    lin.train()
+    torch.manual_seed(5)
+    eps = torch.zeros(10, 24).normal_(0, 1)
+    torch.manual_seed(5)
+    y = lin(x)
+    kl = lin.kl_divergence()
+    ((y * g).sum() + kl * kl_scale).backward()
+    lin.eval()
+    y_eval = lin(x)
+    save("bayes_linear", x=npy(x), g=npy(g), eps=npy(eps), kl_scale=np.float32(kl_scale),
+         mu=npy(lin.weight_mean), lgstd=npy(lin.weight_lgstd), y_train=npy(y), y_eval=npy(y_eval), kl=npy(kl),
+         dx=npy(x.grad), dmu=npy(lin.weight_mean.grad), dlgstd=npy(lin.weight_lgstd.grad))
+
+
+# ---------------------------------------------------------------- F3 Transformer LMs
+def f3_transformer(bayes_pos):
+    V, d, h, ff, L, T, B = 50, 16, 4, 32, 2, 6, 3
+    torch.manual_seed(21)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref.BayesTransformerModel(V, d, h, ff, L, 0.2, True, bayes_pos)
+    zero_dropout(m)  # layer 0 is built with a hard-coded 0.2 (model.py:1202)
+    src = torch.randint(0, V, (T, B))
+    tgt = torch.randint(0, V, (T * B,))
+    kl_scale = float(T) / 123.0
+    shape = {"FFN": (d, ff), "MHA": (d, d), "EMB": (d, d)}.get(bayes_pos)
+    m.train()
+    torch.manual_seed(9)
+    eps = torch.zeros(*shape).normal_() if shape else None
+    torch.manual_seed(9)
+    logits = m(src)
+    mle = torch.nn.functional.cross_entropy(logits.view(-1, V), tgt)
+    if bayes_pos == "FFN":
+        kl = m.transformerlayers[0].linear2.kl_divergence()
+    elif bayes_pos == "MHA":
+        kl = m.transformerlayers[0].self_attn.o_net.kl_divergence()
+    elif bayes_pos == "EMB":
+        kl = m.embed_kl_divergence()
+    else:
+        kl = torch.zeros(())
+    loss = mle + kl * kl_scale
+    loss.backward()
+    m.eval()
+    with torch.no_grad():
+        logits_eval = m(src)
+        nll_eval = torch.nn.functional.cross_entropy(logits_eval.view(-1, V), tgt, reduction="none")
+    kw = dict(src=npy(src), tgt=npy(tgt), nhead=np.int64(h), kl_scale=np.float32(kl_scale),
+              logits_train=npy(logits), mle=npy(mle), kl=npy(kl), loss=npy(loss),
+              logits_eval=npy(logits_eval), nll_eval=npy(nll_eval))
+    if eps is not None:
+        kw["eps"] = npy(eps)
+    kw.update(pack_sd(m))
+    kw.update(grads(m))
+    save("bayes_tlm_" + bayes_pos, **kw)
+
+
+def f3_transformer_baseline():
+    V, d, h, ff, L, T, B = 50, 16, 4, 32, 2, 6, 3
+    torch.manual_seed(22)
+    m = ref.TransformerModel(V, d, h, ff, L, 0.2, "gelu", True)
+    src = torch.randint(0, V, (T, B))
+    tgt = torch.randint(0, V, (T * B,))
+    m.eval()
+    with torch.no_grad():
+        try:
+            torch.backends.mha.set_fastpath_enabled(False)
+        except Exception:
+            pass
+        logits = m(src)
+        nll = torch.nn.functional.cross_entropy(logits.view(-1, V), tgt, reduction="none")
+    save("transformer_baseline", src=npy(src), tgt=npy(tgt), nhead=np.int64(h),
+         logits_eval=npy(logits), nll_eval=npy(nll), **pack_sd(m))
+
+
+def f4_gauss_transformer(gp):
+    V, d, h, ff, L, T, B = 50, 16, 4, 32, 2, 6, 3
+    torch.manual_seed(23 + gp)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref.GaussTransformerModel(V, d, h, ff, L, 0.0, True, gp)
+    src = torch.randint(0, V, (T, B))
+    tgt = torch.randint(0, V, (T * B,))
+    m.train()  # GPNN.sample is False under train.py -> deterministic (model.py:1799)
+    logits = m(src)
+    mle = torch.nn.functional.cross_entropy(logits.view(-1, V), tgt)
+    kl = m.transformerlayers[0].gpnn.kl_divergence() if 1 <= gp <= 3 else torch.zeros(())
+    if not torch.is_tensor(kl):
+        kl = torch.tensor(float(kl))
+    (mle + kl * 0.05).backward()
+    m.eval()
+    with torch.no_grad():
+        logits_eval = m(src)
+    save("gauss_tlm_%d" % gp, src=npy(src), tgt=npy(tgt), nhead=np.int64(h), kl_scale=np.float32(0.05),
+         logits_train=npy(logits), logits_eval=npy(logits_eval), mle=npy(mle), kl=npy(kl),
+         **pack_sd(m), **grads(m))
+
+
+# ---------------------------------------------------------------- F2 Bayes LSTM
+EPS_ORDER = ("weight_hh_lgstd_1", "weight_ih_lgstd_1", "bias_hh_lgstd_1", "bias_ih_lgstd_1",
+             "weight_hh_lgstd_2", "weight_ih_lgstd_2", "bias_hh_lgstd_2", "bias_ih_lgstd_2")
+
+
+def f2_bayes_rnn(pos):
+    V, H, T, B = 40, 12, 5, 3
+    torch.manual_seed(31 + pos)
+    m = ref.BayesRNNModel("LSTM", V, H, H, 2, 0.0, True, pos)
+    x1 = torch.randint(0, V, (T, B))
+    x2 = torch.randint(0, V, (T, B))
+    tgt = torch.randint(0, V, (T * B,))
+    kl_scale = float(T) / 77.0
+    m.train()
+    hidden = m.init_hidden(B)
+    kw = {}
+    eps_all = []
+    for w, x in enumerate((x1, x2)):
+        torch.manual_seed(100 + w)
+        eps8 = []
+        if 1 <= pos <= 4:
+            for k in EPS_ORDER:
+                eps8.append(torch.zeros_like(getattr(m.rnn, k)).normal_())
+        eps_all.append(eps8)
+        torch.manual_seed(100 + w)
+        hidden = tuple(h.detach() for h in hidden)
+        logits, hidden = m(x, hidden)
+        kw["logits_train_%d" % w] = npy(logits)
+        for j, e in enumerate(eps8):
+            kw["eps_%d_%d" % (w, j)] = npy(e)
+    mle = torch.nn.functional.cross_entropy(logits.view(-1, V), tgt)
+    # train.py:337 only asks for the KL when 1 <= pos <= 5 (pos 0 would raise in the reference)
+    kl = m.rnn.kl_divergence() if 1 <= pos <= 4 else torch.zeros(())
+    (mle + kl * kl_scale).backward()
+    kw.update(h_train=npy(hidden[0]), c_train=npy(hidden[1]), mle=npy(mle), kl=npy(kl))
+    m.eval()
+    with torch.no_grad():
+        hidden = m.init_hidden(B)
+        l1, hidden = m(x1, hidden)
+        l2, hidden = m(x2, hidden)
+    kw.update(logits_eval_0=npy(l1), logits_eval_1=npy(l2), h_eval=npy(hidden[0]), c_eval=npy(hidden[1]),
+              x1=npy(x1), x2=npy(x2), tgt=npy(tgt), pos=np.int64(pos), kl_scale=np.float32(kl_scale))
+    kw.update(pack_sd(m))
+    kw.update(grads(m))
+    save("bayes_rnn_pos%d" % pos, **kw)
+
+
+def f2_rnn_baseline():
+    V, H, T, B = 40, 12, 5, 3
+    torch.manual_seed(41)
+    m = ref.RNNModel("LSTM", V, H, H, 2, 0.2, True)
+    x1 = torch.randint(0, V, (T, B))
+    x2 = torch.randint(0, V, (T, B))
+    m.eval()
+    with torch.no_grad():
+        hidden = m.init_hidden(B)
+        l1, hidden = m(x1, hidden)
+        l2, hidden = m(x2, hidden)
+    save("rnn_baseline", x1=npy(x1), x2=npy(x2), logits_eval_0=npy(l1), logits_eval_1=npy(l2),
+         h_eval=npy(hidden[0]), c_eval=npy(hidden[1]), **pack_sd(m))
+
+
+# ---------------------------------------------------------------- F8 data layout
+def f8_data():
+    words = ["<s>", "<unk>"] + ["w%03d" % i for i in range(2, 30)]
+    rng = np.random.RandomState(3)
+    with tempfile.TemporaryDirectory() as dtmp:
+        with open(os.path.join(dtmp, "words.txt"), "w") as f:
+            for i, w in enumerate(words):
+                f.write("%s %d\n" % (w, i))
+        texts = {}
+        for split, n in (("train", 40), ("valid", 9), ("test", 7)):
+            lines = []
+            for _ in range(n):
+                ln = 1 + rng.poisson(4)
+                toks = [words[rng.randint(2, 30)] if rng.rand() > 0.1 else "oov%d" % rng.randint(9) for _ in range(ln)]
+                lines.append(" ".join(toks))
+            texts[split] = "\n".join(lines) + "\n"
+            with open(os.path.join(dtmp, split + ".txt"), "w") as f:
+                f.write(texts[split])
+        c = refdata.Corpus(dtmp)
+    # batchify / get_batch restated from the call sites (train.py:167-179, 299-303) on the reference's ids
+    ids = c.train
+    bsz, seq_len = 4, 5
+    nbatch = ids.size(0) // bsz
+    b = ids.narrow(0, 0, nbatch * bsz).view(bsz, -1).t().contiguous()
+    i = 5
+    sl = min(seq_len, len(b) - 1 - i)
+    save("data_layout", words=np.array(words), train_txt=np.array(texts["train"]), valid_txt=np.array(texts["valid"]),
+         test_txt=np.array(texts["test"]), train_ids=npy(c.train), valid_ids=npy(c.valid), test_ids=npy(c.test),
+         bsz=np.int64(bsz), seq_len=np.int64(seq_len), batchified=npy(b), get_batch_i=np.int64(i),
+         get_batch_data=npy(b[i:i + sl]), get_batch_target=npy(b[i + 1:i + 1 + sl].view(-1)))
+
+
+if __name__ == "__main__":
+    f1_bayes_linear()
+    for bp in ("FFN", "MHA", "EMB", "none"):
+        f3_transformer(bp)
+    f3_transformer_baseline()
+    for gp in (0, 1, 2, 3):
+        f4_gauss_transformer(gp)
+    for pos in (0, 1, 2, 3, 4):
+        f2_bayes_rnn(pos)
+    f2_rnn_baseline()
+    f8_data()

@@ -1,0 +1,141 @@
+"""CPU: the oracle (oracle/bayes_oracle.py) against vectors produced by the
+reference itself (tests/golden/make_golden.py).  Gate: <= 1e-5 abs on logits."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import bayes_oracle as O
+from oracle import philox as P
+
+TOL = dict(rtol=1e-5, atol=2e-6)
+
+
+def test_philox_known_answers():
+    for c, k, out in P.KAT:
+        r = P.philox4x32_10(*[np.array([x], np.uint32) for x in c], k[0], k[1])
+        assert tuple(int(x[0]) for x in r) == out
+
+
+def test_philox_normal_moments_and_determinism():
+    z = P.normal(1 << 18, 1111, P.STREAM_WEIGHT + 3, 7)
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3
+    assert np.isfinite(z).all()
+    np.testing.assert_array_equal(z[:1001], P.normal(1001, 1111, P.STREAM_WEIGHT + 3, 7))
+    assert not np.array_equal(z[:64], P.normal(64, 1111, P.STREAM_WEIGHT + 3, 8)[:64])
+    keep = P.keep_mask(1 << 18, 0.2, 1111, P.STREAM_DROPOUT, 0)
+    assert abs(float(keep.mean()) - 0.8) < 5e-3
+
+
+def test_bayes_linear_matches_reference():
+    g, _, _ = load_golden("bayes_linear")
+    x = g["x"].clone().requires_grad_(True)
+    mu = g["mu"].clone().requires_grad_(True)
+    lg = g["lgstd"].clone().requires_grad_(True)
+    y = O.bayes_linear(x, mu, lg, g["eps"])
+    kl = O.kl_mean_form(mu, lg)
+    torch.testing.assert_close(y, g["y_train"], **TOL)
+    torch.testing.assert_close(kl, g["kl"], **TOL)
+    torch.testing.assert_close(O.bayes_linear(x, mu, lg, None), g["y_eval"], **TOL)
+    ((y * g["g"]).sum() + kl * g["kl_scale"]).backward()
+    torch.testing.assert_close(x.grad, g["dx"], **TOL)
+    torch.testing.assert_close(mu.grad, g["dmu"], **TOL)
+    torch.testing.assert_close(lg.grad, g["dlgstd"], **TOL)
+    # closed forms used by the fused HIP epilogue
+    dW = torch.einsum("tbn,tbk->nk", g["g"], g["x"])
+    n = mu.numel()
+    lam = float(g["kl_scale"])
+    torch.testing.assert_close(dW + lam * g["mu"] / n, g["dmu"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dW * g["eps"] * torch.exp(g["lgstd"]) + lam * (torch.exp(2 * g["lgstd"]) - 1) / n,
+                               g["dlgstd"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("pos", ["FFN", "MHA", "EMB", "none"])
+def test_bayes_transformer_matches_reference(pos):
+    g, sd, grad = load_golden("bayes_tlm_" + pos)
+    nhead = int(g["nhead"])
+    logits = O.transformer_lm(g["src"], sd, nhead, None)
+    torch.testing.assert_close(logits, g["logits_eval"], **TOL)
+    torch.testing.assert_close(O.token_nll(logits, g["tgt"]), g["nll_eval"], **TOL)
+    # train mode (dropout 0, eps injected) + every parameter gradient
+    leaf = {k: v.clone().requires_grad_(v.dtype.is_floating_point and k != "pos_encoder.pe") for k, v in sd.items()}
+    if "decoder.weight" in leaf:  # tied (model.py:1240): one tensor under two names
+        leaf["decoder.weight"] = leaf["encoder.weight"]
+    loss, mle, kl = O.transformer_train_loss(g["src"], g["tgt"], leaf, nhead, pos, g.get("eps"), float(g["kl_scale"]))
+    torch.testing.assert_close(mle, g["mle"], **TOL)
+    torch.testing.assert_close(kl / float(g["kl_scale"]) if pos != "none" else kl, g["kl"], **TOL)
+    torch.testing.assert_close(loss, g["loss"], **TOL)
+    loss.backward()
+    for k, gv in grad.items():
+        if k == "decoder.weight":
+            continue
+        torch.testing.assert_close(leaf[k].grad, gv, rtol=2e-4, atol=2e-6, msg=lambda m, k=k: k + ": " + m)
+
+
+def test_transformer_baseline_matches_reference():
+    g, sd, _ = load_golden("transformer_baseline")
+    logits = O.transformer_lm(g["src"], sd, int(g["nhead"]), None)
+    torch.testing.assert_close(logits, g["logits_eval"], **TOL)
+
+
+@pytest.mark.parametrize("gp", [0, 1, 2, 3])
+def test_gauss_transformer_matches_reference(gp):
+    g, sd, grad = load_golden("gauss_tlm_%d" % gp)
+    nhead = int(g["nhead"])
+    torch.testing.assert_close(O.transformer_lm(g["src"], sd, nhead, None), g["logits_eval"], **TOL)
+    # GPNN.sample stays False under train.py -> train forward == eval forward without dropout
+    torch.testing.assert_close(g["logits_train"], g["logits_eval"], **TOL)
+    pre = "transformerlayers.0.gpnn."
+    kl = torch.zeros(())
+    if gp in (1, 3):
+        kl = kl + O.kl_mean_form_minus1(sd[pre + "coef_mean"], sd[pre + "coef_lgstd"])
+    if gp in (2, 3):
+        kl = kl + O.kl_mean_form_minus1(sd[pre + "weights_mean"], sd[pre + "weights_lgstd"])
+        kl = kl + O.kl_mean_form_minus1(sd[pre + "bias_mean"], sd[pre + "bias_lgstd"])
+    torch.testing.assert_close(kl, g["kl"], **TOL)
+
+
+@pytest.mark.parametrize("pos", [0, 1, 2, 3, 4])
+def test_bayes_lstm_matches_reference(pos):
+    g, sd, grad = load_golden("bayes_rnn_pos%d" % pos)
+    B = g["x1"].shape[1]
+    H = sd["rnn.weight_hh_mean_1"].shape[1]
+    zeros = (torch.zeros(2, B, H), torch.zeros(2, B, H))
+    # eval: two windows with hidden carry-over
+    l1, hid = O.bayes_rnn_lm(g["x1"], zeros, sd, pos, None)
+    l2, hid = O.bayes_rnn_lm(g["x2"], hid, sd, pos, None)
+    torch.testing.assert_close(l1, g["logits_eval_0"], **TOL)
+    torch.testing.assert_close(l2, g["logits_eval_1"], **TOL)
+    torch.testing.assert_close(hid[0], g["h_eval"], **TOL)
+    torch.testing.assert_close(hid[1], g["c_eval"], **TOL)
+    # train: eps in the reference's draw order, hidden detached between windows
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    hid = zeros
+    for w, x in enumerate((g["x1"], g["x2"])):
+        eps8 = [g["eps_%d_%d" % (w, j)] for j in range(8)] if 1 <= pos <= 4 else None
+        hid = tuple(h.detach() for h in hid)
+        logits, hid = O.bayes_rnn_lm(x, hid, leaf, pos, eps8)
+        torch.testing.assert_close(logits, g["logits_train_%d" % w], **TOL)
+    torch.testing.assert_close(hid[0], g["h_train"], **TOL)
+    mle = O.cross_entropy_mean(logits, g["tgt"])
+    kl = O.kl_bayes2lstm(leaf, "rnn.", pos)
+    torch.testing.assert_close(mle, g["mle"], **TOL)
+    torch.testing.assert_close(kl, g["kl"], **TOL)
+    (mle + kl * float(g["kl_scale"])).backward()
+    for k, gv in grad.items():
+        if k == "decoder.weight":
+            continue
+        torch.testing.assert_close(leaf[k].grad, gv, rtol=2e-4, atol=2e-6, msg=lambda m, k=k: k + ": " + m)
+
+
+def test_rnn_baseline_matches_reference():
+    g, sd, _ = load_golden("rnn_baseline")
+    B = g["x1"].shape[1]
+    H = sd["rnn.weight_hh_l0"].shape[1]
+    hid = (torch.zeros(2, B, H), torch.zeros(2, B, H))
+    l1, hid = O.rnn_lm(g["x1"], hid, sd)
+    l2, hid = O.rnn_lm(g["x2"], hid, sd)
+    torch.testing.assert_close(l1, g["logits_eval_0"], **TOL)
+    torch.testing.assert_close(l2, g["logits_eval_1"], **TOL)
+    torch.testing.assert_close(hid[1], g["c_eval"], **TOL)
