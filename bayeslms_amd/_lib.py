@@ -1,0 +1,146 @@
+"""ctypes binding of libbayeslm_hip.so (include/bayeslm.h).
+
+The product path has no CPU fallback: if the library is missing, was built for
+another ABI, or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbayeslm_hip.so")
+
+ABI_VERSION = 1
+OK = 0
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_MUL_DGELU, EPI_BAYES_WGRAD, EPI_GP_MIX, EPI_MUL_DGP_MIX = range(7)
+GEMM_ACCUMULATE = 1
+STREAM_WEIGHT = 0x1000
+STREAM_DROPOUT = 0x2000
+
+c_fp = C.POINTER(C.c_float)
+c_i64p = C.POINTER(C.c_int64)
+
+
+class Rng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("stream", C.c_uint32), ("step", C.c_uint32)]
+
+
+class Variational(C.Structure):
+    _fields_ = [("lgstd", C.c_void_p), ("eps", C.c_void_p), ("row_lo", C.c_int32), ("srows", C.c_int32),
+                ("rng", Rng)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("op", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64),
+                ("C", C.c_void_p), ("ldc", C.c_int64), ("alpha", C.c_float), ("flags", C.c_uint32),
+                ("epilogue", C.c_int32), ("bias", C.c_void_p), ("aux", C.c_void_p), ("coef", C.c_void_p),
+                ("var_b", Variational), ("C2", C.c_void_p), ("wg_mu", C.c_void_p), ("var_c", Variational),
+                ("kl_lambda", C.c_float), ("kl_inv_n", C.c_float), ("drop_p", C.c_float), ("drop_rng", Rng),
+                ("drop_B", C.c_int32), ("drop_col_offset", C.c_int32), ("drop_global_cols", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/bayeslm.h declares
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+_rngp, _varp = C.POINTER(Rng), C.POINTER(Variational)
+SIGNATURES = {
+    "blm_abi_version": (C.c_uint32, []),
+    "blm_last_error": (C.c_char_p, []),
+    "blm_query": (_i, [_i, C.c_char_p, C.POINTER(_i), C.POINTER(_i)]),
+    "blm_sample_weight": (_i, [_vp, _i64, _i64, _varp, _vp, _vp, _f, _vp]),
+    "blm_sample_weight_bwd": (_i, [_vp, _i64, _i64, _varp, _vp, _vp, _vp]),
+    "blm_philox_normal": (_i, [_vp, _i64, _rngp, _vp]),
+    "blm_kl_mean_fwd": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _f, _vp, _vp]),
+    "blm_kl_mean_bwd": (_i, [_vp, _i64, _vp, _i64, _i64, _vp, _f, _vp, _i64, _vp, _vp]),
+    "blm_gemm": (_i, [C.POINTER(GemmArgs), _vp]),
+    "blm_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _f, _f, _rngp, _i, _i, _vp]),
+    "blm_embed_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _f, _f, _rngp, _i, _i, _vp]),
+    "blm_add_pe_dropout": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
+    "blm_dropout": (_i, [_vp, _vp, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
+    "blm_add_dropout_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _rngp, _i, _i, _vp]),
+    "blm_ln_bwd_ws_floats": (_i64, [_i, _i]),
+    "blm_add_dropout_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
+    "blm_attn_fwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
+    "blm_attn_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
+    "blm_ce_fwd_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "blm_ce_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
+    "blm_colsum": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp]),
+    "blm_sqnorm_multi": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "blm_clip_sgd_multi": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _i, _f, _vp]),
+    "blm_lstm_cell_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "blm_lstm_cell_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "blm_axpy": (_i, [_vp, _vp, _i64, _f, _vp]),
+}
+
+_lib = None
+
+
+class BayesLMError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises if it is not built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BayesLMError(
+                "libbayeslm_hip.so is not built (%s). Build it with `make -C bayeslms_amd/csrc` or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if l.blm_abi_version() != ABI_VERSION:
+            raise BayesLMError("libbayeslm_hip.so ABI %d != binding ABI %d" % (l.blm_abi_version(), ABI_VERSION))
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != OK:
+        raise BayesLMError("%s failed (status %d): %s" % (what or "libbayeslm_hip call", rc,
+                                                          lib().blm_last_error().decode("utf-8", "replace")))
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def dev_tensor(t, name="tensor", dtype=torch.float32):
+    """Product-path guard: fp32 (or int64) contiguous tensor on the GPU."""
+    if not t.is_cuda:
+        raise BayesLMError("%s must live on the GPU: bayeslms_amd has no CPU path" % name)
+    if t.dtype != dtype:
+        raise BayesLMError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def rng(seed, stream_id, step):
+    return Rng(int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF)
+
+
+_checked_arch = False
+
+
+def require_gfx950():
+    """Called once per process before the first kernel launch."""
+    global _checked_arch
+    if _checked_arch:
+        return
+    if not torch.cuda.is_available():
+        raise BayesLMError("no GPU visible: bayeslms_amd runs on MI355X (gfx950) only")
+    arch = C.create_string_buffer(32)
+    ncu, lds = C.c_int(0), C.c_int(0)
+    check(lib().blm_query(torch.cuda.current_device(), arch, C.byref(ncu), C.byref(lds)), "blm_query")
+    name = arch.value.decode()
+    if not name.startswith("gfx950"):
+        raise BayesLMError("libbayeslm_hip.so is built for gfx950 only, device is %s" % name)
+    _checked_arch = True

@@ -1,0 +1,295 @@
+// Fused causal self-attention, forward and backward, one workgroup per (batch column, head).
+// Scores, softmax, probability dropout and P.V never leave the CU: K/V (forward) and then Q/dO
+// (backward) tiles sit in LDS, each lane owns one query (or key) row in registers, LDS reads are
+// wave-uniform broadcasts.  T <= 128, head_dim in {4,8,16,32,64}.
+//
+// Replaces model.py:889-920 (MultiheadAttention.forward core: scale, bmm, +mask, softmax, dropout,
+// bmm) and the same lines of BayesMultiheadAttention (:990-1011), plus their autograd.
+// Attention is ~2.4 % of the layer FLOPs at T=128 so this round keeps it on the
+// f32 VALU; the GEMM-shaped QKV/O projections run on the MFMA kernel.
+#include "blm_device.h"
+#include "blm_host.h"
+
+namespace blm {
+
+constexpr int ATT_T = 128;  // threads per block = max sequence length
+
+struct AttnP {
+  const float *q, *k, *v;
+  long ld;
+  float* out;
+  float* lse;
+  const float *o_in, *dout;
+  float *dq, *dk, *dv;
+  long ldd;
+  int T, B, nhead;
+  float scale;
+  blm_rng rng;
+  uint32_t thr;
+  float inv_keep;
+  int col_offset;
+  bool drop;
+};
+
+// keep factor for probability element g (global index into (B_global*nhead, T, T))
+__device__ __forceinline__ float keep_at(const AttnP& p, uint64_t g) {
+  const u32x4 u = philox_block(p.rng, g >> 2);
+  const int c = (int)(g & 3);
+  const uint32_t bits = c == 0 ? u.x : (c == 1 ? u.y : (c == 2 ? u.z : u.w));
+  return bits >= p.thr ? p.inv_keep : 0.f;
+}
+
+template <int HD>
+__device__ __forceinline__ void load_tile(float* dst, const float* src, long ld, int T, int B, int b, int off, float mul) {
+  // dst[t][c] = src[(t*B+b)*ld + off + c] * mul
+  constexpr int Q = HD / 4;
+  for (int i = threadIdx.x; i < T * Q; i += ATT_T) {
+    const int t = i / Q, c = (i - t * Q) * 4;
+    const float* s = src + ((long)t * B + b) * ld + off + c;
+    float4 v;
+    if (((reinterpret_cast<uintptr_t>(s)) & 15) == 0) v = *reinterpret_cast<const float4*>(s);
+    else v = make_float4(s[0], s[1], s[2], s[3]);
+    v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+    *reinterpret_cast<float4*>(dst + t * HD + c) = v;
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(ATT_T) void attn_fwd_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Ks = sm;
+  float* Vs = sm + p.T * HD;
+  const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
+  const int T = p.T, i = threadIdx.x;
+  load_tile<HD>(Ks, p.k, p.ld, T, p.B, b, off, 1.f);
+  load_tile<HD>(Vs, p.v, p.ld, T, p.B, b, off, 1.f);
+  float q[HD], o[HD];
+  const bool act = i < T;
+  if (act) {
+    const float* qs = p.q + ((long)i * p.B + b) * p.ld + off;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) { q[c] = qs[c] * p.scale; o[c] = 0.f; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < HD; ++c) { q[c] = 0.f; o[c] = 0.f; }
+  }
+  __syncthreads();
+  float m = -INFINITY, l = 0.f;
+  const uint64_t gbase = (((uint64_t)(p.col_offset + b) * p.nhead + head) * T + i) * (uint64_t)T;
+  const int wave_last = min(T - 1, (int)(threadIdx.x | 63));
+  for (int j = 0; j <= wave_last; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 kk = *reinterpret_cast<const float4*>(Ks + j * HD + c);
+      s += q[c] * kk.x + q[c + 1] * kk.y + q[c + 2] * kk.z + q[c + 3] * kk.w;
+    }
+    if (act && j <= i) {
+      const float mn = fmaxf(m, s);
+      const float corr = __expf(m - mn), pe = __expf(s - mn);
+      l = l * corr + pe;
+      const float pd = p.drop ? pe * keep_at(p, gbase + j) : pe;
+#pragma unroll
+      for (int c = 0; c < HD; c += 4) {
+        const float4 vv = *reinterpret_cast<const float4*>(Vs + j * HD + c);
+        o[c] = o[c] * corr + pd * vv.x; o[c + 1] = o[c + 1] * corr + pd * vv.y;
+        o[c + 2] = o[c + 2] * corr + pd * vv.z; o[c + 3] = o[c + 3] * corr + pd * vv.w;
+      }
+      m = mn;
+    }
+  }
+  if (act) {
+    const float inv = 1.f / l;
+    float* os = p.out + ((long)i * p.B + b) * ((long)p.nhead * HD) + off;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) os[c] = o[c] * inv;
+    if (p.lse) p.lse[(long)blockIdx.x * T + i] = m + __logf(l);
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(ATT_T) void attn_bwd_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T = p.T;
+  float* A = sm;                // K, then Q*scale
+  float* Bf = sm + T * HD;      // V, then dO
+  float* lse_s = sm + 2 * T * HD;
+  float* del_s = lse_s + T;
+  const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
+  const int i = threadIdx.x;
+  const bool act = i < T;
+  const long dmodel = (long)p.nhead * HD;
+  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
+
+  // ---------------- phase 1: lane = query row -> dQ
+  load_tile<HD>(A, p.k, p.ld, T, p.B, b, off, 1.f);
+  load_tile<HD>(Bf, p.v, p.ld, T, p.B, b, off, 1.f);
+  {
+    float q[HD], dO[HD], dq[HD];
+    float lse = 0.f, delta = 0.f;
+    if (act) {
+      const float* qs = p.q + ((long)i * p.B + b) * p.ld + off;
+      const float* ds = p.dout + ((long)i * p.B + b) * dmodel + off;
+      const float* os = p.o_in + ((long)i * p.B + b) * dmodel + off;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) { q[c] = qs[c] * p.scale; dO[c] = ds[c]; dq[c] = 0.f; delta += ds[c] * os[c]; }
+      lse = p.lse[(long)blockIdx.x * T + i];
+      lse_s[i] = lse;
+      del_s[i] = delta;
+    } else {
+#pragma unroll
+      for (int c = 0; c < HD; ++c) { q[c] = 0.f; dO[c] = 0.f; dq[c] = 0.f; }
+    }
+    __syncthreads();
+    const int wave_last = min(T - 1, (int)(threadIdx.x | 63));
+    for (int j = 0; j <= wave_last; ++j) {
+      float s = 0.f, dpd = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; c += 4) {
+        const float4 kk = *reinterpret_cast<const float4*>(A + j * HD + c);
+        const float4 vv = *reinterpret_cast<const float4*>(Bf + j * HD + c);
+        s += q[c] * kk.x + q[c + 1] * kk.y + q[c + 2] * kk.z + q[c + 3] * kk.w;
+        dpd += dO[c] * vv.x + dO[c + 1] * vv.y + dO[c + 2] * vv.z + dO[c + 3] * vv.w;
+      }
+      if (act && j <= i) {
+        const float pr = __expf(s - lse);
+        const float kp = p.drop ? keep_at(p, (bh * T + i) * (uint64_t)T + j) : 1.f;
+        const float dS = pr * (dpd * kp - delta);
+#pragma unroll
+        for (int c = 0; c < HD; c += 4) {
+          const float4 kk = *reinterpret_cast<const float4*>(A + j * HD + c);
+          dq[c] += dS * kk.x; dq[c + 1] += dS * kk.y; dq[c + 2] += dS * kk.z; dq[c + 3] += dS * kk.w;
+        }
+      }
+    }
+    if (act) {
+      float* o = p.dq + ((long)i * p.B + b) * p.ldd + off;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) o[c] = dq[c] * p.scale;
+    }
+  }
+  __syncthreads();
+  // ---------------- phase 2: lane = key row -> dK, dV
+  load_tile<HD>(A, p.q, p.ld, T, p.B, b, off, p.scale);
+  load_tile<HD>(Bf, p.dout, dmodel, T, p.B, b, off, 1.f);
+  float k[HD], v[HD];
+  const int j = threadIdx.x;
+  if (act) {
+    const float* ks = p.k + ((long)j * p.B + b) * p.ld + off;
+    const float* vs = p.v + ((long)j * p.B + b) * p.ld + off;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) { k[c] = ks[c]; v[c] = vs[c]; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < HD; ++c) { k[c] = 0.f; v[c] = 0.f; }
+  }
+  __syncthreads();
+  constexpr int HALVES = HD >= 16 ? 2 : 1;
+  constexpr int HH = HD / HALVES;
+  const int wave_first = threadIdx.x & ~63;
+#pragma unroll
+  for (int half = 0; half < HALVES; ++half) {
+    float dk[HH], dv[HH];
+#pragma unroll
+    for (int c = 0; c < HH; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+    for (int qi = wave_first; qi < T; ++qi) {
+      float s = 0.f, dpd = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; c += 4) {
+        const float4 qq = *reinterpret_cast<const float4*>(A + qi * HD + c);
+        const float4 dd = *reinterpret_cast<const float4*>(Bf + qi * HD + c);
+        s += qq.x * k[c] + qq.y * k[c + 1] + qq.z * k[c + 2] + qq.w * k[c + 3];
+        dpd += dd.x * v[c] + dd.y * v[c + 1] + dd.z * v[c + 2] + dd.w * v[c + 3];
+      }
+      if (act && j <= qi) {
+        const float pr = __expf(s - lse_s[qi]);
+        const float kp = p.drop ? keep_at(p, (bh * T + qi) * (uint64_t)T + j) : 1.f;
+        const float dS = pr * (dpd * kp - del_s[qi]);
+        const float pd = pr * kp;
+#pragma unroll
+        for (int c = 0; c < HH; c += 4) {
+          const float4 qq = *reinterpret_cast<const float4*>(A + qi * HD + half * HH + c);
+          const float4 dd = *reinterpret_cast<const float4*>(Bf + qi * HD + half * HH + c);
+          dk[c] += dS * qq.x; dk[c + 1] += dS * qq.y; dk[c + 2] += dS * qq.z; dk[c + 3] += dS * qq.w;
+          dv[c] += pd * dd.x; dv[c + 1] += pd * dd.y; dv[c + 2] += pd * dd.z; dv[c + 3] += pd * dd.w;
+        }
+      }
+    }
+    if (act) {
+      float* ok = p.dk + ((long)j * p.B + b) * p.ldd + off + half * HH;
+      float* ov = p.dv + ((long)j * p.B + b) * p.ldd + off + half * HH;
+#pragma unroll
+      for (int c = 0; c < HH; ++c) { ok[c] = dk[c]; ov[c] = dv[c]; }
+    }
+  }
+}
+
+static int fill(AttnP& p, int T, int B, int nhead, int head_dim, float pdrop, const blm_rng* rng, int col_offset,
+                const char* who) {
+  if (T < 0 || B < 0 || nhead <= 0) return blm_fail(BLM_ERR_INVALID, "%s: bad shape", who);
+  if (T > ATT_T) return blm_fail(BLM_ERR_UNSUPPORTED, "%s: T=%d > %d not supported in this build", who, T, ATT_T);
+  if (!(head_dim == 4 || head_dim == 8 || head_dim == 16 || head_dim == 32 || head_dim == 64))
+    return blm_fail(BLM_ERR_UNSUPPORTED, "%s: head_dim %d not in {4,8,16,32,64}", who, head_dim);
+  if (pdrop > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "%s: dropout needs rng", who);
+  p.T = T; p.B = B; p.nhead = nhead;
+  p.scale = 1.0f / sqrtf((float)head_dim);
+  p.drop = pdrop > 0.f;
+  if (p.drop) p.rng = *rng;
+  const double t = (double)pdrop * 4294967296.0;
+  p.thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  p.inv_keep = pdrop < 1.f ? 1.f / (1.f - pdrop) : 0.f;
+  p.col_offset = col_offset;
+  return BLM_OK;
+}
+
+}  // namespace blm
+
+using namespace blm;
+
+#define DISPATCH_HD(KERN, LDS)                                                                                   \
+  switch (head_dim) {                                                                                            \
+    case 4: hipLaunchKernelGGL(KERN<4>, dim3(B * nhead), dim3(ATT_T), LDS, st, p); break;                         \
+    case 8: hipLaunchKernelGGL(KERN<8>, dim3(B * nhead), dim3(ATT_T), LDS, st, p); break;                         \
+    case 16: hipLaunchKernelGGL(KERN<16>, dim3(B * nhead), dim3(ATT_T), LDS, st, p); break;                       \
+    case 32: hipLaunchKernelGGL(KERN<32>, dim3(B * nhead), dim3(ATT_T), LDS, st, p); break;                       \
+    default: hipLaunchKernelGGL(KERN<64>, dim3(B * nhead), dim3(ATT_T), LDS, st, p); break;                       \
+  }
+
+extern "C" int blm_attn_fwd(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, float* lse,
+                            int T, int B, int nhead, int head_dim, float pdrop, const blm_rng* rng, int col_offset,
+                            int global_cols, void* stream) {
+  (void)global_cols;
+  if (!q || !k || !v || !out) return blm_fail(BLM_ERR_INVALID, "blm_attn_fwd: null operand");
+  AttnP p{};
+  int rc = fill(p, T, B, nhead, head_dim, pdrop, rng, col_offset, "blm_attn_fwd");
+  if (rc) return rc;
+  if (ld_qkv < (int64_t)nhead * head_dim) return blm_fail(BLM_ERR_INVALID, "blm_attn_fwd: ld_qkv too small");
+  if ((long)T * B == 0) return BLM_OK;
+  p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.out = out; p.lse = lse;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t lds = (size_t)2 * T * head_dim * sizeof(float);
+  DISPATCH_HD(attn_fwd_kernel, lds)
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_attn_bwd(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out,
+                            const float* dout, const float* lse, float* dq, float* dk, float* dv, int64_t ld_dqkv, int T,
+                            int B, int nhead, int head_dim, float pdrop, const blm_rng* rng, int col_offset,
+                            int global_cols, void* stream) {
+  (void)global_cols;
+  if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv) return blm_fail(BLM_ERR_INVALID, "blm_attn_bwd: null operand");
+  AttnP p{};
+  int rc = fill(p, T, B, nhead, head_dim, pdrop, rng, col_offset, "blm_attn_bwd");
+  if (rc) return rc;
+  if (ld_qkv < (int64_t)nhead * head_dim || ld_dqkv < (int64_t)nhead * head_dim)
+    return blm_fail(BLM_ERR_INVALID, "blm_attn_bwd: leading dimension too small");
+  if ((long)T * B == 0) return BLM_OK;
+  p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.o_in = out; p.dout = dout; p.lse = const_cast<float*>(lse);
+  p.dq = dq; p.dk = dk; p.dv = dv; p.ldd = ld_dqkv;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t lds = ((size_t)2 * T * head_dim + 2 * T) * sizeof(float);
+  DISPATCH_HD(attn_bwd_kernel, lds)
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}

@@ -1,0 +1,109 @@
+// Device-side helpers shared by the gfx950 kernels: Philox4x32-10, Box-Muller,
+// wave/block reductions, exact-erf GELU.  64-lane wavefronts throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bayeslm.h"
+
+#define BLM_WAVE 64
+
+namespace blm {
+
+// ---------------------------------------------------------------- Philox4x32-10
+// Same generator as oracle/philox.py (Random123 philox4x32_R(10)).
+struct u32x4 {
+  uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += W0; k1 += W1;
+  }
+  return {c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ u32x4 philox_block(const blm_rng& r, uint64_t block) {
+  return philox4x32_10((uint32_t)block, (uint32_t)(block >> 32), r.stream, r.step, (uint32_t)r.seed,
+                       (uint32_t)(r.seed >> 32));
+}
+
+// u1 = ((ra>>9)+1)*2^-23 in (0,1], u2 = (rb>>8)*2^-24 in [0,1).
+// v_sin_f32 / v_cos_f32 take revolutions, so cos(2*pi*u2) is one instruction.
+__device__ __forceinline__ void box_muller(uint32_t ra, uint32_t rb, float& z0, float& z1) {
+  const float u1 = ((float)(ra >> 9) + 1.0f) * 1.1920928955078125e-07f;
+  const float u2 = (float)(rb >> 8) * 5.9604644775390625e-08f;
+  const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln u = -2 ln2 log2 u
+  z0 = r * __builtin_amdgcn_cosf(u2);
+  z1 = r * __builtin_amdgcn_sinf(u2);
+}
+
+// Four N(0,1) values of counter block `block` (elements 4*block .. 4*block+3).
+__device__ __forceinline__ float4 philox_normal4(const blm_rng& r, uint64_t block) {
+  const u32x4 u = philox_block(r, block);
+  float4 z;
+  box_muller(u.x, u.y, z.x, z.y);
+  box_muller(u.z, u.w, z.z, z.w);
+  return z;
+}
+
+__device__ __forceinline__ uint32_t dropout_threshold(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+}
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block reductions for blocks of NW waves; `red` is >= NW floats of LDS.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) t += red[i];
+  return t;
+}
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// ---------------------------------------------------------------- activations
+__device__ __forceinline__ float gelu_erf(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_erf(float z) {
+  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
+  return cdf + z * pdf;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+}  // namespace blm

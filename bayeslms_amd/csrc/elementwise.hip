@@ -1,0 +1,706 @@
+// HBM-bound ops around the GEMMs: embedding(+PE+dropout), dropout, residual+dropout+LayerNorm
+// (post-LN tail) forward/backward, cross-entropy forward+backward in one pass over the logits,
+// bias-gradient column sums, global-norm clip + SGD momentum, LSTM cell pointwise, axpy.
+//
+// Dropout masks are Philox bits keyed by the GLOBAL element index of a (rows, global_cols, D)
+// tensor, so a data-parallel run that shards columns reproduces the single-process mask.
+#include "blm_device.h"
+#include "blm_host.h"
+
+namespace blm {
+
+constexpr int TPB = 256;
+
+struct DropKey {
+  blm_rng rng;
+  uint32_t thr;    // drop iff bits < thr
+  float inv_keep;  // 1/(1-p)
+  int B, D, col_offset, global_cols;
+  bool on;
+};
+
+__host__ static DropKey make_key(float p, const blm_rng* rng, int B, int D, int col_offset, int global_cols) {
+  DropKey k{};
+  k.on = p > 0.f && rng != nullptr;
+  if (k.on) k.rng = *rng;
+  const double t = (double)p * 4294967296.0;
+  k.thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  k.inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  k.B = B; k.D = D; k.col_offset = col_offset; k.global_cols = global_cols > 0 ? global_cols : B;
+  return k;
+}
+
+// Scale factors (0 or 1/(1-p)) for the 4 consecutive features j..j+3 (j % 4 == 0, D % 4 == 0) of local (row, b).
+__device__ __forceinline__ float4 keep4(const DropKey& k, int row, int b, int j) {
+  if (!k.on) return make_float4(1.f, 1.f, 1.f, 1.f);
+  const uint64_t g = ((uint64_t)row * k.global_cols + (uint64_t)(k.col_offset + b)) * (uint64_t)k.D + (uint64_t)j;
+  const u32x4 u = philox_block(k.rng, g >> 2);
+  return make_float4(u.x >= k.thr ? k.inv_keep : 0.f, u.y >= k.thr ? k.inv_keep : 0.f,
+                     u.z >= k.thr ? k.inv_keep : 0.f, u.w >= k.thr ? k.inv_keep : 0.f);
+}
+__device__ __forceinline__ float keep1(const DropKey& k, int row, int b, int j) {
+  if (!k.on) return 1.f;
+  const uint64_t g = ((uint64_t)row * k.global_cols + (uint64_t)(k.col_offset + b)) * (uint64_t)k.D + (uint64_t)j;
+  const u32x4 u = philox_block(k.rng, g >> 2);
+  const int c = (int)(g & 3);
+  const uint32_t bits = c == 0 ? u.x : (c == 1 ? u.y : (c == 2 ? u.z : u.w));
+  return bits >= k.thr ? k.inv_keep : 0.f;
+}
+
+// ------------------------------------------------------------------ embedding
+// one wave per (t,b) row, 4 rows per block
+__global__ __launch_bounds__(TPB) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ enc,
+                                                        const float* __restrict__ pe, float* __restrict__ out, int T,
+                                                        int B, int D, long vocab, float scale, DropKey dk) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+  if (row >= (long)T * B) return;
+  const int t = (int)(row / B), b = (int)(row % B);
+  long id = ids[row];
+  if (id < 0 || id >= vocab) id = 0;  // host validates; never read out of bounds
+  const float* e = enc + id * D;
+  const float* pp = pe ? pe + (long)t * D : nullptr;
+  float* o = out + row * D;
+  if ((D & 3) == 0) {
+    for (int j = lane * 4; j < D; j += 256) {
+      float4 v = *reinterpret_cast<const float4*>(e + j);
+      float4 q = pp ? *reinterpret_cast<const float4*>(pp + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 kp = keep4(dk, t, b, j);
+      v.x = (v.x * scale + q.x) * kp.x; v.y = (v.y * scale + q.y) * kp.y;
+      v.z = (v.z * scale + q.z) * kp.z; v.w = (v.w * scale + q.w) * kp.w;
+      *reinterpret_cast<float4*>(o + j) = v;
+    }
+  } else {
+    for (int j = lane; j < D; j += 64) o[j] = (e[j] * scale + (pp ? pp[j] : 0.f)) * keep1(dk, t, b, j);
+  }
+}
+
+__global__ __launch_bounds__(TPB) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dy,
+                                                        float* __restrict__ denc, int T, int B, int D, long vocab,
+                                                        float scale, DropKey dk) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+  if (row >= (long)T * B) return;
+  const int t = (int)(row / B), b = (int)(row % B);
+  long id = ids[row];
+  if (id < 0 || id >= vocab) return;
+  float* g = denc + id * D;
+  const float* d = dy + row * D;
+  // one dword per lane, 256 contiguous bytes per wave-instruction: the fast float-atomic shape
+  for (int j = lane; j < D; j += 64) atomicAdd(g + j, d[j] * scale * keep1(dk, t, b, j));
+}
+
+// ------------------------------------------------------------------ dropout
+__global__ __launch_bounds__(TPB) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long rows,
+                                                      DropKey dk) {
+  const int B = dk.B, D = dk.D;
+  if ((D & 3) == 0) {
+    const long d4 = D >> 2, total = rows * B * d4;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+      const long rb = i / d4;
+      const int j = (int)(i - rb * d4) << 2;
+      const float4 kp = keep4(dk, (int)(rb / B), (int)(rb % B), j);
+      float4 v = *reinterpret_cast<const float4*>(x + rb * D + j);
+      v.x *= kp.x; v.y *= kp.y; v.z *= kp.z; v.w *= kp.w;
+      *reinterpret_cast<float4*>(y + rb * D + j) = v;
+    }
+  } else {
+    const long total = rows * B * D;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+      const long rb = i / D;
+      y[i] = x[i] * keep1(dk, (int)(rb / B), (int)(rb % B), (int)(i - rb * D));
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void add_pe_dropout_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                                             float* __restrict__ y, long rows, DropKey dk) {
+  const int B = dk.B, D = dk.D;
+  const long total = rows * B * D;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const long rb = i / D;
+    const int j = (int)(i - rb * D), t = (int)(rb / B);
+    y[i] = (x[i] + pe[(long)t * D + j]) * keep1(dk, t, (int)(rb % B), j);
+  }
+}
+
+// ------------------------------------------------------------------ residual + dropout + LayerNorm
+// One wave per row; the row lives in registers (VPT float4 per lane) when D == 256*VPT, else the
+// generic kernel re-reads s from s_out.
+template <int VPT>
+__global__ __launch_bounds__(TPB) void add_drop_ln_fwd_reg(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ out,
+                                                           float* __restrict__ s_out, float* __restrict__ mean_o,
+                                                           float* __restrict__ rstd_o, long M, float eps, DropKey dk) {
+  const int lane = threadIdx.x & 63, D = dk.D;
+  const long row = (long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int t = (int)(row / dk.B), b = (int)(row % dk.B);
+  float4 s[VPT];
+  float sum = 0.f;
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    const int j = (v * 64 + lane) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(x + row * D + j);
+    const float4 c = *reinterpret_cast<const float4*>(y + row * D + j);
+    const float4 kp = keep4(dk, t, b, j);
+    s[v] = make_float4(a.x + c.x * kp.x, a.y + c.y * kp.y, a.z + c.z * kp.z, a.w + c.w * kp.w);
+    sum += s[v].x + s[v].y + s[v].z + s[v].w;
+  }
+  const float mean = wave_sum(sum) / D;
+  float var = 0.f;
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    const float dx = s[v].x - mean, dy = s[v].y - mean, dz = s[v].z - mean, dw = s[v].w - mean;
+    var += dx * dx + dy * dy + dz * dz + dw * dw;
+  }
+  const float rstd = rsqrtf(wave_sum(var) / D + eps);
+  if (lane == 0) {
+    if (mean_o) mean_o[row] = mean;
+    if (rstd_o) rstd_o[row] = rstd;
+  }
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    const int j = (v * 64 + lane) * 4;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + j);
+    const float4 be = *reinterpret_cast<const float4*>(beta + j);
+    if (s_out) *reinterpret_cast<float4*>(s_out + row * D + j) = s[v];
+    float4 o;
+    o.x = (s[v].x - mean) * rstd * g.x + be.x; o.y = (s[v].y - mean) * rstd * g.y + be.y;
+    o.z = (s[v].z - mean) * rstd * g.z + be.z; o.w = (s[v].w - mean) * rstd * g.w + be.w;
+    *reinterpret_cast<float4*>(out + row * D + j) = o;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void add_drop_ln_fwd_generic(const float* __restrict__ x, const float* __restrict__ y,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ out,
+                                                               float* __restrict__ s_buf, float* __restrict__ mean_o,
+                                                               float* __restrict__ rstd_o, long M, float eps,
+                                                               DropKey dk) {
+  const int lane = threadIdx.x & 63, D = dk.D;
+  const long row = (long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int t = (int)(row / dk.B), b = (int)(row % dk.B);
+  float* s = s_buf + row * D;  // s_out if given, else `out` doubles as scratch
+  float sum = 0.f;
+  for (int j = lane; j < D; j += 64) {
+    const float v = x[row * D + j] + y[row * D + j] * keep1(dk, t, b, j);
+    s[j] = v;
+    sum += v;
+  }
+  const float mean = wave_sum(sum) / D;
+  float var = 0.f;
+  for (int j = lane; j < D; j += 64) {
+    const float d = s[j] - mean;
+    var += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(var) / D + eps);
+  if (lane == 0) {
+    if (mean_o) mean_o[row] = mean;
+    if (rstd_o) rstd_o[row] = rstd;
+  }
+  for (int j = lane; j < D; j += 64) out[row * D + j] = (s[j] - mean) * rstd * gamma[j] + beta[j];
+}
+
+constexpr int LN_BWD_BLOCKS = 256;
+
+// Each wave walks rows row = blockIdx*4 + wave + k*gridDim*4; per-lane partial dgamma/dbeta for its
+// columns stay in registers, then waves combine through LDS and the block writes one partial row.
+template <int VPT>
+__global__ __launch_bounds__(TPB) void add_drop_ln_bwd_reg(const float* __restrict__ dout, const float* __restrict__ s,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean_i,
+                                                           const float* __restrict__ rstd_i, float* __restrict__ dx,
+                                                           float* __restrict__ dy, float* __restrict__ ws, long M,
+                                                           DropKey dk) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, D = dk.D;
+  float4 pg[VPT], pb[VPT], g[VPT];
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    pg[v] = pb[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    g[v] = *reinterpret_cast<const float4*>(gamma + (v * 64 + lane) * 4);
+  }
+  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+    const int t = (int)(row / dk.B), b = (int)(row % dk.B);
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float4 xh[VPT], dxh[VPT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      const int j = (v * 64 + lane) * 4;
+      const float4 d = *reinterpret_cast<const float4*>(dout + row * D + j);
+      const float4 sv = *reinterpret_cast<const float4*>(s + row * D + j);
+      xh[v] = make_float4((sv.x - mean) * rstd, (sv.y - mean) * rstd, (sv.z - mean) * rstd, (sv.w - mean) * rstd);
+      dxh[v] = make_float4(d.x * g[v].x, d.y * g[v].y, d.z * g[v].z, d.w * g[v].w);
+      pg[v].x += d.x * xh[v].x; pg[v].y += d.y * xh[v].y; pg[v].z += d.z * xh[v].z; pg[v].w += d.w * xh[v].w;
+      pb[v].x += d.x; pb[v].y += d.y; pb[v].z += d.z; pb[v].w += d.w;
+      s1 += dxh[v].x + dxh[v].y + dxh[v].z + dxh[v].w;
+      s2 += dxh[v].x * xh[v].x + dxh[v].y * xh[v].y + dxh[v].z * xh[v].z + dxh[v].w * xh[v].w;
+    }
+    const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      const int j = (v * 64 + lane) * 4;
+      float4 ds;
+      ds.x = rstd * (dxh[v].x - m1 - xh[v].x * m2); ds.y = rstd * (dxh[v].y - m1 - xh[v].y * m2);
+      ds.z = rstd * (dxh[v].z - m1 - xh[v].z * m2); ds.w = rstd * (dxh[v].w - m1 - xh[v].w * m2);
+      *reinterpret_cast<float4*>(dx + row * D + j) = ds;
+      if (dy) {
+        const float4 kp = keep4(dk, t, b, j);
+        ds.x *= kp.x; ds.y *= kp.y; ds.z *= kp.z; ds.w *= kp.w;
+        *reinterpret_cast<float4*>(dy + row * D + j) = ds;
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    const int j = (v * 64 + lane) * 4;
+    *reinterpret_cast<float4*>(sm + (wave * 2 + 0) * D + j) = pg[v];
+    *reinterpret_cast<float4*>(sm + (wave * 2 + 1) * D + j) = pb[v];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * D; j += TPB) {
+    const int which = j / D, c = j - which * D;
+    ws[((long)blockIdx.x * 2 + which) * D + c] =
+        sm[(0 * 2 + which) * D + c] + sm[(1 * 2 + which) * D + c] + sm[(2 * 2 + which) * D + c] + sm[(3 * 2 + which) * D + c];
+  }
+}
+
+__global__ __launch_bounds__(TPB) void add_drop_ln_bwd_generic(const float* __restrict__ dout, const float* __restrict__ s,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ mean_i,
+                                                               const float* __restrict__ rstd_i, float* __restrict__ dx,
+                                                               float* __restrict__ dy, float* __restrict__ ws, long M,
+                                                               DropKey dk) {
+  // one wave per block-row walk; partial dgamma/dbeta accumulated straight into ws[block] (zeroed by launcher)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, D = dk.D;
+  float* wg = ws + ((long)blockIdx.x * 2 + 0) * D;
+  float* wb = ws + ((long)blockIdx.x * 2 + 1) * D;
+  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+    const int t = (int)(row / dk.B), b = (int)(row % dk.B);
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = lane; j < D; j += 64) {
+      const float d = dout[row * D + j], xh = (s[row * D + j] - mean) * rstd, dxh = d * gamma[j];
+      s1 += dxh;
+      s2 += dxh * xh;
+      atomicAdd(wg + j, d * xh);
+      atomicAdd(wb + j, d);
+    }
+    const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
+    for (int j = lane; j < D; j += 64) {
+      const float d = dout[row * D + j], xh = (s[row * D + j] - mean) * rstd;
+      const float ds = rstd * (d * gamma[j] - m1 - xh * m2);
+      dx[row * D + j] = ds;
+      if (dy) dy[row * D + j] = ds * keep1(dk, t, b, j);
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void ln_bwd_finish(const float* __restrict__ ws, int nblk, int D,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int j = blockIdx.x * TPB + threadIdx.x;
+  if (j >= D) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < nblk; ++k) {
+    a += ws[((long)k * 2 + 0) * D + j];
+    b += ws[((long)k * 2 + 1) * D + j];
+  }
+  dgamma[j] += a;
+  dbeta[j] += b;
+}
+
+// ------------------------------------------------------------------ cross entropy
+// One block per row: online (max, sumexp) pass, then the gradient pass (row is L2-resident: V*4 B).
+__global__ __launch_bounds__(TPB) void ce_kernel(const float* __restrict__ logits, long ld, const int64_t* __restrict__ tgt,
+                                                 float* __restrict__ nll, float* __restrict__ lse_out,
+                                                 float* __restrict__ dlogits, float gscale, int V) {
+  __shared__ float red[TPB / 64];
+  const long row = blockIdx.x;
+  const float* x = logits + row * ld;
+  float m = -INFINITY, l = 0.f;
+  const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
+  const int V4 = vec ? (V & ~3) : 0;
+  for (int j = threadIdx.x * 4; j < V4; j += TPB * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(x + j);
+    const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    if (mx > m) { l *= __expf(m - mx); m = mx; }
+    l += __expf(v.x - m) + __expf(v.y - m) + __expf(v.z - m) + __expf(v.w - m);
+  }
+  for (int j = V4 + threadIdx.x; j < V; j += TPB) {
+    const float v = x[j];
+    if (v > m) { l *= __expf(m - v); m = v; }
+    l += __expf(v - m);
+  }
+  const long t = tgt[row];
+  const bool valid = t >= 0 && t < V;
+  const float xt = valid ? x[t] : 0.f;  // read before any in-place gradient write (block_max has barriers)
+  const float M_ = block_max<TPB / 64>(m, red);
+  const float L_ = block_sum<TPB / 64>(m == -INFINITY ? 0.f : l * __expf(m - M_), red);
+  const float lse = M_ + __logf(L_);
+  if (threadIdx.x == 0) {
+    nll[row] = valid ? lse - xt : 0.f;
+    if (lse_out) lse_out[row] = lse;
+  }
+  if (dlogits) {
+    float* d = dlogits + row * ld;
+    for (int j = threadIdx.x * 4; j < V4; j += TPB * 4) {
+      float4 v = *reinterpret_cast<const float4*>(x + j);
+      v.x = __expf(v.x - lse) * gscale; v.y = __expf(v.y - lse) * gscale;
+      v.z = __expf(v.z - lse) * gscale; v.w = __expf(v.w - lse) * gscale;
+      if (valid && t >= j && t < j + 4) {
+        if (t == j) v.x -= gscale; else if (t == j + 1) v.y -= gscale; else if (t == j + 2) v.z -= gscale; else v.w -= gscale;
+      }
+      *reinterpret_cast<float4*>(d + j) = v;
+    }
+    for (int j = V4 + threadIdx.x; j < V; j += TPB) d[j] = (__expf(x[j] - lse) - ((valid && j == t) ? 1.f : 0.f)) * gscale;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void ce_bwd_kernel(const float* __restrict__ logits, long ld,
+                                                     const int64_t* __restrict__ tgt, const float* __restrict__ lse_in,
+                                                     const float* __restrict__ g_dev, float scale,
+                                                     float* __restrict__ dlogits, int V) {
+  const long row = blockIdx.x;
+  const float* x = logits + row * ld;
+  float* d = dlogits + row * ld;
+  const float lse = lse_in[row], gs = g_dev[0] * scale;
+  const long t = tgt[row];
+  const bool valid = t >= 0 && t < V;
+  for (int j = threadIdx.x; j < V; j += TPB) d[j] = (__expf(x[j] - lse) - ((valid && j == t) ? 1.f : 0.f)) * gs;
+}
+
+// deterministic single-block sum: out += sum(x[0..n))
+__global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, long n, float* out) {
+  __shared__ float red[16];
+  float a = 0.f;
+  for (long i = threadIdx.x; i < n; i += 1024) a += x[i];
+  const float t = block_sum<16>(a, red);
+  if (threadIdx.x == 0) out[0] += t;
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients)
+// block = 32 column-quads x 8 row lanes; grid.y row chunks; partials combined with float atomics.
+__global__ __launch_bounds__(TPB) void colsum_kernel(const float* __restrict__ x, long ld, float* __restrict__ out, int M,
+                                                     int N) {
+  __shared__ float4 sm[8][32];
+  const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + cq) * 4;
+  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < N) {
+    const bool vec = (col + 3 < N) && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    for (int r = r0 + rl; r < r1; r += 8) {
+      const float* p = x + (long)r * ld + col;
+      if (vec) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      } else {
+        a.x += p[0];
+        if (col + 1 < N) a.y += p[1];
+        if (col + 2 < N) a.z += p[2];
+        if (col + 3 < N) a.w += p[3];
+      }
+    }
+  }
+  sm[rl][cq] = a;
+  __syncthreads();
+  if (rl == 0 && col < N) {
+    for (int k = 1; k < 8; ++k) { a.x += sm[k][cq].x; a.y += sm[k][cq].y; a.z += sm[k][cq].z; a.w += sm[k][cq].w; }
+    atomicAdd(out + col, a.x);
+    if (col + 1 < N) atomicAdd(out + col + 1, a.y);
+    if (col + 2 < N) atomicAdd(out + col + 2, a.z);
+    if (col + 3 < N) atomicAdd(out + col + 3, a.w);
+  }
+}
+
+// ------------------------------------------------------------------ clip + SGD
+__global__ __launch_bounds__(TPB) void sqnorm_multi_kernel(const float* const* grads, const int64_t* sizes, float* sq) {
+  __shared__ float red[TPB / 64];
+  const float* g = grads[blockIdx.y];
+  const long n = sizes[blockIdx.y];
+  float a = 0.f;
+  const long n4 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? (n >> 2) : 0;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long)gridDim.x * TPB) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    a += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) a += g[i] * g[i];
+  const float t = block_sum<TPB / 64>(a, red);
+  if (threadIdx.x == 0 && t != 0.f) atomicAdd(sq, t);
+}
+
+__global__ __launch_bounds__(TPB) void clip_sgd_multi_kernel(float* const* params, const float* const* grads,
+                                                             float* const* bufs, const int64_t* sizes, const float* sq,
+                                                             float clip, float lr, float mom, int first, float gs) {
+  float* p = params[blockIdx.y];
+  const float* g = grads[blockIdx.y];
+  float* m = bufs[blockIdx.y];
+  const long n = sizes[blockIdx.y];
+  // gradients are gs * g (gs = 1/world for DP averaging): norm of the scaled gradient
+  const float norm = sqrtf(sq[0]) * gs;
+  const float c = fminf(1.0f, clip / (norm + 1e-6f)) * gs;
+  const bool al = (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m)) & 15) == 0);
+  const long n4 = al ? (n >> 2) : 0;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long)gridDim.x * TPB) {
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(m)[i];
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    mv.x = mom * mv.x + c * gv.x; mv.y = mom * mv.y + c * gv.y; mv.z = mom * mv.z + c * gv.z; mv.w = mom * mv.w + c * gv.w;
+    pv.x -= lr * mv.x; pv.y -= lr * mv.y; pv.z -= lr * mv.z; pv.w -= lr * mv.w;
+    reinterpret_cast<float4*>(m)[i] = mv;
+    reinterpret_cast<float4*>(p)[i] = pv;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
+    const float mv = (first ? 0.f : mom * m[i]) + c * g[i];
+    m[i] = mv;
+    p[i] -= lr * mv;
+  }
+}
+
+// ------------------------------------------------------------------ LSTM cell
+__global__ __launch_bounds__(TPB) void lstm_cell_fwd_kernel(const float* __restrict__ xw, const float* __restrict__ hw,
+                                                            const float* __restrict__ c_prev, float* __restrict__ h,
+                                                            float* __restrict__ c, float* __restrict__ ga, int B, int H) {
+  const long total = (long)B * H;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const long b = i / H, j = i - b * H, o = b * 4 * H + j;
+    const float gi = sigmoidf_(xw[o] + hw[o]);
+    const float gf = sigmoidf_(xw[o + H] + hw[o + H]);
+    const float gg = tanhf(xw[o + 2 * H] + hw[o + 2 * H]);
+    const float go = sigmoidf_(xw[o + 3 * H] + hw[o + 3 * H]);
+    const float cn = gf * c_prev[i] + gi * gg;
+    c[i] = cn;
+    h[i] = go * tanhf(cn);
+    if (ga) { ga[o] = gi; ga[o + H] = gf; ga[o + 2 * H] = gg; ga[o + 3 * H] = go; }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void lstm_cell_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc_next,
+                                                            const float* __restrict__ c_prev, const float* __restrict__ c,
+                                                            const float* __restrict__ ga, float* __restrict__ dgates,
+                                                            float* __restrict__ dc_prev, int B, int H) {
+  const long total = (long)B * H;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const long b = i / H, j = i - b * H, o = b * 4 * H + j;
+    const float gi = ga[o], gf = ga[o + H], gg = ga[o + 2 * H], go = ga[o + 3 * H];
+    const float tc = tanhf(c[i]);
+    const float dhv = dh[i];
+    const float dc = (dc_next ? dc_next[i] : 0.f) + dhv * go * (1.f - tc * tc);
+    dgates[o] = dc * gg * gi * (1.f - gi);
+    dgates[o + H] = dc * c_prev[i] * gf * (1.f - gf);
+    dgates[o + 2 * H] = dc * gi * (1.f - gg * gg);
+    dgates[o + 3 * H] = dhv * tc * go * (1.f - go);
+    dc_prev[i] = dc * gf;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float a) {
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) y[i] += a * x[i];
+}
+
+static int grid_for(long items) {
+  long g = (items + TPB - 1) / TPB;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace blm
+
+using namespace blm;
+#define ST static_cast<hipStream_t>(stream)
+
+extern "C" int blm_embed_fwd(const int64_t* ids, const float* enc, const float* pe, float* out, int T, int B, int D,
+                             int64_t vocab, float scale, float p, const blm_rng* rng, int col_offset, int global_cols,
+                             void* stream) {
+  if (!ids || !enc || !out || T < 0 || B < 0 || D <= 0 || vocab <= 0) return blm_fail(BLM_ERR_INVALID, "blm_embed_fwd: bad arguments");
+  if (p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_embed_fwd: dropout needs rng");
+  if ((long)T * B == 0) return BLM_OK;
+  const long rows = (long)T * B;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(TPB), 0, ST, ids, enc, pe, out, T, B, D,
+                     (long)vocab, scale, make_key(p, rng, B, D, col_offset, global_cols));
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_embed_bwd(const int64_t* ids, const float* dy, float* denc, int T, int B, int D, int64_t vocab,
+                             float scale, float p, const blm_rng* rng, int col_offset, int global_cols, void* stream) {
+  if (!ids || !dy || !denc || T < 0 || B < 0 || D <= 0 || vocab <= 0) return blm_fail(BLM_ERR_INVALID, "blm_embed_bwd: bad arguments");
+  if (p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_embed_bwd: dropout needs rng");
+  if ((long)T * B == 0) return BLM_OK;
+  const long rows = (long)T * B;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(TPB), 0, ST, ids, dy, denc, T, B, D,
+                     (long)vocab, scale, make_key(p, rng, B, D, col_offset, global_cols));
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_dropout(const float* x, float* y, int rows, int B, int D, float p, const blm_rng* rng, int col_offset,
+                           int global_cols, void* stream) {
+  if (!x || !y || rows < 0 || B < 0 || D < 0) return blm_fail(BLM_ERR_INVALID, "blm_dropout: bad arguments");
+  if (p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_dropout: dropout needs rng");
+  const long n = (long)rows * B * D;
+  if (n == 0) return BLM_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4 + 1)), dim3(TPB), 0, ST, x, y, (long)rows,
+                     make_key(p, rng, B, D, col_offset, global_cols));
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_add_pe_dropout(const float* x, const float* pe, float* out, int T, int B, int D, float p,
+                                  const blm_rng* rng, int col_offset, int global_cols, void* stream) {
+  if (!x || !pe || !out || T < 0 || B < 0 || D < 0) return blm_fail(BLM_ERR_INVALID, "blm_add_pe_dropout: bad arguments");
+  if (p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_add_pe_dropout: dropout needs rng");
+  const long n = (long)T * B * D;
+  if (n == 0) return BLM_OK;
+  hipLaunchKernelGGL(add_pe_dropout_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, x, pe, out, (long)T,
+                     make_key(p, rng, B, D, col_offset, global_cols));
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_add_dropout_ln_fwd(const float* x, const float* y, const float* gamma, const float* beta, float* out,
+                                      float* s_out, float* mean, float* rstd, int rows, int B, int D, float eps_ln,
+                                      float p, const blm_rng* rng, int col_offset, int global_cols, void* stream) {
+  if (!x || !y || !gamma || !beta || !out || rows < 0 || B < 0 || D <= 0) return blm_fail(BLM_ERR_INVALID, "blm_add_dropout_ln_fwd: bad arguments");
+  if (p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_add_dropout_ln_fwd: dropout needs rng");
+  const long M = (long)rows * B;
+  if (M == 0) return BLM_OK;
+  const DropKey dk = make_key(p, rng, B, D, col_offset, global_cols);
+  const dim3 grid((unsigned)((M + 3) / 4));
+  const bool al = (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out) |
+                     reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(s_out)) & 15) == 0);
+#define LN_FWD(V) hipLaunchKernelGGL(add_drop_ln_fwd_reg<V>, grid, dim3(TPB), 0, ST, x, y, gamma, beta, out, s_out, mean, rstd, M, eps_ln, dk)
+  if (al && D == 256) LN_FWD(1);
+  else if (al && D == 512) LN_FWD(2);
+  else if (al && D == 1024) LN_FWD(4);
+  else if (al && D == 2048) LN_FWD(8);
+  else
+    hipLaunchKernelGGL(add_drop_ln_fwd_generic, grid, dim3(TPB), 0, ST, x, y, gamma, beta, out, s_out ? s_out : out, mean,
+                       rstd, M, eps_ln, dk);
+#undef LN_FWD
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int64_t blm_ln_bwd_ws_floats(int M, int D) {
+  (void)M;
+  return (int64_t)2 * LN_BWD_BLOCKS * D;
+}
+
+extern "C" int blm_add_dropout_ln_bwd(const float* dout, const float* s, const float* gamma, const float* mean,
+                                      const float* rstd, float* dx, float* dy, float* dgamma, float* dbeta, float* ws,
+                                      int rows, int B, int D, float p, const blm_rng* rng, int col_offset,
+                                      int global_cols, void* stream) {
+  if (!dout || !s || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !ws || rows < 0 || B < 0 || D <= 0)
+    return blm_fail(BLM_ERR_INVALID, "blm_add_dropout_ln_bwd: bad arguments");
+  if (p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_add_dropout_ln_bwd: dropout needs rng");
+  const long M = (long)rows * B;
+  if (M == 0) return BLM_OK;
+  const DropKey dk = make_key(p, rng, B, D, col_offset, global_cols);
+  int nblk = (int)((M + 3) / 4);
+  if (nblk > LN_BWD_BLOCKS) nblk = LN_BWD_BLOCKS;
+  const bool al = (((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(dx) |
+                     reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0);
+  const size_t lds = (size_t)8 * D * sizeof(float);
+#define LN_BWD(V) hipLaunchKernelGGL(add_drop_ln_bwd_reg<V>, dim3(nblk), dim3(TPB), lds, ST, dout, s, gamma, mean, rstd, dx, dy, ws, M, dk)
+  if (al && D == 256) LN_BWD(1);
+  else if (al && D == 512) LN_BWD(2);
+  else if (al && D == 1024) LN_BWD(4);
+  else if (al && D == 2048) LN_BWD(8);
+  else {
+    BLM_HIP(hipMemsetAsync(ws, 0, (size_t)2 * nblk * D * sizeof(float), ST));
+    hipLaunchKernelGGL(add_drop_ln_bwd_generic, dim3(nblk), dim3(TPB), 0, ST, dout, s, gamma, mean, rstd, dx, dy, ws, M, dk);
+  }
+#undef LN_BWD
+  BLM_HIP(hipGetLastError());
+  hipLaunchKernelGGL(ln_bwd_finish, dim3((D + TPB - 1) / TPB), dim3(TPB), 0, ST, ws, nblk, D, dgamma, dbeta);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_ce_bwd(const float* logits, int64_t ld, const int64_t* tgt, const float* lse, const float* g_dev,
+                          float scale, float* dlogits, int M, int V, void* stream) {
+  if (!logits || !tgt || !lse || !g_dev || !dlogits || M < 0 || V <= 0 || ld < V) return blm_fail(BLM_ERR_INVALID, "blm_ce_bwd: bad arguments");
+  if (M == 0) return BLM_OK;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(M), dim3(TPB), 0, ST, logits, (long)ld, tgt, lse, g_dev, scale, dlogits, V);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_ce_fwd_bwd(const float* logits, int64_t ld, const int64_t* tgt, float* nll, float* lse, float* loss_sum,
+                              float* dlogits, float grad_scale, int M, int V, void* stream) {
+  if (!logits || !tgt || !nll || M < 0 || V <= 0 || ld < V) return blm_fail(BLM_ERR_INVALID, "blm_ce_fwd_bwd: bad arguments");
+  if (M == 0) return BLM_OK;
+  hipLaunchKernelGGL(ce_kernel, dim3(M), dim3(TPB), 0, ST, logits, (long)ld, tgt, nll, lse, dlogits, grad_scale, V);
+  BLM_HIP(hipGetLastError());
+  if (loss_sum) {
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ST, nll, (long)M, loss_sum);
+    BLM_HIP(hipGetLastError());
+  }
+  return BLM_OK;
+}
+
+extern "C" int blm_colsum(const float* x, int64_t ld, float* out, int M, int N, int accumulate, void* stream) {
+  if (!x || !out || M < 0 || N < 0 || ld < N) return blm_fail(BLM_ERR_INVALID, "blm_colsum: bad arguments");
+  if (N == 0) return BLM_OK;
+  if (!accumulate) BLM_HIP(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), ST));
+  if (M == 0) return BLM_OK;
+  int gy = (M + 255) / 256;
+  if (gy > 64) gy = 64;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 127) / 128, gy), dim3(TPB), 0, ST, x, (long)ld, out, M, N);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_sqnorm_multi(const float* const* grads, const int64_t* sizes, int n, float* sq, void* stream) {
+  if (!grads || !sizes || !sq || n < 0) return blm_fail(BLM_ERR_INVALID, "blm_sqnorm_multi: bad arguments");
+  if (n == 0) return BLM_OK;
+  hipLaunchKernelGGL(sqnorm_multi_kernel, dim3(n == 1 ? 1024 : 64, n), dim3(TPB), 0, ST, grads, sizes, sq);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_clip_sgd_multi(float* const* params, const float* const* grads, float* const* bufs,
+                                  const int64_t* sizes, int n, const float* sq, float clip, float lr, float momentum,
+                                  int first, float grad_scale, void* stream) {
+  if (!params || !grads || !bufs || !sizes || !sq || n < 0) return blm_fail(BLM_ERR_INVALID, "blm_clip_sgd_multi: bad arguments");
+  if (n == 0) return BLM_OK;
+  hipLaunchKernelGGL(clip_sgd_multi_kernel, dim3(n == 1 ? 2048 : 64, n), dim3(TPB), 0, ST, params, grads, bufs, sizes, sq,
+                     clip, lr, momentum, first, grad_scale);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_lstm_cell_fwd(const float* xw, const float* hw, const float* c_prev, float* h, float* c,
+                                 float* gates_act, int B, int H, void* stream) {
+  if (!xw || !hw || !c_prev || !h || !c || B < 0 || H < 0) return blm_fail(BLM_ERR_INVALID, "blm_lstm_cell_fwd: bad arguments");
+  if ((long)B * H == 0) return BLM_OK;
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_for((long)B * H)), dim3(TPB), 0, ST, xw, hw, c_prev, h, c, gates_act, B, H);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_lstm_cell_bwd(const float* dh, const float* dc_next, const float* c_prev, const float* c,
+                                 const float* gates_act, float* dgates, float* dc_prev, int B, int H, void* stream) {
+  if (!dh || !c_prev || !c || !gates_act || !dgates || !dc_prev || B < 0 || H < 0)
+    return blm_fail(BLM_ERR_INVALID, "blm_lstm_cell_bwd: bad arguments");
+  if ((long)B * H == 0) return BLM_OK;
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for((long)B * H)), dim3(TPB), 0, ST, dh, dc_next, c_prev, c, gates_act,
+                     dgates, dc_prev, B, H);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_axpy(const float* x, float* y, int64_t n, float a, void* stream) {
+  if (!x || !y || n < 0) return blm_fail(BLM_ERR_INVALID, "blm_axpy: bad arguments");
+  if (n == 0) return BLM_OK;
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, x, y, (long)n, a);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}

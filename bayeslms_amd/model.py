@@ -1,0 +1,550 @@
+"""Model zoo with the reference's class surface, running on the HIP kernels.
+
+Drop-in for ``steps/pytorchnn/model.py`` of AmourWaltz/BayesLMs on the hot path:
+same class names, positional constructor arguments, ``forward`` / ``init_hidden``
+/ ``kl_divergence`` / ``embed_kl_divergence`` methods, attribute paths used by
+train.py (``model.rnn``, ``model.transformerlayers[i].linear2|self_attn.o_net``)
+and ``state_dict()`` key names and shapes, so a
+``model.pt`` written by either side loads in the other.
+
+What is different underneath: every forward/backward op is a hand-written
+gfx950 kernel behind the C ABI (bayeslms_amd/ops.py); eps of the variational
+tensors and all dropout masks come from a counter-based Philox stream keyed by
+(seed, tensor/site id, step) instead of torch's generator, so backward and all
+data-parallel ranks regenerate them with no storage.  Tensors must live on the
+GPU; there is no CPU path.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import BayesLMError
+from .ops import Drop, NoiseSpec
+
+__all__ = ["NoiseState", "PositionalEncoding", "MultiheadAttention", "BayesMultiheadAttention", "BayesLinear",
+           "StandardTransformerEncoderLayer", "BayesTransformerEncoderLayer", "BayesTransformerModel",
+           "TransformerModel", "RNNModel", "BayesRNNModel", "Bayes2LSTM", "repackage_hidden"]
+
+
+class NoiseState:
+    """Shared by all modules of one model: Philox key, optimisation step and this rank's window of
+    global batch columns.  ``fused`` selects eps generation inside the GEMM tile loader."""
+
+    def __init__(self, seed=1111):
+        self.seed = int(seed)
+        self.step = 0
+        self.col_offset = 0
+        self.global_cols = 0
+        self.fused = False
+
+
+class _Site(nn.Module):
+    """Mixin: access to the model's NoiseState and stable per-module stream ids."""
+    _state = None
+    _site_base = 0
+
+    def _st(self):
+        if self._state is None:
+            self._state = NoiseState()
+        return self._state
+
+    def _drop(self, p, k=0):
+        st = self._st()
+        if not self.training or p <= 0.0:
+            return ops.NO_DROP
+        return Drop(float(p), st.seed, self._site_base + k, st.step, st.col_offset, st.global_cols)
+
+    def _noise(self, k=0, override=None):
+        """NoiseSpec of variational tensor k of this module, or None in eval mode (mean weights)."""
+        if override is not None:
+            return NoiseSpec(eps=override)
+        if not self.training:
+            return None
+        st = self._st()
+        return NoiseSpec(None, st.seed, self._site_base + k, st.step)
+
+
+def bind_state(model, state):
+    """Give every sub-module the model's NoiseState and a unique id range (16 ids per module)."""
+    for idx, m in enumerate(model.modules()):
+        if isinstance(m, _Site):
+            m._state = state
+            m._site_base = 16 * idx
+    return state
+
+
+def repackage_hidden(h):
+    """Detach hidden states from their history (train.py:291-295)."""
+    if isinstance(h, torch.Tensor):
+        return h.detach()
+    return tuple(repackage_hidden(v) for v in h)
+
+
+# ----------------------------------------------------------------------------
+# Transformer parts
+# ----------------------------------------------------------------------------
+class PositionalEncoding(_Site):
+    """Sinusoidal table + dropout (reference model.py:76-117); buffer ``pe`` is (max_len, 1, d)."""
+
+    def __init__(self, d_model, dropout=0.1, max_len=5000):
+        super().__init__()
+        self.p = dropout
+        pos = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        freq = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        table = torch.zeros(max_len, d_model)
+        table[:, 0::2] = torch.sin(pos * freq)
+        table[:, 1::2] = torch.cos(pos * freq)
+        self.register_buffer("pe", table.unsqueeze(1))
+
+    def table(self):
+        return self.pe.view(self.pe.shape[0], self.pe.shape[2])
+
+    def forward(self, x):
+        return ops.add_pe(x, self.table(), self._drop(self.p))
+
+
+class BayesLinear(_Site):
+    """y = x (mu + exp(lgstd) eps)^T, no bias (reference model.py:1049-1134).
+
+    ``eps_override``: inject eps (parity tests).  ``fused_kl_lambda``: when > 0 the wgrad epilogue
+    adds lambda * dKL/d(mu, lgstd) itself, so the caller must NOT also backprop kl_divergence()."""
+
+    def __init__(self, in_features, out_features, bias=False):
+        super().__init__()
+        if bias:
+            raise BayesLMError("BayesLinear(bias=True) is never built by the reference recipes and is not supported")
+        self.in_features, self.out_features = in_features, out_features
+        self.weight_mean = nn.Parameter(torch.empty(out_features, in_features))
+        self.weight_lgstd = nn.Parameter(torch.empty(out_features, in_features))
+        self.use_bias = False
+        self.sample = True
+        self.eps_override = None
+        self.fused_kl_lambda = 0.0
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        s = 1.0 / math.sqrt(self.out_features + 1)  # model.py:1070-1073
+        self.weight_mean.data.uniform_(-s, s)
+        self.weight_lgstd.data.uniform_(2 * np.log(s), np.log(s))
+
+    def noise(self):
+        if not (self.training and self.sample):
+            return None
+        return self._noise(0, self.eps_override)
+
+    def kl_divergence(self, prior=None):
+        if prior is not None:
+            raise BayesLMError("kl_divergence(prior=...) is dead code in the reference (model.py:1120-1122)")
+        return ops.kl_mean(self.weight_mean, self.weight_lgstd)
+
+    def forward(self, input):
+        return ops.bayes_linear(input, self.weight_mean, self.weight_lgstd, self.noise(), self.fused_kl_lambda,
+                                self._st().fused)
+
+    def extra_repr(self):
+        return "in_features={}, out_features={}, bias=False".format(self.in_features, self.out_features)
+
+
+class _ProjHolder(nn.Module):
+    """weight/bias container with nn.Linear's default initialisation (keys '<name>.weight|bias')."""
+
+    def __init__(self, in_f, out_f):
+        super().__init__()
+        lin = nn.Linear(in_f, out_f)
+        self.weight, self.bias = lin.weight, lin.bias
+        self.in_features, self.out_features = in_f, out_f
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+def _need_causal(attn_mask):
+    if attn_mask is None:
+        raise BayesLMError("the fused attention kernel is causal; the reference LMs always pass the "
+                           "square subsequent mask (model.py:1277-1281)")
+
+
+class MultiheadAttention(_Site):
+    """Fused-QKV causal self-attention (reference model.py:836-928).  The head-averaged attention
+    weights the reference also returns are discarded by every caller (``[0]`` at model.py:1040,1163);
+    the fused kernel never materialises them, so the second return value is None."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0., bias=True, add_bias_kv=False, add_zero_attn=False,
+                 kdim=None, vdim=None):
+        super().__init__()
+        if embed_dim % num_heads:
+            raise AssertionError("embed_dim must be divisible by num_heads")
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.head_dim = embed_dim // num_heads
+        self.qkv_net = _ProjHolder(embed_dim, 3 * embed_dim)
+        self.o_net = _ProjHolder(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.qkv_net.weight)  # model.py:863-869
+        nn.init.constant_(self.qkv_net.bias, 0.)
+        nn.init.constant_(self.o_net.bias, 0.)
+
+    def forward(self, query, key=None, value=None, key_padding_mask=None, need_weights=True, attn_mask=None):
+        _need_causal(attn_mask)
+        qkv = self.qkv_net(query)
+        a = ops.attention(qkv, self.num_heads, self._drop(self.dropout))
+        return self.o_net(a), None
+
+
+class BayesMultiheadAttention(_Site):
+    """Separate q/k/v projections, Bayesian output projection (reference model.py:931-1019; its
+    parameter reset is skipped there, :961, so the projections keep nn.Linear's default init)."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0., bias=True, add_bias_kv=False, add_zero_attn=False,
+                 kdim=None, vdim=None):
+        super().__init__()
+        if embed_dim % num_heads:
+            raise AssertionError("embed_dim must be divisible by num_heads")
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.head_dim = embed_dim // num_heads
+        self.q_net = _ProjHolder(embed_dim, embed_dim)
+        self.k_net = _ProjHolder(embed_dim, embed_dim)
+        self.v_net = _ProjHolder(embed_dim, embed_dim)
+        self.o_net = BayesLinear(embed_dim, embed_dim)
+
+    def forward(self, query, key=None, value=None, key_padding_mask=None, need_weights=True, attn_mask=None):
+        _need_causal(attn_mask)
+        key = query if key is None else key
+        value = query if value is None else value
+        a = ops.attention_qkv(self.q_net(query), self.k_net(key), self.v_net(value), self.num_heads,
+                              self._drop(self.dropout))
+        return self.o_net(a), None
+
+
+class _PostLNLayer(_Site):
+    """x = LN1(x + drop(attn(x)));  x = LN2(x + drop(lin2(drop(gelu(lin1(x))))))."""
+
+    def _build(self, d_model, dim_feedforward, dropout, bayes_ffn):
+        self.linear1 = _ProjHolder(d_model, dim_feedforward)
+        self.linear2 = BayesLinear(dim_feedforward, d_model) if bayes_ffn else _ProjHolder(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.p = dropout
+
+    def forward(self, src, src_mask=None):
+        a = self.self_attn(src, src, src, attn_mask=src_mask)[0]
+        x = ops.add_dropout_ln(src, a, self.norm1.weight, self.norm1.bias, self.norm1.eps, self._drop(self.p, 1))
+        l2 = self.linear2
+        if isinstance(l2, BayesLinear):
+            f = ops.ffn(x, self.linear1.weight, self.linear1.bias, l2.weight_mean, None, l2.weight_lgstd, l2.noise(),
+                        l2.fused_kl_lambda, self._st().fused, self._drop(self.p, 0))
+        else:
+            f = ops.ffn(x, self.linear1.weight, self.linear1.bias, l2.weight, l2.bias, drop=self._drop(self.p, 0))
+        return ops.add_dropout_ln(x, f, self.norm2.weight, self.norm2.bias, self.norm2.eps, self._drop(self.p, 2))
+
+
+class StandardTransformerEncoderLayer(_PostLNLayer):
+    """Reference model.py:1022-1046."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self._build(d_model, dim_feedforward, dropout, False)
+
+
+class BayesTransformerEncoderLayer(_PostLNLayer):
+    """Reference model.py:1137-1176: 'FFN' -> Bayesian linear2, 'MHA' -> Bayesian o_net."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, bayes_pos=None):
+        super().__init__()
+        self.bayes_pos = bayes_pos
+        att = BayesMultiheadAttention if bayes_pos == "MHA" else MultiheadAttention
+        self.self_attn = att(d_model, nhead, dropout=dropout)
+        self._build(d_model, dim_feedforward, dropout, bayes_pos == "FFN")
+
+
+class _LMHead(_Site):
+    """Shared embedding / decoder plumbing of the language models."""
+
+    def _init_io(self, ntoken, ninp, nout, tie_weights):
+        self.encoder = nn.Embedding(ntoken, ninp)
+        self.decoder = _ProjHolder(nout, ntoken)
+        if tie_weights:
+            self.decoder.weight = self.encoder.weight
+        nn.init.uniform_(self.encoder.weight, -0.1, 0.1)  # model.py:1264-1268 / :211-215
+        nn.init.zeros_(self.decoder.bias)
+        nn.init.uniform_(self.decoder.weight, -0.1, 0.1)
+
+    # training-loop controls (new; the reference draws from torch's global generator instead)
+    def set_step(self, step):
+        self.noise_state.step = int(step)
+
+    def set_seed(self, seed):
+        self.noise_state.seed = int(seed)
+
+    def set_columns(self, col_offset, global_cols):
+        self.noise_state.col_offset, self.noise_state.global_cols = int(col_offset), int(global_cols)
+
+    def set_fused_sampling(self, on):
+        self.noise_state.fused = bool(on)
+
+
+class BayesTransformerModel(_LMHead):
+    """Reference model.py:1179-1309.  Only layer 0 is Bayesian and it is built with a hard-coded
+    dropout of 0.2 (model.py:1202,1207); any other ``bayes_pos`` string builds zero layers."""
+
+    def __init__(self, ntoken, ninp, nhead, nhid, nlayers, dropout=0.5, tie_weights=False, bayes_pos=None):
+        super().__init__()
+        self.model_type = "Transformer"
+        self.src_mask = None
+        self.ninp = ninp
+        self.pos_encoder = PositionalEncoding(ninp, dropout)
+        self.transformerlayers = nn.ModuleList()
+        if bayes_pos in ("none", "EMB"):
+            for _ in range(nlayers):
+                self.transformerlayers.append(StandardTransformerEncoderLayer(ninp, nhead, nhid, dropout))
+        elif bayes_pos in ("FFN", "MHA"):
+            self.transformerlayers.append(BayesTransformerEncoderLayer(ninp, nhead, nhid, dropout=0.2, bayes_pos=bayes_pos))
+            for _ in range(nlayers - 1):
+                self.transformerlayers.append(StandardTransformerEncoderLayer(ninp, nhead, nhid, dropout))
+        self.bayes_embed = bayes_pos == "EMB"
+        self._init_io(ntoken, ninp, ninp, tie_weights)
+        if self.bayes_embed:
+            s = 1.0 / math.sqrt(ninp + 1)  # model.py:1269-1272
+            self.embed_mean = nn.Parameter(torch.empty(ninp, ninp).uniform_(-s, s))
+            self.embed_lgstd = nn.Parameter(torch.empty(ninp, ninp).uniform_(2 * np.log(s), np.log(s)))
+            self.embed_eps_override = None
+        self.noise_state = bind_state(self, NoiseState())
+
+    def embed_kl_divergence(self):
+        return ops.kl_mean(self.embed_mean, self.embed_lgstd)
+
+    def forward(self, src, has_mask=True):
+        if not has_mask:
+            raise BayesLMError("has_mask=False: the fused attention kernel is causal only")
+        self.src_mask = True
+        scale = math.sqrt(self.ninp)
+        if self.bayes_embed:
+            x = ops.embed(src, self.encoder.weight, None, scale)
+            noise = self._noise(0, self.embed_eps_override) if self.training else None
+            W = ops.sampled(self.embed_mean, self.embed_lgstd, noise) if noise is not None else self.embed_mean
+            x = ops.linear(x, W)
+            x = self.pos_encoder(x)
+        else:
+            # gather * sqrt(d) + positional table + dropout in one kernel (model.py:1284,1293)
+            x = ops.embed(src, self.encoder.weight, self.pos_encoder.table(), scale,
+                          self.pos_encoder._drop(self.pos_encoder.p))
+        for layer in self.transformerlayers:
+            x = layer(x, src_mask=self.src_mask)
+        if self.bayes_embed:
+            x = ops.linear(x, self.embed_mean.t())  # model.py:1302-1304, mean weights
+        return self.decoder(x)
+
+
+class _TorchMHAParams(_Site):
+    """nn.MultiheadAttention's parameter names (in_proj_weight, in_proj_bias, out_proj.*)."""
+
+    def __init__(self, d_model, nhead, dropout):
+        super().__init__()
+        self.num_heads, self.dropout = nhead, dropout
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        self.out_proj = _ProjHolder(d_model, d_model)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.)
+
+    def forward(self, query, key=None, value=None, attn_mask=None, **_):
+        _need_causal(attn_mask)
+        qkv = ops.linear(query, self.in_proj_weight, self.in_proj_bias)
+        return self.out_proj(ops.attention(qkv, self.num_heads, self._drop(self.dropout))), None
+
+
+class _TorchEncoderLayer(_PostLNLayer):
+    def __init__(self, d_model, nhead, dim_feedforward, dropout):
+        super().__init__()
+        self.self_attn = _TorchMHAParams(d_model, nhead, dropout)
+        self._build(d_model, dim_feedforward, dropout, False)
+
+
+class _TorchEncoder(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward, dropout, nlayers):
+        super().__init__()
+        self.layers = nn.ModuleList(_TorchEncoderLayer(d_model, nhead, dim_feedforward, dropout) for _ in range(nlayers))
+
+
+class TransformerModel(_LMHead):
+    """Baseline (reference model.py:120-171): the state_dict keys are nn.TransformerEncoder's
+    (``transformerlayers.layers.N.self_attn.in_proj_weight`` ...), post-LN, GELU."""
+
+    def __init__(self, ntoken, ninp, nhead, nhid, nlayers, dropout=0.5, activation="relu", tie_weights=False):
+        super().__init__()
+        if activation != "gelu":
+            raise BayesLMError("only activation='gelu' is built by the reference entry points (train.py:196-199)")
+        self.model_type = "Transformer"
+        self.src_mask = None
+        self.ninp = ninp
+        self.pos_encoder = PositionalEncoding(ninp, dropout)
+        self.transformerlayers = _TorchEncoder(ninp, nhead, nhid, dropout, nlayers)
+        self._init_io(ntoken, ninp, ninp, tie_weights)
+        self.noise_state = bind_state(self, NoiseState())
+
+    def forward(self, src, has_mask=True):
+        if not has_mask:
+            raise BayesLMError("has_mask=False: the fused attention kernel is causal only")
+        x = ops.embed(src, self.encoder.weight, self.pos_encoder.table(), math.sqrt(self.ninp),
+                      self.pos_encoder._drop(self.pos_encoder.p))
+        for layer in self.transformerlayers.layers:
+            x = layer(x, src_mask=True)
+        return self.decoder(x)
+
+
+# ----------------------------------------------------------------------------
+# LSTM models
+# ----------------------------------------------------------------------------
+class Bayes2LSTM(_Site):
+    """Two LSTM layers whose gate rows [(pos-1)H, pos*H) of all 8 tensors are variational
+    (reference model.py:585-828).  position 0 = plain LSTM; 5 is accepted like the reference
+    (lgstd tensors exist at full gate size, are never sampled)."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, position=0, bias=True, dropout=0., bayes_pos=0):
+        super().__init__()
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.bias, self.dropout, self.position = bias, float(dropout), position
+        G, H = 4 * hidden_size, hidden_size
+        s = 1.0 / math.sqrt(H)
+        for layer in (1, 2):
+            self.register_parameter("weight_ih_mean_%d" % layer, nn.Parameter(torch.empty(G, input_size).uniform_(-s, s)))
+            self.register_parameter("weight_hh_mean_%d" % layer, nn.Parameter(torch.empty(G, H).uniform_(-s, s)))
+            self.register_parameter("bias_ih_mean_%d" % layer, nn.Parameter(torch.empty(G).uniform_(-s, s)))
+            self.register_parameter("bias_hh_mean_%d" % layer, nn.Parameter(torch.empty(G).uniform_(-s, s)))
+        if 1 <= position <= 5:
+            R = H if position <= 4 else G
+            lo, hi = (2 * math.log(s), math.log(s))
+            for layer in (1, 2):
+                def mk(*shape):
+                    t = torch.empty(*shape)
+                    return nn.Parameter(t.uniform_(lo, hi) if position <= 4 else t.uniform_(0, 1))  # model.py:625-633
+                self.register_parameter("weight_hh_lgstd_%d" % layer, mk(R, H))
+                self.register_parameter("weight_ih_lgstd_%d" % layer, mk(R, input_size))
+                self.register_parameter("bias_hh_lgstd_%d" % layer, mk(R))
+                self.register_parameter("bias_ih_lgstd_%d" % layer, mk(R))
+        self.eps_override = None  # list of 8 tensors in the reference's draw order (model.py:668-703)
+
+    _ORDER = ("weight_hh", "weight_ih", "bias_hh", "bias_ih")
+
+    def _weights(self):
+        """The 8 tensors _VF.lstm gets (model.py:705-732), sampled on the gate rows in train mode."""
+        out = {}
+        pos, H = self.position, self.hidden_size
+        k = 0
+        for layer in (1, 2):
+            for name in self._ORDER:
+                mu = getattr(self, "%s_mean_%d" % (name, layer))
+                if 1 <= pos <= 4 and self.training:
+                    lg = getattr(self, "%s_lgstd_%d" % (name, layer))
+                    ov = self.eps_override[k] if self.eps_override is not None else None
+                    out[(name, layer)] = ops.sampled(mu, lg, self._noise(k, ov), (pos - 1) * H)
+                else:
+                    out[(name, layer)] = mu
+                k += 1
+        return out
+
+    def kl_divergence(self, prior=None):
+        pos, H, E = self.position, self.hidden_size, self.input_size
+        if prior is not None or not (1 <= pos <= 4):
+            raise BayesLMError("Bayes2LSTM.kl_divergence is defined for position 1..4 without prior "
+                               "(reference model.py:734-775: other branches are dead or raise)")
+        lo = (pos - 1) * H
+        nw, nb = H * (H + E), 2 * H  # the reference concatenates hh|ih before taking the mean
+        kl = ops.kl_mean(self.weight_hh_mean_1, self.weight_hh_lgstd_1, lo, count=nw)
+        kl = kl + ops.kl_mean(self.weight_ih_mean_1, self.weight_ih_lgstd_1, lo, count=nw)
+        kl = kl + ops.kl_mean(self.bias_hh_mean_1, self.bias_hh_lgstd_1, lo, count=nb)
+        kl = kl + ops.kl_mean(self.bias_ih_mean_1, self.bias_ih_lgstd_1, lo, count=nb)
+        return kl
+
+    def forward(self, inputs, hx=None):
+        T, B, _ = inputs.shape
+        if hx is None:
+            z = torch.zeros(self.num_layers, B, self.hidden_size, dtype=inputs.dtype, device=inputs.device)
+            hx = (z, z)
+        w = self._weights()
+        h0, c0 = hx
+        y, h1, c1 = ops.lstm_layer(inputs, h0[0], c0[0], w[("weight_ih", 1)], w[("weight_hh", 1)], w[("bias_ih", 1)],
+                                   w[("bias_hh", 1)])
+        y, h2, c2 = ops.lstm_layer(y, h0[1], c0[1], w[("weight_ih", 2)], w[("weight_hh", 2)], w[("bias_ih", 2)],
+                                   w[("bias_hh", 2)])
+        return y, (torch.stack([h1, h2]), torch.stack([c1, c2]))
+
+
+class _RNNLM(_LMHead):
+    def _check_type(self, rnn_type):
+        if rnn_type != "LSTM":
+            raise ValueError("An invalid option for `--model` was supplied: this engine builds 'LSTM' "
+                             "(the reference recipes, run_nnlm_ami_lstm.sh) and 'Transformer'")
+
+    def init_hidden(self, bsz):
+        w = next(self.parameters())
+        return (w.new_zeros(self.nlayers, bsz, self.nhid), w.new_zeros(self.nlayers, bsz, self.nhid))
+
+
+class BayesRNNModel(_RNNLM):
+    """Reference model.py:179-229: drop(emb) -> Bayes2LSTM -> drop -> tied decoder."""
+
+    def __init__(self, rnn_type, ntoken, ninp, nhid, nlayers, dropout=0.5, tie_weights=False, bayes_pos=0):
+        super().__init__()
+        self._check_type(rnn_type)
+        if tie_weights and nhid != ninp:
+            raise ValueError("When using the tied flag, nhid must be equal to emsize.")
+        self.rnn_type, self.nhid, self.nlayers, self.p = rnn_type, nhid, nlayers, dropout
+        self.rnn = Bayes2LSTM(ninp, nhid, nlayers, position=bayes_pos, dropout=dropout)
+        self._init_io(ntoken, ninp, nhid, tie_weights)
+        self.noise_state = bind_state(self, NoiseState())
+
+    def forward(self, x, hidden):
+        emb = ops.embed(x, self.encoder.weight, None, 1.0, self._drop(self.p, 0))
+        out, hidden = self.rnn(emb, hidden)
+        out = ops.dropout(out, self._drop(self.p, 1))
+        return self.decoder(out), hidden
+
+
+class _LSTMParams(_Site):
+    """nn.LSTM's parameter names (weight_ih_l0 ...), inter-layer dropout in train mode."""
+
+    def __init__(self, ninp, nhid, nlayers, dropout):
+        super().__init__()
+        self.nlayers, self.p = nlayers, dropout
+        s = 1.0 / math.sqrt(nhid)
+        for k in range(nlayers):
+            inp = ninp if k == 0 else nhid
+            self.register_parameter("weight_ih_l%d" % k, nn.Parameter(torch.empty(4 * nhid, inp).uniform_(-s, s)))
+            self.register_parameter("weight_hh_l%d" % k, nn.Parameter(torch.empty(4 * nhid, nhid).uniform_(-s, s)))
+            self.register_parameter("bias_ih_l%d" % k, nn.Parameter(torch.empty(4 * nhid).uniform_(-s, s)))
+            self.register_parameter("bias_hh_l%d" % k, nn.Parameter(torch.empty(4 * nhid).uniform_(-s, s)))
+
+    def forward(self, x, hx):
+        h0, c0 = hx
+        hs, cs = [], []
+        for k in range(self.nlayers):
+            x, h, c = ops.lstm_layer(x, h0[k], c0[k], getattr(self, "weight_ih_l%d" % k), getattr(self, "weight_hh_l%d" % k),
+                                     getattr(self, "bias_ih_l%d" % k), getattr(self, "bias_hh_l%d" % k))
+            if k + 1 < self.nlayers:
+                x = ops.dropout(x, self._drop(self.p, k))
+            hs.append(h)
+            cs.append(c)
+        return x, (torch.stack(hs), torch.stack(cs))
+
+
+class RNNModel(_RNNLM):
+    """Baseline LSTM LM (reference model.py:23-73, nn.LSTM with inter-layer dropout)."""
+
+    def __init__(self, rnn_type, ntoken, ninp, nhid, nlayers, dropout=0.5, tie_weights=False):
+        super().__init__()
+        self._check_type(rnn_type)
+        if tie_weights and nhid != ninp:
+            raise ValueError("When using the tied flag, nhid must be equal to emsize.")
+        self.rnn_type, self.nhid, self.nlayers, self.p = rnn_type, nhid, nlayers, dropout
+        self.rnn = _LSTMParams(ninp, nhid, nlayers, dropout)
+        self._init_io(ntoken, ninp, nhid, tie_weights)
+        self.noise_state = bind_state(self, NoiseState())
+
+    def forward(self, x, hidden):
+        emb = ops.embed(x, self.encoder.weight, None, 1.0, self._drop(self.p, 0))
+        out, hidden = self.rnn(emb, hidden)
+        out = ops.dropout(out, self._drop(self.p, 1))
+        return self.decoder(out), hidden

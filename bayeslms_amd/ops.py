@@ -1,0 +1,808 @@
+"""Operators of the hot path as torch.autograd.Functions over the C ABI.
+
+Each Function launches hand-written gfx950 kernels from libbayeslm_hip.so on
+torch's current HIP stream with raw device pointers.  PyTorch is used for
+device memory and the autograd tape only.  Parameter gradients are accumulated
+straight into ``param.grad`` by the wgrad kernels (BLM_GEMM_ACCUMULATE), so the
+flat gradient buffer the data-parallel all-reduce works on is filled in place;
+the Functions return ``None`` for parameters.
+
+There is no CPU path: every entry point raises on non-GPU tensors.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib as L
+from ._lib import BayesLMError, check, dev_tensor, lib, ptr, stream
+
+__all__ = ["Drop", "NoiseSpec", "linear", "bayes_linear", "ffn", "attention", "attention_qkv", "add_dropout_ln",
+           "embed", "add_pe", "dropout", "cross_entropy", "kl_mean", "philox_normal", "sample_weight", "sampled", "lstm_layer",
+           "clip_sgd", "gemm", "PtrTable", "set_grad_ready_hook", "KernelTimer", "set_kernel_timer"]
+
+
+# ----------------------------------------------------------------------------
+# small descriptors
+# ----------------------------------------------------------------------------
+@dataclass
+class Drop:
+    """A dropout site: probability + Philox key + the global column window of
+    this rank (masks are keyed by global column)."""
+    p: float = 0.0
+    seed: int = 0
+    site: int = 0
+    step: int = 0
+    col_offset: int = 0
+    global_cols: int = 0
+
+    @property
+    def on(self):
+        return self.p > 0.0
+
+    def rng(self):
+        return L.rng(self.seed, L.STREAM_DROPOUT + self.site, self.step)
+
+
+NO_DROP = Drop()
+
+
+@dataclass
+class NoiseSpec:
+    """Where eps of a variational tensor comes from: an injected tensor
+    (parity tests) or the Philox stream (seed, tensor id, step)."""
+    eps: torch.Tensor = None
+    seed: int = 0
+    tensor_id: int = 0
+    step: int = 0
+
+    def rng(self):
+        return L.rng(self.seed, L.STREAM_WEIGHT + self.tensor_id, self.step)
+
+
+def _variational(lgstd, noise, row_lo, srows):
+    v = L.Variational()
+    v.lgstd = ptr(lgstd)
+    v.eps = ptr(noise.eps) if (noise is not None and noise.eps is not None) else None
+    v.row_lo = int(row_lo)
+    v.srows = int(srows)
+    v.rng = noise.rng() if noise is not None else L.rng(0, 0, 0)
+    return v
+
+
+def _grad_buf(param):
+    """param.grad (allocated zeroed on first use): wgrad kernels accumulate into it."""
+    if param.grad is None:
+        param.grad = torch.zeros_like(param, memory_format=torch.contiguous_format)
+    return param.grad
+
+
+_GRAD_HOOK = None
+
+
+def set_grad_ready_hook(fn):
+    """fn(param) is called after a backward kernel that writes param.grad has been enqueued (the
+    data-parallel reducer uses it to start bucket all-reduces while backward is still running)."""
+    global _GRAD_HOOK
+    _GRAD_HOOK = fn
+
+
+def _notify(*params):
+    if _GRAD_HOOK is not None:
+        for p in params:
+            if p is not None and p.is_leaf and p.requires_grad:
+                _GRAD_HOOK(p)
+
+
+def _wgrad_target(w):
+    """-> (buffer, accumulate, value_to_return): leaf parameters accumulate in place into .grad and
+    autograd gets None; a non-leaf weight (e.g. a sampled tensor) gets a fresh gradient tensor."""
+    if w.is_leaf:
+        return _grad_buf(w), True, None
+    buf = torch.empty_like(w, memory_format=torch.contiguous_format)
+    return buf, False, buf
+
+
+def _f32(t, name):
+    return dev_tensor(t, name, torch.float32)
+
+
+# ----------------------------------------------------------------------------
+# per-kernel timing with HIP events on the launch stream (bench.py's live roofline numbers)
+# ----------------------------------------------------------------------------
+class KernelTimer:
+    def __init__(self):
+        self.records = []
+
+    def bracket(self, tag):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((tag, a, b))
+        return a, b
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for tag, a, b in self.records:
+            agg.setdefault(tag, []).append(a.elapsed_time(b))
+        return {k: {"avg_ms": sum(v) / len(v), "n": len(v)} for k, v in agg.items()}
+
+
+_TIMER = None
+
+
+def set_kernel_timer(t):
+    global _TIMER
+    _TIMER = t
+
+
+# ----------------------------------------------------------------------------
+# raw GEMM
+# ----------------------------------------------------------------------------
+def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, *, alpha=1.0, accumulate=False, epilogue=L.EPI_NONE, bias=None,
+         aux=None, coef=None, var_b=None, C2=None, wg_mu=None, var_c=None, kl_lambda=0.0, kl_inv_n=0.0,
+         drop=None, drop_B=0, tag=None):
+    if _TIMER is not None and tag is not None:
+        ev0, ev1 = _TIMER.bracket(tag)
+        ev0.record()
+        _gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, alpha, accumulate, epilogue, bias, aux, coef, var_b, C2, wg_mu,
+              var_c, kl_lambda, kl_inv_n, drop, drop_B)
+        ev1.record()
+        return
+    _gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, alpha, accumulate, epilogue, bias, aux, coef, var_b, C2, wg_mu,
+          var_c, kl_lambda, kl_inv_n, drop, drop_B)
+
+
+def _gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, alpha, accumulate, epilogue, bias, aux, coef, var_b, C2, wg_mu,
+          var_c, kl_lambda, kl_inv_n, drop, drop_B):
+    L.require_gfx950()
+    a = L.GemmArgs()
+    a.abi_version = L.ABI_VERSION
+    a.op = op
+    a.M, a.N, a.K = int(M), int(N), int(K)
+    a.A, a.lda = ptr(A), int(lda)
+    a.B, a.ldb = ptr(B), int(ldb)
+    a.C, a.ldc = ptr(Cout), int(ldc)
+    a.alpha = float(alpha)
+    a.flags = L.GEMM_ACCUMULATE if accumulate else 0
+    a.epilogue = epilogue
+    a.bias, a.aux, a.coef = ptr(bias), ptr(aux), ptr(coef)
+    if var_b is not None:
+        a.var_b = var_b
+    a.C2, a.wg_mu = ptr(C2), ptr(wg_mu)
+    if var_c is not None:
+        a.var_c = var_c
+    a.kl_lambda, a.kl_inv_n = float(kl_lambda), float(kl_inv_n)
+    if drop is not None and drop.on:
+        a.drop_p = float(drop.p)
+        a.drop_rng = drop.rng()
+        a.drop_B = int(drop_B)
+        a.drop_col_offset = int(drop.col_offset)
+        a.drop_global_cols = int(drop.global_cols or drop_B)
+    check(lib().blm_gemm(C.byref(a), stream()), "blm_gemm")
+
+
+def _colsum_into(dy2, M, N, out, accumulate=True):
+    check(lib().blm_colsum(ptr(dy2), N, ptr(out), M, N, 1 if accumulate else 0, stream()), "blm_colsum")
+
+
+# ----------------------------------------------------------------------------
+# Linear:  y = x W^T + b      (model.py:876,921,975-977,1306 F.linear call sites)
+# ----------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = _f32(x, "x")
+        N, K = w.shape
+        M = x.numel() // K
+        y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+        gemm(L.GEMM_NT, x, w, y, M, N, K, K, K, N, epilogue=L.EPI_BIAS if b is not None else L.EPI_NONE, bias=b)
+        ctx.save_for_backward(x)
+        ctx.w, ctx.b = w, b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w, b = ctx.w, ctx.b
+        dy = _f32(dy, "dy")
+        N, K = w.shape
+        M = x.numel() // K
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(L.GEMM_NN, dy, w, dx, M, K, N, N, K, K)
+        dw = db = None
+        if w.requires_grad:
+            buf, acc, dw = _wgrad_target(w)
+            gemm(L.GEMM_TN, dy, x, buf, N, K, M, N, K, K, accumulate=acc)
+        if b is not None and b.requires_grad:
+            buf, acc, db = _wgrad_target(b)
+            _colsum_into(dy, M, N, buf, accumulate=acc)
+        _notify(w, b)
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    w = _f32(w, "weight")
+    return _Linear.apply(x, w, b)
+
+
+# ----------------------------------------------------------------------------
+# BayesLinear:  y = x (mu + exp(lgstd) eps)^T   (model.py:1083-1129)
+# ----------------------------------------------------------------------------
+def sample_weight(mu, lgstd, noise, row_lo=0, srows=None, out=None, kl_out=None, kl_weight=1.0):
+    """W = mu (+ noise on rows [row_lo,row_lo+srows)); optional fused KL accumulation into kl_out."""
+    L.require_gfx950()
+    mu = _f32(mu, "mu")
+    rows = mu.shape[0]
+    cols = mu.numel() // rows
+    if srows is None:
+        srows = rows
+    v = _variational(lgstd, noise, row_lo, srows)
+    if out is None and (noise is not None or kl_out is None):
+        out = torch.empty_like(mu)
+    check(lib().blm_sample_weight(ptr(mu), rows, cols, C.byref(v), ptr(out), ptr(kl_out), float(kl_weight), stream()),
+          "blm_sample_weight")
+    return out
+
+
+class _SampleWeight(torch.autograd.Function):
+    """Differentiable materialisation, used where the sampled tensor feeds something other than one
+    GEMM (the LSTM stack, bias vectors, the EMB projection)."""
+
+    @staticmethod
+    def forward(ctx, mu, lgstd, noise, row_lo):
+        W = sample_weight(mu, lgstd, noise, row_lo, lgstd.shape[0])
+        ctx.meta = (mu, lgstd, noise, row_lo)
+        return W
+
+    @staticmethod
+    def backward(ctx, dW):
+        mu, lgstd, noise, row_lo = ctx.meta
+        dW = _f32(dW, "dW")
+        rows = mu.shape[0]
+        cols = mu.numel() // rows
+        v = _variational(lgstd, noise, row_lo, lgstd.shape[0])
+        check(lib().blm_sample_weight_bwd(ptr(dW), rows, cols, C.byref(v), ptr(_grad_buf(mu)) if mu.requires_grad else None,
+                                          ptr(_grad_buf(lgstd)) if lgstd.requires_grad else None, stream()),
+              "blm_sample_weight_bwd")
+        _notify(mu, lgstd)
+        return None, None, None, None
+
+
+def sampled(mu, lgstd, noise, row_lo=0):
+    """W = mu with noise on rows [row_lo, row_lo + lgstd.shape[0]); differentiable w.r.t. mu, lgstd."""
+    return _SampleWeight.apply(mu, lgstd, noise, row_lo)
+
+
+class _BayesLinear(torch.autograd.Function):
+    """``fused=True``: eps is generated inside the GEMM tile loader (no W in HBM) in forward and
+    dgrad; ``fused=False``: one materialisation pass writes W, then plain GEMMs.  The wgrad GEMM's
+    epilogue turns dW into (dmu, dlgstd) with eps regenerated from the counter and adds the KL
+    gradient scaled by kl_lambda."""
+
+    @staticmethod
+    def forward(ctx, x, mu, lgstd, noise, kl_lambda, fused):
+        x = _f32(x, "x")
+        N, K = mu.shape
+        M = x.numel() // K
+        y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+        W = None
+        if noise is None:
+            gemm(L.GEMM_NT, x, mu, y, M, N, K, K, K, N)
+        elif fused:
+            gemm(L.GEMM_NT, x, mu, y, M, N, K, K, K, N, var_b=_variational(lgstd, noise, 0, N))
+        else:
+            W = sample_weight(mu, lgstd, noise)
+            gemm(L.GEMM_NT, x, W, y, M, N, K, K, K, N)
+        ctx.save_for_backward(x, W)
+        ctx.mu, ctx.lgstd, ctx.noise, ctx.kl_lambda, ctx.fused = mu, lgstd, noise, kl_lambda, fused
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        mu, lgstd, noise = ctx.mu, ctx.lgstd, ctx.noise
+        dy = _f32(dy, "dy")
+        N, K = mu.shape
+        M = x.numel() // K
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            if noise is None:
+                gemm(L.GEMM_NN, dy, mu, dx, M, K, N, N, K, K)
+            elif ctx.fused:
+                gemm(L.GEMM_NN, dy, mu, dx, M, K, N, N, K, K, var_b=_variational(lgstd, noise, 0, N))
+            else:
+                gemm(L.GEMM_NN, dy, W, dx, M, K, N, N, K, K)
+        if mu.requires_grad:
+            if noise is None:  # eval-mode graph: only the mean gets a gradient
+                gemm(L.GEMM_TN, dy, x, _grad_buf(mu), N, K, M, N, K, K, accumulate=True)
+            else:
+                gemm(L.GEMM_TN, dy, x, _grad_buf(mu), N, K, M, N, K, K, accumulate=True,
+                     epilogue=L.EPI_BAYES_WGRAD, C2=_grad_buf(lgstd), wg_mu=mu,
+                     var_c=_variational(lgstd, noise, 0, N), kl_lambda=ctx.kl_lambda, kl_inv_n=1.0 / (N * K))
+                _notify(lgstd)
+            _notify(mu)
+        return dx, None, None, None, None, None
+
+
+def bayes_linear(x, mu, lgstd, noise=None, kl_lambda=0.0, fused=False):
+    return _BayesLinear.apply(x, mu, lgstd, noise, kl_lambda, fused)
+
+
+# ----------------------------------------------------------------------------
+# FFN:  y = lin2(drop(gelu(x W1^T + b1)))        (model.py:1043, 1169)
+# lin2 is nn.Linear (w2, b2) or BayesLinear (mu2, lgstd2, no bias).
+# ----------------------------------------------------------------------------
+class _FFN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, lgstd2, noise, kl_lambda, fused, drop):
+        x = _f32(x, "x")
+        F_, D = w1.shape  # (ff, d)
+        N2 = w2.shape[0]
+        M = x.numel() // D
+        B = x.shape[-2] if x.dim() >= 2 else 1
+        need_bwd = torch.is_grad_enabled()
+        z = torch.empty(M, F_, device=x.device, dtype=torch.float32) if need_bwd else None
+        h = torch.empty(M, F_, device=x.device, dtype=torch.float32)
+        gemm(L.GEMM_NT, x, w1, h, M, F_, D, D, D, F_, epilogue=L.EPI_BIAS_GELU, bias=b1, aux=z, drop=drop, drop_B=B,
+             tag="ffn_linear1_fwd")
+        y = torch.empty(*x.shape[:-1], N2, device=x.device, dtype=torch.float32)
+        W = None
+        bayes = lgstd2 is not None
+        if bayes and noise is not None:
+            if fused:
+                gemm(L.GEMM_NT, h, w2, y, M, N2, F_, F_, F_, N2, var_b=_variational(lgstd2, noise, 0, N2),
+                     tag="sampled_gemm_fwd")
+            else:
+                W = sample_weight(w2, lgstd2, noise)
+                gemm(L.GEMM_NT, h, W, y, M, N2, F_, F_, F_, N2, tag="sampled_gemm_fwd")
+        else:
+            gemm(L.GEMM_NT, h, w2, y, M, N2, F_, F_, F_, N2,
+                 epilogue=L.EPI_BIAS if b2 is not None else L.EPI_NONE, bias=b2)
+        ctx.save_for_backward(x, z, h, W)
+        ctx.p = (w1, b1, w2, b2, lgstd2, noise, kl_lambda, fused, drop, B)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, h, W = ctx.saved_tensors
+        w1, b1, w2, b2, lgstd2, noise, kl_lambda, fused, drop, B = ctx.p
+        dy = _f32(dy, "dy")
+        F_, D = w1.shape
+        N2 = w2.shape[0]
+        M = x.numel() // D
+        bayes = lgstd2 is not None and noise is not None
+        # dz = (dy W2) * keep * gelu'(z): dropout mask and GELU derivative live in the dgrad epilogue
+        dz = torch.empty(M, F_, device=x.device, dtype=torch.float32)
+        if bayes and fused:
+            gemm(L.GEMM_NN, dy, w2, dz, M, F_, N2, N2, F_, F_, epilogue=L.EPI_MUL_DGELU, aux=z, drop=drop, drop_B=B,
+                 var_b=_variational(lgstd2, noise, 0, N2), tag="sampled_gemm_dgrad")
+        else:
+            gemm(L.GEMM_NN, dy, W if bayes else w2, dz, M, F_, N2, N2, F_, F_, epilogue=L.EPI_MUL_DGELU, aux=z,
+                 drop=drop, drop_B=B, tag="sampled_gemm_dgrad" if bayes else None)
+        # linear2 weight gradients
+        if w2.requires_grad:
+            if bayes:
+                gemm(L.GEMM_TN, dy, h, _grad_buf(w2), N2, F_, M, N2, F_, F_, accumulate=True,
+                     epilogue=L.EPI_BAYES_WGRAD, C2=_grad_buf(lgstd2), wg_mu=w2,
+                     var_c=_variational(lgstd2, noise, 0, N2), kl_lambda=kl_lambda, kl_inv_n=1.0 / (N2 * F_),
+                     tag="sampled_gemm_wgrad")
+            else:
+                gemm(L.GEMM_TN, dy, h, _grad_buf(w2), N2, F_, M, N2, F_, F_, accumulate=True)
+        if b2 is not None and b2.requires_grad:
+            _colsum_into(dy, M, N2, _grad_buf(b2))
+        _notify(w2, b2, lgstd2 if bayes else None)
+        # linear1
+        if w1.requires_grad:
+            gemm(L.GEMM_TN, dz, x, _grad_buf(w1), F_, D, M, F_, D, D, accumulate=True)
+        if b1.requires_grad:
+            _colsum_into(dz, M, F_, _grad_buf(b1))
+        _notify(w1, b1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(L.GEMM_NN, dz, w1, dx, M, D, F_, F_, D, D)
+        return (dx,) + (None,) * 9
+
+
+def ffn(x, w1, b1, w2, b2=None, lgstd2=None, noise=None, kl_lambda=0.0, fused=False, drop=NO_DROP):
+    return _FFN.apply(x, w1, b1, w2, b2, lgstd2, noise, kl_lambda, fused, drop)
+
+
+# ----------------------------------------------------------------------------
+# causal self-attention core on packed or separate q/k/v   (model.py:889-920)
+# ----------------------------------------------------------------------------
+class _Attention(torch.autograd.Function):
+    """Packed: qkv (T,B,3d) = [q|k|v] from one qkv_net GEMM (model.py:876); separate: three (T,B,d)
+    tensors (BayesMultiheadAttention, model.py:975-977).  One input / one gradient tensor in the
+    packed case, so autograd never splits or re-concatenates the 3d-wide activation."""
+
+    @staticmethod
+    def forward(ctx, a, k, v, nhead, drop):
+        a = _f32(a, "qkv")
+        packed = k is None
+        if packed:
+            T, B, d3 = a.shape
+            d = d3 // 3
+            q, kk, vv, ld = a, a[..., d:], a[..., 2 * d:], d3
+        else:
+            T, B, d = a.shape
+            q, kk, vv, ld = a, _f32(k, "k"), _f32(v, "v"), d
+        hd = d // nhead
+        out = torch.empty(T, B, d, device=a.device, dtype=torch.float32)
+        lse = torch.empty(B * nhead, T, device=a.device, dtype=torch.float32)
+        L.require_gfx950()
+        r = drop.rng() if drop.on else None
+        check(lib().blm_attn_fwd(q.data_ptr(), kk.data_ptr(), vv.data_ptr(), ld, ptr(out), ptr(lse), T, B, nhead, hd,
+                                 float(drop.p), C.byref(r) if r is not None else None, drop.col_offset,
+                                 drop.global_cols or B, stream()), "blm_attn_fwd")
+        ctx.save_for_backward(q, kk if not packed else None, vv if not packed else None, out, lse)
+        ctx.meta = (nhead, drop, packed, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, k, v, out, lse = ctx.saved_tensors
+        nhead, drop, packed, d = ctx.meta
+        T, B = a.shape[0], a.shape[1]
+        dout = _f32(dout, "dout")
+        if packed:
+            q, kk, vv, ld = a, a[..., d:], a[..., 2 * d:], 3 * d
+            dqkv = torch.empty(T, B, 3 * d, device=a.device, dtype=torch.float32)
+            dq, dk, dv, ldd = dqkv, dqkv[..., d:], dqkv[..., 2 * d:], 3 * d
+        else:
+            q, kk, vv, ld = a, k, v, d
+            dq, dk, dv = (torch.empty(T, B, d, device=a.device, dtype=torch.float32) for _ in range(3))
+            ldd = d
+        r = drop.rng() if drop.on else None
+        check(lib().blm_attn_bwd(q.data_ptr(), kk.data_ptr(), vv.data_ptr(), ld, ptr(out), ptr(dout), ptr(lse),
+                                 dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ldd, T, B, nhead, d // nhead,
+                                 float(drop.p), C.byref(r) if r is not None else None, drop.col_offset,
+                                 drop.global_cols or B, stream()), "blm_attn_bwd")
+        if packed:
+            return dqkv, None, None, None, None
+        return dq, dk, dv, None, None
+
+
+def attention(qkv, nhead, drop=NO_DROP):
+    """Causal self-attention core on packed (T,B,3d) projections."""
+    return _Attention.apply(qkv, None, None, nhead, drop)
+
+
+def attention_qkv(q, k, v, nhead, drop=NO_DROP):
+    """Same, on three separate (T,B,d) projections."""
+    return _Attention.apply(q, k, v, nhead, drop)
+
+
+# ----------------------------------------------------------------------------
+# out = LayerNorm(x + drop(y))      (model.py:1041-1042, 1044-1045)
+# ----------------------------------------------------------------------------
+class _AddDropLN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, gamma, beta, eps, drop):
+        x, y = _f32(x, "x"), _f32(y, "y")
+        D = x.shape[-1]
+        B = x.shape[-2]
+        rows = x.numel() // (B * D)
+        out = torch.empty_like(x)
+        s = torch.empty_like(x)
+        mean = torch.empty(rows * B, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        L.require_gfx950()
+        r = drop.rng() if drop.on else None
+        check(lib().blm_add_dropout_ln_fwd(ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(out), ptr(s), ptr(mean), ptr(rstd),
+                                           rows, B, D, float(eps), float(drop.p), C.byref(r) if r is not None else None,
+                                           drop.col_offset, drop.global_cols or B, stream()), "blm_add_dropout_ln_fwd")
+        ctx.save_for_backward(s, mean, rstd)
+        ctx.meta = (gamma, beta, drop, rows, B, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        s, mean, rstd = ctx.saved_tensors
+        gamma, beta, drop, rows, B, D = ctx.meta
+        dout = _f32(dout, "dout")
+        dx = torch.empty_like(s)
+        dy = torch.empty_like(s) if drop.on else None
+        ws = torch.empty(int(lib().blm_ln_bwd_ws_floats(rows * B, D)), device=s.device, dtype=torch.float32)
+        r = drop.rng() if drop.on else None
+        check(lib().blm_add_dropout_ln_bwd(ptr(dout), ptr(s), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dy),
+                                           ptr(_grad_buf(gamma)), ptr(_grad_buf(beta)), ptr(ws), rows, B, D,
+                                           float(drop.p), C.byref(r) if r is not None else None, drop.col_offset,
+                                           drop.global_cols or B, stream()), "blm_add_dropout_ln_bwd")
+        _notify(gamma, beta)
+        return dx, (dy if dy is not None else dx), None, None, None, None
+
+
+def add_dropout_ln(x, y, gamma, beta, eps=1e-5, drop=NO_DROP):
+    return _AddDropLN.apply(x, y, gamma, beta, eps, drop)
+
+
+# ----------------------------------------------------------------------------
+# embedding (+ sqrt(d) scale + positional table + dropout)   (model.py:1284,116-117,218)
+# ----------------------------------------------------------------------------
+class _Embed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, weight, pe, scale, drop):
+        ids = dev_tensor(ids, "ids", torch.int64)
+        T, B = ids.shape
+        V, D = weight.shape
+        if pe is not None and pe.shape[0] < T:
+            raise BayesLMError("sequence length %d exceeds the positional table (%d)" % (T, pe.shape[0]))
+        out = torch.empty(T, B, D, device=weight.device, dtype=torch.float32)
+        L.require_gfx950()
+        r = drop.rng() if drop.on else None
+        check(lib().blm_embed_fwd(ptr(ids), ptr(weight), ptr(pe), ptr(out), T, B, D, V, float(scale), float(drop.p),
+                                  C.byref(r) if r is not None else None, drop.col_offset, drop.global_cols or B,
+                                  stream()), "blm_embed_fwd")
+        ctx.save_for_backward(ids)
+        ctx.meta = (weight, scale, drop)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        weight, scale, drop = ctx.meta
+        if weight.requires_grad:
+            dy = _f32(dy, "dy")
+            T, B = ids.shape
+            V, D = weight.shape
+            r = drop.rng() if drop.on else None
+            check(lib().blm_embed_bwd(ptr(ids), ptr(dy), ptr(_grad_buf(weight)), T, B, D, V, float(scale),
+                                      float(drop.p), C.byref(r) if r is not None else None, drop.col_offset,
+                                      drop.global_cols or B, stream()), "blm_embed_bwd")
+            _notify(weight)
+        return None, None, None, None, None
+
+
+def embed(ids, weight, pe=None, scale=1.0, drop=NO_DROP):
+    return _Embed.apply(ids, weight, pe, scale, drop)
+
+
+class _AddPE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pe, drop):
+        x = _f32(x, "x")
+        T, B, D = x.shape
+        if pe.shape[0] < T:
+            raise BayesLMError("sequence length %d exceeds the positional table (%d)" % (T, pe.shape[0]))
+        out = torch.empty_like(x)
+        L.require_gfx950()
+        r = drop.rng() if drop.on else None
+        check(lib().blm_add_pe_dropout(ptr(x), ptr(pe), ptr(out), T, B, D, float(drop.p),
+                                       C.byref(r) if r is not None else None, drop.col_offset, drop.global_cols or B,
+                                       stream()), "blm_add_pe_dropout")
+        ctx.drop = drop
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _f32(dy, "dy")
+        return (_dropout_apply(dy, ctx.drop) if ctx.drop.on else dy), None, None
+
+
+def add_pe(x, pe, drop=NO_DROP):
+    """drop(x + pe[:T]) with pe a (max_len, D) table (model.py:116-117)."""
+    return _AddPE.apply(x, pe, drop)
+
+
+# ----------------------------------------------------------------------------
+# dropout on a (rows, B, D) activation  (model.py:220 etc.)
+# ----------------------------------------------------------------------------
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, drop):
+        x = _f32(x, "x")
+        ctx.drop = drop
+        return _dropout_apply(x, drop)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _dropout_apply(_f32(dy, "dy"), ctx.drop), None
+
+
+def _dropout_apply(x, drop):
+    D = x.shape[-1]
+    B = x.shape[-2] if x.dim() >= 2 else 1
+    rows = x.numel() // (B * D)
+    y = torch.empty_like(x)
+    L.require_gfx950()
+    r = drop.rng()
+    check(lib().blm_dropout(ptr(x), ptr(y), rows, B, D, float(drop.p), C.byref(r), drop.col_offset,
+                            drop.global_cols or B, stream()), "blm_dropout")
+    return y
+
+
+def dropout(x, drop):
+    if not drop.on:
+        return x
+    return _Dropout.apply(x, drop)
+
+
+# ----------------------------------------------------------------------------
+# cross entropy (mean over M tokens) on materialised logits  (train.py:233,332)
+# ----------------------------------------------------------------------------
+class _CrossEntropy(torch.autograd.Function):
+    """unit_grad=True (the trainer's case, loss = CE + KL with coefficient 1, train.py:412): the
+    forward pass over the logits also overwrites them in place with d(mean NLL)/d(logits), and
+    backward returns that buffer untouched.  unit_grad=False: forward keeps lse, backward runs the
+    gradient kernel with the real upstream scalar.  Either way the logits buffer is consumed."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, unit_grad):
+        logits = _f32(logits, "logits")
+        targets = dev_tensor(targets, "targets", torch.int64)
+        V = logits.shape[-1]
+        M = logits.numel() // V
+        if targets.numel() != M:
+            raise BayesLMError("cross_entropy: %d targets for %d rows" % (targets.numel(), M))
+        nll = torch.empty(M, device=logits.device, dtype=torch.float32)
+        loss = torch.zeros((), device=logits.device, dtype=torch.float32)
+        grad_mode = torch.is_grad_enabled()
+        fuse = grad_mode and unit_grad
+        lse = torch.empty(M, device=logits.device, dtype=torch.float32) if (grad_mode and not unit_grad) else None
+        L.require_gfx950()
+        check(lib().blm_ce_fwd_bwd(ptr(logits), V, ptr(targets), ptr(nll), ptr(lse), ptr(loss),
+                                   ptr(logits) if fuse else None, 1.0 / M, M, V, stream()), "blm_ce_fwd_bwd")
+        ctx.meta = (logits, targets, lse, fuse, M, V)
+        ctx.mark_non_differentiable(nll)
+        return loss / M, nll
+
+    @staticmethod
+    def backward(ctx, g, _g_nll):
+        logits, targets, lse, fuse, M, V = ctx.meta
+        if fuse:
+            return logits, None, None
+        g = _f32(g.reshape(1), "g")
+        check(lib().blm_ce_bwd(ptr(logits), V, ptr(targets), ptr(lse), ptr(g), 1.0 / M, ptr(logits), M, V, stream()),
+              "blm_ce_bwd")
+        return logits, None, None
+
+
+def cross_entropy(logits, targets, unit_grad=False):
+    """-> (mean NLL, per-token NLL).  In grad mode the logits buffer is consumed by the gradient."""
+    return _CrossEntropy.apply(logits, targets, unit_grad)
+
+
+# ----------------------------------------------------------------------------
+# KL term  mean(mu^2 - 2 lg + exp(2 lg) [-1]) / 2  over a row window of mu
+# ----------------------------------------------------------------------------
+class _KLMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, lgstd, row_lo, minus_one, count_override):
+        mu = _f32(mu, "mu")
+        lgstd = _f32(lgstd, "lgstd")
+        rows = lgstd.shape[0]
+        cols = lgstd.numel() // rows
+        ld = mu.numel() // mu.shape[0]
+        out = torch.zeros((), device=mu.device, dtype=torch.float32)
+        n = rows * cols
+        w = float(n) / float(count_override) if count_override else 1.0
+        L.require_gfx950()
+        check(lib().blm_kl_mean_fwd(mu.data_ptr() + 4 * row_lo * ld, ld, ptr(lgstd), rows, cols, int(minus_one), w,
+                                    ptr(out), stream()), "blm_kl_mean_fwd")
+        ctx.meta = (mu, lgstd, row_lo, rows, cols, ld, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, lgstd, row_lo, rows, cols, ld, w = ctx.meta
+        g = _f32(g.reshape(1), "g")
+        gm, gl = _grad_buf(mu), _grad_buf(lgstd)
+        check(lib().blm_kl_mean_bwd(mu.data_ptr() + 4 * row_lo * ld, ld, ptr(lgstd), rows, cols, ptr(g), w,
+                                    gm.data_ptr() + 4 * row_lo * ld, ld, ptr(gl), stream()), "blm_kl_mean_bwd")
+        _notify(mu, lgstd)
+        return None, None, None, None, None
+
+
+def kl_mean(mu, lgstd, row_lo=0, minus_one=False, count=None):
+    """KL of the rows [row_lo, row_lo+lgstd.shape[0]) of mu against lgstd.  ``count`` replaces the
+    element count of the mean (Bayes2LSTM concatenates hh and ih before taking it, model.py:737-740)."""
+    return _KLMean.apply(mu, lgstd, row_lo, minus_one, count)
+
+
+def philox_normal(n, seed, stream_id, step, device="cuda"):
+    out = torch.empty(n, device=device, dtype=torch.float32)
+    L.require_gfx950()
+    r = L.rng(seed, stream_id, step)
+    check(lib().blm_philox_normal(ptr(out), n, C.byref(r), stream()), "blm_philox_normal")
+    return out
+
+
+# ----------------------------------------------------------------------------
+# 2-layer LSTM stack as _VF.lstm computes it (model.py:812), explicit cell
+# ----------------------------------------------------------------------------
+class _LSTMLayer(torch.autograd.Function):
+    """One layer over T steps.  Input GEMM batched over T (M = T*B), recurrent GEMM + fused cell per
+    step.  Weights arrive already sampled (W = mu + noise on the gate rows)."""
+
+    @staticmethod
+    def forward(ctx, x, h0, c0, w_ih, w_hh, b_ih, b_hh):
+        x = _f32(x, "x")
+        T, B, E = x.shape
+        H = w_hh.shape[1]
+        G = 4 * H
+        dev = x.device
+        bias = b_ih.clone()
+        check(lib().blm_axpy(ptr(b_hh), ptr(bias), G, 1.0, stream()), "blm_axpy")
+        xw = torch.empty(T, B, G, device=dev, dtype=torch.float32)
+        gemm(L.GEMM_NT, x, w_ih, xw, T * B, G, E, E, E, G, epilogue=L.EPI_BIAS, bias=bias)
+        hs = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
+        cs = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
+        hs[0].copy_(h0)
+        cs[0].copy_(c0)
+        ga = torch.empty(T, B, G, device=dev, dtype=torch.float32)
+        hw = torch.empty(B, G, device=dev, dtype=torch.float32)
+        st = stream()
+        for t in range(T):
+            gemm(L.GEMM_NT, hs[t], w_hh, hw, B, G, H, H, H, G)
+            check(lib().blm_lstm_cell_fwd(ptr(xw[t]), ptr(hw), ptr(cs[t]), ptr(hs[t + 1]), ptr(cs[t + 1]), ptr(ga[t]),
+                                          B, H, st), "blm_lstm_cell_fwd")
+        ctx.save_for_backward(x, hs, cs, ga, w_ih, w_hh)
+        return hs[1:], hs[T], cs[T]
+
+    @staticmethod
+    def backward(ctx, dy, dhT, dcT):
+        x, hs, cs, ga, w_ih, w_hh = ctx.saved_tensors
+        T, B, E = x.shape
+        H = w_hh.shape[1]
+        G = 4 * H
+        dev = x.device
+        dy = _f32(dy, "dy")
+        dgates = torch.empty(T, B, G, device=dev, dtype=torch.float32)
+        dh = torch.zeros(B, H, device=dev, dtype=torch.float32) if dhT is None else _f32(dhT, "dhT").clone()
+        dc = torch.zeros(B, H, device=dev, dtype=torch.float32) if dcT is None else _f32(dcT, "dcT").clone()
+        dh_rec = torch.empty(B, H, device=dev, dtype=torch.float32)
+        st = stream()
+        for t in range(T - 1, -1, -1):
+            check(lib().blm_axpy(ptr(dy[t]), ptr(dh), B * H, 1.0, st), "blm_axpy")
+            dc_prev = torch.empty(B, H, device=dev, dtype=torch.float32)
+            check(lib().blm_lstm_cell_bwd(ptr(dh), ptr(dc), ptr(cs[t]), ptr(cs[t + 1]), ptr(ga[t]), ptr(dgates[t]),
+                                          ptr(dc_prev), B, H, st), "blm_lstm_cell_bwd")
+            gemm(L.GEMM_NN, dgates[t], w_hh, dh_rec, B, H, G, G, H, H)
+            dh, dh_rec = dh_rec, dh
+            dc = dc_prev
+        dx = torch.empty_like(x)
+        gemm(L.GEMM_NN, dgates, w_ih, dx, T * B, E, G, G, E, E)
+        dw_ih = torch.empty_like(w_ih)
+        gemm(L.GEMM_TN, dgates, x, dw_ih, G, E, T * B, G, E, E)
+        dw_hh = torch.empty_like(w_hh)
+        gemm(L.GEMM_TN, dgates, hs, dw_hh, G, H, T * B, G, H, H)  # hs[0:T] = h_{t-1}
+        db = torch.empty(G, device=dev, dtype=torch.float32)
+        _colsum_into(dgates, T * B, G, db, accumulate=False)
+        return dx, dh, dc, dw_ih, dw_hh, db, db
+
+
+def lstm_layer(x, h0, c0, w_ih, w_hh, b_ih, b_hh):
+    return _LSTMLayer.apply(x, h0, c0, w_ih, w_hh, b_ih, b_hh)
+
+
+# ----------------------------------------------------------------------------
+# optimiser:  clip_grad_norm_ + SGD(momentum)   (train.py:419-420,466)
+# ----------------------------------------------------------------------------
+class PtrTable:
+    """Device arrays of pointers/sizes for the multi-tensor kernels (built once per tensor list)."""
+
+    def __init__(self, params, grads, bufs):
+        dev = params[0].device
+        self.n = len(params)
+        self.params = torch.tensor([p.data_ptr() for p in params], dtype=torch.int64, device=dev)
+        self.grads = torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64, device=dev)
+        self.bufs = torch.tensor([b.data_ptr() for b in bufs], dtype=torch.int64, device=dev)
+        self.sizes = torch.tensor([p.numel() for p in params], dtype=torch.int64, device=dev)
+        self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._keep = (params, grads, bufs)
+
+
+def clip_sgd(table, clip, lr, momentum, first, grad_scale=1.0):
+    """-> device scalar holding the squared global gradient norm (before grad_scale)."""
+    L.require_gfx950()
+    table.sq.zero_()
+    st = stream()
+    check(lib().blm_sqnorm_multi(ptr(table.grads), ptr(table.sizes), table.n, ptr(table.sq), st), "blm_sqnorm_multi")
+    check(lib().blm_clip_sgd_multi(ptr(table.params), ptr(table.grads), ptr(table.bufs), ptr(table.sizes), table.n,
+                                   ptr(table.sq), float(clip), float(lr), float(momentum), 1 if first else 0,
+                                   float(grad_scale), st), "blm_clip_sgd_multi")
+    return table.sq

@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training tokens/s of the Bayesian Transformer-FFN LM (BASELINE.json
+configs[2]: 6 layers, d_model 512, d_ff 4096, 8 heads, V = 33,000, seq_len 128, batch 64 per GPU,
+--uncertainty Bayesian --T_bayes_pos FFN, dropout 0.2, tied, clip 1.0, SGD momentum 0.9) on N
+MI355X of one node, synthetic AMI-shaped token stream, random-init weights, fp32.
+
+One step = forward + CE + KL*seq_len/len(train_data) + backward + gradient all-reduce (N > 1)
++ global-norm clip + SGD, nothing skipped.  Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# cfg3 of BASELINE.json
+V, D_MODEL, NHEAD, D_FF, NLAYERS, T, B_PER_GPU = 33000, 512, 8, 4096, 6, 128, 64
+DROPOUT, LR, CLIP = 0.2, 0.1, 1.0
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--fused-sampling", type=int, default=-1,
+                    help="1: eps generated inside the GEMM tile loader; 0: one materialisation pass; -1: engine default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="columns per GPU (default = the named config)")
+    return ap.parse_args()
+
+
+def cpu_baseline(cols=4, steps=2):
+    """The CPU oracle (the reference's algorithm restated, parity-pinned) timed on this box's host
+    cores on a BOUNDED sample of the same workload: the same model and window length, `cols` of the
+    64 batch columns, full fwd + CE + KL + bwd + clip + SGD."""
+    from bayeslms_amd import model as M
+    from bayeslms_amd.data import synthetic_corpus
+    from oracle import bayes_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    torch.manual_seed(1111)
+    m = M.BayesTransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, True, "FFN")
+    names = [k for k, _ in m.named_parameters() if k != "decoder.weight"]
+    sd = {k: v.detach().clone().requires_grad_(k in names) for k, v in m.state_dict().items()}
+    sd["decoder.weight"] = sd["encoder.weight"]
+    del m
+    stream = synthetic_corpus(V, cols * (T * (steps + 1) + 1), seed=1111)
+    data = stream[: cols * (T * (steps + 1) + 1) // cols * cols].view(cols, -1).t().contiguous()
+    bufs = [None] * len(names)
+    times = []
+    for s in range(steps + 1):
+        src = data[s * T:(s + 1) * T]
+        tgt = data[s * T + 1:(s + 1) * T + 1].reshape(-1)
+        t0 = time.perf_counter()
+        eps = torch.randn(D_MODEL, D_FF)
+        for k in names:
+            sd[k].grad = None
+        loss, _, _ = O.transformer_train_loss(src, tgt, sd, NHEAD, "FFN", eps, T / 65536.0)
+        loss.backward()
+        O.clip_and_sgd([sd[k] for k in names], [sd[k].grad for k in names], bufs, LR, CLIP)
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": round(cols * T / best, 1), "unit": "tokens/s", "cores": ncores, "kind": "port",
+            "sample": "oracle/bayes_oracle.py train step (fwd+CE+KL+bwd+clip+SGD, dropout off), same model, "
+                      "T=%d, %d of %d batch columns, best of %d steps after 1 warm-up" % (T, cols, B_PER_GPU, steps)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    from bayeslms_amd import engine, model as M, ops
+    from bayeslms_amd.data import batchify, get_batch, synthetic_corpus
+
+    Bc = args.batch
+    steps_total = args.warmup + args.steps
+    n_rows = steps_total * T + 1
+    stream = synthetic_corpus(V, Bc * world * n_rows + 17, seed=1111)
+    train = batchify(stream, Bc * world, dev, rank, world)  # (rows, Bc) this rank's columns of the global batch
+    torch.manual_seed(1111)  # identical initial weights on every rank (CPU init, then copy)
+    model = M.BayesTransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, True, "FFN").to(dev)
+    if args.fused_sampling >= 0:
+        model.set_fused_sampling(bool(args.fused_sampling))
+    kl_scale = float(T) / float(train.size(0))  # train.py:342: / len(train_data) * seq_len
+    tr = engine.Trainer(model, lr=LR, clip=CLIP, kl_scale=kl_scale, seed=1111, rank=rank, world=world)
+
+    def kl_fn(mm):
+        return mm.transformerlayers[0].linear2.kl_divergence()
+    kl_fn.fusable = True
+
+    timer = ops.KernelTimer()
+
+    def one(i, timed):
+        data, targets = get_batch(train, i * T, T)
+        ops.set_kernel_timer(timer if timed else None)
+        loss, kl, _ = tr.step(data, targets, kl_fn=kl_fn)
+        return loss
+
+    for i in range(args.warmup):
+        loss = one(i, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, steps_total):
+        loss = one(i, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss)
+
+    if rank == 0:
+        tokens = args.steps * T * Bc * world
+        kt = timer.summary()
+        M_, N_, K_ = T * Bc, D_MODEL, D_FF
+        flops = 2.0 * M_ * N_ * K_  # 2*M*N*K per forward launch
+        roof = None
+        if "sampled_gemm_fwd" in kt:
+            ms = kt["sampled_gemm_fwd"]["avg_ms"]
+            ach = flops / (ms * 1e-3) / 1e12
+            roof = {"kernel": "gemm_f32_kernel (Bayesian FFN linear2 forward, M=%d N=%d K=%d)" % (M_, N_, K_),
+                    "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(ms, 4), "launches": kt["sampled_gemm_fwd"]["n"]}
+        out = {
+            "metric": "train_tokens_per_sec", "value": round(tokens / elapsed, 1), "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: Bayesian Transformer LM (--uncertainty Bayesian "
+                                   "--T_bayes_pos FFN) 6L d_model=512 d_ff=4096 8 heads V=33000 tied, dropout 0.2, "
+                                   "clip 1.0, SGD momentum 0.9; fwd+CE+KL+bwd+all-reduce+clip+SGD",
+                       "global_batch": Bc * world, "seq_len": T, "parallelism": "dp%d" % world,
+                       "fused_sampling": bool(model.noise_state.fused)},
+            "roofline": roof,
+            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kt.items()},
+            "final_loss": round(final_loss, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

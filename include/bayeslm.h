@@ -1,0 +1,271 @@
+/*
+ * bayeslm.h -- C ABI of libbayeslm_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (AmourWaltz/BayesLMs) has no FFI of its own: its hot path is
+ * Python calling ATen/cuDNN ops.  Each entry point below
+ * replaces the device work of one group of those call sites; the citation on
+ * each declaration is the reference line(s) it stands in for
+ * (paths relative to steps/pytorchnn/).
+ *
+ * Contract:
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory
+ *     owned by the caller (PyTorch's caching allocator in the Python host);
+ *   - the library allocates nothing persistent and keeps no references;
+ *   - every call is asynchronous on the hipStream_t passed in (void* here so
+ *     the header needs no HIP include); no internal synchronisation;
+ *   - returns 0 (BLM_OK) or a negative blm_status; blm_last_error() gives a
+ *     thread-local message; nothing throws or aborts;
+ *   - all tensors fp32 row-major unless stated; token ids int64.
+ */
+#ifndef BAYESLM_H
+#define BAYESLM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLM_ABI_VERSION 1u
+
+typedef enum blm_status {
+  BLM_OK = 0,
+  BLM_ERR_INVALID = -1,   /* bad shape / null pointer / misaligned operand   */
+  BLM_ERR_ABI = -2,       /* abi_version mismatch                            */
+  BLM_ERR_HIP = -3,       /* a HIP runtime call failed (message has detail)  */
+  BLM_ERR_UNSUPPORTED = -4
+} blm_status;
+
+/* Philox4x32-10 stream ids: counter = (block_lo, block_hi, stream, step),
+ * key = seed.  Must match oracle/philox.py. */
+#define BLM_STREAM_WEIGHT  0x1000u  /* + tensor id */
+#define BLM_STREAM_DROPOUT 0x2000u  /* + site id   */
+
+typedef struct blm_rng {
+  uint64_t seed;    /* Philox key                                             */
+  uint32_t stream;  /* BLM_STREAM_* + id                                      */
+  uint32_t step;    /* optimisation step: same (seed,stream,step) => same eps */
+} blm_rng;
+
+/* --------------------------------------------------------------------------
+ * Library info
+ * ------------------------------------------------------------------------ */
+uint32_t    blm_abi_version(void);
+const char* blm_last_error(void);
+/* Fills gfx arch name (<= 31 chars), CU count and LDS bytes/CU of device
+ * `device`; used by the host to refuse anything that is not gfx950. */
+int blm_query(int device, char* arch32, int* n_cu, int* lds_bytes);
+
+/* --------------------------------------------------------------------------
+ * Variational weights: W = mu + exp(lgstd) * eps, and the KL term
+ * ------------------------------------------------------------------------ */
+
+/* Describes the variational part of a weight matrix W (rows x cols, leading
+ * dimension ld): rows [row_lo, row_lo + srows) carry noise, lgstd is
+ * (srows x cols) with leading dimension cols.
+ *   BayesLinear: row_lo = 0, srows = rows        (model.py:1083-1107)
+ *   Bayes2LSTM : row_lo = (pos-1)*H, srows = H   (model.py:716-725)
+ * eps != NULL  -> injected noise (srows x cols), used for parity tests;
+ * eps == NULL  -> Philox noise from `rng`, element index = r*cols + c with
+ *                 r relative to row_lo.
+ * lgstd == NULL -> no noise at all (eval mode / mean weights). */
+typedef struct blm_variational {
+  const float* lgstd;
+  const float* eps;
+  int32_t row_lo;
+  int32_t srows;
+  blm_rng rng;
+} blm_variational;
+
+/* Materialise W (rows x cols, contiguous) from mu in one pass and, if
+ * kl_out != NULL, add  kl_weight * mean(mu_s^2 - 2 lgstd + exp(2 lgstd))/2
+ * (mu_s = the noisy rows of mu) to *kl_out.
+ * Replaces model.py:1083-1107 (BayesLinear.sample_weight_diff/_flat_weights),
+ * :668-732 (Bayes2LSTM.sample_weight_diff/flat_parameters), :1243-1249.
+ * Bias vectors: pass rows = len, cols = 1. */
+int blm_sample_weight(const float* mu, int64_t rows, int64_t cols, const blm_variational* v,
+                      float* w_out, float* kl_out, float kl_weight, void* stream);
+
+/* Backward of blm_sample_weight: dmu[r,c] += dW[r,c] for all rows;
+ * dlgstd[r',c] += dW[row_lo+r',c] * eps * exp(lgstd) on the noisy rows (eps
+ * injected or regenerated from the counter).  SURVEY.md Appendix C. */
+int blm_sample_weight_bwd(const float* dw, int64_t rows, int64_t cols, const blm_variational* v,
+                          float* dmu, float* dlgstd, void* stream);
+
+/* Write the N(0,1) stream itself (n floats): test/debug visibility of the
+ * generator the fused paths use. */
+int blm_philox_normal(float* out, int64_t n, const blm_rng* rng, void* stream);
+
+/* *out += weight * mean(mu^2 - 2 lg + exp(2 lg) [- 1]) / 2 over an
+ * (rows x cols) window; mu has leading dimension ld_mu, lg is contiguous.
+ * Replaces model.py:1109-1125, :734-765, :1251-1256, :1816-1826. */
+int blm_kl_mean_fwd(const float* mu, int64_t ld_mu, const float* lgstd, int64_t rows, int64_t cols,
+                    int minus_one, float weight, float* out, void* stream);
+/* dmu += g * mu / n ; dlg += g * (exp(2 lg) - 1) / n   (n = rows*cols; g is
+ * the upstream scalar gradient times the same weight, read from device).
+ * SURVEY.md Appendix C. */
+int blm_kl_mean_bwd(const float* mu, int64_t ld_mu, const float* lgstd, int64_t rows, int64_t cols,
+                    const float* g_dev, float weight, float* dmu, int64_t ld_dmu, float* dlgstd, void* stream);
+
+/* --------------------------------------------------------------------------
+ * fp32 MFMA GEMM family (v_mfma_f32_32x32x2_f32, LDS tiled)
+ * ------------------------------------------------------------------------ */
+typedef enum blm_gemm_op {
+  BLM_GEMM_NT = 0, /* C[M,N] = A[M,K] * B[N,K]^T   forward  F.linear      */
+  BLM_GEMM_NN = 1, /* C[M,N] = A[M,K] * B[K,N]     dgrad    dX = dY W     */
+  BLM_GEMM_TN = 2  /* C[M,N] = A[K,M]^T * B[K,N]   wgrad    dW = dY^T X   */
+} blm_gemm_op;
+
+typedef enum blm_epilogue {
+  BLM_EPI_NONE = 0,
+  BLM_EPI_BIAS = 1,        /* C = acc + bias[n]                                        */
+  BLM_EPI_BIAS_GELU = 2,   /* z = acc + bias[n]; aux[m,n] = z (if aux); C = gelu_erf(z) */
+  BLM_EPI_MUL_DGELU = 3,   /* C = acc * gelu_erf'(aux[m,n])                            */
+  BLM_EPI_BAYES_WGRAD = 4, /* TN only, C = dmu, C2 = dlgstd, see below                 */
+  BLM_EPI_GP_MIX = 5,      /* z = acc + bias; aux = z; C = sum_i act_i(z) coef[i,n]     */
+  BLM_EPI_MUL_DGP_MIX = 6  /* C = acc * sum_i act_i'(aux) coef[i,n]                     */
+} blm_epilogue;
+
+#define BLM_GEMM_ACCUMULATE 1u /* C (+= C2) accumulate into existing contents */
+
+typedef struct blm_gemm_args {
+  uint32_t abi_version; /* BLM_ABI_VERSION */
+  int32_t op;           /* blm_gemm_op */
+  int32_t M, N, K;
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  float* C;       int64_t ldc;
+  float alpha;          /* C = alpha * acc (+ epilogue)                        */
+  uint32_t flags;       /* BLM_GEMM_ACCUMULATE                                 */
+  int32_t epilogue;     /* blm_epilogue */
+  const float* bias;    /* [N]                                                 */
+  float* aux;           /* [M,N] ld = ldc: pre-activation (written or read)    */
+  const float* coef;    /* GP mixture coefficients [4,N]: tanh,sigmoid,relu,gelu */
+  /* Variational B operand (NT, NN): B is the *mean* matrix mu and the tile
+   * loader forms W = mu + exp(lgstd)*eps on the fly (fused sampling, no W in
+   * HBM).  var_b.lgstd == NULL -> B used as is.
+   * model.py:1127-1129 fwd; autograd dX of the same. */
+  blm_variational var_b;
+  /* BLM_EPI_BAYES_WGRAD (TN; C has the shape of W):
+   *   dW  = alpha*acc
+   *   C [n,k] (+)= dW + kl_lambda * mu/n_kl      (KL part on noisy rows only)
+   *   C2[r,k] (+)= dW*eps*exp(lgstd) + kl_lambda*(exp(2 lgstd)-1)/n_kl
+   *               for rows r = n - row_lo in [0, srows)
+   * with mu = wg_mu (ld = ldc), var_c describing lgstd/eps/rng, and
+   * 1/n_kl = kl_inv_n (the element count of the mean the KL term belongs to:
+   * srows*N for BayesLinear, H*(H+E) for a Bayes2LSTM matrix, model.py:737-740).
+   * The KL part only touches the noisy rows of mu.
+   * (autograd of model.py:1083-1107 + :1109-1125). */
+  float* C2;
+  const float* wg_mu;
+  blm_variational var_c;
+  float kl_lambda;
+  float kl_inv_n;
+  /* Dropout fused into the activation epilogues (drop_p > 0): C is seen as a
+   * (rows, drop_B, N) activation, m = row*drop_B + b, mask keyed by the global
+   * element (row, drop_col_offset + b, n) of a tensor with drop_global_cols
+   * columns.  BIAS_GELU / GP_MIX: C = act(z) * keep/(1-p);  MUL_DGELU /
+   * MUL_DGP_MIX: C = acc * keep/(1-p) * act'(aux).  (model.py:1043 dropout) */
+  float drop_p;
+  blm_rng drop_rng;
+  int32_t drop_B, drop_col_offset, drop_global_cols;
+} blm_gemm_args;
+
+int blm_gemm(const blm_gemm_args* a, void* stream);
+
+/* --------------------------------------------------------------------------
+ * Surrounding Transformer / LSTM ops (HBM-bound unless stated)
+ * ------------------------------------------------------------------------ */
+
+/* out[t,b,:] = drop(enc[ids[t,b],:] * scale + pe[t,:])   (model.py:1284,116-117)
+ * pe may be NULL (LSTM: plain lookup + dropout, model.py:218).  Dropout keep
+ * mask is keyed by the GLOBAL element (t, col_offset + b, j) of a tensor with
+ * global_cols columns so that a W-rank run equals a 1-rank run.
+ * p == 0 -> no dropout. */
+int blm_embed_fwd(const int64_t* ids, const float* enc, const float* pe, float* out, int T, int B, int D,
+                  int64_t vocab, float scale, float p, const blm_rng* rng, int col_offset, int global_cols,
+                  void* stream);
+/* denc[ids[t,b],:] += scale * keep * dy[t,b,:]  (float atomics). */
+int blm_embed_bwd(const int64_t* ids, const float* dy, float* denc, int T, int B, int D, int64_t vocab, float scale,
+                  float p, const blm_rng* rng, int col_offset, int global_cols, void* stream);
+
+/* out[t,b,:] = drop(x[t,b,:] + pe[t,:])   (PositionalEncoding.forward, model.py:116-117);
+ * backward is blm_dropout with the same key. */
+int blm_add_pe_dropout(const float* x, const float* pe, float* out, int T, int B, int D, float p, const blm_rng* rng,
+                       int col_offset, int global_cols, void* stream);
+
+/* y = x * keep / (1-p)  (nn.Dropout; same call for backward with x = dy).
+ * x is (rows, B, D) with the same global-column keying as above. */
+int blm_dropout(const float* x, float* y, int rows, int B, int D, float p, const blm_rng* rng, int col_offset,
+                int global_cols, void* stream);
+
+/* Post-LN residual block tail (model.py:1041-1042,1044-1045):
+ *   s = x + drop(y);  out = LayerNorm(s) * gamma + beta
+ * Saves s_out (optional), mean, rstd per row for backward.  D <= 8192. */
+int blm_add_dropout_ln_fwd(const float* x, const float* y, const float* gamma, const float* beta, float* out,
+                           float* s_out, float* mean, float* rstd, int rows, int B, int D, float eps_ln, float p,
+                           const blm_rng* rng, int col_offset, int global_cols, void* stream);
+/* Given dout: ds = LN backward wrt s; dx = ds; dy = ds*keep/(1-p);
+ * dgamma/dbeta accumulated (+=) via per-block partials in ws
+ * (ws >= 2*ceil(M/32)*D floats... see blm_ln_bwd_ws_floats). */
+int64_t blm_ln_bwd_ws_floats(int M, int D);
+int blm_add_dropout_ln_bwd(const float* dout, const float* s, const float* gamma, const float* mean, const float* rstd,
+                           float* dx, float* dy, float* dgamma, float* dbeta, float* ws, int rows, int B, int D,
+                           float p, const blm_rng* rng, int col_offset, int global_cols, void* stream);
+
+/* Fused causal self-attention for qkv packed (T, B, 3*d) [q|k|v], head index
+ * = b*nhead + head, head_dim = d/nhead (model.py:876-920).  Scaling
+ * head_dim^-0.5, additive causal mask, softmax, dropout p on the
+ * probabilities, P.V.  Saves lse (B*nhead, T) for backward.  T <= 128,
+ * head_dim <= 64 in this round.  q/k/v may also be three separate (T,B,d)
+ * tensors (BayesMultiheadAttention, model.py:975-977): pass ld_qkv = d. */
+int blm_attn_fwd(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, float* lse, int T, int B,
+                 int nhead, int head_dim, float p, const blm_rng* rng, int col_offset, int global_cols, void* stream);
+int blm_attn_bwd(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out, const float* dout,
+                 const float* lse, float* dq, float* dk, float* dv, int64_t ld_dqkv, int T, int B, int nhead,
+                 int head_dim, float p, const blm_rng* rng, int col_offset, int global_cols, void* stream);
+
+/* Cross entropy over materialised logits (M, V) (train.py:233,332;
+ * compute_sentence_scores_bayes_jianwei.py:168):
+ *   nll[m] = logsumexp(logits[m,:]) - logits[m,tgt[m]]
+ * lse (optional) receives logsumexp per row.  If dlogits != NULL also writes (in place allowed) the gradient of
+ * mean-NLL: (softmax - onehot) * grad_scale.  loss_sum (+=) sum of nll. */
+int blm_ce_fwd_bwd(const float* logits, int64_t ld, const int64_t* tgt, float* nll, float* lse, float* loss_sum,
+                   float* dlogits, float grad_scale, int M, int V, void* stream);
+/* Deferred gradient: dlogits = (exp(logits - lse[m]) - onehot) * g_dev[0] * scale
+ * (in place allowed), for callers that do not know the upstream gradient at
+ * forward time. */
+int blm_ce_bwd(const float* logits, int64_t ld, const int64_t* tgt, const float* lse, const float* g_dev, float scale,
+               float* dlogits, int M, int V, void* stream);
+
+/* out[n] (+)= sum_m x[m,n]   (bias gradients). */
+int blm_colsum(const float* x, int64_t ld, float* out, int M, int N, int accumulate, void* stream);
+
+/* Global-norm clip + SGD momentum over a list of tensors (train.py:419-420,466):
+ *   norm = sqrt(sum_i |g_i|^2); c = min(1, clip/(norm+1e-6));
+ *   buf = first ? c*g : mom*buf + c*g;  p -= lr*buf
+ * Two calls: blm_sqnorm_multi accumulates the squared norm into *sq (must be
+ * zeroed by the caller), blm_clip_sgd_multi consumes it.  Pointer tables are
+ * DEVICE arrays of n pointers/sizes. */
+int blm_sqnorm_multi(const float* const* grads, const int64_t* sizes, int n, float* sq, void* stream);
+int blm_clip_sgd_multi(float* const* params, const float* const* grads, float* const* bufs, const int64_t* sizes,
+                       int n, const float* sq, float clip, float lr, float momentum, int first, float grad_scale,
+                       void* stream);
+
+/* LSTM cell pointwise part (what _VF.lstm fuses, model.py:812): gates =
+ * xw[b,4H] + hw[b,4H] (biases already inside xw), order i,f,g,o.
+ *   c' = sig(f) c + sig(i) tanh(g);  h' = sig(o) tanh(c')
+ * Saves activated gates (B,4H) for backward. */
+int blm_lstm_cell_fwd(const float* xw, const float* hw, const float* c_prev, float* h, float* c, float* gates_act,
+                      int B, int H, void* stream);
+/* In: dh (sum of grad from above and from next step), dc_next; out: dgates (B,4H), dc_prev. */
+int blm_lstm_cell_bwd(const float* dh, const float* dc_next, const float* c_prev, const float* c, const float* gates_act,
+                      float* dgates, float* dc_prev, int B, int H, void* stream);
+
+/* y (+)= a*x elementwise helpers used by the host glue. */
+int blm_axpy(const float* x, float* y, int64_t n, float a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAYESLM_H */

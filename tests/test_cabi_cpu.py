@@ -1,0 +1,100 @@
+"""CPU: the C-ABI library loads and exports exactly what include/bayeslm.h declares (no compute)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "bayeslm.h")
+LIB = os.path.join(ROOT, "bayeslms_amd", "libbayeslm_hip.so")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(blm_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    return LIB
+
+
+def test_header_declares_the_hot_path_entry_points():
+    names = declared_functions()
+    for must in ("blm_gemm", "blm_sample_weight", "blm_kl_mean_fwd", "blm_attn_fwd", "blm_ce_fwd_bwd",
+                 "blm_clip_sgd_multi", "blm_lstm_cell_fwd", "blm_last_error", "blm_abi_version"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", built_lib], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [n for n in declared_functions() if n not in exported]
+    assert not missing, missing
+    # and nothing is exported under the blm_ prefix that the header does not declare
+    extra = sorted(n for n in exported if n.startswith("blm_") and n not in declared_functions())
+    assert extra == ["blm_fail"] or not extra, extra
+
+
+def test_ctypes_binding_covers_the_header_and_loads(built_lib):
+    from bayeslms_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+    lib = _lib.lib()
+    assert lib.blm_abi_version() == _lib.ABI_VERSION
+    # argument validation happens before any HIP call, so it is observable without a GPU
+    assert lib.blm_gemm(None, None) == -1
+    assert b"null args" in lib.blm_last_error()
+    a = _lib.GemmArgs()
+    a.abi_version = _lib.ABI_VERSION + 1
+    assert lib.blm_gemm(ctypes.byref(a), None) == -2
+
+
+def test_struct_layout_matches_the_c_compiler(built_lib, tmp_path):
+    """sizeof/offsetof of blm_gemm_args as gcc sees the header == the ctypes mirror."""
+    from bayeslms_amd import _lib
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bayeslm.h"\n'
+                   'int main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(blm_gemm_args), offsetof(blm_gemm_args, var_b),'
+                   ' offsetof(blm_gemm_args, C2), offsetof(blm_gemm_args, kl_lambda), offsetof(blm_gemm_args, drop_rng));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    G = _lib.GemmArgs
+    assert got == [ctypes.sizeof(G), G.var_b.offset, G.C2.offset, G.kl_lambda.offset, G.drop_rng.offset]
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    from bayeslms_amd import ops, BayesLMError
+    with pytest.raises(BayesLMError):
+        ops.linear(torch.zeros(2, 3), torch.zeros(4, 3))
+    # nothing under bayeslms_amd/ imports the oracle
+    pkg = os.path.join(ROOT, "bayeslms_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            assert "oracle" not in open(os.path.join(pkg, fn)).read(), fn
+
+
+def test_c_philox_oracle_agrees_with_numpy_oracle():
+    import numpy as np
+    from oracle import philox as P
+    so = os.path.join(ROOT, "oracle", "_ref", "libphilox_ref.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(so)
+    n = 257
+    out = (ctypes.c_uint32 * (4 * n))()
+    lib.blm_oracle_philox_words(ctypes.c_uint64(2 ** 40 + 1111), ctypes.c_uint32(0x1003), ctypes.c_uint32(77),
+                                ctypes.c_uint64(n), out)
+    blk = np.arange(n, dtype=np.uint64)
+    r = P.philox4x32_10((blk & P.MASK).astype(np.uint32), (blk >> np.uint64(32)).astype(np.uint32),
+                        np.full(n, 0x1003, np.uint32), np.full(n, 77, np.uint32), (2 ** 40 + 1111) & 0xFFFFFFFF,
+                        (2 ** 40 + 1111) >> 32)
+    np.testing.assert_array_equal(np.stack(r, 1).reshape(-1), np.frombuffer(out, dtype=np.uint32))

@@ -1,0 +1,415 @@
+"""GPU parity of the individual C-ABI operators against fp32 CPU math (torch CPU / the oracle).
+
+Floating point: tolerance 1e-3 relative is BASELINE.json's bar; the GEMMs are checked far tighter
+(the f32 MFMA is an exact fp32 fma chain, only the summation order differs from the CPU BLAS)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bayes_oracle as O  # noqa: E402
+from oracle import philox as P  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def ops_mod():
+    from bayeslms_amd import ops
+    return ops
+
+
+def L():
+    from bayeslms_amd import _lib
+    return _lib
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+# ------------------------------------------------------------------ library / device
+def test_library_is_native_and_gfx950(dev):
+    lib = L()
+    lib.require_gfx950()
+    assert lib.lib().blm_abi_version() == lib.ABI_VERSION
+
+
+def test_errors_are_reported_not_swallowed(dev):
+    import ctypes as C
+    lib = L()
+    a = lib.GemmArgs()
+    a.abi_version = 99
+    assert lib.lib().blm_gemm(C.byref(a), None) == -2
+    assert b"abi_version" in lib.lib().blm_last_error()
+    with pytest.raises(lib.BayesLMError):
+        ops_mod().linear(torch.zeros(2, 3), torch.zeros(4, 3))  # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------ GEMM family
+GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (64, 64, 32), (65, 130, 33), (128, 128, 64), (200, 50, 16), (37, 300, 129),
+               (256, 512, 96), (10, 33000 // 50, 512), (8, 4096, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_nt_nn_tn(dev, M, N, K):
+    ops = ops_mod()
+    lib = L()
+    g = torch.Generator().manual_seed(M * 131 + N * 17 + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(N, K, generator=g)
+    Ad, Bd = A.to(dev), Bm.to(dev)
+    C1 = torch.empty(M, N, device=dev)
+    ops.gemm(lib.GEMM_NT, Ad, Bd, C1, M, N, K, K, K, N)
+    assert rel(C1, A.double() @ Bm.double().t()) < 2e-6
+    # NN: C[M,K'] = D[M,N] * Bm[N,K]
+    D = torch.randn(M, N, generator=g)
+    C2 = torch.empty(M, K, device=dev)
+    ops.gemm(lib.GEMM_NN, D.to(dev), Bd, C2, M, K, N, N, K, K)
+    assert rel(C2, D.double() @ Bm.double()) < 2e-6
+    # TN: C[N,K] = D[M,N]^T * A[M,K]
+    C3 = torch.empty(N, K, device=dev)
+    ops.gemm(lib.GEMM_TN, D.to(dev), Ad, C3, N, K, M, N, K, K)
+    assert rel(C3, D.double().t() @ A.double()) < 2e-6
+    # accumulate + alpha
+    ops.gemm(lib.GEMM_TN, D.to(dev), Ad, C3, N, K, M, N, K, K, alpha=0.5, accumulate=True)
+    assert rel(C3, 1.5 * (D.double().t() @ A.double())) < 2e-6
+
+
+def test_gemm_identity_asymmetric(dev):
+    """A = I with an asymmetric B catches a transposed C write (cdna guide section 3)."""
+    ops, lib = ops_mod(), L()
+    n = 96
+    Bm = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 7.0
+    out = torch.empty(n, n, device=dev)
+    ops.gemm(lib.GEMM_NN, torch.eye(n, device=dev), Bm.to(dev), out, n, n, n, n, n, n)
+    assert torch.equal(out.cpu(), Bm)
+    ops.gemm(lib.GEMM_NT, torch.eye(n, device=dev), Bm.to(dev), out, n, n, n, n, n, n)
+    assert torch.equal(out.cpu(), Bm.t())
+
+
+def test_gemm_epilogues(dev):
+    ops, lib = ops_mod(), L()
+    M, N, K = 70, 90, 40
+    g = torch.Generator().manual_seed(3)
+    A, Bm, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    z_ref = A @ Bm.t() + bias
+    out, aux = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    ops.gemm(lib.GEMM_NT, A.to(dev), Bm.to(dev), out, M, N, K, K, K, N, epilogue=lib.EPI_BIAS, bias=bias.to(dev))
+    assert rel(out, z_ref) < 2e-6
+    ops.gemm(lib.GEMM_NT, A.to(dev), Bm.to(dev), out, M, N, K, K, K, N, epilogue=lib.EPI_BIAS_GELU, bias=bias.to(dev), aux=aux)
+    assert rel(aux, z_ref) < 2e-6
+    assert rel(out, torch.nn.functional.gelu(z_ref)) < 5e-6
+    # dgelu: C = (A B^T) * gelu'(aux)
+    zz = z_ref.clone().requires_grad_(True)
+    torch.nn.functional.gelu(zz).sum().backward()
+    ops.gemm(lib.GEMM_NT, A.to(dev), Bm.to(dev), out, M, N, K, K, K, N, epilogue=lib.EPI_MUL_DGELU, aux=aux)
+    assert rel(out, (A @ Bm.t()) * zz.grad) < 1e-5
+    # GP mixture (tanh, sigmoid, relu, gelu) and its derivative
+    coef = torch.rand(4, N, generator=g)
+    ops.gemm(lib.GEMM_NT, A.to(dev), Bm.to(dev), out, M, N, K, K, K, N, epilogue=lib.EPI_GP_MIX, bias=bias.to(dev), aux=aux,
+             coef=coef.to(dev))
+    assert rel(out, O.gp_mixture(z_ref, coef, ["tanh", "sigmoid", "relu", "gelu"])) < 1e-5
+    zz = z_ref.clone().requires_grad_(True)
+    O.gp_mixture(zz, coef, ["tanh", "sigmoid", "relu", "gelu"]).sum().backward()
+    ops.gemm(lib.GEMM_NT, A.to(dev), Bm.to(dev), out, M, N, K, K, K, N, epilogue=lib.EPI_MUL_DGP_MIX, aux=aux, coef=coef.to(dev))
+    assert rel(out, (A @ Bm.t()) * zz.grad) < 2e-5
+
+
+# ------------------------------------------------------------------ Philox / sampling / KL
+def test_philox_stream_matches_numpy_oracle(dev):
+    ops = ops_mod()
+    for n, seed, stream, step in ((1, 1, 0x1000, 0), (1003, 1111, 0x1005, 7), (1 << 16, 2 ** 40 + 5, 0x1fff, 123456)):
+        z = ops.philox_normal(n, seed, stream, step).cpu().numpy()
+        ref = P.normal(n, seed, stream, step)
+        # integer Philox is bit exact; Box-Muller differs by the transcendental approximations
+        np.testing.assert_allclose(z, ref, rtol=0, atol=3e-5)
+
+
+def test_sample_weight_injected_and_philox(dev):
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(5)
+    for rows, cols, lo, srows in ((8, 12, 0, 8), (16, 12, 4, 4), (12, 1, 3, 3), (7, 5, 0, 7), (512, 4096, 0, 512)):
+        mu = torch.randn(rows, cols, generator=g).squeeze(-1) if cols == 1 else torch.randn(rows, cols, generator=g)
+        lg = (torch.rand(srows, cols, generator=g) - 2.0)
+        lg = lg.squeeze(-1) if cols == 1 else lg
+        eps = torch.randn_like(lg)
+        kl = torch.zeros((), device=dev)
+        W = ops.sample_weight(mu.to(dev), lg.to(dev), ops.NoiseSpec(eps=eps.to(dev)), lo, srows, kl_out=kl, kl_weight=2.0)
+        ref = mu.clone()
+        ref[lo:lo + srows] += torch.exp(lg) * eps
+        assert rel(W, ref) < 1e-6
+        assert abs(float(kl) - 2.0 * float(O.kl_mean_form(mu[lo:lo + srows], lg))) < 1e-4 * abs(float(kl)) + 1e-6
+        # Philox mode equals the numpy stream
+        W2 = ops.sample_weight(mu.to(dev), lg.to(dev), ops.NoiseSpec(None, 77, 3, 9), lo, srows)
+        z = torch.from_numpy(P.normal(srows * cols, 77, P.STREAM_WEIGHT + 3, 9)).view_as(lg)
+        ref2 = mu.clone()
+        ref2[lo:lo + srows] += torch.exp(lg) * z
+        assert float((W2.cpu() - ref2).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_bayes_linear_golden(dev, fused):
+    """BayesLinear fwd/bwd/KL against the reference's own numbers (tests/golden/bayes_linear.npz)."""
+    from conftest import load_golden
+    ops = ops_mod()
+    g, _, _ = load_golden("bayes_linear")
+    x = g["x"].to(dev).requires_grad_(True)
+    mu = torch.nn.Parameter(g["mu"].to(dev))
+    lg = torch.nn.Parameter(g["lgstd"].to(dev))
+    lam = float(g["kl_scale"])
+    noise = ops.NoiseSpec(eps=g["eps"].to(dev))
+    y = ops.bayes_linear(x, mu, lg, noise, kl_lambda=0.0, fused=fused)
+    kl = ops.kl_mean(mu, lg)
+    assert rel(y, g["y_train"]) < 1e-5
+    assert abs(float(kl) - float(g["kl"])) < 1e-5 * abs(float(g["kl"]))
+    ((y * g["g"].to(dev)).sum() + kl * lam).backward()
+    assert rel(x.grad, g["dx"]) < 1e-5
+    assert rel(mu.grad, g["dmu"]) < 1e-5
+    assert rel(lg.grad, g["dlgstd"]) < 1e-5
+    # fused KL gradient in the wgrad epilogue gives the same totals without backprop through kl
+    mu.grad = None
+    lg.grad = None
+    x2 = g["x"].to(dev).requires_grad_(True)
+    y2 = ops.bayes_linear(x2, mu, lg, noise, kl_lambda=lam, fused=fused)
+    (y2 * g["g"].to(dev)).sum().backward()
+    assert rel(mu.grad, g["dmu"]) < 1e-5
+    assert rel(lg.grad, g["dlgstd"]) < 1e-5
+    # eval mode = mean weights
+    assert rel(ops.bayes_linear(x, mu, lg, None), g["y_eval"]) < 1e-5
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_bayes_linear_philox_fwd_bwd_consistent(dev, fused):
+    """Philox mode: forward, dgrad and the wgrad epilogue all regenerate the SAME eps from the counter."""
+    ops = ops_mod()
+    N, K, M = 64, 128, 96
+    g = torch.Generator().manual_seed(8)
+    mu = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.1).to(dev))
+    lg = torch.nn.Parameter((torch.rand(N, K, generator=g) - 3.0).to(dev))
+    x = torch.randn(M, K, generator=g).to(dev).requires_grad_(True)
+    gy = torch.randn(M, N, generator=g).to(dev)
+    noise = ops.NoiseSpec(None, 1111, 5, 42)
+    y = ops.bayes_linear(x, mu, lg, noise, 0.0, fused)
+    (y * gy).sum().backward()
+    eps = torch.from_numpy(P.normal(N * K, 1111, P.STREAM_WEIGHT + 5, 42)).view(N, K)
+    mu_c, lg_c, x_c = mu.detach().cpu().requires_grad_(True), lg.detach().cpu().requires_grad_(True), x.detach().cpu().requires_grad_(True)
+    yr = O.bayes_linear(x_c, mu_c, lg_c, eps)
+    (yr * gy.cpu()).sum().backward()
+    assert rel(y, yr) < 2e-4
+    assert rel(x.grad, x_c.grad) < 2e-4
+    assert rel(mu.grad, mu_c.grad) < 2e-4
+    assert rel(lg.grad, lg_c.grad) < 5e-4
+
+
+def test_kl_mean_window_and_minus_one(dev):
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(2)
+    mu = torch.nn.Parameter(torch.randn(16, 6, generator=g).to(dev))
+    lg = torch.nn.Parameter((torch.rand(4, 6, generator=g) - 1).to(dev))
+    kl = ops.kl_mean(mu, lg, row_lo=8, minus_one=True)
+    mu_c, lg_c = mu.detach().cpu().requires_grad_(True), lg.detach().cpu().requires_grad_(True)
+    ref = O.kl_mean_form_minus1(mu_c[8:12], lg_c)
+    assert abs(float(kl) - float(ref)) < 1e-5
+    (kl * 3.0).backward()
+    (ref * 3.0).backward()
+    assert rel(mu.grad, mu_c.grad) < 1e-5 and rel(lg.grad, lg_c.grad) < 1e-5
+
+
+# ------------------------------------------------------------------ surrounding ops
+def test_embed_pe_dropout0(dev):
+    ops = ops_mod()
+    V, D, T, B = 50, 24, 7, 3
+    g = torch.Generator().manual_seed(4)
+    W = torch.nn.Parameter(torch.randn(V, D, generator=g).to(dev))
+    pe = O.positional_table(64, D).view(64, D)
+    ids = torch.randint(0, V, (T, B), generator=g)
+    out = ops.embed(ids.to(dev), W, pe.to(dev), 3.0)
+    ref_w = W.detach().cpu().requires_grad_(True)
+    ref = torch.nn.functional.embedding(ids, ref_w) * 3.0 + pe[:T].unsqueeze(1)
+    assert rel(out, ref) < 1e-6
+    gy = torch.randn(T, B, D, generator=g)
+    out.backward(gy.to(dev))
+    ref.backward(gy)
+    assert rel(W.grad, ref_w.grad) < 1e-5
+
+
+def test_dropout_mask_is_the_philox_mask_and_column_sharding(dev):
+    ops = ops_mod()
+    T, B, D, p = 5, 8, 16, 0.3
+    x = torch.ones(T, B, D, device=dev)
+    d = ops.Drop(p, 99, 4, 7, 0, B)
+    y = ops.dropout(x, d).cpu()
+    keep = torch.from_numpy(P.keep_mask(T * B * D, p, 99, P.STREAM_DROPOUT + 4, 7)).view(T, B, D)
+    assert torch.equal(y != 0, keep)
+    assert rel(y[keep], torch.full_like(y[keep], 1 / (1 - p))) < 1e-6
+    # rank 1 of 2 (columns 4..7) sees exactly its slice of the global mask
+    y1 = ops.dropout(x[:, 4:].contiguous(), ops.Drop(p, 99, 4, 7, 4, B)).cpu()
+    assert torch.equal(y1, y[:, 4:])
+
+
+@pytest.mark.parametrize("D", [16, 512, 1024])
+def test_add_dropout_ln(dev, D):
+    ops = ops_mod()
+    T, B = 6, 5
+    g = torch.Generator().manual_seed(D)
+    x, y = torch.randn(T, B, D, generator=g), torch.randn(T, B, D, generator=g)
+    gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    gd, bd = torch.nn.Parameter(gamma.to(dev)), torch.nn.Parameter(beta.to(dev))
+    xd, yd = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    out = ops.add_dropout_ln(xd, yd, gd, bd, 1e-5)
+    xr, yr, gr, br = (t.clone().requires_grad_(True) for t in (x, y, gamma, beta))
+    ref = torch.nn.functional.layer_norm(xr + yr, (D,), gr, br, 1e-5)
+    assert rel(out, ref) < 1e-5
+    go = torch.randn(T, B, D, generator=g)
+    out.backward(go.to(dev))
+    ref.backward(go)
+    assert rel(xd.grad, xr.grad) < 2e-5 and rel(yd.grad, yr.grad) < 2e-5
+    assert rel(gd.grad, gr.grad) < 2e-5 and rel(bd.grad, br.grad) < 2e-5
+    # with dropout: s = x + keep*y/(1-p), the mask being the Philox mask
+    p = 0.25
+    drop = ops.Drop(p, 5, 1, 2, 0, B)
+    out2 = ops.add_dropout_ln(x.to(dev), y.to(dev), gd, bd, 1e-5, drop)
+    keep = torch.from_numpy(P.keep_mask(T * B * D, p, 5, P.STREAM_DROPOUT + 1, 2)).view(T, B, D).float() / (1 - p)
+    assert rel(out2, torch.nn.functional.layer_norm(x + y * keep, (D,), gamma, beta, 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("T,B,nhead,hd", [(6, 3, 4, 4), (100, 2, 2, 32), (128, 3, 2, 64), (33, 2, 1, 16)])
+def test_attention_matches_oracle(dev, T, B, nhead, hd):
+    ops = ops_mod()
+    d = nhead * hd
+    g = torch.Generator().manual_seed(T + hd)
+    qkv = torch.randn(T, B, 3 * d, generator=g)
+    qd = qkv.to(dev).requires_grad_(True)
+    out = ops.attention(qd, nhead)
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = qr.chunk(3, dim=-1)
+    ref = O.attention_core(q, k, v, nhead, O.causal_mask(T))
+    assert rel(out, ref) < 1e-5
+    go = torch.randn(T, B, d, generator=g)
+    out.backward(go.to(dev))
+    ref.backward(go)
+    assert rel(qd.grad, qr.grad) < 2e-5
+    # separate q/k/v entry point
+    q3 = [t.contiguous().to(dev).requires_grad_(True) for t in qkv.chunk(3, dim=-1)]
+    out3 = ops.attention_qkv(q3[0], q3[1], q3[2], nhead)
+    assert rel(out3, ref) < 1e-5
+    out3.backward(go.to(dev))
+    assert rel(torch.cat([t.grad for t in q3], -1), qr.grad) < 2e-5
+
+
+def test_attention_dropout_uses_philox_mask(dev):
+    ops = ops_mod()
+    T, B, nhead, hd, p = 8, 2, 2, 4, 0.4
+    d = nhead * hd
+    g = torch.Generator().manual_seed(1)
+    qkv = torch.randn(T, B, 3 * d, generator=g)
+    drop = ops.Drop(p, 321, 9, 3, 0, B)
+    qd = qkv.to(dev).requires_grad_(True)
+    out = ops.attention(qd, nhead, drop)
+    keep = torch.from_numpy(P.keep_mask(B * nhead * T * T, p, 321, P.STREAM_DROPOUT + 9, 3)).view(B * nhead, T, T).float() / (1 - p)
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = qr.chunk(3, dim=-1)
+    qh = (q * hd ** -0.5).contiguous().view(T, B * nhead, hd).transpose(0, 1)
+    kh = k.contiguous().view(T, B * nhead, hd).transpose(0, 1)
+    vh = v.contiguous().view(T, B * nhead, hd).transpose(0, 1)
+    pr = torch.softmax(torch.bmm(qh, kh.transpose(1, 2)) + O.causal_mask(T), -1) * keep
+    ref = torch.bmm(pr, vh).transpose(0, 1).contiguous().view(T, B, d)
+    assert rel(out, ref) < 1e-5
+    go = torch.randn(T, B, d, generator=g)
+    out.backward(go.to(dev))
+    ref.backward(go)
+    assert rel(qd.grad, qr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("M,V", [(5, 7), (18, 50), (64, 33000), (3, 1001)])
+def test_cross_entropy(dev, M, V):
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(V)
+    logits = torch.randn(M, V, generator=g) * 3
+    tgt = torch.randint(0, V, (M,), generator=g)
+    lr = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, tgt)
+    (ref * 1.7).backward()
+    for unit in (False, True):
+        ld = logits.to(dev).requires_grad_(True)
+        loss, nll = ops.cross_entropy(ld * 1.0, tgt.to(dev), unit_grad=unit)
+        assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+        assert rel(nll, O.token_nll(logits, tgt)) < 1e-5
+        (loss * (1.0 if unit else 1.7)).backward()
+        assert rel(ld.grad, lr.grad / (1.7 if unit else 1.0)) < 1e-5
+    with torch.no_grad():
+        loss, _ = ops.cross_entropy(logits.to(dev), tgt.to(dev))
+        assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+
+
+def test_colsum_and_clip_sgd(dev):
+    ops, lib = ops_mod(), L()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(300, 70, generator=g)
+    out = torch.zeros(70, device=dev)
+    lib.check(lib.lib().blm_colsum(x.to(dev).data_ptr(), 70, out.data_ptr(), 300, 70, 0, lib.stream()))
+    assert rel(out, x.sum(0)) < 1e-5
+    # clip + SGD momentum, two steps, vs the oracle restatement of train.py:419-420
+    ps = [torch.randn(n, generator=g) for n in (1000, 37, 4096)]
+    gs = [torch.randn(n, generator=g) * 3 for n in (1000, 37, 4096)]
+    pd, gd = [p.to(dev) for p in ps], [x.to(dev) for x in gs]
+    md = [torch.zeros_like(p) for p in pd]
+    table = ops.PtrTable(pd, gd, md)
+    pr = [torch.nn.Parameter(p.clone()) for p in ps]
+    bufs = [None] * 3
+    for step in range(2):
+        sq = ops.clip_sgd(table, 0.25, 0.1, 0.9, step == 0)
+        total = O.clip_and_sgd(pr, gs, bufs, 0.1, 0.25)
+        assert abs(float(sq.sqrt()) - float(total)) < 1e-4 * float(total)
+        for a, b in zip(pd, pr):
+            assert rel(a, b.data) < 1e-5
+
+
+def test_lstm_layer_matches_oracle(dev):
+    ops = ops_mod()
+    T, B, E, H = 7, 5, 24, 16
+    g = torch.Generator().manual_seed(11)
+    mk = lambda *s: torch.randn(*s, generator=g) * 0.3  # noqa: E731
+    x, h0, c0 = mk(T, B, E), mk(B, H), mk(B, H)
+    w_ih, w_hh, b_ih, b_hh = mk(4 * H, E), mk(4 * H, H), mk(4 * H), mk(4 * H)
+    dl = [t.to(dev).requires_grad_(True) for t in (x, h0, c0, w_ih, w_hh, b_ih, b_hh)]
+    y, hT, cT = ops.lstm_layer(*dl)
+    cl = [t.clone().requires_grad_(True) for t in (x, h0, c0, w_ih, w_hh, b_ih, b_hh)]
+    yr, hr, cr = O.lstm_layer(*cl)
+    assert rel(y, yr) < 1e-5 and rel(hT, hr) < 1e-5 and rel(cT, cr) < 1e-5
+    gy, gh, gc = mk(T, B, H), mk(B, H), mk(B, H)
+    ((y * gy.to(dev)).sum() + (hT * gh.to(dev)).sum() + (cT * gc.to(dev)).sum()).backward()
+    ((yr * gy).sum() + (hr * gh).sum() + (cr * gc).sum()).backward()
+    for a, b, name in zip(dl, cl, "x h0 c0 w_ih w_hh b_ih b_hh".split()):
+        assert rel(a.grad, b.grad) < 5e-5, name
+
+
+# ------------------------------------------------------------------ full-size, size-independent properties
+def test_sampled_gemm_full_size_properties(dev):
+    """cfg3 shape (M=8192, N=512, K=4096): fused-in-loader sampling == materialise-then-GEMM (same
+    Philox counters), linearity in X, and a row subset against fp64 on the CPU."""
+    ops, lib = ops_mod(), L()
+    M, N, K = 8192, 512, 4096
+    g = torch.Generator(device=dev).manual_seed(1)
+    X = torch.randn(M, K, device=dev, generator=g)
+    mu = torch.randn(N, K, device=dev, generator=g) * 0.05
+    lg = torch.rand(N, K, device=dev, generator=g) * 2 - 5
+    noise = ops.NoiseSpec(None, 1111, 16, 3)
+    y_f = ops.bayes_linear(X, mu, lg, noise, 0.0, True)
+    y_m = ops.bayes_linear(X, mu, lg, noise, 0.0, False)
+    assert rel(y_f, y_m) < 1e-6
+    y2 = ops.bayes_linear(2.0 * X, mu, lg, noise, 0.0, True)
+    assert rel(y2, 2.0 * y_f) < 1e-6
+    W = ops.sample_weight(mu, lg, noise)
+    rows = torch.tensor([0, 1, 127, 128, 4095, 8191])
+    ref = X[rows.to(dev)].double().cpu() @ W.double().cpu().t()
+    assert rel(y_f[rows.to(dev)], ref) < 1e-5
+    # a different step draws different noise; the same step is reproducible bit for bit
+    assert torch.equal(ops.bayes_linear(X, mu, lg, noise, 0.0, True), y_f)
+    assert not torch.equal(ops.bayes_linear(X, mu, lg, ops.NoiseSpec(None, 1111, 16, 4), 0.0, True), y_f)
