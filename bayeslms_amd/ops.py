@@ -343,7 +343,7 @@ class _FFN(torch.autograd.Function):
         N2 = w2.shape[0]
         M = x.numel() // D
         B = x.shape[-2] if x.dim() >= 2 else 1
-        need_bwd = torch.is_grad_enabled()
+        need_bwd = any(ctx.needs_input_grad)  # forward itself runs with grad mode off
         z = torch.empty(M, F_, device=x.device, dtype=torch.float32) if need_bwd else None
         h = torch.empty(M, F_, device=x.device, dtype=torch.float32)
         gemm(L.GEMM_NT, x, w1, h, M, F_, D, D, D, F_, epilogue=L.EPI_BIAS_GELU, bias=b1, aux=z, drop=drop, drop_B=B,
@@ -640,7 +640,7 @@ class _CrossEntropy(torch.autograd.Function):
             raise BayesLMError("cross_entropy: %d targets for %d rows" % (targets.numel(), M))
         nll = torch.empty(M, device=logits.device, dtype=torch.float32)
         loss = torch.zeros((), device=logits.device, dtype=torch.float32)
-        grad_mode = torch.is_grad_enabled()
+        grad_mode = ctx.needs_input_grad[0]  # forward itself runs with grad mode off
         fuse = grad_mode and unit_grad
         lse = torch.empty(M, device=logits.device, dtype=torch.float32) if (grad_mode and not unit_grad) else None
         L.require_gfx950()

@@ -49,7 +49,11 @@ def cpu_baseline(cols=4, steps=2):
     from bayeslms_amd import model as M
     from bayeslms_amd.data import synthetic_corpus
     from oracle import bayes_oracle as O
-    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = min(ncores, 16)  # a 1-GPU box's CPU share; more threads than that only oversubscribes
     torch.set_num_threads(ncores)
     torch.manual_seed(1111)
     m = M.BayesTransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, True, "FFN")

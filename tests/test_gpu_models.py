@@ -16,6 +16,13 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def grad_close(a, b, rtol=5e-4, atol=1e-7):
+    """Gradients that are analytically zero (a key-projection bias under softmax) are ~1e-10 noise
+    on both sides: compare with an absolute floor."""
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max()) <= rtol * float(b.abs().max()) + atol
+
+
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available()
@@ -93,7 +100,7 @@ def test_bayes_transformer_golden(dev, pos, fused):
         if k == "decoder.weight":
             continue
         assert p.grad is not None, k
-        assert rel(p.grad, grad[k]) < 5e-4, k
+        assert grad_close(p.grad, grad[k]), k
 
 
 def test_transformer_baseline_golden(dev):
@@ -147,7 +154,7 @@ def test_bayes_lstm_golden(dev, pos):
         if k == "decoder.weight":
             continue
         assert p.grad is not None, k
-        assert rel(p.grad, grad[k]) < 5e-4, k
+        assert grad_close(p.grad, grad[k]), k
 
 
 def test_rnn_baseline_golden(dev):
