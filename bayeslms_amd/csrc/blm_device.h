@@ -30,6 +30,22 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
   return {c0, c1, c2, c3};
 }
 
+// Same function with the round loop kept rolled: for epilogues where the call sits inside a fully
+// unrolled accumulator walk and code size, not latency, is what matters.
+__device__ __noinline__ u32x4 philox4x32_10_rolled(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                   uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll 1
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += W0; k1 += W1;
+  }
+  return {c0, c1, c2, c3};
+}
+
 __device__ __forceinline__ u32x4 philox_block(const blm_rng& r, uint64_t block) {
   return philox4x32_10((uint32_t)block, (uint32_t)(block >> 32), r.stream, r.step, (uint32_t)r.seed,
                        (uint32_t)(r.seed >> 32));
@@ -52,6 +68,24 @@ __device__ __forceinline__ float4 philox_normal4(const blm_rng& r, uint64_t bloc
   box_muller(u.x, u.y, z.x, z.y);
   box_muller(u.z, u.w, z.z, z.w);
   return z;
+}
+
+// One N(0,1) value (element `idx` of the stream), compact code.
+__device__ __forceinline__ float philox_normal1_rolled(const blm_rng& r, uint64_t idx) {
+  const uint64_t block = idx >> 2;
+  const u32x4 u = philox4x32_10_rolled((uint32_t)block, (uint32_t)(block >> 32), r.stream, r.step, (uint32_t)r.seed,
+                                       (uint32_t)(r.seed >> 32));
+  const bool hi = idx & 2;
+  float z0, z1;
+  box_muller(hi ? u.z : u.x, hi ? u.w : u.y, z0, z1);
+  return (idx & 1) ? z1 : z0;
+}
+__device__ __forceinline__ uint32_t philox_bits1_rolled(const blm_rng& r, uint64_t idx) {
+  const uint64_t block = idx >> 2;
+  const u32x4 u = philox4x32_10_rolled((uint32_t)block, (uint32_t)(block >> 32), r.stream, r.step, (uint32_t)r.seed,
+                                       (uint32_t)(r.seed >> 32));
+  const int c = (int)(idx & 3);
+  return c == 0 ? u.x : (c == 1 ? u.y : (c == 2 ? u.z : u.w));
 }
 
 __device__ __forceinline__ uint32_t dropout_threshold(float p) {

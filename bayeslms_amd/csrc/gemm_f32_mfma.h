@@ -14,6 +14,7 @@
 // row).  Operands that are k-contiguous in HBM are transposed on the LDS
 // write (row stride R+1: conflict-free b32 scatter); operands that are
 // m/n-contiguous are copied with ds_write_b128 (row stride R+4).
+#pragma once
 #include "blm_device.h"
 #include "blm_host.h"
 
@@ -37,7 +38,7 @@ struct GemmP {
   const float* wg_mu;
   blm_variational vc;
   float kl_lambda, kl_inv_n;
-  int a_vec, b_vec;
+  int a_vec, b_vec, fast;
   int gm, gn;
   // fused activation dropout
   int drop_on; uint32_t drop_thr; float drop_inv_keep; blm_rng drop_rng;
@@ -48,10 +49,7 @@ struct GemmP {
 __device__ __forceinline__ float gemm_keep(const GemmP& p, int m, int n) {
   const int row = m / p.drop_B, b = m - row * p.drop_B;
   const uint64_t g = ((uint64_t)row * p.drop_global_cols + (uint64_t)(p.drop_col_offset + b)) * (uint64_t)p.N + (uint64_t)n;
-  const u32x4 u = philox_block(p.drop_rng, g >> 2);
-  const int c = (int)(g & 3);
-  const uint32_t bits = c == 0 ? u.x : (c == 1 ? u.y : (c == 2 ? u.z : u.w));
-  return bits >= p.drop_thr ? p.drop_inv_keep : 0.f;
+  return philox_bits1_rolled(p.drop_rng, g) >= p.drop_thr ? p.drop_inv_keep : 0.f;
 }
 
 constexpr int BK = 32;
@@ -153,12 +151,76 @@ __device__ __forceinline__ float dgp_mix(float z, const float* coef, int N, int 
          dgelu_erf(z) * coef[3 * N + n];
 }
 
-template <int OP, int WTM, int WTN, bool SAMP>
+// C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int EPI, int WTM, int WTN>
+__device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN], int m0, int n0, int wm, int wn,
+                                         int li, int lh) {
+  const bool accum = p.flags & BLM_GEMM_ACCUMULATE;
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) {
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int col = n0 + wn * (32 * WTN) + 32 * j + li;
+      const bool col_ok = col < p.N;
+      float bias = 0.f;
+      if constexpr (EPI == BLM_EPI_BIAS || EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_GP_MIX)
+        bias = col_ok ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (32 * WTM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (col_ok && row < p.M) {
+          const long o = (long)row * p.ldc + col;
+          float v = p.alpha * acc[i][j][r];
+          if constexpr (EPI == BLM_EPI_BIAS) {
+            v += bias;
+          } else if constexpr (EPI == BLM_EPI_BIAS_GELU) {
+            v += bias;
+            if (p.aux) p.aux[o] = v;
+            v = gelu_erf(v);
+            if (p.drop_on) v *= gemm_keep(p, row, col);
+          } else if constexpr (EPI == BLM_EPI_MUL_DGELU) {
+            v *= dgelu_erf(p.aux[o]);
+            if (p.drop_on) v *= gemm_keep(p, row, col);
+          } else if constexpr (EPI == BLM_EPI_GP_MIX) {
+            v += bias;
+            if (p.aux) p.aux[o] = v;
+            v = gp_mix(v, p.coef, p.N, col);
+            if (p.drop_on) v *= gemm_keep(p, row, col);
+          } else if constexpr (EPI == BLM_EPI_MUL_DGP_MIX) {
+            v *= dgp_mix(p.aux[o], p.coef, p.N, col);
+            if (p.drop_on) v *= gemm_keep(p, row, col);
+          } else if constexpr (EPI == BLM_EPI_BAYES_WGRAD) {
+            const float dW = v;
+            const int rel = row - p.vc.row_lo;
+            if ((unsigned)rel < (unsigned)p.vc.srows) {
+              const long si = (long)rel * p.N + col;
+              const float sig = __expf(p.vc.lgstd[si]);
+              float e;
+              if (p.vc.eps) e = p.vc.eps[si];
+              else e = philox_normal1_rolled(p.vc.rng, (uint64_t)si);
+              const float g2 = dW * e * sig + p.kl_lambda * (sig * sig - 1.0f) * p.kl_inv_n;
+              p.C2[si] = accum ? p.C2[si] + g2 : g2;
+              v = dW + p.kl_lambda * p.wg_mu[o] * p.kl_inv_n;
+            }
+          }
+          p.C[o] = accum ? p.C[o] + v : v;
+        }
+      }
+    }
+  }
+}
+
+// FAST: every operand 16-B aligned with a leading dimension and contiguous extent that are
+// multiples of 4.  Full K tiles are then fetched by branch-free float4 loads through per-thread
+// pointers set up once (rows/cols outside the matrix are clamped, not zeroed: they only feed
+// C elements that are never stored); only a K tail tile goes through the guarded loaders.
+template <int OP, int WTM, int WTN, bool SAMP, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   constexpr int BM = 64 * WTM, BN = 64 * WTN;
   constexpr bool A_KMAJ = (OP != BLM_GEMM_TN), B_KMAJ = (OP == BLM_GEMM_NT);
   constexpr int SA = A_KMAJ ? BM + 1 : BM + 4;
   constexpr int SB = B_KMAJ ? BN + 1 : BN + 4;
+  constexpr int NA = BM / 32, NB = BN / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const As = smem;
   float* const Bs = smem + 2 * BK * SA;
@@ -170,13 +232,76 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
   const int m0 = (id / p.gn) * BM, n0 = (id % p.gn) * BN;
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
 
-  float4 ra[BM / 32], rb[BN / 32], rl[SAMP ? BN / 32 : 1];
-  const bool av = p.a_vec, bv = p.b_vec;
+  float4 ra[NA], rb[NB], rl[SAMP ? NB : 1];
+  const float* pa[FAST ? NA : 1];
+  const float* pb[FAST ? NB : 1];
+  const float* pl[(FAST && SAMP) ? NB : 1];
+  bool in_slice[(FAST && SAMP) ? NB : 1];
+  long stepA = 0, stepB = 0, stepL = 0;  // element advance per K tile
 
-  auto fetch = [&](int k0) {
+  if constexpr (FAST) {
+    if constexpr (A_KMAJ) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) pa[j] = p.A + (long)min(m0 + (t >> 3) + 32 * j, p.M - 1) * p.lda + 4 * (t & 7);
+      stepA = BK;
+    } else {
+      constexpr int TPR = BM / 4, RPP = 256 / TPR;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) pa[j] = p.A + (long)(t / TPR + RPP * j) * p.lda + min(m0 + 4 * (t % TPR), p.M - 4);
+      stepA = (long)BK * p.lda;
+    }
+    if constexpr (B_KMAJ) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int n = min(n0 + (t >> 3) + 32 * j, p.N - 1);
+        pb[j] = p.B + (long)n * p.ldb + 4 * (t & 7);
+        if constexpr (SAMP) {
+          const int rel = n - p.vb.row_lo;
+          in_slice[j] = (unsigned)rel < (unsigned)p.vb.srows;
+          pl[j] = p.vb.lgstd + (long)min(max(rel, 0), p.vb.srows - 1) * p.vb_cols + 4 * (t & 7);
+        }
+      }
+      stepB = BK;
+      stepL = BK;
+    } else {
+      constexpr int TPR = BN / 4, RPP = 256 / TPR;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int c = min(n0 + 4 * (t % TPR), p.N - 4);
+        pb[j] = p.B + (long)(t / TPR + RPP * j) * p.ldb + c;
+        if constexpr (SAMP) pl[j] = p.vb.lgstd + c;  // row part added per tile (depends on k)
+      }
+      stepB = (long)BK * p.ldb;
+    }
+  }
+
+  auto fetch_fast = [&](int kt) {
+    if constexpr (FAST) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) ra[j] = *reinterpret_cast<const float4*>(pa[j] + kt * stepA);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) rb[j] = *reinterpret_cast<const float4*>(pb[j] + kt * stepB);
+      if constexpr (SAMP) {
+        if constexpr (B_KMAJ) {
+#pragma unroll
+          for (int j = 0; j < NB; ++j) rl[j] = *reinterpret_cast<const float4*>(pl[j] + kt * stepL);
+        } else {
+          constexpr int TPR = BN / 4, RPP = 256 / TPR;
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const int rel = kt * BK + t / TPR + RPP * j - p.vb.row_lo;
+            in_slice[j] = (unsigned)rel < (unsigned)p.vb.srows;
+            rl[j] = *reinterpret_cast<const float4*>(pl[j] + (long)min(max(rel, 0), p.vb.srows - 1) * p.vb_cols);
+          }
+        }
+      }
+    }
+  };
+  auto fetch_slow = [&](int k0) {
+    const bool av = p.a_vec, bv = p.b_vec;
     if constexpr (A_KMAJ) g2r_kmaj<BM>(p.A, p.lda, m0, p.M, k0, p.K, av, ra);
     else g2r_nmaj<BM>(p.A, p.lda, k0, p.K, m0, p.M, av, ra);
     if constexpr (B_KMAJ) g2r_kmaj<BN>(p.B, p.ldb, n0, p.N, k0, p.K, bv, rb);
@@ -186,16 +311,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
       else g2r_nmaj<BN>(p.vb.lgstd, p.vb_cols, k0 - p.vb.row_lo, p.vb.srows, n0, p.N, true, rl);
     }
   };
-  auto stash = [&](int buf, int k0) {
+  // registers -> LDS (with the variational transform W = mu + exp(lgstd)*eps on the B operand)
+  auto stash = [&](int buf, int k0, bool fast) {
     float* At = As + buf * BK * SA;
     float* Bt = Bs + buf * BK * SB;
     if constexpr (SAMP) {
-      const int t = threadIdx.x;
 #pragma unroll
-      for (int j = 0; j < BN / 32; ++j) {
+      for (int j = 0; j < NB; ++j) {
         int srow, scol;
         if constexpr (B_KMAJ) { srow = n0 + (t >> 3) + 32 * j; scol = k0 + 4 * (t & 7); }
         else { constexpr int TPR = BN / 4, RPP = 256 / TPR; srow = k0 + t / TPR + RPP * j; scol = n0 + 4 * (t % TPR); }
+        if constexpr (FAST) {
+          if (fast) {  // clamped fetch: element coordinates follow the clamped address
+            if constexpr (B_KMAJ) srow = min(srow, p.N - 1); else scol = min(scol, p.N - 4);
+            if (in_slice[j]) rb[j] = sample4(rb[j], rl[j], p.vb, p.vb_cols, srow, scol);
+            continue;
+          }
+        }
         rb[j] = sample4(rb[j], rl[j], p.vb, p.vb_cols, srow, scol);
       }
     }
@@ -209,13 +341,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 #pragma unroll
     for (int j = 0; j < WTN; ++j) acc[i][j] = (f32x16)(0.f);
 
-  const int nk = (p.K + BK - 1) / BK;
-  fetch(0);
-  stash(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) fetch((kt + 1) * BK);
+  auto compute = [&](int cur) {
     const float* Ab = As + cur * BK * SA + lh * SA + wm * (32 * WTM) + li;
     const float* Bb = Bs + cur * BK * SB + lh * SB + wn * (32 * WTN) + li;
 #pragma unroll
@@ -230,72 +356,44 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) stash(cur ^ 1, (kt + 1) * BK);
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  const int nfull = FAST ? p.K / BK : 0;  // tiles fetched by the fast path
+  if (nfull > 0) fetch_fast(0); else fetch_slow(0);
+  stash(0, 0, nfull > 0);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < nfull; ++kt) {  // steady state: next tile is a full one
+    fetch_fast(kt + 1);
+    compute(kt & 1);
+    stash((kt + 1) & 1, (kt + 1) * BK, true);
+    __syncthreads();
+  }
+  for (; kt < nk; ++kt) {  // last full tile and/or the K tail
+    const bool more = kt + 1 < nk;
+    if (more) fetch_slow((kt + 1) * BK);
+    compute(kt & 1);
+    if (more) stash((kt + 1) & 1, (kt + 1) * BK, false);
     __syncthreads();
   }
 
-  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const bool accum = p.flags & BLM_GEMM_ACCUMULATE;
-#pragma unroll
-  for (int i = 0; i < WTM; ++i)
-#pragma unroll
-    for (int j = 0; j < WTN; ++j) {
-      const int col = n0 + wn * (32 * WTN) + 32 * j + li;
-      if (col >= p.N) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (32 * WTM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= p.M) continue;
-        const long o = (long)row * p.ldc + col;
-        float v = p.alpha * acc[i][j][r];
-        switch (p.epi) {
-          case BLM_EPI_BIAS: v += p.bias[col]; break;
-          case BLM_EPI_BIAS_GELU: {
-            v += p.bias[col];
-            if (p.aux) p.aux[o] = v;
-            v = gelu_erf(v);
-            if (p.drop_on) v *= gemm_keep(p, row, col);
-          } break;
-          case BLM_EPI_MUL_DGELU: {
-            v *= dgelu_erf(p.aux[o]);
-            if (p.drop_on) v *= gemm_keep(p, row, col);
-          } break;
-          case BLM_EPI_GP_MIX: {
-            v += p.bias[col];
-            if (p.aux) p.aux[o] = v;
-            v = gp_mix(v, p.coef, p.N, col);
-            if (p.drop_on) v *= gemm_keep(p, row, col);
-          } break;
-          case BLM_EPI_MUL_DGP_MIX: {
-            v *= dgp_mix(p.aux[o], p.coef, p.N, col);
-            if (p.drop_on) v *= gemm_keep(p, row, col);
-          } break;
-          case BLM_EPI_BAYES_WGRAD: {
-            const float dW = v;
-            const int rel = row - p.vc.row_lo;
-            if ((unsigned)rel < (unsigned)p.vc.srows) {
-              const long si = (long)rel * p.N + col;
-              const float sig = __expf(p.vc.lgstd[si]);
-              float e;
-              if (p.vc.eps) e = p.vc.eps[si];
-              else {
-                const float4 z = philox_normal4(p.vc.rng, (uint64_t)si >> 2);
-                const int c = (int)(si & 3);
-                e = c == 0 ? z.x : (c == 1 ? z.y : (c == 2 ? z.z : z.w));
-              }
-              const float g2 = dW * e * sig + p.kl_lambda * (sig * sig - 1.0f) * p.kl_inv_n;
-              p.C2[si] = accum ? p.C2[si] + g2 : g2;
-              v = dW + p.kl_lambda * p.wg_mu[o] * p.kl_inv_n;
-            }
-          } break;
-          default: break;
-        }
-        p.C[o] = accum ? p.C[o] + v : v;
-      }
-    }
+  // ---- epilogue (one straight-line, fully unrolled body per epilogue kind: the accumulator must
+  // only ever be indexed by compile-time constants or it is demoted to scratch)
+  switch (p.epi) {
+    case BLM_EPI_BIAS: epilogue<BLM_EPI_BIAS, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
+    case BLM_EPI_BIAS_GELU: epilogue<BLM_EPI_BIAS_GELU, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
+    case BLM_EPI_MUL_DGELU: epilogue<BLM_EPI_MUL_DGELU, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
+    case BLM_EPI_GP_MIX: epilogue<BLM_EPI_GP_MIX, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
+    case BLM_EPI_MUL_DGP_MIX: epilogue<BLM_EPI_MUL_DGP_MIX, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
+    case BLM_EPI_BAYES_WGRAD:
+      if constexpr (OP == BLM_GEMM_TN) epilogue<BLM_EPI_BAYES_WGRAD, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh);
+      break;
+    default: epilogue<BLM_EPI_NONE, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
+  }
 }
 
-template <int OP, int WTM, int WTN, bool SAMP>
+template <int OP, int WTM, int WTN, bool SAMP, bool FAST>
 static int launch_cfg(const GemmP& p, hipStream_t st) {
   constexpr int BM = 64 * WTM, BN = 64 * WTN;
   constexpr bool A_KMAJ = (OP != BLM_GEMM_TN), B_KMAJ = (OP == BLM_GEMM_NT);
@@ -304,7 +402,7 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   GemmP q = p;
   q.gm = (p.M + BM - 1) / BM;
   q.gn = (p.N + BN - 1) / BN;
-  auto kern = gemm_f32_kernel<OP, WTM, WTN, SAMP>;
+  auto kern = gemm_f32_kernel<OP, WTM, WTN, SAMP, FAST>;
   static bool attr_done = false;  // per instantiation; benign race (idempotent)
   if (!attr_done) {
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -317,7 +415,7 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
 }
 
 template <int OP, bool SAMP>
-static int launch_op(const GemmP& p, hipStream_t st) {
+int launch_op(const GemmP& p, hipStream_t st) {
   // Tile choice: 128x128 when it fills the chip (>= 256 blocks) or the problem is large in both
   // dimensions; otherwise shrink the dimension that leaves CUs idle.
   const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
@@ -328,79 +426,11 @@ static int launch_op(const GemmP& p, hipStream_t st) {
                     ((p.N + (small_n ? 63 : 127)) / (small_n ? 64 : 128));
     if (b2 < 256) small_m = small_n = true;
   }
-  if (small_m && small_n) return launch_cfg<OP, 1, 1, SAMP>(p, st);
-  if (small_m) return launch_cfg<OP, 1, 2, SAMP>(p, st);
-  if (small_n) return launch_cfg<OP, 2, 1, SAMP>(p, st);
-  return launch_cfg<OP, 2, 2, SAMP>(p, st);
+  if (!p.fast) return launch_cfg<OP, 1, 1, SAMP, false>(p, st);  // odd shapes/alignments: guarded loaders only
+  if (small_m && small_n) return launch_cfg<OP, 1, 1, SAMP, true>(p, st);
+  if (small_m) return launch_cfg<OP, 1, 2, SAMP, true>(p, st);
+  if (small_n) return launch_cfg<OP, 2, 1, SAMP, true>(p, st);
+  return launch_cfg<OP, 2, 2, SAMP, true>(p, st);
 }
 
 }  // namespace blm
-
-using namespace blm;
-
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
-extern "C" int blm_gemm(const blm_gemm_args* a, void* stream) {
-  if (!a) return blm_fail(BLM_ERR_INVALID, "blm_gemm: null args");
-  if (a->abi_version != BLM_ABI_VERSION) return blm_fail(BLM_ERR_ABI, "blm_gemm: abi_version mismatch");
-  if (a->M < 0 || a->N < 0 || a->K < 0) return blm_fail(BLM_ERR_INVALID, "blm_gemm: negative dimension");
-  if (a->M == 0 || a->N == 0) return BLM_OK;
-  if (!a->A || !a->B || !a->C) return blm_fail(BLM_ERR_INVALID, "blm_gemm: null operand");
-  if (a->op < BLM_GEMM_NT || a->op > BLM_GEMM_TN) return blm_fail(BLM_ERR_INVALID, "blm_gemm: bad op");
-  const int amin = a->op == BLM_GEMM_TN ? a->M : a->K, bmin = a->op == BLM_GEMM_NT ? a->K : a->N;
-  if (a->lda < amin || a->ldb < bmin || a->ldc < a->N) return blm_fail(BLM_ERR_INVALID, "blm_gemm: leading dimension too small");
-  GemmP p{};
-  p.M = a->M; p.N = a->N; p.K = a->K;
-  p.A = a->A; p.lda = a->lda; p.B = a->B; p.ldb = a->ldb; p.C = a->C; p.ldc = a->ldc;
-  p.alpha = a->alpha; p.flags = a->flags; p.epi = a->epilogue;
-  p.bias = a->bias; p.aux = a->aux; p.coef = a->coef;
-  p.vb = a->var_b; p.C2 = a->C2; p.wg_mu = a->wg_mu; p.vc = a->var_c;
-  p.kl_lambda = a->kl_lambda; p.kl_inv_n = a->kl_inv_n;
-  p.drop_on = a->drop_p > 0.f;
-  if (p.drop_on) {
-    if (a->drop_B <= 0 || a->M % a->drop_B != 0) return blm_fail(BLM_ERR_INVALID, "blm_gemm: drop_B must divide M");
-    const double t = (double)a->drop_p * 4294967296.0;
-    p.drop_thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
-    p.drop_inv_keep = a->drop_p < 1.f ? 1.f / (1.f - a->drop_p) : 0.f;
-    p.drop_rng = a->drop_rng;
-    p.drop_B = a->drop_B; p.drop_col_offset = a->drop_col_offset;
-    p.drop_global_cols = a->drop_global_cols > 0 ? a->drop_global_cols : a->drop_B;
-  }
-  p.a_vec = aligned16(a->A) && (a->lda % 4 == 0);
-  p.b_vec = aligned16(a->B) && (a->ldb % 4 == 0);
-  switch (a->epilogue) {
-    case BLM_EPI_NONE: break;
-    case BLM_EPI_BIAS: case BLM_EPI_BIAS_GELU:
-      if (!a->bias) return blm_fail(BLM_ERR_INVALID, "blm_gemm: epilogue needs bias"); break;
-    case BLM_EPI_MUL_DGELU:
-      if (!a->aux) return blm_fail(BLM_ERR_INVALID, "blm_gemm: epilogue needs aux"); break;
-    case BLM_EPI_GP_MIX:
-      if (!a->bias || !a->coef) return blm_fail(BLM_ERR_INVALID, "blm_gemm: GP epilogue needs bias and coef"); break;
-    case BLM_EPI_MUL_DGP_MIX:
-      if (!a->aux || !a->coef) return blm_fail(BLM_ERR_INVALID, "blm_gemm: GP epilogue needs aux and coef"); break;
-    case BLM_EPI_BAYES_WGRAD:
-      if (a->op != BLM_GEMM_TN) return blm_fail(BLM_ERR_INVALID, "blm_gemm: BAYES_WGRAD needs op TN");
-      if (!a->C2 || !a->wg_mu || !a->var_c.lgstd) return blm_fail(BLM_ERR_INVALID, "blm_gemm: BAYES_WGRAD needs C2, wg_mu, var_c.lgstd");
-      if (a->var_c.row_lo < 0 || a->var_c.srows < 0 || a->var_c.row_lo + a->var_c.srows > a->M)
-        return blm_fail(BLM_ERR_INVALID, "blm_gemm: var_c row window outside W");
-      break;
-    default: return blm_fail(BLM_ERR_INVALID, "blm_gemm: unknown epilogue");
-  }
-  const bool samp = a->var_b.lgstd != nullptr;
-  if (samp) {
-    if (a->op == BLM_GEMM_TN) return blm_fail(BLM_ERR_INVALID, "blm_gemm: var_b not valid for TN");
-    // B source matrix is W: NT -> (N x K), NN -> (K x N)
-    const int wrows = a->op == BLM_GEMM_NT ? a->N : a->K;
-    p.vb_cols = a->op == BLM_GEMM_NT ? a->K : a->N;
-    if (p.vb_cols % 4 != 0 || !aligned16(a->var_b.lgstd) || (a->var_b.eps && !aligned16(a->var_b.eps)) || !p.b_vec)
-      return blm_fail(BLM_ERR_INVALID, "blm_gemm: fused sampling needs cols % 4 == 0 and 16-byte aligned mu/lgstd/eps");
-    if (a->var_b.row_lo < 0 || a->var_b.srows < 0 || a->var_b.row_lo + a->var_b.srows > wrows)
-      return blm_fail(BLM_ERR_INVALID, "blm_gemm: var_b row window outside W");
-  }
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (a->op) {
-    case BLM_GEMM_NT: return samp ? launch_op<BLM_GEMM_NT, true>(p, st) : launch_op<BLM_GEMM_NT, false>(p, st);
-    case BLM_GEMM_NN: return samp ? launch_op<BLM_GEMM_NN, true>(p, st) : launch_op<BLM_GEMM_NN, false>(p, st);
-    default: return launch_op<BLM_GEMM_TN, false>(p, st);
-  }
-}
