@@ -300,17 +300,26 @@ __global__ __launch_bounds__(TPB) void add_drop_ln_bwd_generic(const float* __re
   }
 }
 
+// block = 64 columns x 4 partial-row groups; partial rows are summed 4-way in parallel, then via LDS
 __global__ __launch_bounds__(TPB) void ln_bwd_finish(const float* __restrict__ ws, int nblk, int D,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int j = blockIdx.x * TPB + threadIdx.x;
-  if (j >= D) return;
+  __shared__ float sm[2][4][64];
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
   float a = 0.f, b = 0.f;
-  for (int k = 0; k < nblk; ++k) {
-    a += ws[((long)k * 2 + 0) * D + j];
-    b += ws[((long)k * 2 + 1) * D + j];
+  if (j < D) {
+    for (int k = grp; k < nblk; k += 4) {
+      a += ws[((long)k * 2 + 0) * D + j];
+      b += ws[((long)k * 2 + 1) * D + j];
+    }
   }
-  dgamma[j] += a;
-  dbeta[j] += b;
+  sm[0][grp][c] = a;
+  sm[1][grp][c] = b;
+  __syncthreads();
+  if (grp == 0 && j < D) {
+    dgamma[j] += sm[0][0][c] + sm[0][1][c] + sm[0][2][c] + sm[0][3][c];
+    dbeta[j] += sm[1][0][c] + sm[1][1][c] + sm[1][2][c] + sm[1][3][c];
+  }
 }
 
 // ------------------------------------------------------------------ cross entropy
@@ -619,7 +628,7 @@ extern "C" int blm_add_dropout_ln_bwd(const float* dout, const float* s, const f
   }
 #undef LN_BWD
   BLM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(ln_bwd_finish, dim3((D + TPB - 1) / TPB), dim3(TPB), 0, ST, ws, nblk, D, dgamma, dbeta);
+  hipLaunchKernelGGL(ln_bwd_finish, dim3((D + 63) / 64), dim3(TPB), 0, ST, ws, nblk, D, dgamma, dbeta);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }

@@ -1,4 +1,6 @@
 // C-ABI entry point of the fp32 MFMA GEMM family: argument validation and dispatch.
+#include <cstdlib>
+
 #include "gemm_f32_mfma.h"
 
 namespace blm {
@@ -38,6 +40,13 @@ extern "C" int blm_gemm(const blm_gemm_args* a, void* stream) {
     p.drop_rng = a->drop_rng;
     p.drop_B = a->drop_B; p.drop_col_offset = a->drop_col_offset;
     p.drop_global_cols = a->drop_global_cols > 0 ? a->drop_global_cols : a->drop_B;
+  }
+  p.drop_quad = (a->N % 4 == 0);
+  {
+    static int tile = -1, spl = -1;  // tuning overrides, read once
+    if (tile < 0) { const char* e = getenv("BLM_GEMM_TILE"); tile = e ? atoi(e) : 0; }
+    if (spl < 0) { const char* e = getenv("BLM_GEMM_SPLITK"); spl = e ? atoi(e) : 0; }
+    p.force_tile = tile; p.force_splits = spl;
   }
   p.a_vec = aligned16(a->A) && (a->lda % 4 == 0);
   p.b_vec = aligned16(a->B) && (a->ldb % 4 == 0);

@@ -40,9 +40,11 @@ struct GemmP {
   float kl_lambda, kl_inv_n;
   int a_vec, b_vec, fast;
   int gm, gn;
+  int force_tile, force_splits;  // tuning overrides (BLM_GEMM_TILE / BLM_GEMM_SPLITK env), 0 = heuristic
+  int splits, kper, atomic;  // split-K: block ks covers k in [ks*kper, (ks+1)*kper), partial sums by float atomics
   // fused activation dropout
   int drop_on; uint32_t drop_thr; float drop_inv_keep; blm_rng drop_rng;
-  int drop_B, drop_col_offset, drop_global_cols;
+  int drop_B, drop_col_offset, drop_global_cols, drop_quad;
 };
 
 // keep factor of element (m, n) of a (rows, B, N) activation, keyed by global column
@@ -151,6 +153,31 @@ __device__ __forceinline__ float dgp_mix(float z, const float* coef, int N, int 
          dgelu_erf(z) * coef[3 * N + n];
 }
 
+// Dropout keep factors for the four rows base_row + {0,1,2,3} at this lane's column: the four
+// lanes of a quad own four consecutive columns = one Philox block per row, so lane k generates the
+// block of row base_row + k and the quad exchanges words by DPP broadcasts (1 Philox call per
+// 4 elements instead of 4).  Needs N % 4 == 0 and the quad's first column % 4 == 0.
+__device__ __forceinline__ void gemm_keep_quad(const GemmP& p, int base_row, int col, float (&keep)[4]) {
+  const int k = threadIdx.x & 3;
+  const int m = base_row + k;
+  const int row = m / p.drop_B, b = m - row * p.drop_B;
+  const uint64_t g = ((uint64_t)row * p.drop_global_cols + (uint64_t)(p.drop_col_offset + b)) * (uint64_t)p.N +
+                     (uint64_t)(col & ~3);
+  const u32x4 u = philox4x32_10_rolled((uint32_t)(g >> 2), (uint32_t)(g >> 34), p.drop_rng.stream, p.drop_rng.step,
+                                       (uint32_t)p.drop_rng.seed, (uint32_t)(p.drop_rng.seed >> 32));
+#define BLM_QUAD_BCAST(x, j) (uint32_t) __builtin_amdgcn_mov_dpp((int)(x), (j) * 0x55, 0xF, 0xF, true)
+#define BLM_KEEP_FROM(j)                                                                                      \
+  {                                                                                                           \
+    const uint32_t w0 = BLM_QUAD_BCAST(u.x, j), w1 = BLM_QUAD_BCAST(u.y, j), w2 = BLM_QUAD_BCAST(u.z, j),     \
+                   w3 = BLM_QUAD_BCAST(u.w, j);                                                               \
+    const uint32_t w = k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));                                      \
+    keep[j] = w >= p.drop_thr ? p.drop_inv_keep : 0.f;                                                        \
+  }
+  BLM_KEEP_FROM(0) BLM_KEEP_FROM(1) BLM_KEEP_FROM(2) BLM_KEEP_FROM(3)
+#undef BLM_KEEP_FROM
+#undef BLM_QUAD_BCAST
+}
+
 // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 template <int EPI, int WTM, int WTN>
 __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN], int m0, int n0, int wm, int wn,
@@ -166,44 +193,59 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN]
       if constexpr (EPI == BLM_EPI_BIAS || EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_GP_MIX)
         bias = col_ok ? p.bias[col] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (32 * WTM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (col_ok && row < p.M) {
-          const long o = (long)row * p.ldc + col;
-          float v = p.alpha * acc[i][j][r];
-          if constexpr (EPI == BLM_EPI_BIAS) {
-            v += bias;
-          } else if constexpr (EPI == BLM_EPI_BIAS_GELU) {
-            v += bias;
-            if (p.aux) p.aux[o] = v;
-            v = gelu_erf(v);
-            if (p.drop_on) v *= gemm_keep(p, row, col);
-          } else if constexpr (EPI == BLM_EPI_MUL_DGELU) {
-            v *= dgelu_erf(p.aux[o]);
-            if (p.drop_on) v *= gemm_keep(p, row, col);
-          } else if constexpr (EPI == BLM_EPI_GP_MIX) {
-            v += bias;
-            if (p.aux) p.aux[o] = v;
-            v = gp_mix(v, p.coef, p.N, col);
-            if (p.drop_on) v *= gemm_keep(p, row, col);
-          } else if constexpr (EPI == BLM_EPI_MUL_DGP_MIX) {
-            v *= dgp_mix(p.aux[o], p.coef, p.N, col);
-            if (p.drop_on) v *= gemm_keep(p, row, col);
-          } else if constexpr (EPI == BLM_EPI_BAYES_WGRAD) {
-            const float dW = v;
-            const int rel = row - p.vc.row_lo;
-            if ((unsigned)rel < (unsigned)p.vc.srows) {
-              const long si = (long)rel * p.N + col;
-              const float sig = __expf(p.vc.lgstd[si]);
-              float e;
-              if (p.vc.eps) e = p.vc.eps[si];
-              else e = philox_normal1_rolled(p.vc.rng, (uint64_t)si);
-              const float g2 = dW * e * sig + p.kl_lambda * (sig * sig - 1.0f) * p.kl_inv_n;
-              p.C2[si] = accum ? p.C2[si] + g2 : g2;
-              v = dW + p.kl_lambda * p.wg_mu[o] * p.kl_inv_n;
+      for (int rq = 0; rq < 4; ++rq) {
+        const int row0 = m0 + wm * (32 * WTM) + 32 * i + 8 * rq + 4 * lh;
+        float keep[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_MUL_DGELU || EPI == BLM_EPI_GP_MIX ||
+                      EPI == BLM_EPI_MUL_DGP_MIX) {
+          if (p.drop_on) {  // wave-uniform: every lane takes part in the quad exchange
+            if (p.drop_quad) gemm_keep_quad(p, row0, col, keep);
+            else {
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) keep[rr] = gemm_keep(p, row0 + rr, min(col, p.N - 1));
             }
           }
-          p.C[o] = accum ? p.C[o] + v : v;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = row0 + rr;
+          const int r = 4 * rq + rr;
+          if (col_ok && row < p.M) {
+            const long o = (long)row * p.ldc + col;
+            float v = p.alpha * acc[i][j][r];
+            if constexpr (EPI == BLM_EPI_BIAS) {
+              v += bias;
+            } else if constexpr (EPI == BLM_EPI_BIAS_GELU) {
+              v += bias;
+              if (p.aux) p.aux[o] = v;
+              v = gelu_erf(v) * keep[rr];
+            } else if constexpr (EPI == BLM_EPI_MUL_DGELU) {
+              v *= dgelu_erf(p.aux[o]) * keep[rr];
+            } else if constexpr (EPI == BLM_EPI_GP_MIX) {
+              v += bias;
+              if (p.aux) p.aux[o] = v;
+              v = gp_mix(v, p.coef, p.N, col) * keep[rr];
+            } else if constexpr (EPI == BLM_EPI_MUL_DGP_MIX) {
+              v *= dgp_mix(p.aux[o], p.coef, p.N, col) * keep[rr];
+            } else if constexpr (EPI == BLM_EPI_BAYES_WGRAD) {
+              const float dW = v;
+              const int rel = row - p.vc.row_lo;
+              if ((unsigned)rel < (unsigned)p.vc.srows) {
+                const long si = (long)rel * p.N + col;
+                const float sig = __expf(p.vc.lgstd[si]);
+                float e;
+                if (p.vc.eps) e = p.vc.eps[si];
+                else e = philox_normal1_rolled(p.vc.rng, (uint64_t)si);
+                const float g2 = dW * e * sig + p.kl_lambda * (sig * sig - 1.0f) * p.kl_inv_n;
+                p.C2[si] = accum ? p.C2[si] + g2 : g2;
+                v = dW + p.kl_lambda * p.wg_mu[o] * p.kl_inv_n;
+              }
+            }
+            if constexpr (EPI == BLM_EPI_NONE) {
+              if (p.atomic) { atomicAdd(p.C + o, v); continue; }
+            }
+            p.C[o] = accum ? p.C[o] + v : v;
+          }
         }
       }
     }
@@ -227,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
   // contiguous run of tile ids; n is fastest so neighbours reuse the same A panel out of that XCD's L2.
-  const int nb = p.gm * p.gn, bid = blockIdx.x;
+  const int nb = p.gm * p.gn, bid = blockIdx.x % nb, ks = blockIdx.x / nb;
   const int q = nb >> 3, rem = nb & 7, xcd = bid & 7;
   const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
   const int m0 = (id / p.gn) * BM, n0 = (id % p.gn) * BN;
@@ -358,23 +400,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     }
   };
 
-  const int nk = (p.K + BK - 1) / BK;
-  const int nfull = FAST ? p.K / BK : 0;  // tiles fetched by the fast path
-  if (nfull > 0) fetch_fast(0); else fetch_slow(0);
-  stash(0, 0, nfull > 0);
+  // K tiles [t0, t1) of this block (split-K: a slice of K); tiles below K/BK are full
+  const int kbeg = ks * p.kper, kend = min(p.K, kbeg + p.kper);
+  const int t0 = kbeg / BK, t1 = (kend + BK - 1) / BK;
+  const int tfull = FAST ? min(t1, p.K / BK) : t0;  // tiles [t0, tfull) go through the fast loaders
+  if (t0 < tfull) fetch_fast(t0); else fetch_slow(t0 * BK);
+  stash(0, t0 * BK, t0 < tfull);
   __syncthreads();
-  int kt = 0;
-  for (; kt + 1 < nfull; ++kt) {  // steady state: next tile is a full one
+  int kt = t0;
+  for (; kt + 1 < tfull; ++kt) {  // steady state: next tile is a full one
     fetch_fast(kt + 1);
-    compute(kt & 1);
-    stash((kt + 1) & 1, (kt + 1) * BK, true);
+    compute((kt - t0) & 1);
+    stash((kt + 1 - t0) & 1, (kt + 1) * BK, true);
     __syncthreads();
   }
-  for (; kt < nk; ++kt) {  // last full tile and/or the K tail
-    const bool more = kt + 1 < nk;
+  for (; kt < t1; ++kt) {  // last full tile and/or the K tail
+    const bool more = kt + 1 < t1;
     if (more) fetch_slow((kt + 1) * BK);
-    compute(kt & 1);
-    if (more) stash((kt + 1) & 1, (kt + 1) * BK, false);
+    compute((kt - t0) & 1);
+    if (more) stash((kt + 1 - t0) & 1, (kt + 1) * BK, false);
     __syncthreads();
   }
 
@@ -402,6 +446,22 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   GemmP q = p;
   q.gm = (p.M + BM - 1) / BM;
   q.gn = (p.N + BN - 1) / BN;
+  // split-K when the output grid leaves most of the 256 CUs idle and K is long: partial sums meet
+  // in C through float atomics (only for the plain epilogue; C is zeroed first unless accumulating)
+  const long nb = (long)q.gm * q.gn;
+  int splits = 1;
+  if (p.epi == BLM_EPI_NONE && !SAMP && nb < 384 && p.K >= 2048 && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N)) {
+    splits = (int)((512 + nb - 1) / nb);
+    if (splits > 8) splits = 8;
+    while (splits > 1 && p.K / splits < 512) --splits;
+  }
+  if (p.force_splits > 0 && p.epi == BLM_EPI_NONE && !SAMP && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N))
+    splits = p.force_splits;
+  q.splits = splits;
+  q.kper = splits > 1 ? ((p.K + splits - 1) / splits + BK - 1) / BK * BK : (p.K > 0 ? p.K : 1);
+  q.atomic = splits > 1;
+  if (q.atomic && !(p.flags & BLM_GEMM_ACCUMULATE))
+    BLM_HIP(hipMemsetAsync(p.C, 0, (size_t)p.M * p.N * sizeof(float), st));
   auto kern = gemm_f32_kernel<OP, WTM, WTN, SAMP, FAST>;
   static bool attr_done = false;  // per instantiation; benign race (idempotent)
   if (!attr_done) {
@@ -409,7 +469,7 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
                                 (int)lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(q.gm * q.gn), dim3(256), lds, st, q);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nb * splits)), dim3(256), lds, st, q);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }
@@ -426,6 +486,10 @@ int launch_op(const GemmP& p, hipStream_t st) {
                     ((p.N + (small_n ? 63 : 127)) / (small_n ? 64 : 128));
     if (b2 < 256) small_m = small_n = true;
   }
+  if (p.force_tile == 11) { small_m = small_n = true; }
+  else if (p.force_tile == 12) { small_m = true; small_n = false; }
+  else if (p.force_tile == 21) { small_m = false; small_n = true; }
+  else if (p.force_tile == 22) { small_m = small_n = false; }
   if (!p.fast) return launch_cfg<OP, 1, 1, SAMP, false>(p, st);  // odd shapes/alignments: guarded loaders only
   if (small_m && small_n) return launch_cfg<OP, 1, 1, SAMP, true>(p, st);
   if (small_m) return launch_cfg<OP, 1, 2, SAMP, true>(p, st);

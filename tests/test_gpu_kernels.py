@@ -403,9 +403,9 @@ def test_sampled_gemm_full_size_properties(dev):
     noise = ops.NoiseSpec(None, 1111, 16, 3)
     y_f = ops.bayes_linear(X, mu, lg, noise, 0.0, True)
     y_m = ops.bayes_linear(X, mu, lg, noise, 0.0, False)
-    assert rel(y_f, y_m) < 1e-6
+    assert rel(y_f, y_m) < 1e-5  # split-K partial sums (materialised path) vs one chain (fused path)
     y2 = ops.bayes_linear(2.0 * X, mu, lg, noise, 0.0, True)
-    assert rel(y2, 2.0 * y_f) < 1e-6
+    assert rel(y2, 2.0 * y_f) < 1e-5
     W = ops.sample_weight(mu, lg, noise)
     rows = torch.tensor([0, 1, 127, 128, 4095, 8191])
     ref = X[rows.to(dev)].double().cpu() @ W.double().cpu().t()
