@@ -132,11 +132,26 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 // ---------------------------------------------------------------- activations
-__device__ __forceinline__ float gelu_erf(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f)); }
+// Exact-erf GELU (nn.GELU() default, model.py:1035).  erf by Abramowitz-Stegun 7.1.26
+// (|abs err| <= 1.5e-7, i.e. fp32 rounding level) sharing its exp(-z^2/2) with the Gaussian pdf
+// that the derivative needs: one v_exp + one v_rcp per element instead of a libm erff call.
+__device__ __forceinline__ void gelu_parts(float z, float& cdf, float& pdf_exp) {
+  const float x = fabsf(z) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * x);
+  pdf_exp = __expf(-x * x);  // = exp(-z^2/2)
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float tail = 0.5f * poly * pdf_exp;  // = 0.5 erfc(|z|/sqrt2): no cancellation in the tails
+  cdf = z >= 0.f ? 1.0f - tail : tail;
+}
+__device__ __forceinline__ float gelu_erf(float z) {
+  float cdf, e;
+  gelu_parts(z, cdf, e);
+  return z * cdf;
+}
 __device__ __forceinline__ float dgelu_erf(float z) {
-  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
-  return cdf + z * pdf;
+  float cdf, e;
+  gelu_parts(z, cdf, e);
+  return cdf + z * 0.3989422804014327f * e;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 

@@ -486,6 +486,9 @@ int launch_op(const GemmP& p, hipStream_t st) {
                     ((p.N + (small_n ? 63 : 127)) / (small_n ? 64 : 128));
     if (b2 < 256) small_m = small_n = true;
   }
+  // measured on MI355X (tools/gemm_bench.py): wgrad-shaped TN with a very tall output (decoder,
+  // 33000 x 512) and the Bayesian wgrad (no split-K because of its epilogue) run best on 64x64 tiles
+  if (OP == BLM_GEMM_TN && (p.epi == BLM_EPI_BAYES_WGRAD || (long)p.M * p.N >= (1L << 23))) small_m = small_n = true;
   if (p.force_tile == 11) { small_m = small_n = true; }
   else if (p.force_tile == 12) { small_m = true; small_n = false; }
   else if (p.force_tile == 21) { small_m = false; small_n = true; }
