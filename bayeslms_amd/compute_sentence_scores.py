@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""N-best sentence scoring with a trained LM -- same command line and file contract as the
+reference's steps/pytorchnn/compute_sentence_scores_bayes_jianwei.py (stage 6 of
+lmrescore_nbest_pytorchnn_cuda.sh:199-218): n-best file ``uttid-n w1 w2 ...`` in, ``uttid-n %.4f``
+out, score = len * CE_mean = sum of token NLL under mean weights (model.eval(), :225), optional logit
+interpolation with a second model (:157-168), LSTM hidden state carried to the next utterance from
+the FIRST hypothesis of the previous one (:271-274).
+"""
+import argparse
+import os
+from collections import OrderedDict
+
+import torch
+
+
+def load_nbest(path):
+    """uttid-n hyp...  -> {uttid: [hyp, ...]} in file order (reference :20-51; an empty
+    hypothesis becomes ' ')."""
+    nbest = OrderedDict()
+    with open(path, 'r', encoding='utf-8') as f:
+        for line in f:
+            line = line.strip()
+            parts = line.split(' ', 1)
+            key, hyp = (parts[0], parts[1]) if len(parts) == 2 else (line, ' ')
+            nbest.setdefault(key.rsplit('-', 1)[0], []).append(hyp)
+    return nbest
+
+
+def read_vocab(path):
+    word2idx = {}
+    with open(path, 'r', encoding='utf-8') as f:
+        for line in f:
+            fields = line.split()
+            assert len(fields) == 2
+            if fields[0] not in word2idx:
+                word2idx[fields[0]] = len(word2idx)
+    return word2idx
+
+
+def get_input_and_target(hyp, vocab):
+    """'<s> ' + hyp -> input ids; hyp + ' <s>' -> target ids; OOV -> <unk> (reference :87-120)."""
+    unk = vocab.get('<unk>')
+
+    def ids(text):
+        out = []
+        for w in text.split():
+            i = vocab.get(w, unk)
+            if i is None:
+                raise KeyError('<unk>')
+            out.append(i)
+        return out
+    return ids('<s> ' + hyp), ids(hyp + ' <s>')
+
+
+def build_models(args, ntokens):
+    """Model dispatch of the reference (:373-449): dropout 0.5 (irrelevant in eval), tied."""
+    from . import model as M
+    m2 = None
+    if args.model == 'Transformer':
+        if args.uncertainty == 'none':
+            m1 = M.TransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, 0.5, "gelu", True)
+        elif args.uncertainty == 'Bayesian':
+            m1 = M.BayesTransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, 0.5, True, args.T_bayes_pos)
+        elif args.uncertainty == 'Gaussian':
+            m1 = M.GaussTransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, 0.5, True, args.T_gauss_pos)
+        else:
+            raise SystemExit("--uncertainty %s is not built by this engine for Transformers yet" % args.uncertainty)
+        if args.interpolation_flag == 1 and args.uncertainty != 'none':
+            m2 = M.BayesTransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, 0.5, True, 'none')
+    else:
+        if args.uncertainty == 'none':
+            m1 = M.RNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, 0.5, True)
+        elif args.uncertainty == 'Bayesian':
+            m1 = M.BayesRNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, 0.5, True, args.L_bayes_pos)
+        else:
+            raise SystemExit("--uncertainty %s is not built by this engine for LSTMs yet" % args.uncertainty)
+        if args.interpolation_flag == 1 and args.uncertainty != 'none':
+            m2 = M.BayesRNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, 0.5, False, 0)
+    return m1, m2
+
+
+def load_partial(model, path):
+    """Keys filtered by name: extra keys ignored, missing keys keep their init (reference :457-462)."""
+    sd = torch.load(path, map_location='cpu')
+    own = model.state_dict()
+    own.update({k: v for k, v in sd.items() if k in own and tuple(v.shape) == tuple(own[k].shape)})
+    model.load_state_dict(own)
+
+
+def sentence_score(model, ids, tgt, model_type, hidden, device, model_2=None, hidden_2=None, alpha=0.0):
+    from . import ops
+    data = torch.tensor(ids, dtype=torch.int64, device=device).view(-1, 1)
+    target = torch.tensor(tgt, dtype=torch.int64, device=device)
+    with torch.no_grad():
+        if model_type == 'Transformer':
+            out = model(data)
+        else:
+            out, hidden = model(data, hidden)
+        if model_2 is not None:
+            if model_type == 'Transformer':
+                out2 = model_2(data)
+            else:
+                out2, hidden_2 = model_2(data, hidden_2)
+            out = alpha * out + (1. - alpha) * out2  # interpolates LOGITS (reference :163)
+        loss, _ = ops.cross_entropy(out.view(-1, out.shape[-1]), target)
+    return len(ids) * float(loss), hidden, hidden_2
+
+
+def compute_scores(nbest, model, vocab, model_type, device, model_2=None, alpha=0.0):
+    model.eval()
+    if model_2 is not None:
+        model_2.eval()
+    scores = OrderedDict()
+    hidden = model.init_hidden(1) if model_type != 'Transformer' else None
+    hidden_2 = model_2.init_hidden(1) if (model_2 is not None and model_type != 'Transformer') else None
+    for key, hyps in nbest.items():
+        first, first_2 = None, None
+        for hyp in hyps:
+            x, t = get_input_and_target(hyp, vocab)
+            s, h_new, h2_new = sentence_score(model, x, t, model_type, hidden, device, model_2, hidden_2, alpha)
+            if first is None:
+                first, first_2 = h_new, h2_new
+            scores.setdefault(key, []).append((hyp, s))
+        if model_type != 'Transformer':
+            hidden, hidden_2 = first, first_2
+    return scores
+
+
+def write_scores(scores, path):
+    with open(path, 'w', encoding='utf-8') as f:
+        for key, lst in scores.items():
+            for idx, (_, s) in enumerate(lst, 1):
+                f.write('%s %.4f\n' % ('-'.join([key, str(idx)]), s))
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Compute sentence scores of nbest lists with a trained neural LM (MI355X engine).")
+    p.add_argument('--nbest-list', type=str, required=True)
+    p.add_argument('--outfile', type=str, required=True)
+    p.add_argument('--vocabulary', type=str, required=True)
+    p.add_argument('--model-path', type=str, required=True)
+    p.add_argument('--model', type=str, default='LSTM')
+    p.add_argument('--emsize', type=int, default=1024)
+    p.add_argument('--nhid', type=int, default=1024)
+    p.add_argument('--nlayers', type=int, default=2)
+    p.add_argument('--nhead', type=int, default=8)
+    p.add_argument('--uncertainty', type=str, default='none')
+    p.add_argument('--T_bayes_pos', type=str, default='none')
+    p.add_argument('--L_bayes_pos', type=int, default=0)
+    p.add_argument('--L_gauss_pos', type=str, default='00')
+    p.add_argument('--T_gauss_pos', type=int, default=3)
+    p.add_argument('--L_v_pos', type=str, default='11')
+    p.add_argument('--T_v_pos', type=int, default=0)
+    p.add_argument('--interpolation_flag', type=int, default=0)
+    p.add_argument('--inter_path', type=str, default='')
+    p.add_argument('--inter_alpha', type=float, default=0.8)
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    for pth, what in ((args.nbest_list, "Nbest list"), (args.vocabulary, "Vocabulary"), (args.model_path, "Model")):
+        assert os.path.exists(pth), "%s path does not exists." % what
+    if not torch.cuda.is_available():
+        raise SystemExit("bayeslms_amd scoring needs an MI355X: there is no CPU path")
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    vocab = read_vocab(args.vocabulary)
+    model_1, model_2 = build_models(args, len(vocab))
+    load_partial(model_1, args.model_path)
+    model_1 = model_1.to(device)
+    if model_2 is not None:
+        assert os.path.exists(args.inter_path), "Interpolation model path does not exists."
+        load_partial(model_2, args.inter_path)
+        model_2 = model_2.to(device)
+    nbest = load_nbest(args.nbest_list)
+    scores = compute_scores(nbest, model_1, vocab, args.model, device, model_2, args.inter_alpha)
+    write_scores(scores, args.outfile)
+    print("Write to %s" % args.outfile)
+
+
+if __name__ == '__main__':
+    main()

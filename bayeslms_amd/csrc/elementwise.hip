@@ -427,6 +427,32 @@ __global__ __launch_bounds__(TPB) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// GPNN coefficient gradient: 4 column sums of g * act_i(z); block = 64 columns x 4 row lanes
+__global__ __launch_bounds__(TPB) void gp_coef_grad_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                           float* __restrict__ dcoef, int M, int N) {
+  __shared__ float sm[4][4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < N) {
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float gv = g[(long)r * N + col], zv = z[(long)r * N + col];
+      a0 += gv * tanhf(zv);
+      a1 += gv * sigmoidf_(zv);
+      a2 += gv * fmaxf(zv, 0.f);
+      a3 += gv * gelu_erf(zv);
+    }
+  }
+  sm[0][rl][c] = a0; sm[1][rl][c] = a1; sm[2][rl][c] = a2; sm[3][rl][c] = a3;
+  __syncthreads();
+  if (rl == 0 && col < N) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) atomicAdd(dcoef + (long)i * N + col, sm[i][0][c] + sm[i][1][c] + sm[i][2][c] + sm[i][3][c]);
+  }
+}
+
 // ------------------------------------------------------------------ clip + SGD
 __global__ __launch_bounds__(TPB) void sqnorm_multi_kernel(const float* const* grads, const int64_t* sizes, float* sq) {
   __shared__ float red[TPB / 64];
@@ -652,6 +678,16 @@ extern "C" int blm_ce_fwd_bwd(const float* logits, int64_t ld, const int64_t* tg
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ST, nll, (long)M, loss_sum);
     BLM_HIP(hipGetLastError());
   }
+  return BLM_OK;
+}
+
+extern "C" int blm_gp_coef_grad(const float* g, const float* z, float* dcoef, int M, int N, void* stream) {
+  if (!g || !z || !dcoef || M < 0 || N < 0) return blm_fail(BLM_ERR_INVALID, "blm_gp_coef_grad: bad arguments");
+  if (M == 0 || N == 0) return BLM_OK;
+  int gy = (M + 127) / 128;
+  if (gy > 64) gy = 64;
+  hipLaunchKernelGGL(gp_coef_grad_kernel, dim3((N + 63) / 64, gy), dim3(TPB), 0, ST, g, z, dcoef, M, N);
+  BLM_HIP(hipGetLastError());
   return BLM_OK;
 }
 

@@ -226,7 +226,9 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN]
               if (p.aux) p.aux[o] = v;
               v = gp_mix(v, p.coef, p.N, col) * keep[rr];
             } else if constexpr (EPI == BLM_EPI_MUL_DGP_MIX) {
-              v *= dgp_mix(p.aux[o], p.coef, p.N, col) * keep[rr];
+              v *= keep[rr];
+              if (p.C2) p.C2[o] = v;
+              v *= dgp_mix(p.aux[o], p.coef, p.N, col);
             } else if constexpr (EPI == BLM_EPI_BAYES_WGRAD) {
               const float dW = v;
               const int rel = row - p.vc.row_lo;

@@ -26,7 +26,7 @@ from .ops import Drop, NoiseSpec
 
 __all__ = ["NoiseState", "PositionalEncoding", "MultiheadAttention", "BayesMultiheadAttention", "BayesLinear",
            "StandardTransformerEncoderLayer", "BayesTransformerEncoderLayer", "BayesTransformerModel",
-           "TransformerModel", "RNNModel", "BayesRNNModel", "Bayes2LSTM", "repackage_hidden"]
+           "TransformerModel", "GPNN", "GaussTransformerEncoderLayer", "GaussTransformerModel", "RNNModel", "BayesRNNModel", "Bayes2LSTM", "repackage_hidden"]
 
 
 class NoiseState:
@@ -334,6 +334,97 @@ class BayesTransformerModel(_LMHead):
             x = layer(x, src_mask=self.src_mask)
         if self.bayes_embed:
             x = ops.linear(x, self.embed_mean.t())  # model.py:1302-1304, mean weights
+        return self.decoder(x)
+
+
+class GPNN(_Site):
+    """Parameters of the reference's GPNN (model.py:1780-1906): an affine map followed by a learnt
+    mixture of activations, sum_i act_i(z) * coef[i].  ``gpnn_type``: 0 deterministic, 1 Bayesian
+    coefficients, 2 Bayesian weights, 3 both -- which only decides which ``*_lgstd`` tensors exist
+    and enter the KL (with the '-1', model.py:1816-1826): ``self.sample`` is False and no reference
+    entry point ever sets it (model.py:1799), so the forward uses the mean tensors."""
+
+    def __init__(self, input_size, output_size, act_set=('sigmoid', 'tanh', 'relu'), gpnn_type=0):
+        super().__init__()
+        self.input_size, self.output_size, self.gpnn_type, self.act_set = input_size, output_size, gpnn_type, list(act_set)
+        s = 1.0 / math.sqrt(output_size)
+        lo, hi = 2 * np.log(s), np.log(s)
+        self.weights_mean = nn.Parameter(torch.empty(output_size, input_size).uniform_(-s, s))
+        self.bias_mean = nn.Parameter(torch.zeros(output_size))
+        self.coef_mean = nn.Parameter(torch.empty(len(act_set), output_size).uniform_(0, 1))
+        self.sample = False
+        if gpnn_type in (1, 3):
+            self.coef_lgstd = nn.Parameter(torch.empty(len(act_set), output_size).uniform_(lo, hi))
+        if gpnn_type in (2, 3):
+            self.weights_lgstd = nn.Parameter(torch.empty(output_size, input_size).uniform_(lo, hi))
+            self.bias_lgstd = nn.Parameter(torch.empty(output_size).uniform_(lo, hi))
+
+    def kl_divergence(self, prior=None):
+        if prior is not None:
+            raise BayesLMError("GPNN.kl_divergence(prior=...) returns 0 in the reference; not supported")
+        kl = 0
+        if self.gpnn_type in (1, 3):
+            kl = kl + ops.kl_mean(self.coef_mean, self.coef_lgstd, minus_one=True)
+        if self.gpnn_type in (2, 3):
+            kl = kl + ops.kl_mean(self.weights_mean, self.weights_lgstd, minus_one=True)
+            kl = kl + ops.kl_mean(self.bias_mean, self.bias_lgstd, minus_one=True)
+        return kl
+
+
+class GaussTransformerEncoderLayer(_Site):
+    """Reference model.py:2250-2295: GPNN replaces GELU(linear1(x)); ``linear1`` exists in the
+    state_dict but is unused (model.py:2257,2283)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, gauss_pos=None):
+        super().__init__()
+        if not (0 <= gauss_pos <= 3):
+            raise BayesLMError("gauss_pos 4 (GPNN2 random features) is not built by this engine")
+        self.gauss_pos = self.gpnn_type = gauss_pos
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = _ProjHolder(d_model, dim_feedforward)
+        self.linear2 = _ProjHolder(dim_feedforward, d_model)
+        self.gpnn = GPNN(d_model, dim_feedforward, act_set=['tanh', 'sigmoid', 'relu', 'gelu'], gpnn_type=gauss_pos)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.p = dropout
+
+    def forward(self, src, src_mask=None):
+        a = self.self_attn(src, src, src, attn_mask=src_mask)[0]
+        x = ops.add_dropout_ln(src, a, self.norm1.weight, self.norm1.bias, self.norm1.eps, self._drop(self.p, 1))
+        g = self.gpnn
+        f = ops.ffn_gp(x, g.weights_mean, g.bias_mean, g.coef_mean, self.linear2.weight, self.linear2.bias,
+                       self._drop(self.p, 0))
+        return ops.add_dropout_ln(x, f, self.norm2.weight, self.norm2.bias, self.norm2.eps, self._drop(self.p, 2))
+
+
+class GaussTransformerModel(_LMHead):
+    """Reference model.py:2298-2364: layer 0 is the GP layer for gauss_pos 0..3 (built with the
+    model's dropout), gauss_pos > 4 builds an all-standard stack."""
+
+    def __init__(self, ntoken, ninp, nhead, nhid, nlayers, dropout=0.5, tie_weights=False, gauss_pos=4):
+        super().__init__()
+        self.model_type = "Transformer"
+        self.src_mask = None
+        self.ninp = ninp
+        self.pos_encoder = PositionalEncoding(ninp, dropout)
+        self.transformerlayers = nn.ModuleList()
+        if gauss_pos <= 4:
+            self.transformerlayers.append(GaussTransformerEncoderLayer(ninp, nhead, nhid, dropout, gauss_pos=gauss_pos))
+            for _ in range(nlayers - 1):
+                self.transformerlayers.append(StandardTransformerEncoderLayer(ninp, nhead, nhid, dropout))
+        else:
+            for _ in range(nlayers):
+                self.transformerlayers.append(StandardTransformerEncoderLayer(ninp, nhead, nhid, dropout))
+        self._init_io(ntoken, ninp, ninp, tie_weights)
+        self.noise_state = bind_state(self, NoiseState())
+
+    def forward(self, src, has_mask=True):
+        if not has_mask:
+            raise BayesLMError("has_mask=False: the fused attention kernel is causal only")
+        x = ops.embed(src, self.encoder.weight, self.pos_encoder.table(), math.sqrt(self.ninp),
+                      self.pos_encoder._drop(self.pos_encoder.p))
+        for layer in self.transformerlayers:
+            x = layer(x, src_mask=True)
         return self.decoder(x)
 
 

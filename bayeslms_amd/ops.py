@@ -17,7 +17,7 @@ import torch
 from . import _lib as L
 from ._lib import BayesLMError, check, dev_tensor, lib, ptr, stream
 
-__all__ = ["Drop", "NoiseSpec", "linear", "bayes_linear", "ffn", "attention", "attention_qkv", "add_dropout_ln",
+__all__ = ["Drop", "NoiseSpec", "linear", "bayes_linear", "ffn", "ffn_gp", "attention", "attention_qkv", "add_dropout_ln",
            "embed", "add_pe", "dropout", "cross_entropy", "kl_mean", "philox_normal", "sample_weight", "sampled", "lstm_layer",
            "clip_sgd", "gemm", "PtrTable", "set_grad_ready_hook", "KernelTimer", "set_kernel_timer"]
 
@@ -409,6 +409,60 @@ class _FFN(torch.autograd.Function):
 
 def ffn(x, w1, b1, w2, b2=None, lgstd2=None, noise=None, kl_lambda=0.0, fused=False, drop=NO_DROP):
     return _FFN.apply(x, w1, b1, w2, b2, lgstd2, noise, kl_lambda, fused, drop)
+
+
+class _FFNGP(torch.autograd.Function):
+    """y = lin2(drop(sum_i act_i(x Wg^T + bg) coef[i]))   GaussTransformerEncoderLayer FFN
+    (model.py:2283): GPNN replaces GELU(linear1(x)); acts = tanh, sigmoid, relu, gelu (model.py:2263)."""
+
+    @staticmethod
+    def forward(ctx, x, wg, bg, coef, w2, b2, drop):
+        x = _f32(x, "x")
+        F_, D = wg.shape
+        N2 = w2.shape[0]
+        M = x.numel() // D
+        B = x.shape[-2]
+        z = torch.empty(M, F_, device=x.device, dtype=torch.float32) if any(ctx.needs_input_grad) else None
+        h = torch.empty(M, F_, device=x.device, dtype=torch.float32)
+        gemm(L.GEMM_NT, x, wg, h, M, F_, D, D, D, F_, epilogue=L.EPI_GP_MIX, bias=bg, aux=z, coef=coef, drop=drop, drop_B=B)
+        y = torch.empty(*x.shape[:-1], N2, device=x.device, dtype=torch.float32)
+        gemm(L.GEMM_NT, h, w2, y, M, N2, F_, F_, F_, N2, epilogue=L.EPI_BIAS, bias=b2)
+        ctx.save_for_backward(x, z, h)
+        ctx.p = (wg, bg, coef, w2, b2, drop, B)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, h = ctx.saved_tensors
+        wg, bg, coef, w2, b2, drop, B = ctx.p
+        dy = _f32(dy, "dy")
+        F_, D = wg.shape
+        N2 = w2.shape[0]
+        M = x.numel() // D
+        dz = torch.empty(M, F_, device=x.device, dtype=torch.float32)
+        dhk = torch.empty(M, F_, device=x.device, dtype=torch.float32) if coef.requires_grad else None
+        gemm(L.GEMM_NN, dy, w2, dz, M, F_, N2, N2, F_, F_, epilogue=L.EPI_MUL_DGP_MIX, aux=z, coef=coef, C2=dhk,
+             drop=drop, drop_B=B)
+        if coef.requires_grad:
+            check(lib().blm_gp_coef_grad(ptr(dhk), ptr(z), ptr(_grad_buf(coef)), M, F_, stream()), "blm_gp_coef_grad")
+        if w2.requires_grad:
+            gemm(L.GEMM_TN, dy, h, _grad_buf(w2), N2, F_, M, N2, F_, F_, accumulate=True)
+        if b2.requires_grad:
+            _colsum_into(dy, M, N2, _grad_buf(b2))
+        if wg.requires_grad:
+            gemm(L.GEMM_TN, dz, x, _grad_buf(wg), F_, D, M, F_, D, D, accumulate=True)
+        if bg.requires_grad:
+            _colsum_into(dz, M, F_, _grad_buf(bg))
+        _notify(coef, w2, b2, wg, bg)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(L.GEMM_NN, dz, wg, dx, M, D, F_, F_, D, D)
+        return (dx,) + (None,) * 6
+
+
+def ffn_gp(x, wg, bg, coef, w2, b2, drop=NO_DROP):
+    return _FFNGP.apply(x, wg, bg, coef, w2, b2, drop)
 
 
 # ----------------------------------------------------------------------------

@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Train and evaluate a neural LM -- same command line as the reference's
+steps/pytorchnn/train.py (argument names, types, defaults: train.py:28-103; log line formats
+:426-430,476-478,544-545; best-checkpoint / LR-halving / early-stop loop :464-519), running on the
+HIP engine.  New optional behaviour: launched under ``torchrun`` it trains data-parallel, each rank
+owning a slice of the global batch columns (``--batch-size`` stays the GLOBAL batch).
+
+    python -m bayeslms_amd.train --data DIR --model Transformer --emsize 512 --nhid 4096 --nlayers 6 \
+        --nhead 8 --uncertainty Bayesian --T_bayes_pos FFN --tied --cuda --save model.pt
+"""
+import argparse
+import math
+import os
+import random
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Train and evaluate a neural language model (MI355X engine).")
+    p.add_argument('--data', type=str, default='./data/pytorchnn', help='location of the data corpus')
+    p.add_argument('--model', type=str, default='LSTM', help='LSTM or Transformer')
+    p.add_argument('--emsize', type=int, default=200)
+    p.add_argument('--nhid', type=int, default=200)
+    p.add_argument('--nlayers', type=int, default=2)
+    p.add_argument('--nhead', type=int, default=2)
+    p.add_argument('--uncertainty', type=str, default='none', help='[none | Bayesian | Gaussian | Variational]')
+    p.add_argument('--T_bayes_pos', type=str, default='none', help='[none | FFN | MHA | EMB]')
+    p.add_argument('--L_bayes_pos', type=int, default=0, help='0 none, 1 input, 2 forget, 3 cell, 4 output gate')
+    p.add_argument('--L_gauss_pos', type=str, default='00')
+    p.add_argument('--L_v_pos', type=str, default='11')
+    p.add_argument('--T_gauss_pos', type=int, default=3)
+    p.add_argument('--T_v_pos', type=int, default=0)
+    p.add_argument('--mark', type=str, default='none')
+    p.add_argument('--lr', type=float, default=0.1)
+    p.add_argument('--batch-size', type=int, default=20, metavar='N')
+    p.add_argument('--epochs', type=int, default=20)
+    p.add_argument('--seq_len', type=int, default=35)
+    p.add_argument('--clip', type=float, default=0.25)
+    p.add_argument('--dropout', type=float, default=0.2)
+    p.add_argument('--tied', action='store_true')
+    p.add_argument('--optimizer', type=str, default='SGD')
+    p.add_argument('--log-interval', type=int, default=200, metavar='N')
+    p.add_argument('--cuda', action='store_true', help='required: the engine has no CPU path')
+    p.add_argument('--save', type=str, default='model.pt')
+    p.add_argument('--seed', type=int, default=1111)
+    p.add_argument('--resume', type=str, default='')
+    p.add_argument('--debug', action='store_true')
+    p.add_argument('--work_dir', default='TFM', type=str)
+    p.add_argument('--prior', default="False", type=str)
+    p.add_argument('--prior_path', default='steps/pytorchnn/prior', type=str)
+    p.add_argument('--prior2_path', default='steps/pytorchnn/prior/transformer2/', type=str)
+    # new, optional
+    p.add_argument('--fused-sampling', type=int, default=0, help='1: eps generated inside the GEMM tile loader')
+    return p
+
+
+def build_model(args, ntokens):
+    """Model dispatch of train.py:193-223."""
+    from . import model as M
+    if args.model == 'Transformer':
+        if args.uncertainty == 'none':
+            return M.TransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, args.dropout, "gelu", args.tied)
+        if args.uncertainty == 'Bayesian':
+            return M.BayesTransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, args.dropout,
+                                           args.tied, args.T_bayes_pos)
+        if args.uncertainty == 'Gaussian':
+            return M.GaussTransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, args.dropout,
+                                           args.tied, args.T_gauss_pos)
+    else:
+        if args.uncertainty == 'none':
+            return M.RNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, args.dropout, args.tied)
+        if args.uncertainty == 'Bayesian':
+            return M.BayesRNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, args.dropout, args.tied,
+                                   args.L_bayes_pos)
+    raise SystemExit("--model %s --uncertainty %s is not built by this engine yet" % (args.model, args.uncertainty))
+
+
+def kl_selector(args):
+    """Which module's KL train.py adds to the loss for this flag combination (train.py:335-399).
+    Returns None or fn(model) -> KL tensor; ``fn.fusable`` marks KLs whose gradient the Bayesian
+    wgrad epilogue can add itself."""
+    fn = None
+    if args.uncertainty == 'Bayesian':
+        if args.model == 'LSTM' and 1 <= args.L_bayes_pos <= 4:
+            fn = lambda m: m.rnn.kl_divergence()  # noqa: E731
+            fn.fusable = False
+        elif args.model == 'Transformer':
+            if args.T_bayes_pos == 'FFN':
+                fn = lambda m: m.transformerlayers[0].linear2.kl_divergence()  # noqa: E731
+                fn.fusable = True
+            elif args.T_bayes_pos == 'MHA':
+                fn = lambda m: m.transformerlayers[0].self_attn.o_net.kl_divergence()  # noqa: E731
+                fn.fusable = True
+            elif args.T_bayes_pos == 'EMB':
+                fn = lambda m: m.embed_kl_divergence()  # noqa: E731
+                fn.fusable = False
+    elif args.uncertainty == 'Gaussian' and args.model == 'Transformer' and 1 <= args.T_gauss_pos <= 3:
+        fn = lambda m: m.transformerlayers[0].gpnn.kl_divergence()  # noqa: E731
+        fn.fusable = False
+    return fn
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    is_main = rank == 0
+
+    def say(*a):
+        if is_main:
+            print(*a, flush=True)
+
+    random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    if not args.cuda or not torch.cuda.is_available():
+        raise SystemExit("bayeslms_amd.train needs --cuda and an MI355X: there is no CPU path")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from . import data as D, engine
+    from .model import repackage_hidden
+
+    say('Configurations')
+    for k, v in vars(args).items():
+        say(k, v)
+    corpus = D.Corpus(args.data)
+    say("train set:", len(corpus.train))
+    say("valid set:", len(corpus.valid))
+    say("test set:", len(corpus.test))
+    say("num tokens:", len(corpus.dictionary))
+    frac = {"base-0.5set": 2, "base-0.25set": 4, "base-0.1set": 10, "base-0.05set": 20}.get(args.mark, 1)  # train.py:151-165
+    pruning_train = int(len(corpus.train) / frac)
+    eval_batch_size = 20
+    train_data = D.batchify(corpus.train[:pruning_train], args.batch_size, device, rank, world)
+    val_data = D.batchify(corpus.valid, eval_batch_size, device)
+    test_data = D.batchify(corpus.test, eval_batch_size, device)
+    ntokens = len(corpus.dictionary)
+
+    model = build_model(args, ntokens)
+    if args.prior == "True":  # partial state-dict load, keys filtered by name (train.py:239-258)
+        prior = torch.load(os.path.join(args.prior_path, 'model.pt'), map_location='cpu')
+        own = model.state_dict()
+        own.update({k: v for k, v in prior.items() if k in own})
+        model.load_state_dict(own)
+    model = model.to(device)
+    model.set_fused_sampling(bool(args.fused_sampling))
+    total_params = sum(x.data.nelement() for x in model.parameters())
+    say('Args: {}'.format(args))
+    say('Model total parameters: {}'.format(total_params))
+    say(str(model.transformerlayers if args.model == 'Transformer' else model.rnn))
+
+    kl_fn = kl_selector(args)
+    kl_scale = float(args.seq_len) / float(len(train_data))  # KL / len(train_data) * seq_len (train.py:338)
+    trainer = engine.Trainer(model, lr=args.lr, clip=args.clip, momentum=0.9, kl_scale=kl_scale, seed=args.seed,
+                             rank=rank, world=world)
+    is_rnn = args.model != 'Transformer'
+
+    def train_epoch(epoch, lr):
+        total_loss = 0.
+        start = time.time()
+        hidden = model.init_hidden(train_data.size(1)) if is_rnn else None
+        for batch, i in enumerate(range(0, train_data.size(0) - 1, args.seq_len)):
+            data, targets = D.get_batch(train_data, i, args.seq_len)
+            if is_rnn:
+                hidden = repackage_hidden(hidden)
+            loss, kl, hidden = trainer.step(data, targets, hidden, kl_fn)
+            total_loss = total_loss + loss  # stays on the device: one host sync per log interval (train.py:422 syncs per step)
+            if batch % args.log_interval == 0 and batch > 0:
+                cur = float(total_loss) / args.log_interval
+                elapsed = time.time() - start
+                say('| epoch {:3d} | {:5d}/{:5d} batches | lr {:02.3f} | ms/batch {:5.2f} | loss {:5.2f} | '
+                    'kl_loss {:5.4} | ppl {:8.2f}'.format(epoch, batch, len(train_data) // args.seq_len, lr,
+                                                          elapsed * 1000 / args.log_interval, cur,
+                                                          float(kl) if kl is not None else 0., math.exp(min(cur, 80.0))))
+                total_loss = 0.
+                start = time.time()
+
+    lr = args.lr
+    best_val = None
+    counter = 0
+    say("Start training")
+    try:
+        for epoch in range(1, args.epochs + 1):
+            t0 = time.time()
+            train_epoch(epoch, lr)
+            val_loss = engine.evaluate(model, val_data, args.seq_len)
+            say('-' * 89)
+            say('| end of epoch {:3d} | time: {:5.2f}s | valid loss {:5.2f} | valid ppl {:8.2f}'.format(
+                epoch, time.time() - t0, val_loss, math.exp(val_loss)))
+            say('-' * 89)
+            if not best_val or val_loss < best_val:
+                if is_main:
+                    with open(args.save, 'wb') as f:
+                        torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, f)
+                best_val = val_loss
+            else:  # train.py:503-508: halve LR, fresh SGD (momentum reset), reload best
+                lr /= 2.
+                trainer.reset_optimizer(lr)
+                if world > 1:
+                    dist.barrier()
+                with torch.no_grad():
+                    sd = torch.load(args.save, map_location='cpu')
+                    own = model.state_dict()
+                    for k, v in sd.items():
+                        own[k].copy_(v)
+                counter += 1
+            if counter == 8:
+                break
+    except KeyboardInterrupt:
+        say('-' * 89)
+        say('Exiting from training early')
+
+    if world > 1:
+        dist.barrier()
+    if os.path.exists(args.save):
+        with torch.no_grad():
+            sd = torch.load(args.save, map_location='cpu')
+            own = model.state_dict()
+            for k, v in sd.items():
+                own[k].copy_(v)
+    test_loss = engine.evaluate(model, test_data, args.seq_len)
+    say('=' * 89)
+    say('| End of training | test loss {:5.2f} | test ppl {:8.2f}'.format(test_loss, math.exp(test_loss)))
+    say('=' * 89)
+    if world > 1:
+        dist.destroy_process_group()
+    return test_loss
+
+
+if __name__ == "__main__":
+    main()

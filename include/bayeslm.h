@@ -123,7 +123,7 @@ typedef enum blm_epilogue {
   BLM_EPI_MUL_DGELU = 3,   /* C = acc * gelu_erf'(aux[m,n])                            */
   BLM_EPI_BAYES_WGRAD = 4, /* TN only, C = dmu, C2 = dlgstd, see below                 */
   BLM_EPI_GP_MIX = 5,      /* z = acc + bias; aux = z; C = sum_i act_i(z) coef[i,n]     */
-  BLM_EPI_MUL_DGP_MIX = 6  /* C = acc * sum_i act_i'(aux) coef[i,n]                     */
+  BLM_EPI_MUL_DGP_MIX = 6  /* C = acc * sum_i act_i'(aux) coef[i,n]; C2 (optional) = acc (after dropout) */
 } blm_epilogue;
 
 #define BLM_GEMM_ACCUMULATE 1u /* C (+= C2) accumulate into existing contents */
@@ -237,6 +237,10 @@ int blm_ce_fwd_bwd(const float* logits, int64_t ld, const int64_t* tgt, float* n
  * forward time. */
 int blm_ce_bwd(const float* logits, int64_t ld, const int64_t* tgt, const float* lse, const float* g_dev, float scale,
                float* dlogits, int M, int V, void* stream);
+
+/* dcoef[i,n] += sum_m g[m,n] * act_i(z[m,n]), i = tanh, sigmoid, relu, gelu: gradient of the GPNN
+ * mixture coefficients (autograd of model.py:1885-1899). */
+int blm_gp_coef_grad(const float* g, const float* z, float* dcoef, int M, int N, void* stream);
 
 /* out[n] (+)= sum_m x[m,n]   (bias gradients). */
 int blm_colsum(const float* x, int64_t ld, float* out, int M, int N, int accumulate, void* stream);

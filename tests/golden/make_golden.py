@@ -252,7 +252,128 @@ def f8_data():
          get_batch_data=npy(b[i:i + sl]), get_batch_target=npy(b[i + 1:i + 1 + sl].view(-1)))
 
 
+# ---------------------------------------------------------------- F7 scorer, F6 train.py checkpoints
+def _tiny_corpus(dtmp, nwords=30, seed=5, sizes=(("train", 260), ("valid", 40), ("test", 36))):
+    rng = np.random.RandomState(seed)
+    words = ["<s>", "<unk>"] + ["w%03d" % i for i in range(2, nwords)]
+    with open(os.path.join(dtmp, "words.txt"), "w") as f:
+        for i, w in enumerate(words):
+            f.write("%s %d\n" % (w, i))
+    texts = {}
+    for split, n in sizes:
+        lines = [" ".join(words[rng.randint(2, nwords)] for _ in range(1 + rng.poisson(5))) for _ in range(n)]
+        texts[split] = "\n".join(lines) + "\n"
+        with open(os.path.join(dtmp, split + ".txt"), "w") as f:
+            f.write(texts[split])
+    return words, texts
+
+
+def f7_scorer():
+    """Drives the reference scorer's main() on CPU (its hard-coded .cuda() calls are patched to
+    identity in this process) and keeps its output file as the vector."""
+    import importlib
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    scorer = importlib.import_module("compute_sentence_scores_bayes_jianwei")
+    for tag, margs, build in (
+        ("lstm_bayes3", ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Bayesian",
+                         "--L_bayes_pos", "3"],
+         lambda V: ref.BayesRNNModel("LSTM", V, 12, 12, 2, 0.5, True, 3)),
+        ("tlm_ffn", ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                     "--uncertainty", "Bayesian", "--T_bayes_pos", "FFN"],
+         lambda V: ref.BayesTransformerModel(V, 16, 4, 32, 2, 0.5, True, "FFN")),
+    ):
+        with tempfile.TemporaryDirectory() as dtmp:
+            words, _ = _tiny_corpus(dtmp)
+            rng = np.random.RandomState(11)
+            nb = []
+            for u in range(4):
+                for n in range(1, 4):
+                    ln = rng.randint(0, 7)
+                    toks = [words[rng.randint(2, 30)] if rng.rand() > 0.15 else "zzz" for _ in range(ln)]
+                    nb.append("utt%d-A-%d %s" % (u, n, " ".join(toks)))
+            nbest_txt = "\n".join(nb) + "\n"
+            with open(os.path.join(dtmp, "nbest.txt"), "w") as f:
+                f.write(nbest_txt)
+            torch.manual_seed(77)
+            with contextlib.redirect_stdout(io.StringIO()):
+                m = build(len(words))
+            torch.save(m.state_dict(), os.path.join(dtmp, "model.pt"))
+            argv = ["scorer", "--nbest-list", os.path.join(dtmp, "nbest.txt"), "--outfile", os.path.join(dtmp, "out.txt"),
+                    "--vocabulary", os.path.join(dtmp, "words.txt"), "--model-path", os.path.join(dtmp, "model.pt")] + margs
+            old = sys.argv
+            sys.argv = argv
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    scorer.main()
+            finally:
+                sys.argv = old
+            out_txt = open(os.path.join(dtmp, "out.txt")).read()
+            save("scorer_" + tag, words=np.array(words), nbest_txt=np.array(nbest_txt), scores_txt=np.array(out_txt),
+                 argv=np.array(margs), **pack_sd(m))
+
+
+def f6_train_checkpoint():
+    """Runs the reference train.py itself (subprocess, CPU, 1 epoch, tiny corpus) and keeps the
+    checkpoint it saved plus the eval losses: the printed ones (2 decimals) and the same quantity
+    recomputed at full precision with the reference model classes on that checkpoint."""
+    import re
+    import subprocess
+    for tag, margs, build in (
+        ("tlm_ffn", ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                     "--uncertainty", "Bayesian", "--T_bayes_pos", "FFN"],
+         lambda V: ref.BayesTransformerModel(V, 16, 4, 32, 2, 0.0, True, "FFN")),
+        ("lstm_bayes3", ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Bayesian",
+                         "--L_bayes_pos", "3"],
+         lambda V: ref.BayesRNNModel("LSTM", V, 12, 12, 2, 0.0, True, 3)),
+    ):
+        with tempfile.TemporaryDirectory() as dtmp:
+            words, texts = _tiny_corpus(dtmp)
+            save_path = os.path.join(dtmp, "model.pt")
+            cmd = [sys.executable, os.path.join(REF, "train.py"), "--data", dtmp, "--epochs", "1", "--batch-size", "4",
+                   "--seq_len", "7", "--dropout", "0.0", "--lr", "0.5", "--clip", "1.0", "--tied", "--save", save_path,
+                   "--log-interval", "5"] + margs
+            env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=REF)
+            log = subprocess.run(cmd, cwd=dtmp, env=env, capture_output=True, text=True, check=True).stdout
+            printed_valid = float(re.search(r"valid loss\s+([0-9.]+)", log).group(1))
+            printed_test = float(re.search(r"test loss\s+([0-9.]+)", log).group(1))
+            sd = torch.load(save_path, map_location="cpu")
+            with contextlib.redirect_stdout(io.StringIO()):
+                m = build(len(words))
+            m.load_state_dict(sd)
+            m.eval()
+            c = refdata.Corpus(dtmp)
+            out = {}
+            for split in ("valid", "test"):
+                ids = getattr(c, split)
+                bsz, seq_len = 20, 7
+                nb = ids.size(0) // bsz
+                src = ids.narrow(0, 0, nb * bsz).view(bsz, -1).t().contiguous()
+                total = 0.0
+                hidden = m.init_hidden(bsz) if hasattr(m, "init_hidden") else None
+                with torch.no_grad():
+                    for i in range(0, src.size(0) - 1, seq_len):
+                        n = min(seq_len, len(src) - 1 - i)
+                        data, tgt = src[i:i + n], src[i + 1:i + 1 + n].view(-1)
+                        if hidden is None:
+                            o = m(data)
+                        else:
+                            o, hidden = m(data, hidden)
+                        total += len(data) * torch.nn.functional.cross_entropy(o.view(-1, len(words)), tgt).item()
+                out[split] = total / (len(src) - 1)
+            assert abs(out["valid"] - printed_valid) < 0.006 and abs(out["test"] - printed_test) < 0.006, (out, log[-400:])
+            save("train_ckpt_" + tag, words=np.array(words), train_txt=np.array(texts["train"]),
+                 valid_txt=np.array(texts["valid"]), test_txt=np.array(texts["test"]), argv=np.array(margs),
+                 valid_loss=np.float64(out["valid"]), test_loss=np.float64(out["test"]),
+                 printed_valid=np.float64(printed_valid), printed_test=np.float64(printed_test),
+                 **{"sd/" + k: npy(v) for k, v in sd.items() if not k.endswith("pos_encoder.pe")})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "late":
+        f6_train_checkpoint()
+        f7_scorer()
+        sys.exit(0)
     f1_bayes_linear()
     for bp in ("FFN", "MHA", "EMB", "none"):
         f3_transformer(bp)
@@ -263,3 +384,5 @@ if __name__ == "__main__":
         f2_bayes_rnn(pos)
     f2_rnn_baseline()
     f8_data()
+    f6_train_checkpoint()
+    f7_scorer()

@@ -139,3 +139,83 @@ def test_rnn_baseline_matches_reference():
     torch.testing.assert_close(l1, g["logits_eval_0"], **TOL)
     torch.testing.assert_close(l2, g["logits_eval_1"], **TOL)
     torch.testing.assert_close(hid[1], g["c_eval"], **TOL)
+
+
+def _write_corpus(g, d):
+    import os
+    with open(os.path.join(d, "words.txt"), "w") as f:
+        f.write("".join("%s %d\n" % (w, i) for i, w in enumerate(g["words"])))
+    for s in ("train", "valid", "test"):
+        if s + "_txt" in g:
+            with open(os.path.join(d, s + ".txt"), "w") as f:
+                f.write(str(g[s + "_txt"]))
+
+
+def oracle_eval_loss(sd, ids, is_rnn, nhead, pos, bsz=20, seq_len=7):
+    """train.py:441-458 with the oracle forward."""
+    nb = ids.size(0) // bsz
+    src = ids.narrow(0, 0, nb * bsz).view(bsz, -1).t().contiguous()
+    total = 0.0
+    H = sd["rnn.weight_hh_mean_1"].shape[1] if is_rnn else 0
+    hid = (torch.zeros(2, bsz, H), torch.zeros(2, bsz, H)) if is_rnn else None
+    for i in range(0, src.size(0) - 1, seq_len):
+        n = min(seq_len, len(src) - 1 - i)
+        data, tgt = src[i:i + n], src[i + 1:i + 1 + n].reshape(-1)
+        if is_rnn:
+            out, hid = O.bayes_rnn_lm(data, hid, sd, pos, None)
+        else:
+            out = O.transformer_lm(data, sd, nhead, None)
+        total += len(data) * float(O.cross_entropy_mean(out, tgt))
+    return total / (len(src) - 1)
+
+
+@pytest.mark.parametrize("tag", ["tlm_ffn", "lstm_bayes3"])
+def test_eval_loss_of_reference_checkpoint(tag, tmp_path):
+    """A checkpoint written by the reference's own train.py: the oracle reproduces its valid/test loss."""
+    from bayeslms_amd import data as D
+    g, sd, _ = load_golden("train_ckpt_" + tag)
+    _write_corpus(g, str(tmp_path))
+    c = D.Corpus(str(tmp_path))
+    is_rnn = tag.startswith("lstm")
+    if not is_rnn:
+        sd["pos_encoder.pe"] = O.positional_table(64, sd["encoder.weight"].shape[1])
+    for split in ("valid", "test"):
+        got = oracle_eval_loss(sd, getattr(c, split), is_rnn, 4, 3)
+        assert abs(got - float(g[split + "_loss"])) < 1e-5 * float(g[split + "_loss"])
+        assert abs(got - float(g["printed_" + split])) < 0.006  # what train.py printed (2 decimals)
+
+
+@pytest.mark.parametrize("tag", ["tlm_ffn", "lstm_bayes3"])
+def test_scorer_scores_of_reference(tag):
+    """Per-hypothesis scores written by the reference scorer: oracle restatement of its loop
+    (sum of token NLL, '<s>' wrapping, OOV -> <unk>, LSTM hidden carried from the first hypothesis)."""
+    from bayeslms_amd import compute_sentence_scores as S
+    g, sd, _ = load_golden("scorer_" + tag)
+    vocab = {w: i for i, w in enumerate(g["words"])}
+    want = [(ln.split()[0], float(ln.split()[1])) for ln in str(g["scores_txt"]).splitlines()]
+    is_rnn = tag.startswith("lstm")
+    H = sd["rnn.weight_hh_mean_1"].shape[1] if is_rnn else 0
+    hid = (torch.zeros(2, 1, H), torch.zeros(2, 1, H)) if is_rnn else None
+    got = []
+    import collections
+    nbest = collections.OrderedDict()
+    for line in str(g["nbest_txt"]).splitlines():
+        parts = line.strip().split(' ', 1)
+        key, hyp = (parts[0], parts[1]) if len(parts) == 2 else (line.strip(), ' ')
+        nbest.setdefault(key.rsplit('-', 1)[0], []).append(hyp)
+    for key, hyps in nbest.items():
+        first = None
+        for n, hyp in enumerate(hyps, 1):
+            x, t = S.get_input_and_target(hyp, vocab)
+            xs, ts = torch.tensor(x).view(-1, 1), torch.tensor(t)
+            if is_rnn:
+                out, h_new = O.bayes_rnn_lm(xs, hid, sd, 3, None)
+                first = h_new if first is None else first
+            else:
+                out = O.transformer_lm(xs, sd, 4, None)
+            got.append(("%s-%d" % (key, n), float(O.sentence_score(out, ts))))
+        if is_rnn:
+            hid = first
+    assert [k for k, _ in got] == [k for k, _ in want]
+    for (_, a), (_, b) in zip(got, want):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b))
