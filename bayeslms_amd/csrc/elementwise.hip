@@ -454,7 +454,9 @@ __global__ __launch_bounds__(TPB) void gp_coef_grad_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ clip + SGD
-__global__ __launch_bounds__(TPB) void sqnorm_multi_kernel(const float* const* grads, const int64_t* sizes, float* sq) {
+// Deterministic (replicas must stay bit-identical after the all-reduce): each block writes its
+// partial sum, one block adds the partials in a fixed order.
+__global__ __launch_bounds__(TPB) void sqnorm_multi_kernel(const float* const* grads, const int64_t* sizes, float* ws) {
   __shared__ float red[TPB / 64];
   const float* g = grads[blockIdx.y];
   const long n = sizes[blockIdx.y];
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(TPB) void sqnorm_multi_kernel(const float* const* g
   }
   for (long i = (n4 << 2) + (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) a += g[i] * g[i];
   const float t = block_sum<TPB / 64>(a, red);
-  if (threadIdx.x == 0 && t != 0.f) atomicAdd(sq, t);
+  if (threadIdx.x == 0) ws[(long)blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
 __global__ __launch_bounds__(TPB) void clip_sgd_multi_kernel(float* const* params, const float* const* grads,
@@ -703,10 +705,16 @@ extern "C" int blm_colsum(const float* x, int64_t ld, float* out, int M, int N, 
   return BLM_OK;
 }
 
-extern "C" int blm_sqnorm_multi(const float* const* grads, const int64_t* sizes, int n, float* sq, void* stream) {
-  if (!grads || !sizes || !sq || n < 0) return blm_fail(BLM_ERR_INVALID, "blm_sqnorm_multi: bad arguments");
+extern "C" int64_t blm_sqnorm_ws_floats(int n) { return (int64_t)(n == 1 ? 1024 : 64) * (n > 0 ? n : 1); }
+
+extern "C" int blm_sqnorm_multi(const float* const* grads, const int64_t* sizes, int n, float* sq, float* ws,
+                                void* stream) {
+  if (!grads || !sizes || !sq || !ws || n < 0) return blm_fail(BLM_ERR_INVALID, "blm_sqnorm_multi: bad arguments");
   if (n == 0) return BLM_OK;
-  hipLaunchKernelGGL(sqnorm_multi_kernel, dim3(n == 1 ? 1024 : 64, n), dim3(TPB), 0, ST, grads, sizes, sq);
+  const int gx = n == 1 ? 1024 : 64;
+  hipLaunchKernelGGL(sqnorm_multi_kernel, dim3(gx, n), dim3(TPB), 0, ST, grads, sizes, ws);
+  BLM_HIP(hipGetLastError());
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ST, ws, (long)gx * n, sq);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }

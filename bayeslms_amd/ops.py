@@ -847,6 +847,7 @@ class PtrTable:
         self.bufs = torch.tensor([b.data_ptr() for b in bufs], dtype=torch.int64, device=dev)
         self.sizes = torch.tensor([p.numel() for p in params], dtype=torch.int64, device=dev)
         self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.ws = torch.zeros(int(lib().blm_sqnorm_ws_floats(self.n)), dtype=torch.float32, device=dev)
         self._keep = (params, grads, bufs)
 
 
@@ -855,7 +856,8 @@ def clip_sgd(table, clip, lr, momentum, first, grad_scale=1.0):
     L.require_gfx950()
     table.sq.zero_()
     st = stream()
-    check(lib().blm_sqnorm_multi(ptr(table.grads), ptr(table.sizes), table.n, ptr(table.sq), st), "blm_sqnorm_multi")
+    check(lib().blm_sqnorm_multi(ptr(table.grads), ptr(table.sizes), table.n, ptr(table.sq), ptr(table.ws), st),
+          "blm_sqnorm_multi")
     check(lib().blm_clip_sgd_multi(ptr(table.params), ptr(table.grads), ptr(table.bufs), ptr(table.sizes), table.n,
                                    ptr(table.sq), float(clip), float(lr), float(momentum), 1 if first else 0,
                                    float(grad_scale), st), "blm_clip_sgd_multi")

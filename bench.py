@@ -39,6 +39,8 @@ def parse():
                     help="1: eps generated inside the GEMM tile loader; 0: one materialisation pass; -1: engine default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="columns per GPU (default = the named config)")
+    ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
+                    "rehearsing several ranks on one GPU)")
     return ap.parse_args()
 
 
@@ -90,10 +92,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)  # rehearsal of several ranks on one GPU (gloo); one GPU per rank otherwise
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
 
     from bayeslms_amd import engine, model as M, ops
     from bayeslms_amd.data import batchify, get_batch, synthetic_corpus

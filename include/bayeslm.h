@@ -248,10 +248,13 @@ int blm_colsum(const float* x, int64_t ld, float* out, int M, int N, int accumul
 /* Global-norm clip + SGD momentum over a list of tensors (train.py:419-420,466):
  *   norm = sqrt(sum_i |g_i|^2); c = min(1, clip/(norm+1e-6));
  *   buf = first ? c*g : mom*buf + c*g;  p -= lr*buf
- * Two calls: blm_sqnorm_multi accumulates the squared norm into *sq (must be
- * zeroed by the caller), blm_clip_sgd_multi consumes it.  Pointer tables are
- * DEVICE arrays of n pointers/sizes. */
-int blm_sqnorm_multi(const float* const* grads, const int64_t* sizes, int n, float* sq, void* stream);
+ * Two calls: blm_sqnorm_multi adds the squared norm to *sq (zeroed by the
+ * caller) through per-block partials in ws (>= blm_sqnorm_ws_floats(n)) summed
+ * in a fixed order -- deterministic, so data-parallel replicas stay bit-identical;
+ * blm_clip_sgd_multi consumes it.  Pointer tables are DEVICE arrays of n
+ * pointers/sizes. */
+int64_t blm_sqnorm_ws_floats(int n);
+int blm_sqnorm_multi(const float* const* grads, const int64_t* sizes, int n, float* sq, float* ws, void* stream);
 int blm_clip_sgd_multi(float* const* params, const float* const* grads, float* const* bufs, const int64_t* sizes,
                        int n, const float* sq, float clip, float lr, float momentum, int first, float grad_scale,
                        void* stream);
