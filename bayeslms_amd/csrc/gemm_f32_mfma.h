@@ -55,6 +55,11 @@ __device__ __forceinline__ float gemm_keep(const GemmP& p, int m, int n) {
 }
 
 constexpr int BK = 32;
+// Two MFMA tiles of a wave interleaved (rows 2x+t, one ds_read_b64 per operand pair, even LDS stride)
+// or stacked (rows 32t+x, ds_read2_b32, odd conflict-free stride).  Measured on MI355X
+// (tools/gemm_bench.py): LDS read bandwidth is not the limiter, stacked is 1-7 % faster on the
+// NT shapes because the transposing LDS writes stay conflict-free.
+constexpr bool INTERLEAVE = false;
 
 // ---- global -> registers -------------------------------------------------
 // k-contiguous source, tile [R rows][32 k]: 8 lanes cover one 128-B row.
@@ -153,13 +158,40 @@ __device__ __forceinline__ float dgp_mix(float z, const float* coef, int N, int 
          dgelu_erf(z) * coef[3 * N + n];
 }
 
-// Dropout keep factors for the four rows base_row + {0,1,2,3} at this lane's column: the four
+// ---- LDS operand fragments read by inline asm (explicit double buffering, see compute()) ----
+__device__ __forceinline__ uint32_t lds_u32(const float* p) { return (uint32_t)(uintptr_t)p; }  // LDS byte offset
+
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+template <int W> struct Frag;
+template <> struct Frag<1> {
+  float v;
+  __device__ __forceinline__ void read(uint32_t addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr)); }
+  __device__ __forceinline__ float get(int) const { return v; }
+};
+template <> struct Frag<2> {  // the wave's two interleaved MFMA tiles: adjacent floats, 8-byte aligned
+  f32x2 v;
+  __device__ __forceinline__ void read(uint32_t addr) {
+    if constexpr (INTERLEAVE) asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
+    else asm volatile("ds_read2_b32 %0, %1 offset1:32" : "=v"(v) : "v"(addr));
+  }
+  __device__ __forceinline__ float get(int i) const { return i == 0 ? v.x : v.y; }
+};
+template <int WA, int WB>
+__device__ __forceinline__ void wait_lgkm2(Frag<WA>& a, Frag<WB>& b) {
+  asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a.v), "+v"(b.v));
+}
+template <int WA, int WB>
+__device__ __forceinline__ void wait_lgkm0(Frag<WA>& a, Frag<WB>& b) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v), "+v"(b.v));
+}
+
+// Dropout keep factors for the four rows base_row + {0,1,2,3}*row_stride at this lane's column: the four
 // lanes of a quad own four consecutive columns = one Philox block per row, so lane k generates the
 // block of row base_row + k and the quad exchanges words by DPP broadcasts (1 Philox call per
 // 4 elements instead of 4).  Needs N % 4 == 0 and the quad's first column % 4 == 0.
-__device__ __forceinline__ void gemm_keep_quad(const GemmP& p, int base_row, int col, float (&keep)[4]) {
+__device__ __forceinline__ void gemm_keep_quad(const GemmP& p, int base_row, int row_stride, int col, float (&keep)[4]) {
   const int k = threadIdx.x & 3;
-  const int m = base_row + k;
+  const int m = base_row + k * row_stride;
   const int row = m / p.drop_B, b = m - row * p.drop_B;
   const uint64_t g = ((uint64_t)row * p.drop_global_cols + (uint64_t)(p.drop_col_offset + b)) * (uint64_t)p.N +
                      (uint64_t)(col & ~3);
@@ -178,77 +210,129 @@ __device__ __forceinline__ void gemm_keep_quad(const GemmP& p, int base_row, int
 #undef BLM_QUAD_BCAST
 }
 
-// C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// Keep factors of the two adjacent columns (c0, c0+1), c0 even, of row m: one Philox block.
+__device__ __forceinline__ void gemm_keep_pair(const GemmP& p, int m, int c0, float& k0, float& k1) {
+  const int row = m / p.drop_B, b = m - row * p.drop_B;
+  const uint64_t g = ((uint64_t)row * p.drop_global_cols + (uint64_t)(p.drop_col_offset + b)) * (uint64_t)p.N + (uint64_t)c0;
+  const u32x4 u = philox4x32_10_rolled((uint32_t)(g >> 2), (uint32_t)(g >> 34), p.drop_rng.stream, p.drop_rng.step,
+                                       (uint32_t)p.drop_rng.seed, (uint32_t)(p.drop_rng.seed >> 32));
+  const bool hi = g & 2;
+  k0 = (hi ? u.z : u.x) >= p.drop_thr ? p.drop_inv_keep : 0.f;
+  k1 = (hi ? u.w : u.y) >= p.drop_thr ? p.drop_inv_keep : 0.f;
+}
+
+// C/D map of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  A wave that owns
+// two MFMA tiles along a dimension INTERLEAVES them (tile t holds matrix rows/cols 2*x + t), so the
+// two operand values a lane needs per k-step are adjacent in LDS (one ds_read_b64) and a lane's two
+// output columns are adjacent in C.
+template <int EPI>
+__device__ __forceinline__ void epi_elem(const GemmP& p, bool accum, int row, int col, float acc, float bias, float keep) {
+  const long o = (long)row * p.ldc + col;
+  float v = p.alpha * acc;
+  if constexpr (EPI == BLM_EPI_BIAS) {
+    v += bias;
+  } else if constexpr (EPI == BLM_EPI_BIAS_GELU) {
+    v += bias;
+    if (p.aux) p.aux[o] = v;
+    v = gelu_erf(v) * keep;
+  } else if constexpr (EPI == BLM_EPI_MUL_DGELU) {
+    v *= dgelu_erf(p.aux[o]) * keep;
+  } else if constexpr (EPI == BLM_EPI_GP_MIX) {
+    v += bias;
+    if (p.aux) p.aux[o] = v;
+    v = gp_mix(v, p.coef, p.N, col) * keep;
+  } else if constexpr (EPI == BLM_EPI_MUL_DGP_MIX) {
+    v *= keep;
+    if (p.C2) p.C2[o] = v;
+    v *= dgp_mix(p.aux[o], p.coef, p.N, col);
+  } else if constexpr (EPI == BLM_EPI_BAYES_WGRAD) {
+    const float dW = v;
+    const int rel = row - p.vc.row_lo;
+    if ((unsigned)rel < (unsigned)p.vc.srows) {
+      const long si = (long)rel * p.N + col;
+      const float sig = __expf(p.vc.lgstd[si]);
+      float e;
+      if (p.vc.eps) e = p.vc.eps[si];
+      else e = philox_normal1_rolled(p.vc.rng, (uint64_t)si);
+      const float g2 = dW * e * sig + p.kl_lambda * (sig * sig - 1.0f) * p.kl_inv_n;
+      p.C2[si] = accum ? p.C2[si] + g2 : g2;
+      v = dW + p.kl_lambda * p.wg_mu[o] * p.kl_inv_n;
+    }
+  }
+  if constexpr (EPI == BLM_EPI_NONE) {
+    if (p.atomic) { atomicAdd(p.C + o, v); return; }
+  }
+  p.C[o] = accum ? p.C[o] + v : v;
+}
+
 template <int EPI, int WTM, int WTN>
 __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN], int m0, int n0, int wm, int wn,
                                          int li, int lh) {
+  constexpr bool DROP = (EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_MUL_DGELU || EPI == BLM_EPI_GP_MIX ||
+                         EPI == BLM_EPI_MUL_DGP_MIX);
+  constexpr bool BIAS = (EPI == BLM_EPI_BIAS || EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_GP_MIX);
   const bool accum = p.flags & BLM_GEMM_ACCUMULATE;
+  int col[WTN];
+  float bias[WTN];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) {
+    col[j] = n0 + wn * (32 * WTN) + ((INTERLEAVE && WTN == 2) ? 2 * li + j : 32 * j + li);
+    bias[j] = 0.f;
+    if constexpr (BIAS) bias[j] = col[j] < p.N ? p.bias[col[j]] : 0.f;
+  }
+  // plain/bias epilogues with two adjacent columns per lane store them as one 8-byte access
+  const bool pair_store = INTERLEAVE && WTN == 2 && (EPI == BLM_EPI_NONE || EPI == BLM_EPI_BIAS) && !p.atomic && (p.ldc % 2 == 0) &&
+                          ((reinterpret_cast<uintptr_t>(p.C) & 7) == 0);
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
 #pragma unroll
-    for (int j = 0; j < WTN; ++j) {
-      const int col = n0 + wn * (32 * WTN) + 32 * j + li;
-      const bool col_ok = col < p.N;
-      float bias = 0.f;
-      if constexpr (EPI == BLM_EPI_BIAS || EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_GP_MIX)
-        bias = col_ok ? p.bias[col] : 0.f;
+    for (int rq = 0; rq < 4; ++rq) {
+      const int mrow0 = 8 * rq + 4 * lh;  // first of the 4 MFMA rows this lane holds in registers 4rq..4rq+3
+      const int row0 = m0 + wm * (32 * WTM) + ((INTERLEAVE && WTM == 2) ? 2 * mrow0 + i : 32 * i + mrow0);
+      constexpr int RS = (INTERLEAVE && WTM == 2) ? 2 : 1;  // matrix-row stride between consecutive MFMA rows
+      float keep[4][WTN];
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int row0 = m0 + wm * (32 * WTM) + 32 * i + 8 * rq + 4 * lh;
-        float keep[4] = {1.f, 1.f, 1.f, 1.f};
-        if constexpr (EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_MUL_DGELU || EPI == BLM_EPI_GP_MIX ||
-                      EPI == BLM_EPI_MUL_DGP_MIX) {
-          if (p.drop_on) {  // wave-uniform: every lane takes part in the quad exchange
-            if (p.drop_quad) gemm_keep_quad(p, row0, col, keep);
-            else {
+      for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-              for (int rr = 0; rr < 4; ++rr) keep[rr] = gemm_keep(p, row0 + rr, min(col, p.N - 1));
+        for (int j = 0; j < WTN; ++j) keep[rr][j] = 1.f;
+      if constexpr (DROP) {
+        if (p.drop_on) {  // wave-uniform; every lane runs it (the quad exchange needs all lanes)
+          if (INTERLEAVE && WTN == 2 && p.drop_quad) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) gemm_keep_pair(p, row0 + rr * RS, min(col[0], p.N - 2), keep[rr][0], keep[rr][WTN - 1]);
+          } else if (!(INTERLEAVE && WTN == 2) && p.drop_quad) {  // 4 adjacent lanes = 4 adjacent columns
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) {
+              float k4[4];
+              gemm_keep_quad(p, row0, RS, col[j], k4);
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) keep[rr][j] = k4[rr];
             }
+          } else {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+              for (int j = 0; j < WTN; ++j) keep[rr][j] = gemm_keep(p, row0 + rr * RS, min(col[j], p.N - 1));
+          }
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = row0 + rr * RS;
+        const int r = 4 * rq + rr;
+        if (row >= p.M) continue;
+        if constexpr (WTN == 2) {
+          if (pair_store && col[1] < p.N) {
+            float2* dst = reinterpret_cast<float2*>(p.C + (long)row * p.ldc + col[0]);
+            float2 v = make_float2(p.alpha * acc[i][0][r] + bias[0], p.alpha * acc[i][1][r] + bias[1]);
+            if (accum) { const float2 old = *dst; v.x += old.x; v.y += old.y; }
+            *dst = v;
+            continue;
           }
         }
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int row = row0 + rr;
-          const int r = 4 * rq + rr;
-          if (col_ok && row < p.M) {
-            const long o = (long)row * p.ldc + col;
-            float v = p.alpha * acc[i][j][r];
-            if constexpr (EPI == BLM_EPI_BIAS) {
-              v += bias;
-            } else if constexpr (EPI == BLM_EPI_BIAS_GELU) {
-              v += bias;
-              if (p.aux) p.aux[o] = v;
-              v = gelu_erf(v) * keep[rr];
-            } else if constexpr (EPI == BLM_EPI_MUL_DGELU) {
-              v *= dgelu_erf(p.aux[o]) * keep[rr];
-            } else if constexpr (EPI == BLM_EPI_GP_MIX) {
-              v += bias;
-              if (p.aux) p.aux[o] = v;
-              v = gp_mix(v, p.coef, p.N, col) * keep[rr];
-            } else if constexpr (EPI == BLM_EPI_MUL_DGP_MIX) {
-              v *= keep[rr];
-              if (p.C2) p.C2[o] = v;
-              v *= dgp_mix(p.aux[o], p.coef, p.N, col);
-            } else if constexpr (EPI == BLM_EPI_BAYES_WGRAD) {
-              const float dW = v;
-              const int rel = row - p.vc.row_lo;
-              if ((unsigned)rel < (unsigned)p.vc.srows) {
-                const long si = (long)rel * p.N + col;
-                const float sig = __expf(p.vc.lgstd[si]);
-                float e;
-                if (p.vc.eps) e = p.vc.eps[si];
-                else e = philox_normal1_rolled(p.vc.rng, (uint64_t)si);
-                const float g2 = dW * e * sig + p.kl_lambda * (sig * sig - 1.0f) * p.kl_inv_n;
-                p.C2[si] = accum ? p.C2[si] + g2 : g2;
-                v = dW + p.kl_lambda * p.wg_mu[o] * p.kl_inv_n;
-              }
-            }
-            if constexpr (EPI == BLM_EPI_NONE) {
-              if (p.atomic) { atomicAdd(p.C + o, v); continue; }
-            }
-            p.C[o] = accum ? p.C[o] + v : v;
-          }
-        }
+        for (int j = 0; j < WTN; ++j)
+          if (col[j] < p.N) epi_elem<EPI>(p, accum, row, col[j], acc[i][j][r], bias[j], keep[rr][j]);
       }
     }
   }
@@ -262,8 +346,11 @@ template <int OP, int WTM, int WTN, bool SAMP, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   constexpr int BM = 64 * WTM, BN = 64 * WTN;
   constexpr bool A_KMAJ = (OP != BLM_GEMM_TN), B_KMAJ = (OP == BLM_GEMM_NT);
-  constexpr int SA = A_KMAJ ? BM + 1 : BM + 4;
-  constexpr int SB = B_KMAJ ? BN + 1 : BN + 4;
+  // k-contiguous sources are transposed on the LDS write: stride BM+2 keeps that scatter at most
+  // 2-way conflicting (free for ds_write_b32) AND even, so the interleaved two-tile operand read is an
+  // aligned ds_read_b64; single-tile waves use BM+1 (conflict-free).  m/n-contiguous: BM+4 (b128 rows).
+  constexpr int SA = A_KMAJ ? ((INTERLEAVE && WTM == 2) ? BM + 2 : BM + 1) : BM + 4;
+  constexpr int SB = B_KMAJ ? ((INTERLEAVE && WTN == 2) ? BN + 2 : BN + 1) : BN + 4;
   constexpr int NA = BM / 32, NB = BN / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const As = smem;
@@ -385,20 +472,34 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 #pragma unroll
     for (int j = 0; j < WTN; ++j) acc[i][j] = (f32x16)(0.f);
 
+  // One K tile = 16 k-pairs.  Operands of pair s+1 are read from LDS BEFORE the MFMAs of pair s are
+  // issued (two register sets), so the ds_read latency sits under 4 x 64 cycles of matrix work
+  // instead of in front of it.  hipcc re-serialises a plain-C++ version of this (read -> wait ->
+  // MFMA on one register set), so the reads and their counted lgkmcnt waits are inline asm
+  // (cdna_hip_programming.md 5.7: loads "=v", a wait statement naming the consumed set "+v",
+  // then sched_barrier(0) so no MFMA is hoisted above the wait).
   auto compute = [&](int cur) {
-    const float* Ab = As + cur * BK * SA + lh * SA + wm * (32 * WTM) + li;
-    const float* Bb = Bs + cur * BK * SB + lh * SB + wn * (32 * WTN) + li;
+    const uint32_t a_base = lds_u32(As + cur * BK * SA + lh * SA + wm * (32 * WTM) + ((INTERLEAVE && WTM == 2) ? 2 * li : li));
+    const uint32_t b_base = lds_u32(Bs + cur * BK * SB + lh * SB + wn * (32 * WTN) + ((INTERLEAVE && WTN == 2) ? 2 * li : li));
+    Frag<WTM> a[2];
+    Frag<WTN> b[2];
+    a[0].read(a_base);
+    b[0].read(b_base);
 #pragma unroll
     for (int s = 0; s < BK / 2; ++s) {
-      float a[WTM], b[WTN];
-#pragma unroll
-      for (int i = 0; i < WTM; ++i) a[i] = Ab[(2 * s) * SA + 32 * i];
-#pragma unroll
-      for (int j = 0; j < WTN; ++j) b[j] = Bb[(2 * s) * SB + 32 * j];
+      if (s + 1 < BK / 2) {
+        a[(s + 1) & 1].read(a_base + (2 * s + 2) * SA * 4);
+        b[(s + 1) & 1].read(b_base + (2 * s + 2) * SB * 4);
+        wait_lgkm2(a[s & 1], b[s & 1]);  // everything but the two reads just issued has landed
+      } else {
+        wait_lgkm0(a[s & 1], b[s & 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WTN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1].get(i), b[s & 1].get(j), acc[i][j], 0, 0, 0);
     }
   };
 
@@ -412,6 +513,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   int kt = t0;
   for (; kt + 1 < tfull; ++kt) {  // steady state: next tile is a full one
     fetch_fast(kt + 1);
+    asm volatile("" ::: "memory");  // keep the global loads in front of the MFMA phase (hipcc sinks them otherwise)
     compute((kt - t0) & 1);
     stash((kt + 1 - t0) & 1, (kt + 1) * BK, true);
     __syncthreads();
@@ -443,7 +545,8 @@ template <int OP, int WTM, int WTN, bool SAMP, bool FAST>
 static int launch_cfg(const GemmP& p, hipStream_t st) {
   constexpr int BM = 64 * WTM, BN = 64 * WTN;
   constexpr bool A_KMAJ = (OP != BLM_GEMM_TN), B_KMAJ = (OP == BLM_GEMM_NT);
-  constexpr int SA = A_KMAJ ? BM + 1 : BM + 4, SB = B_KMAJ ? BN + 1 : BN + 4;
+  constexpr int SA = A_KMAJ ? ((INTERLEAVE && WTM == 2) ? BM + 2 : BM + 1) : BM + 4,
+                SB = B_KMAJ ? ((INTERLEAVE && WTN == 2) ? BN + 2 : BN + 1) : BN + 4;
   constexpr size_t lds = (size_t)2 * BK * (SA + SB) * sizeof(float);
   GemmP q = p;
   q.gm = (p.M + BM - 1) / BM;
