@@ -5,8 +5,10 @@
 //
 // Replaces model.py:889-920 (MultiheadAttention.forward core: scale, bmm, +mask, softmax, dropout,
 // bmm) and the same lines of BayesMultiheadAttention (:990-1011), plus their autograd.
-// Attention is ~2.4 % of the layer FLOPs at T=128 so this round keeps it on the
-// f32 VALU; the GEMM-shaped QKV/O projections run on the MFMA kernel.
+// These f32 VALU kernels serve head_dim in {4,8,16,32} (and 64 when BLM_ATTN_VALU=1); head_dim 64,
+// the size of every recipe, runs on the matrix cores in attention_mfma.hip.
+#include <cstdlib>
+
 #include "blm_device.h"
 #include "blm_host.h"
 
@@ -246,6 +248,18 @@ static int fill(AttnP& p, int T, int B, int nhead, int head_dim, float pdrop, co
 
 using namespace blm;
 
+// head_dim 64 runs on the matrix cores (attention_mfma.hip); other head sizes on the VALU kernels above
+int blm_attn_fwd_mfma(const float* q, const float* k, const float* v, int64_t ld, float* out, float* lse, int T, int B,
+                      int nhead, float pdrop, const blm_rng* rng, int col_offset, hipStream_t st);
+int blm_attn_bwd_mfma(const float* q, const float* k, const float* v, int64_t ld, const float* out, const float* dout,
+                      const float* lse, float* dq, float* dk, float* dv, int64_t ldd, int T, int B, int nhead,
+                      float pdrop, const blm_rng* rng, int col_offset, hipStream_t st);
+static bool use_mfma(int head_dim) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("BLM_ATTN_VALU"); off = (e && atoi(e)) ? 1 : 0; }
+  return head_dim == 64 && !off;
+}
+
 #define DISPATCH_HD(KERN, LDS)                                                                                   \
   switch (head_dim) {                                                                                            \
     case 4: hipLaunchKernelGGL(KERN<4>, dim3(B * nhead), dim3(ATT_T), LDS, st, p); break;                         \
@@ -265,8 +279,9 @@ extern "C" int blm_attn_fwd(const float* q, const float* k, const float* v, int6
   if (rc) return rc;
   if (ld_qkv < (int64_t)nhead * head_dim) return blm_fail(BLM_ERR_INVALID, "blm_attn_fwd: ld_qkv too small");
   if ((long)T * B == 0) return BLM_OK;
-  p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.out = out; p.lse = lse;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (use_mfma(head_dim)) return blm_attn_fwd_mfma(q, k, v, ld_qkv, out, lse, T, B, nhead, pdrop, rng, col_offset, st);
+  p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.out = out; p.lse = lse;
   const size_t lds = (size_t)2 * T * head_dim * sizeof(float);
   DISPATCH_HD(attn_fwd_kernel, lds)
   BLM_HIP(hipGetLastError());
@@ -285,9 +300,11 @@ extern "C" int blm_attn_bwd(const float* q, const float* k, const float* v, int6
   if (ld_qkv < (int64_t)nhead * head_dim || ld_dqkv < (int64_t)nhead * head_dim)
     return blm_fail(BLM_ERR_INVALID, "blm_attn_bwd: leading dimension too small");
   if ((long)T * B == 0) return BLM_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (use_mfma(head_dim))
+    return blm_attn_bwd_mfma(q, k, v, ld_qkv, out, dout, lse, dq, dk, dv, ld_dqkv, T, B, nhead, pdrop, rng, col_offset, st);
   p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.o_in = out; p.dout = dout; p.lse = const_cast<float*>(lse);
   p.dq = dq; p.dk = dk; p.dv = dv; p.ldd = ld_dqkv;
-  hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t lds = ((size_t)2 * T * head_dim + 2 * T) * sizeof(float);
   DISPATCH_HD(attn_bwd_kernel, lds)
   BLM_HIP(hipGetLastError());

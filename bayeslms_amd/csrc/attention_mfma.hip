@@ -1,0 +1,389 @@
+// Causal self-attention on the f32 matrix cores (v_mfma_f32_32x32x2_f32), head_dim 64, T <= 128:
+// forward, dQ and dK/dV kernels, flash-style (no T x T matrix in HBM, probabilities recomputed in
+// backward from the saved log-sum-exp).
+//
+// Design (one workgroup of 2 waves per (batch column, head); K,V or Q,dO rows of the head sit in
+// LDS once, row-major with a 65-float stride so the same copy serves both operand shapes:
+// "lane = row, k = 2s + half" and "lane = feature, row fixed" are both conflict-free ds_read_b32):
+//  * The score tile is computed TRANSPOSED, S^T[key][query] = K Q^T, so the MFMA result has one
+//    query per lane and its keys in the 16 accumulator registers.  Row max / row sum of the softmax
+//    are then register reductions plus ONE cross-half shuffle, and the probabilities are already in
+//    the B-operand layout of the next product (O^T = V^T P^T, dQ^T = K^T dS^T): P never leaves the
+//    register file (cdna_hip_programming.md section 3, "accumulator tile as the next MFMA's operand",
+//    here for the one-float-per-lane f32 operand map).
+//  * dK/dV use the other orientation (lane = key, queries in registers) for the same reason.
+//  * Causal work is balanced by giving each wave query (key) tiles {w, 3-w}.
+//  * Dropout on the probabilities: Philox bits keyed by the global element ((b*nhead+h)*T+q)*T+key;
+//    4 consecutive keys = one Philox block = 4 accumulator registers of a lane (query orientation)
+//    or a quad exchange (key orientation).
+//
+// Replaces model.py:889-920 / :990-1011 and their autograd.
+#include "blm_device.h"
+#include "blm_host.h"
+
+namespace blm {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int AT = 128;   // max sequence length
+constexpr int HD = 64;    // head dim of the MFMA path
+constexpr int LS = 65;    // LDS row stride (floats)
+
+struct AttnM {
+  const float *q, *k, *v;
+  long ld;
+  float* out;
+  float* lse;
+  const float *o_in, *dout;
+  float *dq, *dk, *dv;
+  long ldd;
+  int T, B, nhead;
+  float scale;
+  blm_rng rng;
+  uint32_t thr;
+  float inv_keep;
+  int col_offset;
+  int drop;
+};
+
+// rows [0,T) x 64 floats of a (T,B,*) tensor -> dst[row*LS + c] (* mul); rows [T,128) zeroed
+__device__ __forceinline__ void load_rows(float* dst, const float* src, long ld, int T, int B, int b, int off, float mul) {
+  for (int i = threadIdx.x; i < AT * (HD / 4); i += 128) {
+    const int row = i >> 4, c = (i & 15) << 2;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < T) {
+      const float* s = src + ((long)row * B + b) * ld + off + c;
+      if ((reinterpret_cast<uintptr_t>(s) & 15) == 0) v = *reinterpret_cast<const float4*>(s);
+      else v = make_float4(s[0], s[1], s[2], s[3]);
+    }
+    float* d = dst + row * LS + c;
+    d[0] = v.x * mul; d[1] = v.y * mul; d[2] = v.z * mul; d[3] = v.w * mul;
+  }
+}
+
+// MFMA row index held in accumulator register r by a lane of half h
+__device__ __forceinline__ constexpr int mrow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// keep factors of the 4 consecutive columns c0..c0+3 (c0 % 4 == 0) of probability row `grow`
+__device__ __forceinline__ void keep_row4(const AttnM& p, uint64_t grow, int c0, float (&k)[4]) {
+  const uint64_t g = grow * (uint64_t)p.T + (uint64_t)c0;
+  if ((p.T & 3) == 0) {
+    const u32x4 u = philox4x32_10_rolled((uint32_t)(g >> 2), (uint32_t)(g >> 34), p.rng.stream, p.rng.step,
+                                         (uint32_t)p.rng.seed, (uint32_t)(p.rng.seed >> 32));
+    k[0] = u.x >= p.thr ? p.inv_keep : 0.f; k[1] = u.y >= p.thr ? p.inv_keep : 0.f;
+    k[2] = u.z >= p.thr ? p.inv_keep : 0.f; k[3] = u.w >= p.thr ? p.inv_keep : 0.f;
+  } else {  // rows do not start on a block boundary: per element
+#pragma unroll
+    for (int e = 0; e < 4; ++e) k[e] = philox_bits1_rolled(p.rng, g + e) >= p.thr ? p.inv_keep : 0.f;
+  }
+}
+
+// S^T tile: acc[r] = sum_k X[row0 + (lane&31)][k] * breg[k-th]  with A from LDS rows, B from registers
+__device__ __forceinline__ f32x16 tile_rows_x_regs(const float* X, int row0, const float (&breg)[32], int li, int lh) {
+  f32x16 acc = (f32x16)(0.f);
+  const float* a = X + (row0 + li) * LS + lh;
+#pragma unroll
+  for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * s], breg[s], acc, 0, 0, 0);
+  return acc;
+}
+
+// Y^T[d][lane col] += sum over the 32 rows of the register tile:  A = X[row0 + mrow(s,h)][32*dt + (lane&31)], B = regs
+__device__ __forceinline__ void acc_xt_regs(f32x16 (&acc)[2], const float* X, int row0, const f32x16& breg, int li, int lh) {
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const float* a = X + (row0 + mrow(s, lh)) * LS + li;
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], breg[s], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[32], breg[s], acc[1], 0, 0, 0);
+  }
+}
+
+// write Y^T accumulators (features in registers, one row per lane) as row-major floats
+__device__ __forceinline__ void store_t(float* dst_row, const f32x16 (&acc)[2], int lh, float mul) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float* d = dst_row + 32 * dt + 8 * g + 4 * lh;
+      const float4 v = make_float4(acc[dt][4 * g] * mul, acc[dt][4 * g + 1] * mul, acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+      if ((reinterpret_cast<uintptr_t>(d) & 15) == 0) *reinterpret_cast<float4*>(d) = v;
+      else { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+    }
+}
+
+// ------------------------------------------------------------------ forward
+__global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(const AttnM p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Ks = sm;
+  float* Vs = sm + AT * LS;
+  const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
+  const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  load_rows(Ks, p.k, p.ld, T, p.B, b, off, 1.f);
+  load_rows(Vs, p.v, p.ld, T, p.B, b, off, 1.f);
+  __syncthreads();
+  const int ntile = (T + 31) >> 5;
+  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int qt = pass == 0 ? wave : 3 - wave;  // tiles {w, 3-w}: equal causal work per wave
+    if (qt >= ntile) continue;
+    const int q = 32 * qt + li;
+    const bool qok = q < T;
+    float qreg[32];
+    {
+      const float* qs = p.q + ((long)min(q, T - 1) * p.B + b) * p.ld + off + lh;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) qreg[s] = qs[2 * s] * p.scale;
+    }
+    f32x16 st[4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      if (kt <= qt) {
+        st[kt] = tile_rows_x_regs(Ks, 32 * kt, qreg, li, lh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * kt + mrow(r, lh);
+          if (key > q) st[kt][r] = -INFINITY;  // causal (also hides keys >= T for valid queries)
+          m = fmaxf(m, st[kt][r]);
+        }
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      if (kt <= qt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          st[kt][r] = __expf(st[kt][r] - m);
+          l += st[kt][r];
+        }
+      }
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    f32x16 ot[2] = {(f32x16)(0.f), (f32x16)(0.f)};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      if (kt <= qt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float kp[4] = {1.f, 1.f, 1.f, 1.f};
+          if (p.drop) keep_row4(p, bh * T + min(q, T - 1), 32 * kt + 8 * g + 4 * lh, kp);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) st[kt][4 * g + e] *= inv * kp[e];
+        }
+        acc_xt_regs(ot, Vs, 32 * kt, st[kt], li, lh);
+      }
+    }
+    if (qok) {
+      store_t(p.out + ((long)q * p.B + b) * ((long)p.nhead * HD) + off, ot, lh, 1.f);
+      if (p.lse && lh == 0) p.lse[(long)blockIdx.x * T + q] = m + __logf(l);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward: dQ (lane = query)
+__global__ __launch_bounds__(128) void attn_bwd_dq_mfma_kernel(const AttnM p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Ks = sm;
+  float* Vs = sm + AT * LS;
+  const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
+  const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const long dmodel = (long)p.nhead * HD;
+  load_rows(Ks, p.k, p.ld, T, p.B, b, off, 1.f);
+  load_rows(Vs, p.v, p.ld, T, p.B, b, off, 1.f);
+  __syncthreads();
+  const int ntile = (T + 31) >> 5;
+  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int qt = pass == 0 ? wave : 3 - wave;
+    if (qt >= ntile) continue;
+    const int q = 32 * qt + li, qc = min(q, T - 1);
+    float qreg[32], doreg[32];
+    float delta = 0.f;
+    {
+      const float* qs = p.q + ((long)qc * p.B + b) * p.ld + off + lh;
+      const float* ds = p.dout + ((long)qc * p.B + b) * dmodel + off + lh;
+      const float* os = p.o_in + ((long)qc * p.B + b) * dmodel + off + lh;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        qreg[s] = qs[2 * s] * p.scale;
+        doreg[s] = ds[2 * s];
+        delta += doreg[s] * os[2 * s];
+      }
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const float lse = p.lse[(long)blockIdx.x * T + qc];
+    f32x16 dqt[2] = {(f32x16)(0.f), (f32x16)(0.f)};
+#pragma unroll 1
+    for (int kt = 0; kt <= qt; ++kt) {
+      f32x16 st = tile_rows_x_regs(Ks, 32 * kt, qreg, li, lh);
+      f32x16 dp = tile_rows_x_regs(Vs, 32 * kt, doreg, li, lh);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float kp[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.drop) keep_row4(p, bh * T + qc, 32 * kt + 8 * g + 4 * lh, kp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const int key = 32 * kt + mrow(r, lh);
+          const float pr = key <= q ? __expf(st[r] - lse) : 0.f;
+          st[r] = pr * (dp[r] * kp[e] - delta);  // dS^T
+        }
+      }
+      acc_xt_regs(dqt, Ks, 32 * kt, st, li, lh);
+    }
+    if (q < T) store_t(p.dq + ((long)q * p.B + b) * p.ldd + off, dqt, lh, p.scale);
+  }
+}
+
+// ------------------------------------------------------------------ backward: dK, dV (lane = key)
+__global__ __launch_bounds__(128) void attn_bwd_dkv_mfma_kernel(const AttnM p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Qs = sm;               // Q * scale
+  float* Os = sm + AT * LS;     // dO
+  float* lse_s = sm + 2 * AT * LS;
+  float* del_s = lse_s + AT;
+  const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
+  const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const long dmodel = (long)p.nhead * HD;
+  load_rows(Qs, p.q, p.ld, T, p.B, b, off, p.scale);
+  load_rows(Os, p.dout, dmodel, T, p.B, b, off, 1.f);
+  {  // delta[q] = rowsum(dO * O), lse[q]
+    const int row = threadIdx.x;
+    float d = 0.f, ls = 0.f;
+    if (row < T) {
+      const float* ds = p.dout + ((long)row * p.B + b) * dmodel + off;
+      const float* os = p.o_in + ((long)row * p.B + b) * dmodel + off;
+      for (int c = 0; c < HD; ++c) d += ds[c] * os[c];
+      ls = p.lse[(long)blockIdx.x * T + row];
+    }
+    lse_s[row] = ls;
+    del_s[row] = d;
+  }
+  __syncthreads();
+  const int ntile = (T + 31) >> 5;
+  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int kt = pass == 0 ? wave : 3 - wave;  // key tile kt meets query tiles kt..ntile-1: {w, 3-w} balances
+    if (kt >= ntile) continue;
+    const int key = 32 * kt + li, kc = min(key, T - 1);
+    float kreg[32], vreg[32];
+    {
+      const float* ks = p.k + ((long)kc * p.B + b) * p.ld + off + lh;
+      const float* vs = p.v + ((long)kc * p.B + b) * p.ld + off + lh;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) { kreg[s] = ks[2 * s]; vreg[s] = vs[2 * s]; }
+    }
+    f32x16 dkt[2] = {(f32x16)(0.f), (f32x16)(0.f)}, dvt[2] = {(f32x16)(0.f), (f32x16)(0.f)};
+#pragma unroll 1
+    for (int qt = kt; qt < ntile; ++qt) {
+      f32x16 sc = tile_rows_x_regs(Qs, 32 * qt, kreg, li, lh);   // S[q][key], q in registers
+      f32x16 dp = tile_rows_x_regs(Os, 32 * qt, vreg, li, lh);   // dP[q][key]
+      f32x16 pd;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float kp[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.drop) {  // rows q0..q0+3 of the probability matrix, 4 adjacent lanes = 4 adjacent keys
+          const int q0 = 32 * qt + 8 * g + 4 * lh;
+          const int kq = lane & 3;
+          const int qrow = min(q0 + kq, T - 1);
+          if ((T & 3) == 0) {
+            const uint64_t gidx = (bh * T + qrow) * (uint64_t)T + (uint64_t)(min(key, T - 1) & ~3);
+            const u32x4 u = philox4x32_10_rolled((uint32_t)(gidx >> 2), (uint32_t)(gidx >> 34), p.rng.stream, p.rng.step,
+                                                 (uint32_t)p.rng.seed, (uint32_t)(p.rng.seed >> 32));
+#define BLM_QB(x, j) (uint32_t) __builtin_amdgcn_mov_dpp((int)(x), (j) * 0x55, 0xF, 0xF, true)
+#define BLM_KP(j)                                                                                         \
+  {                                                                                                       \
+    const uint32_t w0 = BLM_QB(u.x, j), w1 = BLM_QB(u.y, j), w2 = BLM_QB(u.z, j), w3 = BLM_QB(u.w, j);     \
+    const uint32_t w = kq == 0 ? w0 : (kq == 1 ? w1 : (kq == 2 ? w2 : w3));                               \
+    kp[j] = w >= p.thr ? p.inv_keep : 0.f;                                                                \
+  }
+            BLM_KP(0) BLM_KP(1) BLM_KP(2) BLM_KP(3)
+#undef BLM_KP
+#undef BLM_QB
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              kp[e] = philox_bits1_rolled(p.rng, (bh * T + min(q0 + e, T - 1)) * (uint64_t)T + kc) >= p.thr ? p.inv_keep : 0.f;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const int qr = 32 * qt + mrow(r, lh);
+          const float pr = (qr >= key && qr < T) ? __expf(sc[r] - lse_s[qr]) : 0.f;
+          pd[r] = pr * kp[e];
+          sc[r] = pr * (dp[r] * kp[e] - del_s[qr]);  // dS[q][key]
+        }
+      }
+      acc_xt_regs(dvt, Os, 32 * qt, pd, li, lh);
+      acc_xt_regs(dkt, Qs, 32 * qt, sc, li, lh);
+    }
+    if (key < T) {
+      store_t(p.dk + ((long)key * p.B + b) * p.ldd + off, dkt, lh, 1.f);
+      store_t(p.dv + ((long)key * p.B + b) * p.ldd + off, dvt, lh, 1.f);
+    }
+  }
+}
+
+}  // namespace blm
+
+using namespace blm;
+
+static void fill_m(AttnM& p, int T, int B, int nhead, float pdrop, const blm_rng* rng, int col_offset) {
+  p.T = T; p.B = B; p.nhead = nhead;
+  p.scale = 0.125f;  // 64^-0.5
+  p.drop = pdrop > 0.f;
+  if (p.drop) p.rng = *rng;
+  const double t = (double)pdrop * 4294967296.0;
+  p.thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  p.inv_keep = pdrop < 1.f ? 1.f / (1.f - pdrop) : 0.f;
+  p.col_offset = col_offset;
+}
+
+template <typename K>
+static int set_lds(K kern, size_t lds) {
+  BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return BLM_OK;
+}
+
+// called by blm_attn_fwd / blm_attn_bwd (attention.hip) when head_dim == 64
+int blm_attn_fwd_mfma(const float* q, const float* k, const float* v, int64_t ld, float* out, float* lse, int T, int B,
+                      int nhead, float pdrop, const blm_rng* rng, int col_offset, hipStream_t st) {
+  AttnM p{};
+  fill_m(p, T, B, nhead, pdrop, rng, col_offset);
+  p.q = q; p.k = k; p.v = v; p.ld = ld; p.out = out; p.lse = lse;
+  const size_t lds = (size_t)2 * AT * LS * sizeof(float);
+  static bool once = false;
+  if (!once) { int rc = set_lds(attn_fwd_mfma_kernel, lds); if (rc) return rc; once = true; }
+  hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * nhead), dim3(128), lds, st, p);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+int blm_attn_bwd_mfma(const float* q, const float* k, const float* v, int64_t ld, const float* out, const float* dout,
+                      const float* lse, float* dq, float* dk, float* dv, int64_t ldd, int T, int B, int nhead,
+                      float pdrop, const blm_rng* rng, int col_offset, hipStream_t st) {
+  AttnM p{};
+  fill_m(p, T, B, nhead, pdrop, rng, col_offset);
+  p.q = q; p.k = k; p.v = v; p.ld = ld; p.o_in = out; p.dout = dout; p.lse = const_cast<float*>(lse);
+  p.dq = dq; p.dk = dk; p.dv = dv; p.ldd = ldd;
+  const size_t lds1 = (size_t)2 * AT * LS * sizeof(float), lds2 = lds1 + 2 * AT * sizeof(float);
+  static bool once = false;
+  if (!once) {
+    int rc = set_lds(attn_bwd_dq_mfma_kernel, lds1);
+    if (rc) return rc;
+    rc = set_lds(attn_bwd_dkv_mfma_kernel, lds2);
+    if (rc) return rc;
+    once = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(B * nhead), dim3(128), lds1, st, p);
+  BLM_HIP(hipGetLastError());
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(B * nhead), dim3(128), lds2, st, p);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}

@@ -279,7 +279,8 @@ def test_add_dropout_ln(dev, D):
     assert rel(out2, torch.nn.functional.layer_norm(x + y * keep, (D,), gamma, beta, 1e-5)) < 1e-5
 
 
-@pytest.mark.parametrize("T,B,nhead,hd", [(6, 3, 4, 4), (100, 2, 2, 32), (128, 3, 2, 64), (33, 2, 1, 16)])
+@pytest.mark.parametrize("T,B,nhead,hd", [(6, 3, 4, 4), (100, 2, 2, 32), (128, 3, 2, 64), (33, 2, 1, 16), (33, 2, 2, 64),
+                                          (1, 1, 1, 64), (97, 1, 3, 64)])
 def test_attention_matches_oracle(dev, T, B, nhead, hd):
     ops = ops_mod()
     d = nhead * hd
@@ -303,9 +304,12 @@ def test_attention_matches_oracle(dev, T, B, nhead, hd):
     assert rel(torch.cat([t.grad for t in q3], -1), qr.grad) < 2e-5
 
 
-def test_attention_dropout_uses_philox_mask(dev):
+@pytest.mark.parametrize("T,B,nhead,hd", [(8, 2, 2, 4), (96, 2, 2, 64), (50, 3, 1, 64), (128, 1, 2, 64)])
+def test_attention_dropout_uses_philox_mask(dev, T, B, nhead, hd):
+    """Probability dropout (VALU kernels for small heads, MFMA kernels for head_dim 64; T % 4 != 0
+    takes the per-element Philox path)."""
     ops = ops_mod()
-    T, B, nhead, hd, p = 8, 2, 2, 4, 0.4
+    p = 0.4
     d = nhead * hd
     g = torch.Generator().manual_seed(1)
     qkv = torch.randn(T, B, 3 * d, generator=g)
