@@ -156,12 +156,16 @@ def main():
         M_, N_, K_ = T * Bc, D_MODEL, D_FF
         flops = 2.0 * M_ * N_ * K_  # 2*M*N*K per forward launch
         roof = None
+        traffic = None  # HBM bytes per launch from the PMC passes committed under profiles/ (not collected live)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_sampled_gemm_fwd.json")
+        if os.path.exists(pmc) and Bc == B_PER_GPU and not model.noise_state.fused:
+            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
         if "sampled_gemm_fwd" in kt:
             ms = kt["sampled_gemm_fwd"]["avg_ms"]
             ach = flops / (ms * 1e-3) / 1e12
             roof = {"kernel": "gemm_f32_kernel (Bayesian FFN linear2 forward, M=%d N=%d K=%d)" % (M_, N_, K_),
                     "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_ms": round(ms, 4), "launches": kt["sampled_gemm_fwd"]["n"]}
         out = {
             "metric": "train_tokens_per_sec", "value": round(tokens / elapsed, 1), "unit": "tokens/s",
