@@ -73,6 +73,11 @@ SIGNATURES = {
     "blm_clip_sgd_multi": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _i, _f, _vp]),
     "blm_lstm_cell_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "blm_lstm_cell_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "blm_lstm_cell_ovr_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "blm_lstm_cell_ovr_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "blm_gp_mix_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "blm_gp_mix_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "blm_add_rowvec": (_i, [_vp, _vp, _i, _i, _vp]),
     "blm_axpy": (_i, [_vp, _vp, _i64, _f, _vp]),
 }
 

@@ -63,8 +63,10 @@ def build_models(args, ntokens):
             m1 = M.BayesTransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, 0.5, True, args.T_bayes_pos)
         elif args.uncertainty == 'Gaussian':
             m1 = M.GaussTransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, 0.5, True, args.T_gauss_pos)
+        elif args.uncertainty == 'Variational':
+            m1 = M.VTransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, 0.5, True, args.T_v_pos)
         else:
-            raise SystemExit("--uncertainty %s is not built by this engine for Transformers yet" % args.uncertainty)
+            raise SystemExit("unknown --uncertainty %s" % args.uncertainty)
         if args.interpolation_flag == 1 and args.uncertainty != 'none':
             m2 = M.BayesTransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, 0.5, True, 'none')
     else:
@@ -72,8 +74,12 @@ def build_models(args, ntokens):
             m1 = M.RNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, 0.5, True)
         elif args.uncertainty == 'Bayesian':
             m1 = M.BayesRNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, 0.5, True, args.L_bayes_pos)
+        elif args.uncertainty == 'Gaussian':  # tie_weights False here, as in the reference (:428-429)
+            m1 = M.GaussRNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, 0.5, False, args.L_gauss_pos)
+        elif args.uncertainty == 'Variational':
+            m1 = M.VariationalRNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, 0.5, True, args.L_v_pos)
         else:
-            raise SystemExit("--uncertainty %s is not built by this engine for LSTMs yet" % args.uncertainty)
+            raise SystemExit("unknown --uncertainty %s" % args.uncertainty)
         if args.interpolation_flag == 1 and args.uncertainty != 'none':
             m2 = M.BayesRNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, 0.5, False, 0)
     return m1, m2

@@ -536,6 +536,70 @@ __global__ __launch_bounds__(TPB) void lstm_cell_bwd_kernel(const float* __restr
   }
 }
 
+__global__ __launch_bounds__(TPB) void lstm_cell_ovr_fwd_kernel(const float* __restrict__ xw, const float* __restrict__ hw,
+                                                                const float* __restrict__ c_prev,
+                                                                const float* __restrict__ ovr, int gidx,
+                                                                float* __restrict__ h, float* __restrict__ c,
+                                                                float* __restrict__ ga, int B, int H) {
+  const long total = (long)B * H;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const long b = i / H, j = i - b * H, o = b * 4 * H + j;
+    const float ov = ovr[i];
+    const float gi = gidx == 0 ? ov : sigmoidf_(xw[o] + hw[o]);
+    const float gf = gidx == 1 ? ov : sigmoidf_(xw[o + H] + hw[o + H]);
+    const float gg = gidx == 2 ? ov : tanhf(xw[o + 2 * H] + hw[o + 2 * H]);
+    const float go = gidx == 3 ? ov : sigmoidf_(xw[o + 3 * H] + hw[o + 3 * H]);
+    const float cn = gf * c_prev[i] + gi * gg;
+    c[i] = cn;
+    h[i] = go * tanhf(cn);
+    if (ga) { ga[o] = gi; ga[o + H] = gf; ga[o + 2 * H] = gg; ga[o + 3 * H] = go; }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void lstm_cell_ovr_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc_next,
+                                                                const float* __restrict__ c_prev, const float* __restrict__ c,
+                                                                const float* __restrict__ ga, int gidx,
+                                                                float* __restrict__ dgates, float* __restrict__ d_ovr,
+                                                                float* __restrict__ dc_prev, int B, int H) {
+  const long total = (long)B * H;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const long b = i / H, j = i - b * H, o = b * 4 * H + j;
+    const float gi = ga[o], gf = ga[o + H], gg = ga[o + 2 * H], go = ga[o + 3 * H];
+    const float tc = tanhf(c[i]);
+    const float dhv = dh[i];
+    const float dc = (dc_next ? dc_next[i] : 0.f) + dhv * go * (1.f - tc * tc);
+    const float dgi = dc * gg, dgf = dc * c_prev[i], dgg = dc * gi, dgo = dhv * tc;  // w.r.t. activated gates
+    dgates[o] = gidx == 0 ? 0.f : dgi * gi * (1.f - gi);
+    dgates[o + H] = gidx == 1 ? 0.f : dgf * gf * (1.f - gf);
+    dgates[o + 2 * H] = gidx == 2 ? 0.f : dgg * (1.f - gg * gg);
+    dgates[o + 3 * H] = gidx == 3 ? 0.f : dgo * go * (1.f - go);
+    d_ovr[i] = gidx == 0 ? dgi : (gidx == 1 ? dgf : (gidx == 2 ? dgg : dgo));
+    dc_prev[i] = dc * gf;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void gp_mix_fwd_kernel(const float* __restrict__ z, const float* __restrict__ coef,
+                                                         float* __restrict__ out, long total, int N) {
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const int n = (int)(i % N);
+    const float v = z[i];
+    out[i] = tanhf(v) * coef[n] + sigmoidf_(v) * coef[N + n] + fmaxf(v, 0.f) * coef[2 * N + n] + gelu_erf(v) * coef[3 * N + n];
+  }
+}
+__global__ __launch_bounds__(TPB) void gp_mix_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                         const float* __restrict__ coef, float* __restrict__ dz, long total,
+                                                         int N) {
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const int n = (int)(i % N);
+    const float v = z[i], th = tanhf(v), sg = sigmoidf_(v);
+    dz[i] = dout[i] * ((1.f - th * th) * coef[n] + sg * (1.f - sg) * coef[N + n] + (v > 0.f ? coef[2 * N + n] : 0.f) +
+                       dgelu_erf(v) * coef[3 * N + n]);
+  }
+}
+__global__ __launch_bounds__(TPB) void add_rowvec_kernel(float* __restrict__ x, const float* __restrict__ v, long total, int H) {
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) x[i] += v[i % H];
+}
+
 __global__ __launch_bounds__(TPB) void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float a) {
   for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) y[i] += a * x[i];
 }
@@ -746,6 +810,53 @@ extern "C" int blm_lstm_cell_bwd(const float* dh, const float* dc_next, const fl
   if ((long)B * H == 0) return BLM_OK;
   hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for((long)B * H)), dim3(TPB), 0, ST, dh, dc_next, c_prev, c, gates_act,
                      dgates, dc_prev, B, H);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_lstm_cell_ovr_fwd(const float* xw, const float* hw, const float* c_prev, const float* gate_ovr, int gate_idx,
+                                     float* h, float* c, float* gates_act, int B, int H, void* stream) {
+  if (!xw || !hw || !c_prev || !gate_ovr || !h || !c || B < 0 || H < 0 || gate_idx < 0 || gate_idx > 3)
+    return blm_fail(BLM_ERR_INVALID, "blm_lstm_cell_ovr_fwd: bad arguments");
+  if ((long)B * H == 0) return BLM_OK;
+  hipLaunchKernelGGL(lstm_cell_ovr_fwd_kernel, dim3(grid_for((long)B * H)), dim3(TPB), 0, ST, xw, hw, c_prev, gate_ovr, gate_idx,
+                     h, c, gates_act, B, H);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_lstm_cell_ovr_bwd(const float* dh, const float* dc_next, const float* c_prev, const float* c,
+                                     const float* gates_act, int gate_idx, float* dgates, float* d_ovr, float* dc_prev,
+                                     int B, int H, void* stream) {
+  if (!dh || !c_prev || !c || !gates_act || !dgates || !d_ovr || !dc_prev || B < 0 || H < 0 || gate_idx < 0 || gate_idx > 3)
+    return blm_fail(BLM_ERR_INVALID, "blm_lstm_cell_ovr_bwd: bad arguments");
+  if ((long)B * H == 0) return BLM_OK;
+  hipLaunchKernelGGL(lstm_cell_ovr_bwd_kernel, dim3(grid_for((long)B * H)), dim3(TPB), 0, ST, dh, dc_next, c_prev, c, gates_act,
+                     gate_idx, dgates, d_ovr, dc_prev, B, H);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_gp_mix_fwd(const float* z, const float* coef, float* out, int M, int N, void* stream) {
+  if (!z || !coef || !out || M < 0 || N < 0) return blm_fail(BLM_ERR_INVALID, "blm_gp_mix_fwd: bad arguments");
+  if ((long)M * N == 0) return BLM_OK;
+  hipLaunchKernelGGL(gp_mix_fwd_kernel, dim3(grid_for((long)M * N)), dim3(TPB), 0, ST, z, coef, out, (long)M * N, N);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_gp_mix_bwd(const float* dout, const float* z, const float* coef, float* dz, int M, int N, void* stream) {
+  if (!dout || !z || !coef || !dz || M < 0 || N < 0) return blm_fail(BLM_ERR_INVALID, "blm_gp_mix_bwd: bad arguments");
+  if ((long)M * N == 0) return BLM_OK;
+  hipLaunchKernelGGL(gp_mix_bwd_kernel, dim3(grid_for((long)M * N)), dim3(TPB), 0, ST, dout, z, coef, dz, (long)M * N, N);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_add_rowvec(float* x, const float* v, int B, int H, void* stream) {
+  if (!x || !v || B < 0 || H < 0) return blm_fail(BLM_ERR_INVALID, "blm_add_rowvec: bad arguments");
+  if ((long)B * H == 0) return BLM_OK;
+  hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for((long)B * H)), dim3(TPB), 0, ST, x, v, (long)B * H, H);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }

@@ -26,7 +26,9 @@ from .ops import Drop, NoiseSpec
 
 __all__ = ["NoiseState", "PositionalEncoding", "MultiheadAttention", "BayesMultiheadAttention", "BayesLinear",
            "StandardTransformerEncoderLayer", "BayesTransformerEncoderLayer", "BayesTransformerModel",
-           "TransformerModel", "GPNN", "GaussTransformerEncoderLayer", "GaussTransformerModel", "RNNModel", "BayesRNNModel", "Bayes2LSTM", "repackage_hidden"]
+           "TransformerModel", "GPNN", "GaussTransformerEncoderLayer", "GaussTransformerModel", "RNNModel", "BayesRNNModel", "Bayes2LSTM", "repackage_hidden",
+           "VTransformerEncoderLayer", "VTransformerModel", "GPLSTMCell", "GPLSTM", "GaussRNNModel", "VNN", "VLSTMCell",
+           "VariationalLSTM", "VariationalRNNModel"]
 
 
 class NoiseState:
@@ -359,6 +361,21 @@ class GPNN(_Site):
             self.weights_lgstd = nn.Parameter(torch.empty(output_size, input_size).uniform_(lo, hi))
             self.bias_lgstd = nn.Parameter(torch.empty(output_size).uniform_(lo, hi))
 
+    _SLOT = {"tanh": 0, "sigmoid": 1, "relu": 2, "gelu": 3}
+
+    def coef4(self):
+        """coef_mean rows placed in the kernels' fixed slot order (tanh, sigmoid, relu, gelu)."""
+        rows = [None] * 4
+        for i, a in enumerate(self.act_set):
+            rows[self._SLOT[a]] = self.coef_mean[i]
+        zero = torch.zeros_like(self.coef_mean[0])
+        return torch.stack([r if r is not None else zero for r in rows])
+
+    def forward(self, inp, hx=None):
+        """Generic (unfused) form used by the LSTM cells: sum_i act_i(W [inp|hx] + b) coef[i]."""
+        x = inp if hx is None else torch.cat([inp, hx], -1)
+        return ops.gp_mix(ops.linear(x, self.weights_mean, self.bias_mean), self.coef4())
+
     def kl_divergence(self, prior=None):
         if prior is not None:
             raise BayesLMError("GPNN.kl_divergence(prior=...) returns 0 in the reference; not supported")
@@ -415,6 +432,62 @@ class GaussTransformerModel(_LMHead):
         else:
             for _ in range(nlayers):
                 self.transformerlayers.append(StandardTransformerEncoderLayer(ninp, nhead, nhid, dropout))
+        self._init_io(ntoken, ninp, ninp, tie_weights)
+        self.noise_state = bind_state(self, NoiseState())
+
+    def forward(self, src, has_mask=True):
+        if not has_mask:
+            raise BayesLMError("has_mask=False: the fused attention kernel is causal only")
+        x = ops.embed(src, self.encoder.weight, self.pos_encoder.table(), math.sqrt(self.ninp),
+                      self.pos_encoder._drop(self.pos_encoder.p))
+        for layer in self.transformerlayers:
+            x = layer(x, src_mask=True)
+        return self.decoder(x)
+
+
+class VTransformerEncoderLayer(StandardTransformerEncoderLayer):
+    """Reference model.py:2741-2805.  Carries the four (100, 1, d) ``hiddens_*`` tensors (left at
+    their torch.rand initialisation there, :2756-2759).  The reference's noise branch only fires in
+    train mode at exactly T == 100 and then dereferences ``self.hiddens``, which does not exist:
+    the same AttributeError is raised here; at every other length the layer is a standard one."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
+        super().__init__(d_model, nhead, dim_feedforward, dropout)
+        for name in ("hiddens_mean_p", "hiddens_lgstd_p", "hiddens_mean", "hiddens_lgstd"):
+            self.register_parameter(name, nn.Parameter(torch.rand(100, 1, d_model)))
+
+    def kl_divergence(self):
+        raise BayesLMError("VTransformerEncoderLayer.kl_divergence broadcasts (T,B,d) against (100,1,d) and only "
+                           "reaches its formula in the branch that already crashed in forward (reference model.py:2770-2779)")
+
+    def forward(self, src, src_mask=None):
+        if self.training and src.size(0) == 100:
+            raise AttributeError("'VTransformerEncoderLayer' object has no attribute 'hiddens'")
+        return super().forward(src, src_mask)
+
+
+class VTransformerModel(_LMHead):
+    """Reference model.py:2808-2897, including its layer-count arithmetic: v_pos 2 and 3 build
+    nlayers-1 layers, any other value (e.g. the README's 11) builds none."""
+
+    def __init__(self, ntoken, ninp, nhead, nhid, nlayers, dropout=0.5, tie_weights=False, v_pos=0):
+        super().__init__()
+        self.model_type = "Transformer"
+        self.src_mask = None
+        self.ninp = ninp
+        self.pos_encoder = PositionalEncoding(ninp, dropout)
+        std = lambda: StandardTransformerEncoderLayer(ninp, nhead, nhid, dropout)  # noqa: E731
+        var = lambda: VTransformerEncoderLayer(ninp, nhead, nhid, dropout)  # noqa: E731
+        layers = []
+        if v_pos == 0:
+            layers = [std() for _ in range(nlayers)]
+        elif v_pos == 1:
+            layers = [var()] + [std() for _ in range(nlayers - 1)]
+        elif v_pos == 2:
+            layers = [std(), var()] + [std() for _ in range(nlayers - 3)]
+        elif v_pos == 3:
+            layers = [var(), var()] + [std() for _ in range(nlayers - 3)]
+        self.transformerlayers = nn.ModuleList(layers)
         self._init_io(ntoken, ninp, ninp, tie_weights)
         self.noise_state = bind_state(self, NoiseState())
 
@@ -638,4 +711,225 @@ class RNNModel(_RNNLM):
         emb = ops.embed(x, self.encoder.weight, None, 1.0, self._drop(self.p, 0))
         out, hidden = self.rnn(emb, hidden)
         out = ops.dropout(out, self._drop(self.p, 1))
+        return self.decoder(out), hidden
+
+
+# ----------------------------------------------------------------------------
+# GP / Variational LSTMs (Python time loops, as in the reference)
+# ----------------------------------------------------------------------------
+class _LoopCell(_Site):
+    """weights_ih/weights_hh/bias_ih/bias_hh with the reference's init (model.py:1712-1717) and its
+    quirk: ``bias_ih`` is added twice, ``bias_hh`` is never used (model.py:1750-1752, 2519)."""
+
+    def _params(self, input_size, hidden_size):
+        s = 1.0 / math.sqrt(hidden_size)
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.weights_ih = nn.Parameter(torch.empty(4 * hidden_size, input_size).uniform_(-s, s))
+        self.bias_ih = nn.Parameter(torch.zeros(4 * hidden_size))
+        self.weights_hh = nn.Parameter(torch.empty(4 * hidden_size, hidden_size).uniform_(-s, s))
+        self.bias_hh = nn.Parameter(torch.zeros(4 * hidden_size))
+
+
+class GPLSTMCell(_LoopCell):
+    """Reference model.py:1674-1777.  gate_type 1-4: that gate's activation is a GPNN of [inp|h];
+    5: the cell state passes through a GPNN first; 6 / 7: the hidden / input projection of all four
+    gates is a GPNN.  gpnn_type 0-3 (4 = GPNN2 random features is not built)."""
+
+    def __init__(self, input_size, hidden_size, gate_type=0, gpnn_type=0):
+        super().__init__()
+        if gpnn_type > 3:
+            raise BayesLMError("gpnn_type 4 (GPNN2 random features) is not built by this engine")
+        self.gate_type, self.gpnn_type = gate_type, gpnn_type
+        H, E = hidden_size, input_size
+        if gate_type == 3:
+            self.gpnn = GPNN(H + E, H, gpnn_type=gpnn_type)
+        elif gate_type in (1, 4):
+            self.gpnn = GPNN(H + E, H, act_set=['sigmoid', 'tanh', 'relu'], gpnn_type=gpnn_type)
+        elif gate_type == 2:
+            self.gpnn = GPNN(H + E, H, act_set=['sigmoid'], gpnn_type=gpnn_type)
+        elif gate_type == 5:
+            self.gpnn = GPNN(E, H, gpnn_type=gpnn_type)
+        elif 5 < gate_type <= 7:
+            self.gpnn = GPNN(E, 4 * H, gpnn_type=gpnn_type)
+        self._params(input_size, hidden_size)
+
+    def forward(self, inputs, hid=None):
+        if inputs.dim() == 2:
+            inputs = inputs.unsqueeze(0)
+        T, B, _ = inputs.shape
+        if hid is None:
+            z = torch.zeros(B, self.hidden_size, dtype=inputs.dtype, device=inputs.device)
+            hid = (z, z)
+        hx, cx = hid
+        gt = self.gate_type
+        # input-side projection of all steps in one GEMM (the reference does it per step)
+        xw_all = self.gpnn(inputs) if gt == 7 else ops.linear(inputs, self.weights_ih, self.bias_ih)
+        outs = []
+        for t in range(T):
+            hw = self.gpnn(hx) if gt == 6 else ops.linear(hx, self.weights_hh, self.bias_ih)
+            if gt == 5:
+                cx = self.gpnn(cx)
+            if 1 <= gt <= 4:
+                hx, cx = ops.lstm_cell(xw_all[t], hw, cx, self.gpnn(inputs[t], hx), gt - 1)
+            else:
+                hx, cx = ops.lstm_cell(xw_all[t], hw, cx)
+            outs.append(hx)
+        return torch.stack(outs, 0), (hx, cx)
+
+
+class GPLSTM(_Site):
+    """Reference model.py:1609-1671: which of the two layers is a GP cell is decided by the LENGTH of
+    the ``gpnn_type`` string ('00' plain; 'gt' GP cell then nn.LSTM; 'gtx' nn.LSTM then GP cell;
+    'gtg2x' two GP cells with gates g and g2)."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, bias=True, dropout=0., gpnn_type='00'):
+        super().__init__()
+        self.input_size, self.hidden_size, self.num_layers, self.gpnn_type = input_size, hidden_size, num_layers, gpnn_type
+        g = gpnn_type
+        cells = []
+        if int(g[0]) != 0:
+            if len(g) == 2:
+                cells = [GPLSTMCell(input_size, hidden_size, int(g[0]), int(g[1])),
+                         _LSTMParams(hidden_size, hidden_size, num_layers - 1, 0.0)]
+            elif len(g) == 3:
+                cells = [_LSTMParams(hidden_size, hidden_size, num_layers - 1, 0.0),
+                         GPLSTMCell(input_size, hidden_size, int(g[0]), int(g[1]))]
+            else:
+                cells = [GPLSTMCell(input_size, hidden_size, int(g[0]), int(g[1])),
+                         GPLSTMCell(input_size, hidden_size, int(g[2]), int(g[1]))]
+        else:
+            cells = [_LSTMParams(hidden_size, hidden_size, num_layers, float(dropout))]
+        self.rnn = nn.ModuleList(cells)
+
+    def forward(self, inputs, hidden=None):
+        g = self.gpnn_type
+        h0, c0 = hidden
+        if int(g[0]) == 0:
+            return self.rnn[0](inputs, hidden)
+        if len(g) == 2:
+            y, (h1, c1) = self.rnn[0](inputs, (h0[0], c0[0]))
+            y, (hr, cr) = self.rnn[1](y, (h0[1:], c0[1:]))
+            return y, (torch.cat([h1.unsqueeze(0), hr], 0), torch.cat([c1.unsqueeze(0), cr], 0))
+        if len(g) == 3:
+            y, (hr, cr) = self.rnn[0](inputs, (h0[:1], c0[:1]))
+            y, (h1, c1) = self.rnn[1](y, (h0[1], c0[1]))
+            return y, (torch.cat([hr, h1.unsqueeze(0)], 0), torch.cat([cr, c1.unsqueeze(0)], 0))
+        y, (h1, c1) = self.rnn[0](inputs, (h0[0], c0[0]))
+        y, (h2, c2) = self.rnn[1](y, (h0[1], c0[1]))
+        return y, (torch.stack([h1, h2]), torch.stack([c1, c2]))
+
+
+class GaussRNNModel(_RNNLM):
+    """Reference model.py:1317-1366."""
+
+    def __init__(self, rnn_type, ntoken, ninp, nhid, nlayers, dropout=0.5, tie_weights=False, gauss_pos='00'):
+        super().__init__()
+        self._check_type(rnn_type)
+        if tie_weights and nhid != ninp:
+            raise ValueError("When using the tied flag, nhid must be equal to emsize.")
+        self.rnn_type, self.nhid, self.nlayers, self.p = rnn_type, nhid, nlayers, dropout
+        self.rnn = GPLSTM(ninp, nhid, nlayers, dropout=dropout, gpnn_type=gauss_pos)
+        self._init_io(ntoken, ninp, nhid, tie_weights)
+        self.noise_state = bind_state(self, NoiseState())
+
+    def forward(self, x, hidden):
+        emb = ops.embed(x, self.encoder.weight, None, 1.0, self._drop(self.p, 0))
+        out, hidden = self.rnn(emb, hidden)
+        out = ops.dropout(out.contiguous(), self._drop(self.p, 1))
+        return self.decoder(out), hidden
+
+
+class VNN(_Site):
+    """Reference model.py:2534-2579: after every time step h += eps * exp(hidden_lgstd) with
+    eps ~ N(0, 0.1) of shape (1, H) (shared by the batch columns), in train mode only.  The KL
+    (model.py:2545-2550) uses the LAST step's h as the mean and contains exp(2*h) (sic)."""
+
+    def __init__(self, input_size):
+        super().__init__()
+        self.input_size = input_size
+        self.sample = True
+        s = 1.0 / math.sqrt(input_size)
+        self.hidden_lgstd = nn.Parameter(torch.empty(1, input_size).uniform_(2 * np.log(s), np.log(s)))
+        self.hidden_mean = None
+
+    def kl_divergence(self, prior=None):
+        hm, lg = self.hidden_mean, self.hidden_lgstd
+        return torch.mean(hm ** 2 - lg * 2. + torch.exp(hm * 2) - 1) / 2.  # small (B,H) glue, as written in the reference
+
+    def noise_rows(self, T, eps=None):
+        """(T, H) rows eps_t * exp(lgstd), eps_t ~ N(0, 0.1) from the Philox stream (or injected)."""
+        H = self.input_size
+        if eps is None:
+            st = self._st()
+            eps = ops.philox_normal(T * H, st.seed, ops.L.STREAM_WEIGHT + self._site_base, st.step,
+                                    self.hidden_lgstd.device).view(T, H) * 0.1
+        return eps * torch.exp(self.hidden_lgstd)
+
+
+class VLSTMCell(_LoopCell):
+    """Reference model.py:2471-2531."""
+
+    def __init__(self, input_size, hidden_size, vnn_type=0):
+        super().__init__()
+        self.vnn_type = vnn_type
+        self.vnn = VNN(input_size)
+        self._params(input_size, hidden_size)
+        self.eps_override = None  # (T, H) injected noise for parity tests
+
+    def forward(self, inputs, hid=None):
+        if inputs.dim() == 2:
+            inputs = inputs.unsqueeze(0)
+        T, B, _ = inputs.shape
+        if hid is None:
+            z = torch.zeros(B, self.hidden_size, dtype=inputs.dtype, device=inputs.device)
+            hid = (z, z)
+        hx, cx = hid
+        xw_all = ops.linear(inputs, self.weights_ih, self.bias_ih)
+        noisy = self.vnn_type == 1 and self.training and self.vnn.sample
+        rows = self.vnn.noise_rows(T, self.eps_override) if noisy else None
+        outs = []
+        for t in range(T):
+            hw = ops.linear(hx, self.weights_hh, self.bias_ih)
+            hx, cx = ops.lstm_cell(xw_all[t], hw, cx)
+            if self.vnn_type == 1:
+                self.vnn.hidden_mean = hx
+                if noisy:
+                    hx = ops.add_rowvec(hx, rows[t])
+            outs.append(hx)
+        return torch.stack(outs, 0), (hx, cx)
+
+
+class VariationalLSTM(_Site):
+    """Reference model.py:2426-2468: always two VLSTMCells; ``vlstm_type`` '00'/'01'/'10'/'11'."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, bias=True, dropout=0., vlstm_type='00'):
+        super().__init__()
+        self.vlstm_type = vlstm_type
+        self.rnn = nn.ModuleList([VLSTMCell(input_size, hidden_size, vnn_type=int(vlstm_type[0])),
+                                  VLSTMCell(input_size, hidden_size, vnn_type=int(vlstm_type[1]))])
+
+    def forward(self, inputs, hidden=None):
+        h0, c0 = hidden
+        y, (h1, c1) = self.rnn[0](inputs, (h0[0], c0[0]))
+        y, (h2, c2) = self.rnn[1](y, (h0[1], c0[1]))
+        return y, (torch.stack([h1, h2]), torch.stack([c1, c2]))
+
+
+class VariationalRNNModel(_RNNLM):
+    """Reference model.py:2373-2423."""
+
+    def __init__(self, rnn_type, ntoken, ninp, nhid, nlayers, dropout=0.5, tie_weights=False, v_pos='00'):
+        super().__init__()
+        self._check_type(rnn_type)
+        if tie_weights and nhid != ninp:
+            raise ValueError("When using the tied flag, nhid must be equal to emsize.")
+        self.rnn_type, self.nhid, self.nlayers, self.p = rnn_type, nhid, nlayers, dropout
+        self.rnn = VariationalLSTM(ninp, nhid, nlayers, dropout=dropout, vlstm_type=v_pos)
+        self._init_io(ntoken, ninp, nhid, tie_weights)
+        self.noise_state = bind_state(self, NoiseState())
+
+    def forward(self, x, hidden):
+        emb = ops.embed(x, self.encoder.weight, None, 1.0, self._drop(self.p, 0))
+        out, hidden = self.rnn(emb, hidden)
+        out = ops.dropout(out.contiguous(), self._drop(self.p, 1))
         return self.decoder(out), hidden

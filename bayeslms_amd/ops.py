@@ -18,7 +18,7 @@ from . import _lib as L
 from ._lib import BayesLMError, check, dev_tensor, lib, ptr, stream
 
 __all__ = ["Drop", "NoiseSpec", "linear", "bayes_linear", "ffn", "ffn_gp", "attention", "attention_qkv", "add_dropout_ln",
-           "embed", "add_pe", "dropout", "cross_entropy", "kl_mean", "philox_normal", "sample_weight", "sampled", "lstm_layer",
+           "embed", "add_pe", "dropout", "cross_entropy", "kl_mean", "philox_normal", "sample_weight", "sampled", "lstm_layer", "lstm_cell", "gp_mix", "add_rowvec",
            "clip_sgd", "gemm", "PtrTable", "set_grad_ready_hook", "KernelTimer", "set_kernel_timer"]
 
 
@@ -831,6 +831,114 @@ class _LSTMLayer(torch.autograd.Function):
 
 def lstm_layer(x, h0, c0, w_ih, w_hh, b_ih, b_hh):
     return _LSTMLayer.apply(x, h0, c0, w_ih, w_hh, b_ih, b_hh)
+
+
+# ----------------------------------------------------------------------------
+# Step-wise cells for the GP / Variational LSTMs (the reference runs them as Python time loops,
+# model.py:1734-1777, 2503-2531; so does this host code, one fused cell kernel per step)
+# ----------------------------------------------------------------------------
+class _LSTMCellStep(torch.autograd.Function):
+    """(xw, hw, c_prev[, gate_ovr]) -> (h, c).  gates = xw + hw (biases inside), order i,f,g,o; gate
+    ``gate_idx`` may take an externally computed activation (GPNN output)."""
+
+    @staticmethod
+    def forward(ctx, xw, hw, c_prev, gate_ovr, gate_idx):
+        xw, hw, c_prev = _f32(xw, "xw"), _f32(hw, "hw"), _f32(c_prev, "c_prev")
+        B, G = xw.shape
+        H = G // 4
+        h = torch.empty(B, H, device=xw.device, dtype=torch.float32)
+        c = torch.empty_like(h)
+        ga = torch.empty(B, G, device=xw.device, dtype=torch.float32)
+        L.require_gfx950()
+        if gate_ovr is None:
+            check(lib().blm_lstm_cell_fwd(ptr(xw), ptr(hw), ptr(c_prev), ptr(h), ptr(c), ptr(ga), B, H, stream()),
+                  "blm_lstm_cell_fwd")
+        else:
+            gate_ovr = _f32(gate_ovr, "gate_ovr")
+            check(lib().blm_lstm_cell_ovr_fwd(ptr(xw), ptr(hw), ptr(c_prev), ptr(gate_ovr), int(gate_idx), ptr(h), ptr(c),
+                                              ptr(ga), B, H, stream()), "blm_lstm_cell_ovr_fwd")
+        ctx.save_for_backward(c_prev, c, ga)
+        ctx.meta = (gate_ovr is not None, int(gate_idx), B, H)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        c_prev, c, ga = ctx.saved_tensors
+        has_ovr, gidx, B, H = ctx.meta
+        dev = c.device
+        dh = torch.zeros(B, H, device=dev) if dh is None else _f32(dh, "dh")
+        dc = None if dc is None else _f32(dc, "dc")
+        dgates = torch.empty(B, 4 * H, device=dev, dtype=torch.float32)
+        dc_prev = torch.empty(B, H, device=dev, dtype=torch.float32)
+        d_ovr = None
+        if has_ovr:
+            d_ovr = torch.empty(B, H, device=dev, dtype=torch.float32)
+            check(lib().blm_lstm_cell_ovr_bwd(ptr(dh), ptr(dc), ptr(c_prev), ptr(c), ptr(ga), gidx, ptr(dgates), ptr(d_ovr),
+                                              ptr(dc_prev), B, H, stream()), "blm_lstm_cell_ovr_bwd")
+        else:
+            check(lib().blm_lstm_cell_bwd(ptr(dh), ptr(dc), ptr(c_prev), ptr(c), ptr(ga), ptr(dgates), ptr(dc_prev), B, H,
+                                          stream()), "blm_lstm_cell_bwd")
+        return dgates, dgates, dc_prev, d_ovr, None
+
+
+def lstm_cell(xw, hw, c_prev, gate_ovr=None, gate_idx=-1):
+    return _LSTMCellStep.apply(xw, hw, c_prev, gate_ovr, gate_idx)
+
+
+class _GPMix(torch.autograd.Function):
+    """out = sum_i act_i(z) * coef4[i]  with the fixed slot order tanh, sigmoid, relu, gelu."""
+
+    @staticmethod
+    def forward(ctx, z, coef4):
+        z, coef4 = _f32(z, "z"), _f32(coef4, "coef4")
+        N = z.shape[-1]
+        M = z.numel() // N
+        out = torch.empty_like(z)
+        L.require_gfx950()
+        check(lib().blm_gp_mix_fwd(ptr(z), ptr(coef4), ptr(out), M, N, stream()), "blm_gp_mix_fwd")
+        ctx.save_for_backward(z, coef4)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, coef4 = ctx.saved_tensors
+        dout = _f32(dout, "dout")
+        N = z.shape[-1]
+        M = z.numel() // N
+        dz = torch.empty_like(z)
+        check(lib().blm_gp_mix_bwd(ptr(dout), ptr(z), ptr(coef4), ptr(dz), M, N, stream()), "blm_gp_mix_bwd")
+        dcoef = torch.zeros_like(coef4)
+        check(lib().blm_gp_coef_grad(ptr(dout), ptr(z), ptr(dcoef), M, N, stream()), "blm_gp_coef_grad")
+        return dz, dcoef
+
+
+def gp_mix(z, coef4):
+    return _GPMix.apply(z, coef4)
+
+
+class _AddRowVec(torch.autograd.Function):
+    """h (B,H) + v (H,) broadcast over rows (VNN noise on the hidden state, model.py:2571-2577)."""
+
+    @staticmethod
+    def forward(ctx, h, v):
+        out = _f32(h, "h").clone()
+        v = _f32(v, "v")
+        B, H = out.shape
+        L.require_gfx950()
+        check(lib().blm_add_rowvec(ptr(out), ptr(v), B, H, stream()), "blm_add_rowvec")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32(g, "g")
+        B, H = g.shape
+        dv = torch.empty(H, device=g.device, dtype=torch.float32)
+        _colsum_into(g, B, H, dv, accumulate=False)
+        return g, dv
+
+
+def add_rowvec(h, v):
+    return _AddRowVec.apply(h, v)
 
 
 # ----------------------------------------------------------------------------

@@ -69,12 +69,21 @@ def build_model(args, ntokens):
         if args.uncertainty == 'Gaussian':
             return M.GaussTransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, args.dropout,
                                            args.tied, args.T_gauss_pos)
+        if args.uncertainty == 'Variational':
+            return M.VTransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, args.dropout,
+                                       args.tied, args.T_v_pos)
     else:
         if args.uncertainty == 'none':
             return M.RNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, args.dropout, args.tied)
         if args.uncertainty == 'Bayesian':
             return M.BayesRNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, args.dropout, args.tied,
                                    args.L_bayes_pos)
+        if args.uncertainty == 'Gaussian':
+            return M.GaussRNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, args.dropout, args.tied,
+                                   args.L_gauss_pos)
+        if args.uncertainty == 'Variational':
+            return M.VariationalRNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, args.dropout,
+                                         args.tied, args.L_v_pos)
     raise SystemExit("--model %s --uncertainty %s is not built by this engine yet" % (args.model, args.uncertainty))
 
 
@@ -99,6 +108,21 @@ def kl_selector(args):
                 fn.fusable = False
     elif args.uncertainty == 'Gaussian' and args.model == 'Transformer' and 1 <= args.T_gauss_pos <= 3:
         fn = lambda m: m.transformerlayers[0].gpnn.kl_divergence()  # noqa: E731
+        fn.fusable = False
+    elif args.uncertainty == 'Gaussian' and args.model == 'LSTM':
+        g = args.L_gauss_pos
+        if int(g[0]) > 0 and 0 < int(g[1]) <= 3:  # train.py:367-375
+            cells = [0] if len(g) < 3 else ([1] if len(g) == 3 else [0, 1])
+            fn = lambda m: sum(m.rnn.rnn[c].gpnn.kl_divergence() for c in cells)  # noqa: E731
+            fn.fusable = False
+    elif args.uncertainty == 'Variational' and args.model == 'LSTM':
+        cells = [c for c in (0, 1) if int(args.L_v_pos[c]) == 1]  # train.py:379-382
+        if cells:
+            fn = lambda m: sum(m.rnn.rnn[c].vnn.kl_divergence() for c in cells)  # noqa: E731
+            fn.fusable = False
+    elif args.uncertainty == 'Variational' and args.model == 'Transformer' and int(args.T_v_pos) in (1, 2, 3):
+        layers = {1: [0], 2: [1], 3: [0, 1]}[int(args.T_v_pos)]  # train.py:387-396 (raises like the reference)
+        fn = lambda m: sum(m.transformerlayers[i].kl_divergence() for i in layers)  # noqa: E731
         fn.fusable = False
     return fn
 

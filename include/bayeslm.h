@@ -268,6 +268,21 @@ int blm_lstm_cell_fwd(const float* xw, const float* hw, const float* c_prev, flo
 /* In: dh (sum of grad from above and from next step), dc_next; out: dgates (B,4H), dc_prev. */
 int blm_lstm_cell_bwd(const float* dh, const float* dc_next, const float* c_prev, const float* c, const float* gates_act,
                       float* dgates, float* dc_prev, int B, int H, void* stream);
+/* GP-LSTM cell (GPLSTMCell.Gplstm, model.py:1745-1777): same cell, but gate `gate_idx` (0 i, 1 f,
+ * 2 g, 3 o) takes its ACTIVATED value from gate_ovr (B,H) -- the output of a GPNN -- instead of
+ * sigmoid/tanh of its pre-activation.  Backward returns, in slot gate_idx of dgates, the gradient
+ * w.r.t. that activated value (d_ovr, (B,H)) and zero pre-activation gradient for it. */
+int blm_lstm_cell_ovr_fwd(const float* xw, const float* hw, const float* c_prev, const float* gate_ovr, int gate_idx,
+                          float* h, float* c, float* gates_act, int B, int H, void* stream);
+int blm_lstm_cell_ovr_bwd(const float* dh, const float* dc_next, const float* c_prev, const float* c,
+                          const float* gates_act, int gate_idx, float* dgates, float* d_ovr, float* dc_prev, int B,
+                          int H, void* stream);
+/* Elementwise GPNN mixture on pre-activations z (M,N): out = sum_i act_i(z) coef[i,n];
+ * backward dz = dout * sum_i act_i'(z) coef[i,n]   (model.py:1885-1899). */
+int blm_gp_mix_fwd(const float* z, const float* coef, float* out, int M, int N, void* stream);
+int blm_gp_mix_bwd(const float* dout, const float* z, const float* coef, float* dz, int M, int N, void* stream);
+/* x[b,:] += v[:]  (VNN hidden-state noise, model.py:2571-2577); rows B, cols H. */
+int blm_add_rowvec(float* x, const float* v, int B, int H, void* stream);
 
 /* y (+)= a*x elementwise helpers used by the host glue. */
 int blm_axpy(const float* x, float* y, int64_t n, float a, void* stream);

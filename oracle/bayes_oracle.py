@@ -291,3 +291,137 @@ def transformer_train_loss(src, targets, sd, nhead, bayes_pos, eps, kl_scale):
     mle = cross_entropy_mean(logits, targets)
     kl = kl_transformer(sd, bayes_pos) * kl_scale
     return mle + kl, mle, kl
+
+
+# ----------------------------------------------------------------------------
+# GP / Variational LSTMs (Python time loops in the reference)
+# ----------------------------------------------------------------------------
+def gpnn(x, sd, pre, acts):
+    """GPNN.forward with sample=False (model.py:1863-1902)."""
+    z = F.linear(x, sd[pre + "weights_mean"], sd[pre + "bias_mean"])
+    return gp_mixture(z, sd[pre + "coef_mean"], acts)
+
+
+def _gp_acts(gate_type):
+    return ["sigmoid"] if gate_type == 2 else ["sigmoid", "tanh", "relu"]  # model.py:1688-1697
+
+
+def gp_lstm_cell(x, h, c, sd, pre, gate_type):
+    """GPLSTMCell.forward (model.py:1720-1777): bias_ih is added twice, bias_hh unused; gate 1-4 is
+    a GPNN of [inp|h]; 5: c = GPNN(c) first; 6/7: the hidden/input projection is a GPNN."""
+    acts = _gp_acts(gate_type)
+    w_ih, b_ih, w_hh = sd[pre + "weights_ih"], sd[pre + "bias_ih"], sd[pre + "weights_hh"]
+    outs = []
+    for t in range(x.shape[0]):
+        inp = x[t]
+        if gate_type == 6:
+            gates = F.linear(inp, w_ih, b_ih) + gpnn(h, sd, pre + "gpnn.", acts)
+        elif gate_type == 7:
+            gates = gpnn(inp, sd, pre + "gpnn.", acts) + F.linear(h, w_hh, b_ih)
+        else:
+            gates = F.linear(inp, w_ih, b_ih) + F.linear(h, w_hh, b_ih)
+        i, f, g, o = gates.chunk(4, 1)
+        gp = gpnn(torch.cat([inp, h], -1), sd, pre + "gpnn.", acts) if 1 <= gate_type <= 4 else None
+        i = gp if gate_type == 1 else torch.sigmoid(i)
+        f = gp if gate_type == 2 else torch.sigmoid(f)
+        g = gp if gate_type == 3 else torch.tanh(g)
+        o = gp if gate_type == 4 else torch.sigmoid(o)
+        if gate_type == 5:
+            c = gpnn(c, sd, pre + "gpnn.", acts)
+        c = f * c + i * g
+        h = o * torch.tanh(c)
+        outs.append(h)
+    return torch.stack(outs, 0), h, c
+
+
+def _nn_lstm(x, h0, c0, sd, pre):
+    """nn.LSTM stack stored under ``pre`` (weight_ih_l{k} ...), eval / dropout 0."""
+    hs, cs, k = [], [], 0
+    while pre + "weight_ih_l%d" % k in sd:
+        x, h, c = lstm_layer(x, h0[k], c0[k], sd[pre + "weight_ih_l%d" % k], sd[pre + "weight_hh_l%d" % k],
+                             sd[pre + "bias_ih_l%d" % k], sd[pre + "bias_hh_l%d" % k])
+        hs.append(h)
+        cs.append(c)
+        k += 1
+    return x, torch.stack(hs), torch.stack(cs)
+
+
+def gauss_rnn_lm(x, hidden, sd, gauss_pos):
+    """GaussRNNModel.forward, dropout off (model.py:1355-1360 -> GPLSTM.forward :1638-1671)."""
+    y = F.embedding(x, sd["encoder.weight"])
+    h0, c0 = hidden
+    g = gauss_pos
+    if int(g[0]) == 0:
+        y, hs, cs = _nn_lstm(y, h0, c0, sd, "rnn.rnn.0.")
+    elif len(g) == 2:
+        y, h1, c1 = gp_lstm_cell(y, h0[0], c0[0], sd, "rnn.rnn.0.", int(g[0]))
+        y, hr, cr = _nn_lstm(y, h0[1:], c0[1:], sd, "rnn.rnn.1.")
+        hs, cs = torch.cat([h1.unsqueeze(0), hr]), torch.cat([c1.unsqueeze(0), cr])
+    elif len(g) == 3:
+        y, hr, cr = _nn_lstm(y, h0[:1], c0[:1], sd, "rnn.rnn.0.")
+        y, h1, c1 = gp_lstm_cell(y, h0[1], c0[1], sd, "rnn.rnn.1.", int(g[0]))
+        hs, cs = torch.cat([hr, h1.unsqueeze(0)]), torch.cat([cr, c1.unsqueeze(0)])
+    else:
+        y, h1, c1 = gp_lstm_cell(y, h0[0], c0[0], sd, "rnn.rnn.0.", int(g[0]))
+        y, h2, c2 = gp_lstm_cell(y, h0[1], c0[1], sd, "rnn.rnn.1.", int(g[2]))
+        hs, cs = torch.stack([h1, h2]), torch.stack([c1, c2])
+    return F.linear(y, sd["decoder.weight"], sd["decoder.bias"]), (hs, cs)
+
+
+def kl_gauss_rnn(sd, gauss_pos):
+    """train.py:366-376 + GPNN.kl_divergence (model.py:1816-1826, with the '-1')."""
+    g = gauss_pos
+
+    def one(pre, t):
+        kl = torch.zeros(())
+        if t in (1, 3):
+            kl = kl + kl_mean_form_minus1(sd[pre + "coef_mean"], sd[pre + "coef_lgstd"])
+        if t in (2, 3):
+            kl = kl + kl_mean_form_minus1(sd[pre + "weights_mean"], sd[pre + "weights_lgstd"])
+            kl = kl + kl_mean_form_minus1(sd[pre + "bias_mean"], sd[pre + "bias_lgstd"])
+        return kl
+    if not (int(g[0]) > 0 and 0 < int(g[1]) <= 3):
+        return torch.zeros(())
+    t = int(g[1])
+    if len(g) < 3:
+        return one("rnn.rnn.0.gpnn.", t)
+    if len(g) == 3:
+        return one("rnn.rnn.1.gpnn.", t)
+    return one("rnn.rnn.0.gpnn.", t) + one("rnn.rnn.1.gpnn.", t)
+
+
+def v_lstm_cell(x, h, c, sd, pre, eps_rows=None):
+    """VLSTMCell.forward (model.py:2493-2531) + VNN (2571-2577): after each step h += eps_t *
+    exp(hidden_lgstd); eps_rows (T,H) or None.  Also returns the last pre-noise h (VNN.hidden_mean)."""
+    w_ih, b_ih, w_hh = sd[pre + "weights_ih"], sd[pre + "bias_ih"], sd[pre + "weights_hh"]
+    outs, hm = [], None
+    for t in range(x.shape[0]):
+        gates = F.linear(x[t], w_ih, b_ih) + F.linear(h, w_hh, b_ih)
+        i, f, g, o = gates.chunk(4, 1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        hm = h
+        if eps_rows is not None:
+            h = h + eps_rows[t] * torch.exp(sd[pre + "vnn.hidden_lgstd"])
+        outs.append(h)
+    return torch.stack(outs, 0), h, c, hm
+
+
+def variational_rnn_lm(x, hidden, sd, v_pos, eps=None):
+    """VariationalRNNModel.forward (model.py:2414-2419); eps = {cell: (T,H)} for train mode.
+    Returns logits, hidden and the KL train.py would add (train.py:379-382; VNN.kl_divergence
+    model.py:2545-2550 uses exp(2*hidden_mean), as written)."""
+    y = F.embedding(x, sd["encoder.weight"])
+    h0, c0 = hidden
+    eps = eps or {}
+    kl = torch.zeros(())
+    hs, cs = [], []
+    for cidx in (0, 1):
+        pre = "rnn.rnn.%d." % cidx
+        y, h, c, hm = v_lstm_cell(y, h0[cidx], c0[cidx], sd, pre, eps.get(cidx))
+        hs.append(h)
+        cs.append(c)
+        if int(v_pos[cidx]) == 1:
+            lg = sd[pre + "vnn.hidden_lgstd"]
+            kl = kl + torch.mean(hm ** 2 - lg * 2.0 + torch.exp(hm * 2) - 1) / 2.0
+    return F.linear(y, sd["decoder.weight"], sd["decoder.bias"]), (torch.stack(hs), torch.stack(cs)), kl

@@ -369,7 +369,80 @@ def f6_train_checkpoint():
                  **{"sd/" + k: npy(v) for k, v in sd.items() if not k.endswith("pos_encoder.pe")})
 
 
+def f5_gauss_variational_rnn():
+    V, H, T, B = 40, 12, 5, 3
+    for gp in ("33", "31", "13", "23", "43", "330", "6360", "3333", "53", "73", "00"):
+        torch.manual_seed(51 + len(gp) + int(gp[0]))
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = ref.GaussRNNModel("LSTM", V, H, H, 2, 0.0, True, gp)
+        x1, x2 = torch.randint(0, V, (T, B)), torch.randint(0, V, (T, B))
+        tgt = torch.randint(0, V, (T * B,))
+        m.train()
+        hid = m.init_hidden(B)
+        l1, hid = m(x1, hid)
+        hid = tuple(h.detach() for h in hid)
+        l2, hid = m(x2, hid)
+        mle = torch.nn.functional.cross_entropy(l2.view(-1, V), tgt)
+        kl = torch.zeros(())
+        if int(gp[0]) > 0 and 0 < int(gp[1]) <= 3:  # train.py:366-376
+            if len(gp) < 3:
+                kl = m.rnn.rnn[0].gpnn.kl_divergence()
+            elif len(gp) == 3:
+                kl = m.rnn.rnn[1].gpnn.kl_divergence()
+            else:
+                kl = m.rnn.rnn[0].gpnn.kl_divergence() + m.rnn.rnn[1].gpnn.kl_divergence()
+        if not torch.is_tensor(kl):
+            kl = torch.tensor(float(kl))
+        (mle + kl * 0.07).backward()
+        m.eval()
+        with torch.no_grad():
+            hid = m.init_hidden(B)
+            e1, hid = m(x1, hid)
+            e2, hid = m(x2, hid)
+        save("gauss_rnn_" + gp, x1=npy(x1), x2=npy(x2), tgt=npy(tgt), kl_scale=np.float32(0.07), logits_train_0=npy(l1),
+             logits_train_1=npy(l2), mle=npy(mle), kl=npy(kl), logits_eval_0=npy(e1), logits_eval_1=npy(e2),
+             h_eval=npy(hid[0]), c_eval=npy(hid[1]), **pack_sd(m), **grads(m))
+    for vp in ("00", "01", "10", "11"):
+        torch.manual_seed(61 + int(vp))
+        m = ref.VariationalRNNModel("LSTM", V, H, H, 2, 0.0, True, vp)
+        x1 = torch.randint(0, V, (T, B))
+        tgt = torch.randint(0, V, (T * B,))
+        m.train()
+        torch.manual_seed(200)
+        eps = {}
+        for c in (0, 1):  # cell 0 draws its T rows first, then cell 1 (model.py:2503-2512)
+            if int(vp[c]) == 1:
+                eps[c] = torch.stack([torch.zeros(1, H).normal_(0, 0.1)[0] for _ in range(T)])
+        torch.manual_seed(200)
+        l1, hid = m(x1, m.init_hidden(B))
+        mle = torch.nn.functional.cross_entropy(l1.view(-1, V), tgt)
+        kl = torch.zeros(())
+        for c in (0, 1):  # train.py:379-382
+            if int(vp[c]) == 1:
+                kl = kl + m.rnn.rnn[c].vnn.kl_divergence()
+        (mle + kl * 0.07).backward()
+        m.eval()
+        with torch.no_grad():
+            e1, hid = m(x1, m.init_hidden(B))
+        kw = dict(x1=npy(x1), tgt=npy(tgt), kl_scale=np.float32(0.07), logits_train_0=npy(l1), mle=npy(mle), kl=npy(kl),
+                  logits_eval_0=npy(e1), h_eval=npy(hid[0]), c_eval=npy(hid[1]))
+        for c, e in eps.items():
+            kw["eps_%d" % c] = npy(e)
+        save("variational_rnn_" + vp, **kw, **pack_sd(m), **grads(m))
+    for v_pos in (0, 1, 2, 3):
+        torch.manual_seed(71 + v_pos)
+        m = ref.VTransformerModel(50, 16, 4, 32, 4, 0.0, True, v_pos)
+        src = torch.randint(0, 50, (6, 3))
+        m.eval()
+        with torch.no_grad():
+            out = m(src)
+        save("vtransformer_%d" % v_pos, src=npy(src), nhead=np.int64(4), logits_eval=npy(out), **pack_sd(m))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "rnnv":
+        f5_gauss_variational_rnn()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "late":
         f6_train_checkpoint()
         f7_scorer()

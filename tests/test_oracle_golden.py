@@ -219,3 +219,58 @@ def test_scorer_scores_of_reference(tag):
     assert [k for k, _ in got] == [k for k, _ in want]
     for (_, a), (_, b) in zip(got, want):
         assert abs(a - b) <= 2e-4 * max(1.0, abs(b))
+
+
+GAUSS_RNN = ["33", "31", "13", "23", "43", "330", "6360", "3333", "53", "73", "00"]
+
+
+@pytest.mark.parametrize("gp", GAUSS_RNN)
+def test_gauss_rnn_matches_reference(gp):
+    g, sd, grad = load_golden("gauss_rnn_" + gp)
+    B, H = g["x1"].shape[1], sd["encoder.weight"].shape[1]
+    zeros = (torch.zeros(2, B, H), torch.zeros(2, B, H))
+    e1, hid = O.gauss_rnn_lm(g["x1"], zeros, sd, gp)
+    e2, hid = O.gauss_rnn_lm(g["x2"], hid, sd, gp)
+    torch.testing.assert_close(e1, g["logits_eval_0"], **TOL)
+    torch.testing.assert_close(e2, g["logits_eval_1"], **TOL)
+    torch.testing.assert_close(hid[1], g["c_eval"], **TOL)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    l1, hid = O.gauss_rnn_lm(g["x1"], zeros, leaf, gp)
+    l2, hid = O.gauss_rnn_lm(g["x2"], tuple(h.detach() for h in hid), leaf, gp)
+    torch.testing.assert_close(l2, g["logits_train_1"], **TOL)
+    mle = O.cross_entropy_mean(l2, g["tgt"])
+    kl = O.kl_gauss_rnn(leaf, gp)
+    torch.testing.assert_close(kl, g["kl"], **TOL)
+    (mle + kl * float(g["kl_scale"])).backward()
+    for k, gv in grad.items():
+        if k != "decoder.weight":
+            torch.testing.assert_close(leaf[k].grad, gv, rtol=2e-4, atol=2e-6, msg=lambda m, k=k: k + ": " + m)
+
+
+@pytest.mark.parametrize("vp", ["00", "01", "10", "11"])
+def test_variational_rnn_matches_reference(vp):
+    g, sd, grad = load_golden("variational_rnn_" + vp)
+    B, H = g["x1"].shape[1], sd["encoder.weight"].shape[1]
+    zeros = (torch.zeros(2, B, H), torch.zeros(2, B, H))
+    e1, hid, _ = O.variational_rnn_lm(g["x1"], zeros, sd, vp)
+    torch.testing.assert_close(e1, g["logits_eval_0"], **TOL)
+    torch.testing.assert_close(hid[0], g["h_eval"], **TOL)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    eps = {c: g["eps_%d" % c] for c in (0, 1) if "eps_%d" % c in g}
+    l1, hid, kl = O.variational_rnn_lm(g["x1"], zeros, leaf, vp, eps)
+    torch.testing.assert_close(l1, g["logits_train_0"], **TOL)
+    torch.testing.assert_close(kl, g["kl"], **TOL)
+    (O.cross_entropy_mean(l1, g["tgt"]) + kl * float(g["kl_scale"])).backward()
+    for k, gv in grad.items():
+        if k != "decoder.weight":
+            torch.testing.assert_close(leaf[k].grad, gv, rtol=2e-4, atol=2e-6, msg=lambda m, k=k: k + ": " + m)
+
+
+@pytest.mark.parametrize("v_pos", [0, 1, 2, 3])
+def test_vtransformer_matches_reference(v_pos):
+    g, sd, _ = load_golden("vtransformer_%d" % v_pos)
+    torch.testing.assert_close(O.transformer_lm(g["src"], sd, int(g["nhead"]), None), g["logits_eval"], **TOL)
+    nl = len({k.split(".")[1] for k in sd if k.startswith("transformerlayers.")})
+    assert nl == {0: 4, 1: 4, 2: 3, 3: 3}[v_pos]  # the reference's layer-count arithmetic (model.py:2822-2843)
