@@ -39,7 +39,8 @@ class GemmArgs(C.Structure):
                 ("epilogue", C.c_int32), ("bias", C.c_void_p), ("aux", C.c_void_p), ("coef", C.c_void_p),
                 ("var_b", Variational), ("C2", C.c_void_p), ("wg_mu", C.c_void_p), ("var_c", Variational),
                 ("kl_lambda", C.c_float), ("kl_inv_n", C.c_float), ("drop_p", C.c_float), ("drop_rng", Rng),
-                ("drop_B", C.c_int32), ("drop_col_offset", C.c_int32), ("drop_global_cols", C.c_int32)]
+                ("drop_B", C.c_int32), ("drop_col_offset", C.c_int32), ("drop_global_cols", C.c_int32),
+                ("colsum_a", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/bayeslm.h declares

@@ -41,6 +41,8 @@ extern "C" int blm_gemm(const blm_gemm_args* a, void* stream) {
     p.drop_B = a->drop_B; p.drop_col_offset = a->drop_col_offset;
     p.drop_global_cols = a->drop_global_cols > 0 ? a->drop_global_cols : a->drop_B;
   }
+  p.colsum_a = a->colsum_a;
+  if (a->colsum_a && a->op != BLM_GEMM_TN) return blm_fail(BLM_ERR_INVALID, "blm_gemm: colsum_a needs op TN");
   p.drop_quad = (a->N % 4 == 0);
   {
     static int tile = -1, spl = -1;  // tuning overrides, read once
@@ -85,6 +87,11 @@ extern "C" int blm_gemm(const blm_gemm_args* a, void* stream) {
     p.fast = p.a_vec && p.b_vec && ac % 4 == 0 && bc % 4 == 0 && ac >= 4 && bc >= 4;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (p.colsum_a && !p.fast) {  // odd shapes: the guarded-loader kernel does not fuse it
+    const int rc = blm_colsum(a->A, a->lda, a->colsum_a, a->K, a->M, 1, stream);
+    if (rc) return rc;
+    p.colsum_a = nullptr;
+  }
   switch (a->op) {
     case BLM_GEMM_NT: return samp ? launch_op<BLM_GEMM_NT, true>(p, st) : launch_op<BLM_GEMM_NT, false>(p, st);
     case BLM_GEMM_NN: return samp ? launch_op<BLM_GEMM_NN, true>(p, st) : launch_op<BLM_GEMM_NN, false>(p, st);

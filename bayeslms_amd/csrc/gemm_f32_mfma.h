@@ -41,6 +41,7 @@ struct GemmP {
   int a_vec, b_vec, fast;
   int gm, gn;
   int force_tile, force_splits;  // tuning overrides (BLM_GEMM_TILE / BLM_GEMM_SPLITK env), 0 = heuristic
+  float* colsum_a;  // TN only: += column sums of A (= bias gradient of the layer whose wgrad this is)
   int splits, kper, atomic;  // split-K: block ks covers k in [ks*kper, (ks+1)*kper), partial sums by float atomics
   // fused activation dropout
   int drop_on; uint32_t drop_thr; float drop_inv_keep; blm_rng drop_rng;
@@ -233,10 +234,12 @@ __device__ __forceinline__ void epi_elem(const GemmP& p, bool accum, int row, in
     v += bias;
   } else if constexpr (EPI == BLM_EPI_BIAS_GELU) {
     v += bias;
-    if (p.aux) p.aux[o] = v;
-    v = gelu_erf(v) * keep;
+    float cdf, e;
+    gelu_parts(v, cdf, e);
+    if (p.aux) p.aux[o] = (cdf + v * 0.3989422804014327f * e) * keep;  // d(output)/dz: GELU'(z) * dropout keep
+    v = v * cdf * keep;
   } else if constexpr (EPI == BLM_EPI_MUL_DGELU) {
-    v *= dgelu_erf(p.aux[o]) * keep;
+    v *= p.aux[o];
   } else if constexpr (EPI == BLM_EPI_GP_MIX) {
     v += bias;
     if (p.aux) p.aux[o] = v;
@@ -268,8 +271,7 @@ __device__ __forceinline__ void epi_elem(const GemmP& p, bool accum, int row, in
 template <int EPI, int WTM, int WTN>
 __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN], int m0, int n0, int wm, int wn,
                                          int li, int lh) {
-  constexpr bool DROP = (EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_MUL_DGELU || EPI == BLM_EPI_GP_MIX ||
-                         EPI == BLM_EPI_MUL_DGP_MIX);
+  constexpr bool DROP = (EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_GP_MIX || EPI == BLM_EPI_MUL_DGP_MIX);
   constexpr bool BIAS = (EPI == BLM_EPI_BIAS || EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_GP_MIX);
   const bool accum = p.flags & BLM_GEMM_ACCUMULATE;
   int col[WTN];
@@ -409,6 +411,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     }
   }
 
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool do_cs = !A_KMAJ && p.colsum_a != nullptr && (id % p.gn) == 0;  // one N-tile column of blocks does it
+
   auto fetch_fast = [&](int kt) {
     if constexpr (FAST) {
 #pragma unroll
@@ -460,6 +465,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
           }
         }
         rb[j] = sample4(rb[j], rl[j], p.vb, p.vb_cols, srow, scol);
+      }
+    }
+    if constexpr (!A_KMAJ) {  // wgrad: A = dY[k][m]; its column sums are the bias gradient
+      if (do_cs) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) { cs.x += ra[j].x; cs.y += ra[j].y; cs.z += ra[j].z; cs.w += ra[j].w; }
       }
     }
     if constexpr (A_KMAJ) r2s_kmaj<BM, SA>(At, ra); else r2s_nmaj<BM, SA>(At, ra);
@@ -524,6 +535,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     compute((kt - t0) & 1);
     if (more) stash((kt + 1 - t0) & 1, (kt + 1) * BK, false);
     __syncthreads();
+  }
+
+  if constexpr (!A_KMAJ) {
+    if (do_cs) {  // reduce the per-thread partial column sums over the k-row groups through LDS
+      constexpr int TPR = BM / 4, RPP = 256 / TPR;
+      float* red = smem;  // all tiles consumed: the staging buffers are free
+      *reinterpret_cast<float4*>(red + (t / TPR) * BM + 4 * (t % TPR)) = cs;
+      __syncthreads();
+      if (t < BM && m0 + t < p.M) {
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < RPP; ++g) sum += red[g * BM + t];
+        atomicAdd(p.colsum_a + m0 + t, sum * p.alpha);
+      }
+    }
   }
 
   // ---- epilogue (one straight-line, fully unrolled body per epilogue kind: the accumulator must

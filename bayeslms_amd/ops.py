@@ -140,20 +140,20 @@ def set_kernel_timer(t):
 # ----------------------------------------------------------------------------
 def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, *, alpha=1.0, accumulate=False, epilogue=L.EPI_NONE, bias=None,
          aux=None, coef=None, var_b=None, C2=None, wg_mu=None, var_c=None, kl_lambda=0.0, kl_inv_n=0.0,
-         drop=None, drop_B=0, tag=None):
+         drop=None, drop_B=0, tag=None, colsum_a=None):
     if _TIMER is not None and tag is not None:
         ev0, ev1 = _TIMER.bracket(tag)
         ev0.record()
         _gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, alpha, accumulate, epilogue, bias, aux, coef, var_b, C2, wg_mu,
-              var_c, kl_lambda, kl_inv_n, drop, drop_B)
+              var_c, kl_lambda, kl_inv_n, drop, drop_B, colsum_a)
         ev1.record()
         return
     _gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, alpha, accumulate, epilogue, bias, aux, coef, var_b, C2, wg_mu,
-          var_c, kl_lambda, kl_inv_n, drop, drop_B)
+          var_c, kl_lambda, kl_inv_n, drop, drop_B, colsum_a)
 
 
 def _gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, alpha, accumulate, epilogue, bias, aux, coef, var_b, C2, wg_mu,
-          var_c, kl_lambda, kl_inv_n, drop, drop_B):
+          var_c, kl_lambda, kl_inv_n, drop, drop_B, colsum_a=None):
     L.require_gfx950()
     a = L.GemmArgs()
     a.abi_version = L.ABI_VERSION
@@ -178,6 +178,7 @@ def _gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, alpha, accumulate, epilogue, b
         a.drop_B = int(drop_B)
         a.drop_col_offset = int(drop.col_offset)
         a.drop_global_cols = int(drop.global_cols or drop_B)
+    a.colsum_a = ptr(colsum_a)
     check(lib().blm_gemm(C.byref(a), stream()), "blm_gemm")
 
 
@@ -212,10 +213,11 @@ class _Linear(torch.autograd.Function):
             dx = torch.empty_like(x)
             gemm(L.GEMM_NN, dy, w, dx, M, K, N, N, K, K)
         dw = db = None
+        fuse_b = w.requires_grad and b is not None and b.requires_grad and b.is_leaf
         if w.requires_grad:
             buf, acc, dw = _wgrad_target(w)
-            gemm(L.GEMM_TN, dy, x, buf, N, K, M, N, K, K, accumulate=acc)
-        if b is not None and b.requires_grad:
+            gemm(L.GEMM_TN, dy, x, buf, N, K, M, N, K, K, accumulate=acc, colsum_a=_grad_buf(b) if fuse_b else None)
+        if b is not None and b.requires_grad and not fuse_b:
             buf, acc, db = _wgrad_target(b)
             _colsum_into(dy, M, N, buf, accumulate=acc)
         _notify(w, b)
@@ -374,14 +376,14 @@ class _FFN(torch.autograd.Function):
         N2 = w2.shape[0]
         M = x.numel() // D
         bayes = lgstd2 is not None and noise is not None
-        # dz = (dy W2) * keep * gelu'(z): dropout mask and GELU derivative live in the dgrad epilogue
+        # dz = (dy W2) * [gelu'(z) * keep]: the bracket was written by the forward epilogue (aux)
         dz = torch.empty(M, F_, device=x.device, dtype=torch.float32)
         if bayes and fused:
-            gemm(L.GEMM_NN, dy, w2, dz, M, F_, N2, N2, F_, F_, epilogue=L.EPI_MUL_DGELU, aux=z, drop=drop, drop_B=B,
+            gemm(L.GEMM_NN, dy, w2, dz, M, F_, N2, N2, F_, F_, epilogue=L.EPI_MUL_DGELU, aux=z,
                  var_b=_variational(lgstd2, noise, 0, N2), tag="sampled_gemm_dgrad")
         else:
             gemm(L.GEMM_NN, dy, W if bayes else w2, dz, M, F_, N2, N2, F_, F_, epilogue=L.EPI_MUL_DGELU, aux=z,
-                 drop=drop, drop_B=B, tag="sampled_gemm_dgrad" if bayes else None)
+                 tag="sampled_gemm_dgrad" if bayes else None)
         # linear2 weight gradients
         if w2.requires_grad:
             if bayes:
@@ -390,14 +392,16 @@ class _FFN(torch.autograd.Function):
                      var_c=_variational(lgstd2, noise, 0, N2), kl_lambda=kl_lambda, kl_inv_n=1.0 / (N2 * F_),
                      tag="sampled_gemm_wgrad")
             else:
-                gemm(L.GEMM_TN, dy, h, _grad_buf(w2), N2, F_, M, N2, F_, F_, accumulate=True)
-        if b2 is not None and b2.requires_grad:
+                gemm(L.GEMM_TN, dy, h, _grad_buf(w2), N2, F_, M, N2, F_, F_, accumulate=True,
+                     colsum_a=_grad_buf(b2) if (b2 is not None and b2.requires_grad) else None)
+        elif b2 is not None and b2.requires_grad:
             _colsum_into(dy, M, N2, _grad_buf(b2))
         _notify(w2, b2, lgstd2 if bayes else None)
-        # linear1
+        # linear1 (bias gradient = column sums of dz, taken inside the wgrad GEMM)
         if w1.requires_grad:
-            gemm(L.GEMM_TN, dz, x, _grad_buf(w1), F_, D, M, F_, D, D, accumulate=True)
-        if b1.requires_grad:
+            gemm(L.GEMM_TN, dz, x, _grad_buf(w1), F_, D, M, F_, D, D, accumulate=True,
+                 colsum_a=_grad_buf(b1) if b1.requires_grad else None)
+        elif b1.requires_grad:
             _colsum_into(dz, M, F_, _grad_buf(b1))
         _notify(w1, b1)
         dx = None

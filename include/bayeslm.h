@@ -119,8 +119,8 @@ typedef enum blm_gemm_op {
 typedef enum blm_epilogue {
   BLM_EPI_NONE = 0,
   BLM_EPI_BIAS = 1,        /* C = acc + bias[n]                                        */
-  BLM_EPI_BIAS_GELU = 2,   /* z = acc + bias[n]; aux[m,n] = z (if aux); C = gelu_erf(z) */
-  BLM_EPI_MUL_DGELU = 3,   /* C = acc * gelu_erf'(aux[m,n])                            */
+  BLM_EPI_BIAS_GELU = 2,   /* z = acc + bias[n]; C = gelu_erf(z)*keep; aux[m,n] = gelu_erf'(z)*keep (if aux) */
+  BLM_EPI_MUL_DGELU = 3,   /* C = acc * aux[m,n]   (aux as written by BIAS_GELU: GELU' and dropout in one factor) */
   BLM_EPI_BAYES_WGRAD = 4, /* TN only, C = dmu, C2 = dlgstd, see below                 */
   BLM_EPI_GP_MIX = 5,      /* z = acc + bias; aux = z; C = sum_i act_i(z) coef[i,n]     */
   BLM_EPI_MUL_DGP_MIX = 6  /* C = acc * sum_i act_i'(aux) coef[i,n]; C2 (optional) = acc (after dropout) */
@@ -164,11 +164,14 @@ typedef struct blm_gemm_args {
   /* Dropout fused into the activation epilogues (drop_p > 0): C is seen as a
    * (rows, drop_B, N) activation, m = row*drop_B + b, mask keyed by the global
    * element (row, drop_col_offset + b, n) of a tensor with drop_global_cols
-   * columns.  BIAS_GELU / GP_MIX: C = act(z) * keep/(1-p);  MUL_DGELU /
-   * MUL_DGP_MIX: C = acc * keep/(1-p) * act'(aux).  (model.py:1043 dropout) */
+   * columns.  BIAS_GELU / GP_MIX: C = act(z) * keep/(1-p) (BIAS_GELU also folds keep
+   * into aux);  MUL_DGP_MIX: C = acc * keep/(1-p) * act'(aux).  (model.py:1043 dropout) */
   float drop_p;
   blm_rng drop_rng;
   int32_t drop_B, drop_col_offset, drop_global_cols;
+  /* TN only (wgrad dW = dY^T X, A = dY): colsum_a[m] += alpha * sum_k A[k,m], i.e. the bias
+   * gradient of the same layer, taken from the A tiles the kernel stages anyway. */
+  float* colsum_a;
 } blm_gemm_args;
 
 int blm_gemm(const blm_gemm_args* a, void* stream);

@@ -103,13 +103,20 @@ def test_gemm_epilogues(dev):
     ops.gemm(lib.GEMM_NT, A.to(dev), Bm.to(dev), out, M, N, K, K, K, N, epilogue=lib.EPI_BIAS, bias=bias.to(dev))
     assert rel(out, z_ref) < 1e-5
     ops.gemm(lib.GEMM_NT, A.to(dev), Bm.to(dev), out, M, N, K, K, K, N, epilogue=lib.EPI_BIAS_GELU, bias=bias.to(dev), aux=aux)
-    assert rel(aux, z_ref) < 1e-5
     assert rel(out, torch.nn.functional.gelu(z_ref)) < 5e-6
-    # dgelu: C = (A B^T) * gelu'(aux)
+    # aux = gelu'(z) (times the dropout keep factor, 1 here); MUL_DGELU: C = (A B^T) * aux
     zz = z_ref.clone().requires_grad_(True)
     torch.nn.functional.gelu(zz).sum().backward()
+    assert rel(aux, zz.grad) < 1e-5
     ops.gemm(lib.GEMM_NT, A.to(dev), Bm.to(dev), out, M, N, K, K, K, N, epilogue=lib.EPI_MUL_DGELU, aux=aux)
     assert rel(out, (A @ Bm.t()) * zz.grad) < 1e-5
+    # fused bias gradient: column sums of the A operand of a wgrad-shaped TN GEMM (also with split-K)
+    for Mw, Nw, Kw in ((90, 40, 70), (512, 512, 4096), (1536, 64, 300)):
+        dY, X = torch.randn(Kw, Mw, generator=g), torch.randn(Kw, Nw, generator=g)
+        dW, db = torch.zeros(Mw, Nw, device=dev), torch.ones(Mw, device=dev)
+        ops.gemm(lib.GEMM_TN, dY.to(dev), X.to(dev), dW, Mw, Nw, Kw, Mw, Nw, Nw, accumulate=True, colsum_a=db)
+        assert rel(dW, dY.double().t() @ X.double()) < 1e-5
+        assert rel(db, 1.0 + dY.double().sum(0)) < 1e-5
     # GP mixture (tanh, sigmoid, relu, gelu) and its derivative
     coef = torch.rand(4, N, generator=g)
     ops.gemm(lib.GEMM_NT, A.to(dev), Bm.to(dev), out, M, N, K, K, K, N, epilogue=lib.EPI_GP_MIX, bias=bias.to(dev), aux=aux,
