@@ -132,6 +132,83 @@ def compute_scores(nbest, model, vocab, model_type, device, model_2=None, alpha=
     return scores
 
 
+def _batch_nll(model, data, target_flat, model_type, hidden, model_2, hidden_2, alpha):
+    """Per-token NLL (T, N) of a padded batch of hypotheses (all columns start from the same state)."""
+    from . import ops
+    if model_type == 'Transformer':
+        out = model(data)
+    else:
+        out, _ = model(data, hidden)
+    if model_2 is not None:
+        out2 = model_2(data) if model_type == 'Transformer' else model_2(data, hidden_2)[0]
+        out = alpha * out + (1. - alpha) * out2
+    _, nll = ops.cross_entropy(out.view(-1, out.shape[-1]), target_flat)
+    return nll.view(data.shape[0], data.shape[1])
+
+
+def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None, alpha=0.0, mc_samples=0, seed=1111):
+    """the N hypotheses of an utterance are padded into ONE (T_max, N) batch instead
+    of N separate launches.  Exact for causal Transformers (padding sits after every real token) and
+    for LSTMs (all hypotheses start from the same carried state, the carry itself is taken from a
+    B = 1 pass over the first hypothesis exactly as the reference does, :271-274).
+
+    mc_samples = S > 0 (new, default off; not in the reference, which scores with mean weights):
+    S passes with the variational weights sampled (dropout off) and the sentence PROBABILITIES
+    averaged, score = -log(mean_s exp(-NLL_s))."""
+    model.eval()
+    if model_2 is not None:
+        model_2.eval()
+    scores = OrderedDict()
+    is_rnn = model_type != 'Transformer'
+    hidden = model.init_hidden(1) if is_rnn else None
+    hidden_2 = model_2.init_hidden(1) if (model_2 is not None and is_rnn) else None
+    S = max(1, int(mc_samples))
+    if mc_samples > 0:
+        model.train()
+        model.noise_state.dropout_off = True
+        model.set_seed(seed)
+    step = 0
+    with torch.no_grad():
+        for key, hyps in nbest.items():
+            pairs = [get_input_and_target(h, vocab) for h in hyps]
+            lens = [len(x) for x, _ in pairs]
+            Tm, N = max(lens), len(hyps)
+            data = torch.zeros(Tm, N, dtype=torch.int64)
+            tgt = torch.zeros(Tm, N, dtype=torch.int64)
+            for n, (x, t) in enumerate(pairs):
+                data[:lens[n], n] = torch.tensor(x, dtype=torch.int64)
+                tgt[:lens[n], n] = torch.tensor(t, dtype=torch.int64)
+            data, tgt = data.to(device), tgt.to(device)
+            mask = (torch.arange(Tm, device=device).unsqueeze(1) < torch.tensor(lens, device=device).unsqueeze(0)).float()
+            hN = tuple(h.expand(-1, N, -1).contiguous() for h in hidden) if is_rnn else None
+            h2N = tuple(h.expand(-1, N, -1).contiguous() for h in hidden_2) if hidden_2 is not None else None
+            sent = []
+            for s_i in range(S):
+                if mc_samples > 0:
+                    model.set_step(step)
+                    step += 1
+                nll = _batch_nll(model, data, tgt.view(-1), model_type, hN, model_2, h2N, alpha)
+                sent.append((nll * mask).sum(0))
+            if S == 1:
+                tot = sent[0]
+            else:
+                tot = -(torch.logsumexp(-torch.stack(sent), 0) - torch.log(torch.tensor(float(S), device=device)))
+            tot = tot.tolist()
+            scores[key] = [(h, float(v)) for h, v in zip(hyps, tot)]
+            if is_rnn:  # carry = state after the FIRST hypothesis alone, mean weights (reference :271-274)
+                was_training = model.training
+                model.eval()
+                x0 = torch.tensor(pairs[0][0], dtype=torch.int64, device=device).view(-1, 1)
+                _, hidden = model(x0, hidden)
+                if model_2 is not None:
+                    _, hidden_2 = model_2(x0, hidden_2)
+                model.train(was_training)
+    if mc_samples > 0:
+        model.noise_state.dropout_off = False
+        model.eval()
+    return scores
+
+
 def write_scores(scores, path):
     with open(path, 'w', encoding='utf-8') as f:
         for key, lst in scores.items():
@@ -160,6 +237,10 @@ def build_parser():
     p.add_argument('--interpolation_flag', type=int, default=0)
     p.add_argument('--inter_path', type=str, default='')
     p.add_argument('--inter_alpha', type=float, default=0.8)
+    # new, optional
+    p.add_argument('--batched', type=int, default=1, help='1: all hypotheses of an utterance in one padded batch; '
+                   '0: one launch per hypothesis like the reference')
+    p.add_argument('--mc-samples', type=int, default=0, help='S > 0: average sentence probabilities over S weight samples')
     return p
 
 
@@ -179,7 +260,10 @@ def main(argv=None):
         load_partial(model_2, args.inter_path)
         model_2 = model_2.to(device)
     nbest = load_nbest(args.nbest_list)
-    scores = compute_scores(nbest, model_1, vocab, args.model, device, model_2, args.inter_alpha)
+    if args.batched or args.mc_samples > 0:
+        scores = compute_scores_batched(nbest, model_1, vocab, args.model, device, model_2, args.inter_alpha, args.mc_samples)
+    else:
+        scores = compute_scores(nbest, model_1, vocab, args.model, device, model_2, args.inter_alpha)
     write_scores(scores, args.outfile)
     print("Write to %s" % args.outfile)
 

@@ -581,10 +581,13 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   // in C through float atomics (only for the plain epilogue; C is zeroed first unless accumulating)
   const long nb = (long)q.gm * q.gn;
   int splits = 1;
-  if (p.epi == BLM_EPI_NONE && !SAMP && nb < 384 && p.K >= 2048 && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N)) {
+  const bool can_split = p.epi == BLM_EPI_NONE && !SAMP && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N);
+  const bool small_out = (long)p.M * p.N <= (1L << 20);  // e.g. the LSTM recurrent GEMMs (64 x 4096): zeroing C is free
+  const int min_k = small_out ? 128 : 512;               // K per split
+  if (can_split && nb < 384 && p.K >= (small_out ? 512 : 2048)) {
     splits = (int)((512 + nb - 1) / nb);
     if (splits > 8) splits = 8;
-    while (splits > 1 && p.K / splits < 512) --splits;
+    while (splits > 1 && p.K / splits < min_k) --splits;
   }
   if (p.force_splits > 0 && p.epi == BLM_EPI_NONE && !SAMP && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N))
     splits = p.force_splits;

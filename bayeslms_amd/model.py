@@ -41,6 +41,7 @@ class NoiseState:
         self.col_offset = 0
         self.global_cols = 0
         self.fused = False
+        self.dropout_off = False  # Monte-Carlo weight sampling at inference: noise on, dropout off
 
 
 class _Site(nn.Module):
@@ -55,7 +56,7 @@ class _Site(nn.Module):
 
     def _drop(self, p, k=0):
         st = self._st()
-        if not self.training or p <= 0.0:
+        if not self.training or p <= 0.0 or st.dropout_off:
             return ops.NO_DROP
         return Drop(float(p), st.seed, self._site_base + k, st.step, st.col_offset, st.global_cols)
 

@@ -297,12 +297,17 @@ def test_scorer_cli_matches_reference_output(dev, tag, tmp_path):
     torch.save(full, os.path.join(d, "model.pt"))
     argv = ["--nbest-list", os.path.join(d, "nbest.txt"), "--outfile", os.path.join(d, "out.txt"), "--vocabulary",
             os.path.join(d, "words.txt"), "--model-path", os.path.join(d, "model.pt")] + [str(a) for a in g["argv"]]
-    S.main(argv)
-    got = [ln.split() for ln in open(os.path.join(d, "out.txt")).read().splitlines()]
     want = [ln.split() for ln in str(g["scores_txt"]).splitlines()]
-    assert [a[0] for a in got] == [b[0] for b in want]
-    for a, b in zip(got, want):
-        assert abs(float(a[1]) - float(b[1])) <= 1e-3 * max(1.0, abs(float(b[1]))), (a, b)
+    for batched in ("1", "0"):  # padded per-utterance batch (default) and the reference's one-launch-per-hypothesis loop
+        S.main(argv + ["--batched", batched])
+        got = [ln.split() for ln in open(os.path.join(d, "out.txt")).read().splitlines()]
+        assert [a[0] for a in got] == [b[0] for b in want]
+        for a, b in zip(got, want):
+            assert abs(float(a[1]) - float(b[1])) <= 1e-3 * max(1.0, abs(float(b[1]))), (batched, a, b)
+    # Monte-Carlo weight sampling (new option): finite, close to the mean-weight scores for small sigmas
+    S.main(argv + ["--mc-samples", "4"])
+    mc = [float(ln.split()[1]) for ln in open(os.path.join(d, "out.txt")).read().splitlines()]
+    assert len(mc) == len(want) and all(v == v and v >= 0 for v in mc)
 
 
 @pytest.mark.parametrize("margs", [
