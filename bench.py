@@ -44,7 +44,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cols=4, steps=2):
+def cpu_baseline(cols=32, steps=3):
     """The CPU oracle (the reference's algorithm restated, parity-pinned) timed on this box's host
     cores on a BOUNDED sample of the same workload: the same model and window length, `cols` of the
     64 batch columns, full fwd + CE + KL + bwd + clip + SGD."""

@@ -447,3 +447,46 @@ def test_vtransformer_golden(dev, v_pos):
         m.train()
         with pytest.raises(AttributeError):
             m(torch.zeros(100, 1, dtype=torch.long, device=dev))
+
+
+def test_full_size_cfg3_model_against_oracle(dev):
+    """BASELINE.json configs[2] at its real dimensions (6L, d 512, ff 4096, 8 heads, V 33000, T 128;
+    2 batch columns so the CPU oracle finishes in seconds): eval NLL and one train-mode loss +
+    gradients with eps = the Philox stream, GPU engine vs CPU oracle."""
+    from bayeslms_amd import model as M, ops
+    from oracle import bayes_oracle as O, philox as P
+    V, d, h, ff, nl, T, B = 33000, 512, 8, 4096, 6, 128, 2
+    torch.manual_seed(1111)
+    m = M.BayesTransformerModel(V, d, h, ff, nl, 0.0, True, "FFN")
+    zero_dropout(m)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(dev)
+    gen = torch.Generator().manual_seed(5)
+    src = torch.randint(0, V, (T, B), generator=gen)
+    tgt = torch.randint(0, V, (T * B,), generator=gen)
+    torch.set_num_threads(16)
+    m.eval()
+    with torch.no_grad():
+        logits = m(src.to(dev))
+        _, nll = ops.cross_entropy(logits.view(-1, V), tgt.to(dev))
+        ref_logits = O.transformer_lm(src, sd, h, None)
+        ref_nll = O.token_nll(ref_logits, tgt)
+    assert rel(nll, ref_nll) < 1e-4
+    # train mode: eps of layer-0 linear2 from the Philox stream (seed 1111, this module's stream id, step 3)
+    m.train()
+    m.set_seed(1111)
+    m.set_step(3)
+    lin2 = m.transformerlayers[0].linear2
+    logits = m(src.to(dev))
+    loss, _ = ops.cross_entropy(logits.view(-1, V), tgt.to(dev))
+    loss.backward()
+    eps = torch.from_numpy(P.normal(d * ff, 1111, P.STREAM_WEIGHT + lin2._site_base, 3)).view(d, ff)
+    leaf = {k: v.clone().requires_grad_(k.endswith(("weight_mean", "weight_lgstd", "linear1.weight"))) for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    rl = O.cross_entropy_mean(O.transformer_lm(src, leaf, h, eps), tgt)
+    rl.backward()
+    assert abs(float(loss) - float(rl)) < 1e-4 * abs(float(rl))
+    cur = dict(m.named_parameters())
+    for k in ("transformerlayers.0.linear2.weight_mean", "transformerlayers.0.linear2.weight_lgstd",
+              "transformerlayers.3.linear1.weight"):
+        assert grad_close(cur[k].grad, leaf[k].grad, rtol=1e-3, atol=1e-9), k
