@@ -15,6 +15,8 @@
 // write (row stride R+1: conflict-free b32 scatter); operands that are
 // m/n-contiguous are copied with ds_write_b128 (row stride R+4).
 #pragma once
+#include <cstdlib>
+
 #include "blm_device.h"
 #include "blm_host.h"
 
@@ -38,7 +40,7 @@ struct GemmP {
   const float* wg_mu;
   blm_variational vc;
   float kl_lambda, kl_inv_n;
-  int a_vec, b_vec, fast;
+  int a_vec, b_vec, fast, vec_epi;
   int gm, gn;
   int force_tile, force_splits;  // tuning overrides (BLM_GEMM_TILE / BLM_GEMM_SPLITK env), 0 = heuristic
   float* colsum_a;  // TN only: += column sums of A (= bias gradient of the layer whose wgrad this is)
@@ -340,6 +342,74 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN]
   }
 }
 
+// Row-wise epilogue through LDS: the accumulator tile (columns on lanes, rows in registers) is
+// written to the now idle staging buffer 64 rows at a time and read back row-major, so every lane
+// handles 4 consecutive columns: 16-byte loads of bias/aux, one Philox block per lane for the
+// dropout mask, 16-byte stores of C (4x fewer memory instructions than the register-layout walk).
+template <int EPI, int WTM, int WTN>
+__device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM][WTN], float* stage, int m0, int n0,
+                                              int wm, int wn, int li, int lh) {
+  constexpr int BN = 64 * WTN, SS = BN + 4;
+  constexpr int NP = WTM == 2 ? 2 : 1;
+  constexpr int TPRW = BN / 4, RPS = 256 / TPRW;
+  const int t = threadIdx.x, c4 = 4 * (t % TPRW);
+  const int col = n0 + c4;
+  const bool accum = p.flags & BLM_GEMM_ACCUMULATE;
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (EPI == BLM_EPI_BIAS || EPI == BLM_EPI_BIAS_GELU)
+    if (col < p.N) bias = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
+    __syncthreads();
+    if (WTM == 1 || wm == pass) {
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int lrow = (WTM == 2 ? 32 * i : 32 * wm) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            stage[lrow * SS + wn * (32 * WTN) + 32 * j + li] = p.alpha * acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    if (col < p.N) {
+      for (int lr = t / TPRW; lr < 64; lr += RPS) {
+        const int row = m0 + 64 * pass + lr;
+        if (row >= p.M) break;
+        float4 v = *reinterpret_cast<const float4*>(stage + lr * SS + c4);
+        const long o = (long)row * p.ldc + col;
+        if constexpr (EPI == BLM_EPI_BIAS) {
+          v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        } else if constexpr (EPI == BLM_EPI_BIAS_GELU) {
+          float4 kp = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (p.drop_on) {
+            const int rr = row / p.drop_B, b = row - rr * p.drop_B;
+            const uint64_t g = ((uint64_t)rr * p.drop_global_cols + (uint64_t)(p.drop_col_offset + b)) * (uint64_t)p.N + (uint64_t)col;
+            const u32x4 u = philox4x32_10_rolled((uint32_t)(g >> 2), (uint32_t)(g >> 34), p.drop_rng.stream, p.drop_rng.step,
+                                                 (uint32_t)p.drop_rng.seed, (uint32_t)(p.drop_rng.seed >> 32));
+            kp = make_float4(u.x >= p.drop_thr ? p.drop_inv_keep : 0.f, u.y >= p.drop_thr ? p.drop_inv_keep : 0.f,
+                             u.z >= p.drop_thr ? p.drop_inv_keep : 0.f, u.w >= p.drop_thr ? p.drop_inv_keep : 0.f);
+          }
+          float4 d;
+          float cdf, e;
+          v.x += bias.x; gelu_parts(v.x, cdf, e); d.x = (cdf + v.x * 0.3989422804014327f * e) * kp.x; v.x = v.x * cdf * kp.x;
+          v.y += bias.y; gelu_parts(v.y, cdf, e); d.y = (cdf + v.y * 0.3989422804014327f * e) * kp.y; v.y = v.y * cdf * kp.y;
+          v.z += bias.z; gelu_parts(v.z, cdf, e); d.z = (cdf + v.z * 0.3989422804014327f * e) * kp.z; v.z = v.z * cdf * kp.z;
+          v.w += bias.w; gelu_parts(v.w, cdf, e); d.w = (cdf + v.w * 0.3989422804014327f * e) * kp.w; v.w = v.w * cdf * kp.w;
+          if (p.aux) *reinterpret_cast<float4*>(p.aux + o) = d;
+        } else if constexpr (EPI == BLM_EPI_MUL_DGELU) {
+          const float4 a = *reinterpret_cast<const float4*>(p.aux + o);
+          v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
+        }
+        float4* dst = reinterpret_cast<float4*>(p.C + o);
+        if (accum) { const float4 old = *dst; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+        *dst = v;
+      }
+    }
+  }
+}
+
 // FAST: every operand 16-B aligned with a leading dimension and contiguous extent that are
 // multiples of 4.  Full K tiles are then fetched by branch-free float4 loads through per-thread
 // pointers set up once (rows/cols outside the matrix are clamped, not zeroed: they only feed
@@ -554,6 +624,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 
   // ---- epilogue (one straight-line, fully unrolled body per epilogue kind: the accumulator must
   // only ever be indexed by compile-time constants or it is demoted to scratch)
+  if (p.vec_epi) {  // aligned C/aux, N % 4 == 0, no atomics: 16-byte row-wise epilogue through LDS
+    switch (p.epi) {
+      case BLM_EPI_NONE: epilogue_rows<BLM_EPI_NONE, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
+      case BLM_EPI_BIAS: epilogue_rows<BLM_EPI_BIAS, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
+      case BLM_EPI_BIAS_GELU: epilogue_rows<BLM_EPI_BIAS_GELU, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
+      case BLM_EPI_MUL_DGELU: epilogue_rows<BLM_EPI_MUL_DGELU, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
+      default: break;
+    }
+  }
   switch (p.epi) {
     case BLM_EPI_BIAS: epilogue<BLM_EPI_BIAS, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
     case BLM_EPI_BIAS_GELU: epilogue<BLM_EPI_BIAS_GELU, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
@@ -594,6 +673,13 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   q.splits = splits;
   q.kper = splits > 1 ? ((p.K + splits - 1) / splits + BK - 1) / BK * BK : (p.K > 0 ? p.K : 1);
   q.atomic = splits > 1;
+  {
+    static int off = -1, row_plain = -1;  // BLM_GEMM_ROW_EPI=0: register-layout epilogue everywhere; =1: rows only for the GELU epilogues (A/B knobs; default: rows for all four)
+    if (off < 0) { const char* e = getenv("BLM_GEMM_ROW_EPI"); off = (e && atoi(e) == 0) ? 1 : 0; row_plain = (e && atoi(e) == 1) ? 0 : 1; }
+    const bool al = ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.aux) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
+    q.vec_epi = !off && !q.atomic && al && p.N % 4 == 0 && p.ldc % 4 == 0 &&
+                (((p.epi == BLM_EPI_NONE || p.epi == BLM_EPI_BIAS) && row_plain) || p.epi == BLM_EPI_BIAS_GELU || p.epi == BLM_EPI_MUL_DGELU);
+  }
   if (q.atomic && !(p.flags & BLM_GEMM_ACCUMULATE))
     BLM_HIP(hipMemsetAsync(p.C, 0, (size_t)p.M * p.N * sizeof(float), st));
   auto kern = gemm_f32_kernel<OP, WTM, WTN, SAMP, FAST>;
