@@ -58,10 +58,8 @@ __device__ __forceinline__ float gemm_keep(const GemmP& p, int m, int n) {
 }
 
 constexpr int BK = 32;
-// Two MFMA tiles of a wave interleaved (rows 2x+t, one ds_read_b64 per operand pair, even LDS stride)
-// or stacked (rows 32t+x, ds_read2_b32, odd conflict-free stride).  Measured on MI355X
-// (tools/gemm_bench.py): LDS read bandwidth is not the limiter, stacked is 1-7 % faster on the
-// NT shapes because the transposing LDS writes stay conflict-free.
+// Epilogue-only switch kept from an experiment (two MFMA tiles of a wave interleaved by rows 2x+t
+// instead of stacked 32t+x; measured neutral on MI355X): the operand paths below are the stacked form.
 constexpr bool INTERLEAVE = false;
 
 // ---- global -> registers -------------------------------------------------
@@ -115,17 +113,14 @@ __device__ __forceinline__ void g2r_nmaj(const float* __restrict__ src, long ld,
   }
 }
 // ---- registers -> LDS ------------------------------------------------------
-template <int R, int S>
+// k-contiguous source: LDS image tile[row][KS] (KS = 32 k + 4 pad floats), written as it was loaded
+// (one ds_write_b128 per float4, 8 lanes cover a row: conflict-free)
+constexpr int KS = 36;
+template <int R>
 __device__ __forceinline__ void r2s_kmaj(float* tile, const float4 (&r)[R / 32]) {
   const int t = threadIdx.x, kq = t & 7, rr = t >> 3;
 #pragma unroll
-  for (int j = 0; j < R / 32; ++j) {
-    float* d = tile + (4 * kq) * S + rr + 32 * j;
-    d[0] = r[j].x;
-    d[S] = r[j].y;
-    d[2 * S] = r[j].z;
-    d[3 * S] = r[j].w;
-  }
+  for (int j = 0; j < R / 32; ++j) *reinterpret_cast<float4*>(tile + (rr + 32 * j) * KS + 4 * kq) = r[j];
 }
 template <int C, int S>
 __device__ __forceinline__ void r2s_nmaj(float* tile, const float4 (&r)[C / 32]) {
@@ -165,28 +160,59 @@ __device__ __forceinline__ float dgp_mix(float z, const float* coef, int N, int 
 __device__ __forceinline__ uint32_t lds_u32(const float* p) { return (uint32_t)(uintptr_t)p; }  // LDS byte offset
 
 using f32x2 = __attribute__((ext_vector_type(2))) float;
-template <int W> struct Frag;
-template <> struct Frag<1> {
-  float v;
-  __device__ __forceinline__ void read(uint32_t addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr)); }
-  __device__ __forceinline__ float get(int) const { return v; }
-};
-template <> struct Frag<2> {  // the wave's two interleaved MFMA tiles: adjacent floats, 8-byte aligned
-  f32x2 v;
-  __device__ __forceinline__ void read(uint32_t addr) {
-    if constexpr (INTERLEAVE) asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
-    else asm volatile("ds_read2_b32 %0, %1 offset1:32" : "=v"(v) : "v"(addr));
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// Operand fragments of one GROUP of four MFMA k-steps.  Within a K tile of 32 the k order is
+// k(t, s, half) = 8t + 4*half + s  (t = group 0..3, s = step 0..3, half = lane >> 5): a lane's four
+// values of a group are then CONTIGUOUS in a k-contiguous LDS row, i.e. one ds_read_b128.
+//   FragG<true , W>: image tile[row][KS]   -> W ds_read_b128 per group
+//   FragG<false, W>: image tile[k][S]      -> 4 ds_read(2)_b32 per group (rows 8t + 4*half + s)
+// All reads are inline asm so that the group t+1 reads can be put in front of the group t MFMAs with
+// a counted lgkmcnt (hipcc re-serialises the C++ form).
+template <bool KMAJ, int W, int S> struct FragG;
+template <int W, int S> struct FragG<true, W, S> {
+  static constexpr int NREAD = W;
+  f32x4 v[W];
+  // base = byte address of (row = lane&31 of MFMA tile 0, k = 4*half)
+  __device__ __forceinline__ void read(uint32_t base, int t) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(v[i]) : "v"(base + (uint32_t)((32 * i * KS + 8 * t) * 4)));
   }
-  __device__ __forceinline__ float get(int i) const { return i == 0 ? v.x : v.y; }
+  __device__ __forceinline__ float get(int i, int s) const { return v[i][s]; }
+  __device__ __forceinline__ void tie() {
+#pragma unroll
+    for (int i = 0; i < W; ++i) asm volatile("" : "+v"(v[i]));
+  }
 };
-template <int WA, int WB>
-__device__ __forceinline__ void wait_lgkm2(Frag<WA>& a, Frag<WB>& b) {
-  asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a.v), "+v"(b.v));
-}
-template <int WA, int WB>
-__device__ __forceinline__ void wait_lgkm0(Frag<WA>& a, Frag<WB>& b) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v), "+v"(b.v));
-}
+template <int S> struct FragG<false, 2, S> {
+  static constexpr int NREAD = 4;
+  f32x2 v[4];
+  // base = byte address of (k row = 4*half, column = lane&31 of MFMA tile 0); tile 1 is 32 floats further
+  __device__ __forceinline__ void read(uint32_t base, int t) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("ds_read2_b32 %0, %1 offset1:32" : "=v"(v[s]) : "v"(base + (uint32_t)((8 * t + s) * S * 4)));
+  }
+  __device__ __forceinline__ float get(int i, int s) const { return i == 0 ? v[s].x : v[s].y; }
+  __device__ __forceinline__ void tie() {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(v[s]));
+  }
+};
+template <int S> struct FragG<false, 1, S> {
+  static constexpr int NREAD = 4;
+  float v[4];
+  __device__ __forceinline__ void read(uint32_t base, int t) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("ds_read_b32 %0, %1" : "=v"(v[s]) : "v"(base + (uint32_t)((8 * t + s) * S * 4)));
+  }
+  __device__ __forceinline__ float get(int, int s) const { return v[s]; }
+  __device__ __forceinline__ void tie() {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(v[s]));
+  }
+};
+template <int N>
+__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
 
 // Dropout keep factors for the four rows base_row + {0,1,2,3}*row_stride at this lane's column: the four
 // lanes of a quad own four consecutive columns = one Philox block per row, so lane k generates the
@@ -421,12 +447,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   // k-contiguous sources are transposed on the LDS write: stride BM+2 keeps that scatter at most
   // 2-way conflicting (free for ds_write_b32) AND even, so the interleaved two-tile operand read is an
   // aligned ds_read_b64; single-tile waves use BM+1 (conflict-free).  m/n-contiguous: BM+4 (b128 rows).
-  constexpr int SA = A_KMAJ ? ((INTERLEAVE && WTM == 2) ? BM + 2 : BM + 1) : BM + 4;
-  constexpr int SB = B_KMAJ ? ((INTERLEAVE && WTN == 2) ? BN + 2 : BN + 1) : BN + 4;
+  // m/n-contiguous operands: image tile[k][BM+4]; k-contiguous ones: tile[row][KS]
+  constexpr int SA = BM + 4, SB = BN + 4;
+  constexpr int TA = A_KMAJ ? BM * KS : BK * SA, TB = B_KMAJ ? BN * KS : BK * SB;  // floats per staged tile
   constexpr int NA = BM / 32, NB = BN / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const As = smem;
-  float* const Bs = smem + 2 * BK * SA;
+  float* const Bs = smem + 2 * TA;
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
   // contiguous run of tile ids; n is fastest so neighbours reuse the same A panel out of that XCD's L2.
@@ -519,8 +546,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   };
   // registers -> LDS (with the variational transform W = mu + exp(lgstd)*eps on the B operand)
   auto stash = [&](int buf, int k0, bool fast) {
-    float* At = As + buf * BK * SA;
-    float* Bt = Bs + buf * BK * SB;
+    float* At = As + buf * TA;
+    float* Bt = Bs + buf * TB;
     if constexpr (SAMP) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
@@ -543,8 +570,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
         for (int j = 0; j < NA; ++j) { cs.x += ra[j].x; cs.y += ra[j].y; cs.z += ra[j].z; cs.w += ra[j].w; }
       }
     }
-    if constexpr (A_KMAJ) r2s_kmaj<BM, SA>(At, ra); else r2s_nmaj<BM, SA>(At, ra);
-    if constexpr (B_KMAJ) r2s_kmaj<BN, SB>(Bt, rb); else r2s_nmaj<BN, SB>(Bt, rb);
+    if constexpr (A_KMAJ) r2s_kmaj<BM>(At, ra); else r2s_nmaj<BM, SA>(At, ra);
+    if constexpr (B_KMAJ) r2s_kmaj<BN>(Bt, rb); else r2s_nmaj<BN, SB>(Bt, rb);
   };
 
   f32x16 acc[WTM][WTN];
@@ -553,34 +580,41 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 #pragma unroll
     for (int j = 0; j < WTN; ++j) acc[i][j] = (f32x16)(0.f);
 
-  // One K tile = 16 k-pairs.  Operands of pair s+1 are read from LDS BEFORE the MFMAs of pair s are
-  // issued (two register sets), so the ds_read latency sits under 4 x 64 cycles of matrix work
-  // instead of in front of it.  hipcc re-serialises a plain-C++ version of this (read -> wait ->
-  // MFMA on one register set), so the reads and their counted lgkmcnt waits are inline asm
-  // (cdna_hip_programming.md 5.7: loads "=v", a wait statement naming the consumed set "+v",
-  // then sched_barrier(0) so no MFMA is hoisted above the wait).
+  // One K tile = 4 groups of 4 MFMA k-steps.  The fragments of group t+1 are requested from LDS BEFORE
+  // the 4 x WTM x WTN MFMAs of group t are issued (two register sets), so the ds_read latency sits
+  // under >= 1024 cycles of matrix work.  Reads and their counted lgkmcnt wait are inline asm
+  // (cdna_hip_programming.md 5.7): after the wait every fragment register of the group is tied with an
+  // empty "+v" statement and a sched_barrier(0) keeps the MFMAs below it.
   auto compute = [&](int cur) {
-    const uint32_t a_base = lds_u32(As + cur * BK * SA + lh * SA + wm * (32 * WTM) + ((INTERLEAVE && WTM == 2) ? 2 * li : li));
-    const uint32_t b_base = lds_u32(Bs + cur * BK * SB + lh * SB + wn * (32 * WTN) + ((INTERLEAVE && WTN == 2) ? 2 * li : li));
-    Frag<WTM> a[2];
-    Frag<WTN> b[2];
-    a[0].read(a_base);
-    b[0].read(b_base);
+    using FA = FragG<A_KMAJ, WTM, SA>;
+    using FB = FragG<B_KMAJ, WTN, SB>;
+    const uint32_t a_base = A_KMAJ ? lds_u32(As + cur * TA + (wm * (32 * WTM) + li) * KS + 4 * lh)
+                                   : lds_u32(As + cur * TA + (4 * lh) * SA + wm * (32 * WTM) + li);
+    const uint32_t b_base = B_KMAJ ? lds_u32(Bs + cur * TB + (wn * (32 * WTN) + li) * KS + 4 * lh)
+                                   : lds_u32(Bs + cur * TB + (4 * lh) * SB + wn * (32 * WTN) + li);
+    FA a[2];
+    FB b[2];
+    a[0].read(a_base, 0);
+    b[0].read(b_base, 0);
 #pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
-      if (s + 1 < BK / 2) {
-        a[(s + 1) & 1].read(a_base + (2 * s + 2) * SA * 4);
-        b[(s + 1) & 1].read(b_base + (2 * s + 2) * SB * 4);
-        wait_lgkm2(a[s & 1], b[s & 1]);  // everything but the two reads just issued has landed
+    for (int t4 = 0; t4 < 4; ++t4) {
+      if (t4 + 1 < 4) {
+        a[(t4 + 1) & 1].read(a_base, t4 + 1);
+        b[(t4 + 1) & 1].read(b_base, t4 + 1);
+        wait_lgkm<FA::NREAD + FB::NREAD>();  // all but the reads just issued have landed
       } else {
-        wait_lgkm0(a[s & 1], b[s & 1]);
+        wait_lgkm<0>();
       }
+      a[t4 & 1].tie();
+      b[t4 & 1].tie();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < WTM; ++i)
+      for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-        for (int j = 0; j < WTN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1].get(i), b[s & 1].get(j), acc[i][j], 0, 0, 0);
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t4 & 1].get(i, s4), b[t4 & 1].get(j, s4), acc[i][j], 0, 0, 0);
     }
   };
 
@@ -650,9 +684,8 @@ template <int OP, int WTM, int WTN, bool SAMP, bool FAST>
 static int launch_cfg(const GemmP& p, hipStream_t st) {
   constexpr int BM = 64 * WTM, BN = 64 * WTN;
   constexpr bool A_KMAJ = (OP != BLM_GEMM_TN), B_KMAJ = (OP == BLM_GEMM_NT);
-  constexpr int SA = A_KMAJ ? ((INTERLEAVE && WTM == 2) ? BM + 2 : BM + 1) : BM + 4,
-                SB = B_KMAJ ? ((INTERLEAVE && WTN == 2) ? BN + 2 : BN + 1) : BN + 4;
-  constexpr size_t lds = (size_t)2 * BK * (SA + SB) * sizeof(float);
+  constexpr int TA = A_KMAJ ? BM * KS : BK * (BM + 4), TB = B_KMAJ ? BN * KS : BK * (BN + 4);
+  constexpr size_t lds = (size_t)2 * (TA + TB) * sizeof(float);
   GemmP q = p;
   q.gm = (p.M + BM - 1) / BM;
   q.gn = (p.N + BN - 1) / BN;

@@ -149,6 +149,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss)
+    # eval PPL (the other half of BASELINE.json's metric): mean-weight forward on held-out synthetic
+    # text exactly as train.py:441-458 (eval batch 20), outside the timed region
+    eval_ppl = None
+    if rank == 0:
+        import math
+        valid = batchify(synthetic_corpus(V, 20 * (4 * T + 1), seed=2222), 20, dev)
+        eval_ppl = math.exp(min(engine.evaluate(model, valid, T), 50.0))
 
     if rank == 0:
         tokens = args.steps * T * Bc * world
@@ -179,7 +186,7 @@ def main():
                        "fused_sampling": bool(model.noise_state.fused)},
             "roofline": roof,
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kt.items()},
-            "final_loss": round(final_loss, 4),
+            "final_loss": round(final_loss, 4), "eval_ppl": round(eval_ppl, 2),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
