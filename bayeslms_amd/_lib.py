@@ -74,6 +74,7 @@ SIGNATURES = {
     "blm_clip_sgd_multi": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _i, _f, _vp]),
     "blm_lstm_cell_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "blm_lstm_cell_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "blm_lstm_cell_bwd2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "blm_lstm_cell_ovr_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "blm_lstm_cell_ovr_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "blm_gp_mix_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),

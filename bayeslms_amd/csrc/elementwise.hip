@@ -517,7 +517,8 @@ __global__ __launch_bounds__(TPB) void lstm_cell_fwd_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(TPB) void lstm_cell_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc_next,
+__global__ __launch_bounds__(TPB) void lstm_cell_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dh2,
+                                                            const float* __restrict__ dc_next,
                                                             const float* __restrict__ c_prev, const float* __restrict__ c,
                                                             const float* __restrict__ ga, float* __restrict__ dgates,
                                                             float* __restrict__ dc_prev, int B, int H) {
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(TPB) void lstm_cell_bwd_kernel(const float* __restr
     const long b = i / H, j = i - b * H, o = b * 4 * H + j;
     const float gi = ga[o], gf = ga[o + H], gg = ga[o + 2 * H], go = ga[o + 3 * H];
     const float tc = tanhf(c[i]);
-    const float dhv = dh[i];
+    const float dhv = dh[i] + (dh2 ? dh2[i] : 0.f);
     const float dc = (dc_next ? dc_next[i] : 0.f) + dhv * go * (1.f - tc * tc);
     dgates[o] = dc * gg * gi * (1.f - gi);
     dgates[o + H] = dc * c_prev[i] * gf * (1.f - gf);
@@ -805,10 +806,16 @@ extern "C" int blm_lstm_cell_fwd(const float* xw, const float* hw, const float* 
 
 extern "C" int blm_lstm_cell_bwd(const float* dh, const float* dc_next, const float* c_prev, const float* c,
                                  const float* gates_act, float* dgates, float* dc_prev, int B, int H, void* stream) {
+  return blm_lstm_cell_bwd2(dh, nullptr, dc_next, c_prev, c, gates_act, dgates, dc_prev, B, H, stream);
+}
+
+extern "C" int blm_lstm_cell_bwd2(const float* dh, const float* dh2, const float* dc_next, const float* c_prev,
+                                  const float* c, const float* gates_act, float* dgates, float* dc_prev, int B, int H,
+                                  void* stream) {
   if (!dh || !c_prev || !c || !gates_act || !dgates || !dc_prev || B < 0 || H < 0)
     return blm_fail(BLM_ERR_INVALID, "blm_lstm_cell_bwd: bad arguments");
   if ((long)B * H == 0) return BLM_OK;
-  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for((long)B * H)), dim3(TPB), 0, ST, dh, dc_next, c_prev, c, gates_act,
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for((long)B * H)), dim3(TPB), 0, ST, dh, dh2, dc_next, c_prev, c, gates_act,
                      dgates, dc_prev, B, H);
   BLM_HIP(hipGetLastError());
   return BLM_OK;

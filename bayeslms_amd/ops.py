@@ -814,14 +814,15 @@ class _LSTMLayer(torch.autograd.Function):
         dc = torch.zeros(B, H, device=dev, dtype=torch.float32) if dcT is None else _f32(dcT, "dcT").clone()
         dh_rec = torch.empty(B, H, device=dev, dtype=torch.float32)
         st = stream()
+        dcs = torch.empty(2, B, H, device=dev, dtype=torch.float32)  # ping-pong dc buffers
+        dcs[0].copy_(dc)
         for t in range(T - 1, -1, -1):
-            check(lib().blm_axpy(ptr(dy[t]), ptr(dh), B * H, 1.0, st), "blm_axpy")
-            dc_prev = torch.empty(B, H, device=dev, dtype=torch.float32)
-            check(lib().blm_lstm_cell_bwd(ptr(dh), ptr(dc), ptr(cs[t]), ptr(cs[t + 1]), ptr(ga[t]), ptr(dgates[t]),
-                                          ptr(dc_prev), B, H, st), "blm_lstm_cell_bwd")
+            k = (T - 1 - t) & 1
+            check(lib().blm_lstm_cell_bwd2(ptr(dh), ptr(dy[t]), ptr(dcs[k]), ptr(cs[t]), ptr(cs[t + 1]), ptr(ga[t]),
+                                           ptr(dgates[t]), ptr(dcs[k ^ 1]), B, H, st), "blm_lstm_cell_bwd2")
             gemm(L.GEMM_NN, dgates[t], w_hh, dh_rec, B, H, G, G, H, H)
             dh, dh_rec = dh_rec, dh
-            dc = dc_prev
+        dc = dcs[T & 1]
         dx = torch.empty_like(x)
         gemm(L.GEMM_NN, dgates, w_ih, dx, T * B, E, G, G, E, E)
         dw_ih = torch.empty_like(w_ih)

@@ -271,6 +271,10 @@ int blm_lstm_cell_fwd(const float* xw, const float* hw, const float* c_prev, flo
 /* In: dh (sum of grad from above and from next step), dc_next; out: dgates (B,4H), dc_prev. */
 int blm_lstm_cell_bwd(const float* dh, const float* dc_next, const float* c_prev, const float* c, const float* gates_act,
                       float* dgates, float* dc_prev, int B, int H, void* stream);
+/* Same with the incoming hidden gradient given as two addends (recurrent part + this step's dy),
+ * so the host needs no separate accumulation pass per time step. */
+int blm_lstm_cell_bwd2(const float* dh, const float* dh2, const float* dc_next, const float* c_prev, const float* c,
+                       const float* gates_act, float* dgates, float* dc_prev, int B, int H, void* stream);
 /* GP-LSTM cell (GPLSTMCell.Gplstm, model.py:1745-1777): same cell, but gate `gate_idx` (0 i, 1 f,
  * 2 g, 3 o) takes its ACTIVATED value from gate_ovr (B,H) -- the output of a GPNN -- instead of
  * sigmoid/tanh of its pre-activation.  Backward returns, in slot gate_idx of dgates, the gradient
