@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libbayeslm_hip.so")
 
 ABI_VERSION = 1
 OK = 0
+ERR_INVALID, ERR_ABI, ERR_HIP, ERR_UNSUPPORTED = -1, -2, -3, -4  # blm_status (include/bayeslm.h)
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_MUL_DGELU, EPI_BAYES_WGRAD, EPI_GP_MIX, EPI_MUL_DGP_MIX = range(7)
 GEMM_ACCUMULATE = 1
@@ -72,6 +73,9 @@ SIGNATURES = {
     "blm_sqnorm_ws_floats": (_i64, [_i]),
     "blm_sqnorm_multi": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "blm_clip_sgd_multi": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _i, _f, _vp]),
+    "blm_lstm_step_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "blm_lstm_step_bwd": (_i, [_vp] * 10 + [_i, _i, _vp]),
+    "blm_transpose": (_i, [_vp, _vp, _i, _i, _vp]),
     "blm_lstm_cell_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "blm_lstm_cell_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "blm_lstm_cell_bwd2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),

@@ -46,19 +46,34 @@ struct AttnM {
   int drop;
 };
 
-// rows [0,T) x 64 floats of a (T,B,*) tensor -> dst[row*LS + c] (* mul); rows [T,128) zeroed
-__device__ __forceinline__ void load_rows(float* dst, const float* src, long ld, int T, int B, int b, int off, float mul) {
-  for (int i = threadIdx.x; i < AT * (HD / 4); i += 128) {
-    const int row = i >> 4, c = (i & 15) << 2;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < T) {
-      const float* s = src + ((long)row * B + b) * ld + off + c;
-      if ((reinterpret_cast<uintptr_t>(s) & 15) == 0) v = *reinterpret_cast<const float4*>(s);
-      else v = make_float4(s[0], s[1], s[2], s[3]);
-    }
-    float* d = dst + row * LS + c;
-    d[0] = v.x * mul; d[1] = v.y * mul; d[2] = v.z * mul; d[3] = v.w * mul;
+// rows [0,T) x 64 floats of a (T,B,*) tensor -> dst[row*LS + c] (* mul); rows [T,128) zeroed.
+// Split in an issue half (16 independent float4 loads per thread) and an LDS-write half so a kernel
+// can put ALL of its prologue loads in flight before it waits on any of them: a 2-wave workgroup has
+// nothing else to hide the memory latency behind (PMC: waves of the first version were parked on
+// s_waitcnt for half of their lifetime).
+__device__ __forceinline__ void fetch_rows(float4 (&v)[16], const float* src, long ld, int T, int B, int b, int off) {
+  const bool al = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)(ld * 4) | (uintptr_t)(off * 4)) & 15) == 0;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int i = threadIdx.x + 128 * u, row = i >> 4, c = (i & 15) << 2;
+    const float* s = src + ((long)min(row, T - 1) * B + b) * ld + off + c;
+    if (al) v[u] = *reinterpret_cast<const float4*>(s);
+    else v[u] = make_float4(s[0], s[1], s[2], s[3]);
   }
+}
+__device__ __forceinline__ void put_rows(float* dst, const float4 (&v)[16], int T, float mul) {
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int i = threadIdx.x + 128 * u, row = i >> 4, c = (i & 15) << 2;
+    const float m = row < T ? mul : 0.f;
+    float* d = dst + row * LS + c;
+    d[0] = v[u].x * m; d[1] = v[u].y * m; d[2] = v[u].z * m; d[3] = v[u].w * m;
+  }
+}
+// the 32 B-operand values of one lane: row-contiguous floats base[2s] (base already includes the lane's k half)
+__device__ __forceinline__ void fetch_op(float (&r)[32], const float* base) {
+#pragma unroll
+  for (int s = 0; s < 32; ++s) r[s] = base[2 * s];
 }
 
 // MFMA row index held in accumulator register r by a lane of half h
@@ -82,18 +97,50 @@ __device__ __forceinline__ void keep_row4(const AttnM& p, uint64_t grow, int c0,
 __device__ __forceinline__ f32x16 tile_rows_x_regs(const float* X, int row0, const float (&breg)[32], int li, int lh) {
   f32x16 acc = (f32x16)(0.f);
   const float* a = X + (row0 + li) * LS + lh;
+  // all 32 LDS operand reads are issued first (independent, one VGPR each) so the matrix pipe is not
+  // stalled on a ds_read latency in front of every MFMA
+  float av[32];
 #pragma unroll
-  for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * s], breg[s], acc, 0, 0, 0);
+  for (int s = 0; s < 32; ++s) av[s] = a[2 * s];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], breg[s], acc, 0, 0, 0);
   return acc;
+}
+
+// two independent S^T-style tiles with their MFMA chains interleaved (a chain of dependent
+// v_mfma_f32_32x32x2_f32 on one accumulator leaves issue slots empty between links)
+__device__ __forceinline__ void tile2_rows_x_regs(f32x16& acc1, f32x16& acc2, const float* X1, const float* X2, int row0,
+                                                  const float (&b1)[32], const float (&b2)[32], int li, int lh) {
+  acc1 = (f32x16)(0.f);
+  acc2 = (f32x16)(0.f);
+  const float* a1 = X1 + (row0 + li) * LS + lh;
+  const float* a2 = X2 + (row0 + li) * LS + lh;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float av1[16], av2[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { av1[s] = a1[2 * (16 * h + s)]; av2[s] = a2[2 * (16 * h + s)]; }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], b1[16 * h + s], acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[s], b2[16 * h + s], acc2, 0, 0, 0);
+    }
+  }
 }
 
 // Y^T[d][lane col] += sum over the 32 rows of the register tile:  A = X[row0 + mrow(s,h)][32*dt + (lane&31)], B = regs
 __device__ __forceinline__ void acc_xt_regs(f32x16 (&acc)[2], const float* X, int row0, const f32x16& breg, int li, int lh) {
+  float a0[16], a1[16];
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
     const float* a = X + (row0 + mrow(s, lh)) * LS + li;
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], breg[s], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[32], breg[s], acc[1], 0, 0, 0);
+    a0[s] = a[0];
+    a1[s] = a[32];
+  }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], breg[s], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], breg[s], acc[1], 0, 0, 0);
   }
 }
 
@@ -111,79 +158,116 @@ __device__ __forceinline__ void store_t(float* dst_row, const f32x16 (&acc)[2], 
 }
 
 // ------------------------------------------------------------------ forward
+__device__ __forceinline__ void attn_fwd_pass(const AttnM& p, const float* Ks, const float* Vs, int qt, float (&qreg)[32],
+                                              int b, int off, uint64_t bh, int li, int lh) {
+  const int T = p.T;
+  const int q = 32 * qt + li;
+  const bool qok = q < T;
+#pragma unroll
+  for (int s = 0; s < 32; ++s) qreg[s] *= p.scale;
+  f32x16 st[4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    if (kt <= qt) {
+      st[kt] = tile_rows_x_regs(Ks, 32 * kt, qreg, li, lh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kt + mrow(r, lh);
+        if (key > q) st[kt][r] = -INFINITY;  // causal (also hides keys >= T for valid queries)
+        m = fmaxf(m, st[kt][r]);
+      }
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float l = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    if (kt <= qt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[kt][r] = __expf(st[kt][r] - m);
+        l += st[kt][r];
+      }
+    }
+  }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.f / l;
+  f32x16 ot[2] = {(f32x16)(0.f), (f32x16)(0.f)};
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    if (kt <= qt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float kp[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.drop) keep_row4(p, bh * T + min(q, T - 1), 32 * kt + 8 * g + 4 * lh, kp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st[kt][4 * g + e] *= inv * kp[e];
+      }
+      acc_xt_regs(ot, Vs, 32 * kt, st[kt], li, lh);
+    }
+  }
+  if (qok) {
+    store_t(p.out + ((long)q * p.B + b) * ((long)p.nhead * HD) + off, ot, lh, 1.f);
+    if (p.lse && lh == 0) p.lse[(long)blockIdx.x * T + q] = m + __logf(l);
+  }
+}
+
 __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(const AttnM p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Ks = sm;
   float* Vs = sm + AT * LS;
   const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
   const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
-  load_rows(Ks, p.k, p.ld, T, p.B, b, off, 1.f);
-  load_rows(Vs, p.v, p.ld, T, p.B, b, off, 1.f);
-  __syncthreads();
   const int ntile = (T + 31) >> 5;
-  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    const int qt = pass == 0 ? wave : 3 - wave;  // tiles {w, 3-w}: equal causal work per wave
-    if (qt >= ntile) continue;
-    const int q = 32 * qt + li;
-    const bool qok = q < T;
-    float qreg[32];
-    {
-      const float* qs = p.q + ((long)min(q, T - 1) * p.B + b) * p.ld + off + lh;
-#pragma unroll
-      for (int s = 0; s < 32; ++s) qreg[s] = qs[2 * s] * p.scale;
-    }
-    f32x16 st[4];
-    float m = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      if (kt <= qt) {
-        st[kt] = tile_rows_x_regs(Ks, 32 * kt, qreg, li, lh);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = 32 * kt + mrow(r, lh);
-          if (key > q) st[kt][r] = -INFINITY;  // causal (also hides keys >= T for valid queries)
-          m = fmaxf(m, st[kt][r]);
-        }
-      }
-    }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      if (kt <= qt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          st[kt][r] = __expf(st[kt][r] - m);
-          l += st[kt][r];
-        }
-      }
-    }
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.f / l;
-    f32x16 ot[2] = {(f32x16)(0.f), (f32x16)(0.f)};
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      if (kt <= qt) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float kp[4] = {1.f, 1.f, 1.f, 1.f};
-          if (p.drop) keep_row4(p, bh * T + min(q, T - 1), 32 * kt + 8 * g + 4 * lh, kp);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) st[kt][4 * g + e] *= inv * kp[e];
-        }
-        acc_xt_regs(ot, Vs, 32 * kt, st[kt], li, lh);
-      }
-    }
-    if (qok) {
-      store_t(p.out + ((long)q * p.B + b) * ((long)p.nhead * HD) + off, ot, lh, 1.f);
-      if (p.lse && lh == 0) p.lse[(long)blockIdx.x * T + q] = m + __logf(l);
-    }
+  const int qt0 = wave, qt1 = 3 - wave;  // tiles {w, 3-w}: equal causal work per wave
+  float qa[32], qb[32];
+  {
+    float4 kk[16], vv[16];
+    fetch_rows(kk, p.k, p.ld, T, p.B, b, off);
+    fetch_rows(vv, p.v, p.ld, T, p.B, b, off);
+    fetch_op(qa, p.q + ((long)min(32 * qt0 + li, T - 1) * p.B + b) * p.ld + off + lh);
+    put_rows(Ks, kk, T, 1.f);
+    put_rows(Vs, vv, T, 1.f);
+    fetch_op(qb, p.q + ((long)min(32 * qt1 + li, T - 1) * p.B + b) * p.ld + off + lh);
   }
+  __syncthreads();
+  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
+  if (qt0 < ntile) attn_fwd_pass(p, Ks, Vs, qt0, qa, b, off, bh, li, lh);
+  if (qt1 < ntile) attn_fwd_pass(p, Ks, Vs, qt1, qb, b, off, bh, li, lh);
 }
 
 // ------------------------------------------------------------------ backward: dQ (lane = query)
+__device__ __forceinline__ void attn_dq_pass(const AttnM& p, const float* Ks, const float* Vs, int qt, float (&qreg)[32],
+                                             const float (&doreg)[32], float delta, int b, int off, uint64_t bh, int li, int lh) {
+  const int T = p.T;
+  const int q = 32 * qt + li, qc = min(q, T - 1);
+#pragma unroll
+  for (int s = 0; s < 32; ++s) qreg[s] *= p.scale;
+  delta += __shfl_xor(delta, 32, 64);
+  const float lse = p.lse[(long)blockIdx.x * T + qc];
+  f32x16 dqt[2] = {(f32x16)(0.f), (f32x16)(0.f)};
+#pragma unroll 1
+  for (int kt = 0; kt <= qt; ++kt) {
+    f32x16 st, dp;
+    tile2_rows_x_regs(st, dp, Ks, Vs, 32 * kt, qreg, doreg, li, lh);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float kp[4] = {1.f, 1.f, 1.f, 1.f};
+      if (p.drop) keep_row4(p, bh * T + qc, 32 * kt + 8 * g + 4 * lh, kp);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const int key = 32 * kt + mrow(r, lh);
+        const float pr = key <= q ? __expf(st[r] - lse) : 0.f;
+        st[r] = pr * (dp[r] * kp[e] - delta);  // dS^T
+      }
+    }
+    acc_xt_regs(dqt, Ks, 32 * kt, st, li, lh);
+  }
+  if (q < T) store_t(p.dq + ((long)q * p.B + b) * p.ldd + off, dqt, lh, p.scale);
+}
+
 __global__ __launch_bounds__(128) void attn_bwd_dq_mfma_kernel(const AttnM p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Ks = sm;
@@ -191,55 +275,92 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_mfma_kernel(const AttnM p) {
   const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
   const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
   const long dmodel = (long)p.nhead * HD;
-  load_rows(Ks, p.k, p.ld, T, p.B, b, off, 1.f);
-  load_rows(Vs, p.v, p.ld, T, p.B, b, off, 1.f);
-  __syncthreads();
   const int ntile = (T + 31) >> 5;
-  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    const int qt = pass == 0 ? wave : 3 - wave;
-    if (qt >= ntile) continue;
-    const int q = 32 * qt + li, qc = min(q, T - 1);
-    float qreg[32], doreg[32];
-    float delta = 0.f;
-    {
-      const float* qs = p.q + ((long)qc * p.B + b) * p.ld + off + lh;
-      const float* ds = p.dout + ((long)qc * p.B + b) * dmodel + off + lh;
-      const float* os = p.o_in + ((long)qc * p.B + b) * dmodel + off + lh;
+  const int qt0 = wave, qt1 = 3 - wave;
+  float qa[32], da[32], qb[32], db[32];
+  float delta0 = 0.f, delta1 = 0.f;
+  {
+    const long r0 = (long)min(32 * qt0 + li, T - 1) * p.B + b, r1 = (long)min(32 * qt1 + li, T - 1) * p.B + b;
+    float4 kk[16], vv[16];
+    float oa[32];
+    fetch_rows(kk, p.k, p.ld, T, p.B, b, off);
+    fetch_rows(vv, p.v, p.ld, T, p.B, b, off);
+    fetch_op(qa, p.q + r0 * p.ld + off + lh);
+    fetch_op(da, p.dout + r0 * dmodel + off + lh);
+    fetch_op(oa, p.o_in + r0 * dmodel + off + lh);
+    put_rows(Ks, kk, T, 1.f);
+    put_rows(Vs, vv, T, 1.f);
 #pragma unroll
-      for (int s = 0; s < 32; ++s) {
-        qreg[s] = qs[2 * s] * p.scale;
-        doreg[s] = ds[2 * s];
-        delta += doreg[s] * os[2 * s];
-      }
-    }
-    delta += __shfl_xor(delta, 32, 64);
-    const float lse = p.lse[(long)blockIdx.x * T + qc];
-    f32x16 dqt[2] = {(f32x16)(0.f), (f32x16)(0.f)};
-#pragma unroll 1
-    for (int kt = 0; kt <= qt; ++kt) {
-      f32x16 st = tile_rows_x_regs(Ks, 32 * kt, qreg, li, lh);
-      f32x16 dp = tile_rows_x_regs(Vs, 32 * kt, doreg, li, lh);
+    for (int s = 0; s < 32; ++s) delta0 += da[s] * oa[s];
+    fetch_op(qb, p.q + r1 * p.ld + off + lh);
+    fetch_op(db, p.dout + r1 * dmodel + off + lh);
+    fetch_op(oa, p.o_in + r1 * dmodel + off + lh);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float kp[4] = {1.f, 1.f, 1.f, 1.f};
-        if (p.drop) keep_row4(p, bh * T + qc, 32 * kt + 8 * g + 4 * lh, kp);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const int key = 32 * kt + mrow(r, lh);
-          const float pr = key <= q ? __expf(st[r] - lse) : 0.f;
-          st[r] = pr * (dp[r] * kp[e] - delta);  // dS^T
-        }
-      }
-      acc_xt_regs(dqt, Ks, 32 * kt, st, li, lh);
-    }
-    if (q < T) store_t(p.dq + ((long)q * p.B + b) * p.ldd + off, dqt, lh, p.scale);
+    for (int s = 0; s < 32; ++s) delta1 += db[s] * oa[s];
   }
+  __syncthreads();
+  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
+  if (qt0 < ntile) attn_dq_pass(p, Ks, Vs, qt0, qa, da, delta0, b, off, bh, li, lh);
+  if (qt1 < ntile) attn_dq_pass(p, Ks, Vs, qt1, qb, db, delta1, b, off, bh, li, lh);
 }
 
 // ------------------------------------------------------------------ backward: dK, dV (lane = key)
+__device__ __forceinline__ void attn_dkv_pass(const AttnM& p, const float* Qs, const float* Os, const float* lse_s,
+                                              const float* del_s, int kt, int ntile, const float (&kreg)[32],
+                                              const float (&vreg)[32], int b, int off, uint64_t bh, int lane, int li, int lh) {
+  const int T = p.T;
+  const int key = 32 * kt + li, kc = min(key, T - 1);
+  f32x16 dkt[2] = {(f32x16)(0.f), (f32x16)(0.f)}, dvt[2] = {(f32x16)(0.f), (f32x16)(0.f)};
+#pragma unroll 1
+  for (int qt = kt; qt < ntile; ++qt) {
+    f32x16 sc, dp;  // S[q][key], dP[q][key]: q in registers
+    tile2_rows_x_regs(sc, dp, Qs, Os, 32 * qt, kreg, vreg, li, lh);
+    f32x16 pd;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float kp[4] = {1.f, 1.f, 1.f, 1.f};
+      if (p.drop) {  // rows q0..q0+3 of the probability matrix, 4 adjacent lanes = 4 adjacent keys
+        const int q0 = 32 * qt + 8 * g + 4 * lh;
+        const int kq = lane & 3;
+        const int qrow = min(q0 + kq, T - 1);
+        if ((T & 3) == 0) {
+          const uint64_t gidx = (bh * T + qrow) * (uint64_t)T + (uint64_t)(min(key, T - 1) & ~3);
+          const u32x4 u = philox4x32_10_rolled((uint32_t)(gidx >> 2), (uint32_t)(gidx >> 34), p.rng.stream, p.rng.step,
+                                               (uint32_t)p.rng.seed, (uint32_t)(p.rng.seed >> 32));
+#define BLM_QB(x, j) (uint32_t) __builtin_amdgcn_mov_dpp((int)(x), (j) * 0x55, 0xF, 0xF, true)
+#define BLM_KP(j)                                                                                         \
+{                                                                                                       \
+  const uint32_t w0 = BLM_QB(u.x, j), w1 = BLM_QB(u.y, j), w2 = BLM_QB(u.z, j), w3 = BLM_QB(u.w, j);     \
+  const uint32_t w = kq == 0 ? w0 : (kq == 1 ? w1 : (kq == 2 ? w2 : w3));                               \
+  kp[j] = w >= p.thr ? p.inv_keep : 0.f;                                                                \
+}
+          BLM_KP(0) BLM_KP(1) BLM_KP(2) BLM_KP(3)
+#undef BLM_KP
+#undef BLM_QB
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            kp[e] = philox_bits1_rolled(p.rng, (bh * T + min(q0 + e, T - 1)) * (uint64_t)T + kc) >= p.thr ? p.inv_keep : 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const int qr = 32 * qt + mrow(r, lh);
+        const float pr = (qr >= key && qr < T) ? __expf(sc[r] - lse_s[qr]) : 0.f;
+        pd[r] = pr * kp[e];
+        sc[r] = pr * (dp[r] * kp[e] - del_s[qr]);  // dS[q][key]
+      }
+    }
+    acc_xt_regs(dvt, Os, 32 * qt, pd, li, lh);
+    acc_xt_regs(dkt, Qs, 32 * qt, sc, li, lh);
+  }
+  if (key < T) {
+    store_t(p.dk + ((long)key * p.B + b) * p.ldd + off, dkt, lh, 1.f);
+    store_t(p.dv + ((long)key * p.B + b) * p.ldd + off, dvt, lh, 1.f);
+  }
+}
+
 __global__ __launch_bounds__(128) void attn_bwd_dkv_mfma_kernel(const AttnM p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Qs = sm;               // Q * scale
@@ -249,85 +370,47 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_mfma_kernel(const AttnM p) {
   const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
   const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
   const long dmodel = (long)p.nhead * HD;
-  load_rows(Qs, p.q, p.ld, T, p.B, b, off, p.scale);
-  load_rows(Os, p.dout, dmodel, T, p.B, b, off, 1.f);
-  {  // delta[q] = rowsum(dO * O), lse[q]
-    const int row = threadIdx.x;
-    float d = 0.f, ls = 0.f;
-    if (row < T) {
-      const float* ds = p.dout + ((long)row * p.B + b) * dmodel + off;
-      const float* os = p.o_in + ((long)row * p.B + b) * dmodel + off;
+  const int ntile = (T + 31) >> 5;
+  const int kt0 = wave, kt1 = 3 - wave;  // key tile kt meets query tiles kt..ntile-1: {w, 3-w} balances
+  float ka[32], va[32], kb[32], vb[32];
+  {
+    const long r0 = (long)min(32 * kt0 + li, T - 1) * p.B + b;
+    float4 qq[16], dd[16];
+    fetch_rows(qq, p.q, p.ld, T, p.B, b, off);
+    fetch_rows(dd, p.dout, dmodel, T, p.B, b, off);
+    fetch_op(ka, p.k + r0 * p.ld + off + lh);
+    fetch_op(va, p.v + r0 * p.ld + off + lh);
+    put_rows(Qs, qq, T, p.scale);
+    put_rows(Os, dd, T, 1.f);
+  }
+  {  // delta[q] = rowsum(dO * O), lse[q]: thread = row, 2 x 16 float4 in flight, then this wave's second K/V tile
+    const int row = threadIdx.x, rc = min(row, T - 1);
+    const float* ds = p.dout + ((long)rc * p.B + b) * dmodel + off;
+    const float* os = p.o_in + ((long)rc * p.B + b) * dmodel + off;
+    const float ls = p.lse[(long)blockIdx.x * T + rc];
+    float d = 0.f;
+    if ((((uintptr_t)ds | (uintptr_t)os) & 15) == 0) {
+      float4 dv4[HD / 4], ov4[HD / 4];
+#pragma unroll
+      for (int c = 0; c < HD / 4; ++c) { dv4[c] = reinterpret_cast<const float4*>(ds)[c]; ov4[c] = reinterpret_cast<const float4*>(os)[c]; }
+      const long r1 = (long)min(32 * kt1 + li, T - 1) * p.B + b;
+      fetch_op(kb, p.k + r1 * p.ld + off + lh);
+      fetch_op(vb, p.v + r1 * p.ld + off + lh);
+#pragma unroll
+      for (int c = 0; c < HD / 4; ++c) d += dv4[c].x * ov4[c].x + dv4[c].y * ov4[c].y + dv4[c].z * ov4[c].z + dv4[c].w * ov4[c].w;
+    } else {
+      const long r1 = (long)min(32 * kt1 + li, T - 1) * p.B + b;
+      fetch_op(kb, p.k + r1 * p.ld + off + lh);
+      fetch_op(vb, p.v + r1 * p.ld + off + lh);
       for (int c = 0; c < HD; ++c) d += ds[c] * os[c];
-      ls = p.lse[(long)blockIdx.x * T + row];
     }
-    lse_s[row] = ls;
-    del_s[row] = d;
+    lse_s[row] = row < T ? ls : 0.f;
+    del_s[row] = row < T ? d : 0.f;
   }
   __syncthreads();
-  const int ntile = (T + 31) >> 5;
   const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    const int kt = pass == 0 ? wave : 3 - wave;  // key tile kt meets query tiles kt..ntile-1: {w, 3-w} balances
-    if (kt >= ntile) continue;
-    const int key = 32 * kt + li, kc = min(key, T - 1);
-    float kreg[32], vreg[32];
-    {
-      const float* ks = p.k + ((long)kc * p.B + b) * p.ld + off + lh;
-      const float* vs = p.v + ((long)kc * p.B + b) * p.ld + off + lh;
-#pragma unroll
-      for (int s = 0; s < 32; ++s) { kreg[s] = ks[2 * s]; vreg[s] = vs[2 * s]; }
-    }
-    f32x16 dkt[2] = {(f32x16)(0.f), (f32x16)(0.f)}, dvt[2] = {(f32x16)(0.f), (f32x16)(0.f)};
-#pragma unroll 1
-    for (int qt = kt; qt < ntile; ++qt) {
-      f32x16 sc = tile_rows_x_regs(Qs, 32 * qt, kreg, li, lh);   // S[q][key], q in registers
-      f32x16 dp = tile_rows_x_regs(Os, 32 * qt, vreg, li, lh);   // dP[q][key]
-      f32x16 pd;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float kp[4] = {1.f, 1.f, 1.f, 1.f};
-        if (p.drop) {  // rows q0..q0+3 of the probability matrix, 4 adjacent lanes = 4 adjacent keys
-          const int q0 = 32 * qt + 8 * g + 4 * lh;
-          const int kq = lane & 3;
-          const int qrow = min(q0 + kq, T - 1);
-          if ((T & 3) == 0) {
-            const uint64_t gidx = (bh * T + qrow) * (uint64_t)T + (uint64_t)(min(key, T - 1) & ~3);
-            const u32x4 u = philox4x32_10_rolled((uint32_t)(gidx >> 2), (uint32_t)(gidx >> 34), p.rng.stream, p.rng.step,
-                                                 (uint32_t)p.rng.seed, (uint32_t)(p.rng.seed >> 32));
-#define BLM_QB(x, j) (uint32_t) __builtin_amdgcn_mov_dpp((int)(x), (j) * 0x55, 0xF, 0xF, true)
-#define BLM_KP(j)                                                                                         \
-  {                                                                                                       \
-    const uint32_t w0 = BLM_QB(u.x, j), w1 = BLM_QB(u.y, j), w2 = BLM_QB(u.z, j), w3 = BLM_QB(u.w, j);     \
-    const uint32_t w = kq == 0 ? w0 : (kq == 1 ? w1 : (kq == 2 ? w2 : w3));                               \
-    kp[j] = w >= p.thr ? p.inv_keep : 0.f;                                                                \
-  }
-            BLM_KP(0) BLM_KP(1) BLM_KP(2) BLM_KP(3)
-#undef BLM_KP
-#undef BLM_QB
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              kp[e] = philox_bits1_rolled(p.rng, (bh * T + min(q0 + e, T - 1)) * (uint64_t)T + kc) >= p.thr ? p.inv_keep : 0.f;
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const int qr = 32 * qt + mrow(r, lh);
-          const float pr = (qr >= key && qr < T) ? __expf(sc[r] - lse_s[qr]) : 0.f;
-          pd[r] = pr * kp[e];
-          sc[r] = pr * (dp[r] * kp[e] - del_s[qr]);  // dS[q][key]
-        }
-      }
-      acc_xt_regs(dvt, Os, 32 * qt, pd, li, lh);
-      acc_xt_regs(dkt, Qs, 32 * qt, sc, li, lh);
-    }
-    if (key < T) {
-      store_t(p.dk + ((long)key * p.B + b) * p.ldd + off, dkt, lh, 1.f);
-      store_t(p.dv + ((long)key * p.B + b) * p.ldd + off, dvt, lh, 1.f);
-    }
-  }
+  if (kt0 < ntile) attn_dkv_pass(p, Qs, Os, lse_s, del_s, kt0, ntile, ka, va, b, off, bh, lane, li, lh);
+  if (kt1 < ntile) attn_dkv_pass(p, Qs, Os, lse_s, del_s, kt1, ntile, kb, vb, b, off, bh, lane, li, lh);
 }
 
 }  // namespace blm

@@ -1,0 +1,368 @@
+// One LSTM time step in ONE launch: recurrent product h_{t-1} W_hh^T on the f32 matrix cores with the
+// cell non-linearity fused behind it (replaces: split-K memset + skinny GEMM M=B + cell kernel; the
+// reference gets the same fusion from _VF.lstm, model.py:812).
+//
+// The recurrent GEMM is skinny (M = B = 64, N = 4H, K = H): the generic 128x128 tiles cannot fill the
+// chip without split-K atomics.  Here a workgroup OWNS 8 hidden units = their 32 gate rows (i,f,g,o
+// of each unit) for 32 batch rows, so that after the product the four gates of a unit sit in the same
+// workgroup and the cell update needs no second pass over HBM:
+//   * grid (H/8, ceil(B/32)); 4 waves split K = H in four contiguous quarters, one 32x32 MFMA
+//     accumulator tile per wave, reduced across the waves through LDS at the end (no atomics, no
+//     memset: the summation order is fixed, results are run-to-run identical).
+//   * v_mfma_f32_32x32x2_f32 only needs A and B to agree on WHICH k a (step, lane half) pair means, so
+//     lane half 0 walks the first half of the wave's K quarter and half 1 the second half: every lane
+//     then consumes a contiguous run of its row, fetched as float4 and read back as ds_read_b128.
+//   * operands are staged through wave-private LDS tiles [32 rows][64 k + 4 pad] (coalesced 128-B
+//     global segments in, conflict-free b128 reads out) from a 4-deep register ring of global loads
+//     (64 KB per wave in flight under the MFMAs); the waves never meet at a barrier inside the K loop.
+// Per step and workgroup: 128 KB of h and 128 KB of W_hh (L2/MALL resident across steps), 128 MFMA
+// per wave.  H % 32 == 0 and 16-byte aligned operands are required (blm_lstm_step_fwd returns
+// BLM_ERR_UNSUPPORTED otherwise and the host uses blm_gemm + blm_lstm_cell_fwd).
+#include "blm_device.h"
+#include "blm_host.h"
+
+namespace blm {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int LSTR = 68;                  // staged tile row stride (floats): 64 k + 4 pad
+constexpr int TILE = 32 * LSTR;           // one 32-row operand tile
+constexpr int WAVE_LDS = 2 * 2 * TILE;    // 2 buffers x (h tile + W tile)
+constexpr int RSTR = 40;                  // reduction row stride
+
+struct LstmStepP {
+  const float *xw, *whh, *hprev, *cprev;
+  float *h, *c, *ga;
+  int B, H;
+};
+
+template <int RING>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_step_fwd_kernel(const LstmStepP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int j0 = blockIdx.x * 8, b0 = blockIdx.y * 32;
+  const int H = p.H, B = p.B;
+  const int Kw = H >> 2, Kh = Kw >> 1, kbase = wave * Kw;
+  const int nchunk = (Kh + 31) >> 5;
+  float* base = sm + wave * WAVE_LDS;
+
+  // epilogue operands first: their latency hides behind the whole K loop
+  const int brow = threadIdx.x >> 3, eu = threadIdx.x & 7;
+  const int eb = b0 + brow, ej = j0 + eu;
+  const bool eok = eb < B;
+  float xg[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+  if (eok) {
+    const long o = (long)eb * 4 * H + ej;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xg[g] = p.xw[o + (long)g * H];
+    cprev = p.cprev[(long)eb * H + ej];
+  }
+
+  // staging roles: one instruction moves 4 rows x 2 halves x 128 B
+  const int srow = lane >> 4, shalf = (lane >> 3) & 1, spart = lane & 7;
+  const float* arow[8];
+  const float* wrow[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int row = 4 * q + srow;
+    arow[q] = p.hprev + (long)min(b0 + row, B - 1) * H + kbase + shalf * Kh + 4 * spart;
+    wrow[q] = p.whh + ((long)(row >> 3) * H + j0 + (row & 7)) * H + kbase + shalf * Kh + 4 * spart;
+  }
+  const int soff = srow * LSTR + shalf * 32 + 4 * spart;
+  // register ring of RING chunks: with one wave per SIMD the only way to cover the L2/MALL latency is
+  // to keep RING x 16 KB per wave of loads in flight while the matrix core works on a chunk.  The loop
+  // body is branch free (tail lanes and the refill past the last chunk read a clamped, valid address)
+  // so that the s_waitcnt in front of each put() only waits for ITS chunk.
+  float4 ra0[8], rw0[8], ra1[8], rw1[8];
+  auto fetch = [&](float4 (&a)[8], float4 (&w)[8], int c) {
+    const int off = min(32 * min(c, nchunk - 1) + 4 * spart, Kh - 4) - 4 * spart;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      a[q] = *reinterpret_cast<const float4*>(arow[q] + off);
+      w[q] = *reinterpret_cast<const float4*>(wrow[q] + off);
+    }
+  };
+  f32x16 acc = (f32x16)(0.f);
+  // one chunk: registers -> LDS tile `buf`, refill the registers with chunk c + RING, 32 MFMA steps
+  auto chunk = [&](float4 (&a)[8], float4 (&w)[8], int buf, int c) {
+    const bool in = 32 * c + 4 * spart < Kh;  // K tail of the last chunk -> zeros
+    float* d = base + buf * 2 * TILE + soff;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {  // component-wise selects: a select of whole float4 lvalues would demote the ring to scratch
+      const float4 x = a[q], y = w[q];
+      *reinterpret_cast<float4*>(d + 4 * q * LSTR) = make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
+      *reinterpret_cast<float4*>(d + TILE + 4 * q * LSTR) = make_float4(in ? y.x : 0.f, in ? y.y : 0.f, in ? y.z : 0.f, in ? y.w : 0.f);
+    }
+    fetch(a, w, c + RING);
+    // the tiles are wave private: LDS executes a wave's instructions in order, so the reads below see
+    // the writes above without a workgroup barrier; the fence only pins the compiler's order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float* at = base + buf * 2 * TILE + li * LSTR + lh * 32;
+    const float* wt = at + TILE;
+    float4 av[8], wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      av[j] = *reinterpret_cast<const float4*>(at + 4 * j);
+      wv[j] = *reinterpret_cast<const float4*>(wt + 4 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].x, wv[j].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, wv[j].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].z, wv[j].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].w, wv[j].w, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  fetch(ra0, rw0, 0);
+  if (RING == 2) fetch(ra1, rw1, 1);
+#pragma unroll 1
+  for (int cc = 0; cc < nchunk; cc += RING) {  // nchunk % RING == 0 (host picks RING)
+    chunk(ra0, rw0, 0, cc);
+    if (RING == 2) chunk(ra1, rw1, 1, cc + 1);
+  }
+
+  // cross-wave reduction of the four K quarters: red[wave][batch row][gate row]
+  __syncthreads();  // every wave is done with its staging tiles: the reduction buffer overlays them
+  float* red = sm;  // 4 x 32 x RSTR floats = 20 KB
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    red[(wave * 32 + row) * RSTR + li] = acc[r];
+  }
+  __syncthreads();
+  if (eok) {
+    float s[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = g * 8 + eu;
+      s[g] = xg[g] + ((red[(0 * 32 + brow) * RSTR + n] + red[(1 * 32 + brow) * RSTR + n]) +
+                      (red[(2 * 32 + brow) * RSTR + n] + red[(3 * 32 + brow) * RSTR + n]));
+    }
+    const float gi = sigmoidf_(s[0]), gf = sigmoidf_(s[1]), gg = tanhf(s[2]), go = sigmoidf_(s[3]);
+    const float cn = gf * cprev + gi * gg;
+    const long i = (long)eb * H + ej, o = (long)eb * 4 * H + ej;
+    p.c[i] = cn;
+    p.h[i] = go * tanhf(cn);
+    if (p.ga) {
+      p.ga[o] = gi;
+      p.ga[o + H] = gf;
+      p.ga[o + 2L * H] = gg;
+      p.ga[o + 3L * H] = go;
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------ backward step
+// dh_{t-1} = dgates_t . W_hh  (B x 4H times 4H x H), fused with the cell backward of step t-1, so that
+// one launch per time step replaces cell kernel + memset + split-K GEMM and dh never visits HBM.
+// Both operands are row-contiguous along the contraction index n (dgates_t rows, and rows of the
+// TRANSPOSED recurrent weight W_hh^T (H x 4H) that the host makes once per layer and backward pass),
+// so the kernel has the forward kernel's shape with v_mfma_f32_16x16x4_f32 tiles: a workgroup owns a
+// 16 (batch) x 16 (hidden unit) tile of dh -- 256 workgroups at B = 64, H = 1024 -- wave g contracts
+// over gate block g (n in [gH, gH+H)), lane quarter kq over the kq-th quarter of it.  Staged tiles
+// are [16 rows][4 quarters x (32 + 4 pad)] with a 152-float row stride: conflict-free ds_read_b128
+// for every 16-lane group of the instruction (searched).
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int BSTR = 152;                 // staged row stride (floats)
+constexpr int BQ = 36;                    // quarter offset inside a row
+constexpr int BTILE = 16 * BSTR;
+constexpr int BWAVE_LDS = 2 * 2 * BTILE;  // 2 buffers x (dgates tile + W^T tile)
+constexpr int BRSTR = 20;                 // reduction row stride
+
+struct LstmBwdP {
+  const float *dg, *wt;                   // dgates_t (B,4H), W_hh^T (H,4H)
+  const float *dy, *dc_next, *cprev, *c, *ga;
+  float *dg_out, *dc_prev, *dh_out;
+  int B, H;
+};
+
+template <int RING>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_step_bwd_kernel(const LstmBwdP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+  const int k0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+  const int H = p.H, B = p.B;
+  const long G = 4L * H;
+  const int Kq = H >> 2;                  // contraction run of one lane quarter
+  const int nchunk = (Kq + 31) >> 5;
+  float* base = sm + wave * BWAVE_LDS;
+
+  // epilogue operands first
+  const int brow = threadIdx.x >> 4, ecol = threadIdx.x & 15;
+  const int eb = b0 + brow, ek = k0 + ecol;
+  const bool eok = eb < B;
+  const long ei = (long)eb * H + ek, eo = (long)eb * G + ek;
+  float e_dy = 0.f, e_dcn = 0.f, e_cp = 0.f, e_c = 0.f, e_g[4] = {0.f, 0.f, 0.f, 0.f};
+  if (eok && p.dg_out) {
+    if (p.dy) e_dy = p.dy[ei];
+    if (p.dc_next) e_dcn = p.dc_next[ei];
+    e_cp = p.cprev[ei];
+    e_c = p.c[ei];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e_g[g] = p.ga[eo + (long)g * H];
+  }
+
+  // staging roles: one instruction moves 2 rows x 4 quarters x 128 B
+  const int srow = lane >> 5, squart = (lane >> 3) & 3, spart = lane & 7;
+  const float* arow[8];
+  const float* wrow[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int row = 2 * q + srow;
+    arow[q] = p.dg + (long)min(b0 + row, B - 1) * G + (long)wave * H + squart * Kq + 4 * spart;
+    wrow[q] = p.wt + (long)(k0 + row) * G + (long)wave * H + squart * Kq + 4 * spart;
+  }
+  const int soff = srow * BSTR + squart * BQ + 4 * spart;
+  float4 ra0[8], rw0[8], ra1[8], rw1[8];
+  auto fetch = [&](float4 (&a)[8], float4 (&w)[8], int c) {
+    const int off = min(32 * min(c, nchunk - 1) + 4 * spart, Kq - 4) - 4 * spart;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      a[q] = *reinterpret_cast<const float4*>(arow[q] + off);
+      w[q] = *reinterpret_cast<const float4*>(wrow[q] + off);
+    }
+  };
+  f32x4 acc = (f32x4)(0.f);
+  auto chunk = [&](float4 (&a)[8], float4 (&w)[8], int buf, int c) {
+    const bool in = 32 * c + 4 * spart < Kq;
+    float* d = base + buf * 2 * BTILE + soff;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 x = a[q], y = w[q];
+      *reinterpret_cast<float4*>(d + 2 * q * BSTR) = make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
+      *reinterpret_cast<float4*>(d + BTILE + 2 * q * BSTR) = make_float4(in ? y.x : 0.f, in ? y.y : 0.f, in ? y.z : 0.f, in ? y.w : 0.f);
+    }
+    fetch(a, w, c + RING);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // wave-private tiles, in-order LDS: see the forward kernel
+    __builtin_amdgcn_wave_barrier();
+    const float* at = base + buf * 2 * BTILE + li * BSTR + lq * BQ;
+    const float* wt = at + BTILE;
+    float4 av[8], wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      av[j] = *reinterpret_cast<const float4*>(at + 4 * j);
+      wv[j] = *reinterpret_cast<const float4*>(wt + 4 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, wv[j].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, wv[j].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, wv[j].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, wv[j].w, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  fetch(ra0, rw0, 0);
+  if (RING == 2) fetch(ra1, rw1, 1);
+#pragma unroll 1
+  for (int cc = 0; cc < nchunk; cc += RING) {
+    chunk(ra0, rw0, 0, cc);
+    if (RING == 2) chunk(ra1, rw1, 1, cc + 1);
+  }
+
+  __syncthreads();
+  float* red = sm;  // 4 x 16 x BRSTR floats, overlays the staging tiles
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * lq + r) * BRSTR + li] = acc[r];
+  __syncthreads();
+  if (!eok) return;
+  const float dh = (red[(0 * 16 + brow) * BRSTR + ecol] + red[(1 * 16 + brow) * BRSTR + ecol]) +
+                   (red[(2 * 16 + brow) * BRSTR + ecol] + red[(3 * 16 + brow) * BRSTR + ecol]);
+  if (p.dh_out) p.dh_out[ei] = dh;
+  if (p.dg_out) {  // cell backward of the step that produced h_{t-1} (elementwise.hip lstm_cell_bwd_kernel)
+    const float gi = e_g[0], gf = e_g[1], gg = e_g[2], go = e_g[3];
+    const float tc = tanhf(e_c);
+    const float dhv = dh + e_dy;
+    const float dc = e_dcn + dhv * go * (1.f - tc * tc);
+    p.dg_out[eo] = dc * gg * gi * (1.f - gi);
+    p.dg_out[eo + H] = dc * e_cp * gf * (1.f - gf);
+    p.dg_out[eo + 2L * H] = dc * gi * (1.f - gg * gg);
+    p.dg_out[eo + 3L * H] = dhv * tc * go * (1.f - go);
+    p.dc_prev[ei] = dc * gf;
+  }
+}
+
+// out (cols x rows) = in (rows x cols)^T, 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+  __shared__ float t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r0 + ty + 8 * j, c = c0 + tx;
+    if (r < rows && c < cols) t[ty + 8 * j][tx] = in[(long)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + ty + 8 * j, r = r0 + tx;
+    if (r < rows && c < cols) out[(long)c * rows + r] = t[tx][ty + 8 * j];
+  }
+}
+
+}  // namespace blm
+
+using namespace blm;
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int blm_lstm_step_fwd(const float* xw_t, const float* w_hh, const float* h_prev, const float* c_prev, float* h,
+                                 float* c, float* gates_act, int B, int H, void* stream) {
+  if (!xw_t || !w_hh || !h_prev || !c_prev || !h || !c || B < 0 || H < 0)
+    return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_fwd: bad arguments");
+  if ((long)B * H == 0) return BLM_OK;
+  if (H % 32 != 0 || !al16(w_hh) || !al16(h_prev))
+    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_fwd: needs H % 32 == 0 and 16-byte aligned h_prev / w_hh");
+  LstmStepP p{xw_t, w_hh, h_prev, c_prev, h, c, gates_act, B, H};
+  const size_t lds = (size_t)4 * WAVE_LDS * sizeof(float);
+  static bool once = false;
+  if (!once) {
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    once = true;
+  }
+  const int nchunk = (H / 8 + 31) / 32;  // 32-k chunks per lane half of a wave's K quarter
+  const dim3 grid(H / 8, (B + 31) / 32), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (nchunk % 2 == 0) hipLaunchKernelGGL(lstm_step_fwd_kernel<2>, grid, block, lds, st, p);
+  else hipLaunchKernelGGL(lstm_step_fwd_kernel<1>, grid, block, lds, st, p);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_transpose(const float* in, float* out, int rows, int cols, void* stream) {
+  if (!in || !out || rows < 0 || cols < 0) return blm_fail(BLM_ERR_INVALID, "blm_transpose: bad arguments");
+  if ((long)rows * cols == 0) return BLM_OK;
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_lstm_step_bwd(const float* dgates_t, const float* w_hh_t, const float* dy_prev, const float* dc_next,
+                                 const float* c_prev, const float* c, const float* gates_act, float* dgates_out,
+                                 float* dc_prev, float* dh_out, int B, int H, void* stream) {
+  if (!dgates_t || !w_hh_t || B < 0 || H < 0 || (!dgates_out && !dh_out) ||
+      (dgates_out && (!c_prev || !c || !gates_act || !dc_prev)))
+    return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_bwd: bad arguments");
+  if ((long)B * H == 0) return BLM_OK;
+  if (H % 32 != 0 || !al16(dgates_t) || !al16(w_hh_t))
+    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_bwd: needs H % 32 == 0 and 16-byte aligned dgates_t / w_hh_t");
+  LstmBwdP p{dgates_t, w_hh_t, dy_prev, dc_next, c_prev, c, gates_act, dgates_out, dc_prev, dh_out, B, H};
+  const size_t lds = (size_t)4 * BWAVE_LDS * sizeof(float);
+  static bool once = false;
+  if (!once) {
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    once = true;
+  }
+  const int nchunk = (H / 4 + 31) / 32;
+  const dim3 grid(H / 16, (B + 15) / 16), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (nchunk % 2 == 0) hipLaunchKernelGGL(lstm_step_bwd_kernel<2>, grid, block, lds, st, p);
+  else hipLaunchKernelGGL(lstm_step_bwd_kernel<1>, grid, block, lds, st, p);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}

@@ -111,8 +111,9 @@ def _f32(t, name):
 # per-kernel timing with HIP events on the launch stream (bench.py's live roofline numbers)
 # ----------------------------------------------------------------------------
 class KernelTimer:
-    def __init__(self):
+    def __init__(self, all_gemms=False):
         self.records = []
+        self.all_gemms = all_gemms  # also bracket untagged GEMMs, keyed by layout/shape/epilogue
 
     def bracket(self, tag):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -141,7 +142,9 @@ def set_kernel_timer(t):
 def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, *, alpha=1.0, accumulate=False, epilogue=L.EPI_NONE, bias=None,
          aux=None, coef=None, var_b=None, C2=None, wg_mu=None, var_c=None, kl_lambda=0.0, kl_inv_n=0.0,
          drop=None, drop_B=0, tag=None, colsum_a=None):
-    if _TIMER is not None and tag is not None:
+    if _TIMER is not None and (tag is not None or _TIMER.all_gemms):
+        if _TIMER.all_gemms:
+            tag = f"{('NT', 'NN', 'TN')[op]} {M}x{N}x{K} epi{epilogue}{' acc' if accumulate else ''} [{tag or '-'}]"
         ev0, ev1 = _TIMER.bracket(tag)
         ev0.record()
         _gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, alpha, accumulate, epilogue, bias, aux, coef, var_b, C2, wg_mu,
@@ -794,7 +797,14 @@ class _LSTMLayer(torch.autograd.Function):
         ga = torch.empty(T, B, G, device=dev, dtype=torch.float32)
         hw = torch.empty(B, G, device=dev, dtype=torch.float32)
         st = stream()
+        # one launch per step (recurrent product + cell, blm_lstm_step_fwd) when the shape allows it,
+        # else skinny GEMM + cell kernel
+        fused_step = H % 32 == 0 and w_hh.data_ptr() % 16 == 0 and hs.data_ptr() % 16 == 0 and w_hh.is_contiguous()
         for t in range(T):
+            if fused_step:
+                check(lib().blm_lstm_step_fwd(ptr(xw[t]), ptr(w_hh), ptr(hs[t]), ptr(cs[t]), ptr(hs[t + 1]),
+                                              ptr(cs[t + 1]), ptr(ga[t]), B, H, st), "blm_lstm_step_fwd")
+                continue
             gemm(L.GEMM_NT, hs[t], w_hh, hw, B, G, H, H, H, G)
             check(lib().blm_lstm_cell_fwd(ptr(xw[t]), ptr(hw), ptr(cs[t]), ptr(hs[t + 1]), ptr(cs[t + 1]), ptr(ga[t]),
                                           B, H, st), "blm_lstm_cell_fwd")
@@ -812,17 +822,38 @@ class _LSTMLayer(torch.autograd.Function):
         dgates = torch.empty(T, B, G, device=dev, dtype=torch.float32)
         dh = torch.zeros(B, H, device=dev, dtype=torch.float32) if dhT is None else _f32(dhT, "dhT").clone()
         dc = torch.zeros(B, H, device=dev, dtype=torch.float32) if dcT is None else _f32(dcT, "dcT").clone()
-        dh_rec = torch.empty(B, H, device=dev, dtype=torch.float32)
         st = stream()
         dcs = torch.empty(2, B, H, device=dev, dtype=torch.float32)  # ping-pong dc buffers
         dcs[0].copy_(dc)
-        for t in range(T - 1, -1, -1):
-            k = (T - 1 - t) & 1
-            check(lib().blm_lstm_cell_bwd2(ptr(dh), ptr(dy[t]), ptr(dcs[k]), ptr(cs[t]), ptr(cs[t + 1]), ptr(ga[t]),
-                                           ptr(dgates[t]), ptr(dcs[k ^ 1]), B, H, st), "blm_lstm_cell_bwd2")
-            gemm(L.GEMM_NN, dgates[t], w_hh, dh_rec, B, H, G, G, H, H)
-            dh, dh_rec = dh_rec, dh
-        dc = dcs[T & 1]
+        fused_step = (H % 32 == 0 and w_hh.is_contiguous() and w_hh.data_ptr() % 16 == 0 and dgates.data_ptr() % 16 == 0)
+        if fused_step:
+            # one launch per step: dh_{t-1} = dgates_t . W_hh on the matrix cores with the cell backward
+            # of step t-1 fused behind it (blm_lstm_step_bwd); W_hh is transposed once per layer
+            w_t = torch.empty(H, G, device=dev, dtype=torch.float32)
+            check(lib().blm_transpose(ptr(w_hh), ptr(w_t), G, H, st), "blm_transpose")
+            check(lib().blm_lstm_cell_bwd2(ptr(dh), ptr(dy[T - 1]), ptr(dcs[0]), ptr(cs[T - 1]), ptr(cs[T]), ptr(ga[T - 1]),
+                                           ptr(dgates[T - 1]), ptr(dcs[1]), B, H, st), "blm_lstm_cell_bwd2")
+            k = 1
+            for t in range(T - 1, 0, -1):
+                check(lib().blm_lstm_step_bwd(ptr(dgates[t]), ptr(w_t), ptr(dy[t - 1]), ptr(dcs[k]), ptr(cs[t - 1]),
+                                              ptr(cs[t]), ptr(ga[t - 1]), ptr(dgates[t - 1]), ptr(dcs[k ^ 1]), None,
+                                              B, H, st), "blm_lstm_step_bwd")
+                k ^= 1
+            dh = torch.empty(B, H, device=dev, dtype=torch.float32)
+            check(lib().blm_lstm_step_bwd(ptr(dgates[0]), ptr(w_t), None, None, None, None, None, None, None, ptr(dh),
+                                          B, H, st), "blm_lstm_step_bwd")
+            dc = dcs[k]
+        else:
+            # recurrent dh of every step accumulates (split-K atomics) into one pre-zeroed buffer: a
+            # single memset per layer instead of one in front of every skinny GEMM
+            dh_all = torch.zeros(T, B, H, device=dev, dtype=torch.float32)
+            for t in range(T - 1, -1, -1):
+                k = (T - 1 - t) & 1
+                check(lib().blm_lstm_cell_bwd2(ptr(dh), ptr(dy[t]), ptr(dcs[k]), ptr(cs[t]), ptr(cs[t + 1]), ptr(ga[t]),
+                                               ptr(dgates[t]), ptr(dcs[k ^ 1]), B, H, st), "blm_lstm_cell_bwd2")
+                gemm(L.GEMM_NN, dgates[t], w_hh, dh_all[t], B, H, G, G, H, H, accumulate=True)
+                dh = dh_all[t]
+            dc = dcs[T & 1]
         dx = torch.empty_like(x)
         gemm(L.GEMM_NN, dgates, w_ih, dx, T * B, E, G, G, E, E)
         dw_ih = torch.empty_like(w_ih)

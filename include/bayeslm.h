@@ -262,6 +262,27 @@ int blm_clip_sgd_multi(float* const* params, const float* const* grads, float* c
                        int n, const float* sq, float clip, float lr, float momentum, int first, float grad_scale,
                        void* stream);
 
+/* One whole LSTM time step in a single launch (recurrent product on the matrix
+ * cores + the cell below fused behind it; model.py:812 `_VF.lstm` per step):
+ *   gates = xw_t[b,4H] + h_prev[b,H] . w_hh[4H,H]^T ; then the cell update.
+ * Requires H % 32 == 0 and 16-byte aligned h_prev / w_hh; otherwise returns
+ * BLM_ERR_UNSUPPORTED and the caller composes blm_gemm + blm_lstm_cell_fwd.
+ * Deterministic (fixed summation order, no atomics). */
+int blm_lstm_step_fwd(const float* xw_t, const float* w_hh, const float* h_prev, const float* c_prev, float* h,
+                      float* c, float* gates_act, int B, int H, void* stream);
+
+/* Backward of one LSTM time step in a single launch:
+ *   dh = dgates_t[b,4H] . w_hh[4H,H]   (w_hh passed TRANSPOSED: w_hh_t (H,4H), see blm_transpose)
+ * then, when dgates_out != NULL, the cell backward of the previous step (blm_lstm_cell_bwd2 with
+ * dh = this product, dh2 = dy_prev): dgates_out (B,4H) and dc_prev (B,H) are written and dh itself
+ * never reaches memory unless dh_out != NULL.  dgates_out == NULL: only dh_out is written.
+ * Same shape/alignment rule and status codes as blm_lstm_step_fwd. */
+int blm_lstm_step_bwd(const float* dgates_t, const float* w_hh_t, const float* dy_prev, const float* dc_next,
+                      const float* c_prev, const float* c, const float* gates_act, float* dgates_out, float* dc_prev,
+                      float* dh_out, int B, int H, void* stream);
+/* out (cols,rows) = in (rows,cols)^T */
+int blm_transpose(const float* in, float* out, int rows, int cols, void* stream);
+
 /* LSTM cell pointwise part (what _VF.lstm fuses, model.py:812): gates =
  * xw[b,4H] + hw[b,4H] (biases already inside xw), order i,f,g,o.
  *   c' = sig(f) c + sig(i) tanh(g);  h' = sig(o) tanh(c')

@@ -401,6 +401,52 @@ def test_lstm_layer_matches_oracle(dev):
         assert rel(a.grad, b.grad) < 5e-5, name
 
 
+@pytest.mark.parametrize("T,B,E,H", [(5, 64, 48, 256), (4, 20, 32, 96), (3, 70, 40, 320), (3, 1, 16, 32)])
+def test_lstm_layer_fused_step_matches_oracle(dev, T, B, E, H):
+    """H % 32 == 0 takes blm_lstm_step_fwd (one launch per step: MFMA recurrent product + cell):
+    ragged batch tiles (20, 70, 1), K tails (H/8 = 12, 40), and the accumulate-in-place backward."""
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(12)
+    mk = lambda *s: torch.randn(*s, generator=g) * 0.2  # noqa: E731
+    x, h0, c0 = mk(T, B, E), mk(B, H), mk(B, H)
+    w_ih, w_hh, b_ih, b_hh = mk(4 * H, E), mk(4 * H, H) * 0.5, mk(4 * H), mk(4 * H)
+    dl = [t.to(dev).requires_grad_(True) for t in (x, h0, c0, w_ih, w_hh, b_ih, b_hh)]
+    y, hT, cT = ops.lstm_layer(*dl)
+    cl = [t.clone().requires_grad_(True) for t in (x, h0, c0, w_ih, w_hh, b_ih, b_hh)]
+    yr, hr, cr = O.lstm_layer(*cl)
+    assert rel(y, yr) < 1e-5 and rel(hT, hr) < 1e-5 and rel(cT, cr) < 1e-5
+    gy, gh, gc = mk(T, B, H), mk(B, H), mk(B, H)
+    ((y * gy.to(dev)).sum() + (hT * gh.to(dev)).sum() + (cT * gc.to(dev)).sum()).backward()
+    ((yr * gy).sum() + (hr * gh).sum() + (cr * gc).sum()).backward()
+    for a, b, name in zip(dl, cl, "x h0 c0 w_ih w_hh b_ih b_hh".split()):
+        assert rel(a.grad, b.grad) < 5e-5, name
+
+
+def test_lstm_step_fwd_is_deterministic_and_rejects_bad_shapes(dev):
+    lib = L().lib()
+    from bayeslms_amd._lib import ptr, stream, ERR_UNSUPPORTED
+    B, H = 64, 1024
+    g = torch.Generator(device=dev).manual_seed(3)
+    xw = torch.randn(B, 4 * H, device=dev, generator=g)
+    w = torch.randn(4 * H, H, device=dev, generator=g) * 0.03
+    hp, cp = torch.randn(B, H, device=dev, generator=g), torch.randn(B, H, device=dev, generator=g)
+    outs = []
+    for _ in range(2):
+        h, c, ga = torch.empty(B, H, device=dev), torch.empty(B, H, device=dev), torch.empty(B, 4 * H, device=dev)
+        assert lib.blm_lstm_step_fwd(ptr(xw), ptr(w), ptr(hp), ptr(cp), ptr(h), ptr(c), ptr(ga), B, H, stream()) == 0
+        outs.append((h, c, ga))
+    torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    gates = xw.double() + hp.double() @ w.double().t()
+    i, f, gg, o = gates.split(H, dim=1)
+    cn = torch.sigmoid(f) * cp.double() + torch.sigmoid(i) * torch.tanh(gg)
+    hn = torch.sigmoid(o) * torch.tanh(cn)
+    assert rel(outs[0][0], hn.float()) < 1e-5 and rel(outs[0][1], cn.float()) < 1e-5
+    # H not a multiple of 32: refused, nothing launched
+    assert lib.blm_lstm_step_fwd(ptr(xw), ptr(w), ptr(hp), ptr(cp), ptr(h), ptr(c), ptr(ga), 4, 40, stream()) == ERR_UNSUPPORTED
+
+
 # ------------------------------------------------------------------ full-size, size-independent properties
 def test_sampled_gemm_full_size_properties(dev):
     """cfg3 shape (M=8192, N=512, K=4096): fused-in-loader sampling == materialise-then-GEMM (same
