@@ -698,9 +698,13 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   const int min_k = small_out ? 128 : 512;               // K per split
   if (can_split && nb < 384 && p.K >= (small_out ? 512 : 2048)) {
     splits = (int)((512 + nb - 1) / nb);
-    if (splits > 8) splits = 8;
+    if (splits > 8 || nb <= 96) splits = 8;  // 8 slices = one per XCD: measured best for small output grids
     while (splits > 1 && p.K / splits < min_k) --splits;
   }
+  // weight-gradient layout with a long reduction: 4 K slices even when the output grid alone fills the
+  // chip -- the workgroups of one slice then share the same rows of both operands in L2
+  // (decoder dW 33000x512x8192: 102 -> 120 TFLOP/s, tools/gemm_sweep.sh)
+  if (OP == BLM_GEMM_TN && can_split && p.K >= 4096 && splits < 4) splits = 4;
   if (p.force_splits > 0 && p.epi == BLM_EPI_NONE && !SAMP && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N))
     splits = p.force_splits;
   q.splits = splits;
@@ -739,9 +743,22 @@ int launch_op(const GemmP& p, hipStream_t st) {
                     ((p.N + (small_n ? 63 : 127)) / (small_n ? 64 : 128));
     if (b2 < 256) small_m = small_n = true;
   }
-  // measured on MI355X (tools/gemm_bench.py): wgrad-shaped TN with a very tall output (decoder,
-  // 33000 x 512) and the Bayesian wgrad (no split-K because of its epilogue) run best on 64x64 tiles
-  if (OP == BLM_GEMM_TN && (p.epi == BLM_EPI_BAYES_WGRAD || (long)p.M * p.N >= (1L << 23))) small_m = small_n = true;
+  // measured on MI355X (tools/gemm_sweep.sh, cfg3 shapes):
+  //  * split-K capable launches with a long K keep the biggest tile that still gives >= 64 output
+  //    tiles and let split-K fill the chip (wgrads: 128x128 +8%, qkv wgrad 64x128 x 8 slices +40%);
+  //  * short-K launches (K <= 1024) whose 128x128 grid is less than two full rounds of the chip run
+  //    better on 64x128 tiles (qkv / out-proj forward, out-proj dgrad: +10..25%);
+  //  * the Bayesian wgrad (no split-K because of its epilogue) runs best on 64x64 tiles.
+  const bool can_split = p.epi == BLM_EPI_NONE && !SAMP && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N);
+  if (can_split && p.K >= 2048 && p.M > 64 && p.N > 64) {
+    const long t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
+    if (b128 >= 96) small_m = small_n = false;
+    else if (t12 >= 64) { small_m = true; small_n = false; }
+    else small_m = small_n = true;
+  } else if (p.K <= 1024 && b128 >= 256 && b128 < 1024 && p.M >= 128 && p.N >= 128) {
+    small_m = true; small_n = false;
+  }
+  if (OP == BLM_GEMM_TN && p.epi == BLM_EPI_BAYES_WGRAD) small_m = small_n = true;
   if (p.force_tile == 11) { small_m = small_n = true; }
   else if (p.force_tile == 12) { small_m = true; small_n = false; }
   else if (p.force_tile == 21) { small_m = false; small_n = true; }

@@ -24,9 +24,12 @@ SHAPES = [  # (name, op, M, N, K)
 
 def main():
     dev = torch.device("cuda:0")
-    reps = 5
+    reps = int(os.environ.get("REPS", "20"))
+    only = os.environ.get("ONLY")
     print("BLM_GEMM_TILE=%s BLM_GEMM_SPLITK=%s" % (os.environ.get("BLM_GEMM_TILE", "auto"), os.environ.get("BLM_GEMM_SPLITK", "auto")))
     for name, op, m, n, k in SHAPES:
+        if only and not any(o in name for o in only.split(",")):
+            continue
         if op == L.GEMM_NT:
             A, B, lda, ldb = torch.randn(m, k, device=dev), torch.randn(n, k, device=dev), k, k
         elif op == L.GEMM_NN:
@@ -35,7 +38,7 @@ def main():
             A, B, lda, ldb = torch.randn(k, m, device=dev), torch.randn(k, n, device=dev), m, n
         C = torch.zeros(m, n, device=dev)
         acc = op == L.GEMM_TN
-        for _ in range(2):
+        for _ in range(6):
             ops.gemm(op, A, B, C, m, n, k, lda, ldb, n, accumulate=acc)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
