@@ -70,10 +70,20 @@ __device__ __forceinline__ void put_rows(float* dst, const float4 (&v)[16], int 
     d[0] = v[u].x * m; d[1] = v[u].y * m; d[2] = v[u].z * m; d[3] = v[u].w * m;
   }
 }
-// the 32 B-operand values of one lane: row-contiguous floats base[2s] (base already includes the lane's k half)
+// the 32 B-operand values of one lane.  v_mfma_f32_32x32x2_f32 only needs A and B to agree on which
+// feature a (step, lane half) pair means, so half 0 takes features 0..31 and half 1 features 32..63 of
+// the lane's row: one contiguous 128-B line per lane, 8 float4 loads (base = row + 32 * half).
 __device__ __forceinline__ void fetch_op(float (&r)[32], const float* base) {
+  if ((reinterpret_cast<uintptr_t>(base) & 15) == 0) {
 #pragma unroll
-  for (int s = 0; s < 32; ++s) r[s] = base[2 * s];
+    for (int j = 0; j < 8; ++j) {
+      const float4 v = reinterpret_cast<const float4*>(base)[j];
+      r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) r[s] = base[s];
+  }
 }
 
 // MFMA row index held in accumulator register r by a lane of half h
@@ -96,12 +106,12 @@ __device__ __forceinline__ void keep_row4(const AttnM& p, uint64_t grow, int c0,
 // S^T tile: acc[r] = sum_k X[row0 + (lane&31)][k] * breg[k-th]  with A from LDS rows, B from registers
 __device__ __forceinline__ f32x16 tile_rows_x_regs(const float* X, int row0, const float (&breg)[32], int li, int lh) {
   f32x16 acc = (f32x16)(0.f);
-  const float* a = X + (row0 + li) * LS + lh;
+  const float* a = X + (row0 + li) * LS + 32 * lh;
   // all 32 LDS operand reads are issued first (independent, one VGPR each) so the matrix pipe is not
   // stalled on a ds_read latency in front of every MFMA
   float av[32];
 #pragma unroll
-  for (int s = 0; s < 32; ++s) av[s] = a[2 * s];
+  for (int s = 0; s < 32; ++s) av[s] = a[s];
 #pragma unroll
   for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], breg[s], acc, 0, 0, 0);
   return acc;
@@ -113,13 +123,13 @@ __device__ __forceinline__ void tile2_rows_x_regs(f32x16& acc1, f32x16& acc2, co
                                                   const float (&b1)[32], const float (&b2)[32], int li, int lh) {
   acc1 = (f32x16)(0.f);
   acc2 = (f32x16)(0.f);
-  const float* a1 = X1 + (row0 + li) * LS + lh;
-  const float* a2 = X2 + (row0 + li) * LS + lh;
+  const float* a1 = X1 + (row0 + li) * LS + 32 * lh;
+  const float* a2 = X2 + (row0 + li) * LS + 32 * lh;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     float av1[16], av2[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) { av1[s] = a1[2 * (16 * h + s)]; av2[s] = a2[2 * (16 * h + s)]; }
+    for (int s = 0; s < 16; ++s) { av1[s] = a1[16 * h + s]; av2[s] = a2[16 * h + s]; }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], b1[16 * h + s], acc1, 0, 0, 0);
@@ -226,10 +236,10 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(const AttnM p) {
     float4 kk[16], vv[16];
     fetch_rows(kk, p.k, p.ld, T, p.B, b, off);
     fetch_rows(vv, p.v, p.ld, T, p.B, b, off);
-    fetch_op(qa, p.q + ((long)min(32 * qt0 + li, T - 1) * p.B + b) * p.ld + off + lh);
+    fetch_op(qa, p.q + ((long)min(32 * qt0 + li, T - 1) * p.B + b) * p.ld + off + 32 * lh);
     put_rows(Ks, kk, T, 1.f);
     put_rows(Vs, vv, T, 1.f);
-    fetch_op(qb, p.q + ((long)min(32 * qt1 + li, T - 1) * p.B + b) * p.ld + off + lh);
+    fetch_op(qb, p.q + ((long)min(32 * qt1 + li, T - 1) * p.B + b) * p.ld + off + 32 * lh);
   }
   __syncthreads();
   const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
@@ -285,16 +295,16 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_mfma_kernel(const AttnM p) {
     float oa[32];
     fetch_rows(kk, p.k, p.ld, T, p.B, b, off);
     fetch_rows(vv, p.v, p.ld, T, p.B, b, off);
-    fetch_op(qa, p.q + r0 * p.ld + off + lh);
-    fetch_op(da, p.dout + r0 * dmodel + off + lh);
-    fetch_op(oa, p.o_in + r0 * dmodel + off + lh);
+    fetch_op(qa, p.q + r0 * p.ld + off + 32 * lh);
+    fetch_op(da, p.dout + r0 * dmodel + off + 32 * lh);
+    fetch_op(oa, p.o_in + r0 * dmodel + off + 32 * lh);
     put_rows(Ks, kk, T, 1.f);
     put_rows(Vs, vv, T, 1.f);
 #pragma unroll
     for (int s = 0; s < 32; ++s) delta0 += da[s] * oa[s];
-    fetch_op(qb, p.q + r1 * p.ld + off + lh);
-    fetch_op(db, p.dout + r1 * dmodel + off + lh);
-    fetch_op(oa, p.o_in + r1 * dmodel + off + lh);
+    fetch_op(qb, p.q + r1 * p.ld + off + 32 * lh);
+    fetch_op(db, p.dout + r1 * dmodel + off + 32 * lh);
+    fetch_op(oa, p.o_in + r1 * dmodel + off + 32 * lh);
 #pragma unroll
     for (int s = 0; s < 32; ++s) delta1 += db[s] * oa[s];
   }
@@ -378,8 +388,8 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_mfma_kernel(const AttnM p) {
     float4 qq[16], dd[16];
     fetch_rows(qq, p.q, p.ld, T, p.B, b, off);
     fetch_rows(dd, p.dout, dmodel, T, p.B, b, off);
-    fetch_op(ka, p.k + r0 * p.ld + off + lh);
-    fetch_op(va, p.v + r0 * p.ld + off + lh);
+    fetch_op(ka, p.k + r0 * p.ld + off + 32 * lh);
+    fetch_op(va, p.v + r0 * p.ld + off + 32 * lh);
     put_rows(Qs, qq, T, p.scale);
     put_rows(Os, dd, T, 1.f);
   }
@@ -394,14 +404,14 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_mfma_kernel(const AttnM p) {
 #pragma unroll
       for (int c = 0; c < HD / 4; ++c) { dv4[c] = reinterpret_cast<const float4*>(ds)[c]; ov4[c] = reinterpret_cast<const float4*>(os)[c]; }
       const long r1 = (long)min(32 * kt1 + li, T - 1) * p.B + b;
-      fetch_op(kb, p.k + r1 * p.ld + off + lh);
-      fetch_op(vb, p.v + r1 * p.ld + off + lh);
+      fetch_op(kb, p.k + r1 * p.ld + off + 32 * lh);
+      fetch_op(vb, p.v + r1 * p.ld + off + 32 * lh);
 #pragma unroll
       for (int c = 0; c < HD / 4; ++c) d += dv4[c].x * ov4[c].x + dv4[c].y * ov4[c].y + dv4[c].z * ov4[c].z + dv4[c].w * ov4[c].w;
     } else {
       const long r1 = (long)min(32 * kt1 + li, T - 1) * p.B + b;
-      fetch_op(kb, p.k + r1 * p.ld + off + lh);
-      fetch_op(vb, p.v + r1 * p.ld + off + lh);
+      fetch_op(kb, p.k + r1 * p.ld + off + 32 * lh);
+      fetch_op(vb, p.v + r1 * p.ld + off + 32 * lh);
       for (int c = 0; c < HD; ++c) d += ds[c] * os[c];
     }
     lse_s[row] = row < T ? ls : 0.f;

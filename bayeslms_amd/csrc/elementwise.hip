@@ -308,7 +308,18 @@ __global__ __launch_bounds__(TPB) void ln_bwd_finish(const float* __restrict__ w
   const int j = blockIdx.x * 64 + c;
   float a = 0.f, b = 0.f;
   if (j < D) {
-    for (int k = grp; k < nblk; k += 4) {
+    int k = grp;
+    for (; k + 28 < nblk; k += 32) {  // 8 partial rows (16 independent loads) in flight per thread
+      float ta[8], tb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        ta[u] = ws[((long)(k + 4 * u) * 2 + 0) * D + j];
+        tb[u] = ws[((long)(k + 4 * u) * 2 + 1) * D + j];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a += ta[u]; b += tb[u]; }
+    }
+    for (; k < nblk; k += 4) {
       a += ws[((long)k * 2 + 0) * D + j];
       b += ws[((long)k * 2 + 1) * D + j];
     }
