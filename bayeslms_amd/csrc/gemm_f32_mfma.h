@@ -696,7 +696,12 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   const bool can_split = p.epi == BLM_EPI_NONE && !SAMP && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N);
   const bool small_out = (long)p.M * p.N <= (1L << 20);  // e.g. the LSTM recurrent GEMMs (64 x 4096): zeroing C is free
   const int min_k = small_out ? 128 : 512;               // K per split
-  if (can_split && nb < 384 && p.K >= (small_out ? 512 : 2048)) {
+  // forward layout, one full round of the chip (>= 256 tiles): no split unless K is very long -- within
+  // 1.5% of the 2-slice time at K = 4096 without the memset, the atomics and the second copy of the
+  // output (235 -> 218 MB of HBM traffic on the Bayesian FFN forward; what remains above the
+  // algorithmic 159 MB is W fetched once per XCD L2).  dgrad (NN) keeps the 2 slices: +4% in the step.
+  const bool one_round_ok = OP == BLM_GEMM_NN ? nb < 384 : (nb < 256 || (nb < 384 && p.K > 8192));
+  if (can_split && one_round_ok && p.K >= (small_out ? 512 : 2048)) {
     splits = (int)((512 + nb - 1) / nb);
     if (splits > 8 || nb <= 96) splits = 8;  // 8 slices = one per XCD: measured best for small output grids
     while (splits > 1 && p.K / splits < min_k) --splits;
