@@ -447,6 +447,42 @@ def test_lstm_step_fwd_is_deterministic_and_rejects_bad_shapes(dev):
     assert lib.blm_lstm_step_fwd(ptr(xw), ptr(w), ptr(hp), ptr(cp), ptr(h), ptr(c), ptr(ga), 4, 40, stream()) == ERR_UNSUPPORTED
 
 
+def test_lstm_step_bwd_full_size_matches_composition(dev):
+    """cfg2 shape (B = 64, H = 1024): the fused backward step == blm_gemm (fp64 reference here) followed
+    by the cell backward kernel; run twice: bit-identical (fixed summation order, no atomics)."""
+    lib = L().lib()
+    from bayeslms_amd._lib import ptr, stream
+    B, H = 64, 1024
+    g = torch.Generator(device=dev).manual_seed(5)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
+    dg_t, w = rn(B, 4 * H) * 0.1, rn(4 * H, H) * 0.03
+    dy, dcn, cp, c = rn(B, H) * 0.1, rn(B, H) * 0.1, rn(B, H), rn(B, H)
+    ga = torch.sigmoid(rn(B, 4 * H))
+    ga[:, 2 * H:3 * H] = torch.tanh(rn(B, H))
+    w_t = torch.empty(H, 4 * H, device=dev)
+    assert lib.blm_transpose(ptr(w), ptr(w_t), 4 * H, H, stream()) == 0
+    assert torch.equal(w_t, w.t().contiguous())
+    outs = []
+    for _ in range(2):
+        dgo, dcp, dh = torch.empty(B, 4 * H, device=dev), torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+        assert lib.blm_lstm_step_bwd(ptr(dg_t), ptr(w_t), ptr(dy), ptr(dcn), ptr(cp), ptr(c), ptr(ga), ptr(dgo), ptr(dcp),
+                                     ptr(dh), B, H, stream()) == 0
+        outs.append((dgo, dcp, dh))
+    torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    dh_ref = (dg_t.double() @ w.double()).float()
+    assert rel(outs[0][2], dh_ref) < 1e-5
+    dgo_ref, dcp_ref = torch.empty(B, 4 * H, device=dev), torch.empty(B, H, device=dev)
+    assert lib.blm_lstm_cell_bwd2(ptr(dh_ref), ptr(dy), ptr(dcn), ptr(cp), ptr(c), ptr(ga), ptr(dgo_ref), ptr(dcp_ref), B, H,
+                                  stream()) == 0
+    assert rel(outs[0][0], dgo_ref) < 1e-5 and rel(outs[0][1], dcp_ref) < 1e-5
+    # dh-only mode (last step of a layer)
+    dh2 = torch.empty(B, H, device=dev)
+    assert lib.blm_lstm_step_bwd(ptr(dg_t), ptr(w_t), None, None, None, None, None, None, None, ptr(dh2), B, H, stream()) == 0
+    assert torch.equal(dh2, outs[0][2])
+
+
 # ------------------------------------------------------------------ full-size, size-independent properties
 def test_sampled_gemm_full_size_properties(dev):
     """cfg3 shape (M=8192, N=512, K=4096): fused-in-loader sampling == materialise-then-GEMM (same
