@@ -98,3 +98,4 @@ extern "C" int blm_gemm(const blm_gemm_args* a, void* stream) {
     default: return launch_op<BLM_GEMM_TN, false>(p, st);
   }
 }
+

@@ -58,6 +58,9 @@ __device__ __forceinline__ float gemm_keep(const GemmP& p, int m, int n) {
 }
 
 constexpr int BK = 32;
+#ifdef BLM_GEMM_PROF
+static __device__ unsigned long long blm_prof[4];  // per translation unit (debug build only)
+#endif
 // Epilogue-only switch kept from an experiment (two MFMA tiles of a wave interleaved by rows 2x+t
 // instead of stacked 32t+x; measured neutral on MI355X): the operand paths below are the stacked form.
 constexpr bool INTERLEAVE = false;
@@ -626,13 +629,87 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   stash(0, t0 * BK, t0 < tfull);
   __syncthreads();
   int kt = t0;
-  for (; kt + 1 < tfull; ++kt) {  // steady state: next tile is a full one
-    fetch_fast(kt + 1);
-    asm volatile("" ::: "memory");  // keep the global loads in front of the MFMA phase (hipcc sinks them otherwise)
-    compute((kt - t0) & 1);
-    stash((kt + 1 - t0) & 1, (kt + 1) * BK, true);
-    __syncthreads();
+#ifdef BLM_GEMM_PROF
+  unsigned long long pf_compute = 0, pf_stash = 0, pf_barrier = 0, pf_n = 0;
+  unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
+#define BLM_PF_NOW(x) { __builtin_amdgcn_sched_barrier(0); x = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define BLM_PF_ADD() { pf_compute += tb - ta; pf_stash += tc - tb; pf_barrier += td - tc; pf_n += 1; }
+#else
+#define BLM_PF_NOW(x)
+#define BLM_PF_ADD()
+#endif
+  if constexpr (FAST && !SAMP && WTM == 2 && WTN == 2) {  // smaller tiles: the second register set would cost them a workgroup per CU
+    // Steady state with the global loads TWO K tiles ahead (two register sets, LDS still double
+    // buffered): tile kt+2 is requested before the MFMAs of tile kt, tile kt+1 -- requested one
+    // iteration earlier -- is written to LDS after them.  In-kernel stamps on the one-tile-ahead loop
+    // showed 0.5-1.3k cycles per K tile parked on the vmcnt in front of the LDS write (short-K
+    // launches stream fresh rows all the time), against 8.2k cycles of MFMA issue per tile pair.
+    // The refill past the last tile re-reads the last one (clamped index): branch-free body, so
+    // every s_waitcnt counts exactly its own set.
+    float4 ra1[NA], rb1[NB];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) ra1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rb1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch2 = [&](float4 (&xa)[NA], float4 (&xb)[NB], int k) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) xa[j] = *reinterpret_cast<const float4*>(pa[j] + k * stepA);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) xb[j] = *reinterpret_cast<const float4*>(pb[j] + k * stepB);
+    };
+    auto stash2 = [&](float4 (&xa)[NA], float4 (&xb)[NB], int buf) {
+      if constexpr (!A_KMAJ) {
+        if (do_cs) {
+#pragma unroll
+          for (int j = 0; j < NA; ++j) { cs.x += xa[j].x; cs.y += xa[j].y; cs.z += xa[j].z; cs.w += xa[j].w; }
+        }
+      }
+      if constexpr (A_KMAJ) r2s_kmaj<BM>(As + buf * TA, xa); else r2s_nmaj<BM, SA>(As + buf * TA, xa);
+      if constexpr (B_KMAJ) r2s_kmaj<BN>(Bs + buf * TB, xb); else r2s_nmaj<BN, SB>(Bs + buf * TB, xb);
+    };
+    if (t0 + 1 < tfull) fetch2(ra1, rb1, t0 + 1);
+    for (; kt + 2 < tfull; kt += 2) {  // tile kt is in LDS buffer 0, tile kt+1 in the second register set
+      BLM_PF_NOW(ta)
+      fetch2(ra, rb, kt + 2);
+      asm volatile("" ::: "memory");  // keep the global loads in front of the MFMA phase (hipcc sinks them otherwise)
+      compute(0);
+      BLM_PF_NOW(tb)
+      stash2(ra1, rb1, 1);
+      BLM_PF_NOW(tc)
+      __syncthreads();
+      BLM_PF_NOW(td)
+      BLM_PF_ADD()
+      BLM_PF_NOW(ta)
+      fetch2(ra1, rb1, min(kt + 3, tfull - 1));
+      asm volatile("" ::: "memory");
+      compute(1);
+      BLM_PF_NOW(tb)
+      stash2(ra, rb, 0);
+      BLM_PF_NOW(tc)
+      __syncthreads();
+      BLM_PF_NOW(td)
+      BLM_PF_ADD()
+    }
+    if (kt + 1 < tfull) {
+      compute(0);
+      stash2(ra1, rb1, 1);
+      __syncthreads();
+      ++kt;
+    }
+  } else {
+    for (; kt + 1 < tfull; ++kt) {  // steady state: next tile is a full one
+      fetch_fast(kt + 1);
+      asm volatile("" ::: "memory");  // keep the global loads in front of the MFMA phase (hipcc sinks them otherwise)
+      compute((kt - t0) & 1);
+      stash((kt + 1 - t0) & 1, (kt + 1) * BK, true);
+      __syncthreads();
+    }
   }
+#ifdef BLM_GEMM_PROF
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&blm_prof[0], pf_compute); atomicAdd(&blm_prof[1], pf_stash); atomicAdd(&blm_prof[2], pf_barrier); atomicAdd(&blm_prof[3], pf_n);
+  }
+#endif
   for (; kt < t1; ++kt) {  // last full tile and/or the K tail
     const bool more = kt + 1 < t1;
     if (more) fetch_slow((kt + 1) * BK);

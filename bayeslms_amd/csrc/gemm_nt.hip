@@ -5,3 +5,11 @@ namespace blm {
 template int launch_op<BLM_GEMM_NT, false>(const GemmP&, hipStream_t);
 template int launch_op<BLM_GEMM_NT, true>(const GemmP&, hipStream_t);
 }  // namespace blm
+
+#ifdef BLM_GEMM_PROF
+extern "C" int blm_debug_prof_nt(unsigned long long* out, int reset) {
+  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(blm::blm_prof), 4 * sizeof(unsigned long long));
+  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(blm::blm_prof), z, sizeof(z)); }
+  return 0;
+}
+#endif
