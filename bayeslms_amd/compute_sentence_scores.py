@@ -107,8 +107,10 @@ def sentence_score(model, ids, tgt, model_type, hidden, device, model_2=None, hi
                 out2 = model_2(data)
             else:
                 out2, hidden_2 = model_2(data, hidden_2)
-            out = alpha * out + (1. - alpha) * out2  # interpolates LOGITS (reference :163)
-        loss, _ = ops.cross_entropy(out.view(-1, out.shape[-1]), target)
+            # interpolates LOGITS (reference :163); the mixture is formed inside the CE kernel
+            loss, _ = ops.cross_entropy_interp(out.view(-1, out.shape[-1]), out2.view(-1, out2.shape[-1]), alpha, target)
+        else:
+            loss, _ = ops.cross_entropy(out.view(-1, out.shape[-1]), target)
     return len(ids) * float(loss), hidden, hidden_2
 
 
@@ -141,8 +143,9 @@ def _batch_nll(model, data, target_flat, model_type, hidden, model_2, hidden_2, 
         out, _ = model(data, hidden)
     if model_2 is not None:
         out2 = model_2(data) if model_type == 'Transformer' else model_2(data, hidden_2)[0]
-        out = alpha * out + (1. - alpha) * out2
-    _, nll = ops.cross_entropy(out.view(-1, out.shape[-1]), target_flat)
+        _, nll = ops.cross_entropy_interp(out.view(-1, out.shape[-1]), out2.view(-1, out2.shape[-1]), alpha, target_flat)
+    else:
+        _, nll = ops.cross_entropy(out.view(-1, out.shape[-1]), target_flat)
     return nll.view(data.shape[0], data.shape[1])
 
 

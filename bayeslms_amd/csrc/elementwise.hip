@@ -380,6 +380,39 @@ __global__ __launch_bounds__(TPB) void ce_kernel(const float* __restrict__ logit
   }
 }
 
+// Two-model scoring (compute_sentence_scores_bayes_jianwei.py:157-168): NLL of the INTERPOLATED LOGITS
+// z = alpha * a + (1 - alpha) * b, one pass over both logit rows, z never stored.
+__global__ __launch_bounds__(TPB) void ce_interp_kernel(const float* __restrict__ la, const float* __restrict__ lb, long ld,
+                                                        float alpha, const int64_t* __restrict__ tgt,
+                                                        float* __restrict__ nll, int V) {
+  __shared__ float red[TPB / 64];
+  const long row = blockIdx.x;
+  const float* a = la + row * ld;
+  const float* b = lb + row * ld;
+  const float beta = 1.f - alpha;
+  float m = -INFINITY, l = 0.f;
+  const bool vec = ((ld & 3) == 0) && (((reinterpret_cast<uintptr_t>(la) | reinterpret_cast<uintptr_t>(lb)) & 15) == 0);
+  const int V4 = vec ? (V & ~3) : 0;
+  for (int j = threadIdx.x * 4; j < V4; j += TPB * 4) {
+    const float4 u = *reinterpret_cast<const float4*>(a + j), w = *reinterpret_cast<const float4*>(b + j);
+    const float4 v = make_float4(alpha * u.x + beta * w.x, alpha * u.y + beta * w.y, alpha * u.z + beta * w.z, alpha * u.w + beta * w.w);
+    const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    if (mx > m) { l *= __expf(m - mx); m = mx; }
+    l += __expf(v.x - m) + __expf(v.y - m) + __expf(v.z - m) + __expf(v.w - m);
+  }
+  for (int j = V4 + threadIdx.x; j < V; j += TPB) {
+    const float v = alpha * a[j] + beta * b[j];
+    if (v > m) { l *= __expf(m - v); m = v; }
+    l += __expf(v - m);
+  }
+  const long t = tgt[row];
+  const bool valid = t >= 0 && t < V;
+  const float xt = valid ? alpha * a[t] + beta * b[t] : 0.f;
+  const float M_ = block_max<TPB / 64>(m, red);
+  const float L_ = block_sum<TPB / 64>(m == -INFINITY ? 0.f : l * __expf(m - M_), red);
+  if (threadIdx.x == 0) nll[row] = valid ? M_ + __logf(L_) - xt : 0.f;
+}
+
 __global__ __launch_bounds__(TPB) void ce_bwd_kernel(const float* __restrict__ logits, long ld,
                                                      const int64_t* __restrict__ tgt, const float* __restrict__ lse_in,
                                                      const float* __restrict__ g_dev, float scale,
@@ -756,6 +789,15 @@ extern "C" int blm_ce_fwd_bwd(const float* logits, int64_t ld, const int64_t* tg
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ST, nll, (long)M, loss_sum);
     BLM_HIP(hipGetLastError());
   }
+  return BLM_OK;
+}
+
+extern "C" int blm_ce_interp_fwd(const float* logits_a, const float* logits_b, int64_t ld, float alpha, const int64_t* tgt,
+                                 float* nll, int M, int V, void* stream) {
+  if (!logits_a || !logits_b || !tgt || !nll || M < 0 || V <= 0 || ld < V) return blm_fail(BLM_ERR_INVALID, "blm_ce_interp_fwd: bad arguments");
+  if (M == 0) return BLM_OK;
+  hipLaunchKernelGGL(ce_interp_kernel, dim3(M), dim3(TPB), 0, ST, logits_a, logits_b, (long)ld, alpha, tgt, nll, V);
+  BLM_HIP(hipGetLastError());
   return BLM_OK;
 }
 

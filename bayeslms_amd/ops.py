@@ -727,6 +727,21 @@ def cross_entropy(logits, targets, unit_grad=False):
     return _CrossEntropy.apply(logits, targets, unit_grad)
 
 
+def cross_entropy_interp(logits_a, logits_b, alpha, targets):
+    """Scoring with two models: per-token NLL of the interpolated LOGITS alpha*a + (1-alpha)*b
+    (compute_sentence_scores_bayes_jianwei.py:157-168) without storing the mixture.  Forward only.
+    -> (mean NLL, per-token NLL)"""
+    a, b = _f32(logits_a, "logits_a"), _f32(logits_b, "logits_b")
+    if a.shape != b.shape or a.dim() != 2:
+        raise ValueError("cross_entropy_interp: logits must be two (M, V) matrices of the same shape")
+    L.require_gfx950()
+    M, V = a.shape
+    tgt = targets.contiguous()
+    nll = torch.empty(M, device=a.device, dtype=torch.float32)
+    check(lib().blm_ce_interp_fwd(ptr(a), ptr(b), V, float(alpha), ptr(tgt), ptr(nll), M, V, stream()), "blm_ce_interp_fwd")
+    return nll.mean(), nll
+
+
 # ----------------------------------------------------------------------------
 # KL term  mean(mu^2 - 2 lg + exp(2 lg) [-1]) / 2  over a row window of mu
 # ----------------------------------------------------------------------------

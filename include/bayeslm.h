@@ -241,6 +241,13 @@ int blm_ce_fwd_bwd(const float* logits, int64_t ld, const int64_t* tgt, float* n
 int blm_ce_bwd(const float* logits, int64_t ld, const int64_t* tgt, const float* lse, const float* g_dev, float scale,
                float* dlogits, int M, int V, void* stream);
 
+/* Scoring with two interpolated models (compute_sentence_scores_bayes_jianwei.py:157-168: the
+ * LOGITS are mixed, alpha*a + (1-alpha)*b, before the log-softmax): per-row NLL in one pass over
+ * both logit matrices (M, V), the mixture is never stored.  Forward only. */
+int blm_ce_interp_fwd(const float* logits_a, const float* logits_b, int64_t ld, float alpha, const int64_t* tgt,
+                      float* nll, int M, int V, void* stream);
+
+
 /* dcoef[i,n] += sum_m g[m,n] * act_i(z[m,n]), i = tanh, sigmoid, relu, gelu: gradient of the GPNN
  * mixture coefficients (autograd of model.py:1885-1899). */
 int blm_gp_coef_grad(const float* g, const float* z, float* dcoef, int M, int N, void* stream);

@@ -26,6 +26,8 @@ def load_golden(name, device="cpu"):
             sd[k[3:]] = t
         elif k.startswith("grad/"):
             grad[k[5:]] = t
+        elif k.startswith("sd2/"):  # second model of an interpolation fixture
+            plain.setdefault("sd2", {})[k[4:]] = t
         else:
             plain[k] = t
     return plain, sd, grad

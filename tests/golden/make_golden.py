@@ -313,6 +313,57 @@ def f7_scorer():
                  argv=np.array(margs), **pack_sd(m))
 
 
+def f7_scorer_interp():
+    """Reference scorer with interpolation: logits of the Bayesian model and of a second, standard
+    model (built as the reference builds it, :385-436) mixed with alpha = 0.7 before the log-softmax
+    (:157-168).  The second state dict travels under the sd2/ prefix."""
+    import importlib
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    scorer = importlib.import_module("compute_sentence_scores_bayes_jianwei")
+    for tag, margs, build, build2 in (
+        ("lstm_bayes3_interp", ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty",
+                                "Bayesian", "--L_bayes_pos", "3"],
+         lambda V: ref.BayesRNNModel("LSTM", V, 12, 12, 2, 0.5, True, 3),
+         lambda V: ref.BayesRNNModel("LSTM", V, 12, 12, 2, 0.5, False, 0)),
+        ("tlm_ffn_interp", ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                            "--uncertainty", "Bayesian", "--T_bayes_pos", "FFN"],
+         lambda V: ref.BayesTransformerModel(V, 16, 4, 32, 2, 0.5, True, "FFN"),
+         lambda V: ref.BayesTransformerModel(V, 16, 4, 32, 2, 0.5, True, "none")),
+    ):
+        with tempfile.TemporaryDirectory() as dtmp:
+            words, _ = _tiny_corpus(dtmp)
+            rng = np.random.RandomState(12)
+            nb = []
+            for u in range(3):
+                for n in range(1, 4):
+                    ln = rng.randint(1, 7)
+                    toks = [words[rng.randint(2, 30)] if rng.rand() > 0.15 else "zzz" for _ in range(ln)]
+                    nb.append("utt%d-B-%d %s" % (u, n, " ".join(toks)))
+            nbest_txt = "\n".join(nb) + "\n"
+            with open(os.path.join(dtmp, "nbest.txt"), "w") as f:
+                f.write(nbest_txt)
+            torch.manual_seed(78)
+            with contextlib.redirect_stdout(io.StringIO()):
+                m, m2 = build(len(words)), build2(len(words))
+            torch.save(m.state_dict(), os.path.join(dtmp, "model.pt"))
+            torch.save(m2.state_dict(), os.path.join(dtmp, "model2.pt"))
+            extra = ["--interpolation_flag", "1", "--inter_alpha", "0.7"]
+            # the reference's main() overwrites --inter_path with an absolute path of its authors' cluster
+            # (:451-454), so the interpolation run calls its compute_scores()/write_scores() directly
+            mtype = margs[1]
+            vocab = scorer.read_vocab(os.path.join(dtmp, "words.txt"))
+            nbest = scorer.load_nbest(os.path.join(dtmp, "nbest.txt"))
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = scorer.compute_scores(nbest, m, torch.nn.CrossEntropyLoss(), len(vocab), vocab, model_type=mtype,
+                                            inter_flag=1, alpha=0.7, model_2=m2)
+                scorer.write_scores(res, os.path.join(dtmp, "out.txt"))
+            out_txt = open(os.path.join(dtmp, "out.txt")).read()
+            sd2 = {"sd2/" + k: (npy(v)[:64] if k.endswith("pos_encoder.pe") else npy(v)) for k, v in m2.state_dict().items()}
+            save("scorer_" + tag, words=np.array(words), nbest_txt=np.array(nbest_txt), scores_txt=np.array(out_txt),
+                 argv=np.array(margs + extra), **pack_sd(m), **sd2)
+
+
 def f6_train_checkpoint():
     """Runs the reference train.py itself (subprocess, CPU, 1 epoch, tiny corpus) and keeps the
     checkpoint it saved plus the eval losses: the printed ones (2 decimals) and the same quantity
@@ -443,6 +494,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rnnv":
         f5_gauss_variational_rnn()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "interp":
+        f7_scorer_interp()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "late":
         f6_train_checkpoint()
         f7_scorer()
@@ -459,3 +513,4 @@ if __name__ == "__main__":
     f8_data()
     f6_train_checkpoint()
     f7_scorer()
+    f7_scorer_interp()

@@ -483,6 +483,20 @@ def test_lstm_step_bwd_full_size_matches_composition(dev):
     assert torch.equal(dh2, outs[0][2])
 
 
+@pytest.mark.parametrize("M,V", [(7, 50), (33, 33000), (5, 1001)])
+def test_ce_interp_matches_torch(dev, M, V):
+    """two-model scoring: NLL of alpha*a + (1-alpha)*b (reference scorer :157-168), odd V = scalar tail"""
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(M + V)
+    a, b = torch.randn(M, V, generator=g) * 3, torch.randn(M, V, generator=g) * 3
+    tgt = torch.randint(0, V, (M,), generator=g)
+    for alpha in (0.0, 0.3, 1.0):
+        ref = torch.nn.functional.cross_entropy((alpha * a + (1 - alpha) * b).double(), tgt, reduction="none")
+        mean, nll = ops.cross_entropy_interp(a.to(dev), b.to(dev), alpha, tgt.to(dev))
+        assert rel(nll, ref.float()) < 1e-5
+        assert abs(float(mean) - float(ref.mean())) < 1e-4 * max(1.0, float(ref.mean()))
+
+
 # ------------------------------------------------------------------ full-size, size-independent properties
 def test_sampled_gemm_full_size_properties(dev):
     """cfg3 shape (M=8192, N=512, K=4096): fused-in-loader sampling == materialise-then-GEMM (same

@@ -310,6 +310,34 @@ def test_scorer_cli_matches_reference_output(dev, tag, tmp_path):
     assert len(mc) == len(want) and all(v == v and v >= 0 for v in mc)
 
 
+@pytest.mark.parametrize("tag", ["tlm_ffn_interp", "lstm_bayes3_interp"])
+def test_scorer_cli_interpolation_matches_reference(dev, tag, tmp_path):
+    """--interpolation_flag 1: two models, logits mixed inside the CE kernel (blm_ce_interp_fwd); scores of
+    the reference's compute_scores on the same two checkpoints."""
+    import os
+    from bayeslms_amd import compute_sentence_scores as S
+    from oracle import bayes_oracle as O
+    g, sd, _ = load_golden("scorer_" + tag)
+    d = str(tmp_path)
+    _write_corpus(g, d)
+    with open(os.path.join(d, "nbest.txt"), "w") as f:
+        f.write(str(g["nbest_txt"]))
+    for name, full in (("model.pt", dict(sd)), ("model2.pt", dict(g["sd2"]))):
+        if "pos_encoder.pe" in full:
+            full["pos_encoder.pe"] = O.positional_table(5000, full["encoder.weight"].shape[1])
+        torch.save(full, os.path.join(d, name))
+    argv = ["--nbest-list", os.path.join(d, "nbest.txt"), "--outfile", os.path.join(d, "out.txt"), "--vocabulary",
+            os.path.join(d, "words.txt"), "--model-path", os.path.join(d, "model.pt"), "--inter_path",
+            os.path.join(d, "model2.pt")] + [str(a) for a in g["argv"]]
+    want = [ln.split() for ln in str(g["scores_txt"]).splitlines()]
+    for batched in ("1", "0"):
+        S.main(argv + ["--batched", batched])
+        got = [ln.split() for ln in open(os.path.join(d, "out.txt")).read().splitlines()]
+        assert [a[0] for a in got] == [b[0] for b in want]
+        for a, b in zip(got, want):
+            assert abs(float(a[1]) - float(b[1])) <= 1e-3 * max(1.0, abs(float(b[1]))), (batched, a, b)
+
+
 @pytest.mark.parametrize("margs", [
     ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4", "--uncertainty",
      "Bayesian", "--T_bayes_pos", "FFN"],

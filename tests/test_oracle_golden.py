@@ -221,6 +221,45 @@ def test_scorer_scores_of_reference(tag):
         assert abs(a - b) <= 2e-4 * max(1.0, abs(b))
 
 
+@pytest.mark.parametrize("tag", ["tlm_ffn_interp", "lstm_bayes3_interp"])
+def test_scorer_interpolation_of_reference(tag):
+    """Two-model scoring by the reference's compute_scores (:157-168): the LOGITS are mixed with
+    alpha = 0.7 before the log-softmax; the second LSTM carries its own hidden state."""
+    from bayeslms_amd import compute_sentence_scores as S
+    import collections
+    g, sd, _ = load_golden("scorer_" + tag)
+    sd2 = g["sd2"]
+    vocab = {w: i for i, w in enumerate(g["words"])}
+    want = [(ln.split()[0], float(ln.split()[1])) for ln in str(g["scores_txt"]).splitlines()]
+    is_rnn = tag.startswith("lstm")
+    H = sd["rnn.weight_hh_mean_1"].shape[1] if is_rnn else 0
+    hid = (torch.zeros(2, 1, H), torch.zeros(2, 1, H)) if is_rnn else None
+    hid2 = (torch.zeros(2, 1, H), torch.zeros(2, 1, H)) if is_rnn else None
+    nbest = collections.OrderedDict()
+    for line in str(g["nbest_txt"]).splitlines():
+        parts = line.strip().split(' ', 1)
+        key, hyp = (parts[0], parts[1]) if len(parts) == 2 else (line.strip(), ' ')
+        nbest.setdefault(key.rsplit('-', 1)[0], []).append(hyp)
+    got = []
+    for key, hyps in nbest.items():
+        first = first2 = None
+        for n, hyp in enumerate(hyps, 1):
+            x, t = S.get_input_and_target(hyp, vocab)
+            xs, ts = torch.tensor(x).view(-1, 1), torch.tensor(t)
+            if is_rnn:
+                o1, h1 = O.bayes_rnn_lm(xs, hid, sd, 3, None)
+                o2, h2 = O.bayes_rnn_lm(xs, hid2, sd2, 0, None)
+                first, first2 = (h1, h2) if first is None else (first, first2)
+            else:
+                o1, o2 = O.transformer_lm(xs, sd, 4, None), O.transformer_lm(xs, sd2, 4, None)
+            got.append(("%s-%d" % (key, n), float(O.sentence_score(0.7 * o1 + 0.3 * o2, ts))))
+        if is_rnn:
+            hid, hid2 = first, first2
+    assert [k for k, _ in got] == [k for k, _ in want]
+    for (_, a), (_, b) in zip(got, want):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b))
+
+
 GAUSS_RNN = ["33", "31", "13", "23", "43", "330", "6360", "3333", "53", "73", "00"]
 
 
