@@ -588,7 +588,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   // under >= 1024 cycles of matrix work.  Reads and their counted lgkmcnt wait are inline asm
   // (cdna_hip_programming.md 5.7): after the wait every fragment register of the group is tied with an
   // empty "+v" statement and a sched_barrier(0) keeps the MFMAs below it.
-  auto compute = [&](int cur) {
+  // `mid` runs once in the middle of the tile (after the second fragment group's wait): the deep-
+  // prefetch loop writes the NEXT tile to the other LDS buffer there, so that the write latency sits
+  // under the remaining 32 MFMA steps and the end-of-tile barrier finds lgkmcnt already at 0
+  auto compute = [&](int cur, auto&& mid) {
     using FA = FragG<A_KMAJ, WTM, SA>;
     using FB = FragG<B_KMAJ, WTN, SB>;
     const uint32_t a_base = A_KMAJ ? lds_u32(As + cur * TA + (wm * (32 * WTM) + li) * KS + 4 * lh)
@@ -610,6 +613,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
       }
       a[t4 & 1].tie();
       b[t4 & 1].tie();
+      if (t4 == 2) mid();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4)
@@ -672,9 +676,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
       BLM_PF_NOW(ta)
       fetch2(ra, rb, kt + 2);
       asm volatile("" ::: "memory");  // keep the global loads in front of the MFMA phase (hipcc sinks them otherwise)
-      compute(0);
+      compute(0, [&] { stash2(ra1, rb1, 1); });
       BLM_PF_NOW(tb)
-      stash2(ra1, rb1, 1);
       BLM_PF_NOW(tc)
       __syncthreads();
       BLM_PF_NOW(td)
@@ -682,17 +685,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
       BLM_PF_NOW(ta)
       fetch2(ra1, rb1, min(kt + 3, tfull - 1));
       asm volatile("" ::: "memory");
-      compute(1);
+      compute(1, [&] { stash2(ra, rb, 0); });
       BLM_PF_NOW(tb)
-      stash2(ra, rb, 0);
       BLM_PF_NOW(tc)
       __syncthreads();
       BLM_PF_NOW(td)
       BLM_PF_ADD()
     }
     if (kt + 1 < tfull) {
-      compute(0);
-      stash2(ra1, rb1, 1);
+      compute(0, [&] { stash2(ra1, rb1, 1); });
       __syncthreads();
       ++kt;
     }
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     for (; kt + 1 < tfull; ++kt) {  // steady state: next tile is a full one
       fetch_fast(kt + 1);
       asm volatile("" ::: "memory");  // keep the global loads in front of the MFMA phase (hipcc sinks them otherwise)
-      compute((kt - t0) & 1);
+      compute((kt - t0) & 1, [] {});
       stash((kt + 1 - t0) & 1, (kt + 1) * BK, true);
       __syncthreads();
     }
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   for (; kt < t1; ++kt) {  // last full tile and/or the K tail
     const bool more = kt + 1 < t1;
     if (more) fetch_slow((kt + 1) * BK);
-    compute((kt - t0) & 1);
+    compute((kt - t0) & 1, [] {});
     if (more) stash((kt + 1 - t0) & 1, (kt + 1) * BK, false);
     __syncthreads();
   }
