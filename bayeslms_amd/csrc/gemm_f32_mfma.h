@@ -258,7 +258,7 @@ __device__ __forceinline__ void gemm_keep_pair(const GemmP& p, int m, int c0, fl
 // two operand values a lane needs per k-step are adjacent in LDS (one ds_read_b64) and a lane's two
 // output columns are adjacent in C.
 template <int EPI>
-__device__ __forceinline__ void epi_elem(const GemmP& p, bool accum, int row, int col, float acc, float bias, float keep) {
+__device__ __forceinline__ void epi_elem(const GemmP& p, bool accum, int row, int col, float acc, float bias, float keep, bool kl_on = true) {
   const long o = (long)row * p.ldc + col;
   float v = p.alpha * acc;
   if constexpr (EPI == BLM_EPI_BIAS) {
@@ -288,12 +288,16 @@ __device__ __forceinline__ void epi_elem(const GemmP& p, bool accum, int row, in
       float e;
       if (p.vc.eps) e = p.vc.eps[si];
       else e = philox_normal1_rolled(p.vc.rng, (uint64_t)si);
-      const float g2 = dW * e * sig + p.kl_lambda * (sig * sig - 1.0f) * p.kl_inv_n;
-      p.C2[si] = accum ? p.C2[si] + g2 : g2;
-      v = dW + p.kl_lambda * p.wg_mu[o] * p.kl_inv_n;
+      // both gradients are linear in dW, so K slices add up through atomics; the KL terms (no dW in
+      // them) are contributed by the first slice only
+      const float klw = kl_on ? p.kl_lambda * p.kl_inv_n : 0.f;
+      const float g2 = dW * e * sig + klw * (sig * sig - 1.0f);
+      if (p.atomic) atomicAdd(p.C2 + si, g2);
+      else p.C2[si] = accum ? p.C2[si] + g2 : g2;
+      v = dW + klw * p.wg_mu[o];
     }
   }
-  if constexpr (EPI == BLM_EPI_NONE) {
+  if constexpr (EPI == BLM_EPI_NONE || EPI == BLM_EPI_BAYES_WGRAD) {
     if (p.atomic) { atomicAdd(p.C + o, v); return; }
   }
   p.C[o] = accum ? p.C[o] + v : v;
@@ -301,7 +305,7 @@ __device__ __forceinline__ void epi_elem(const GemmP& p, bool accum, int row, in
 
 template <int EPI, int WTM, int WTN>
 __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN], int m0, int n0, int wm, int wn,
-                                         int li, int lh) {
+                                         int li, int lh, bool kl_on = true) {
   constexpr bool DROP = (EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_GP_MIX || EPI == BLM_EPI_MUL_DGP_MIX);
   constexpr bool BIAS = (EPI == BLM_EPI_BIAS || EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_GP_MIX);
   const bool accum = p.flags & BLM_GEMM_ACCUMULATE;
@@ -365,7 +369,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN]
         }
 #pragma unroll
         for (int j = 0; j < WTN; ++j)
-          if (col[j] < p.N) epi_elem<EPI>(p, accum, row, col[j], acc[i][j][r], bias[j], keep[rr][j]);
+          if (col[j] < p.N) epi_elem<EPI>(p, accum, row, col[j], acc[i][j][r], bias[j], keep[rr][j], kl_on);
       }
     }
   }
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     case BLM_EPI_GP_MIX: epilogue<BLM_EPI_GP_MIX, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
     case BLM_EPI_MUL_DGP_MIX: epilogue<BLM_EPI_MUL_DGP_MIX, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
     case BLM_EPI_BAYES_WGRAD:
-      if constexpr (OP == BLM_GEMM_TN) epilogue<BLM_EPI_BAYES_WGRAD, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh);
+      if constexpr (OP == BLM_GEMM_TN) epilogue<BLM_EPI_BAYES_WGRAD, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh, ks == 0);
       break;
     default: epilogue<BLM_EPI_NONE, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
   }
@@ -771,7 +775,10 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   // in C through float atomics (only for the plain epilogue; C is zeroed first unless accumulating)
   const long nb = (long)q.gm * q.gn;
   int splits = 1;
-  const bool can_split = p.epi == BLM_EPI_NONE && !SAMP && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N);
+  // the Bayesian wgrad epilogue is linear in dW (KL terms from the first slice only): it splits too,
+  // but only when accumulating (its second output has no zeroing pass here)
+  const bool can_split = !SAMP && ((p.epi == BLM_EPI_NONE && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N)) ||
+                                   (p.epi == BLM_EPI_BAYES_WGRAD && (p.flags & BLM_GEMM_ACCUMULATE)));
   const bool small_out = (long)p.M * p.N <= (1L << 20);  // e.g. the LSTM recurrent GEMMs (64 x 4096): zeroing C is free
   const int min_k = small_out ? 128 : 512;               // K per split
   // forward layout, one full round of the chip (>= 256 tiles): no split unless K is very long -- within
@@ -788,8 +795,7 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   // chip -- the workgroups of one slice then share the same rows of both operands in L2
   // (decoder dW 33000x512x8192: 102 -> 120 TFLOP/s, tools/gemm_sweep.sh)
   if (OP == BLM_GEMM_TN && can_split && p.K >= 4096 && splits < 4) splits = 4;
-  if (p.force_splits > 0 && p.epi == BLM_EPI_NONE && !SAMP && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N))
-    splits = p.force_splits;
+  if (p.force_splits > 0 && can_split) splits = p.force_splits;
   q.splits = splits;
   q.kper = splits > 1 ? ((p.K + splits - 1) / splits + BK - 1) / BK * BK : (p.K > 0 ? p.K : 1);
   q.atomic = splits > 1;
@@ -831,8 +837,10 @@ int launch_op(const GemmP& p, hipStream_t st) {
   //    tiles and let split-K fill the chip (wgrads: 128x128 +8%, qkv wgrad 64x128 x 8 slices +40%);
   //  * short-K launches (K <= 1024) whose 128x128 grid is less than two full rounds of the chip run
   //    better on 64x128 tiles (qkv / out-proj forward, out-proj dgrad: +10..25%);
-  //  * the Bayesian wgrad (no split-K because of its epilogue) runs best on 64x64 tiles.
-  const bool can_split = p.epi == BLM_EPI_NONE && !SAMP && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N);
+  //  * the Bayesian wgrad splits like the plain ones when it accumulates (its epilogue is linear in
+  //    dW); without split-K it runs best on 64x64 tiles.
+  const bool can_split = !SAMP && ((p.epi == BLM_EPI_NONE && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N)) ||
+                                   (p.epi == BLM_EPI_BAYES_WGRAD && (p.flags & BLM_GEMM_ACCUMULATE)));
   if (can_split && p.K >= 2048 && p.M > 64 && p.N > 64) {
     const long t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
     if (b128 >= 96) small_m = small_n = false;
@@ -841,7 +849,7 @@ int launch_op(const GemmP& p, hipStream_t st) {
   } else if (p.K <= 1024 && b128 >= 256 && b128 < 1024 && p.M >= 128 && p.N >= 128) {
     small_m = true; small_n = false;
   }
-  if (OP == BLM_GEMM_TN && p.epi == BLM_EPI_BAYES_WGRAD) small_m = small_n = true;
+  if (OP == BLM_GEMM_TN && p.epi == BLM_EPI_BAYES_WGRAD && !(can_split && p.K >= 2048)) small_m = small_n = true;
   if (p.force_tile == 11) { small_m = small_n = true; }
   else if (p.force_tile == 12) { small_m = true; small_n = false; }
   else if (p.force_tile == 21) { small_m = false; small_n = true; }

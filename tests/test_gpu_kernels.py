@@ -214,6 +214,30 @@ def test_bayes_linear_philox_fwd_bwd_consistent(dev, fused):
     assert rel(lg.grad, lg_c.grad) < 5e-4
 
 
+@pytest.mark.parametrize("M,K,N", [(4096, 256, 512), (8192, 512, 1024)])
+def test_bayes_linear_wgrad_split_k(dev, M, K, N):
+    """Long reduction (M rows of the batch): the Bayesian wgrad epilogue runs under split-K -- both
+    gradients accumulate through atomics, the KL terms are added by the first K slice only.  Two
+    backward passes into the same .grad must give exactly twice the CPU gradient (KL included once
+    per pass)."""
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(M + N)
+    mu = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.1).to(dev))
+    lg = torch.nn.Parameter((torch.rand(N, K, generator=g) - 3.0).to(dev))
+    x = (torch.randn(M, K, generator=g) * 0.5).to(dev)
+    gy = (torch.randn(M, N, generator=g) * 0.1).to(dev)
+    eps = torch.randn(N, K, generator=g)
+    lam = 0.37
+    for _ in range(2):
+        y = ops.bayes_linear(x, mu, lg, ops.NoiseSpec(eps=eps.to(dev)), kl_lambda=lam, fused=False)
+        (y * gy).sum().backward()
+    mu_c, lg_c = mu.detach().cpu().double().requires_grad_(True), lg.detach().cpu().double().requires_grad_(True)
+    yr = O.bayes_linear(x.cpu().double(), mu_c, lg_c, eps.double())
+    ((yr * gy.cpu().double()).sum() + lam * O.kl_mean_form(mu_c, lg_c)).backward()
+    assert rel(mu.grad, 2 * mu_c.grad.float()) < 2e-5
+    assert rel(lg.grad, 2 * lg_c.grad.float()) < 2e-5
+
+
 def test_kl_mean_window_and_minus_one(dev):
     ops = ops_mod()
     g = torch.Generator().manual_seed(2)
