@@ -44,6 +44,7 @@ extern "C" int blm_gemm(const blm_gemm_args* a, void* stream) {
   p.colsum_a = a->colsum_a;
   if (a->colsum_a && a->op != BLM_GEMM_TN) return blm_fail(BLM_ERR_INVALID, "blm_gemm: colsum_a needs op TN");
   p.drop_quad = (a->N % 4 == 0);
+  p.eps_quad = (a->epilogue == BLM_EPI_BAYES_WGRAD && a->N % 4 == 0 && !blm::INTERLEAVE && !a->var_c.eps) ? 1 : 0;
   {
     static int tile = -1, spl = -1;  // tuning overrides, read once
     if (tile < 0) { const char* e = getenv("BLM_GEMM_TILE"); tile = e ? atoi(e) : 0; }

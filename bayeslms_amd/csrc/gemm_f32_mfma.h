@@ -42,6 +42,7 @@ struct GemmP {
   float kl_lambda, kl_inv_n;
   int a_vec, b_vec, fast, vec_epi;
   int gm, gn;
+  int eps_quad;                  // Bayesian wgrad: eps drawn once per 4 columns and shared inside the quad (N % 4 == 0, Philox mode)
   int force_tile, force_splits;  // tuning overrides (BLM_GEMM_TILE / BLM_GEMM_SPLITK env), 0 = heuristic
   float* colsum_a;  // TN only: += column sums of A (= bias gradient of the layer whose wgrad this is)
   int splits, kper, atomic;  // split-K: block ks covers k in [ks*kper, (ks+1)*kper), partial sums by float atomics
@@ -253,6 +254,31 @@ __device__ __forceinline__ void gemm_keep_pair(const GemmP& p, int m, int c0, fl
   k1 = (hi ? u.w : u.y) >= p.drop_thr ? p.drop_inv_keep : 0.f;
 }
 
+// Bayesian wgrad: eps of the four rows base_row + {0,1,2,3}*row_stride at this lane's column, same quad
+// scheme as gemm_keep_quad: lane k draws the Philox block (4 normals = 4 consecutive columns) of row k,
+// the quad exchanges them by DPP broadcasts -- one Philox call + two Box-Muller per 4 elements instead
+// of one call per element.  Needs N % 4 == 0 (then element index & 3 == column & 3 == lane & 3).
+__device__ __forceinline__ void gemm_eps_quad(const GemmP& p, int base_row, int row_stride, int col, float (&eps)[4]) {
+  const int k = threadIdx.x & 3;
+  const int rel = min(max(base_row + k * row_stride - p.vc.row_lo, 0), p.vc.srows - 1);
+  const uint64_t si = (uint64_t)rel * (uint64_t)p.N + (uint64_t)(min(col, p.N - 1) & ~3);
+  const u32x4 u = philox4x32_10_rolled((uint32_t)(si >> 2), (uint32_t)(si >> 34), p.vc.rng.stream, p.vc.rng.step,
+                                       (uint32_t)p.vc.rng.seed, (uint32_t)(p.vc.rng.seed >> 32));
+  float z0, z1, z2, z3;
+  box_muller(u.x, u.y, z0, z1);
+  box_muller(u.z, u.w, z2, z3);
+#define BLM_QUAD_BCASTF(x, j) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), (j) * 0x55, 0xF, 0xF, true))
+#define BLM_EPS_FROM(j)                                                                                   \
+  {                                                                                                       \
+    const float w0 = BLM_QUAD_BCASTF(z0, j), w1 = BLM_QUAD_BCASTF(z1, j), w2 = BLM_QUAD_BCASTF(z2, j),     \
+                w3 = BLM_QUAD_BCASTF(z3, j);                                                              \
+    eps[j] = k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));                                            \
+  }
+  BLM_EPS_FROM(0) BLM_EPS_FROM(1) BLM_EPS_FROM(2) BLM_EPS_FROM(3)
+#undef BLM_EPS_FROM
+#undef BLM_QUAD_BCASTF
+}
+
 // C/D map of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  A wave that owns
 // two MFMA tiles along a dimension INTERLEAVES them (tile t holds matrix rows/cols 2*x + t), so the
 // two operand values a lane needs per k-step are adjacent in LDS (one ds_read_b64) and a lane's two
@@ -287,6 +313,7 @@ __device__ __forceinline__ void epi_elem(const GemmP& p, bool accum, int row, in
       const float sig = __expf(p.vc.lgstd[si]);
       float e;
       if (p.vc.eps) e = p.vc.eps[si];
+      else if (p.eps_quad) e = keep;  // drawn per quad by the caller (gemm_eps_quad)
       else e = philox_normal1_rolled(p.vc.rng, (uint64_t)si);
       // both gradients are linear in dW, so K slices add up through atomics; the KL terms (no dW in
       // them) are contributed by the first slice only
@@ -332,6 +359,17 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN]
       for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
         for (int j = 0; j < WTN; ++j) keep[rr][j] = 1.f;
+      if constexpr (EPI == BLM_EPI_BAYES_WGRAD) {
+        if (p.eps_quad) {  // wave-uniform; every lane runs it (the quad exchange needs all lanes)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) {
+            float e4[4];
+            gemm_eps_quad(p, row0, RS, col[j], e4);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) keep[rr][j] = e4[rr];
+          }
+        }
+      }
       if constexpr (DROP) {
         if (p.drop_on) {  // wave-uniform; every lane runs it (the quad exchange needs all lanes)
           if (INTERLEAVE && WTN == 2 && p.drop_quad) {
