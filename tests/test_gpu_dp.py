@@ -74,3 +74,55 @@ def test_two_ranks_equal_one_rank_on_the_global_batch():
 def _spawn(world, ret):
     port = _free_port()
     mp.spawn(_run, args=(world, port, ret), nprocs=world, join=True)
+
+
+def _rccl_one_rank(port, ret):
+    """RCCL itself (backend "nccl"), one rank: process-group init with device_id as bench.py does it,
+    the reducer's side-stream async all-reduce pattern, barrier, and a Trainer step in 'world 2'
+    arithmetic (the collective over a 1-rank group is the identity, so the result must equal the
+    plain run with gradients halved by grad_scale)."""
+    import torch.distributed as dist
+    from bayeslms_amd import data as D, engine
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        x = torch.arange(1024, device=dev, dtype=torch.float32)
+        side = torch.cuda.Stream()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            h = dist.all_reduce(x[128:512], op=dist.ReduceOp.SUM, async_op=True)
+        h.wait()
+        torch.cuda.current_stream().wait_stream(side)
+        dist.barrier()
+        ok_identity = bool(torch.equal(x.cpu(), torch.arange(1024, dtype=torch.float32)))
+        stream = torch.randint(0, 150, (8 * 61,), generator=torch.Generator().manual_seed(1))
+        train = D.batchify(stream, 8, dev)
+        m = _build(dev)
+        tr = engine.Trainer(m, lr=0.2, clip=0.5, kl_scale=0.01, seed=1111, rank=0, world=2, bucket_bytes=8192)
+        tr.reducer.world = 2  # grad-ready hooks on, bucketed collectives issued over RCCL (1-rank group: identity)
+        losses = []
+        for i in range(3):
+            data, tgt = D.get_batch(train, i * 12, 12)
+            loss, _, _ = tr.step(data, tgt, kl_fn=_kl)
+            losses.append(float(loss))
+        ret["rccl"] = (ok_identity, losses, bool(torch.isfinite(tr.flat.flat_param).all()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank_smoke():
+    import torch.distributed as dist
+    if not dist.is_nccl_available():
+        pytest.skip("no RCCL in this torch build")
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        p = mp.get_context("spawn").Process(target=_rccl_one_rank, args=(_free_port(), ret))
+        p.start()
+        p.join(300)
+        assert p.exitcode == 0
+        ok, losses, finite = ret["rccl"]
+        assert ok and finite and all(v == v for v in losses) and losses[-1] < losses[0] + 1.0
