@@ -81,6 +81,41 @@ def test_gemm_nt_nn_tn(dev, M, N, K):
     assert rel(C3, 1.5 * (D.double().t() @ A.double())) < 1e-5
 
 
+def test_gemm_random_shapes_all_paths(dev):
+    """Seeded random sweep over the launch paths: 128x128 deep-prefetch loop (1, 2, 3, many K tiles, K
+    tails), small tiles, split-K (long K, small outputs, tall TN), padded leading dimensions, bias
+    epilogue, accumulate -- every result against fp64 on the device."""
+    ops, lib = ops_mod(), L()
+    rng = np.random.RandomState(2024)
+    dims = [1, 3, 31, 32, 33, 64, 96, 127, 128, 129, 160, 255, 256, 300, 512, 640]
+    ks = [1, 31, 32, 33, 64, 65, 96, 100, 128, 160, 512, 2048, 2080, 4096, 4100]
+    cases = [(int(rng.choice(dims)), int(rng.choice(dims)), int(rng.choice(ks))) for _ in range(36)]
+    cases += [(1536, 512, 8192), (512, 512, 8192), (256, 256, 33000), (2048, 128, 4096)]
+    for idx, (M, N, K) in enumerate(cases):
+        op = (lib.GEMM_NT, lib.GEMM_NN, lib.GEMM_TN)[idx % 3]
+        pad_a, pad_b, pad_c = (0, 4, 8)[idx % 3], (0, 4)[idx % 2], (0, 4)[(idx // 2) % 2]
+        g = torch.Generator(device=dev).manual_seed(idx)
+        rn = lambda r, c, pad: torch.randn(r, c + pad, device=dev, generator=g)[:, :c]  # noqa: E731
+        if op == lib.GEMM_NT:
+            A, B = rn(M, K, pad_a), rn(N, K, pad_b)
+            ref = A.double() @ B.double().t()
+        elif op == lib.GEMM_NN:
+            A, B = rn(M, K, pad_a), rn(K, N, pad_b)
+            ref = A.double() @ B.double()
+        else:
+            A, B = rn(K, M, pad_a), rn(K, N, pad_b)
+            ref = A.double().t() @ B.double()
+        Cfull = torch.randn(M, N + pad_c, device=dev, generator=g)
+        C = Cfull[:, :N]
+        acc = idx % 4 == 1
+        bias = torch.randn(N, device=dev, generator=g) if (idx % 5 == 2 and not acc) else None
+        want = ref + (C.double() if acc else 0) + (bias.double() if bias is not None else 0)
+        ops.gemm(op, A, B, C, M, N, K, A.stride(0), B.stride(0), C.stride(0), accumulate=acc,
+                 epilogue=lib.EPI_BIAS if bias is not None else lib.EPI_NONE, bias=bias)
+        err = float((C.double() - want).abs().max() / (want.abs().max() + 1e-30))
+        assert err < 2e-5, (idx, op, M, N, K, pad_a, pad_b, pad_c, acc, bias is not None, err)
+
+
 def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric B catches a transposed C write (cdna guide section 3)."""
     ops, lib = ops_mod(), L()
