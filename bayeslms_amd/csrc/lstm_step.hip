@@ -33,6 +33,7 @@ constexpr int RSTR = 40;                  // reduction row stride
 struct LstmStepP {
   const float *xw, *whh, *hprev, *cprev;
   float *h, *c, *ga;
+  const float* hnoise;  // optional (H): added to h after the cell (VLSTMCell, model.py:2523-2527)
   int B, H;
 };
 
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float cn = gf * cprev + gi * gg;
     const long i = (long)eb * H + ej, o = (long)eb * 4 * H + ej;
     p.c[i] = cn;
-    p.h[i] = go * tanhf(cn);
+    p.h[i] = go * tanhf(cn) + (p.hnoise ? p.hnoise[ej] : 0.f);
     if (p.ga) {
       p.ga[o] = gi;
       p.ga[o + H] = gf;
@@ -310,13 +311,13 @@ using namespace blm;
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int blm_lstm_step_fwd(const float* xw_t, const float* w_hh, const float* h_prev, const float* c_prev, float* h,
-                                 float* c, float* gates_act, int B, int H, void* stream) {
+                                 float* c, float* gates_act, const float* h_noise, int B, int H, void* stream) {
   if (!xw_t || !w_hh || !h_prev || !c_prev || !h || !c || B < 0 || H < 0)
     return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_fwd: bad arguments");
   if ((long)B * H == 0) return BLM_OK;
   if (H % 32 != 0 || !al16(w_hh) || !al16(h_prev))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_fwd: needs H % 32 == 0 and 16-byte aligned h_prev / w_hh");
-  LstmStepP p{xw_t, w_hh, h_prev, c_prev, h, c, gates_act, B, H};
+  LstmStepP p{xw_t, w_hh, h_prev, c_prev, h, c, gates_act, h_noise, B, H};
   const size_t lds = (size_t)4 * WAVE_LDS * sizeof(float);
   static bool once = false;
   if (!once) {

@@ -885,19 +885,15 @@ class VLSTMCell(_LoopCell):
             z = torch.zeros(B, self.hidden_size, dtype=inputs.dtype, device=inputs.device)
             hid = (z, z)
         hx, cx = hid
-        xw_all = ops.linear(inputs, self.weights_ih, self.bias_ih)
         noisy = self.vnn_type == 1 and self.training and self.vnn.sample
         rows = self.vnn.noise_rows(T, self.eps_override) if noisy else None
-        outs = []
-        for t in range(T):
-            hw = ops.linear(hx, self.weights_hh, self.bias_ih)
-            hx, cx = ops.lstm_cell(xw_all[t], hw, cx)
-            if self.vnn_type == 1:
-                self.vnn.hidden_mean = hx
-                if noisy:
-                    hx = ops.add_rowvec(hx, rows[t])
-            outs.append(hx)
-        return torch.stack(outs, 0), (hx, cx)
+        # the whole layer in the fused LSTM path (input GEMM batched over T, one launch per time step in
+        # each direction); the reference's quirk -- bias_ih added twice, bias_hh unused -- is the bias pair
+        # (bias_ih, bias_ih); the per-step noise row is added to h inside the step kernel
+        y, hT, cT = ops.lstm_layer(inputs, hx, cx, self.weights_ih, self.weights_hh, self.bias_ih, self.bias_ih, rows)
+        if self.vnn_type == 1:
+            self.vnn.hidden_mean = hT - rows[T - 1] if noisy else hT  # the last step's h BEFORE its noise
+        return y, (hT, cT)
 
 
 class VariationalLSTM(_Site):

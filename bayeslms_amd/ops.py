@@ -795,9 +795,11 @@ class _LSTMLayer(torch.autograd.Function):
     step.  Weights arrive already sampled (W = mu + noise on the gate rows)."""
 
     @staticmethod
-    def forward(ctx, x, h0, c0, w_ih, w_hh, b_ih, b_hh):
+    def forward(ctx, x, h0, c0, w_ih, w_hh, b_ih, b_hh, noise_rows=None):
         x = _f32(x, "x")
         T, B, E = x.shape
+        if noise_rows is not None:  # (T, H): row t is added to every batch row of h_t (VLSTMCell)
+            noise_rows = _f32(noise_rows, "noise_rows")
         H = w_hh.shape[1]
         G = 4 * H
         dev = x.device
@@ -816,14 +818,18 @@ class _LSTMLayer(torch.autograd.Function):
         # else skinny GEMM + cell kernel
         fused_step = H % 32 == 0 and w_hh.data_ptr() % 16 == 0 and hs.data_ptr() % 16 == 0 and w_hh.is_contiguous()
         for t in range(T):
+            nz = None if noise_rows is None else ptr(noise_rows[t])
             if fused_step:
                 check(lib().blm_lstm_step_fwd(ptr(xw[t]), ptr(w_hh), ptr(hs[t]), ptr(cs[t]), ptr(hs[t + 1]),
-                                              ptr(cs[t + 1]), ptr(ga[t]), B, H, st), "blm_lstm_step_fwd")
+                                              ptr(cs[t + 1]), ptr(ga[t]), nz, B, H, st), "blm_lstm_step_fwd")
                 continue
             gemm(L.GEMM_NT, hs[t], w_hh, hw, B, G, H, H, H, G)
             check(lib().blm_lstm_cell_fwd(ptr(xw[t]), ptr(hw), ptr(cs[t]), ptr(hs[t + 1]), ptr(cs[t + 1]), ptr(ga[t]),
                                           B, H, st), "blm_lstm_cell_fwd")
+            if nz is not None:
+                check(lib().blm_add_rowvec(ptr(hs[t + 1]), nz, B, H, st), "blm_add_rowvec")
         ctx.save_for_backward(x, hs, cs, ga, w_ih, w_hh)
+        ctx.has_noise = noise_rows is not None
         return hs[1:], hs[T], cs[T]
 
     @staticmethod
@@ -841,6 +847,12 @@ class _LSTMLayer(torch.autograd.Function):
         dcs = torch.empty(2, B, H, device=dev, dtype=torch.float32)  # ping-pong dc buffers
         dcs[0].copy_(dc)
         fused_step = (H % 32 == 0 and w_hh.is_contiguous() and w_hh.data_ptr() % 16 == 0 and dgates.data_ptr() % 16 == 0)
+        noise = getattr(ctx, "has_noise", False)
+        # dhr[t] = gradient reaching h_t from step t+1 (dhr[T-1] = dhT); kept for every step only when the
+        # additive noise rows need their gradient (column sums of dhr + dy)
+        dhr = torch.zeros(T, B, H, device=dev, dtype=torch.float32) if (noise or not fused_step) else None
+        if dhr is not None:
+            dhr[T - 1].copy_(dh)
         if fused_step:
             # one launch per step: dh_{t-1} = dgates_t . W_hh on the matrix cores with the cell backward
             # of step t-1 fused behind it (blm_lstm_step_bwd); W_hh is transposed once per layer
@@ -851,8 +863,8 @@ class _LSTMLayer(torch.autograd.Function):
             k = 1
             for t in range(T - 1, 0, -1):
                 check(lib().blm_lstm_step_bwd(ptr(dgates[t]), ptr(w_t), ptr(dy[t - 1]), ptr(dcs[k]), ptr(cs[t - 1]),
-                                              ptr(cs[t]), ptr(ga[t - 1]), ptr(dgates[t - 1]), ptr(dcs[k ^ 1]), None,
-                                              B, H, st), "blm_lstm_step_bwd")
+                                              ptr(cs[t]), ptr(ga[t - 1]), ptr(dgates[t - 1]), ptr(dcs[k ^ 1]),
+                                              ptr(dhr[t - 1]) if noise else None, B, H, st), "blm_lstm_step_bwd")
                 k ^= 1
             dh = torch.empty(B, H, device=dev, dtype=torch.float32)
             check(lib().blm_lstm_step_bwd(ptr(dgates[0]), ptr(w_t), None, None, None, None, None, None, None, ptr(dh),
@@ -861,14 +873,20 @@ class _LSTMLayer(torch.autograd.Function):
         else:
             # recurrent dh of every step accumulates (split-K atomics) into one pre-zeroed buffer: a
             # single memset per layer instead of one in front of every skinny GEMM
-            dh_all = torch.zeros(T, B, H, device=dev, dtype=torch.float32)
+            dh0 = torch.zeros(B, H, device=dev, dtype=torch.float32)
             for t in range(T - 1, -1, -1):
                 k = (T - 1 - t) & 1
-                check(lib().blm_lstm_cell_bwd2(ptr(dh), ptr(dy[t]), ptr(dcs[k]), ptr(cs[t]), ptr(cs[t + 1]), ptr(ga[t]),
+                check(lib().blm_lstm_cell_bwd2(ptr(dhr[t]), ptr(dy[t]), ptr(dcs[k]), ptr(cs[t]), ptr(cs[t + 1]), ptr(ga[t]),
                                                ptr(dgates[t]), ptr(dcs[k ^ 1]), B, H, st), "blm_lstm_cell_bwd2")
-                gemm(L.GEMM_NN, dgates[t], w_hh, dh_all[t], B, H, G, G, H, H, accumulate=True)
-                dh = dh_all[t]
+                gemm(L.GEMM_NN, dgates[t], w_hh, dhr[t - 1] if t > 0 else dh0, B, H, G, G, H, H, accumulate=True)
+            dh = dh0
             dc = dcs[T & 1]
+        d_noise = None
+        if noise:  # noise row t was added to every batch row of h_t: its gradient is the column sum of dh_t
+            d_noise = torch.empty(T, H, device=dev, dtype=torch.float32)
+            tot = dhr + dy
+            for t in range(T):
+                _colsum_into(tot[t], B, H, d_noise[t], accumulate=False)
         dx = torch.empty_like(x)
         gemm(L.GEMM_NN, dgates, w_ih, dx, T * B, E, G, G, E, E)
         dw_ih = torch.empty_like(w_ih)
@@ -877,11 +895,13 @@ class _LSTMLayer(torch.autograd.Function):
         gemm(L.GEMM_TN, dgates, hs, dw_hh, G, H, T * B, G, H, H)  # hs[0:T] = h_{t-1}
         db = torch.empty(G, device=dev, dtype=torch.float32)
         _colsum_into(dgates, T * B, G, db, accumulate=False)
-        return dx, dh, dc, dw_ih, dw_hh, db, db
+        return dx, dh, dc, dw_ih, dw_hh, db, db, d_noise
 
 
-def lstm_layer(x, h0, c0, w_ih, w_hh, b_ih, b_hh):
-    return _LSTMLayer.apply(x, h0, c0, w_ih, w_hh, b_ih, b_hh)
+def lstm_layer(x, h0, c0, w_ih, w_hh, b_ih, b_hh, noise_rows=None):
+    """One LSTM layer over T steps.  ``noise_rows`` (T, H), optional: row t is added to every batch row
+    of h_t after the cell and carried into step t+1 (VLSTMCell, reference model.py:2523-2527)."""
+    return _LSTMLayer.apply(x, h0, c0, w_ih, w_hh, b_ih, b_hh, noise_rows)
 
 
 # ----------------------------------------------------------------------------

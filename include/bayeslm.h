@@ -271,12 +271,14 @@ int blm_clip_sgd_multi(float* const* params, const float* const* grads, float* c
 
 /* One whole LSTM time step in a single launch (recurrent product on the matrix
  * cores + the cell below fused behind it; model.py:812 `_VF.lstm` per step):
- *   gates = xw_t[b,4H] + h_prev[b,H] . w_hh[4H,H]^T ; then the cell update.
+ *   gates = xw_t[b,4H] + h_prev[b,H] . w_hh[4H,H]^T ; then the cell update;
+ *   h_noise (H floats, may be NULL) is added to every row of h afterwards (the Variational
+ *   LSTM's h += eps*exp(hidden_lgstd), model.py:2523-2527).
  * Requires H % 32 == 0 and 16-byte aligned h_prev / w_hh; otherwise returns
  * BLM_ERR_UNSUPPORTED and the caller composes blm_gemm + blm_lstm_cell_fwd.
  * Deterministic (fixed summation order, no atomics). */
 int blm_lstm_step_fwd(const float* xw_t, const float* w_hh, const float* h_prev, const float* c_prev, float* h,
-                      float* c, float* gates_act, int B, int H, void* stream);
+                      float* c, float* gates_act, const float* h_noise, int B, int H, void* stream);
 
 /* Backward of one LSTM time step in a single launch:
  *   dh = dgates_t[b,4H] . w_hh[4H,H]   (w_hh passed TRANSPOSED: w_hh_t (H,4H), see blm_transpose)

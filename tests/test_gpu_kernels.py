@@ -492,7 +492,7 @@ def test_lstm_step_fwd_is_deterministic_and_rejects_bad_shapes(dev):
     outs = []
     for _ in range(2):
         h, c, ga = torch.empty(B, H, device=dev), torch.empty(B, H, device=dev), torch.empty(B, 4 * H, device=dev)
-        assert lib.blm_lstm_step_fwd(ptr(xw), ptr(w), ptr(hp), ptr(cp), ptr(h), ptr(c), ptr(ga), B, H, stream()) == 0
+        assert lib.blm_lstm_step_fwd(ptr(xw), ptr(w), ptr(hp), ptr(cp), ptr(h), ptr(c), ptr(ga), None, B, H, stream()) == 0
         outs.append((h, c, ga))
     torch.cuda.synchronize()
     for a, b in zip(*outs):
@@ -503,7 +503,7 @@ def test_lstm_step_fwd_is_deterministic_and_rejects_bad_shapes(dev):
     hn = torch.sigmoid(o) * torch.tanh(cn)
     assert rel(outs[0][0], hn.float()) < 1e-5 and rel(outs[0][1], cn.float()) < 1e-5
     # H not a multiple of 32: refused, nothing launched
-    assert lib.blm_lstm_step_fwd(ptr(xw), ptr(w), ptr(hp), ptr(cp), ptr(h), ptr(c), ptr(ga), 4, 40, stream()) == ERR_UNSUPPORTED
+    assert lib.blm_lstm_step_fwd(ptr(xw), ptr(w), ptr(hp), ptr(cp), ptr(h), ptr(c), ptr(ga), None, 4, 40, stream()) == ERR_UNSUPPORTED
 
 
 def test_lstm_step_bwd_full_size_matches_composition(dev):

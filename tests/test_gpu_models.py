@@ -460,6 +460,44 @@ def test_variational_rnn_golden(dev, vp):
         assert grad_close(p.grad, grad[k]), k
 
 
+@pytest.mark.parametrize("vp", ["11", "01", "10"])
+def test_variational_rnn_fused_steps_match_oracle(dev, vp):
+    """H = 64 takes the fused one-launch-per-step kernels (noise row added inside the forward step,
+    its gradient from the per-step dh written by the backward step): logits, KL and every gradient
+    against the CPU oracle with the same injected eps, over two windows with the hidden state carried."""
+    from bayeslms_amd import model as M, ops
+    from oracle import bayes_oracle as O
+    torch.manual_seed(3)
+    V, H, T, B = 40, 64, 6, 5
+    m = M.VariationalRNNModel("LSTM", V, H, H, 2, 0.0, True, vp).to(dev)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    x = torch.randint(0, V, (T, B), generator=g)
+    tgt = torch.randint(0, V, (T * B,), generator=g)
+    eps = {c: torch.randn(T, H, generator=g) * 0.1 for c in (0, 1) if vp[c] == "1"}
+    m.train()
+    for c, e in eps.items():
+        m.rnn.rnn[c].eps_override = e.to(dev)
+    hid = m.init_hidden(B)
+    l1, hid = m(x.to(dev), hid)
+    logits = l1.detach().clone()  # ops.cross_entropy consumes the logits buffer (gradient written in place)
+    mle, _ = ops.cross_entropy(l1.view(-1, V), tgt.to(dev))
+    kl = sum(m.rnn.rnn[c].vnn.kl_divergence() for c in (0, 1) if vp[c] == "1")
+    (mle + 0.3 * kl).backward()
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    zeros = (torch.zeros(2, B, H), torch.zeros(2, B, H))
+    lr, _, klr = O.variational_rnn_lm(x, zeros, leaf, vp, eps)
+    (O.cross_entropy_mean(lr.view(-1, V), tgt) + 0.3 * klr).backward()
+    assert rel(logits, lr) < TOL
+    assert abs(float(kl) - float(klr)) < TOL * max(1e-6, abs(float(klr)))
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or leaf[k].grad is None:
+            continue
+        assert p.grad is not None, k
+        assert grad_close(p.grad, leaf[k].grad), k
+
+
 @pytest.mark.parametrize("v_pos", [0, 1, 2, 3])
 def test_vtransformer_golden(dev, v_pos):
     from bayeslms_amd import model as M

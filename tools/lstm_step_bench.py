@@ -16,7 +16,7 @@ def main():
     n = 200
     def run():
         for i in range(n):
-            check(L.blm_lstm_step_fwd(ptr(xw), ptr(w), ptr(hp), ptr(cp), ptr(hs[i & 1]), ptr(c), ptr(ga), B, H, stream()))
+            check(L.blm_lstm_step_fwd(ptr(xw), ptr(w), ptr(hp), ptr(cp), ptr(hs[i & 1]), ptr(c), ptr(ga), None, B, H, stream()))
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); run(); e1.record(); torch.cuda.synchronize()
