@@ -155,6 +155,19 @@ __device__ __forceinline__ float dgelu_erf(float z) {
   gelu_parts(z, cdf, e);
   return cdf + z * 0.3989422804014327f * e;
 }
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// GPNN activation mixture sum_i act_i(z) coef[i][n] in the fixed slot order tanh, sigmoid, relu, gelu
+// (model.py:1885-1899) and its derivative in z; coef is (4, N).
+__device__ __forceinline__ float gp_mix(float z, const float* coef, int N, int n) {
+  return tanhf(z) * coef[n] + sigmoidf_(z) * coef[N + n] + fmaxf(z, 0.f) * coef[2 * N + n] +
+         gelu_erf(z) * coef[3 * N + n];
+}
+__device__ __forceinline__ float dgp_mix(float z, const float* coef, int N, int n) {
+  const float th = tanhf(z), sg = sigmoidf_(z);
+  return (1.f - th * th) * coef[n] + sg * (1.f - sg) * coef[N + n] + (z > 0.f ? coef[2 * N + n] : 0.f) +
+         dgelu_erf(z) * coef[3 * N + n];
+}
 
 }  // namespace blm

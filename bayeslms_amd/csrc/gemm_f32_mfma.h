@@ -150,15 +150,6 @@ __device__ __forceinline__ float4 sample4(float4 mu, float4 lg, const blm_variat
   return mu;
 }
 
-__device__ __forceinline__ float gp_mix(float z, const float* coef, int N, int n) {
-  return tanhf(z) * coef[n] + sigmoidf_(z) * coef[N + n] + fmaxf(z, 0.f) * coef[2 * N + n] +
-         gelu_erf(z) * coef[3 * N + n];
-}
-__device__ __forceinline__ float dgp_mix(float z, const float* coef, int N, int n) {
-  const float th = tanhf(z), sg = sigmoidf_(z);
-  return (1.f - th * th) * coef[n] + sg * (1.f - sg) * coef[N + n] + (z > 0.f ? coef[2 * N + n] : 0.f) +
-         dgelu_erf(z) * coef[3 * N + n];
-}
 
 // ---- LDS operand fragments read by inline asm (explicit double buffering, see compute()) ----
 __device__ __forceinline__ uint32_t lds_u32(const float* p) { return (uint32_t)(uintptr_t)p; }  // LDS byte offset

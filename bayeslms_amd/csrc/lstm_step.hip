@@ -34,6 +34,9 @@ struct LstmStepP {
   const float *xw, *whh, *hprev, *cprev;
   float *h, *c, *ga;
   const float* hnoise;  // optional (H): added to h after the cell (VLSTMCell, model.py:2523-2527)
+  const float* coef;    // GPLSTMCell gate types 1-4 (model.py:1754-1771): gate `ovr` is the GPNN mixture of its
+  float* zsave;         //   pre-activation (coef (4,H), slot order of gp_mix), z kept for the backward pass
+  int ovr;              //   -1: plain LSTM
   int B, H;
 };
 
@@ -141,9 +144,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       s[g] = xg[g] + ((red[(0 * 32 + brow) * RSTR + n] + red[(1 * 32 + brow) * RSTR + n]) +
                       (red[(2 * 32 + brow) * RSTR + n] + red[(3 * 32 + brow) * RSTR + n]));
     }
-    const float gi = sigmoidf_(s[0]), gf = sigmoidf_(s[1]), gg = tanhf(s[2]), go = sigmoidf_(s[3]);
-    const float cn = gf * cprev + gi * gg;
+    float gi = sigmoidf_(s[0]), gf = sigmoidf_(s[1]), gg = tanhf(s[2]), go = sigmoidf_(s[3]);
     const long i = (long)eb * H + ej, o = (long)eb * 4 * H + ej;
+    if (p.ovr >= 0) {  // wave-uniform
+      const float z = p.ovr == 0 ? s[0] : (p.ovr == 1 ? s[1] : (p.ovr == 2 ? s[2] : s[3]));
+      const float a = gp_mix(z, p.coef, H, ej);
+      if (p.ovr == 0) gi = a; else if (p.ovr == 1) gf = a; else if (p.ovr == 2) gg = a; else go = a;
+      if (p.zsave) p.zsave[i] = z;
+    }
+    const float cn = gf * cprev + gi * gg;
     p.c[i] = cn;
     p.h[i] = go * tanhf(cn) + (p.hnoise ? p.hnoise[ej] : 0.f);
     if (p.ga) {
@@ -178,6 +187,9 @@ struct LstmBwdP {
   const float *dg, *wt;                   // dgates_t (B,4H), W_hh^T (H,4H)
   const float *dy, *dc_next, *cprev, *c, *ga;
   float *dg_out, *dc_prev, *dh_out;
+  const float *zprev, *coef;              // GP gate (see LstmStepP): z of step t-1's overridden gate, coef (4,H)
+  float* dact_out;                        //   gradient w.r.t. that gate's mixture value (for the coef gradient)
+  int ovr;
   int B, H;
 };
 
@@ -197,12 +209,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int eb = b0 + brow, ek = k0 + ecol;
   const bool eok = eb < B;
   const long ei = (long)eb * H + ek, eo = (long)eb * G + ek;
-  float e_dy = 0.f, e_dcn = 0.f, e_cp = 0.f, e_c = 0.f, e_g[4] = {0.f, 0.f, 0.f, 0.f};
+  float e_dy = 0.f, e_dcn = 0.f, e_cp = 0.f, e_c = 0.f, e_z = 0.f, e_g[4] = {0.f, 0.f, 0.f, 0.f};
   if (eok && p.dg_out) {
     if (p.dy) e_dy = p.dy[ei];
     if (p.dc_next) e_dcn = p.dc_next[ei];
     e_cp = p.cprev[ei];
     e_c = p.c[ei];
+    if (p.ovr >= 0) e_z = p.zprev[ei];
 #pragma unroll
     for (int g = 0; g < 4; ++g) e_g[g] = p.ga[eo + (long)g * H];
   }
@@ -279,10 +292,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float tc = tanhf(e_c);
     const float dhv = dh + e_dy;
     const float dc = e_dcn + dhv * go * (1.f - tc * tc);
-    p.dg_out[eo] = dc * gg * gi * (1.f - gi);
-    p.dg_out[eo + H] = dc * e_cp * gf * (1.f - gf);
-    p.dg_out[eo + 2L * H] = dc * gi * (1.f - gg * gg);
-    p.dg_out[eo + 3L * H] = dhv * tc * go * (1.f - go);
+    const float dgi = dc * gg, dgf = dc * e_cp, dgg = dc * gi, dgo = dhv * tc;  // w.r.t. the activated gates
+    float o0 = dgi * gi * (1.f - gi), o1 = dgf * gf * (1.f - gf), o2 = dgg * (1.f - gg * gg), o3 = dgo * go * (1.f - go);
+    if (p.ovr >= 0) {  // wave-uniform: that gate's activation was the GPNN mixture of its pre-activation z
+      const float da = p.ovr == 0 ? dgi : (p.ovr == 1 ? dgf : (p.ovr == 2 ? dgg : dgo));
+      const float dz = da * dgp_mix(e_z, p.coef, H, ek);
+      if (p.ovr == 0) o0 = dz; else if (p.ovr == 1) o1 = dz; else if (p.ovr == 2) o2 = dz; else o3 = dz;
+      if (p.dact_out) p.dact_out[ei] = da;
+    }
+    p.dg_out[eo] = o0;
+    p.dg_out[eo + H] = o1;
+    p.dg_out[eo + 2L * H] = o2;
+    p.dg_out[eo + 3L * H] = o3;
     p.dc_prev[ei] = dc * gf;
   }
 }
@@ -308,16 +329,27 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 using namespace blm;
 
+extern "C" int blm_lstm_step_fwd_gp(const float*, const float*, const float*, const float*, float*, float*, float*, const float*, int,
+                                    const float*, float*, int, int, void*);
+extern "C" int blm_lstm_step_bwd_gp(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                                    float*, float*, float*, int, const float*, const float*, float*, int, int, void*);
+
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int blm_lstm_step_fwd(const float* xw_t, const float* w_hh, const float* h_prev, const float* c_prev, float* h,
                                  float* c, float* gates_act, const float* h_noise, int B, int H, void* stream) {
-  if (!xw_t || !w_hh || !h_prev || !c_prev || !h || !c || B < 0 || H < 0)
+  return blm_lstm_step_fwd_gp(xw_t, w_hh, h_prev, c_prev, h, c, gates_act, h_noise, -1, nullptr, nullptr, B, H, stream);
+}
+
+extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const float* h_prev, const float* c_prev, float* h,
+                                    float* c, float* gates_act, const float* h_noise, int gate_ovr, const float* coef4,
+                                    float* z_out, int B, int H, void* stream) {
+  if (!xw_t || !w_hh || !h_prev || !c_prev || !h || !c || B < 0 || H < 0 || gate_ovr > 3 || (gate_ovr >= 0 && !coef4))
     return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_fwd: bad arguments");
   if ((long)B * H == 0) return BLM_OK;
   if (H % 32 != 0 || !al16(w_hh) || !al16(h_prev))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_fwd: needs H % 32 == 0 and 16-byte aligned h_prev / w_hh");
-  LstmStepP p{xw_t, w_hh, h_prev, c_prev, h, c, gates_act, h_noise, B, H};
+  LstmStepP p{xw_t, w_hh, h_prev, c_prev, h, c, gates_act, h_noise, coef4, z_out, gate_ovr < 0 ? -1 : gate_ovr, B, H};
   const size_t lds = (size_t)4 * WAVE_LDS * sizeof(float);
   static bool once = false;
   if (!once) {
@@ -345,13 +377,23 @@ extern "C" int blm_transpose(const float* in, float* out, int rows, int cols, vo
 extern "C" int blm_lstm_step_bwd(const float* dgates_t, const float* w_hh_t, const float* dy_prev, const float* dc_next,
                                  const float* c_prev, const float* c, const float* gates_act, float* dgates_out,
                                  float* dc_prev, float* dh_out, int B, int H, void* stream) {
+  return blm_lstm_step_bwd_gp(dgates_t, w_hh_t, dy_prev, dc_next, c_prev, c, gates_act, dgates_out, dc_prev, dh_out, -1, nullptr,
+                              nullptr, nullptr, B, H, stream);
+}
+
+extern "C" int blm_lstm_step_bwd_gp(const float* dgates_t, const float* w_hh_t, const float* dy_prev, const float* dc_next,
+                                    const float* c_prev, const float* c, const float* gates_act, float* dgates_out,
+                                    float* dc_prev, float* dh_out, int gate_ovr, const float* coef4, const float* z_prev,
+                                    float* dact_out, int B, int H, void* stream) {
   if (!dgates_t || !w_hh_t || B < 0 || H < 0 || (!dgates_out && !dh_out) ||
-      (dgates_out && (!c_prev || !c || !gates_act || !dc_prev)))
+      (dgates_out && (!c_prev || !c || !gates_act || !dc_prev)) || gate_ovr > 3 ||
+      (dgates_out && gate_ovr >= 0 && (!coef4 || !z_prev)))
     return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_bwd: bad arguments");
   if ((long)B * H == 0) return BLM_OK;
   if (H % 32 != 0 || !al16(dgates_t) || !al16(w_hh_t))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_bwd: needs H % 32 == 0 and 16-byte aligned dgates_t / w_hh_t");
-  LstmBwdP p{dgates_t, w_hh_t, dy_prev, dc_next, c_prev, c, gates_act, dgates_out, dc_prev, dh_out, B, H};
+  LstmBwdP p{dgates_t, w_hh_t, dy_prev, dc_next, c_prev, c, gates_act, dgates_out, dc_prev, dh_out, z_prev, coef4, dact_out,
+             (dgates_out && gate_ovr >= 0) ? gate_ovr : -1, B, H};
   const size_t lds = (size_t)4 * BWAVE_LDS * sizeof(float);
   static bool once = false;
   if (!once) {

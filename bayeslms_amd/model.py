@@ -763,6 +763,19 @@ class GPLSTMCell(_LoopCell):
             hid = (z, z)
         hx, cx = hid
         gt = self.gate_type
+        if 1 <= gt <= 4 and ops.lstm_recurrent_gp_supported(self.hidden_size, self.weights_hh):
+            # GPNN on one gate: the whole layer on the fused step kernels.  The GPNN's affine map over
+            # [inp|h] splits into an input part (batched over T with the other gates' input GEMM) and a
+            # hidden part that takes that gate's row block of the recurrent weight; the mixture is the
+            # gate's activation inside the step kernel.  bias_ih enters twice, as in the reference.
+            g, E, H = gt - 1, self.input_size, self.hidden_size
+            Wg = self.gpnn.weights_mean
+            xw_std = ops.linear(inputs, self.weights_ih, 2.0 * self.bias_ih)
+            xw_gp = ops.linear(inputs, Wg[:, :E], self.gpnn.bias_mean)
+            xw = torch.cat([xw_std[..., :g * H], xw_gp, xw_std[..., (g + 1) * H:]], -1)
+            w_rec = torch.cat([self.weights_hh[:g * H], Wg[:, E:], self.weights_hh[(g + 1) * H:]], 0)
+            y, hT, cT = ops.lstm_recurrent_gp(xw, hx, cx, w_rec, self.gpnn.coef4(), g)
+            return y, (hT, cT)
         # input-side projection of all steps in one GEMM (the reference does it per step)
         xw_all = self.gpnn(inputs) if gt == 7 else ops.linear(inputs, self.weights_ih, self.bias_ih)
         outs = []

@@ -289,6 +289,20 @@ int blm_lstm_step_fwd(const float* xw_t, const float* w_hh, const float* h_prev,
 int blm_lstm_step_bwd(const float* dgates_t, const float* w_hh_t, const float* dy_prev, const float* dc_next,
                       const float* c_prev, const float* c, const float* gates_act, float* dgates_out, float* dc_prev,
                       float* dh_out, int B, int H, void* stream);
+/* The same two step kernels for the GP-LSTM cell with a GPNN on one gate (GPLSTMCell gate types 1-4,
+ * model.py:1754-1771): gate `gate_ovr` (0 i, 1 f, 2 g, 3 o; -1 = plain LSTM) takes the activation
+ * mixture sum_i act_i(z) coef4[i] of its pre-activation z instead of its sigmoid/tanh.  The caller
+ * places the GPNN's weight rows into that gate's row block of w_hh / xw_t.  coef4 is (4,H) in the slot
+ * order tanh, sigmoid, relu, gelu.  Forward keeps z (z_out, (B,H)) for the backward pass; backward
+ * multiplies that gate's gradient by the mixture's derivative at z_prev and returns the gradient
+ * w.r.t. the mixture value in dact_out (B,H) (for blm_gp_coef_grad). */
+int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const float* h_prev, const float* c_prev, float* h,
+                         float* c, float* gates_act, const float* h_noise, int gate_ovr, const float* coef4,
+                         float* z_out, int B, int H, void* stream);
+int blm_lstm_step_bwd_gp(const float* dgates_t, const float* w_hh_t, const float* dy_prev, const float* dc_next,
+                         const float* c_prev, const float* c, const float* gates_act, float* dgates_out, float* dc_prev,
+                         float* dh_out, int gate_ovr, const float* coef4, const float* z_prev, float* dact_out, int B,
+                         int H, void* stream);
 /* out (cols,rows) = in (rows,cols)^T */
 int blm_transpose(const float* in, float* out, int rows, int cols, void* stream);
 

@@ -426,6 +426,56 @@ def test_gauss_rnn_golden(dev, gp):
         assert grad_close(p.grad, grad[k]), k
 
 
+@pytest.mark.parametrize("gp", ["33", "13", "23", "43", "330", "3343", "31"])
+def test_gauss_rnn_fused_steps_match_oracle(dev, gp):
+    """H = 64: GP cells with a GPNN on one gate (types 1-4) take the fused step kernels (GPNN rows inside
+    the recurrent weight, mixture as the gate activation, its derivative and the coefficient gradient
+    in the backward step).  Two windows with the carried hidden state; logits, KL, every gradient
+    against the CPU oracle (which the golden tests pin to the reference)."""
+    from bayeslms_amd import model as M, ops
+    from oracle import bayes_oracle as O
+    torch.manual_seed(11)
+    V, H, T, B = 30, 64, 5, 4
+    m = M.GaussRNNModel("LSTM", V, H, H, 2, 0.0, True, gp).to(dev)
+    with torch.no_grad():  # livelier than the init: larger recurrent weights and mixed-sign coefficients
+        for k, p in m.named_parameters():
+            if "coef_mean" in k:
+                p.uniform_(-1.0, 1.0)
+            elif "weights" in k or "weight_hh" in k:
+                p.mul_(3.0)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    x1, x2 = torch.randint(0, V, (T, B), generator=g), torch.randint(0, V, (T, B), generator=g)
+    tgt = torch.randint(0, V, (T * B,), generator=g)
+    m.train()
+    hid = m.init_hidden(B)
+    l1, hid = m(x1.to(dev), hid)
+    keep1 = l1.detach().clone()
+    l2, hid = m(x2.to(dev), M.repackage_hidden(hid))
+    keep2 = l2.detach().clone()
+    mle, _ = ops.cross_entropy(l2.view(-1, V), tgt.to(dev))
+    cells = [0] if len(gp) < 3 else ([1] if len(gp) == 3 else [0, 1])
+    kl = sum(m.rnn.rnn[c].gpnn.kl_divergence() for c in cells) if (int(gp[0]) > 0 and 0 < int(gp[1]) <= 3) else None
+    (mle + (0.2 * kl if kl is not None else 0.0)).backward()
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    zeros = (torch.zeros(2, B, H), torch.zeros(2, B, H))
+    r1, hr = O.gauss_rnn_lm(x1, zeros, leaf, gp)
+    r2, hr = O.gauss_rnn_lm(x2, tuple(h.detach() for h in hr), leaf, gp)
+    assert rel(keep1, r1) < TOL and rel(keep2, r2) < TOL
+    loss = O.cross_entropy_mean(r2.view(-1, V), tgt)
+    if kl is not None:
+        klr = O.kl_gauss_rnn(leaf, gp)
+        assert abs(float(kl) - float(klr)) < TOL * abs(float(klr)) + 1e-7
+        loss = loss + 0.2 * klr
+    loss.backward()
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or leaf[k].grad is None:
+            continue
+        assert p.grad is not None, k
+        assert grad_close(p.grad, leaf[k].grad), k
+
+
 @pytest.mark.parametrize("vp", ["00", "01", "10", "11"])
 def test_variational_rnn_golden(dev, vp):
     from bayeslms_amd import model as M, ops
