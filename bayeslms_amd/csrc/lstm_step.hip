@@ -36,7 +36,8 @@ struct LstmStepP {
   const float* hnoise;  // optional (H): added to h after the cell (VLSTMCell, model.py:2523-2527)
   const float* coef;    // GPLSTMCell gate types 1-4 (model.py:1754-1771): gate `ovr` is the GPNN mixture of its
   float* zsave;         //   pre-activation (coef (4,H), slot order of gp_mix), z kept for the backward pass
-  int ovr;              //   -1: plain LSTM
+  int ovr;              //   -1: plain LSTM; 4: gate type 6 -- the whole hidden projection h W^T + rbias passes through
+  const float* rbias;   //   the mixture (coef (4,4H), z (B,4H)) before it is added to xw (model.py:1744-1752)
   int B, H;
 };
 
@@ -138,15 +139,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __syncthreads();
   if (eok) {
     float s[4];
+    const long o4 = (long)eb * 4 * H + ej;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int n = g * 8 + eu;
-      s[g] = xg[g] + ((red[(0 * 32 + brow) * RSTR + n] + red[(1 * 32 + brow) * RSTR + n]) +
-                      (red[(2 * 32 + brow) * RSTR + n] + red[(3 * 32 + brow) * RSTR + n]));
+      float hw = (red[(0 * 32 + brow) * RSTR + n] + red[(1 * 32 + brow) * RSTR + n]) +
+                 (red[(2 * 32 + brow) * RSTR + n] + red[(3 * 32 + brow) * RSTR + n]);
+      if (p.ovr == 4) {  // wave-uniform
+        const float z = hw + p.rbias[g * H + ej];
+        if (p.zsave) p.zsave[o4 + (long)g * H] = z;
+        hw = gp_mix(z, p.coef, 4 * H, g * H + ej);
+      }
+      s[g] = xg[g] + hw;
     }
     float gi = sigmoidf_(s[0]), gf = sigmoidf_(s[1]), gg = tanhf(s[2]), go = sigmoidf_(s[3]);
     const long i = (long)eb * H + ej, o = (long)eb * 4 * H + ej;
-    if (p.ovr >= 0) {  // wave-uniform
+    if (p.ovr >= 0 && p.ovr < 4) {  // wave-uniform
       const float z = p.ovr == 0 ? s[0] : (p.ovr == 1 ? s[1] : (p.ovr == 2 ? s[2] : s[3]));
       const float a = gp_mix(z, p.coef, H, ej);
       if (p.ovr == 0) gi = a; else if (p.ovr == 1) gf = a; else if (p.ovr == 2) gg = a; else go = a;
@@ -189,6 +197,7 @@ struct LstmBwdP {
   float *dg_out, *dc_prev, *dh_out;
   const float *zprev, *coef;              // GP gate (see LstmStepP): z of step t-1's overridden gate, coef (4,H)
   float* dact_out;                        //   gradient w.r.t. that gate's mixture value (for the coef gradient)
+  float* dz_out;                          // mode 4: dgates_out * mixture'(z) (B,4H) = the next launch's A operand
   int ovr;
   int B, H;
 };
@@ -209,13 +218,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int eb = b0 + brow, ek = k0 + ecol;
   const bool eok = eb < B;
   const long ei = (long)eb * H + ek, eo = (long)eb * G + ek;
-  float e_dy = 0.f, e_dcn = 0.f, e_cp = 0.f, e_c = 0.f, e_z = 0.f, e_g[4] = {0.f, 0.f, 0.f, 0.f};
+  float e_dy = 0.f, e_dcn = 0.f, e_cp = 0.f, e_c = 0.f, e_z = 0.f, e_g[4] = {0.f, 0.f, 0.f, 0.f}, e_z4[4] = {0.f, 0.f, 0.f, 0.f};
   if (eok && p.dg_out) {
     if (p.dy) e_dy = p.dy[ei];
     if (p.dc_next) e_dcn = p.dc_next[ei];
     e_cp = p.cprev[ei];
     e_c = p.c[ei];
-    if (p.ovr >= 0) e_z = p.zprev[ei];
+    if (p.ovr >= 0 && p.ovr < 4) e_z = p.zprev[ei];
+    if (p.ovr == 4) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) e_z4[g] = p.zprev[eo + (long)g * H];
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) e_g[g] = p.ga[eo + (long)g * H];
   }
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float dc = e_dcn + dhv * go * (1.f - tc * tc);
     const float dgi = dc * gg, dgf = dc * e_cp, dgg = dc * gi, dgo = dhv * tc;  // w.r.t. the activated gates
     float o0 = dgi * gi * (1.f - gi), o1 = dgf * gf * (1.f - gf), o2 = dgg * (1.f - gg * gg), o3 = dgo * go * (1.f - go);
-    if (p.ovr >= 0) {  // wave-uniform: that gate's activation was the GPNN mixture of its pre-activation z
+    if (p.ovr >= 0 && p.ovr < 4) {  // wave-uniform: that gate's activation was the GPNN mixture of its pre-activation z
       const float da = p.ovr == 0 ? dgi : (p.ovr == 1 ? dgf : (p.ovr == 2 ? dgg : dgo));
       const float dz = da * dgp_mix(e_z, p.coef, H, ek);
       if (p.ovr == 0) o0 = dz; else if (p.ovr == 1) o1 = dz; else if (p.ovr == 2) o2 = dz; else o3 = dz;
@@ -304,6 +317,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     p.dg_out[eo + H] = o1;
     p.dg_out[eo + 2L * H] = o2;
     p.dg_out[eo + 3L * H] = o3;
+    if (p.ovr == 4) {  // the hidden projection went through the mixture: what the next product needs is d z
+      p.dz_out[eo] = o0 * dgp_mix(e_z4[0], p.coef, 4 * H, ek);
+      p.dz_out[eo + H] = o1 * dgp_mix(e_z4[1], p.coef, 4 * H, H + ek);
+      p.dz_out[eo + 2L * H] = o2 * dgp_mix(e_z4[2], p.coef, 4 * H, 2 * H + ek);
+      p.dz_out[eo + 3L * H] = o3 * dgp_mix(e_z4[3], p.coef, 4 * H, 3 * H + ek);
+    }
     p.dc_prev[ei] = dc * gf;
   }
 }
@@ -330,26 +349,27 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 using namespace blm;
 
 extern "C" int blm_lstm_step_fwd_gp(const float*, const float*, const float*, const float*, float*, float*, float*, const float*, int,
-                                    const float*, float*, int, int, void*);
+                                    const float*, const float*, float*, int, int, void*);
 extern "C" int blm_lstm_step_bwd_gp(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
-                                    float*, float*, float*, int, const float*, const float*, float*, int, int, void*);
+                                    float*, float*, float*, int, const float*, const float*, float*, float*, int, int, void*);
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int blm_lstm_step_fwd(const float* xw_t, const float* w_hh, const float* h_prev, const float* c_prev, float* h,
                                  float* c, float* gates_act, const float* h_noise, int B, int H, void* stream) {
-  return blm_lstm_step_fwd_gp(xw_t, w_hh, h_prev, c_prev, h, c, gates_act, h_noise, -1, nullptr, nullptr, B, H, stream);
+  return blm_lstm_step_fwd_gp(xw_t, w_hh, h_prev, c_prev, h, c, gates_act, h_noise, -1, nullptr, nullptr, nullptr, B, H, stream);
 }
 
 extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const float* h_prev, const float* c_prev, float* h,
                                     float* c, float* gates_act, const float* h_noise, int gate_ovr, const float* coef4,
-                                    float* z_out, int B, int H, void* stream) {
-  if (!xw_t || !w_hh || !h_prev || !c_prev || !h || !c || B < 0 || H < 0 || gate_ovr > 3 || (gate_ovr >= 0 && !coef4))
+                                    const float* rbias, float* z_out, int B, int H, void* stream) {
+  if (!xw_t || !w_hh || !h_prev || !c_prev || !h || !c || B < 0 || H < 0 || gate_ovr > 4 || (gate_ovr >= 0 && !coef4) ||
+      (gate_ovr == 4 && !rbias))
     return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_fwd: bad arguments");
   if ((long)B * H == 0) return BLM_OK;
   if (H % 32 != 0 || !al16(w_hh) || !al16(h_prev))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_fwd: needs H % 32 == 0 and 16-byte aligned h_prev / w_hh");
-  LstmStepP p{xw_t, w_hh, h_prev, c_prev, h, c, gates_act, h_noise, coef4, z_out, gate_ovr < 0 ? -1 : gate_ovr, B, H};
+  LstmStepP p{xw_t, w_hh, h_prev, c_prev, h, c, gates_act, h_noise, coef4, z_out, gate_ovr < 0 ? -1 : gate_ovr, rbias, B, H};
   const size_t lds = (size_t)4 * WAVE_LDS * sizeof(float);
   static bool once = false;
   if (!once) {
@@ -378,22 +398,22 @@ extern "C" int blm_lstm_step_bwd(const float* dgates_t, const float* w_hh_t, con
                                  const float* c_prev, const float* c, const float* gates_act, float* dgates_out,
                                  float* dc_prev, float* dh_out, int B, int H, void* stream) {
   return blm_lstm_step_bwd_gp(dgates_t, w_hh_t, dy_prev, dc_next, c_prev, c, gates_act, dgates_out, dc_prev, dh_out, -1, nullptr,
-                              nullptr, nullptr, B, H, stream);
+                              nullptr, nullptr, nullptr, B, H, stream);
 }
 
 extern "C" int blm_lstm_step_bwd_gp(const float* dgates_t, const float* w_hh_t, const float* dy_prev, const float* dc_next,
                                     const float* c_prev, const float* c, const float* gates_act, float* dgates_out,
                                     float* dc_prev, float* dh_out, int gate_ovr, const float* coef4, const float* z_prev,
-                                    float* dact_out, int B, int H, void* stream) {
+                                    float* dact_out, float* dz_out, int B, int H, void* stream) {
   if (!dgates_t || !w_hh_t || B < 0 || H < 0 || (!dgates_out && !dh_out) ||
-      (dgates_out && (!c_prev || !c || !gates_act || !dc_prev)) || gate_ovr > 3 ||
-      (dgates_out && gate_ovr >= 0 && (!coef4 || !z_prev)))
+      (dgates_out && (!c_prev || !c || !gates_act || !dc_prev)) || gate_ovr > 4 ||
+      (dgates_out && gate_ovr >= 0 && (!coef4 || !z_prev)) || (dgates_out && gate_ovr == 4 && !dz_out))
     return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_bwd: bad arguments");
   if ((long)B * H == 0) return BLM_OK;
   if (H % 32 != 0 || !al16(dgates_t) || !al16(w_hh_t))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_bwd: needs H % 32 == 0 and 16-byte aligned dgates_t / w_hh_t");
   LstmBwdP p{dgates_t, w_hh_t, dy_prev, dc_next, c_prev, c, gates_act, dgates_out, dc_prev, dh_out, z_prev, coef4, dact_out,
-             (dgates_out && gate_ovr >= 0) ? gate_ovr : -1, B, H};
+             dz_out, (dgates_out && gate_ovr >= 0) ? gate_ovr : -1, B, H};
   const size_t lds = (size_t)4 * BWAVE_LDS * sizeof(float);
   static bool once = false;
   if (!once) {

@@ -776,6 +776,14 @@ class GPLSTMCell(_LoopCell):
             w_rec = torch.cat([self.weights_hh[:g * H], Wg[:, E:], self.weights_hh[(g + 1) * H:]], 0)
             y, hT, cT = ops.lstm_recurrent_gp(xw, hx, cx, w_rec, self.gpnn.coef4(), g)
             return y, (hT, cT)
+        if gt in (6, 7) and ops.lstm_recurrent_gp_supported(self.hidden_size, self.weights_hh):
+            if gt == 6:  # the hidden projection of all four gates is the GPNN of h (no bias_ih on that side)
+                xw = ops.linear(inputs, self.weights_ih, self.bias_ih)
+                y, hT, cT = ops.lstm_recurrent_gp(xw, hx, cx, self.gpnn.weights_mean, self.gpnn.coef4(), 4, self.gpnn.bias_mean)
+            else:        # the input projection is the GPNN of the inputs; the hidden side carries bias_ih
+                xw = self.gpnn(inputs) + self.bias_ih
+                y, hT, cT = ops.lstm_recurrent_gp(xw, hx, cx, self.weights_hh)
+            return y, (hT, cT)
         # input-side projection of all steps in one GEMM (the reference does it per step)
         xw_all = self.gpnn(inputs) if gt == 7 else ops.linear(inputs, self.weights_ih, self.bias_ih)
         outs = []

@@ -905,14 +905,20 @@ def lstm_layer(x, h0, c0, w_ih, w_hh, b_ih, b_hh, noise_rows=None):
 
 
 class _LSTMRecurrentGP(torch.autograd.Function):
-    """Recurrent part of a GP-LSTM layer with a GPNN on one gate (GPLSTMCell gate types 1-4, reference
-    model.py:1754-1771) on the fused step kernels: ``xw`` (T,B,4H) holds the input-side pre-activations
-    of all steps (biases inside; block ``ovr`` = the GPNN's input part), ``w_rec`` (4H,H) the recurrent
-    rows (block ``ovr`` = the GPNN's hidden part), ``coef4`` (4,H) the mixture coefficients."""
+    """Recurrent part of a GP-LSTM layer on the fused step kernels.  ``xw`` (T,B,4H) holds the input-side
+    pre-activations of all steps (biases inside), ``w_rec`` (4H,H) the recurrent rows.  ``ovr``:
+      0..3  GPNN on that gate (GPLSTMCell gate types 1-4, reference model.py:1754-1771): block ``ovr`` of
+            xw / w_rec is the GPNN's input / hidden part, ``coef4`` (4,H) its mixture coefficients;
+      4     gate type 6 (model.py:1744-1752): the whole hidden projection h w_rec^T + rbias goes through
+            the mixture (``coef4`` (4,4H)) before it is added to xw;
+      -1    plain recurrence on a given xw (gate type 7: xw is the GPNN of the inputs)."""
 
     @staticmethod
-    def forward(ctx, xw, h0, c0, w_rec, coef4, ovr):
-        xw, w_rec, coef4 = _f32(xw, "xw"), _f32(w_rec, "w_rec"), _f32(coef4, "coef4")
+    def forward(ctx, xw, h0, c0, w_rec, coef4, ovr, rbias):
+        xw, w_rec = _f32(xw, "xw"), _f32(w_rec, "w_rec")
+        ovr = int(ovr)
+        coef4 = _f32(coef4, "coef4") if ovr >= 0 else None
+        rbias = _f32(rbias, "rbias") if ovr == 4 else None
         T, B, G = xw.shape
         H = G // 4
         dev = xw.device
@@ -922,62 +928,83 @@ class _LSTMRecurrentGP(torch.autograd.Function):
         hs[0].copy_(h0)
         cs[0].copy_(c0)
         ga = torch.empty(T, B, G, device=dev, dtype=torch.float32)
-        zs = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+        zs = torch.empty(T, B, G if ovr == 4 else H, device=dev, dtype=torch.float32) if ovr >= 0 else None
         st = stream()
         for t in range(T):
             check(lib().blm_lstm_step_fwd_gp(ptr(xw[t]), ptr(w_rec), ptr(hs[t]), ptr(cs[t]), ptr(hs[t + 1]), ptr(cs[t + 1]),
-                                             ptr(ga[t]), None, int(ovr), ptr(coef4), ptr(zs[t]), B, H, st),
-                  "blm_lstm_step_fwd_gp")
-        ctx.save_for_backward(hs, cs, ga, zs, w_rec, coef4)
-        ctx.ovr = int(ovr)
+                                             ptr(ga[t]), None, ovr, ptr(coef4), ptr(rbias), None if zs is None else ptr(zs[t]),
+                                             B, H, st), "blm_lstm_step_fwd_gp")
+        ctx.save_for_backward(hs, cs, ga, w_rec, *([zs, coef4] if ovr >= 0 else []))
+        ctx.ovr = ovr
         return hs[1:], hs[T], cs[T]
 
     @staticmethod
     def backward(ctx, dy, dhT, dcT):
-        hs, cs, ga, zs, w_rec, coef4 = ctx.saved_tensors
         ovr = ctx.ovr
+        if ovr >= 0:
+            hs, cs, ga, w_rec, zs, coef4 = ctx.saved_tensors
+        else:
+            hs, cs, ga, w_rec = ctx.saved_tensors
+            zs = coef4 = None
         T, B, G = ga.shape
         H = G // 4
         dev = ga.device
         dy = _f32(dy, "dy")
         st = stream()
         dgates = torch.empty(T, B, G, device=dev, dtype=torch.float32)
-        dact = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+        dact = torch.empty(T, B, H, device=dev, dtype=torch.float32) if 0 <= ovr < 4 else None
+        dzs = torch.empty(T, B, G, device=dev, dtype=torch.float32) if ovr == 4 else None  # A operands of the dh products
         dh = torch.zeros(B, H, device=dev, dtype=torch.float32) if dhT is None else _f32(dhT, "dhT").clone()
-        check(lib().blm_axpy(ptr(dy[T - 1]), ptr(dh), B * H, 1.0, st), "blm_axpy")
         dcs = torch.zeros(2, B, H, device=dev, dtype=torch.float32)
         if dcT is not None:
             dcs[0].copy_(dcT)
         w_t = torch.empty(H, G, device=dev, dtype=torch.float32)
         check(lib().blm_transpose(ptr(w_rec), ptr(w_t), G, H, st), "blm_transpose")
-        # last step: cell backward with the gate treated as an external activation, then the mixture's derivative
-        check(lib().blm_lstm_cell_ovr_bwd(ptr(dh), ptr(dcs[0]), ptr(cs[T - 1]), ptr(cs[T]), ptr(ga[T - 1]), ovr,
-                                          ptr(dgates[T - 1]), ptr(dact[T - 1]), ptr(dcs[1]), B, H, st), "blm_lstm_cell_ovr_bwd")
-        dz = torch.empty(B, H, device=dev, dtype=torch.float32)
-        check(lib().blm_gp_mix_bwd(ptr(dact[T - 1]), ptr(zs[T - 1]), ptr(coef4), ptr(dz), B, H, st), "blm_gp_mix_bwd")
-        dgates[T - 1][:, ovr * H:(ovr + 1) * H].copy_(dz)
+        # last step: plain cell backward (the GP gate as an external activation), then the mixture's derivative
+        if 0 <= ovr < 4:
+            check(lib().blm_axpy(ptr(dy[T - 1]), ptr(dh), B * H, 1.0, st), "blm_axpy")
+            check(lib().blm_lstm_cell_ovr_bwd(ptr(dh), ptr(dcs[0]), ptr(cs[T - 1]), ptr(cs[T]), ptr(ga[T - 1]), ovr,
+                                              ptr(dgates[T - 1]), ptr(dact[T - 1]), ptr(dcs[1]), B, H, st), "blm_lstm_cell_ovr_bwd")
+            dz = torch.empty(B, H, device=dev, dtype=torch.float32)
+            check(lib().blm_gp_mix_bwd(ptr(dact[T - 1]), ptr(zs[T - 1]), ptr(coef4), ptr(dz), B, H, st), "blm_gp_mix_bwd")
+            dgates[T - 1][:, ovr * H:(ovr + 1) * H].copy_(dz)
+        else:
+            check(lib().blm_lstm_cell_bwd2(ptr(dh), ptr(dy[T - 1]), ptr(dcs[0]), ptr(cs[T - 1]), ptr(cs[T]), ptr(ga[T - 1]),
+                                           ptr(dgates[T - 1]), ptr(dcs[1]), B, H, st), "blm_lstm_cell_bwd2")
+            if ovr == 4:
+                check(lib().blm_gp_mix_bwd(ptr(dgates[T - 1]), ptr(zs[T - 1]), ptr(coef4), ptr(dzs[T - 1]), B, G, st),
+                      "blm_gp_mix_bwd")
+        A = dzs if ovr == 4 else dgates
         k = 1
         for t in range(T - 1, 0, -1):
-            check(lib().blm_lstm_step_bwd_gp(ptr(dgates[t]), ptr(w_t), ptr(dy[t - 1]), ptr(dcs[k]), ptr(cs[t - 1]), ptr(cs[t]),
+            check(lib().blm_lstm_step_bwd_gp(ptr(A[t]), ptr(w_t), ptr(dy[t - 1]), ptr(dcs[k]), ptr(cs[t - 1]), ptr(cs[t]),
                                              ptr(ga[t - 1]), ptr(dgates[t - 1]), ptr(dcs[k ^ 1]), None, ovr, ptr(coef4),
-                                             ptr(zs[t - 1]), ptr(dact[t - 1]), B, H, st), "blm_lstm_step_bwd_gp")
+                                             None if zs is None else ptr(zs[t - 1]), None if dact is None else ptr(dact[t - 1]),
+                                             None if dzs is None else ptr(dzs[t - 1]), B, H, st), "blm_lstm_step_bwd_gp")
             k ^= 1
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32)
-        check(lib().blm_lstm_step_bwd(ptr(dgates[0]), ptr(w_t), None, None, None, None, None, None, None, ptr(dh0), B, H, st),
+        check(lib().blm_lstm_step_bwd(ptr(A[0]), ptr(w_t), None, None, None, None, None, None, None, ptr(dh0), B, H, st),
               "blm_lstm_step_bwd")
         dw = torch.empty_like(w_rec)
-        gemm(L.GEMM_TN, dgates, hs, dw, G, H, T * B, G, H, H)  # hs[0:T] = h_{t-1}
-        dcoef = torch.zeros_like(coef4)
-        check(lib().blm_gp_coef_grad(ptr(dact), ptr(zs), ptr(dcoef), T * B, H, st), "blm_gp_coef_grad")
-        return dgates, dh0, dcs[k], dw, dcoef, None
+        gemm(L.GEMM_TN, A, hs, dw, G, H, T * B, G, H, H)  # hs[0:T] = h_{t-1}
+        dcoef = drb = None
+        if 0 <= ovr < 4:
+            dcoef = torch.zeros_like(coef4)
+            check(lib().blm_gp_coef_grad(ptr(dact), ptr(zs), ptr(dcoef), T * B, H, st), "blm_gp_coef_grad")
+        elif ovr == 4:
+            dcoef = torch.zeros_like(coef4)
+            check(lib().blm_gp_coef_grad(ptr(dgates), ptr(zs), ptr(dcoef), T * B, G, st), "blm_gp_coef_grad")
+            drb = torch.empty(G, device=dev, dtype=torch.float32)
+            _colsum_into(dzs, T * B, G, drb, accumulate=False)
+        return dgates, dh0, dcs[k], dw, dcoef, None, drb
 
 
 def lstm_recurrent_gp_supported(H, w_rec):
     return H % 32 == 0
 
 
-def lstm_recurrent_gp(xw, h0, c0, w_rec, coef4, ovr):
-    return _LSTMRecurrentGP.apply(xw, h0, c0, w_rec, coef4, ovr)
+def lstm_recurrent_gp(xw, h0, c0, w_rec, coef4=None, ovr=-1, rbias=None):
+    return _LSTMRecurrentGP.apply(xw, h0, c0, w_rec, coef4, ovr, rbias)
 
 
 # ----------------------------------------------------------------------------

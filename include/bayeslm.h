@@ -295,14 +295,18 @@ int blm_lstm_step_bwd(const float* dgates_t, const float* w_hh_t, const float* d
  * places the GPNN's weight rows into that gate's row block of w_hh / xw_t.  coef4 is (4,H) in the slot
  * order tanh, sigmoid, relu, gelu.  Forward keeps z (z_out, (B,H)) for the backward pass; backward
  * multiplies that gate's gradient by the mixture's derivative at z_prev and returns the gradient
- * w.r.t. the mixture value in dact_out (B,H) (for blm_gp_coef_grad). */
+ * w.r.t. the mixture value in dact_out (B,H) (for blm_gp_coef_grad).
+ * gate_ovr = 4 is GPLSTMCell gate type 6 (model.py:1744-1752): the whole hidden projection
+ * h_prev . w_hh^T + rbias (4H) passes through the mixture (coef4 (4,4H), z (B,4H)) before it is added
+ * to xw_t; backward then also writes dz_out = dgates_out * mixture'(z_prev) (B,4H), which is the
+ * dgates_t operand of the next (earlier) step's launch. */
 int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const float* h_prev, const float* c_prev, float* h,
                          float* c, float* gates_act, const float* h_noise, int gate_ovr, const float* coef4,
-                         float* z_out, int B, int H, void* stream);
+                         const float* rbias, float* z_out, int B, int H, void* stream);
 int blm_lstm_step_bwd_gp(const float* dgates_t, const float* w_hh_t, const float* dy_prev, const float* dc_next,
                          const float* c_prev, const float* c, const float* gates_act, float* dgates_out, float* dc_prev,
-                         float* dh_out, int gate_ovr, const float* coef4, const float* z_prev, float* dact_out, int B,
-                         int H, void* stream);
+                         float* dh_out, int gate_ovr, const float* coef4, const float* z_prev, float* dact_out,
+                         float* dz_out, int B, int H, void* stream);
 /* out (cols,rows) = in (rows,cols)^T */
 int blm_transpose(const float* in, float* out, int rows, int cols, void* stream);
 

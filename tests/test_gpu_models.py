@@ -426,7 +426,7 @@ def test_gauss_rnn_golden(dev, gp):
         assert grad_close(p.grad, grad[k]), k
 
 
-@pytest.mark.parametrize("gp", ["33", "13", "23", "43", "330", "3343", "31"])
+@pytest.mark.parametrize("gp", ["33", "13", "23", "43", "330", "3343", "31", "63", "6360", "73", "730", "6373"])
 def test_gauss_rnn_fused_steps_match_oracle(dev, gp):
     """H = 64: GP cells with a GPNN on one gate (types 1-4) take the fused step kernels (GPNN rows inside
     the recurrent weight, mixture as the gate activation, its derivative and the coefficient gradient

@@ -59,6 +59,8 @@ def main():
            ns(model="LSTM", uncertainty="Bayesian", L_bayes_pos=3)),
           ("LSTM Gaussian L_gauss_pos 33", lambda: M.GaussRNNModel("LSTM", V, 1024, 1024, 2, 0.2, True, "33"),
            ns(model="LSTM", uncertainty="Gaussian", L_gauss_pos="33")),
+          ("LSTM Gaussian L_gauss_pos 6360 (README example)", lambda: M.GaussRNNModel("LSTM", V, 1024, 1024, 2, 0.2, True, "6360"),
+           ns(model="LSTM", uncertainty="Gaussian", L_gauss_pos="6360")),
           ("LSTM Variational L_v_pos 11", lambda: M.VariationalRNNModel("LSTM", V, 1024, 1024, 2, 0.2, True, "11"),
            ns(model="LSTM", uncertainty="Variational", L_v_pos="11"))]
     for name, build, a in rn:
