@@ -149,11 +149,14 @@ def _batch_nll(model, data, target_flat, model_type, hidden, model_2, hidden_2, 
     return nll.view(data.shape[0], data.shape[1])
 
 
-def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None, alpha=0.0, mc_samples=0, seed=1111):
+def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None, alpha=0.0, mc_samples=0, seed=1111,
+                           batch_tokens=8192):
     """the N hypotheses of an utterance are padded into ONE (T_max, N) batch instead
     of N separate launches.  Exact for causal Transformers (padding sits after every real token) and
     for LSTMs (all hypotheses start from the same carried state, the carry itself is taken from a
-    B = 1 pass over the first hypothesis exactly as the reference does, :271-274).
+    B = 1 pass over the first hypothesis exactly as the reference does, :271-274).  Transformers carry
+    no state between utterances, so consecutive utterances are packed into one batch up to
+    ``batch_tokens`` padded tokens (20-best lists alone are launch bound).
 
     mc_samples = S > 0 (new, default off; not in the reference, which scores with mean weights):
     S passes with the variational weights sampled (dropout off) and the sentence PROBABILITIES
@@ -171,34 +174,46 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
         model.noise_state.dropout_off = True
         model.set_seed(seed)
     step = 0
+
+    def score_group(group, hidden, hidden_2):
+        """group = [(key, hyps, pairs)]; one padded batch over all their hypotheses."""
+        nonlocal step
+        pairs = [p for _, _, ps in group for p in ps]
+        lens = [len(x) for x, _ in pairs]
+        Tm, N = max(lens), len(pairs)
+        data = torch.zeros(Tm, N, dtype=torch.int64)
+        tgt = torch.zeros(Tm, N, dtype=torch.int64)
+        for n, (x, t) in enumerate(pairs):
+            data[:lens[n], n] = torch.tensor(x, dtype=torch.int64)
+            tgt[:lens[n], n] = torch.tensor(t, dtype=torch.int64)
+        data, tgt = data.to(device), tgt.to(device)
+        mask = (torch.arange(Tm, device=device).unsqueeze(1) < torch.tensor(lens, device=device).unsqueeze(0)).float()
+        hN = tuple(h.expand(-1, N, -1).contiguous() for h in hidden) if is_rnn else None
+        h2N = tuple(h.expand(-1, N, -1).contiguous() for h in hidden_2) if hidden_2 is not None else None
+        sent = []
+        for _ in range(S):
+            if mc_samples > 0:
+                model.set_step(step)
+                step += 1
+            nll = _batch_nll(model, data, tgt.view(-1), model_type, hN, model_2, h2N, alpha)
+            sent.append((nll * mask).sum(0))
+        if S == 1:
+            tot = sent[0]
+        else:
+            tot = -(torch.logsumexp(-torch.stack(sent), 0) - torch.log(torch.tensor(float(S), device=device)))
+        tot = tot.tolist()
+        o = 0
+        for key, hyps, ps in group:
+            scores[key] = [(h, float(v)) for h, v in zip(hyps, tot[o:o + len(hyps)])]
+            o += len(hyps)
+
     with torch.no_grad():
+        group, g_cols, g_tmax = [], 0, 0
         for key, hyps in nbest.items():
             pairs = [get_input_and_target(h, vocab) for h in hyps]
-            lens = [len(x) for x, _ in pairs]
-            Tm, N = max(lens), len(hyps)
-            data = torch.zeros(Tm, N, dtype=torch.int64)
-            tgt = torch.zeros(Tm, N, dtype=torch.int64)
-            for n, (x, t) in enumerate(pairs):
-                data[:lens[n], n] = torch.tensor(x, dtype=torch.int64)
-                tgt[:lens[n], n] = torch.tensor(t, dtype=torch.int64)
-            data, tgt = data.to(device), tgt.to(device)
-            mask = (torch.arange(Tm, device=device).unsqueeze(1) < torch.tensor(lens, device=device).unsqueeze(0)).float()
-            hN = tuple(h.expand(-1, N, -1).contiguous() for h in hidden) if is_rnn else None
-            h2N = tuple(h.expand(-1, N, -1).contiguous() for h in hidden_2) if hidden_2 is not None else None
-            sent = []
-            for s_i in range(S):
-                if mc_samples > 0:
-                    model.set_step(step)
-                    step += 1
-                nll = _batch_nll(model, data, tgt.view(-1), model_type, hN, model_2, h2N, alpha)
-                sent.append((nll * mask).sum(0))
-            if S == 1:
-                tot = sent[0]
-            else:
-                tot = -(torch.logsumexp(-torch.stack(sent), 0) - torch.log(torch.tensor(float(S), device=device)))
-            tot = tot.tolist()
-            scores[key] = [(h, float(v)) for h, v in zip(hyps, tot)]
-            if is_rnn:  # carry = state after the FIRST hypothesis alone, mean weights (reference :271-274)
+            if is_rnn:
+                score_group([(key, hyps, pairs)], hidden, hidden_2)
+                # carry = state after the FIRST hypothesis alone, mean weights (reference :271-274)
                 was_training = model.training
                 model.eval()
                 x0 = torch.tensor(pairs[0][0], dtype=torch.int64, device=device).view(-1, 1)
@@ -206,6 +221,15 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
                 if model_2 is not None:
                     _, hidden_2 = model_2(x0, hidden_2)
                 model.train(was_training)
+                continue
+            tmax = max(len(x) for x, _ in pairs)
+            if group and max(g_tmax, tmax) * (g_cols + len(pairs)) > batch_tokens:
+                score_group(group, None, None)
+                group, g_cols, g_tmax = [], 0, 0
+            group.append((key, hyps, pairs))
+            g_cols, g_tmax = g_cols + len(pairs), max(g_tmax, tmax)
+        if group:
+            score_group(group, None, None)
     if mc_samples > 0:
         model.noise_state.dropout_off = False
         model.eval()
@@ -244,6 +268,7 @@ def build_parser():
     p.add_argument('--batched', type=int, default=1, help='1: all hypotheses of an utterance in one padded batch; '
                    '0: one launch per hypothesis like the reference')
     p.add_argument('--mc-samples', type=int, default=0, help='S > 0: average sentence probabilities over S weight samples')
+    p.add_argument('--batch-tokens', type=int, default=8192, help='Transformer scoring: padded tokens per batch across utterances')
     return p
 
 
@@ -264,7 +289,8 @@ def main(argv=None):
         model_2 = model_2.to(device)
     nbest = load_nbest(args.nbest_list)
     if args.batched or args.mc_samples > 0:
-        scores = compute_scores_batched(nbest, model_1, vocab, args.model, device, model_2, args.inter_alpha, args.mc_samples)
+        scores = compute_scores_batched(nbest, model_1, vocab, args.model, device, model_2, args.inter_alpha, args.mc_samples,
+                                        batch_tokens=args.batch_tokens)
     else:
         scores = compute_scores(nbest, model_1, vocab, args.model, device, model_2, args.inter_alpha)
     write_scores(scores, args.outfile)

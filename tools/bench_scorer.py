@@ -21,7 +21,8 @@ def main():
     vocab = {w: i + 2 for i, w in enumerate(words)}
     vocab["<s>"], vocab["<unk>"] = 0, 1
     nbest = OrderedDict()
-    n_utt, n_hyp = 40, 100
+    import os
+    n_utt, n_hyp = int(os.environ.get("N_UTT", "40")), int(os.environ.get("N_HYP", "100"))
     for u in range(n_utt):
         base = [rnd.choice(words) for _ in range(rnd.randint(6, 30))]
         hyps = []
