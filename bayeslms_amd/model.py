@@ -389,19 +389,74 @@ class GPNN(_Site):
         return kl
 
 
+class GPNN2(_Site):
+    """Reference model.py:2036-2102 (``--T_gauss_pos 4``): random-feature GP.  features = x @ frequency
+    with frequency = frequency_mean + eps * exp(frequency_lgstd) in train mode (one N(0,1) draw of
+    shape (input_dim, n_MC_terms)); output = coef((features + sum_act act(features)) / sqrt(n_MC))
+    over the act set {sigmoid, tanh, relu, gelu} (summed: the order is irrelevant).  The frequencies are
+    sampled by the weight-sampling kernel in their own layout, the product is a plain GEMM, the
+    activation sum the GPNN mixture kernel with unit coefficients.  train.py adds no KL for
+    this position (train.py:360); ``kl_divergence`` needs ``reset_prior()`` first, as in the reference."""
+
+    def __init__(self, input_dim, output_dim, n_MC_terms=150, act_set=('sigmoid', 'tanh', 'relu', 'gelu'), skip_act=True,
+                 deterministic=False, update_prior=True):
+        super().__init__()
+        self.input_dim, self.output_dim, self.n_MC_terms = input_dim, output_dim, n_MC_terms
+        self.act_set, self.skip_act, self.deterministic, self.update_prior = set(act_set), skip_act, deterministic, update_prior
+        bad = self.act_set - set(GPNN._SLOT)
+        if bad:
+            raise BayesLMError("GPNN2 activations %s are not built by this engine" % sorted(bad))
+        stdv = 1.0 / math.sqrt(n_MC_terms)
+        self.frequency_mean = nn.Parameter(torch.empty(input_dim, n_MC_terms).uniform_(-stdv, stdv))
+        self.frequency_lgstd = nn.Parameter(torch.empty(input_dim, n_MC_terms).uniform_(2 * np.log(stdv), np.log(stdv)))
+        self.coef = _ProjHolder(n_MC_terms, output_dim)
+        self.eps_override = None  # (input_dim, n_MC_terms), the reference's layout
+        self.frequency_mean_prior = self.frequency_lgstd_prior = None
+
+    def forward(self, x):
+        freq = self.frequency_mean
+        if self.training and not self.deterministic:  # elementwise sampling in the parameters' own layout
+            freq = ops.sampled(self.frequency_mean, self.frequency_lgstd, self._noise(0, self.eps_override))
+        z = ops.linear(x, freq.t().contiguous())  # x @ frequency; the (n_MC, input_dim) copy is 77 k floats
+        ones = torch.zeros(4, self.n_MC_terms, device=z.device, dtype=torch.float32)
+        for a in self.act_set:
+            ones[GPNN._SLOT[a]] = 1.0
+        mix = ops.gp_mix(z, ones)
+        a = (z + mix) if self.skip_act else mix
+        return self.coef(a * (1.0 / math.sqrt(self.n_MC_terms)))
+
+    def reset_prior(self):
+        self.frequency_mean_prior = torch.zeros_like(self.frequency_mean.data)
+        self.frequency_lgstd_prior = torch.zeros_like(self.frequency_lgstd.data)
+        if self.update_prior:
+            self.frequency_mean_prior = self.frequency_mean.data.clone()
+            self.frequency_lgstd_prior = self.frequency_lgstd.data.clone()
+
+    def kl_divergence(self):
+        if self.frequency_mean_prior is None:
+            raise BayesLMError("GPNN2.kl_divergence needs reset_prior() first (reference model.py:2078-2096)")
+        var, var_p = torch.exp(2 * self.frequency_lgstd), torch.exp(2 * self.frequency_lgstd_prior)
+        ms = (self.frequency_mean - self.frequency_mean_prior) ** 2. / var_p
+        ls = 2 * (self.frequency_lgstd_prior - self.frequency_lgstd) / self.frequency_mean.size(1)
+        return torch.sum(ms + var / var_p - ls - 1) / 2.  # small (input_dim, n_MC) glue, never called by train.py
+
+
 class GaussTransformerEncoderLayer(_Site):
     """Reference model.py:2250-2295: GPNN replaces GELU(linear1(x)); ``linear1`` exists in the
     state_dict but is unused (model.py:2257,2283)."""
 
     def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, gauss_pos=None):
         super().__init__()
-        if not (0 <= gauss_pos <= 3):
-            raise BayesLMError("gauss_pos 4 (GPNN2 random features) is not built by this engine")
+        if not (0 <= gauss_pos <= 4):
+            raise BayesLMError("GaussTransformerEncoderLayer: gauss_pos must be 0..4")
         self.gauss_pos = self.gpnn_type = gauss_pos
         self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
         self.linear1 = _ProjHolder(d_model, dim_feedforward)
         self.linear2 = _ProjHolder(dim_feedforward, d_model)
-        self.gpnn = GPNN(d_model, dim_feedforward, act_set=['tanh', 'sigmoid', 'relu', 'gelu'], gpnn_type=gauss_pos)
+        if gauss_pos < 4:
+            self.gpnn = GPNN(d_model, dim_feedforward, act_set=['tanh', 'sigmoid', 'relu', 'gelu'], gpnn_type=gauss_pos)
+        else:
+            self.gpnn = GPNN2(d_model, dim_feedforward, act_set=['tanh', 'sigmoid', 'relu', 'gelu'])
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
         self.p = dropout
@@ -410,8 +465,11 @@ class GaussTransformerEncoderLayer(_Site):
         a = self.self_attn(src, src, src, attn_mask=src_mask)[0]
         x = ops.add_dropout_ln(src, a, self.norm1.weight, self.norm1.bias, self.norm1.eps, self._drop(self.p, 1))
         g = self.gpnn
-        f = ops.ffn_gp(x, g.weights_mean, g.bias_mean, g.coef_mean, self.linear2.weight, self.linear2.bias,
-                       self._drop(self.p, 0))
+        if self.gauss_pos == 4:  # GPNN2: 150 random features, then its own Linear to dim_feedforward
+            f = self.linear2(ops.dropout(g(x), self._drop(self.p, 0)))
+        else:
+            f = ops.ffn_gp(x, g.weights_mean, g.bias_mean, g.coef_mean, self.linear2.weight, self.linear2.bias,
+                           self._drop(self.p, 0))
         return ops.add_dropout_ln(x, f, self.norm2.weight, self.norm2.bias, self.norm2.eps, self._drop(self.p, 2))
 
 

@@ -109,6 +109,17 @@ def gp_mixture(z, coef, acts):
     return out
 
 
+def gpnn2(x, sd, pre, eps=None):
+    """GPNN2.forward (model.py:2061-2076): frequency = mean + eps * exp(lgstd) in train mode (eps
+    (input_dim, n_MC), the module's single N(0,1) draw), features = x @ frequency, output =
+    coef((features + sum_act act(features)) / sqrt(n_MC)) with the act set {sigmoid, tanh, relu, gelu}."""
+    fm, fl = sd[pre + "frequency_mean"], sd[pre + "frequency_lgstd"]
+    freq = fm if eps is None else fm + eps * torch.exp(fl)
+    z = x.matmul(freq)
+    a = z + torch.sigmoid(z) + torch.tanh(z) + F.relu(z) + F.gelu(z)
+    return F.linear(a / math.sqrt(fm.shape[1]), sd[pre + "coef.weight"], sd[pre + "coef.bias"])
+
+
 def encoder_layer(x, sd, pre, nhead, mask, eps=None):
     """Post-LN block (model.py:1037-1046, 1162-1176, 2274-2295).  ``eps`` is the
     single draw this layer makes: for the FFN position it belongs to linear2,
@@ -122,6 +133,8 @@ def encoder_layer(x, sd, pre, nhead, mask, eps=None):
     if pre + "gpnn.weights_mean" in sd:
         z = F.linear(x, sd[pre + "gpnn.weights_mean"], sd[pre + "gpnn.bias_mean"])
         h = gp_mixture(z, sd[pre + "gpnn.coef_mean"], ["tanh", "sigmoid", "relu", "gelu"])
+    elif pre + "gpnn.frequency_mean" in sd:  # gauss_pos 4: GPNN2 random features (model.py:2036-2076)
+        h = gpnn2(x, sd, pre + "gpnn.", eps)
     else:
         h = F.gelu(F.linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"]))
     if pre + "linear2.weight_mean" in sd:

@@ -158,6 +158,31 @@ def f4_gauss_transformer(gp):
          **pack_sd(m), **grads(m))
 
 
+def f4_gauss_transformer4():
+    """gauss_pos 4: layer 0 uses GPNN2 (random-feature GP, model.py:2036-2102), whose frequencies are
+    sampled in train mode with one N(0,1) draw of shape (d_model, 150) -- the first draw of the forward
+    (dropout 0), recovered by replaying the seed.  train.py adds no KL for this position."""
+    V, d, h, ff, L, T, B = 50, 16, 4, 32, 2, 6, 3
+    torch.manual_seed(27)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref.GaussTransformerModel(V, d, h, ff, L, 0.0, True, 4)
+    src = torch.randint(0, V, (T, B))
+    tgt = torch.randint(0, V, (T * B,))
+    m.train()
+    g2 = m.transformerlayers[0].gpnn
+    torch.manual_seed(301)
+    eps = torch.zeros(g2.input_dim, g2.n_MC_terms).normal_()
+    torch.manual_seed(301)
+    logits = m(src)
+    mle = torch.nn.functional.cross_entropy(logits.view(-1, V), tgt)
+    mle.backward()
+    m.eval()
+    with torch.no_grad():
+        logits_eval = m(src)
+    save("gauss_tlm_4", src=npy(src), tgt=npy(tgt), nhead=np.int64(h), eps=npy(eps), logits_train=npy(logits),
+         logits_eval=npy(logits_eval), mle=npy(mle), **pack_sd(m), **grads(m))
+
+
 # ---------------------------------------------------------------- F2 Bayes LSTM
 EPS_ORDER = ("weight_hh_lgstd_1", "weight_ih_lgstd_1", "bias_hh_lgstd_1", "bias_ih_lgstd_1",
              "weight_hh_lgstd_2", "weight_ih_lgstd_2", "bias_hh_lgstd_2", "bias_ih_lgstd_2")
@@ -494,6 +519,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rnnv":
         f5_gauss_variational_rnn()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "gpnn2":
+        f4_gauss_transformer4()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "interp":
         f7_scorer_interp()
         sys.exit(0)
@@ -514,3 +542,4 @@ if __name__ == "__main__":
     f6_train_checkpoint()
     f7_scorer()
     f7_scorer_interp()
+    f4_gauss_transformer4()

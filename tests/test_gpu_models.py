@@ -247,6 +247,42 @@ def test_gauss_transformer_golden(dev, gp):
         assert grad_close(p.grad, grad[k]), k
 
 
+def test_gauss_transformer_gpnn2_golden(dev):
+    """--T_gauss_pos 4 (GPNN2 random-feature layer) vs the reference: eval logits, train logits with the
+    recovered frequency draw injected, and every gradient."""
+    from bayeslms_amd import model as M, ops
+    g, sd, grad = load_golden("gauss_tlm_4")
+    V, d = sd["encoder.weight"].shape
+    ff = sd["transformerlayers.0.linear1.weight"].shape[0]
+    m = M.GaussTransformerModel(V, d, int(g["nhead"]), ff, 2, 0.0, True, 4).to(dev)
+    with torch.no_grad():
+        load_sd(m, sd)
+    src, tgt = g["src"].to(dev), g["tgt"].to(dev)
+    m.eval()
+    with torch.no_grad():
+        assert rel(m(src), g["logits_eval"]) < TOL
+    m.train()
+    m.transformerlayers[0].gpnn.eps_override = g["eps"].to(dev)
+    logits = m(src)
+    assert rel(logits, g["logits_train"]) < TOL
+    mle, _ = ops.cross_entropy(logits.view(-1, V), tgt)
+    mle.backward()
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or k not in grad:
+            continue
+        assert p.grad is not None, k
+        assert grad_close(p.grad, grad[k]), k
+    # Philox mode: a different draw per step, same draw for the same step
+    m.transformerlayers[0].gpnn.eps_override = None
+    m.set_seed(7)
+    m.set_step(1)
+    a = m(src).detach().clone()
+    b = m(src).detach().clone()
+    m.set_step(2)
+    c = m(src).detach().clone()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
 def _write_corpus(g, d):
     import os
     with open(os.path.join(d, "words.txt"), "w") as f:

@@ -95,6 +95,24 @@ def test_gauss_transformer_matches_reference(gp):
     torch.testing.assert_close(kl, g["kl"], **TOL)
 
 
+def test_gauss_transformer_gpnn2_matches_reference():
+    """--T_gauss_pos 4: GPNN2 random features in layer 0 (model.py:2036-2076); train mode samples the
+    frequencies with the recovered draw; gradients of every parameter against the reference's."""
+    g, sd, grad = load_golden("gauss_tlm_4")
+    nhead = int(g["nhead"])
+    V = sd["encoder.weight"].shape[0]
+    torch.testing.assert_close(O.transformer_lm(g["src"], sd, nhead, None), g["logits_eval"], **TOL)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    logits = O.transformer_lm(g["src"], leaf, nhead, g["eps"])
+    torch.testing.assert_close(logits, g["logits_train"], **TOL)
+    O.cross_entropy_mean(logits.view(-1, V), g["tgt"]).backward()
+    for k, v in grad.items():
+        if k == "decoder.weight":
+            continue
+        torch.testing.assert_close(leaf[k].grad, v, rtol=2e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("pos", [0, 1, 2, 3, 4])
 def test_bayes_lstm_matches_reference(pos):
     g, sd, grad = load_golden("bayes_rnn_pos%d" % pos)
