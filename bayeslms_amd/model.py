@@ -670,9 +670,18 @@ class Bayes2LSTM(_Site):
 
     def kl_divergence(self, prior=None):
         pos, H, E = self.position, self.hidden_size, self.input_size
-        if prior is not None or not (1 <= pos <= 4):
-            raise BayesLMError("Bayes2LSTM.kl_divergence is defined for position 1..4 without prior "
+        if prior is not None or not (1 <= pos <= 5):
+            raise BayesLMError("Bayes2LSTM.kl_divergence is defined for position 1..5 without prior "
                                "(reference model.py:734-775: other branches are dead or raise)")
+        if pos == 5:
+            # model.py:746-755, as written: layer 1's [hh|ih] tensors PLUS [hh of layer 2 | ih of layer 1
+            # again], means and log-sigmas alike, then the mean-form KL.  Nothing is ever sampled at this
+            # position; plain tensor glue on the parameters, not a hot path.
+            wm = torch.cat([self.weight_hh_mean_1, self.weight_ih_mean_1], -1) + torch.cat([self.weight_hh_mean_2, self.weight_ih_mean_1], -1)
+            wl = torch.cat([self.weight_hh_lgstd_1, self.weight_ih_lgstd_1], -1) + torch.cat([self.weight_hh_lgstd_2, self.weight_ih_lgstd_1], -1)
+            bm = torch.cat([self.bias_hh_mean_1, self.bias_ih_mean_1], -1) + torch.cat([self.bias_hh_mean_2, self.bias_ih_mean_1], -1)
+            bl = torch.cat([self.bias_hh_lgstd_1, self.bias_ih_lgstd_1], -1) + torch.cat([self.bias_hh_lgstd_2, self.bias_ih_lgstd_1], -1)
+            return torch.mean(wm ** 2. - wl * 2. + torch.exp(wl * 2)) / 2. + torch.mean(bm ** 2. - bl * 2. + torch.exp(bl * 2)) / 2.
         lo = (pos - 1) * H
         nw, nb = H * (H + E), 2 * H  # the reference concatenates hh|ih before taking the mean
         kl = ops.kl_mean(self.weight_hh_mean_1, self.weight_hh_lgstd_1, lo, count=nw)

@@ -93,7 +93,7 @@ def kl_selector(args):
     wgrad epilogue can add itself."""
     fn = None
     if args.uncertainty == 'Bayesian':
-        if args.model == 'LSTM' and 1 <= args.L_bayes_pos <= 4:
+        if args.model == 'LSTM' and 1 <= args.L_bayes_pos <= 5:  # train.py:337
             fn = lambda m: m.rnn.kl_divergence()  # noqa: E731
             fn.fusable = False
         elif args.model == 'Transformer':

@@ -249,8 +249,16 @@ def rnn_lm(x, hidden, sd):
 
 
 def kl_bayes2lstm(sd, pre, pos):
-    """Bayes2LSTM.kl_divergence, pos 1..4 (model.py:734-765): layer-1 tensors
-    only; weights and biases each get their own mean."""
+    """Bayes2LSTM.kl_divergence (model.py:734-765).  pos 1..4: layer-1 tensors only; weights and
+    biases each get their own mean.  pos 5 (:746-755, as written): layer 1's [hh|ih] plus
+    [hh of layer 2 | ih of layer 1 again], for means and log-sigmas alike."""
+    if pos == 5:
+        c = lambda a, b: torch.cat([sd[pre + a], sd[pre + b]], -1)  # noqa: E731
+        wm = c("weight_hh_mean_1", "weight_ih_mean_1") + c("weight_hh_mean_2", "weight_ih_mean_1")
+        wl = c("weight_hh_lgstd_1", "weight_ih_lgstd_1") + c("weight_hh_lgstd_2", "weight_ih_lgstd_1")
+        bm = c("bias_hh_mean_1", "bias_ih_mean_1") + c("bias_hh_mean_2", "bias_ih_mean_1")
+        bl = c("bias_hh_lgstd_1", "bias_ih_lgstd_1") + c("bias_hh_lgstd_2", "bias_ih_lgstd_1")
+        return kl_mean_form(wm, wl) + kl_mean_form(bm, bl)
     if not (1 <= pos <= 4):
         return torch.zeros(())
     H = sd[pre + "weight_hh_lgstd_1"].shape[0]

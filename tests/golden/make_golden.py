@@ -215,7 +215,7 @@ def f2_bayes_rnn(pos):
             kw["eps_%d_%d" % (w, j)] = npy(e)
     mle = torch.nn.functional.cross_entropy(logits.view(-1, V), tgt)
     # train.py:337 only asks for the KL when 1 <= pos <= 5 (pos 0 would raise in the reference)
-    kl = m.rnn.kl_divergence() if 1 <= pos <= 4 else torch.zeros(())
+    kl = m.rnn.kl_divergence() if 1 <= pos <= 5 else torch.zeros(())  # train.py:337 adds it for 1..5
     (mle + kl * kl_scale).backward()
     kw.update(h_train=npy(hidden[0]), c_train=npy(hidden[1]), mle=npy(mle), kl=npy(kl))
     m.eval()
@@ -519,6 +519,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rnnv":
         f5_gauss_variational_rnn()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pos5":
+        f2_bayes_rnn(5)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gpnn2":
         f4_gauss_transformer4()
         sys.exit(0)
@@ -535,7 +538,7 @@ if __name__ == "__main__":
     f3_transformer_baseline()
     for gp in (0, 1, 2, 3):
         f4_gauss_transformer(gp)
-    for pos in (0, 1, 2, 3, 4):
+    for pos in (0, 1, 2, 3, 4, 5):
         f2_bayes_rnn(pos)
     f2_rnn_baseline()
     f8_data()

@@ -113,7 +113,7 @@ def test_gauss_transformer_gpnn2_matches_reference():
         torch.testing.assert_close(leaf[k].grad, v, rtol=2e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("pos", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("pos", [0, 1, 2, 3, 4, 5])
 def test_bayes_lstm_matches_reference(pos):
     g, sd, grad = load_golden("bayes_rnn_pos%d" % pos)
     B = g["x1"].shape[1]
