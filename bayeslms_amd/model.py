@@ -413,10 +413,21 @@ class GPNN2(_Site):
         self.eps_override = None  # (input_dim, n_MC_terms), the reference's layout
         self.frequency_mean_prior = self.frequency_lgstd_prior = None
 
-    def forward(self, x):
+    def forward(self, x, call=0):
+        """``call``: index of this call inside one forward of the parent (the time step of the GP-LSTM
+        loop) -- the reference draws fresh frequencies at EVERY call, so the Philox counter gets the call
+        index next to the training step; ``eps_override`` may be one tensor or a list indexed by it."""
         freq = self.frequency_mean
         if self.training and not self.deterministic:  # elementwise sampling in the parameters' own layout
-            freq = ops.sampled(self.frequency_mean, self.frequency_lgstd, self._noise(0, self.eps_override))
+            ov = self.eps_override
+            if isinstance(ov, (list, tuple)):
+                ov = ov[call]
+            if ov is not None:
+                noise = NoiseSpec(eps=ov)
+            else:
+                st = self._st()
+                noise = NoiseSpec(None, st.seed, self._site_base, (st.step * 1024 + call) & 0xFFFFFFFF)
+            freq = ops.sampled(self.frequency_mean, self.frequency_lgstd, noise)
         z = ops.linear(x, freq.t().contiguous())  # x @ frequency; the (n_MC, input_dim) copy is 77 k floats
         ones = torch.zeros(4, self.n_MC_terms, device=z.device, dtype=torch.float32)
         for a in self.act_set:
@@ -801,15 +812,21 @@ class _LoopCell(_Site):
 class GPLSTMCell(_LoopCell):
     """Reference model.py:1674-1777.  gate_type 1-4: that gate's activation is a GPNN of [inp|h];
     5: the cell state passes through a GPNN first; 6 / 7: the hidden / input projection of all four
-    gates is a GPNN.  gpnn_type 0-3 (4 = GPNN2 random features is not built)."""
+    gates is a GPNN.  gpnn_type 0-3; 4 = GPNN2 random features on the gate's pre-activation etc.
+    (``_forward_gpnn2``)."""
 
     def __init__(self, input_size, hidden_size, gate_type=0, gpnn_type=0):
         super().__init__()
-        if gpnn_type > 3:
-            raise BayesLMError("gpnn_type 4 (GPNN2 random features) is not built by this engine")
+        if gpnn_type > 4:
+            raise BayesLMError("GPLSTMCell: gpnn_type must be 0..4")
         self.gate_type, self.gpnn_type = gate_type, gpnn_type
         H, E = hidden_size, input_size
-        if gate_type == 3:
+        if gpnn_type == 4:  # GPNN2 on the gate's pre-activation / cell state / a whole projection (model.py:1698-1702)
+            if 0 < gate_type <= 5:
+                self.gpnn = GPNN2(H, H, act_set=['sigmoid', 'relu', 'tanh'])
+            elif 5 < gate_type <= 7:
+                self.gpnn = GPNN2(H, 4 * H, act_set=['sigmoid', 'relu', 'tanh'])
+        elif gate_type == 3:
             self.gpnn = GPNN(H + E, H, gpnn_type=gpnn_type)
         elif gate_type in (1, 4):
             self.gpnn = GPNN(H + E, H, act_set=['sigmoid', 'tanh', 'relu'], gpnn_type=gpnn_type)
@@ -830,6 +847,8 @@ class GPLSTMCell(_LoopCell):
             hid = (z, z)
         hx, cx = hid
         gt = self.gate_type
+        if self.gpnn_type == 4 and gt > 0:
+            return self._forward_gpnn2(inputs, hx, cx)
         if 1 <= gt <= 4 and ops.lstm_recurrent_gp_supported(self.hidden_size, self.weights_hh):
             # GPNN on one gate: the whole layer on the fused step kernels.  The GPNN's affine map over
             # [inp|h] splits into an input part (batched over T with the other gates' input GEMM) and a
@@ -862,6 +881,35 @@ class GPLSTMCell(_LoopCell):
                 hx, cx = ops.lstm_cell(xw_all[t], hw, cx, self.gpnn(inputs[t], hx), gt - 1)
             else:
                 hx, cx = ops.lstm_cell(xw_all[t], hw, cx)
+            outs.append(hx)
+        return torch.stack(outs, 0), (hx, cx)
+
+
+    def _forward_gpnn2(self, inputs, hx, cx):
+        """gpnn_type 4 (reference model.py:1744-1771): GPNN2 with fresh frequencies at every time step, on
+        the overridden gate's pre-activation (gate types 1-4), on the cell state (5) or as the hidden /
+        input projection (6 / 7).  Step-wise, like the reference."""
+        gt, H = self.gate_type, self.hidden_size
+        T = inputs.shape[0]
+        xw_all = None if gt == 7 else ops.linear(inputs, self.weights_ih, self.bias_ih)
+        outs = []
+        zero = None
+        for t in range(T):
+            if gt == 6:
+                xw, hw = xw_all[t], self.gpnn(hx, t)
+            elif gt == 7:
+                xw, hw = self.gpnn(inputs[t], t), ops.linear(hx, self.weights_hh, self.bias_ih)
+            else:
+                xw, hw = xw_all[t], ops.linear(hx, self.weights_hh, self.bias_ih)
+            if gt == 5:
+                cx = self.gpnn(cx, t)
+            if 1 <= gt <= 4:
+                pre = xw + hw  # the gate's pre-activation is the GPNN2's input
+                if zero is None:
+                    zero = torch.zeros_like(pre)
+                hx, cx = ops.lstm_cell(pre, zero, cx, self.gpnn(pre[:, (gt - 1) * H:gt * H].contiguous(), t), gt - 1)
+            else:
+                hx, cx = ops.lstm_cell(xw, hw, cx)
             outs.append(hx)
         return torch.stack(outs, 0), (hx, cx)
 

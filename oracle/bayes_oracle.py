@@ -109,14 +109,16 @@ def gp_mixture(z, coef, acts):
     return out
 
 
-def gpnn2(x, sd, pre, eps=None):
+def gpnn2(x, sd, pre, eps=None, gelu=False):
     """GPNN2.forward (model.py:2061-2076): frequency = mean + eps * exp(lgstd) in train mode (eps
     (input_dim, n_MC), the module's single N(0,1) draw), features = x @ frequency, output =
     coef((features + sum_act act(features)) / sqrt(n_MC)) with the act set {sigmoid, tanh, relu, gelu}."""
     fm, fl = sd[pre + "frequency_mean"], sd[pre + "frequency_lgstd"]
     freq = fm if eps is None else fm + eps * torch.exp(fl)
     z = x.matmul(freq)
-    a = z + torch.sigmoid(z) + torch.tanh(z) + F.relu(z) + F.gelu(z)
+    a = z + torch.sigmoid(z) + torch.tanh(z) + F.relu(z)
+    if gelu:  # the Transformer layer's set has gelu (model.py:2264), the LSTM cells' does not (:1699-1702)
+        a = a + F.gelu(z)
     return F.linear(a / math.sqrt(fm.shape[1]), sd[pre + "coef.weight"], sd[pre + "coef.bias"])
 
 
@@ -134,7 +136,7 @@ def encoder_layer(x, sd, pre, nhead, mask, eps=None):
         z = F.linear(x, sd[pre + "gpnn.weights_mean"], sd[pre + "gpnn.bias_mean"])
         h = gp_mixture(z, sd[pre + "gpnn.coef_mean"], ["tanh", "sigmoid", "relu", "gelu"])
     elif pre + "gpnn.frequency_mean" in sd:  # gauss_pos 4: GPNN2 random features (model.py:2036-2076)
-        h = gpnn2(x, sd, pre + "gpnn.", eps)
+        h = gpnn2(x, sd, pre + "gpnn.", eps, gelu=True)
     else:
         h = F.gelu(F.linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"]))
     if pre + "linear2.weight_mean" in sd:
@@ -327,28 +329,40 @@ def _gp_acts(gate_type):
     return ["sigmoid"] if gate_type == 2 else ["sigmoid", "tanh", "relu"]  # model.py:1688-1697
 
 
-def gp_lstm_cell(x, h, c, sd, pre, gate_type):
-    """GPLSTMCell.forward (model.py:1720-1777): bias_ih is added twice, bias_hh unused; gate 1-4 is
-    a GPNN of [inp|h]; 5: c = GPNN(c) first; 6/7: the hidden/input projection is a GPNN."""
+def gp_lstm_cell(x, h, c, sd, pre, gate_type, eps=None):
+    """GPLSTMCell.forward (model.py:1720-1777): bias_ih is added twice, bias_hh unused.  gpnn_type 0-3
+    (GPNN, keys gpnn.weights_mean ...): gate 1-4 is a GPNN of [inp|h]; 5: c = GPNN(c) first; 6/7: the
+    hidden/input projection is a GPNN.  gpnn_type 4 (GPNN2, keys gpnn.frequency_mean ...): gate 1-4 is
+    GPNN2 of that gate's PRE-ACTIVATION, 5: c = GPNN2(c), 6/7 as above with GPNN2; every call draws new
+    frequencies in train mode: ``eps`` = list of T tensors (input_dim, n_MC) or None (eval)."""
     acts = _gp_acts(gate_type)
     w_ih, b_ih, w_hh = sd[pre + "weights_ih"], sd[pre + "bias_ih"], sd[pre + "weights_hh"]
+    two = pre + "gpnn.frequency_mean" in sd
     outs = []
     for t in range(x.shape[0]):
         inp = x[t]
+        e = None if eps is None else eps[t]
+        gp_of = (lambda v: gpnn2(v, sd, pre + "gpnn.", e)) if two else (lambda v: gpnn(v, sd, pre + "gpnn.", acts))
         if gate_type == 6:
-            gates = F.linear(inp, w_ih, b_ih) + gpnn(h, sd, pre + "gpnn.", acts)
+            gates = F.linear(inp, w_ih, b_ih) + gp_of(h)
         elif gate_type == 7:
-            gates = gpnn(inp, sd, pre + "gpnn.", acts) + F.linear(h, w_hh, b_ih)
+            gates = gp_of(inp) + F.linear(h, w_hh, b_ih)
         else:
             gates = F.linear(inp, w_ih, b_ih) + F.linear(h, w_hh, b_ih)
         i, f, g, o = gates.chunk(4, 1)
-        gp = gpnn(torch.cat([inp, h], -1), sd, pre + "gpnn.", acts) if 1 <= gate_type <= 4 else None
-        i = gp if gate_type == 1 else torch.sigmoid(i)
-        f = gp if gate_type == 2 else torch.sigmoid(f)
-        g = gp if gate_type == 3 else torch.tanh(g)
-        o = gp if gate_type == 4 else torch.sigmoid(o)
+        if two:
+            i = gp_of(i) if gate_type == 1 else torch.sigmoid(i)
+            f = gp_of(f) if gate_type == 2 else torch.sigmoid(f)
+            g = gp_of(g) if gate_type == 3 else torch.tanh(g)
+            o = gp_of(o) if gate_type == 4 else torch.sigmoid(o)
+        else:
+            gp = gp_of(torch.cat([inp, h], -1)) if 1 <= gate_type <= 4 else None
+            i = gp if gate_type == 1 else torch.sigmoid(i)
+            f = gp if gate_type == 2 else torch.sigmoid(f)
+            g = gp if gate_type == 3 else torch.tanh(g)
+            o = gp if gate_type == 4 else torch.sigmoid(o)
         if gate_type == 5:
-            c = gpnn(c, sd, pre + "gpnn.", acts)
+            c = gp_of(c)
         c = f * c + i * g
         h = o * torch.tanh(c)
         outs.append(h)
@@ -367,24 +381,26 @@ def _nn_lstm(x, h0, c0, sd, pre):
     return x, torch.stack(hs), torch.stack(cs)
 
 
-def gauss_rnn_lm(x, hidden, sd, gauss_pos):
-    """GaussRNNModel.forward, dropout off (model.py:1355-1360 -> GPLSTM.forward :1638-1671)."""
+def gauss_rnn_lm(x, hidden, sd, gauss_pos, eps=None):
+    """GaussRNNModel.forward, dropout off (model.py:1355-1360 -> GPLSTM.forward :1638-1671).
+    ``eps`` = {cell index: [T tensors]} for GPNN2 cells in train mode."""
     y = F.embedding(x, sd["encoder.weight"])
     h0, c0 = hidden
     g = gauss_pos
+    eps = eps or {}
     if int(g[0]) == 0:
         y, hs, cs = _nn_lstm(y, h0, c0, sd, "rnn.rnn.0.")
     elif len(g) == 2:
-        y, h1, c1 = gp_lstm_cell(y, h0[0], c0[0], sd, "rnn.rnn.0.", int(g[0]))
+        y, h1, c1 = gp_lstm_cell(y, h0[0], c0[0], sd, "rnn.rnn.0.", int(g[0]), eps.get(0))
         y, hr, cr = _nn_lstm(y, h0[1:], c0[1:], sd, "rnn.rnn.1.")
         hs, cs = torch.cat([h1.unsqueeze(0), hr]), torch.cat([c1.unsqueeze(0), cr])
     elif len(g) == 3:
         y, hr, cr = _nn_lstm(y, h0[:1], c0[:1], sd, "rnn.rnn.0.")
-        y, h1, c1 = gp_lstm_cell(y, h0[1], c0[1], sd, "rnn.rnn.1.", int(g[0]))
+        y, h1, c1 = gp_lstm_cell(y, h0[1], c0[1], sd, "rnn.rnn.1.", int(g[0]), eps.get(1))
         hs, cs = torch.cat([hr, h1.unsqueeze(0)]), torch.cat([cr, c1.unsqueeze(0)])
     else:
-        y, h1, c1 = gp_lstm_cell(y, h0[0], c0[0], sd, "rnn.rnn.0.", int(g[0]))
-        y, h2, c2 = gp_lstm_cell(y, h0[1], c0[1], sd, "rnn.rnn.1.", int(g[2]))
+        y, h1, c1 = gp_lstm_cell(y, h0[0], c0[0], sd, "rnn.rnn.0.", int(g[0]), eps.get(0))
+        y, h2, c2 = gp_lstm_cell(y, h0[1], c0[1], sd, "rnn.rnn.1.", int(g[2]), eps.get(1))
         hs, cs = torch.stack([h1, h2]), torch.stack([c1, c2])
     return F.linear(y, sd["decoder.weight"], sd["decoder.bias"]), (hs, cs)
 

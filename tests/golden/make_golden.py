@@ -515,9 +515,50 @@ def f5_gauss_variational_rnn():
         save("vtransformer_%d" % v_pos, src=npy(src), nhead=np.int64(4), logits_eval=npy(out), **pack_sd(m))
 
 
+def f5_gauss_rnn_gpnn2():
+    """--L_gauss_pos with type digit 4: GPNN2 inside the GP-LSTM cells (model.py:1698-1702, 1763-1770).
+    Every GPNN2 call of the time loop draws fresh frequencies in train mode; layer 0 runs all its steps
+    before layer 1, so the draws are replayed in that order (T tensors per GPNN2 cell and window)."""
+    V, H, T, B = 40, 12, 5, 3
+    for gp in ("34", "14", "64", "74", "54", "340", "3464"):
+        torch.manual_seed(81 + len(gp) + int(gp[0]))
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = ref.GaussRNNModel("LSTM", V, H, H, 2, 0.0, True, gp)
+        x1, x2 = torch.randint(0, V, (T, B)), torch.randint(0, V, (T, B))
+        tgt = torch.randint(0, V, (T * B,))
+        cells = [c for c in (0, 1) if hasattr(m.rnn.rnn[c], "gpnn") and isinstance(m.rnn.rnn[c].gpnn, ref.GPNN2)]
+        m.train()
+        hid = m.init_hidden(B)
+        kw = {}
+        outs = []
+        for w, x in enumerate((x1, x2)):
+            torch.manual_seed(400 + w)
+            for c in cells:
+                g2 = m.rnn.rnn[c].gpnn
+                for t in range(T):
+                    kw["eps_%d_%d_%d" % (w, c, t)] = npy(torch.zeros(g2.input_dim, g2.n_MC_terms).normal_())
+            torch.manual_seed(400 + w)
+            hid = tuple(h.detach() for h in hid)
+            l, hid = m(x, hid)
+            outs.append(l)
+        mle = torch.nn.functional.cross_entropy(outs[1].view(-1, V), tgt)
+        mle.backward()  # train.py:367 adds no KL when the type digit is 4
+        m.eval()
+        with torch.no_grad():
+            hid = m.init_hidden(B)
+            e1, hid = m(x1, hid)
+            e2, hid = m(x2, hid)
+        save("gauss_rnn_" + gp, x1=npy(x1), x2=npy(x2), tgt=npy(tgt), logits_train_0=npy(outs[0]), logits_train_1=npy(outs[1]),
+             mle=npy(mle), logits_eval_0=npy(e1), logits_eval_1=npy(e2), h_eval=npy(hid[0]), c_eval=npy(hid[1]),
+             cells=np.array(cells, dtype=np.int64), **kw, **pack_sd(m), **grads(m))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rnnv":
         f5_gauss_variational_rnn()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rnn_gpnn2":
+        f5_gauss_rnn_gpnn2()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pos5":
         f2_bayes_rnn(5)
@@ -546,3 +587,4 @@ if __name__ == "__main__":
     f7_scorer()
     f7_scorer_interp()
     f4_gauss_transformer4()
+    f5_gauss_rnn_gpnn2()

@@ -462,6 +462,55 @@ def test_gauss_rnn_golden(dev, gp):
         assert grad_close(p.grad, grad[k]), k
 
 
+@pytest.mark.parametrize("gp", ["34", "14", "64", "74", "54", "340", "3464"])
+def test_gauss_rnn_gpnn2_golden(dev, gp):
+    """Type digit 4: GPNN2 inside the GP-LSTM cells vs the reference (eval, train with the replayed
+    per-time-step frequency draws, every gradient; no KL for this type, train.py:367)."""
+    from bayeslms_amd import model as M, ops
+    g, sd, grad = load_golden("gauss_rnn_" + gp)
+    V, H = sd["encoder.weight"].shape
+    m = M.GaussRNNModel("LSTM", V, H, H, 2, 0.0, True, gp).to(dev)
+    with torch.no_grad():
+        load_sd(m, sd)
+    x1, x2, tgt = g["x1"].to(dev), g["x2"].to(dev), g["tgt"].to(dev)
+    T, B = x1.shape
+    m.eval()
+    with torch.no_grad():
+        hid = m.init_hidden(B)
+        e1, hid = m(x1, hid)
+        e2, hid = m(x2, hid)
+    assert rel(e1, g["logits_eval_0"]) < TOL and rel(e2, g["logits_eval_1"]) < TOL
+    assert rel(hid[0], g["h_eval"]) < TOL and rel(hid[1], g["c_eval"]) < TOL
+    m.train()
+    hid = m.init_hidden(B)
+    outs = []
+    for w, x in enumerate((x1, x2)):
+        for c in g["cells"]:
+            m.rnn.rnn[int(c)].gpnn.eps_override = [g["eps_%d_%d_%d" % (w, int(c), t)].to(dev) for t in range(T)]
+        logits, hid = m(x, M.repackage_hidden(hid))
+        outs.append(logits.detach().clone())
+    assert rel(outs[0], g["logits_train_0"]) < TOL and rel(outs[1], g["logits_train_1"]) < TOL
+    mle, _ = ops.cross_entropy(logits.view(-1, V), tgt)
+    assert abs(float(mle) - float(g["mle"])) < TOL * abs(float(g["mle"]))
+    mle.backward()
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or k not in grad:
+            continue
+        assert p.grad is not None, k
+        assert grad_close(p.grad, grad[k]), k
+    # Philox mode: the time steps of one forward draw different frequencies; same step -> same result
+    for c in g["cells"]:
+        m.rnn.rnn[int(c)].gpnn.eps_override = None
+    m.set_seed(3)
+    m.set_step(5)
+    with torch.no_grad():
+        a, _ = m(x1, m.init_hidden(B))
+        b, _ = m(x1, m.init_hidden(B))
+        m.set_step(6)
+        c2, _ = m(x1, m.init_hidden(B))
+    assert torch.equal(a, b) and not torch.equal(a, c2)
+
+
 @pytest.mark.parametrize("gp", ["33", "13", "23", "43", "330", "3343", "31", "63", "6360", "73", "730", "6373"])
 def test_gauss_rnn_fused_steps_match_oracle(dev, gp):
     """H = 64: GP cells with a GPNN on one gate (types 1-4) take the fused step kernels (GPNN rows inside

@@ -281,6 +281,39 @@ def test_scorer_interpolation_of_reference(tag):
 GAUSS_RNN = ["33", "31", "13", "23", "43", "330", "6360", "3333", "53", "73", "00"]
 
 
+GAUSS_RNN_GPNN2 = ["34", "14", "64", "74", "54", "340", "3464"]
+
+
+def _gpnn2_eps(g, w, T):
+    return {int(c): [g["eps_%d_%d_%d" % (w, int(c), t)] for t in range(T)] for c in g["cells"]}
+
+
+@pytest.mark.parametrize("gp", GAUSS_RNN_GPNN2)
+def test_gauss_rnn_gpnn2_matches_reference(gp):
+    """Type digit 4: GPNN2 inside the GP-LSTM cells; fresh frequencies at every time step in train mode
+    (the replayed draws), no KL (train.py:367)."""
+    g, sd, grad = load_golden("gauss_rnn_" + gp)
+    T, B = g["x1"].shape
+    H, V = sd["encoder.weight"].shape[1], sd["encoder.weight"].shape[0]
+    zeros = (torch.zeros(2, B, H), torch.zeros(2, B, H))
+    e1, hid = O.gauss_rnn_lm(g["x1"], zeros, sd, gp)
+    e2, hid = O.gauss_rnn_lm(g["x2"], hid, sd, gp)
+    torch.testing.assert_close(e1, g["logits_eval_0"], **TOL)
+    torch.testing.assert_close(e2, g["logits_eval_1"], **TOL)
+    torch.testing.assert_close(hid[1], g["c_eval"], **TOL)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    l1, hid = O.gauss_rnn_lm(g["x1"], zeros, leaf, gp, _gpnn2_eps(g, 0, T))
+    l2, hid = O.gauss_rnn_lm(g["x2"], tuple(h.detach() for h in hid), leaf, gp, _gpnn2_eps(g, 1, T))
+    torch.testing.assert_close(l1, g["logits_train_0"], **TOL)
+    torch.testing.assert_close(l2, g["logits_train_1"], **TOL)
+    O.cross_entropy_mean(l2.view(-1, V), g["tgt"]).backward()
+    for k, v in grad.items():
+        if k == "decoder.weight":
+            continue
+        torch.testing.assert_close(leaf[k].grad, v, rtol=2e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("gp", GAUSS_RNN)
 def test_gauss_rnn_matches_reference(gp):
     g, sd, grad = load_golden("gauss_rnn_" + gp)
