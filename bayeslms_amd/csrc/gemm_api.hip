@@ -86,6 +86,9 @@ extern "C" int blm_gemm(const blm_gemm_args* a, void* stream) {
   {
     const int ac = a->op == BLM_GEMM_TN ? a->M : a->K, bc = a->op == BLM_GEMM_NT ? a->K : a->N;
     p.fast = p.a_vec && p.b_vec && ac % 4 == 0 && bc % 4 == 0 && ac >= 4 && bc >= 4;
+    // the LDS-DMA loaders address an operand with 32-bit byte offsets from a scalar base
+    const long arows = a->op == BLM_GEMM_TN ? a->K : a->M, brows = a->op == BLM_GEMM_NT ? a->N : a->K;
+    if (arows * (long)a->lda * 4 >= (1L << 32) || brows * (long)a->ldb * 4 >= (1L << 32)) p.fast = false;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (p.colsum_a && !p.fast) {  // odd shapes: the guarded-loader kernel does not fuse it

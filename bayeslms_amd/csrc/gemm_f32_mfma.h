@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "blm_device.h"
+#include <type_traits>
 #include "blm_host.h"
 
 namespace blm {
@@ -206,6 +207,59 @@ template <int S> struct FragG<false, 1, S> {
     for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(v[s]));
   }
 };
+// ---- LDS-DMA variant of the 128x128 kernels ----------------------------------------------------
+// Timing-only ablations put the distance to the bare-MFMA rate on the register-staged
+// global loads.  Here the steady-state tiles go global -> LDS directly (global_load_lds_dwordx4: no
+// VGPR destination, no ds_write).  One instruction writes 1 KB = 8 rows x 128 B contiguously, so rows
+// cannot be padded; the ds_read_b128 bank conflicts of a 128-B row stride are removed by an XOR
+// swizzle of the 16-byte chunk index with (row >> 1) & 7, applied on the SOURCE address of the DMA and
+// on the fragment read address (linear destination; cdna_hip_programming.md 5.4 rule 21).  An m/n-
+// contiguous operand keeps its tile[k][128] image, unpadded (one instruction = 2 k rows x 512 B); its
+// per-step ds_read2_b32 reads are conflict free at any row stride.
+#ifndef BLM_GEMM_DMA
+#define BLM_GEMM_DMA 1
+#endif
+template <int OP, int WTM, int WTN, bool SAMP, bool FAST>
+constexpr bool use_dma() { return BLM_GEMM_DMA && WTM == 2 && WTN == 2 && !SAMP && FAST; }
+
+template <int R>
+__device__ __forceinline__ void r2s_kmaj_swz(float* tile, const float4 (&r)[R / 32]) {  // tile[row][32], chunk ^ ((row>>1)&7)
+  const int t = threadIdx.x, kq = t & 7, rr = t >> 3;
+#pragma unroll
+  for (int j = 0; j < R / 32; ++j) {
+    const int row = rr + 32 * j;
+    *reinterpret_cast<float4*>(tile + row * 32 + 4 * (kq ^ ((row >> 1) & 7))) = r[j];
+  }
+}
+
+// 16 bytes per lane, global -> LDS at lds_dst (wave uniform) + lane * 16; M0 is written in the same statement
+__device__ __forceinline__ void glds16(const float* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: half the address
+// data per instruction and no per-tile VALU address arithmetic (the K advance goes into the scalar base)
+__device__ __forceinline__ void glds16s(const float* sbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+template <int W> struct FragD {  // swizzled tile[row][32]: per-group byte addresses bt[t], MFMA tile i is 32 rows = 4096 B further
+  static constexpr int NREAD = W;
+  f32x4 v[W];
+  __device__ __forceinline__ void read(const uint32_t (&bt)[4], int t) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(v[i]) : "v"(bt[t] + (uint32_t)(4096 * i)));
+  }
+  __device__ __forceinline__ float get(int i, int s) const { return v[i][s]; }
+  __device__ __forceinline__ void tie() {
+#pragma unroll
+    for (int i = 0; i < W; ++i) asm volatile("" : "+v"(v[i]));
+  }
+};
+
 template <int N>
 __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
 
@@ -484,8 +538,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   // 2-way conflicting (free for ds_write_b32) AND even, so the interleaved two-tile operand read is an
   // aligned ds_read_b64; single-tile waves use BM+1 (conflict-free).  m/n-contiguous: BM+4 (b128 rows).
   // m/n-contiguous operands: image tile[k][BM+4]; k-contiguous ones: tile[row][KS]
-  constexpr int SA = BM + 4, SB = BN + 4;
-  constexpr int TA = A_KMAJ ? BM * KS : BK * SA, TB = B_KMAJ ? BN * KS : BK * SB;  // floats per staged tile
+  constexpr bool DMA = use_dma<OP, WTM, WTN, SAMP, FAST>();
+  constexpr int SA = BM + (DMA ? 0 : 4), SB = BN + (DMA ? 0 : 4);
+  constexpr int KSX = DMA ? 32 : KS;  // k-contiguous row stride: unpadded + swizzled under LDS-DMA
+  constexpr int TA = A_KMAJ ? BM * KSX : BK * SA, TB = B_KMAJ ? BN * KSX : BK * SB;  // floats per staged tile
   constexpr int NA = BM / 32, NB = BN / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const As = smem;
@@ -600,14 +656,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
         rb[j] = sample4(rb[j], rl[j], p.vb, p.vb_cols, srow, scol);
       }
     }
-    if constexpr (!A_KMAJ) {  // wgrad: A = dY[k][m]; its column sums are the bias gradient
+    if constexpr (!A_KMAJ && !DMA) {  // wgrad: A = dY[k][m]; its column sums are the bias gradient
       if (do_cs) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) { cs.x += ra[j].x; cs.y += ra[j].y; cs.z += ra[j].z; cs.w += ra[j].w; }
       }
     }
-    if constexpr (A_KMAJ) r2s_kmaj<BM>(At, ra); else r2s_nmaj<BM, SA>(At, ra);
-    if constexpr (B_KMAJ) r2s_kmaj<BN>(Bt, rb); else r2s_nmaj<BN, SB>(Bt, rb);
+    if constexpr (DMA) {
+      if constexpr (A_KMAJ) r2s_kmaj_swz<BM>(At, ra); else r2s_nmaj<BM, SA>(At, ra);
+      if constexpr (B_KMAJ) r2s_kmaj_swz<BN>(Bt, rb); else r2s_nmaj<BN, SB>(Bt, rb);
+    } else {
+      if constexpr (A_KMAJ) r2s_kmaj<BM>(At, ra); else r2s_nmaj<BM, SA>(At, ra);
+      if constexpr (B_KMAJ) r2s_kmaj<BN>(Bt, rb); else r2s_nmaj<BN, SB>(Bt, rb);
+    }
   };
 
   f32x16 acc[WTM][WTN];
@@ -658,6 +719,92 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     }
   };
 
+  // LDS-DMA path: fragment addresses of the swizzled tiles and the per-wave DMA sources
+  const int swz = (li >> 1) & 7;  // (row >> 1) & 7 of this lane's MFMA row (same for both 32-row tiles)
+  float cs1 = 0.f;                // LDS-DMA wgrad: this thread's column of the bias gradient (threads 0..BM-1)
+  auto compute_dma = [&](int cur) {
+    if constexpr (DMA) {
+      if constexpr (!A_KMAJ) {
+        if (do_cs && t < BM) {  // column sums of the A tile (= dY tile) straight from LDS
+          const float* col = As + cur * TA + t;
+#pragma unroll 8
+          for (int k = 0; k < BK; ++k) cs1 += col[k * SA];
+        }
+      }
+      using FA = typename std::conditional<A_KMAJ, FragD<2>, FragG<false, 2, SA>>::type;
+      using FB = typename std::conditional<B_KMAJ, FragD<2>, FragG<false, 2, SB>>::type;
+      uint32_t abt[4], bbt[4];
+      const uint32_t a0 = A_KMAJ ? lds_u32(As + cur * TA + (wm * 64 + li) * 32) : lds_u32(As + cur * TA + (4 * lh) * SA + wm * 64 + li);
+      const uint32_t b0 = B_KMAJ ? lds_u32(Bs + cur * TB + (wn * 64 + li) * 32) : lds_u32(Bs + cur * TB + (4 * lh) * SB + wn * 64 + li);
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const uint32_t ch = (uint32_t)(((2 * t4 + lh) ^ swz) * 16);
+        abt[t4] = a0 + ch;
+        bbt[t4] = b0 + ch;
+      }
+      auto rd_a = [&](FA& f, int t4) { if constexpr (A_KMAJ) f.read(abt, t4); else f.read(a0, t4); };
+      auto rd_b = [&](FB& f, int t4) { if constexpr (B_KMAJ) f.read(bbt, t4); else f.read(b0, t4); };
+      FA a[2];
+      FB b[2];
+      rd_a(a[0], 0);
+      rd_b(b[0], 0);
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        if (t4 + 1 < 4) {
+          rd_a(a[(t4 + 1) & 1], t4 + 1);
+          rd_b(b[(t4 + 1) & 1], t4 + 1);
+          wait_lgkm<FA::NREAD + FB::NREAD>();
+        } else {
+          wait_lgkm<0>();
+        }
+        a[t4 & 1].tie();
+        b[t4 & 1].tie();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t4 & 1].get(i, s4), b[t4 & 1].get(j, s4), acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  // wave w moves chunks 4w..4w+3 (1 KB each) of the A and of the B tile: 8 rows x 128 B of a k-contiguous
+  // operand (chunk index swizzled), 2 k rows x 512 B of an m/n-contiguous one
+  uint32_t dsa[4], dsb[4];  // per-lane byte offsets from the (K-advanced) scalar base; the host takes this path below 4 GB
+  if constexpr (DMA) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * wave + q;
+      if constexpr (A_KMAJ) {
+        const int row = 8 * c + (lane >> 3);
+        dsa[q] = (uint32_t)(((long)min(m0 + row, p.M - 1) * p.lda + 4 * ((lane & 7) ^ ((row >> 1) & 7))) * 4);
+      } else {
+        dsa[q] = (uint32_t)(((long)(2 * c + (lane >> 5)) * p.lda + min(m0 + 4 * (lane & 31), p.M - 4)) * 4);
+      }
+      if constexpr (B_KMAJ) {
+        const int row = 8 * c + (lane >> 3);
+        dsb[q] = (uint32_t)(((long)min(n0 + row, p.N - 1) * p.ldb + 4 * ((lane & 7) ^ ((row >> 1) & 7))) * 4);
+      } else {
+        dsb[q] = (uint32_t)(((long)(2 * c + (lane >> 5)) * p.ldb + min(n0 + 4 * (lane & 31), p.N - 4)) * 4);
+      }
+    }
+  }
+  auto dma_issue = [&](int buf, int ktile) {
+    if constexpr (DMA) {
+      const uint32_t la = __builtin_amdgcn_readfirstlane(lds_u32(As + buf * TA) + (uint32_t)(4 * wave) * 1024u);
+      const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_u32(Bs + buf * TB) + (uint32_t)(4 * wave) * 1024u);
+      const float* sa = p.A + (A_KMAJ ? (long)ktile * BK : (long)ktile * BK * p.lda);  // wave uniform: stays in SGPRs
+      const float* sb = p.B + (B_KMAJ ? (long)ktile * BK : (long)ktile * BK * p.ldb);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        glds16s(sa, dsa[q], la + 1024u * q);
+        glds16s(sb, dsb[q], lb + 1024u * q);
+      }
+    }
+  };
+
   // K tiles [t0, t1) of this block (split-K: a slice of K); tiles below K/BK are full
   const int kbeg = ks * p.kper, kend = min(p.K, kbeg + p.kper);
   const int t0 = kbeg / BK, t1 = (kend + BK - 1) / BK;
@@ -675,7 +822,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 #define BLM_PF_NOW(x)
 #define BLM_PF_ADD()
 #endif
-  if constexpr (FAST && !SAMP && WTM == 2 && WTN == 2) {  // smaller tiles: the second register set would cost them a workgroup per CU
+  if constexpr (DMA) {
+    // tile kt+1 travels global -> LDS (other buffer) while tile kt is multiplied; the counted wait
+    // retires this wave's DMA, the barrier everybody's, and also fences the reads of the buffer that the
+    // next iteration overwrites
+    for (; kt + 1 < tfull; ++kt) {
+      const int cur = (kt - t0) & 1;
+      dma_issue(cur ^ 1, kt + 1);
+      compute_dma(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else if constexpr (FAST && !SAMP && WTM == 2 && WTN == 2) {  // smaller tiles: the second register set would cost them a workgroup per CU
     // Steady state with the global loads TWO K tiles ahead (two register sets, LDS still double
     // buffered): tile kt+2 is requested before the MFMAs of tile kt, tile kt+1 -- requested one
     // iteration earlier -- is written to LDS after them.  In-kernel stamps on the one-tile-ahead loop
@@ -747,12 +905,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   for (; kt < t1; ++kt) {  // last full tile and/or the K tail
     const bool more = kt + 1 < t1;
     if (more) fetch_slow((kt + 1) * BK);
-    compute((kt - t0) & 1, [] {});
+    if constexpr (DMA) compute_dma((kt - t0) & 1); else compute((kt - t0) & 1, [] {});
     if (more) stash((kt + 1 - t0) & 1, (kt + 1) * BK, false);
     __syncthreads();
   }
 
-  if constexpr (!A_KMAJ) {
+  if constexpr (!A_KMAJ && DMA) {
+    if (do_cs && t < BM && m0 + t < p.M) atomicAdd(p.colsum_a + m0 + t, cs1 * p.alpha);
+  }
+  if constexpr (!A_KMAJ && !DMA) {
     if (do_cs) {  // reduce the per-thread partial column sums over the k-row groups through LDS
       constexpr int TPR = BM / 4, RPP = 256 / TPR;
       float* red = smem;  // all tiles consumed: the staging buffers are free
@@ -795,7 +956,9 @@ template <int OP, int WTM, int WTN, bool SAMP, bool FAST>
 static int launch_cfg(const GemmP& p, hipStream_t st) {
   constexpr int BM = 64 * WTM, BN = 64 * WTN;
   constexpr bool A_KMAJ = (OP != BLM_GEMM_TN), B_KMAJ = (OP == BLM_GEMM_NT);
-  constexpr int TA = A_KMAJ ? BM * KS : BK * (BM + 4), TB = B_KMAJ ? BN * KS : BK * (BN + 4);
+  constexpr bool DMAL = use_dma<OP, WTM, WTN, SAMP, FAST>();
+  constexpr int KSX = DMAL ? 32 : KS, PADL = DMAL ? 0 : 4;
+  constexpr int TA = A_KMAJ ? BM * KSX : BK * (BM + PADL), TB = B_KMAJ ? BN * KSX : BK * (BN + PADL);
   constexpr size_t lds = (size_t)2 * (TA + TB) * sizeof(float);
   GemmP q = p;
   q.gm = (p.M + BM - 1) / BM;
