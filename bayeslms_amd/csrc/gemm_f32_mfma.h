@@ -979,8 +979,20 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   // algorithmic 159 MB is W fetched once per XCD L2).  dgrad (NN) keeps the 2 slices: +4% in the step.
   const bool one_round_ok = OP == BLM_GEMM_NN ? nb < 384 : (nb < 256 || (nb < 384 && p.K > 8192));
   if (can_split && one_round_ok && p.K >= (small_out ? 512 : 2048)) {
-    splits = (int)((512 + nb - 1) / nb);
-    if (splits > 8 || nb <= 96) splits = 8;  // 8 slices = one per XCD: measured best for small output grids
+    if (nb <= 96) {
+      splits = 8;  // 8 slices = one per XCD: measured best for small output grids
+    } else {
+      // 512 workgroup slots (2 per CU): pick the slice count whose grid fills whole rounds of them --
+      // 144 tiles x 4 slices = 576 workgroups leave a second round 1/8 full (NN 2240x1024x33000: 75 TF),
+      // x 7 = 1008 fill two rounds; a small penalty per slice prefers the fewest slices among equals
+      double best = -1.0;
+      for (int sp = 1; sp <= 8; ++sp) {
+        if (sp > 1 && p.K / sp < min_k) break;
+        const long g = nb * sp, rounds = (g + 511) / 512;
+        const double u = (double)g / (double)(rounds * 512) - 0.01 * sp;
+        if (u > best + 1e-9) { best = u; splits = sp; }
+      }
+    }
     while (splits > 1 && p.K / splits < min_k) --splits;
   }
   // weight-gradient layout with a long reduction: 4 K slices even when the output grid alone fills the

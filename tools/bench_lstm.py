@@ -14,7 +14,7 @@ from bayeslms_amd.data import batchify, get_batch, synthetic_corpus  # noqa: E40
 
 
 def main():
-    V, H, T, B, steps, warm = 33000, 1024, 35, 64, 20, 8
+    V, H, T, B, steps, warm = 33000, 1024, 35, 64, int(os.environ.get("STEPS", "30")), int(os.environ.get("WARM", "30"))
     dev = torch.device("cuda:0")
     stream = synthetic_corpus(V, B * ((steps + warm) * T + 1) + 5, seed=1111)
     train = batchify(stream, B, dev)
