@@ -490,9 +490,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
     }
     __syncthreads();
     if (col < p.N) {
-      for (int lr = t / TPRW; lr < 64; lr += RPS) {
+      auto row_body = [&](int lr, const float4& a) {
         const int row = m0 + 64 * pass + lr;
-        if (row >= p.M) break;
         float4 v = *reinterpret_cast<const float4*>(stage + lr * SS + c4);
         const long o = (long)row * p.ldc + col;
         if constexpr (EPI == BLM_EPI_BIAS) {
@@ -515,12 +514,33 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
           v.w += bias.w; gelu_parts(v.w, cdf, e); d.w = (cdf + v.w * 0.3989422804014327f * e) * kp.w; v.w = v.w * cdf * kp.w;
           if (p.aux) *reinterpret_cast<float4*>(p.aux + o) = d;
         } else if constexpr (EPI == BLM_EPI_MUL_DGELU) {
-          const float4 a = *reinterpret_cast<const float4*>(p.aux + o);
           v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
         }
         float4* dst = reinterpret_cast<float4*>(p.C + o);
         if (accum) { const float4 old = *dst; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
         *dst = v;
+      };
+      if constexpr (EPI == BLM_EPI_MUL_DGELU) {
+        // the second factor of all this pass's rows is requested in one go (a load inside the row loop
+        // costs one full memory latency per row: 8 rows x 2 passes per tile)
+        constexpr int NIT = 64 / RPS;
+        float4 ax[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int row = m0 + 64 * pass + t / TPRW + RPS * i;
+          ax[i] = row < p.M ? *reinterpret_cast<const float4*>(p.aux + (long)row * p.ldc + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int lr = t / TPRW + RPS * i;
+          if (m0 + 64 * pass + lr < p.M) row_body(lr, ax[i]);
+        }
+      } else {
+        const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int lr = t / TPRW; lr < 64; lr += RPS) {
+          if (m0 + 64 * pass + lr >= p.M) break;
+          row_body(lr, none);
+        }
       }
     }
   }
