@@ -207,7 +207,7 @@ template <int S> struct FragG<false, 1, S> {
     for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(v[s]));
   }
 };
-// ---- LDS-DMA variant of the 128x128 kernels ----------------------------------------------------
+// ---- LDS-DMA loaders ----------------------------------------------------------------------------
 // Timing-only ablations put the distance to the bare-MFMA rate on the register-staged
 // global loads.  Here the steady-state tiles go global -> LDS directly (global_load_lds_dwordx4: no
 // VGPR destination, no ds_write).  One instruction writes 1 KB = 8 rows x 128 B contiguously, so rows
@@ -220,7 +220,7 @@ template <int S> struct FragG<false, 1, S> {
 #define BLM_GEMM_DMA 1
 #endif
 template <int OP, int WTM, int WTN, bool SAMP, bool FAST>
-constexpr bool use_dma() { return BLM_GEMM_DMA && WTM == 2 && WTN == 2 && !SAMP && FAST; }
+constexpr bool use_dma() { return BLM_GEMM_DMA && !SAMP && FAST; }
 
 template <int R>
 __device__ __forceinline__ void r2s_kmaj_swz(float* tile, const float4 (&r)[R / 32]) {  // tile[row][32], chunk ^ ((row>>1)&7)
@@ -751,11 +751,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
           for (int k = 0; k < BK; ++k) cs1 += col[k * SA];
         }
       }
-      using FA = typename std::conditional<A_KMAJ, FragD<2>, FragG<false, 2, SA>>::type;
-      using FB = typename std::conditional<B_KMAJ, FragD<2>, FragG<false, 2, SB>>::type;
+      using FA = typename std::conditional<A_KMAJ, FragD<WTM>, FragG<false, WTM, SA>>::type;
+      using FB = typename std::conditional<B_KMAJ, FragD<WTN>, FragG<false, WTN, SB>>::type;
       uint32_t abt[4], bbt[4];
-      const uint32_t a0 = A_KMAJ ? lds_u32(As + cur * TA + (wm * 64 + li) * 32) : lds_u32(As + cur * TA + (4 * lh) * SA + wm * 64 + li);
-      const uint32_t b0 = B_KMAJ ? lds_u32(Bs + cur * TB + (wn * 64 + li) * 32) : lds_u32(Bs + cur * TB + (4 * lh) * SB + wn * 64 + li);
+      const uint32_t a0 = A_KMAJ ? lds_u32(As + cur * TA + (wm * (32 * WTM) + li) * 32) : lds_u32(As + cur * TA + (4 * lh) * SA + wm * (32 * WTM) + li);
+      const uint32_t b0 = B_KMAJ ? lds_u32(Bs + cur * TB + (wn * (32 * WTN) + li) * 32) : lds_u32(Bs + cur * TB + (4 * lh) * SB + wn * (32 * WTN) + li);
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4) {
         const uint32_t ch = (uint32_t)(((2 * t4 + lh) ^ swz) * 16);
@@ -783,45 +783,51 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < WTM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < WTN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t4 & 1].get(i, s4), b[t4 & 1].get(j, s4), acc[i][j], 0, 0, 0);
       }
     }
   };
   // wave w moves chunks 4w..4w+3 (1 KB each) of the A and of the B tile: 8 rows x 128 B of a k-contiguous
   // operand (chunk index swizzled), 2 k rows x 512 B of an m/n-contiguous one
-  uint32_t dsa[4], dsb[4];  // per-lane byte offsets from the (K-advanced) scalar base; the host takes this path below 4 GB
+  // NQA / NQB chunks of 1 KB per wave and tile: dim / 32 (a tile of `dim` rows x 32 k or 32 k x `dim` columns is dim/8 KB)
+  constexpr int NQA = BM / 32, NQB = BN / 32;
+  uint32_t dsa[NQA], dsb[NQB];  // per-lane byte offsets from the (K-advanced) scalar base; the host takes this path below 4 GB
   if constexpr (DMA) {
+    constexpr int LPA = BM / 4, LPB = BN / 4;  // lanes per k row of an m/n-contiguous tile (rows per instruction: 64 / LP)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = 4 * wave + q;
+    for (int q = 0; q < NQA; ++q) {
+      const int c = NQA * wave + q;
       if constexpr (A_KMAJ) {
         const int row = 8 * c + (lane >> 3);
         dsa[q] = (uint32_t)(((long)min(m0 + row, p.M - 1) * p.lda + 4 * ((lane & 7) ^ ((row >> 1) & 7))) * 4);
       } else {
-        dsa[q] = (uint32_t)(((long)(2 * c + (lane >> 5)) * p.lda + min(m0 + 4 * (lane & 31), p.M - 4)) * 4);
+        dsa[q] = (uint32_t)(((long)((64 / LPA) * c + lane / LPA) * p.lda + min(m0 + 4 * (lane % LPA), p.M - 4)) * 4);
       }
+    }
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+      const int c = NQB * wave + q;
       if constexpr (B_KMAJ) {
         const int row = 8 * c + (lane >> 3);
         dsb[q] = (uint32_t)(((long)min(n0 + row, p.N - 1) * p.ldb + 4 * ((lane & 7) ^ ((row >> 1) & 7))) * 4);
       } else {
-        dsb[q] = (uint32_t)(((long)(2 * c + (lane >> 5)) * p.ldb + min(n0 + 4 * (lane & 31), p.N - 4)) * 4);
+        dsb[q] = (uint32_t)(((long)((64 / LPB) * c + lane / LPB) * p.ldb + min(n0 + 4 * (lane % LPB), p.N - 4)) * 4);
       }
     }
   }
   auto dma_issue = [&](int buf, int ktile) {
     if constexpr (DMA) {
-      const uint32_t la = __builtin_amdgcn_readfirstlane(lds_u32(As + buf * TA) + (uint32_t)(4 * wave) * 1024u);
-      const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_u32(Bs + buf * TB) + (uint32_t)(4 * wave) * 1024u);
+      const uint32_t la = __builtin_amdgcn_readfirstlane(lds_u32(As + buf * TA) + (uint32_t)(NQA * wave) * 1024u);
+      const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_u32(Bs + buf * TB) + (uint32_t)(NQB * wave) * 1024u);
       const float* sa = p.A + (A_KMAJ ? (long)ktile * BK : (long)ktile * BK * p.lda);  // wave uniform: stays in SGPRs
       const float* sb = p.B + (B_KMAJ ? (long)ktile * BK : (long)ktile * BK * p.ldb);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        glds16s(sa, dsa[q], la + 1024u * q);
-        glds16s(sb, dsb[q], lb + 1024u * q);
-      }
+      for (int q = 0; q < NQA; ++q) glds16s(sa, dsa[q], la + 1024u * q);
+#pragma unroll
+      for (int q = 0; q < NQB; ++q) glds16s(sb, dsb[q], lb + 1024u * q);
     }
   };
 
