@@ -472,7 +472,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
   const int col = n0 + c4;
   const bool accum = p.flags & BLM_GEMM_ACCUMULATE;
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (EPI == BLM_EPI_BIAS || EPI == BLM_EPI_BIAS_GELU)
+  if constexpr (EPI == BLM_EPI_BIAS || EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_GP_MIX)
     if (col < p.N) bias = *reinterpret_cast<const float4*>(p.bias + col);
 #pragma unroll
   for (int pass = 0; pass < NP; ++pass) {
@@ -490,22 +490,42 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
     }
     __syncthreads();
     if (col < p.N) {
+      auto keep4 = [&](int row) {  // dropout keep factors of this lane's 4 consecutive columns: one Philox block
+        float4 kp = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.drop_on) {
+          const int rr = row / p.drop_B, b = row - rr * p.drop_B;
+          const uint64_t g = ((uint64_t)rr * p.drop_global_cols + (uint64_t)(p.drop_col_offset + b)) * (uint64_t)p.N + (uint64_t)col;
+          const u32x4 u = philox4x32_10_rolled((uint32_t)(g >> 2), (uint32_t)(g >> 34), p.drop_rng.stream, p.drop_rng.step,
+                                               (uint32_t)p.drop_rng.seed, (uint32_t)(p.drop_rng.seed >> 32));
+          kp = make_float4(u.x >= p.drop_thr ? p.drop_inv_keep : 0.f, u.y >= p.drop_thr ? p.drop_inv_keep : 0.f,
+                           u.z >= p.drop_thr ? p.drop_inv_keep : 0.f, u.w >= p.drop_thr ? p.drop_inv_keep : 0.f);
+        }
+        return kp;
+      };
       auto row_body = [&](int lr, const float4& a) {
         const int row = m0 + 64 * pass + lr;
         float4 v = *reinterpret_cast<const float4*>(stage + lr * SS + c4);
         const long o = (long)row * p.ldc + col;
         if constexpr (EPI == BLM_EPI_BIAS) {
           v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        } else if constexpr (EPI == BLM_EPI_GP_MIX) {  // z = acc + bias kept for backward; out = mixture(z) * keep
+          const float4 kp = keep4(row);
+          v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+          if (p.aux) *reinterpret_cast<float4*>(p.aux + o) = v;
+          v.x = gp_mix(v.x, p.coef, p.N, col) * kp.x;
+          v.y = gp_mix(v.y, p.coef, p.N, col + 1) * kp.y;
+          v.z = gp_mix(v.z, p.coef, p.N, col + 2) * kp.z;
+          v.w = gp_mix(v.w, p.coef, p.N, col + 3) * kp.w;
+        } else if constexpr (EPI == BLM_EPI_MUL_DGP_MIX) {  // a = z of the forward; C2 = grad w.r.t. the mixture value
+          const float4 kp = keep4(row);
+          v.x *= kp.x; v.y *= kp.y; v.z *= kp.z; v.w *= kp.w;
+          if (p.C2) *reinterpret_cast<float4*>(p.C2 + o) = v;
+          v.x *= dgp_mix(a.x, p.coef, p.N, col);
+          v.y *= dgp_mix(a.y, p.coef, p.N, col + 1);
+          v.z *= dgp_mix(a.z, p.coef, p.N, col + 2);
+          v.w *= dgp_mix(a.w, p.coef, p.N, col + 3);
         } else if constexpr (EPI == BLM_EPI_BIAS_GELU) {
-          float4 kp = make_float4(1.f, 1.f, 1.f, 1.f);
-          if (p.drop_on) {
-            const int rr = row / p.drop_B, b = row - rr * p.drop_B;
-            const uint64_t g = ((uint64_t)rr * p.drop_global_cols + (uint64_t)(p.drop_col_offset + b)) * (uint64_t)p.N + (uint64_t)col;
-            const u32x4 u = philox4x32_10_rolled((uint32_t)(g >> 2), (uint32_t)(g >> 34), p.drop_rng.stream, p.drop_rng.step,
-                                                 (uint32_t)p.drop_rng.seed, (uint32_t)(p.drop_rng.seed >> 32));
-            kp = make_float4(u.x >= p.drop_thr ? p.drop_inv_keep : 0.f, u.y >= p.drop_thr ? p.drop_inv_keep : 0.f,
-                             u.z >= p.drop_thr ? p.drop_inv_keep : 0.f, u.w >= p.drop_thr ? p.drop_inv_keep : 0.f);
-          }
+          const float4 kp = keep4(row);
           float4 d;
           float cdf, e;
           v.x += bias.x; gelu_parts(v.x, cdf, e); d.x = (cdf + v.x * 0.3989422804014327f * e) * kp.x; v.x = v.x * cdf * kp.x;
@@ -520,7 +540,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
         if (accum) { const float4 old = *dst; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
         *dst = v;
       };
-      if constexpr (EPI == BLM_EPI_MUL_DGELU) {
+      if constexpr (EPI == BLM_EPI_MUL_DGELU || EPI == BLM_EPI_MUL_DGP_MIX) {
         // the second factor of all this pass's rows is requested in one go (a load inside the row loop
         // costs one full memory latency per row: 8 rows x 2 passes per tile)
         constexpr int NIT = 64 / RPS;
@@ -962,6 +982,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
       case BLM_EPI_BIAS: epilogue_rows<BLM_EPI_BIAS, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
       case BLM_EPI_BIAS_GELU: epilogue_rows<BLM_EPI_BIAS_GELU, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
       case BLM_EPI_MUL_DGELU: epilogue_rows<BLM_EPI_MUL_DGELU, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
+      case BLM_EPI_GP_MIX: epilogue_rows<BLM_EPI_GP_MIX, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
+      case BLM_EPI_MUL_DGP_MIX: epilogue_rows<BLM_EPI_MUL_DGP_MIX, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
       default: break;
     }
   }
@@ -1032,9 +1054,10 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   {
     static int off = -1, row_plain = -1;  // BLM_GEMM_ROW_EPI=0: register-layout epilogue everywhere; =1: rows only for the GELU epilogues (A/B knobs; default: rows for all four)
     if (off < 0) { const char* e = getenv("BLM_GEMM_ROW_EPI"); off = (e && atoi(e) == 0) ? 1 : 0; row_plain = (e && atoi(e) == 1) ? 0 : 1; }
-    const bool al = ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.aux) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
+    const bool al = ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.aux) | reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.C2)) & 15) == 0;
     q.vec_epi = !off && !q.atomic && al && p.N % 4 == 0 && p.ldc % 4 == 0 &&
-                (((p.epi == BLM_EPI_NONE || p.epi == BLM_EPI_BIAS) && row_plain) || p.epi == BLM_EPI_BIAS_GELU || p.epi == BLM_EPI_MUL_DGELU);
+                (((p.epi == BLM_EPI_NONE || p.epi == BLM_EPI_BIAS) && row_plain) || p.epi == BLM_EPI_BIAS_GELU || p.epi == BLM_EPI_MUL_DGELU ||
+                 p.epi == BLM_EPI_GP_MIX || p.epi == BLM_EPI_MUL_DGP_MIX);
   }
   if (q.atomic && !(p.flags & BLM_GEMM_ACCUMULATE))
     BLM_HIP(hipMemsetAsync(p.C, 0, (size_t)p.M * p.N * sizeof(float), st));

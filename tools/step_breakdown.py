@@ -14,10 +14,11 @@ def main():
     stream = synthetic_corpus(V, B * ((steps + 2) * T + 1) + 17, seed=1111)
     train = batchify(stream, B, dev)
     torch.manual_seed(1111)
-    model = M.BayesTransformerModel(V, D, H, FF, NL, 0.2, True, "FFN").to(dev)
+    gauss = len(sys.argv) > 1 and sys.argv[1] == "gauss"
+    model = (M.GaussTransformerModel(V, D, H, FF, NL, 0.2, True, 3) if gauss else M.BayesTransformerModel(V, D, H, FF, NL, 0.2, True, "FFN")).to(dev)
     tr = engine.Trainer(model, lr=0.1, clip=0.25, kl_scale=float(T) / train.size(0), seed=1111)
-    kl_fn = lambda mm: mm.transformerlayers[0].linear2.kl_divergence()
-    kl_fn.fusable = True
+    kl_fn = (lambda mm: mm.transformerlayers[0].gpnn.kl_divergence()) if gauss else (lambda mm: mm.transformerlayers[0].linear2.kl_divergence())
+    kl_fn.fusable = not gauss
     timer = ops.KernelTimer(all_gemms=True)
     for i in range(steps + 2):
         data, targets = get_batch(train, i * T, T)
