@@ -691,3 +691,66 @@ def test_full_size_cfg3_model_against_oracle(dev):
     for k in ("transformerlayers.0.linear2.weight_mean", "transformerlayers.0.linear2.weight_lgstd",
               "transformerlayers.3.linear1.weight"):
         assert grad_close(cur[k].grad, leaf[k].grad, rtol=1e-3, atol=1e-9), k
+
+
+# ------------------------------------------------------------------ BASELINE.json sizes
+def test_cfg3_full_size_matches_oracle_on_a_column_subset(dev):
+    """BASELINE configs[2] at its real size (6L d512 ff4096 h8 V33000, T128 B64 -> M = 8192 rows through
+    the production tiles): batch columns are independent, so the logits of the first 4 columns must
+    equal the CPU oracle run on those columns alone; eval mode and train mode with the sampled weight
+    (eps injected, dropout off).  Also: same (seed, step) -> bit-identical logits, next step -> not."""
+    from bayeslms_amd import model as M
+    from oracle import bayes_oracle as O
+    torch.manual_seed(1111)
+    V, T, B, C = 33000, 128, 64, 4
+    m = M.BayesTransformerModel(V, 512, 8, 4096, 6, 0.2, True, "FFN").to(dev)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    src = torch.randint(0, V, (T, B), generator=g)
+    m.eval()
+    with torch.no_grad():
+        e = m(src.to(dev))[:, :C].cpu()
+        ref = O.transformer_lm(src[:, :C], sd, 8, None)
+    assert rel(e, ref) < 1e-4
+    eps = torch.randn(512, 4096, generator=g)
+    m.train()
+    m.noise_state.dropout_off = True
+    m.transformerlayers[0].linear2.eps_override = eps.to(dev)
+    with torch.no_grad():
+        t = m(src.to(dev))[:, :C].cpu()
+        ref_t = O.transformer_lm(src[:, :C], sd, 8, eps)
+    assert rel(t, ref_t) < 1e-4
+    assert rel(t, ref) > 1e-4  # the noise is really in
+    m.transformerlayers[0].linear2.eps_override = None
+    m.noise_state.dropout_off = False
+    m.set_seed(5)
+    m.set_step(3)
+    with torch.no_grad():
+        a = m(src.to(dev))
+        b = m(src.to(dev))
+        m.set_step(4)
+        c = m(src.to(dev))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_cfg2_full_size_matches_oracle_on_a_column_subset(dev):
+    """BASELINE configs[1] at its real size (2x1024 LSTM, V33000, T35 B64): fused step kernels and the
+    decoder GEMMs at M = 2240; first 3 columns against the CPU oracle, eval mode, with a carried state."""
+    from bayeslms_amd import model as M
+    from oracle import bayes_oracle as O
+    torch.manual_seed(1111)
+    V, H, T, B, C = 33000, 1024, 35, 64, 3
+    m = M.BayesRNNModel("LSTM", V, H, H, 2, 0.2, True, 3).to(dev)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(10)
+    x1, x2 = torch.randint(0, V, (T, B), generator=g), torch.randint(0, V, (T, B), generator=g)
+    m.eval()
+    with torch.no_grad():
+        hid = m.init_hidden(B)
+        l1, hid = m(x1.to(dev), hid)
+        l2, hid = m(x2.to(dev), hid)
+        z = (torch.zeros(2, C, H), torch.zeros(2, C, H))
+        r1, hr = O.bayes_rnn_lm(x1[:, :C], z, sd, 3, None)
+        r2, hr = O.bayes_rnn_lm(x2[:, :C], hr, sd, 3, None)
+    assert rel(l1[:, :C], r1) < 1e-4 and rel(l2[:, :C], r2) < 1e-4
+    assert rel(hid[0][:, :C], hr[0]) < 1e-4 and rel(hid[1][:, :C], hr[1]) < 1e-4
