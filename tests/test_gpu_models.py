@@ -754,3 +754,42 @@ def test_cfg2_full_size_matches_oracle_on_a_column_subset(dev):
         r2, hr = O.bayes_rnn_lm(x2[:, :C], hr, sd, 3, None)
     assert rel(l1[:, :C], r1) < 1e-4 and rel(l2[:, :C], r2) < 1e-4
     assert rel(hid[0][:, :C], hr[0]) < 1e-4 and rel(hid[1][:, :C], hr[1]) < 1e-4
+
+
+def test_cfg3_full_model_backward_matches_oracle(dev):
+    """The cfg3 model at its real width/depth/vocabulary (B = 8 columns, T = 128 keep the CPU side at a few
+    seconds): train-mode loss with the sampled FFN weight (eps injected, dropout off) plus the KL term,
+    and every parameter gradient against the oracle's autograd -- the decoder GEMMs at K = 33000 /
+    N = 33000, the Bayesian wgrad epilogue at 512 x 4096, attention backward at T = 128."""
+    from bayeslms_amd import model as M, ops
+    from oracle import bayes_oracle as O
+    torch.manual_seed(1111)
+    V, T, B = 33000, 128, 8
+    m = M.BayesTransformerModel(V, 512, 8, 4096, 6, 0.2, True, "FFN").to(dev)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(19)
+    src = torch.randint(0, V, (T, B), generator=g)
+    tgt = torch.randint(0, V, (T * B,), generator=g)
+    eps = torch.randn(512, 4096, generator=g)
+    kl_scale = 0.01
+    m.train()
+    m.noise_state.dropout_off = True
+    m.transformerlayers[0].linear2.eps_override = eps.to(dev)
+    logits = m(src.to(dev))
+    mle, _ = ops.cross_entropy(logits.view(-1, V), tgt.to(dev))
+    kl = m.transformerlayers[0].linear2.kl_divergence()
+    (mle + kl * kl_scale).backward()
+    leaf = {k: v.clone().requires_grad_(v.dtype.is_floating_point and k != "pos_encoder.pe") for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    loss_r, mle_r, kl_r = O.transformer_train_loss(src, tgt, leaf, 8, "FFN", eps, kl_scale)
+    loss_r.backward()
+    assert abs(float(mle) - float(mle_r)) < 1e-4 * float(mle_r)
+    assert abs(float(kl) * kl_scale - float(kl_r)) < 1e-4 * abs(float(kl_r)) + 1e-9
+    checked = 0
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or leaf[k].grad is None:
+            continue
+        assert p.grad is not None, k
+        assert grad_close(p.grad, leaf[k].grad), k
+        checked += 1
+    assert checked > 70
