@@ -380,6 +380,66 @@ __global__ __launch_bounds__(TPB) void ce_kernel(const float* __restrict__ logit
   }
 }
 
+// Same result with the whole row held in registers: 1024 threads x NV float4 cover V <= 4096 NV logits, so
+// the row is read from HBM exactly once (the two-pass kernel above re-reads it for the gradient, and at
+// V = 33000 the 2048 rows in flight no longer fit L2/MALL: 3 passes over 1.08 GB instead of 2), and all
+// NV loads of a thread are in flight together.
+template <int NV>
+__global__ __launch_bounds__(1024) void ce_row_kernel(const float* __restrict__ logits, long ld, const int64_t* __restrict__ tgt,
+                                                      float* __restrict__ nll, float* __restrict__ lse_out,
+                                                      float* __restrict__ dlogits, float gscale, int V) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const float* x = logits + row * ld;
+  const int t0 = threadIdx.x * 4;
+  float4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = t0 + 4096 * i;
+    if (j + 3 < V) v[i] = *reinterpret_cast<const float4*>(x + j);
+    else {
+      v[i].x = j < V ? x[j] : -INFINITY;
+      v[i].y = j + 1 < V ? x[j + 1] : -INFINITY;
+      v[i].z = j + 2 < V ? x[j + 2] : -INFINITY;
+      v[i].w = -INFINITY;
+    }
+  }
+  const long t = tgt[row];
+  const bool valid = t >= 0 && t < V;
+  const float xt = valid ? x[t] : 0.f;
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+  const float M_ = block_max<16>(m, red);
+  float l = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) l += __expf(v[i].x - M_) + __expf(v[i].y - M_) + __expf(v[i].z - M_) + __expf(v[i].w - M_);
+  const float L_ = block_sum<16>(l, red);
+  const float lse = M_ + __logf(L_);
+  if (threadIdx.x == 0) {
+    nll[row] = valid ? lse - xt : 0.f;
+    if (lse_out) lse_out[row] = lse;
+  }
+  if (dlogits) {
+    float* d = dlogits + row * ld;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int j = t0 + 4096 * i;
+      float4 g = make_float4(__expf(v[i].x - lse) * gscale, __expf(v[i].y - lse) * gscale, __expf(v[i].z - lse) * gscale,
+                             __expf(v[i].w - lse) * gscale);
+      if (valid && t >= j && t < j + 4) {
+        if (t == j) g.x -= gscale; else if (t == j + 1) g.y -= gscale; else if (t == j + 2) g.z -= gscale; else g.w -= gscale;
+      }
+      if (j + 3 < V) *reinterpret_cast<float4*>(d + j) = g;
+      else {
+        if (j < V) d[j] = g.x;
+        if (j + 1 < V) d[j + 1] = g.y;
+        if (j + 2 < V) d[j + 2] = g.z;
+      }
+    }
+  }
+}
+
 // Two-model scoring (compute_sentence_scores_bayes_jianwei.py:157-168): NLL of the INTERPOLATED LOGITS
 // z = alpha * a + (1 - alpha) * b, one pass over both logit rows, z never stored.
 __global__ __launch_bounds__(TPB) void ce_interp_kernel(const float* __restrict__ la, const float* __restrict__ lb, long ld,
@@ -783,7 +843,15 @@ extern "C" int blm_ce_fwd_bwd(const float* logits, int64_t ld, const int64_t* tg
                               float* dlogits, float grad_scale, int M, int V, void* stream) {
   if (!logits || !tgt || !nll || M < 0 || V <= 0 || ld < V) return blm_fail(BLM_ERR_INVALID, "blm_ce_fwd_bwd: bad arguments");
   if (M == 0) return BLM_OK;
-  hipLaunchKernelGGL(ce_kernel, dim3(M), dim3(TPB), 0, ST, logits, (long)ld, tgt, nll, lse, dlogits, grad_scale, V);
+  const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0) && (!dlogits || (reinterpret_cast<uintptr_t>(dlogits) & 15) == 0);
+  if (vec && V <= 4096 * 3)
+    hipLaunchKernelGGL(ce_row_kernel<3>, dim3(M), dim3(1024), 0, ST, logits, (long)ld, tgt, nll, lse, dlogits, grad_scale, V);
+  else if (vec && V <= 4096 * 9)
+    hipLaunchKernelGGL(ce_row_kernel<9>, dim3(M), dim3(1024), 0, ST, logits, (long)ld, tgt, nll, lse, dlogits, grad_scale, V);
+  else if (vec && V <= 4096 * 16)
+    hipLaunchKernelGGL(ce_row_kernel<16>, dim3(M), dim3(1024), 0, ST, logits, (long)ld, tgt, nll, lse, dlogits, grad_scale, V);
+  else
+    hipLaunchKernelGGL(ce_kernel, dim3(M), dim3(TPB), 0, ST, logits, (long)ld, tgt, nll, lse, dlogits, grad_scale, V);
   BLM_HIP(hipGetLastError());
   if (loss_sum) {
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, ST, nll, (long)M, loss_sum);

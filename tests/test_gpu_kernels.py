@@ -397,7 +397,7 @@ def test_attention_dropout_uses_philox_mask(dev, T, B, nhead, hd):
     assert rel(qd.grad, qr.grad) < 2e-5
 
 
-@pytest.mark.parametrize("M,V", [(5, 7), (18, 50), (64, 33000), (3, 1001)])
+@pytest.mark.parametrize("M,V", [(5, 7), (18, 50), (64, 33000), (3, 1001), (9, 40), (4, 12288), (5, 12284), (3, 50000), (2, 70000)])
 def test_cross_entropy(dev, M, V):
     ops = ops_mod()
     g = torch.Generator().manual_seed(V)
