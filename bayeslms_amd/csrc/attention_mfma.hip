@@ -2,7 +2,7 @@
 // forward, dQ and dK/dV kernels, flash-style (no T x T matrix in HBM, probabilities recomputed in
 // backward from the saved log-sum-exp).
 //
-// Design (one workgroup of 2 waves per (batch column, head); K,V or Q,dO rows of the head sit in
+// Design (one workgroup of 4 waves per (batch column, head); K,V or Q,dO rows of the head sit in
 // LDS once, row-major with a 65-float stride so the same copy serves both operand shapes:
 // "lane = row, k = 2s + half" and "lane = feature, row fixed" are both conflict-free ds_read_b32):
 //  * The score tile is computed TRANSPOSED, S^T[key][query] = K Q^T, so the MFMA result has one
@@ -12,7 +12,8 @@
 //    register file (cdna_hip_programming.md section 3, "accumulator tile as the next MFMA's operand",
 //    here for the one-float-per-lane f32 operand map).
 //  * dK/dV use the other orientation (lane = key, queries in registers) for the same reason.
-//  * Causal work is balanced by giving each wave query (key) tiles {w, 3-w}.
+//  * One 32-query (32-key) tile per wave, the longest causal tile on the first wave: the kernels are
+//    latency- not MFMA-bound, so 4 unbalanced waves beat 2 waves with the balanced tile pairs {w, 3-w}.
 //  * Dropout on the probabilities: Philox bits keyed by the global element ((b*nhead+h)*T+q)*T+key;
 //    4 consecutive keys = one Philox block = 4 accumulator registers of a lane (query orientation)
 //    or a quad exchange (key orientation).
@@ -51,20 +52,22 @@ struct AttnM {
 // can put ALL of its prologue loads in flight before it waits on any of them: a 2-wave workgroup has
 // nothing else to hide the memory latency behind (PMC: waves of the first version were parked on
 // s_waitcnt for half of their lifetime).
-__device__ __forceinline__ void fetch_rows(float4 (&v)[16], const float* src, long ld, int T, int B, int b, int off) {
+template <int NT>
+__device__ __forceinline__ void fetch_rows(float4 (&v)[2048 / NT], const float* src, long ld, int T, int B, int b, int off) {
   const bool al = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)(ld * 4) | (uintptr_t)(off * 4)) & 15) == 0;
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int i = threadIdx.x + 128 * u, row = i >> 4, c = (i & 15) << 2;
+  for (int u = 0; u < 2048 / NT; ++u) {
+    const int i = threadIdx.x + NT * u, row = i >> 4, c = (i & 15) << 2;
     const float* s = src + ((long)min(row, T - 1) * B + b) * ld + off + c;
     if (al) v[u] = *reinterpret_cast<const float4*>(s);
     else v[u] = make_float4(s[0], s[1], s[2], s[3]);
   }
 }
-__device__ __forceinline__ void put_rows(float* dst, const float4 (&v)[16], int T, float mul) {
+template <int NT>
+__device__ __forceinline__ void put_rows(float* dst, const float4 (&v)[2048 / NT], int T, float mul) {
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int i = threadIdx.x + 128 * u, row = i >> 4, c = (i & 15) << 2;
+  for (int u = 0; u < 2048 / NT; ++u) {
+    const int i = threadIdx.x + NT * u, row = i >> 4, c = (i & 15) << 2;
     const float m = row < T ? mul : 0.f;
     float* d = dst + row * LS + c;
     d[0] = v[u].x * m; d[1] = v[u].y * m; d[2] = v[u].z * m; d[3] = v[u].w * m;
@@ -223,28 +226,29 @@ __device__ __forceinline__ void attn_fwd_pass(const AttnM& p, const float* Ks, c
   }
 }
 
-__global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(const AttnM p) {
+// 4 waves, one query tile each: the kernel is bound by its load -> compute -> store latency chain, not
+// by the matrix pipe (9 us of MFMA in 40), so twice the waves per workgroup (twice the loads in flight,
+// half the serial work per wave) beat the balanced two-tiles-per-wave split of the causal triangle.
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnM p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Ks = sm;
   float* Vs = sm + AT * LS;
   const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
   const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
   const int ntile = (T + 31) >> 5;
-  const int qt0 = wave, qt1 = 3 - wave;  // tiles {w, 3-w}: equal causal work per wave
-  float qa[32], qb[32];
+  const int qt = 3 - wave;  // the longest tile on the first wave
+  float qa[32];
   {
-    float4 kk[16], vv[16];
-    fetch_rows(kk, p.k, p.ld, T, p.B, b, off);
-    fetch_rows(vv, p.v, p.ld, T, p.B, b, off);
-    fetch_op(qa, p.q + ((long)min(32 * qt0 + li, T - 1) * p.B + b) * p.ld + off + 32 * lh);
-    put_rows(Ks, kk, T, 1.f);
-    put_rows(Vs, vv, T, 1.f);
-    fetch_op(qb, p.q + ((long)min(32 * qt1 + li, T - 1) * p.B + b) * p.ld + off + 32 * lh);
+    float4 kk[8], vv[8];
+    fetch_rows<256>(kk, p.k, p.ld, T, p.B, b, off);
+    fetch_rows<256>(vv, p.v, p.ld, T, p.B, b, off);
+    fetch_op(qa, p.q + ((long)min(32 * qt + li, T - 1) * p.B + b) * p.ld + off + 32 * lh);
+    put_rows<256>(Ks, kk, T, 1.f);
+    put_rows<256>(Vs, vv, T, 1.f);
   }
   __syncthreads();
   const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
-  if (qt0 < ntile) attn_fwd_pass(p, Ks, Vs, qt0, qa, b, off, bh, li, lh);
-  if (qt1 < ntile) attn_fwd_pass(p, Ks, Vs, qt1, qb, b, off, bh, li, lh);
+  if (qt < ntile) attn_fwd_pass(p, Ks, Vs, qt, qa, b, off, bh, li, lh);
 }
 
 // ------------------------------------------------------------------ backward: dQ (lane = query)
@@ -278,7 +282,7 @@ __device__ __forceinline__ void attn_dq_pass(const AttnM& p, const float* Ks, co
   if (q < T) store_t(p.dq + ((long)q * p.B + b) * p.ldd + off, dqt, lh, p.scale);
 }
 
-__global__ __launch_bounds__(128) void attn_bwd_dq_mfma_kernel(const AttnM p) {
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnM p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Ks = sm;
   float* Vs = sm + AT * LS;
@@ -286,32 +290,26 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_mfma_kernel(const AttnM p) {
   const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
   const long dmodel = (long)p.nhead * HD;
   const int ntile = (T + 31) >> 5;
-  const int qt0 = wave, qt1 = 3 - wave;
-  float qa[32], da[32], qb[32], db[32];
-  float delta0 = 0.f, delta1 = 0.f;
+  const int qt = 3 - wave;  // one query tile per wave, the longest first
+  float qa[32], da[32];
+  float delta = 0.f;
   {
-    const long r0 = (long)min(32 * qt0 + li, T - 1) * p.B + b, r1 = (long)min(32 * qt1 + li, T - 1) * p.B + b;
-    float4 kk[16], vv[16];
+    const long r0 = (long)min(32 * qt + li, T - 1) * p.B + b;
+    float4 kk[8], vv[8];
     float oa[32];
-    fetch_rows(kk, p.k, p.ld, T, p.B, b, off);
-    fetch_rows(vv, p.v, p.ld, T, p.B, b, off);
+    fetch_rows<256>(kk, p.k, p.ld, T, p.B, b, off);
+    fetch_rows<256>(vv, p.v, p.ld, T, p.B, b, off);
     fetch_op(qa, p.q + r0 * p.ld + off + 32 * lh);
     fetch_op(da, p.dout + r0 * dmodel + off + 32 * lh);
     fetch_op(oa, p.o_in + r0 * dmodel + off + 32 * lh);
-    put_rows(Ks, kk, T, 1.f);
-    put_rows(Vs, vv, T, 1.f);
+    put_rows<256>(Ks, kk, T, 1.f);
+    put_rows<256>(Vs, vv, T, 1.f);
 #pragma unroll
-    for (int s = 0; s < 32; ++s) delta0 += da[s] * oa[s];
-    fetch_op(qb, p.q + r1 * p.ld + off + 32 * lh);
-    fetch_op(db, p.dout + r1 * dmodel + off + 32 * lh);
-    fetch_op(oa, p.o_in + r1 * dmodel + off + 32 * lh);
-#pragma unroll
-    for (int s = 0; s < 32; ++s) delta1 += db[s] * oa[s];
+    for (int s = 0; s < 32; ++s) delta += da[s] * oa[s];
   }
   __syncthreads();
   const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
-  if (qt0 < ntile) attn_dq_pass(p, Ks, Vs, qt0, qa, da, delta0, b, off, bh, li, lh);
-  if (qt1 < ntile) attn_dq_pass(p, Ks, Vs, qt1, qb, db, delta1, b, off, bh, li, lh);
+  if (qt < ntile) attn_dq_pass(p, Ks, Vs, qt, qa, da, delta, b, off, bh, li, lh);
 }
 
 // ------------------------------------------------------------------ backward: dK, dV (lane = key)
@@ -371,7 +369,7 @@ __device__ __forceinline__ void attn_dkv_pass(const AttnM& p, const float* Qs, c
   }
 }
 
-__global__ __launch_bounds__(128) void attn_bwd_dkv_mfma_kernel(const AttnM p) {
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnM p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Qs = sm;               // Q * scale
   float* Os = sm + AT * LS;     // dO
@@ -381,46 +379,42 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_mfma_kernel(const AttnM p) {
   const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
   const long dmodel = (long)p.nhead * HD;
   const int ntile = (T + 31) >> 5;
-  const int kt0 = wave, kt1 = 3 - wave;  // key tile kt meets query tiles kt..ntile-1: {w, 3-w} balances
-  float ka[32], va[32], kb[32], vb[32];
+  const int kt = wave;  // key tile kt meets query tiles kt..ntile-1: one per wave, the longest first
+  float ka[32], va[32];
   {
-    const long r0 = (long)min(32 * kt0 + li, T - 1) * p.B + b;
-    float4 qq[16], dd[16];
-    fetch_rows(qq, p.q, p.ld, T, p.B, b, off);
-    fetch_rows(dd, p.dout, dmodel, T, p.B, b, off);
+    const long r0 = (long)min(32 * kt + li, T - 1) * p.B + b;
+    float4 qq[8], dd[8];
+    fetch_rows<256>(qq, p.q, p.ld, T, p.B, b, off);
+    fetch_rows<256>(dd, p.dout, dmodel, T, p.B, b, off);
     fetch_op(ka, p.k + r0 * p.ld + off + 32 * lh);
     fetch_op(va, p.v + r0 * p.ld + off + 32 * lh);
-    put_rows(Qs, qq, T, p.scale);
-    put_rows(Os, dd, T, 1.f);
+    put_rows<256>(Qs, qq, T, p.scale);
+    put_rows<256>(Os, dd, T, 1.f);
   }
-  {  // delta[q] = rowsum(dO * O), lse[q]: thread = row, 2 x 16 float4 in flight, then this wave's second K/V tile
-    const int row = threadIdx.x, rc = min(row, T - 1);
-    const float* ds = p.dout + ((long)rc * p.B + b) * dmodel + off;
-    const float* os = p.o_in + ((long)rc * p.B + b) * dmodel + off;
+  {  // delta[q] = rowsum(dO * O), lse[q]: two threads per row (half a row each, 2 x 8 float4 in flight)
+    const int row = threadIdx.x >> 1, half = threadIdx.x & 1, rc = min(row, T - 1);
+    const float* ds = p.dout + ((long)rc * p.B + b) * dmodel + off + (HD / 2) * half;
+    const float* os = p.o_in + ((long)rc * p.B + b) * dmodel + off + (HD / 2) * half;
     const float ls = p.lse[(long)blockIdx.x * T + rc];
     float d = 0.f;
     if ((((uintptr_t)ds | (uintptr_t)os) & 15) == 0) {
-      float4 dv4[HD / 4], ov4[HD / 4];
+      float4 dv4[HD / 8], ov4[HD / 8];
 #pragma unroll
-      for (int c = 0; c < HD / 4; ++c) { dv4[c] = reinterpret_cast<const float4*>(ds)[c]; ov4[c] = reinterpret_cast<const float4*>(os)[c]; }
-      const long r1 = (long)min(32 * kt1 + li, T - 1) * p.B + b;
-      fetch_op(kb, p.k + r1 * p.ld + off + 32 * lh);
-      fetch_op(vb, p.v + r1 * p.ld + off + 32 * lh);
+      for (int c = 0; c < HD / 8; ++c) { dv4[c] = reinterpret_cast<const float4*>(ds)[c]; ov4[c] = reinterpret_cast<const float4*>(os)[c]; }
 #pragma unroll
-      for (int c = 0; c < HD / 4; ++c) d += dv4[c].x * ov4[c].x + dv4[c].y * ov4[c].y + dv4[c].z * ov4[c].z + dv4[c].w * ov4[c].w;
+      for (int c = 0; c < HD / 8; ++c) d += dv4[c].x * ov4[c].x + dv4[c].y * ov4[c].y + dv4[c].z * ov4[c].z + dv4[c].w * ov4[c].w;
     } else {
-      const long r1 = (long)min(32 * kt1 + li, T - 1) * p.B + b;
-      fetch_op(kb, p.k + r1 * p.ld + off + 32 * lh);
-      fetch_op(vb, p.v + r1 * p.ld + off + 32 * lh);
-      for (int c = 0; c < HD; ++c) d += ds[c] * os[c];
+      for (int c = 0; c < HD / 2; ++c) d += ds[c] * os[c];
     }
-    lse_s[row] = row < T ? ls : 0.f;
-    del_s[row] = row < T ? d : 0.f;
+    d += __shfl_xor(d, 1);
+    if (half == 0) {
+      lse_s[row] = row < T ? ls : 0.f;
+      del_s[row] = row < T ? d : 0.f;
+    }
   }
   __syncthreads();
   const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
-  if (kt0 < ntile) attn_dkv_pass(p, Qs, Os, lse_s, del_s, kt0, ntile, ka, va, b, off, bh, lane, li, lh);
-  if (kt1 < ntile) attn_dkv_pass(p, Qs, Os, lse_s, del_s, kt1, ntile, kb, vb, b, off, bh, lane, li, lh);
+  if (kt < ntile) attn_dkv_pass(p, Qs, Os, lse_s, del_s, kt, ntile, ka, va, b, off, bh, lane, li, lh);
 }
 
 }  // namespace blm
@@ -453,7 +447,7 @@ int blm_attn_fwd_mfma(const float* q, const float* k, const float* v, int64_t ld
   const size_t lds = (size_t)2 * AT * LS * sizeof(float);
   static bool once = false;
   if (!once) { int rc = set_lds(attn_fwd_mfma_kernel, lds); if (rc) return rc; once = true; }
-  hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * nhead), dim3(128), lds, st, p);
+  hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * nhead), dim3(256), lds, st, p);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }
@@ -474,9 +468,9 @@ int blm_attn_bwd_mfma(const float* q, const float* k, const float* v, int64_t ld
     if (rc) return rc;
     once = true;
   }
-  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(B * nhead), dim3(128), lds1, st, p);
+  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(B * nhead), dim3(256), lds1, st, p);
   BLM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(B * nhead), dim3(128), lds2, st, p);
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(B * nhead), dim3(256), lds2, st, p);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }
