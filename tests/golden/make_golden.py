@@ -553,9 +553,179 @@ def f5_gauss_rnn_gpnn2():
              cells=np.array(cells, dtype=np.int64), **kw, **pack_sd(m), **grads(m))
 
 
+# ---------------------------------------------------------------- F9 architecture search
+def _load_search():
+    """model_search_bayes.py / architect.py call ``.cuda()`` on sub-modules while building
+    (model_search_bayes.py:99,258); with no GPU here the harness maps ``.cuda()`` to identity."""
+    torch.nn.Module.cuda = lambda self, device=None: self
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    with contextlib.redirect_stdout(io.StringIO()):
+        import model_search_bayes as S
+        import architect as A
+    return S, A
+
+
+def _gp_eps(layer):
+    g = layer.gpnn
+    return {"coef": npy(g.coef_sample), "weights": npy(g.weights_sample), "bias": npy(g.bias_sample)}
+
+
+def f9_search_models():
+    """One forward/backward of the two super-nets train_search_bayes.py builds (:158-163)."""
+    S, _ = _load_search()
+    V, d, h, ff, L, T, B = 50, 16, 4, 32, 2, 6, 3
+    for sample in (False, True):
+        torch.manual_seed(301 + sample)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = S.GaussTransModelSearch(V, d, h, ff, L, 0.0, True)
+        m.weights.data.copy_(torch.randn(L, 1, 2) * 0.7)
+        src = torch.randint(0, V, (T, B))
+        tgt = torch.randint(0, V, (T * B,))
+        m.train()
+        for lyr in m.transformerlayers:
+            lyr.gpnn.sample = sample
+        logits = m(src)
+        kw = {}
+        for i, lyr in enumerate(m.transformerlayers):  # the eps of THIS forward (layer forward redraws first, :232-233)
+            for k, v in _gp_eps(lyr).items():
+                kw["eps_%d_%s" % (i, k)] = v
+        mle = torch.nn.functional.cross_entropy(logits.view(-1, V), tgt)
+        kl = sum(lyr.gpnn.kl_divergence() for lyr in m.transformerlayers)
+        (mle + kl * 0.05).backward()
+        m.eval()
+        with torch.no_grad():
+            logits_eval = m(src)
+        save("search_gauss_tlm_%d" % sample, src=npy(src), tgt=npy(tgt), nhead=np.int64(h), kl_scale=np.float32(0.05),
+             arch=npy(m.weights), arch_grad=npy(m.weights.grad), logits_train=npy(logits), logits_eval=npy(logits_eval),
+             mle=npy(mle), kl=npy(kl), **kw, **pack_sd(m), **grads(m))
+    V, H, T, B = 40, 12, 5, 3
+    for sample in (False, True):
+        torch.manual_seed(311 + sample)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = S.BayesLSTMModelSearch("LSTM", V, H, H, 2, 0.0, True)
+        m.weights.data.copy_(torch.randn(2, 4, 2) * 0.7)
+        x1, x2 = torch.randint(0, V, (T, B)), torch.randint(0, V, (T, B))
+        tgt = torch.randint(0, V, (T * B,))
+        m.train()
+        gates = ("ingate", "forgate", "cellgate", "outgate")
+        for c in m.rnn.rnn:
+            for g in gates:
+                getattr(c, "bayes_" + g).sample = sample
+        hid = m.init_hidden(B)
+        l1, hid = m(x1, hid)
+        hid = tuple(t.detach() for t in hid)
+        l2, hid = m(x2, hid)
+        kw = {}
+        for ci, c in enumerate(m.rnn.rnn):  # eps of the SECOND window (cell forward redraws first, :662-665)
+            for g in gates:
+                b = getattr(c, "bayes_" + g)
+                kw["eps_%d_%s_w" % (ci, g)] = npy(b.weights_sample)
+                kw["eps_%d_%s_b" % (ci, g)] = npy(b.bias_sample)
+        mle = torch.nn.functional.cross_entropy(l2.view(-1, V), tgt)
+        kl = torch.zeros(())
+        for c in m.rnn.rnn:  # train_search_bayes.py:312-318 evaluates the KL with sample = True
+            for g in gates:
+                b = getattr(c, "bayes_" + g)
+                old, b.sample = b.sample, True
+                kl = kl + b.kl_divergence()
+                b.sample = old
+        (mle + kl * 0.07).backward()
+        m.eval()
+        with torch.no_grad():
+            hid = m.init_hidden(B)
+            e1, hid = m(x1, hid)
+            e2, hid = m(x2, hid)
+        save("search_bayes_lstm_%d" % sample, x1=npy(x1), x2=npy(x2), tgt=npy(tgt), kl_scale=np.float32(0.07),
+             arch=npy(m.weights), arch_grad=npy(m.weights.grad), logits_train_1=npy(l2), mle=npy(mle), kl=npy(kl),
+             logits_eval_0=npy(e1), logits_eval_1=npy(e2), h_eval=npy(hid[0]), c_eval=npy(hid[1]), **kw, **pack_sd(m),
+             **grads(m))
+
+
+def f9_search_loop():
+    """The alternating loop of train_search_bayes.py:203-290 (first-order Architect step on a validation
+    window, then the SGD(momentum 0.9, weight_decay 1e-5) network step), driven with the reference's own
+    Architect and model classes for a few windows; every quantity at full precision."""
+    import types
+    S, A = _load_search()
+    nsteps, T, B, lr, clip = 6, 6, 3, 0.5, 1.0
+    for kind in ("tlm", "lstm"):
+        torch.manual_seed(321)
+        V = 40
+        with contextlib.redirect_stdout(io.StringIO()):
+            if kind == "tlm":
+                m = S.GaussTransModelSearch(V, 16, 4, 32, 2, 0.0, True)
+            else:
+                m = S.BayesLSTMModelSearch("LSTM", V, 12, 12, 2, 0.0, True)
+        args = types.SimpleNamespace(wdecay=5e-7, clip=clip, arch_lr=3e-3, arch_wdecay=1e-3)
+        arch = A.Architect(m, V, args)
+        opt = torch.optim.SGD(m.parameters(), lr=lr, momentum=0.9, weight_decay=1e-5)
+        train = torch.randint(0, V, (nsteps * T + 1, B))
+        valid = torch.randint(0, V, (nsteps * T + 1, B))
+        kw = {"init/" + k: (npy(v)[:64] if k.endswith("pos_encoder.pe") else npy(v)).copy() for k, v in m.state_dict().items()}
+        kw["arch_init"] = npy(m.weights).copy()
+        kl_scale = 0.01
+        gates = ("ingate", "forgate", "cellgate", "outgate")
+        m.train()
+        if kind == "lstm":
+            hidden = m.init_hidden(B)
+            hidden_valid = m.init_hidden(B)
+        losses, kls, archs = [], [], []
+        for s in range(nsteps):
+            data, tg = train[s * T:(s + 1) * T], train[s * T + 1:(s + 1) * T + 1].reshape(-1)
+            dv, tv = valid[s * T:(s + 1) * T], valid[s * T + 1:(s + 1) * T + 1].reshape(-1)
+            opt.zero_grad()
+            if kind == "tlm":
+                arch.step(data, tg, dv, tv, opt, False)
+            else:
+                arch.step(data, tg, dv, tv, opt, False, hidden_valid)
+            archs.append(npy(m.weights).copy())
+            opt.zero_grad()
+            if kind == "tlm":
+                for lyr in m.transformerlayers:
+                    lyr.gpnn.sample = True
+                out = m(data)
+                for i, lyr in enumerate(m.transformerlayers):
+                    for k, v in _gp_eps(lyr).items():
+                        kw["eps_%d_%d_%s" % (s, i, k)] = v
+                kl = sum(lyr.gpnn.kl_divergence() for lyr in m.transformerlayers) * kl_scale  # --T_bayes_pos FFN
+                for lyr in m.transformerlayers:
+                    lyr.gpnn.sample = False
+            else:
+                hidden = tuple(t.detach() for t in hidden)
+                out, hidden = m(data, hidden)
+                kl = torch.zeros(())
+                for c in m.rnn.rnn:  # --L_bayes_pos > 0
+                    for g in gates:
+                        b = getattr(c, "bayes_" + g)
+                        b.sample = True
+                        kl = kl + b.kl_divergence() * kl_scale
+                        b.sample = False
+            mle = torch.nn.functional.cross_entropy(out.view(-1, V), tg)
+            (mle + kl).backward()
+            torch.nn.utils.clip_grad_norm_(m.parameters(), clip)
+            opt.step()
+            losses.append(float(mle.detach()))
+            kls.append(float(kl.detach()))
+        m.eval()
+        with torch.no_grad():
+            if kind == "tlm":
+                ev = m(valid[:T])
+            else:
+                ev, _ = m(valid[:T], m.init_hidden(B))
+        save("search_loop_" + kind, train=npy(train), valid=npy(valid), nhead=np.int64(4), lr=np.float64(lr),
+             clip=np.float64(clip), kl_scale=np.float64(kl_scale), T=np.int64(T), mle=np.array(losses), kl=np.array(kls),
+             arch_after=np.stack(archs), logits_eval=npy(ev), **kw, **pack_sd(m))
+
+
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rnnv":
         f5_gauss_variational_rnn()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "search":
+        f9_search_models()
+        f9_search_loop()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "rnn_gpnn2":
         f5_gauss_rnn_gpnn2()
@@ -588,3 +758,5 @@ if __name__ == "__main__":
     f7_scorer_interp()
     f4_gauss_transformer4()
     f5_gauss_rnn_gpnn2()
+    f9_search_models()
+    f9_search_loop()
