@@ -88,6 +88,14 @@ SIGNATURES = {
     "blm_gp_mix_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "blm_add_rowvec": (_i, [_vp, _vp, _i, _i, _vp]),
     "blm_axpy": (_i, [_vp, _vp, _i64, _f, _vp]),
+    "blm_mix2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
+    "blm_mix2_partials": (_i64, [_i, _i, _i]),
+    "blm_mix2_bwd": (_i, [_vp] * 8 + [_i, _i, _i, _f, _rngp, _i, _i, _vp]),
+    "blm_lstm_search_cell_fwd": (_i, [_vp] * 7 + [_i, _i, _vp]),
+    "blm_lstm_search_cell_partials": (_i64, [_i, _i]),
+    "blm_lstm_search_cell_bwd": (_i, [_vp] * 10 + [_i, _i, _vp]),
+    "blm_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp]),
+    "blm_clip_sgd_multi_wd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _i, _f, _f, _vp]),
 }
 
 _lib = None

@@ -6,46 +6,11 @@
 // tensor, so a data-parallel run that shards columns reproduces the single-process mask.
 #include "blm_device.h"
 #include "blm_host.h"
+#include "blm_dropkey.h"
 
 namespace blm {
 
 constexpr int TPB = 256;
-
-struct DropKey {
-  blm_rng rng;
-  uint32_t thr;    // drop iff bits < thr
-  float inv_keep;  // 1/(1-p)
-  int B, D, col_offset, global_cols;
-  bool on;
-};
-
-__host__ static DropKey make_key(float p, const blm_rng* rng, int B, int D, int col_offset, int global_cols) {
-  DropKey k{};
-  k.on = p > 0.f && rng != nullptr;
-  if (k.on) k.rng = *rng;
-  const double t = (double)p * 4294967296.0;
-  k.thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
-  k.inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
-  k.B = B; k.D = D; k.col_offset = col_offset; k.global_cols = global_cols > 0 ? global_cols : B;
-  return k;
-}
-
-// Scale factors (0 or 1/(1-p)) for the 4 consecutive features j..j+3 (j % 4 == 0, D % 4 == 0) of local (row, b).
-__device__ __forceinline__ float4 keep4(const DropKey& k, int row, int b, int j) {
-  if (!k.on) return make_float4(1.f, 1.f, 1.f, 1.f);
-  const uint64_t g = ((uint64_t)row * k.global_cols + (uint64_t)(k.col_offset + b)) * (uint64_t)k.D + (uint64_t)j;
-  const u32x4 u = philox_block(k.rng, g >> 2);
-  return make_float4(u.x >= k.thr ? k.inv_keep : 0.f, u.y >= k.thr ? k.inv_keep : 0.f,
-                     u.z >= k.thr ? k.inv_keep : 0.f, u.w >= k.thr ? k.inv_keep : 0.f);
-}
-__device__ __forceinline__ float keep1(const DropKey& k, int row, int b, int j) {
-  if (!k.on) return 1.f;
-  const uint64_t g = ((uint64_t)row * k.global_cols + (uint64_t)(k.col_offset + b)) * (uint64_t)k.D + (uint64_t)j;
-  const u32x4 u = philox_block(k.rng, g >> 2);
-  const int c = (int)(g & 3);
-  const uint32_t bits = c == 0 ? u.x : (c == 1 ? u.y : (c == 2 ? u.z : u.w));
-  return bits >= k.thr ? k.inv_keep : 0.f;
-}
 
 // ------------------------------------------------------------------ embedding
 // one wave per (t,b) row, 4 rows per block
@@ -575,9 +540,11 @@ __global__ __launch_bounds__(TPB) void sqnorm_multi_kernel(const float* const* g
   if (threadIdx.x == 0) ws[(long)blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
+// WD: torch.optim.SGD(weight_decay) semantics, g' = c*g + wd*p after the clip (train_search_bayes.py:391-392)
+template <bool WD>
 __global__ __launch_bounds__(TPB) void clip_sgd_multi_kernel(float* const* params, const float* const* grads,
                                                              float* const* bufs, const int64_t* sizes, const float* sq,
-                                                             float clip, float lr, float mom, int first, float gs) {
+                                                             float clip, float lr, float mom, int first, float gs, float wd) {
   float* p = params[blockIdx.y];
   const float* g = grads[blockIdx.y];
   float* m = bufs[blockIdx.y];
@@ -591,13 +558,18 @@ __global__ __launch_bounds__(TPB) void clip_sgd_multi_kernel(float* const* param
     const float4 gv = reinterpret_cast<const float4*>(g)[i];
     float4 mv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(m)[i];
     float4 pv = reinterpret_cast<float4*>(p)[i];
-    mv.x = mom * mv.x + c * gv.x; mv.y = mom * mv.y + c * gv.y; mv.z = mom * mv.z + c * gv.z; mv.w = mom * mv.w + c * gv.w;
+    if (WD) {
+      mv.x = mom * mv.x + (c * gv.x + wd * pv.x); mv.y = mom * mv.y + (c * gv.y + wd * pv.y);
+      mv.z = mom * mv.z + (c * gv.z + wd * pv.z); mv.w = mom * mv.w + (c * gv.w + wd * pv.w);
+    } else {
+      mv.x = mom * mv.x + c * gv.x; mv.y = mom * mv.y + c * gv.y; mv.z = mom * mv.z + c * gv.z; mv.w = mom * mv.w + c * gv.w;
+    }
     pv.x -= lr * mv.x; pv.y -= lr * mv.y; pv.z -= lr * mv.z; pv.w -= lr * mv.w;
     reinterpret_cast<float4*>(m)[i] = mv;
     reinterpret_cast<float4*>(p)[i] = pv;
   }
   for (long i = (n4 << 2) + (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
-    const float mv = (first ? 0.f : mom * m[i]) + c * g[i];
+    const float mv = (first ? 0.f : mom * m[i]) + (WD ? c * g[i] + wd * p[i] : c * g[i]);
     m[i] = mv;
     p[i] -= lr * mv;
   }
@@ -910,8 +882,19 @@ extern "C" int blm_clip_sgd_multi(float* const* params, const float* const* grad
                                   int first, float grad_scale, void* stream) {
   if (!params || !grads || !bufs || !sizes || !sq || n < 0) return blm_fail(BLM_ERR_INVALID, "blm_clip_sgd_multi: bad arguments");
   if (n == 0) return BLM_OK;
-  hipLaunchKernelGGL(clip_sgd_multi_kernel, dim3(n == 1 ? 2048 : 64, n), dim3(TPB), 0, ST, params, grads, bufs, sizes, sq,
-                     clip, lr, momentum, first, grad_scale);
+  hipLaunchKernelGGL(clip_sgd_multi_kernel<false>, dim3(n == 1 ? 2048 : 64, n), dim3(TPB), 0, ST, params, grads, bufs, sizes,
+                     sq, clip, lr, momentum, first, grad_scale, 0.f);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_clip_sgd_multi_wd(float* const* params, const float* const* grads, float* const* bufs,
+                                     const int64_t* sizes, int n, const float* sq, float clip, float lr, float momentum,
+                                     int first, float grad_scale, float weight_decay, void* stream) {
+  if (!params || !grads || !bufs || !sizes || !sq || n < 0) return blm_fail(BLM_ERR_INVALID, "blm_clip_sgd_multi_wd: bad arguments");
+  if (n == 0) return BLM_OK;
+  hipLaunchKernelGGL(clip_sgd_multi_kernel<true>, dim3(n == 1 ? 2048 : 64, n), dim3(TPB), 0, ST, params, grads, bufs, sizes,
+                     sq, clip, lr, momentum, first, grad_scale, weight_decay);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }

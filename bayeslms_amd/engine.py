@@ -141,9 +141,10 @@ class Trainer:
     + clip + SGD, as train.py:315-420 does, for any of the model families."""
 
     def __init__(self, model, lr, clip, momentum=0.9, kl_scale=0.0, seed=1111, rank=0, world=1, global_batch=None,
-                 bucket_bytes=32 << 20, fused_kl=True):
+                 bucket_bytes=32 << 20, fused_kl=True, weight_decay=0.0):
         self.model = model
         self.lr, self.clip, self.momentum = lr, clip, momentum
+        self.weight_decay = weight_decay  # torch.optim.SGD(weight_decay=...) of train_search_bayes.py:391-392
         self.kl_scale = kl_scale
         self.rank, self.world = rank, world
         self.flat = FlatBuffers(model)
@@ -165,12 +166,13 @@ class Trainer:
         self.lr = lr
         self.first = True
 
-    def step(self, data, targets, hidden=None, kl_fn=None):
+    def step(self, data, targets, hidden=None, kl_fn=None, philox_step=None):
         """-> (loss tensor, kl tensor, new hidden).  ``kl_fn(model)`` returns the KL term train.py
-        would add for this configuration (train.py:335-399), or None."""
+        would add for this configuration (train.py:335-399), or None.  ``philox_step`` overrides the
+        noise / dropout stream index (default: the optimisation step count)."""
         m = self.model
         m.train()
-        m.set_step(self.step_no)
+        m.set_step(self.step_no if philox_step is None else philox_step)
         B = data.shape[1]
         m.set_columns(self.rank * B, self.world * B)
         self.flat.zero_grad()
@@ -193,7 +195,7 @@ class Trainer:
             loss = mle + kl
             loss.backward()
         self.reducer.finish()
-        ops.clip_sgd(self.table, self.clip, self.lr, self.momentum, self.first, 1.0 / self.world)
+        ops.clip_sgd(self.table, self.clip, self.lr, self.momentum, self.first, 1.0 / self.world, self.weight_decay)
         self.first = False
         self.step_no += 1
         return loss.detach(), (kl.detach() if kl is not None else None), hidden

@@ -569,8 +569,11 @@ class _AddDropLN(torch.autograd.Function):
         dy = torch.empty_like(s) if drop.on else None
         ws = torch.empty(int(lib().blm_ln_bwd_ws_floats(rows * B, D)), device=s.device, dtype=torch.float32)
         r = drop.rng() if drop.on else None
+        # frozen LayerNorm parameters (architect step): their sums land in a scratch row instead of .grad
+        dgamma = _grad_buf(gamma) if gamma.requires_grad else torch.empty_like(gamma)
+        dbeta = _grad_buf(beta) if beta.requires_grad else torch.empty_like(beta)
         check(lib().blm_add_dropout_ln_bwd(ptr(dout), ptr(s), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dy),
-                                           ptr(_grad_buf(gamma)), ptr(_grad_buf(beta)), ptr(ws), rows, B, D,
+                                           ptr(dgamma), ptr(dbeta), ptr(ws), rows, B, D,
                                            float(drop.p), C.byref(r) if r is not None else None, drop.col_offset,
                                            drop.global_cols or B, stream()), "blm_add_dropout_ln_bwd")
         _notify(gamma, beta)
@@ -1133,14 +1136,211 @@ class PtrTable:
         self._keep = (params, grads, bufs)
 
 
-def clip_sgd(table, clip, lr, momentum, first, grad_scale=1.0):
-    """-> device scalar holding the squared global gradient norm (before grad_scale)."""
+def clip_sgd(table, clip, lr, momentum, first, grad_scale=1.0, weight_decay=0.0):
+    """-> device scalar holding the squared global gradient norm (before grad_scale).  ``weight_decay``:
+    torch.optim.SGD's L2 term, added after the clip (train_search_bayes.py:391-392)."""
     L.require_gfx950()
     table.sq.zero_()
     st = stream()
     check(lib().blm_sqnorm_multi(ptr(table.grads), ptr(table.sizes), table.n, ptr(table.sq), ptr(table.ws), st),
           "blm_sqnorm_multi")
-    check(lib().blm_clip_sgd_multi(ptr(table.params), ptr(table.grads), ptr(table.bufs), ptr(table.sizes), table.n,
-                                   ptr(table.sq), float(clip), float(lr), float(momentum), 1 if first else 0,
-                                   float(grad_scale), st), "blm_clip_sgd_multi")
+    if weight_decay:
+        check(lib().blm_clip_sgd_multi_wd(ptr(table.params), ptr(table.grads), ptr(table.bufs), ptr(table.sizes), table.n,
+                                          ptr(table.sq), float(clip), float(lr), float(momentum), 1 if first else 0,
+                                          float(grad_scale), float(weight_decay), st), "blm_clip_sgd_multi_wd")
+    else:
+        check(lib().blm_clip_sgd_multi(ptr(table.params), ptr(table.grads), ptr(table.bufs), ptr(table.sizes), table.n,
+                                       ptr(table.sq), float(clip), float(lr), float(momentum), 1 if first else 0,
+                                       float(grad_scale), st), "blm_clip_sgd_multi")
     return table.sq
+
+
+def adam_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """In-place torch.optim.Adam update of one tensor (architect.py:33); ``step`` counts from 1."""
+    L.require_gfx950()
+    check(lib().blm_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
+                              float(eps), float(weight_decay), int(step), stream()), "blm_adam_step")
+
+
+# ----------------------------------------------------------------------------
+# architecture search (model_search_bayes.py): branch mixes with gradients for the mixing weights
+# ----------------------------------------------------------------------------
+def _reduce_partials(partial, k):
+    """(n, k) per-block partial sums -> (k,) on the device."""
+    out = torch.empty(k, device=partial.device, dtype=torch.float32)
+    _colsum_into(partial, partial.numel() // k, k, out, accumulate=False)
+    return out
+
+
+def _drop_args(drop, B):
+    if drop is not None and drop.on:
+        return float(drop.p), C.byref(drop.rng()), int(drop.col_offset), int(drop.global_cols or B)
+    return 0.0, None, 0, 0
+
+
+class _SearchFFN(torch.autograd.Function):
+    """y = lin2(drop(p[0] * GELU(x W1^T + b1) + p[1] * sum_i act_i(x Wg^T + bg) coef[i]))
+    GaussTransSearchEncoderLayer FFN (model_search_bayes.py:234-236).  ``probs`` (2,) lives on the device and
+    gets its gradient; wg/bg/coef may be leaf parameters or sampled (non-leaf) tensors.  The weight-gradient
+    GEMMs are skipped for tensors that do not require grad (the architect step differentiates w.r.t. the
+    architecture logits only, architect.py:66-75)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, wg, bg, coef, probs, w2, b2, drop):
+        x, probs = _f32(x, "x"), _f32(probs, "probs")
+        F_, D = w1.shape
+        N2 = w2.shape[0]
+        M = x.numel() // D
+        B = x.shape[-2]
+        rows = M // B
+        dev = x.device
+        need_bwd = any(ctx.needs_input_grad)
+        a1 = torch.empty(M, F_, device=dev, dtype=torch.float32) if need_bwd else None
+        zg = torch.empty(M, F_, device=dev, dtype=torch.float32) if need_bwd else None
+        h1 = torch.empty(M, F_, device=dev, dtype=torch.float32)
+        hg = torch.empty(M, F_, device=dev, dtype=torch.float32)
+        gemm(L.GEMM_NT, x, w1, h1, M, F_, D, D, D, F_, epilogue=L.EPI_BIAS_GELU, bias=b1, aux=a1)
+        gemm(L.GEMM_NT, x, wg, hg, M, F_, D, D, D, F_, epilogue=L.EPI_GP_MIX, bias=bg, aux=zg, coef=coef)
+        s = torch.empty(M, F_, device=dev, dtype=torch.float32)
+        dp, drng, dco, dgc = _drop_args(drop, B)
+        check(lib().blm_mix2_fwd(ptr(h1), ptr(hg), ptr(probs), ptr(s), rows, B, F_, dp, drng, dco, dgc, stream()),
+              "blm_mix2_fwd")
+        y = torch.empty(*x.shape[:-1], N2, device=dev, dtype=torch.float32)
+        gemm(L.GEMM_NT, s, w2, y, M, N2, F_, F_, F_, N2, epilogue=L.EPI_BIAS, bias=b2)
+        ctx.save_for_backward(x, a1, h1, zg, hg, s, probs)
+        ctx.p = (w1, b1, wg, bg, coef, w2, b2, drop, B)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a1, h1, zg, hg, s, probs = ctx.saved_tensors
+        w1, b1, wg, bg, coef, w2, b2, drop, B = ctx.p
+        dy = _f32(dy, "dy")
+        F_, D = w1.shape
+        N2 = w2.shape[0]
+        M = x.numel() // D
+        rows = M // B
+        dev = x.device
+        st = stream()
+        ds = torch.empty(M, F_, device=dev, dtype=torch.float32)
+        gemm(L.GEMM_NN, dy, w2, ds, M, F_, N2, N2, F_, F_)
+        partial = torch.empty(int(lib().blm_mix2_partials(rows, B, F_)), device=dev, dtype=torch.float32)
+        dz1 = torch.empty(M, F_, device=dev, dtype=torch.float32)
+        dzg = torch.empty(M, F_, device=dev, dtype=torch.float32)
+        dp, drng, dco, dgc = _drop_args(drop, B)
+        check(lib().blm_mix2_bwd(ptr(ds), ptr(h1), ptr(hg), ptr(probs), ptr(a1), ptr(dz1), ptr(dzg), ptr(partial), rows, B,
+                                 F_, dp, drng, dco, dgc, st), "blm_mix2_bwd")
+        dprobs = _reduce_partials(partial, 2) if ctx.needs_input_grad[6] else None
+        dcoef = None
+        if coef.requires_grad:  # needs the gradient of the GP output (dzg still holds it)
+            buf, _, dcoef = _wgrad_target(coef)
+            if dcoef is not None:
+                buf.zero_()
+            check(lib().blm_gp_coef_grad(ptr(dzg), ptr(zg), ptr(buf), M, F_, st), "blm_gp_coef_grad")
+        check(lib().blm_gp_mix_bwd(ptr(dzg), ptr(zg), ptr(coef), ptr(dzg), M, F_, st), "blm_gp_mix_bwd")  # in place
+        if w2.requires_grad:
+            gemm(L.GEMM_TN, dy, s, _grad_buf(w2), N2, F_, M, N2, F_, F_, accumulate=True,
+                 colsum_a=_grad_buf(b2) if b2.requires_grad else None)
+        elif b2.requires_grad:
+            _colsum_into(dy, M, N2, _grad_buf(b2))
+        if w1.requires_grad:
+            gemm(L.GEMM_TN, dz1, x, _grad_buf(w1), F_, D, M, F_, D, D, accumulate=True,
+                 colsum_a=_grad_buf(b1) if b1.requires_grad else None)
+        elif b1.requires_grad:
+            _colsum_into(dz1, M, F_, _grad_buf(b1))
+        dwg = dbg = None
+        if wg.requires_grad:
+            buf, acc, dwg = _wgrad_target(wg)
+            gemm(L.GEMM_TN, dzg, x, buf, F_, D, M, F_, D, D, accumulate=acc)
+        if bg.requires_grad:
+            buf, acc, dbg = _wgrad_target(bg)
+            _colsum_into(dzg, M, F_, buf, accumulate=acc)
+        _notify(w2, b2, w1, b1, wg, bg, coef)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(L.GEMM_NN, dz1, w1, dx, M, D, F_, F_, D, D)
+            gemm(L.GEMM_NN, dzg, wg, dx, M, D, F_, F_, D, D, accumulate=True)
+        return dx, None, None, dwg, dbg, dcoef, dprobs, None, None, None
+
+
+def search_ffn(x, w1, b1, wg, bg, coef, probs, w2, b2, drop=NO_DROP):
+    return _SearchFFN.apply(x, w1, b1, wg, bg, coef, probs, w2, b2, drop)
+
+
+class _LSTMSearchLayer(torch.autograd.Function):
+    """One BayesLSTMSearchCell over a window (model_search_bayes.py:661-710).  w8_ih (8H,I), w8_hh (8H,H),
+    bias8 (8H): the standard gate block [i f g o] stacked on the four `Bayes` gate maps; probs (4,2) on the
+    device.  Per step: one (B,8H) recurrent GEMM + the pointwise search cell; the input products of all
+    steps, both weight gradients and dx are single GEMMs over the whole window."""
+
+    @staticmethod
+    def forward(ctx, x, h0, c0, w8_ih, w8_hh, bias8, probs):
+        x, h0, c0, probs = _f32(x, "x"), _f32(h0, "h0"), _f32(c0, "c0"), _f32(probs, "probs")
+        w8_ih, w8_hh, bias8 = _f32(w8_ih, "w8_ih"), _f32(w8_hh, "w8_hh"), _f32(bias8, "bias8")
+        T, B, I = x.shape
+        H = h0.shape[-1]
+        dev = x.device
+        st = stream()
+        need_bwd = any(ctx.needs_input_grad)
+        xw = torch.empty(T, B, 8 * H, device=dev, dtype=torch.float32)
+        gemm(L.GEMM_NT, x, w8_ih, xw, T * B, 8 * H, I, I, I, 8 * H, epilogue=L.EPI_BIAS, bias=bias8)
+        hs = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
+        cs = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
+        hs[0].copy_(h0)
+        cs[0].copy_(c0)
+        acts = torch.empty(T, B, 8 * H, device=dev, dtype=torch.float32) if need_bwd else None
+        hw = torch.empty(B, 8 * H, device=dev, dtype=torch.float32)
+        for t in range(T):
+            gemm(L.GEMM_NT, hs[t], w8_hh, hw, B, 8 * H, H, H, H, 8 * H)
+            check(lib().blm_lstm_search_cell_fwd(ptr(xw[t]), ptr(hw), ptr(cs[t]), ptr(probs), ptr(hs[t + 1]), ptr(cs[t + 1]),
+                                                 ptr(acts[t]) if need_bwd else None, B, H, st), "blm_lstm_search_cell_fwd")
+        ctx.save_for_backward(x, hs, cs, acts, w8_ih, w8_hh, probs)
+        ctx.dims = (T, B, I, H)
+        return hs[1:], hs[T], cs[T]
+
+    @staticmethod
+    def backward(ctx, dy, dhT, dcT):
+        x, hs, cs, acts, w8_ih, w8_hh, probs = ctx.saved_tensors
+        T, B, I, H = ctx.dims
+        dev = x.device
+        st = stream()
+        dy = _f32(dy.contiguous(), "dy")
+        npart = int(lib().blm_lstm_search_cell_partials(B, H))
+        part = torch.empty(T, npart, device=dev, dtype=torch.float32)
+        dz = torch.empty(T, B, 8 * H, device=dev, dtype=torch.float32)
+        dcb = [torch.empty(B, H, device=dev, dtype=torch.float32) for _ in range(2)]
+        dhr = [torch.empty(B, H, device=dev, dtype=torch.float32) for _ in range(2)]
+        dh_rec = _f32(dhT.contiguous(), "dhT") if dhT is not None else None
+        dc = _f32(dcT.contiguous(), "dcT") if dcT is not None else None
+        for t in range(T - 1, -1, -1):
+            k = t & 1
+            check(lib().blm_lstm_search_cell_bwd(ptr(dy[t]), ptr(dh_rec), ptr(dc), ptr(cs[t]), ptr(cs[t + 1]), ptr(acts[t]),
+                                                 ptr(probs), ptr(dz[t]), ptr(dcb[k]), ptr(part[t]), B, H, st),
+                  "blm_lstm_search_cell_bwd")
+            dc = dcb[k]
+            gemm(L.GEMM_NN, dz[t], w8_hh, dhr[k], B, H, 8 * H, 8 * H, H, H)
+            dh_rec = dhr[k]
+        dprobs = _reduce_partials(part, 8).view(4, 2) if ctx.needs_input_grad[6] else None
+        dw_ih = dw_hh = db = dx = None
+        M = T * B
+        if ctx.needs_input_grad[4]:
+            dw_hh = torch.empty_like(w8_hh)
+            gemm(L.GEMM_TN, dz, hs, dw_hh, 8 * H, H, M, 8 * H, H, H)
+        if ctx.needs_input_grad[3]:
+            dw_ih = torch.empty_like(w8_ih)
+            db = torch.empty(8 * H, device=dev, dtype=torch.float32) if ctx.needs_input_grad[5] else None
+            if db is not None:
+                db.zero_()
+            gemm(L.GEMM_TN, dz, x, dw_ih, 8 * H, I, M, 8 * H, I, I, colsum_a=db)
+        elif ctx.needs_input_grad[5]:
+            db = torch.empty(8 * H, device=dev, dtype=torch.float32)
+            _colsum_into(dz, M, 8 * H, db, accumulate=False)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(L.GEMM_NN, dz, w8_ih, dx, M, I, 8 * H, 8 * H, I, I)
+        return dx, dh_rec, dc, dw_ih, dw_hh, db, dprobs
+
+
+def lstm_search_layer(x, h0, c0, w8_ih, w8_hh, bias8, probs):
+    return _LSTMSearchLayer.apply(x, h0, c0, w8_ih, w8_hh, bias8, probs)

@@ -342,6 +342,53 @@ int blm_add_rowvec(float* x, const float* v, int B, int H, void* stream);
 /* y (+)= a*x elementwise helpers used by the host glue. */
 int blm_axpy(const float* x, float* y, int64_t n, float a, void* stream);
 
+/* --------------------------------------------------------------------------
+ * Architecture search (model_search_bayes.py, architect.py,
+ * train_search_bayes.py).  HBM-bound streaming kernels.
+ * ------------------------------------------------------------------------ */
+
+/* Mix of two candidate branches by the softmax'd architecture weights
+ * (model_search_bayes.py:234-236, :77-78):
+ *   out = (probs[0]*a + probs[1]*b) * keep        probs: 2 floats on the DEVICE
+ * a, b, out are (rows, B, N) activations; dropout (model_search_bayes.py:236
+ * `self.dropout(src1)`) as blm_dropout keys it; drop_p == 0 -> none. */
+int blm_mix2_fwd(const float* a, const float* b, const float* probs, float* out, int rows, int B, int N, float drop_p,
+                 const blm_rng* rng, int col_offset, int global_cols, void* stream);
+/* Backward: g = dout*keep; da = probs[0]*g*(mul_a ? mul_a : 1); db = probs[1]*g (either may be NULL);
+ * partial[2*j+{0,1}] = block j's share of sum(g*a), sum(g*b) -- blm_mix2_partials(rows,B,N) floats,
+ * written (not accumulated), fixed order inside a block; reduce with blm_colsum(partial, 2, dprobs, n/2, 2).
+ * mul_a lets the GELU branch fold its derivative (aux of BLM_EPI_BIAS_GELU) into the same pass. */
+int64_t blm_mix2_partials(int rows, int B, int N);
+int blm_mix2_bwd(const float* dout, const float* a, const float* b, const float* probs, const float* mul_a, float* da,
+                 float* db, float* partial, int rows, int B, int N, float drop_p, const blm_rng* rng, int col_offset,
+                 int global_cols, void* stream);
+
+/* BayesLSTMSearchCell.bayeslstm pointwise part (model_search_bayes.py:686-710).  z8 = xw8 + hw8 is
+ * (B, 8H) with row layout [i f g o | i' f' g' o'] (standard gates, then the four `Bayes` maps);
+ * probs (4,2) on the device, rows i,f,g,o:
+ *   gate_k = act_k(z_k)*probs[k][0] + act_k(z'_k)*probs[k][1];  c = f*c_prev + i*g;  h = o*tanh(c)
+ * acts8 (B,8H, may be NULL) keeps the eight activations for the backward. */
+int blm_lstm_search_cell_fwd(const float* xw8, const float* hw8, const float* c_prev, const float* probs, float* h,
+                             float* c, float* acts8, int B, int H, void* stream);
+/* Backward: dh (+ dh2, may be NULL), dc_next (may be NULL) -> dz8 (B,8H), dc_prev (B,H) and
+ * partial[8*j + 2k + s] = block j's share of d probs[k][s]; blm_lstm_search_cell_partials(B,H) floats. */
+int64_t blm_lstm_search_cell_partials(int B, int H);
+int blm_lstm_search_cell_bwd(const float* dh, const float* dh2, const float* dc_next, const float* c_prev, const float* c,
+                             const float* acts8, const float* probs, float* dz8, float* dc_prev, float* partial, int B,
+                             int H, void* stream);
+
+/* torch.optim.Adam(lr, betas, eps, weight_decay) on one tensor (architect.py:33): g += wd*p;
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr * (m/(1-b1^step)) / (sqrt(v/(1-b2^step)) + eps).
+ * step counts from 1. */
+int blm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, void* stream);
+
+/* blm_clip_sgd_multi with torch.optim.SGD's weight decay: the clipped gradient becomes
+ * c*g + weight_decay*p before the momentum update (train_search_bayes.py:330,391-392). */
+int blm_clip_sgd_multi_wd(float* const* params, const float* const* grads, float* const* bufs, const int64_t* sizes, int n,
+                          const float* sq, float clip, float lr, float momentum, int first, float grad_scale,
+                          float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

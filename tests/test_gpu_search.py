@@ -1,0 +1,344 @@
+"""GPU parity of the architecture-search path: the search kernels against plain torch
+fp32, the two super-nets against the reference's golden vectors, and the alternating architect / network
+loop against the trajectory the reference's own Architect + SGD produced."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from test_gpu_models import grad_close, load_sd, rel
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+GATES = ("ingate", "forgate", "cellgate", "outgate")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------ kernels vs torch
+@pytest.mark.parametrize("shape", [(5, 3, 32), (7, 2, 30), (128, 64, 512)])
+def test_mix2_fwd_bwd(dev, shape):
+    from bayeslms_amd import _lib as L, ops
+    lib = L.lib()
+    rows, B, N = shape
+    torch.manual_seed(1)
+    a, b, mul, g = (torch.randn(rows * B, N, device=dev) for _ in range(4))
+    probs = torch.softmax(torch.randn(2, device=dev), 0)
+    out = torch.empty_like(a)
+    st = L.stream()
+    L.check(lib.blm_mix2_fwd(L.ptr(a), L.ptr(b), L.ptr(probs), L.ptr(out), rows, B, N, 0.0, None, 0, 0, st), "fwd")
+    torch.testing.assert_close(out, probs[0] * a + probs[1] * b, rtol=1e-6, atol=1e-6)
+    da, db = torch.empty_like(a), torch.empty_like(a)
+    part = torch.empty(int(lib.blm_mix2_partials(rows, B, N)), device=dev)
+    L.check(lib.blm_mix2_bwd(L.ptr(g), L.ptr(a), L.ptr(b), L.ptr(probs), L.ptr(mul), L.ptr(da), L.ptr(db), L.ptr(part), rows, B,
+                             N, 0.0, None, 0, 0, st), "bwd")
+    torch.testing.assert_close(da, probs[0] * g * mul, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(db, probs[1] * g, rtol=1e-6, atol=1e-6)
+    dp = ops._reduce_partials(part, 2)
+    ref = torch.stack([(g.double() * a.double()).sum(), (g.double() * b.double()).sum()]).float()
+    torch.testing.assert_close(dp, ref, rtol=2e-4, atol=1e-3)
+
+
+def test_mix2_dropout_is_consistent(dev):
+    """Forward and backward regenerate the same Philox keep mask (scale 1/(1-p)), keyed as blm_dropout."""
+    from bayeslms_amd import _lib as L, ops
+    lib = L.lib()
+    rows, B, N, p = 6, 4, 64, 0.25
+    a, b = torch.randn(rows * B, N, device=dev), torch.randn(rows * B, N, device=dev)
+    probs = torch.tensor([0.3, 0.7], device=dev)
+    drop = ops.Drop(p, 1234, 5, 9, 0, B)
+    out = torch.empty_like(a)
+    import ctypes as C
+    st = L.stream()
+    L.check(lib.blm_mix2_fwd(L.ptr(a), L.ptr(b), L.ptr(probs), L.ptr(out), rows, B, N, p, C.byref(drop.rng()), 0, B, st), "fwd")
+    ones = torch.ones_like(a)
+    mask = ops.dropout(ones.view(rows, B, N), drop).view(rows * B, N)
+    torch.testing.assert_close(out, (0.3 * a + 0.7 * b) * mask, rtol=1e-6, atol=1e-6)
+    assert 0.6 < float((mask > 0).float().mean()) < 0.9
+    da, db = torch.empty_like(a), torch.empty_like(a)
+    part = torch.empty(int(lib.blm_mix2_partials(rows, B, N)), device=dev)
+    L.check(lib.blm_mix2_bwd(L.ptr(ones), L.ptr(a), L.ptr(b), L.ptr(probs), None, L.ptr(da), L.ptr(db), L.ptr(part), rows, B, N, p,
+                             C.byref(drop.rng()), 0, B, st), "bwd")
+    torch.testing.assert_close(da, 0.3 * mask, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(db, 0.7 * mask, rtol=1e-6, atol=1e-6)
+
+
+def _cell_ref(xw, hw, c_prev, probs):
+    z = xw + hw
+    H = c_prev.shape[1]
+    zs = z.view(z.shape[0], 8, H)
+    act = [torch.sigmoid, torch.sigmoid, torch.tanh, torch.sigmoid]
+    gate = [act[k](zs[:, k]) * probs[k, 0] + act[k](zs[:, k + 4]) * probs[k, 1] for k in range(4)]
+    c = gate[1] * c_prev + gate[0] * gate[2]
+    return gate[3] * torch.tanh(c), c
+
+
+@pytest.mark.parametrize("B,H", [(3, 12), (64, 1024)])
+def test_lstm_search_cell(dev, B, H):
+    from bayeslms_amd import _lib as L, ops
+    lib = L.lib()
+    torch.manual_seed(2)
+    xw = torch.randn(B, 8 * H, device=dev, requires_grad=True)
+    hw = torch.randn(B, 8 * H, device=dev)
+    c_prev = torch.randn(B, H, device=dev, requires_grad=True)
+    probs = torch.softmax(torch.randn(4, 2, device=dev), -1).requires_grad_(True)
+    h, c, acts = torch.empty(B, H, device=dev), torch.empty(B, H, device=dev), torch.empty(B, 8 * H, device=dev)
+    st = L.stream()
+    L.check(lib.blm_lstm_search_cell_fwd(L.ptr(xw), L.ptr(hw), L.ptr(c_prev), L.ptr(probs), L.ptr(h), L.ptr(c), L.ptr(acts), B, H,
+                                         st), "fwd")
+    hr, cr = _cell_ref(xw, hw, c_prev, probs)
+    torch.testing.assert_close(h, hr, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(c, cr, rtol=1e-5, atol=1e-6)
+    dh, dh2, dcn = (torch.randn(B, H, device=dev) for _ in range(3))
+    ((hr * (dh + dh2)).sum() + (cr * dcn).sum()).backward()
+    dz, dcp = torch.empty(B, 8 * H, device=dev), torch.empty(B, H, device=dev)
+    part = torch.empty(int(lib.blm_lstm_search_cell_partials(B, H)), device=dev)
+    L.check(lib.blm_lstm_search_cell_bwd(L.ptr(dh), L.ptr(dh2), L.ptr(dcn), L.ptr(c_prev), L.ptr(c), L.ptr(acts), L.ptr(probs),
+                                         L.ptr(dz), L.ptr(dcp), L.ptr(part), B, H, st), "bwd")
+    torch.testing.assert_close(dz, xw.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(dcp, c_prev.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(ops._reduce_partials(part, 8).view(4, 2), probs.grad, rtol=5e-4, atol=1e-3 if H > 100 else 1e-5)
+
+
+def test_adam_matches_torch(dev):
+    from bayeslms_amd import ops
+    torch.manual_seed(3)
+    p = torch.randn(2, 4, 2, device=dev)
+    q = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([q], lr=3e-3, weight_decay=1e-3)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for t in range(1, 6):
+        g = torch.randn_like(p)
+        q.grad = g.clone()
+        opt.step()
+        ops.adam_step(p, g, m, v, t, 3e-3, weight_decay=1e-3)
+        torch.testing.assert_close(p, q.detach(), rtol=1e-5, atol=1e-7)
+
+
+def test_clip_sgd_weight_decay(dev):
+    from bayeslms_amd import ops
+    from oracle import search_oracle as S
+    torch.manual_seed(4)
+    n = 1000
+    p, g = torch.randn(n, device=dev), torch.randn(n, device=dev) * 3
+    mom = torch.zeros(n, device=dev)
+    table = ops.PtrTable([p], [g], [mom])
+    pc, bufs = p.cpu().clone(), [None]
+    for step in range(3):
+        ops.clip_sgd(table, 1.0, 0.5, 0.9, step == 0, 1.0, weight_decay=1e-2)
+        S.clip_and_sgd_wd([pc], [g.cpu()], bufs, 0.5, 1.0, 1e-2)
+        torch.testing.assert_close(p.cpu(), pc, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ super-nets vs the reference's vectors
+def _tlm(g, sd, dev):
+    from bayeslms_amd import model_search_bayes as S
+    V, d = sd["encoder.weight"].shape
+    ff = sd["transformerlayers.0.linear1.weight"].shape[0]
+    nl = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("transformerlayers."))
+    m = S.GaussTransModelSearch(V, d, int(g["nhead"]), ff, nl, 0.0, True).to(dev)
+    with torch.no_grad():
+        load_sd(m, sd)
+    return m, V
+
+
+@pytest.mark.parametrize("sample", [0, 1])
+def test_gauss_trans_search_golden(dev, sample):
+    from bayeslms_amd import ops
+    g, sd, grad = load_golden("search_gauss_tlm_%d" % sample)
+    m, V = _tlm(g, sd, dev)
+    m.set_arch(g["arch"])
+    assert m.weights.device.type == "cuda" and m.transformerlayers[1].weights.shape == (1, 2)
+    src, tgt = g["src"].to(dev), g["tgt"].to(dev)
+    m.eval()
+    with torch.no_grad():
+        assert rel(m(src), g["logits_eval"]) < TOL
+    m.train()
+    for i, layer in enumerate(m.transformerlayers):
+        layer.gpnn.sample = bool(sample)
+        layer.gpnn.eps_override = {k: g["eps_%d_%s" % (i, k)].to(dev) for k in ("coef", "weights", "bias")}
+    logits = m(src)
+    assert rel(logits, g["logits_train"]) < TOL
+    mle, _ = ops.cross_entropy(logits.clone().view(-1, V), tgt)
+    kl = sum(layer.gpnn.kl_divergence() for layer in m.transformerlayers)
+    assert rel(mle, g["mle"]) < TOL and rel(kl, g["kl"]) < TOL
+    (mle + kl * float(g["kl_scale"])).backward()
+    assert grad_close(m.weights.grad, g["arch_grad"]), (m.weights.grad, g["arch_grad"])
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or k not in grad:
+            continue
+        assert p.grad is not None, k
+        assert grad_close(p.grad, grad[k]), k
+
+
+def _lstm(sd, dev):
+    from bayeslms_amd import model_search_bayes as S
+    V, H = sd["encoder.weight"].shape
+    m = S.BayesLSTMModelSearch("LSTM", V, H, H, 2, 0.0, True).to(dev)
+    with torch.no_grad():
+        load_sd(m, sd)
+    return m, V, H
+
+
+@pytest.mark.parametrize("sample", [0, 1])
+def test_bayes_lstm_search_golden(dev, sample):
+    from bayeslms_amd import ops
+    g, sd, grad = load_golden("search_bayes_lstm_%d" % sample)
+    m, V, H = _lstm(sd, dev)
+    m.set_arch(g["arch"])
+    x1, x2, tgt = g["x1"].to(dev), g["x2"].to(dev), g["tgt"].to(dev)
+    B = x1.shape[1]
+    m.eval()
+    with torch.no_grad():
+        hid = m.init_hidden(B)
+        e1, hid = m(x1, hid)
+        e2, hid = m(x2, hid)
+    assert rel(e1, g["logits_eval_0"]) < TOL and rel(e2, g["logits_eval_1"]) < TOL
+    assert rel(hid[0], g["h_eval"]) < TOL and rel(hid[1], g["c_eval"]) < TOL
+    if sample:  # the first window's draw is not in the fixture: check the KL and a sampled forward for determinism
+        for c in m.rnn.rnn:
+            for gate in c.gates():
+                gate.sample = True
+        kl = sum(gate.kl_divergence() for c in m.rnn.rnn for gate in c.gates())
+        assert rel(kl, g["kl"]) < TOL
+        m.train()
+        m.set_seed(5)
+        m.set_step(1)
+        a, _ = m(x1, m.init_hidden(B))
+        b, _ = m(x1, m.init_hidden(B))
+        m.set_step(2)
+        c_, _ = m(x1, m.init_hidden(B))
+        assert torch.equal(a, b) and not torch.equal(a, c_) and not torch.equal(a.detach(), e1)
+        return
+    m.train()
+    hid = m.init_hidden(B)
+    _, hid = m(x1, hid)
+    hid = tuple(t.detach() for t in hid)
+    logits, _ = m(x2, hid)
+    assert rel(logits, g["logits_train_1"]) < TOL
+    mle, _ = ops.cross_entropy(logits.clone().view(-1, V), tgt)
+    for c in m.rnn.rnn:
+        for gate in c.gates():
+            gate.sample = True
+    kl = sum(gate.kl_divergence() for c in m.rnn.rnn for gate in c.gates())
+    assert rel(mle, g["mle"]) < TOL and rel(kl, g["kl"]) < TOL
+    (mle + kl * float(g["kl_scale"])).backward()
+    assert grad_close(m.weights.grad, g["arch_grad"]), (m.weights.grad, g["arch_grad"])
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or k not in grad:
+            continue
+        assert p.grad is not None, k
+        assert grad_close(p.grad, grad[k]), k
+
+
+def test_bayes_lstm_search_sampled_forward(dev):
+    """Bayes gates with ``sample`` on and injected eps: logits of the second window against the oracle run on
+    the same draws (the reference fixture holds the draws of window 2 only, so window 1 runs with mean weights
+    on both sides)."""
+    from oracle import search_oracle as O
+    g, sd, _ = load_golden("search_bayes_lstm_1")
+    m, V, H = _lstm(sd, dev)
+    m.set_arch(g["arch"])
+    x1, x2 = g["x1"].to(dev), g["x2"].to(dev)
+    B = x1.shape[1]
+    eps = [{gate: (g["eps_%d_%s_w" % (c, gate)], g["eps_%d_%s_b" % (c, gate)]) for gate in GATES} for c in range(2)]
+    zeros = (torch.zeros(2, B, H), torch.zeros(2, B, H))
+    _, h1 = O.bayes_lstm_search_lm(g["x1"], zeros, sd, g["arch"])
+    want, _ = O.bayes_lstm_search_lm(g["x2"], h1, sd, g["arch"], eps)
+    m.train()
+    _, hid = m(x1, m.init_hidden(B))
+    for ci, c in enumerate(m.rnn.rnn):
+        for gate in GATES:
+            b = getattr(c, "bayes_" + gate)
+            b.sample = True
+            b.eps_override = tuple(t.to(dev) for t in eps[ci][gate])
+    got, _ = m(x2, tuple(t.detach() for t in hid))
+    assert rel(got, want) < TOL
+
+
+# ------------------------------------------------------------------ the alternating loop
+@pytest.mark.parametrize("kind", ["tlm", "lstm"])
+def test_search_loop_golden(dev, kind):
+    """Six architect + network steps from the reference's initial state (its Architect, Adam, SGD with weight
+    decay): per-step CE and KL, the architecture logits after every Adam step, final parameters, eval logits."""
+    from bayeslms_amd import engine, train_search_bayes as TS
+    from bayeslms_amd.architect import Architect
+    from bayeslms_amd.model import repackage_hidden
+    g, sd_final, _ = load_golden("search_loop_" + kind)
+    z = np.load(GOLDEN + "/search_loop_%s.npz" % kind)
+    sd0 = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("init/")}
+    T, lr, clip, kl_scale = int(g["T"]), float(g["lr"]), float(g["clip"]), float(g["kl_scale"])
+    if kind == "tlm":
+        m, V = _tlm(g, sd0, dev)
+        args = types.SimpleNamespace(model="Transformer", T_bayes_pos="FFN", uncertainty="none", L_bayes_pos=0)
+    else:
+        m, V, H = _lstm(sd0, dev)
+        args = types.SimpleNamespace(model="LSTM", T_bayes_pos="none", uncertainty="none", L_bayes_pos=1)
+    m.set_arch(g["arch_init"])
+    TS.freeze_unused(args, m)
+    kl_fn = TS.kl_selector(args)
+    arch = Architect(m, V, types.SimpleNamespace(wdecay=5e-7, clip=clip, arch_lr=3e-3, arch_wdecay=1e-3))
+    trainer = engine.Trainer(m, lr=lr, clip=clip, momentum=0.9, kl_scale=kl_scale, weight_decay=TS.SGD_WEIGHT_DECAY)
+    train, valid = g["train"].to(dev), g["valid"].to(dev)
+    B = train.shape[1]
+    hidden = m.init_hidden(B) if kind == "lstm" else None
+    hv = m.init_hidden(B) if kind == "lstm" else None
+    nsteps = (train.shape[0] - 1) // T
+    for s in range(nsteps):
+        data, tg = train[s * T:(s + 1) * T], train[s * T + 1:(s + 1) * T + 1].reshape(-1)
+        dv, tv = valid[s * T:(s + 1) * T], valid[s * T + 1:(s + 1) * T + 1].reshape(-1)
+        m.train()
+        arch.step(data, tg, dv, tv, None, False, hv)
+        assert rel(m.weights.detach(), g["arch_after"][s]) < 2e-3, s
+        torch.testing.assert_close(m.weights.detach().cpu(), g["arch_after"][s], rtol=2e-3, atol=2e-6)
+        if kind == "tlm":
+            for i, layer in enumerate(m.transformerlayers):
+                layer.gpnn.sample = True
+                layer.gpnn.eps_override = {k: g["eps_%d_%d_%s" % (s, i, k)].to(dev) for k in ("coef", "weights", "bias")}
+        else:
+            hidden = repackage_hidden(hidden)
+        loss, kl, hidden = trainer.step(data, tg, hidden, kl_fn)
+        if kind == "tlm":
+            for layer in m.transformerlayers:
+                layer.gpnn.sample = False
+        assert abs(float(kl) - float(g["kl"][s])) <= 1e-4 * abs(float(g["kl"][s])) + 1e-7, s
+        assert abs(float(loss) - float(kl) - float(g["mle"][s])) < 2e-4 * float(g["mle"][s]), (s, float(loss), float(g["mle"][s]))
+    own = m.state_dict()
+    for k, v in sd_final.items():
+        if k.endswith("pos_encoder.pe"):
+            continue
+        assert grad_close(own[k], v, rtol=2e-3, atol=1e-5), k
+    m.eval()
+    with torch.no_grad():
+        ev = m(valid[:T]) if kind == "tlm" else m(valid[:T], m.init_hidden(B))[0]
+    assert rel(ev, g["logits_eval"]) < 2e-3
+
+
+def test_unrolled_raises_like_reference(dev):
+    from bayeslms_amd import model_search_bayes as S
+    from bayeslms_amd.architect import Architect
+    m = S.GaussTransModelSearch(30, 16, 4, 32, 1, 0.0, True).to(dev)
+    arch = Architect(m, 30, types.SimpleNamespace(wdecay=5e-7, clip=0.25, arch_lr=3e-3, arch_wdecay=1e-3))
+    x = torch.randint(0, 30, (4, 2), device=dev)
+    with pytest.raises(AttributeError, match="arch_parameters"):
+        arch.step(x, x.view(-1), x, x.view(-1), None, True)
+
+
+def test_architect_skips_weight_gradients(dev):
+    """The architect step leaves every network gradient untouched and restores requires_grad."""
+    from bayeslms_amd import model_search_bayes as S
+    from bayeslms_amd.architect import Architect
+    m = S.GaussTransModelSearch(30, 16, 4, 32, 2, 0.1, True).to(dev)
+    arch = Architect(m, 30, types.SimpleNamespace(wdecay=5e-7, clip=0.25, arch_lr=3e-3, arch_wdecay=1e-3))
+    x = torch.randint(0, 30, (6, 3), device=dev)
+    before = m.weights.detach().clone()
+    m.train()
+    arch.step(x, x.view(-1), x, x.view(-1), None, False)
+    assert all(p.grad is None for p in m.parameters()) and all(p.requires_grad for p in m.parameters())
+    assert not torch.equal(before, m.weights.detach()) and torch.isfinite(m.weights).all()
