@@ -200,6 +200,7 @@ struct LstmBwdP {
   float* dz_out;                          // mode 4: dgates_out * mixture'(z) (B,4H) = the next launch's A operand
   int ovr;
   int B, H;
+  int G;                                  // contraction length = row length of dg and wt: 4H (LSTM), 8H (search cell)
 };
 
 template <int RING>
@@ -208,8 +209,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
   const int k0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
   const int H = p.H, B = p.B;
-  const long G = 4L * H;
-  const int Kq = H >> 2;                  // contraction run of one lane quarter
+  const long G = p.G, G4 = 4L * H;       // G4: row length of the cell arrays (ga, dg_out, zprev of mode 4)
+  const int Kw = p.G >> 2;                // contraction run of one wave
+  const int Kq = Kw >> 2;                 // ... and of one lane quarter
   const int nchunk = (Kq + 31) >> 5;
   float* base = sm + wave * BWAVE_LDS;
 
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int brow = threadIdx.x >> 4, ecol = threadIdx.x & 15;
   const int eb = b0 + brow, ek = k0 + ecol;
   const bool eok = eb < B;
-  const long ei = (long)eb * H + ek, eo = (long)eb * G + ek;
+  const long ei = (long)eb * H + ek, eo = (long)eb * G4 + ek;
   float e_dy = 0.f, e_dcn = 0.f, e_cp = 0.f, e_c = 0.f, e_z = 0.f, e_g[4] = {0.f, 0.f, 0.f, 0.f}, e_z4[4] = {0.f, 0.f, 0.f, 0.f};
   if (eok && p.dg_out) {
     if (p.dy) e_dy = p.dy[ei];
@@ -240,8 +242,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int row = 2 * q + srow;
-    arow[q] = p.dg + (long)min(b0 + row, B - 1) * G + (long)wave * H + squart * Kq + 4 * spart;
-    wrow[q] = p.wt + (long)(k0 + row) * G + (long)wave * H + squart * Kq + 4 * spart;
+    arow[q] = p.dg + (long)min(b0 + row, B - 1) * G + (long)wave * Kw + squart * Kq + 4 * spart;
+    wrow[q] = p.wt + (long)(k0 + row) * G + (long)wave * Kw + squart * Kq + 4 * spart;
   }
   const int soff = srow * BSTR + squart * BQ + 4 * spart;
   float4 ra0[8], rw0[8], ra1[8], rw1[8];
@@ -394,6 +396,23 @@ extern "C" int blm_transpose(const float* in, float* out, int rows, int cols, vo
   return BLM_OK;
 }
 
+static int launch_step_bwd(const LstmBwdP& p, void* stream) {
+  const size_t lds = (size_t)4 * BWAVE_LDS * sizeof(float);
+  static bool once = false;
+  if (!once) {
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    once = true;
+  }
+  const int nchunk = (p.G / 16 + 31) / 32;  // 32-k chunks per lane quarter of a wave's contraction run
+  const dim3 grid(p.H / 16, (p.B + 15) / 16), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (nchunk % 2 == 0) hipLaunchKernelGGL(lstm_step_bwd_kernel<2>, grid, block, lds, st, p);
+  else hipLaunchKernelGGL(lstm_step_bwd_kernel<1>, grid, block, lds, st, p);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
 extern "C" int blm_lstm_step_bwd(const float* dgates_t, const float* w_hh_t, const float* dy_prev, const float* dc_next,
                                  const float* c_prev, const float* c, const float* gates_act, float* dgates_out,
                                  float* dc_prev, float* dh_out, int B, int H, void* stream) {
@@ -413,19 +432,16 @@ extern "C" int blm_lstm_step_bwd_gp(const float* dgates_t, const float* w_hh_t, 
   if (H % 32 != 0 || !al16(dgates_t) || !al16(w_hh_t))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_bwd: needs H % 32 == 0 and 16-byte aligned dgates_t / w_hh_t");
   LstmBwdP p{dgates_t, w_hh_t, dy_prev, dc_next, c_prev, c, gates_act, dgates_out, dc_prev, dh_out, z_prev, coef4, dact_out,
-             dz_out, (dgates_out && gate_ovr >= 0) ? gate_ovr : -1, B, H};
-  const size_t lds = (size_t)4 * BWAVE_LDS * sizeof(float);
-  static bool once = false;
-  if (!once) {
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    once = true;
-  }
-  const int nchunk = (H / 4 + 31) / 32;
-  const dim3 grid(H / 16, (B + 15) / 16), block(256);
-  hipStream_t st = (hipStream_t)stream;
-  if (nchunk % 2 == 0) hipLaunchKernelGGL(lstm_step_bwd_kernel<2>, grid, block, lds, st, p);
-  else hipLaunchKernelGGL(lstm_step_bwd_kernel<1>, grid, block, lds, st, p);
-  BLM_HIP(hipGetLastError());
-  return BLM_OK;
+             dz_out, (dgates_out && gate_ovr >= 0) ? gate_ovr : -1, B, H, 4 * H};
+  return launch_step_bwd(p, stream);
+}
+
+extern "C" int blm_lstm_step_dh(const float* dz, const float* w_t, float* dh_out, int B, int H, int G, void* stream) {
+  if (!dz || !w_t || !dh_out || B < 0 || H < 0 || G < 0) return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_dh: bad arguments");
+  if ((long)B * H == 0) return BLM_OK;
+  if (H % 16 != 0 || G % 64 != 0 || G == 0 || !al16(dz) || !al16(w_t))
+    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_dh: needs H % 16 == 0, G % 64 == 0 and 16-byte aligned dz / w_t");
+  LstmBwdP p{dz, w_t, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dh_out, nullptr, nullptr, nullptr, nullptr, -1,
+             B, H, G};
+  return launch_step_bwd(p, stream);
 }

@@ -1313,13 +1313,22 @@ class _LSTMSearchLayer(torch.autograd.Function):
         dhr = [torch.empty(B, H, device=dev, dtype=torch.float32) for _ in range(2)]
         dh_rec = _f32(dhT.contiguous(), "dhT") if dhT is not None else None
         dc = _f32(dcT.contiguous(), "dcT") if dcT is not None else None
+        # skinny recurrent dgrad: one launch per step on the LSTM step kernel (fixed summation order, no
+        # split-K memset + atomics) against the weight transposed once per window; blm_gemm otherwise
+        fused = H % 16 == 0
+        if fused:
+            w_t = torch.empty(H, 8 * H, device=dev, dtype=torch.float32)
+            check(lib().blm_transpose(ptr(w8_hh), ptr(w_t), 8 * H, H, st), "blm_transpose")
         for t in range(T - 1, -1, -1):
             k = t & 1
             check(lib().blm_lstm_search_cell_bwd(ptr(dy[t]), ptr(dh_rec), ptr(dc), ptr(cs[t]), ptr(cs[t + 1]), ptr(acts[t]),
                                                  ptr(probs), ptr(dz[t]), ptr(dcb[k]), ptr(part[t]), B, H, st),
                   "blm_lstm_search_cell_bwd")
             dc = dcb[k]
-            gemm(L.GEMM_NN, dz[t], w8_hh, dhr[k], B, H, 8 * H, 8 * H, H, H)
+            if fused:
+                check(lib().blm_lstm_step_dh(ptr(dz[t]), ptr(w_t), ptr(dhr[k]), B, H, 8 * H, st), "blm_lstm_step_dh")
+            else:
+                gemm(L.GEMM_NN, dz[t], w8_hh, dhr[k], B, H, 8 * H, 8 * H, H, H)
             dh_rec = dhr[k]
         dprobs = _reduce_partials(part, 8).view(4, 2) if ctx.needs_input_grad[6] else None
         dw_ih = dw_hh = db = dx = None

@@ -377,6 +377,12 @@ int blm_lstm_search_cell_bwd(const float* dh, const float* dh2, const float* dc_
                              const float* acts8, const float* probs, float* dz8, float* dc_prev, float* partial, int B,
                              int H, void* stream);
 
+/* The skinny recurrent dgrad of one search-cell step on the blm_lstm_step_bwd kernel (no cell fused):
+ *   dh_out (B,H) = dz (B,G) . w_t (H,G)^T      w_t = the stacked recurrent weight (G,H) TRANSPOSED
+ * One launch, fixed summation order, no memset / atomics.  Needs H % 16 == 0, G % 64 == 0, 16-byte
+ * aligned operands (BLM_ERR_UNSUPPORTED otherwise: use blm_gemm). */
+int blm_lstm_step_dh(const float* dz, const float* w_t, float* dh_out, int B, int H, int G, void* stream);
+
 /* torch.optim.Adam(lr, betas, eps, weight_decay) on one tensor (architect.py:33): g += wd*p;
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr * (m/(1-b1^step)) / (sqrt(v/(1-b2^step)) + eps).
  * step counts from 1. */

@@ -12,7 +12,7 @@ TOL = 1e-4  # well inside the 1e-3 bar of BASELINE.json
 
 
 def rel(a, b):
-    a, b = a.double().cpu(), b.double().cpu()
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 

@@ -106,6 +106,61 @@ def test_lstm_search_cell(dev, B, H):
     torch.testing.assert_close(ops._reduce_partials(part, 8).view(4, 2), probs.grad, rtol=5e-4, atol=1e-3 if H > 100 else 1e-5)
 
 
+@pytest.mark.parametrize("B,H,G", [(64, 1024, 8192), (5, 32, 256), (64, 1024, 4096), (33, 48, 192)])
+def test_lstm_step_dh(dev, B, H, G):
+    """Skinny recurrent dgrad on the LSTM step kernel: dh = dz . W against torch fp32 (fp64 accumulate)."""
+    from bayeslms_amd import _lib as L
+    lib = L.lib()
+    torch.manual_seed(5)
+    dz = torch.randn(B, G, device=dev)
+    w = torch.randn(G, H, device=dev) / G ** 0.5
+    w_t = torch.empty(H, G, device=dev)
+    st = L.stream()
+    L.check(lib.blm_transpose(L.ptr(w), L.ptr(w_t), G, H, st), "transpose")
+    assert torch.equal(w_t, w.t().contiguous())
+    dh = torch.empty(B, H, device=dev)
+    L.check(lib.blm_lstm_step_dh(L.ptr(dz), L.ptr(w_t), L.ptr(dh), B, H, G, st), "dh")
+    ref = (dz.double() @ w.double()).float()
+    torch.testing.assert_close(dh, ref, rtol=1e-4, atol=1e-4)
+    dh2 = torch.empty(B, H, device=dev)
+    L.check(lib.blm_lstm_step_dh(L.ptr(dz), L.ptr(w_t), L.ptr(dh2), B, H, G, st), "dh")
+    assert torch.equal(dh, dh2)  # fixed summation order
+
+
+def test_bayes_lstm_search_fused_shapes_vs_oracle(dev):
+    """H = 32 takes the fused recurrent-dgrad path (the golden fixtures use H = 12): logits, CE and every
+    gradient, the architecture logits included, against the CPU oracle on the same random model."""
+    from bayeslms_amd import model_search_bayes as S, ops
+    from oracle import bayes_oracle as BO, search_oracle as O
+    torch.manual_seed(6)
+    V, H, T, B = 50, 32, 6, 5
+    m = S.BayesLSTMModelSearch("LSTM", V, H, H, 2, 0.0, True).to(dev)
+    m.set_arch(torch.randn(2, 4, 2) * 0.7)
+    with torch.no_grad():
+        for c in m.rnn.rnn:
+            c.bias_ih.normal_(0, 0.1)
+            for gate in c.gates():
+                gate.bias_mean.normal_(0, 0.1)
+    x, tgt = torch.randint(0, V, (T, B)), torch.randint(0, V, (T * B,))
+    h0, c0 = torch.randn(2, B, H) * 0.3, torch.randn(2, B, H) * 0.3
+    m.train()
+    logits, (hT, cT) = m(x.to(dev), (h0.to(dev), c0.to(dev)))
+    mle, _ = ops.cross_entropy(logits.clone().view(-1, V), tgt.to(dev))
+    (mle + 0.1 * hT.sum() + 0.1 * cT.sum()).backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items() if k != "decoder.weight"}
+    sd["decoder.weight"] = sd["encoder.weight"]
+    arch = m.weights.detach().cpu().clone().requires_grad_(True)
+    want, (hr, cr) = O.bayes_lstm_search_lm(x, (h0, c0), sd, arch)
+    assert rel(logits, want) < TOL and rel(hT, hr) < TOL and rel(cT, cr) < TOL
+    (BO.cross_entropy_mean(want.view(-1, V), tgt) + 0.1 * hr.sum() + 0.1 * cr.sum()).backward()
+    assert grad_close(m.weights.grad, arch.grad)
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or sd[k].grad is None:
+            continue
+        assert p.grad is not None, k
+        assert grad_close(p.grad, sd[k].grad), k
+
+
 def test_adam_matches_torch(dev):
     from bayeslms_amd import ops
     torch.manual_seed(3)
