@@ -39,27 +39,33 @@ struct LstmStepP {
   int ovr;              //   -1: plain LSTM; 4: gate type 6 -- the whole hidden projection h W^T + rbias passes through
   const float* rbias;   //   the mixture (coef (4,4H), z (B,4H)) before it is added to xw (model.py:1744-1752)
   int B, H;
+  const float* probs;   // NS = 8 (architecture-search cell, model_search_bayes.py:686-710): (4,2) mixing weights on the device
 };
 
-template <int RING>
+// NS = number of gate streams per hidden unit: 4 (LSTM: i f g o) or 8 (search cell: i f g o | i' f' g' o', every
+// gate the probs-weighted mix of the two activations).  A workgroup owns 32 / NS units = 32 rows of the weight.
+template <int RING, int NS = 4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_step_fwd_kernel(const LstmStepP p) {
+  constexpr int U = 32 / NS;  // hidden units per workgroup
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
-  const int j0 = blockIdx.x * 8, b0 = blockIdx.y * 32;
+  const int j0 = blockIdx.x * U, b0 = blockIdx.y * 32;
   const int H = p.H, B = p.B;
   const int Kw = H >> 2, Kh = Kw >> 1, kbase = wave * Kw;
   const int nchunk = (Kh + 31) >> 5;
   float* base = sm + wave * WAVE_LDS;
 
   // epilogue operands first: their latency hides behind the whole K loop
-  const int brow = threadIdx.x >> 3, eu = threadIdx.x & 7;
+  const int brow = threadIdx.x / U, eu = threadIdx.x % U;
   const int eb = b0 + brow, ej = j0 + eu;
-  const bool eok = eb < B;
-  float xg[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
-  if (eok) {
-    const long o = (long)eb * 4 * H + ej;
+  const bool eok = eb < B && brow < 32;
+  float xg[NS], cprev = 0.f;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) xg[g] = p.xw[o + (long)g * H];
+  for (int g = 0; g < NS; ++g) xg[g] = 0.f;
+  if (eok) {
+    const long o = (long)eb * NS * H + ej;
+#pragma unroll
+    for (int g = 0; g < NS; ++g) xg[g] = p.xw[o + (long)g * H];
     cprev = p.cprev[(long)eb * H + ej];
   }
 
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int q = 0; q < 8; ++q) {
     const int row = 4 * q + srow;
     arow[q] = p.hprev + (long)min(b0 + row, B - 1) * H + kbase + shalf * Kh + 4 * spart;
-    wrow[q] = p.whh + ((long)(row >> 3) * H + j0 + (row & 7)) * H + kbase + shalf * Kh + 4 * spart;
+    wrow[q] = p.whh + ((long)(row / U) * H + j0 + (row % U)) * H + kbase + shalf * Kh + 4 * spart;
   }
   const int soff = srow * LSTR + shalf * 32 + 4 * spart;
   // register ring of RING chunks: with one wave per SIMD the only way to cover the L2/MALL latency is
@@ -138,36 +144,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   __syncthreads();
   if (eok) {
-    float s[4];
-    const long o4 = (long)eb * 4 * H + ej;
+    float hw[NS];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = g * 8 + eu;
-      float hw = (red[(0 * 32 + brow) * RSTR + n] + red[(1 * 32 + brow) * RSTR + n]) +
-                 (red[(2 * 32 + brow) * RSTR + n] + red[(3 * 32 + brow) * RSTR + n]);
-      if (p.ovr == 4) {  // wave-uniform
-        const float z = hw + p.rbias[g * H + ej];
-        if (p.zsave) p.zsave[o4 + (long)g * H] = z;
-        hw = gp_mix(z, p.coef, 4 * H, g * H + ej);
+    for (int g = 0; g < NS; ++g) {
+      const int n = g * U + eu;
+      hw[g] = (red[(0 * 32 + brow) * RSTR + n] + red[(1 * 32 + brow) * RSTR + n]) +
+              (red[(2 * 32 + brow) * RSTR + n] + red[(3 * 32 + brow) * RSTR + n]);
+    }
+    const long i = (long)eb * H + ej, o = (long)eb * NS * H + ej;
+    if constexpr (NS == 8) {  // search cell: eight activations, four probs-weighted mixes (search.hip search_cell_fwd_kernel)
+      float a[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float z = xg[k] + hw[k];
+        a[k] = (k & 3) == 2 ? tanhf(z) : sigmoidf_(z);
       }
-      s[g] = xg[g] + hw;
-    }
-    float gi = sigmoidf_(s[0]), gf = sigmoidf_(s[1]), gg = tanhf(s[2]), go = sigmoidf_(s[3]);
-    const long i = (long)eb * H + ej, o = (long)eb * 4 * H + ej;
-    if (p.ovr >= 0 && p.ovr < 4) {  // wave-uniform
-      const float z = p.ovr == 0 ? s[0] : (p.ovr == 1 ? s[1] : (p.ovr == 2 ? s[2] : s[3]));
-      const float a = gp_mix(z, p.coef, H, ej);
-      if (p.ovr == 0) gi = a; else if (p.ovr == 1) gf = a; else if (p.ovr == 2) gg = a; else go = a;
-      if (p.zsave) p.zsave[i] = z;
-    }
-    const float cn = gf * cprev + gi * gg;
-    p.c[i] = cn;
-    p.h[i] = go * tanhf(cn) + (p.hnoise ? p.hnoise[ej] : 0.f);
-    if (p.ga) {
-      p.ga[o] = gi;
-      p.ga[o + H] = gf;
-      p.ga[o + 2L * H] = gg;
-      p.ga[o + 3L * H] = go;
+      const float gi = a[0] * p.probs[0] + a[4] * p.probs[1];
+      const float gf = a[1] * p.probs[2] + a[5] * p.probs[3];
+      const float gg = a[2] * p.probs[4] + a[6] * p.probs[5];
+      const float go = a[3] * p.probs[6] + a[7] * p.probs[7];
+      const float cn = gf * cprev + gi * gg;
+      p.c[i] = cn;
+      p.h[i] = go * tanhf(cn);
+      if (p.ga) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p.ga[o + (long)k * H] = a[k];
+      }
+    } else {
+      float s[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v = hw[g];
+        if (p.ovr == 4) {  // wave-uniform
+          const float z = v + p.rbias[g * H + ej];
+          if (p.zsave) p.zsave[o + (long)g * H] = z;
+          v = gp_mix(z, p.coef, 4 * H, g * H + ej);
+        }
+        s[g] = xg[g] + v;
+      }
+      float gi = sigmoidf_(s[0]), gf = sigmoidf_(s[1]), gg = tanhf(s[2]), go = sigmoidf_(s[3]);
+      if (p.ovr >= 0 && p.ovr < 4) {  // wave-uniform
+        const float z = p.ovr == 0 ? s[0] : (p.ovr == 1 ? s[1] : (p.ovr == 2 ? s[2] : s[3]));
+        const float a = gp_mix(z, p.coef, H, ej);
+        if (p.ovr == 0) gi = a; else if (p.ovr == 1) gf = a; else if (p.ovr == 2) gg = a; else go = a;
+        if (p.zsave) p.zsave[i] = z;
+      }
+      const float cn = gf * cprev + gi * gg;
+      p.c[i] = cn;
+      p.h[i] = go * tanhf(cn) + (p.hnoise ? p.hnoise[ej] : 0.f);
+      if (p.ga) {
+        p.ga[o] = gi;
+        p.ga[o + H] = gf;
+        p.ga[o + 2L * H] = gg;
+        p.ga[o + 3L * H] = go;
+      }
     }
   }
 }
@@ -371,19 +401,43 @@ extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const 
   if ((long)B * H == 0) return BLM_OK;
   if (H % 32 != 0 || !al16(w_hh) || !al16(h_prev))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_fwd: needs H % 32 == 0 and 16-byte aligned h_prev / w_hh");
-  LstmStepP p{xw_t, w_hh, h_prev, c_prev, h, c, gates_act, h_noise, coef4, z_out, gate_ovr < 0 ? -1 : gate_ovr, rbias, B, H};
+  LstmStepP p{xw_t, w_hh, h_prev, c_prev, h, c, gates_act, h_noise, coef4, z_out, gate_ovr < 0 ? -1 : gate_ovr, rbias, B, H, nullptr};
   const size_t lds = (size_t)4 * WAVE_LDS * sizeof(float);
   static bool once = false;
   if (!once) {
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     once = true;
   }
   const int nchunk = (H / 8 + 31) / 32;  // 32-k chunks per lane half of a wave's K quarter
   const dim3 grid(H / 8, (B + 31) / 32), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (nchunk % 2 == 0) hipLaunchKernelGGL(lstm_step_fwd_kernel<2>, grid, block, lds, st, p);
-  else hipLaunchKernelGGL(lstm_step_fwd_kernel<1>, grid, block, lds, st, p);
+  if (nchunk % 2 == 0) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4>), grid, block, lds, st, p);
+  else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 4>), grid, block, lds, st, p);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_lstm_search_step_fwd(const float* xw8_t, const float* w8_hh, const float* h_prev, const float* c_prev,
+                                        const float* probs, float* h, float* c, float* acts8, int B, int H, void* stream) {
+  if (!xw8_t || !w8_hh || !h_prev || !c_prev || !probs || !h || !c || B < 0 || H < 0)
+    return blm_fail(BLM_ERR_INVALID, "blm_lstm_search_step_fwd: bad arguments");
+  if ((long)B * H == 0) return BLM_OK;
+  if (H % 32 != 0 || !al16(w8_hh) || !al16(h_prev))
+    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_search_step_fwd: needs H % 32 == 0 and 16-byte aligned h_prev / w8_hh");
+  LstmStepP p{xw8_t, w8_hh, h_prev, c_prev, h, c, acts8, nullptr, nullptr, nullptr, -1, nullptr, B, H, probs};
+  const size_t lds = (size_t)4 * WAVE_LDS * sizeof(float);
+  static bool once = false;
+  if (!once) {
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    once = true;
+  }
+  const int nchunk = (H / 8 + 31) / 32;
+  const dim3 grid(H / 4, (B + 31) / 32), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (nchunk % 2 == 0) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 8>), grid, block, lds, st, p);
+  else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 8>), grid, block, lds, st, p);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }

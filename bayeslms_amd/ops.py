@@ -1290,11 +1290,18 @@ class _LSTMSearchLayer(torch.autograd.Function):
         hs[0].copy_(h0)
         cs[0].copy_(c0)
         acts = torch.empty(T, B, 8 * H, device=dev, dtype=torch.float32) if need_bwd else None
-        hw = torch.empty(B, 8 * H, device=dev, dtype=torch.float32)
-        for t in range(T):
-            gemm(L.GEMM_NT, hs[t], w8_hh, hw, B, 8 * H, H, H, H, 8 * H)
-            check(lib().blm_lstm_search_cell_fwd(ptr(xw[t]), ptr(hw), ptr(cs[t]), ptr(probs), ptr(hs[t + 1]), ptr(cs[t + 1]),
-                                                 ptr(acts[t]) if need_bwd else None, B, H, st), "blm_lstm_search_cell_fwd")
+        if H % 32 == 0:  # one launch per step: recurrent product over the stacked weight + the search cell
+            for t in range(T):
+                check(lib().blm_lstm_search_step_fwd(ptr(xw[t]), ptr(w8_hh), ptr(hs[t]), ptr(cs[t]), ptr(probs), ptr(hs[t + 1]),
+                                                     ptr(cs[t + 1]), ptr(acts[t]) if need_bwd else None, B, H, st),
+                      "blm_lstm_search_step_fwd")
+        else:
+            hw = torch.empty(B, 8 * H, device=dev, dtype=torch.float32)
+            for t in range(T):
+                gemm(L.GEMM_NT, hs[t], w8_hh, hw, B, 8 * H, H, H, H, 8 * H)
+                check(lib().blm_lstm_search_cell_fwd(ptr(xw[t]), ptr(hw), ptr(cs[t]), ptr(probs), ptr(hs[t + 1]),
+                                                     ptr(cs[t + 1]), ptr(acts[t]) if need_bwd else None, B, H, st),
+                      "blm_lstm_search_cell_fwd")
         ctx.save_for_backward(x, hs, cs, acts, w8_ih, w8_hh, probs)
         ctx.dims = (T, B, I, H)
         return hs[1:], hs[T], cs[T]

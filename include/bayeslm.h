@@ -377,6 +377,13 @@ int blm_lstm_search_cell_bwd(const float* dh, const float* dh2, const float* dc_
                              const float* acts8, const float* probs, float* dz8, float* dc_prev, float* partial, int B,
                              int H, void* stream);
 
+/* One whole search-cell time step in a single launch (blm_lstm_step_fwd with eight gate streams):
+ *   z8 = xw8_t[b,8H] + h_prev[b,H] . w8_hh[8H,H]^T, then blm_lstm_search_cell_fwd's pointwise part.
+ * Same shape rule and status codes as blm_lstm_step_fwd (BLM_ERR_UNSUPPORTED: compose blm_gemm +
+ * blm_lstm_search_cell_fwd). */
+int blm_lstm_search_step_fwd(const float* xw8_t, const float* w8_hh, const float* h_prev, const float* c_prev,
+                             const float* probs, float* h, float* c, float* acts8, int B, int H, void* stream);
+
 /* The skinny recurrent dgrad of one search-cell step on the blm_lstm_step_bwd kernel (no cell fused):
  *   dh_out (B,H) = dz (B,G) . w_t (H,G)^T      w_t = the stacked recurrent weight (G,H) TRANSPOSED
  * One launch, fixed summation order, no memset / atomics.  Needs H % 16 == 0, G % 64 == 0, 16-byte

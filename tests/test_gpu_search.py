@@ -106,6 +106,33 @@ def test_lstm_search_cell(dev, B, H):
     torch.testing.assert_close(ops._reduce_partials(part, 8).view(4, 2), probs.grad, rtol=5e-4, atol=1e-3 if H > 100 else 1e-5)
 
 
+@pytest.mark.parametrize("B,H", [(64, 1024), (5, 32), (33, 96), (64, 256)])
+def test_lstm_search_step_fwd_fused(dev, B, H):
+    """One-launch search step (recurrent product over the stacked weight + cell) == blm_gemm + cell kernel."""
+    from bayeslms_amd import _lib as L
+    lib = L.lib()
+    torch.manual_seed(7)
+    xw = torch.randn(B, 8 * H, device=dev)
+    w8 = torch.randn(8 * H, H, device=dev) / H ** 0.5
+    hp, cp = torch.randn(B, H, device=dev), torch.randn(B, H, device=dev)
+    probs = torch.softmax(torch.randn(4, 2, device=dev), -1)
+    h, c, acts = torch.empty(B, H, device=dev), torch.empty(B, H, device=dev), torch.empty(B, 8 * H, device=dev)
+    st = L.stream()
+    L.check(lib.blm_lstm_search_step_fwd(L.ptr(xw), L.ptr(w8), L.ptr(hp), L.ptr(cp), L.ptr(probs), L.ptr(h), L.ptr(c), L.ptr(acts),
+                                         B, H, st), "fused")
+    hw = (hp.double() @ w8.double().t()).float()
+    hr, cr = _cell_ref(xw, hw, cp, probs)
+    torch.testing.assert_close(h, hr, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(c, cr, rtol=1e-4, atol=2e-5)
+    z = (xw + hw).view(B, 8, H)
+    want = torch.stack([torch.tanh(z[:, k]) if k % 4 == 2 else torch.sigmoid(z[:, k]) for k in range(8)], 1).reshape(B, 8 * H)
+    torch.testing.assert_close(acts, want, rtol=1e-4, atol=2e-5)
+    h2, c2 = torch.empty_like(h), torch.empty_like(c)
+    L.check(lib.blm_lstm_search_step_fwd(L.ptr(xw), L.ptr(w8), L.ptr(hp), L.ptr(cp), L.ptr(probs), L.ptr(h2), L.ptr(c2), None, B, H,
+                                         st), "fused")
+    assert torch.equal(h, h2) and torch.equal(c, c2)
+
+
 @pytest.mark.parametrize("B,H,G", [(64, 1024, 8192), (5, 32, 256), (64, 1024, 4096), (33, 48, 192)])
 def test_lstm_step_dh(dev, B, H, G):
     """Skinny recurrent dgrad on the LSTM step kernel: dh = dz . W against torch fp32 (fp64 accumulate)."""
