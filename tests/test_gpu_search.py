@@ -424,3 +424,57 @@ def test_architect_skips_weight_gradients(dev):
     arch.step(x, x.view(-1), x, x.view(-1), None, False)
     assert all(p.grad is None for p in m.parameters()) and all(p.requires_grad for p in m.parameters())
     assert not torch.equal(before, m.weights.detach()) and torch.isfinite(m.weights).all()
+
+
+@pytest.mark.parametrize("margs", [
+    ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4", "--T_bayes_pos", "FFN"],
+    ["--model", "LSTM", "--emsize", "32", "--nhid", "32", "--nlayers", "2", "--L_bayes_pos", "1"],
+])
+def test_train_search_cli(dev, margs, tmp_path, capsys):
+    """The train_search_bayes.py-compatible CLI: 2 epochs on a learnable toy corpus; the loss goes down, the
+    architecture logits move, the checkpoint has the reference's keys and reproduces the printed test loss
+    through the CPU oracle (with the logits the run ended on)."""
+    import os
+    import re
+    from bayeslms_amd import data as D, train_search_bayes as TS
+    from oracle import bayes_oracle as BO, search_oracle as O
+    from test_gpu_models import _write_corpus
+    rng = np.random.RandomState(0)
+    words = ["<s>", "<unk>"] + ["w%03d" % i for i in range(2, 30)]
+
+    def text(n):
+        lines = []
+        for _ in range(n):
+            a, ln = rng.randint(2, 30), rng.randint(3, 9)
+            lines.append(" ".join(words[2 + (a - 2 + k) % 28] for k in range(ln)))
+        return "\n".join(lines) + "\n"
+    d = str(tmp_path)
+    _write_corpus({"words": words, "train_txt": text(600), "valid_txt": text(120), "test_txt": text(60)}, d)
+    save = os.path.join(d, "search.pt")
+    is_lstm = margs[1] == "LSTM"
+    TS.main(["--data", d, "--epochs", "2", "--batch-size", "4", "--seq_len", "7", "--dropout", "0.1",
+             "--lr", "0.5" if is_lstm else "0.1", "--clip", "1.0", "--tied", "--cuda", "--save", save,
+             "--log-interval", "20", "--arch_lr", "3e-2"] + margs)
+    out = capsys.readouterr().out
+    vals = [float(x) for x in re.findall(r"valid loss\s+([0-9.]+)", out)]
+    test_loss = float(re.search(r"test loss\s+([0-9.]+)", out).group(1))
+    assert len(vals) == 2 and vals[1] < vals[0] and vals[1] < 3.0, out[-600:]
+    assert "| epoch   1 |" in out and "kl_loss" in out and "tensor(" in out
+    sd = torch.load(save, map_location="cpu")
+    arch = torch.load(save + ".arch", map_location="cpu")
+    assert arch.shape == ((2, 4, 2) if is_lstm else (2, 1, 2)) and float(arch.abs().max()) > 1e-3
+    assert not any(k.endswith("weights") and "bayes" not in k and "rnn" not in k for k in sd)  # logits are not in the state_dict
+    # eval loss of the checkpoint through the oracle, eval batch 20 (engine.evaluate / train_search_bayes.py:345-360)
+    c = D.Corpus(d)
+    src = D.batchify(c.test, 20)
+    total = 0.0
+    hidden = (torch.zeros(2, 20, 32), torch.zeros(2, 20, 32))
+    with torch.no_grad():
+        for i in range(0, src.size(0) - 1, 7):
+            data, tg = D.get_batch(src, i, 7)
+            if is_lstm:
+                o, hidden = O.bayes_lstm_search_lm(data, hidden, sd, arch)
+            else:
+                o = O.gauss_trans_search_lm(data, sd, arch, 4)
+            total += len(data) * float(BO.cross_entropy_mean(o.view(-1, len(words)), tg))
+    assert abs(total / (len(src) - 1) - test_loss) < 0.006
