@@ -22,20 +22,22 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import BayesLMError
-from .model import (GPNN, MultiheadAttention, NoiseState, PositionalEncoding, _LMHead, _ProjHolder, _RNNLM, _Site,
-                    bind_state)
+from .model import (GPNN, BayesLinear, MultiheadAttention, NoiseState, PositionalEncoding, _LMHead, _ProjHolder, _RNNLM,
+                    _Site, bind_state)
 
-__all__ = ["differentiable_gumble_sample", "GaussTransSearchEncoderLayer", "GaussTransModel", "GaussTransModelSearch",
+__all__ = ["differentiable_gumble_sample", "BayesTransSearchEncoderLayer", "BayesTransModel", "BayesTransModelSearch",
+           "GaussTransSearchEncoderLayer", "GaussTransModel", "GaussTransModelSearch",
            "Bayes", "BayesLSTMSearchCell", "BayesLSTMSearch", "BayesLSTMModel", "BayesLSTMModelSearch"]
 
 INITRANGE = 0.04
 TEMPERATURE = 5
 
 
-def differentiable_gumble_sample(logits):
+def differentiable_gumble_sample(logits, noise=None):
     """softmax((logits - log(-log(U))) / TEMPERATURE), U ~ U(0,1) (model_search_bayes.py:25-30).  Twelve
-    numbers at most: plain tensor glue on the device."""
-    noise = torch.rand_like(logits)
+    numbers at most: plain tensor glue on the device.  ``noise``: inject U (parity tests)."""
+    if noise is None:
+        noise = torch.rand_like(logits)
     return torch.softmax((logits - torch.log(-torch.log(noise))) / TEMPERATURE, dim=-1)
 
 
@@ -43,6 +45,74 @@ def _arch_tensor(data, device):
     w = data.detach().to(device=device, dtype=torch.float32).clone().contiguous()
     w.requires_grad_(True)
     return w
+
+
+# ----------------------------------------------------------------------------
+# Transformer: standard | Bayesian linear2 search (not built by train_search_bayes.py; class surface kept)
+# ----------------------------------------------------------------------------
+class BayesTransSearchEncoderLayer(_Site):
+    """Reference model_search_bayes.py:33-81.  FFN output = ffn_linear2(drop(h)) * p[0] + bayes_linear2(drop2(h)) *
+    p[1], h = GELU(linear1(x)), drop2 a hard-coded 0.1 (:51); p = the layer's RAW logits pushed through the
+    Gumbel softmax while ``gumble_flag`` is set (:61-65).  As in the reference, h is computed once per branch."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, bayes_pos=None):
+        super().__init__()
+        self.bayes_pos = bayes_pos
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = _ProjHolder(d_model, dim_feedforward)
+        self.bayes_linear2 = BayesLinear(dim_feedforward, d_model)
+        self.ffn_linear2 = _ProjHolder(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.p = dropout
+        self.p2 = 0.1
+        self.gumble_flag = True
+        self.gumble_noise_override = None
+        self.weights = None
+
+    def probs(self):
+        if self.weights is None:
+            raise AttributeError("'BayesTransSearchEncoderLayer' object has no attribute 'weights'")
+        p = self.weights
+        if self.gumble_flag is True:
+            p = differentiable_gumble_sample(p, self.gumble_noise_override)
+        return p.reshape(-1)
+
+    def forward(self, src, src_mask=None):
+        a = self.self_attn(src, src, src, attn_mask=src_mask)[0]
+        x = ops.add_dropout_ln(src, a, self.norm1.weight, self.norm1.bias, self.norm1.eps, self._drop(self.p, 1))
+        bl = self.bayes_linear2
+        ya = ops.ffn(x, self.linear1.weight, self.linear1.bias, self.ffn_linear2.weight, self.ffn_linear2.bias,
+                     drop=self._drop(self.p, 0))
+        yb = ops.ffn(x, self.linear1.weight, self.linear1.bias, bl.weight_mean, None, bl.weight_lgstd, bl.noise(),
+                     bl.fused_kl_lambda, self._st().fused, self._drop(self.p2, 3))
+        f = ops.mix2(ya, yb, self.probs())
+        return ops.add_dropout_ln(x, f, self.norm2.weight, self.norm2.bias, self.norm2.eps, self._drop(self.p, 2))
+
+
+class BayesTransModel(_LMHead):
+    """Reference model_search_bayes.py:84-150."""
+
+    def __init__(self, ntoken, ninp, nhead, nhid, nlayers, dropout=0.5, tie_weights=False):
+        super().__init__()
+        self.model_type = "Transformer"
+        self.src_mask = None
+        self.ninp = ninp
+        self.nlayers = nlayers
+        self.pos_encoder = PositionalEncoding(ninp, dropout)
+        self.transformerlayers = nn.ModuleList(BayesTransSearchEncoderLayer(ninp, nhead, nhid, dropout)
+                                               for _ in range(nlayers))
+        self._init_io(ntoken, ninp, ninp, tie_weights)
+        self.noise_state = bind_state(self, NoiseState())
+
+    def forward(self, src, has_mask=True):
+        if not has_mask:
+            raise BayesLMError("has_mask=False: the fused attention kernel is causal only")
+        x = ops.embed(src, self.encoder.weight, self.pos_encoder.table(), math.sqrt(self.ninp),
+                      self.pos_encoder._drop(self.pos_encoder.p))
+        for layer in self.transformerlayers:
+            x = layer(x, src_mask=True)
+        return self.decoder(x)
 
 
 # ----------------------------------------------------------------------------
@@ -171,6 +241,26 @@ class GaussTransModelSearch(_ArchMixin, GaussTransModel):
         """The reference builds a BayesTransModel here and then asks it for ``arch_parameters()``, which that
         class does not have (model_search_bayes.py:316-320): ``--unrolled`` cannot run there either."""
         raise AttributeError("'BayesTransModel' object has no attribute 'arch_parameters'")
+
+    def _initialize_arch_parameters(self):
+        self.set_arch(torch.zeros(self.nlayers, 1, 2))
+
+    def _attach(self):
+        for i, layer in enumerate(self.transformerlayers):
+            layer.weights = self.weights[i]
+
+
+class BayesTransModelSearch(_ArchMixin, BayesTransModel):
+    """Reference model_search_bayes.py:153-179: architecture logits (nlayers,1,2), zero-initialised, consumed raw
+    (Gumbel softmax) by the layers."""
+
+    def __init__(self, *args):
+        super().__init__(*args)
+        self._args = args
+        self._initialize_arch_parameters()
+
+    def new(self):
+        raise AttributeError("'BayesTransModel' object has no attribute 'arch_parameters'")  # :161-165
 
     def _initialize_arch_parameters(self):
         self.set_arch(torch.zeros(self.nlayers, 1, 2))

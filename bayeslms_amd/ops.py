@@ -1178,6 +1178,42 @@ def _drop_args(drop, B):
     return 0.0, None, 0, 0
 
 
+class _Mix2(torch.autograd.Function):
+    """out = (p[0] a + p[1] b) * keep over (rows, B, N) activations, probs (2,) on the device
+    (BayesTransSearchEncoderLayer, model_search_bayes.py:77-78)."""
+
+    @staticmethod
+    def forward(ctx, a, b, probs, drop):
+        a, b, probs = _f32(a, "a"), _f32(b, "b"), _f32(probs, "probs")
+        N, B = a.shape[-1], a.shape[-2]
+        rows = a.numel() // (B * N)
+        out = torch.empty_like(a)
+        dp, drng, dco, dgc = _drop_args(drop, B)
+        L.require_gfx950()
+        check(lib().blm_mix2_fwd(ptr(a), ptr(b), ptr(probs), ptr(out), rows, B, N, dp, drng, dco, dgc, stream()), "blm_mix2_fwd")
+        ctx.save_for_backward(a, b, probs)
+        ctx.meta = (drop, rows, B, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b, probs = ctx.saved_tensors
+        drop, rows, B, N = ctx.meta
+        dout = _f32(dout, "dout")
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        partial = torch.empty(int(lib().blm_mix2_partials(rows, B, N)), device=a.device, dtype=torch.float32)
+        dp, drng, dco, dgc = _drop_args(drop, B)
+        check(lib().blm_mix2_bwd(ptr(dout), ptr(a), ptr(b), ptr(probs), None, ptr(da), ptr(db), ptr(partial), rows, B, N, dp,
+                                 drng, dco, dgc, stream()), "blm_mix2_bwd")
+        dprobs = _reduce_partials(partial, 2) if ctx.needs_input_grad[2] else None
+        return da, db, dprobs, None
+
+
+def mix2(a, b, probs, drop=NO_DROP):
+    return _Mix2.apply(a, b, probs, drop)
+
+
 class _SearchFFN(torch.autograd.Function):
     """y = lin2(drop(p[0] * GELU(x W1^T + b1) + p[1] * sum_i act_i(x Wg^T + bg) coef[i]))
     GaussTransSearchEncoderLayer FFN (model_search_bayes.py:234-236).  ``probs`` (2,) lives on the device and

@@ -641,6 +641,40 @@ def f9_search_models():
              **grads(m))
 
 
+def f9_search_bayes_tlm():
+    """BayesTransModelSearch (model_search_bayes.py:33-194): FFN output mixed from a standard and a Bayesian
+    linear2 by Gumbel-softmax'd logits.  Draw order per layer: the (1,2) uniform of the Gumbel sample (:26), then
+    the eps of bayes_linear2 (model.py:1087); replayed from the same seed to recover both."""
+    S, _ = _load_search()
+    V, d, h, ff, L, T, B = 50, 16, 4, 32, 2, 6, 3
+    torch.manual_seed(331)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = S.BayesTransModelSearch(V, d, h, ff, L, 0.0, True)
+    zero_dropout(m)  # dropout2 is a hard-coded 0.1 (:51)
+    m.weights.data.copy_(torch.randn(L, 1, 2) * 0.7)
+    src = torch.randint(0, V, (T, B))
+    tgt = torch.randint(0, V, (T * B,))
+    m.train()
+    torch.manual_seed(17)
+    kw = {}
+    for i in range(L):
+        kw["u_%d" % i] = npy(torch.zeros(1, 2).uniform_(0, 1))
+        kw["eps_%d" % i] = npy(torch.zeros(d, ff).normal_(0, 1))
+    torch.manual_seed(17)
+    logits = m(src)
+    mle = torch.nn.functional.cross_entropy(logits.view(-1, V), tgt)
+    kl = sum(lyr.bayes_linear2.kl_divergence() for lyr in m.transformerlayers)
+    (mle + kl * 0.05).backward()
+    m.eval()
+    for lyr in m.transformerlayers:
+        lyr.gumble_flag = False  # eval-mode fixture without the Gumbel draw: probs = the raw logits (:61)
+    with torch.no_grad():
+        logits_eval = m(src)
+    save("search_bayes_tlm", src=npy(src), tgt=npy(tgt), nhead=np.int64(h), kl_scale=np.float32(0.05), arch=npy(m.weights),
+         arch_grad=npy(m.weights.grad), logits_train=npy(logits), logits_eval_nogumbel=npy(logits_eval), mle=npy(mle),
+         kl=npy(kl), **kw, **pack_sd(m), **grads(m))
+
+
 def f9_search_loop():
     """The alternating loop of train_search_bayes.py:203-290 (first-order Architect step on a validation
     window, then the SGD(momentum 0.9, weight_decay 1e-5) network step), driven with the reference's own
@@ -723,6 +757,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rnnv":
         f5_gauss_variational_rnn()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "search_btlm":
+        f9_search_bayes_tlm()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "search":
         f9_search_models()
         f9_search_loop()
@@ -760,3 +797,4 @@ if __name__ == "__main__":
     f5_gauss_rnn_gpnn2()
     f9_search_models()
     f9_search_loop()
+    f9_search_bayes_tlm()

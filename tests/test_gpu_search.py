@@ -478,3 +478,47 @@ def test_train_search_cli(dev, margs, tmp_path, capsys):
                 o = O.gauss_trans_search_lm(data, sd, arch, 4)
             total += len(data) * float(BO.cross_entropy_mean(o.view(-1, len(words)), tg))
     assert abs(total / (len(src) - 1) - test_loss) < 0.006
+
+
+def test_bayes_trans_search_golden(dev):
+    """BayesTransModelSearch vs the reference: Gumbel-softmax'd logits (uniform draw injected), Bayesian linear2
+    (eps injected), gradient of the logits and of every parameter."""
+    from bayeslms_amd import model_search_bayes as S, ops
+    g, sd, grad = load_golden("search_bayes_tlm")
+    V, d = sd["encoder.weight"].shape
+    ff = sd["transformerlayers.0.linear1.weight"].shape[0]
+    m = S.BayesTransModelSearch(V, d, int(g["nhead"]), ff, 2, 0.0, True).to(dev)
+    with torch.no_grad():
+        load_sd(m, sd)
+    m.set_arch(g["arch"])
+    for layer in m.transformerlayers:
+        layer.p2 = 0.0
+    src, tgt = g["src"].to(dev), g["tgt"].to(dev)
+    m.eval()
+    for layer in m.transformerlayers:
+        layer.gumble_flag = False
+    with torch.no_grad():
+        assert rel(m(src), g["logits_eval_nogumbel"]) < TOL
+    m.train()
+    for i, layer in enumerate(m.transformerlayers):
+        layer.gumble_flag = True
+        layer.gumble_noise_override = g["u_%d" % i].to(dev)
+        layer.bayes_linear2.eps_override = g["eps_%d" % i].to(dev)
+    logits = m(src)
+    assert rel(logits, g["logits_train"]) < TOL
+    mle, _ = ops.cross_entropy(logits.clone().view(-1, V), tgt)
+    kl = sum(layer.bayes_linear2.kl_divergence() for layer in m.transformerlayers)
+    assert rel(mle, g["mle"]) < TOL and rel(kl, g["kl"]) < TOL
+    (mle + kl * float(g["kl_scale"])).backward()
+    assert grad_close(m.weights.grad, g["arch_grad"]), (m.weights.grad, g["arch_grad"])
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or k not in grad:
+            continue
+        assert p.grad is not None, k
+        assert grad_close(p.grad, grad[k]), k
+    # free-running: a fresh Gumbel draw per forward, finite outputs
+    for layer in m.transformerlayers:
+        layer.gumble_noise_override = None
+        layer.bayes_linear2.eps_override = None
+    a, b = m(src).detach(), m(src).detach()
+    assert torch.isfinite(a).all() and not torch.equal(a, b)

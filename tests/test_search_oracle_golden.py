@@ -112,3 +112,25 @@ def test_search_loop_matches_reference(kind):
             B, H = g["valid"].shape[1], sd["encoder.weight"].shape[1]
             ev, _ = S.bayes_lstm_search_lm(g["valid"][:T], (torch.zeros(2, B, H), torch.zeros(2, B, H)), sd, arch)
     torch.testing.assert_close(ev, g["logits_eval"], rtol=1e-4, atol=1e-5)
+
+
+def test_bayes_trans_search_matches_reference():
+    """BayesTransModelSearch: Gumbel-softmax'd logits with the recovered uniform draw, Bayesian linear2 with the
+    recovered eps; logits, CE, KL, gradient of the logits and of every parameter."""
+    g, sd, grad = load_golden("search_bayes_tlm")
+    nhead, V = int(g["nhead"]), sd["encoder.weight"].shape[0]
+    torch.testing.assert_close(S.bayes_trans_search_lm(g["src"], sd, g["arch"], nhead), g["logits_eval_nogumbel"], **TOL)
+    leaf = leaves(sd)
+    arch = g["arch"].clone().requires_grad_(True)
+    logits = S.bayes_trans_search_lm(g["src"], leaf, arch, nhead, [g["u_0"], g["u_1"]], [g["eps_0"], g["eps_1"]])
+    torch.testing.assert_close(logits, g["logits_train"], **TOL)
+    mle = O.cross_entropy_mean(logits.view(-1, V), g["tgt"])
+    kl = sum(O.kl_mean_form(leaf["transformerlayers.%d.bayes_linear2.weight_mean" % i],
+                            leaf["transformerlayers.%d.bayes_linear2.weight_lgstd" % i]) for i in range(2))
+    torch.testing.assert_close(mle, g["mle"], **TOL)
+    torch.testing.assert_close(kl, g["kl"], **TOL)
+    (mle + kl * g["kl_scale"]).backward()
+    torch.testing.assert_close(arch.grad, g["arch_grad"], **GTOL)
+    for k, v in grad.items():
+        if k != "decoder.weight":
+            torch.testing.assert_close(leaf[k].grad, v, **GTOL)
