@@ -522,3 +522,80 @@ def test_bayes_trans_search_golden(dev):
         layer.bayes_linear2.eps_override = None
     a, b = m(src).detach(), m(src).detach()
     assert torch.isfinite(a).all() and not torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE shapes)
+def test_search_ffn_full_size_limits(dev):
+    """cfg3 shape (M = 8192, d = 512, ff = 4096): with probs = (1,0) the searched feed-forward IS the standard
+    FFN and with (0,1) it IS the GP feed-forward -- outputs and input/weight gradients against the two
+    production paths (ops.ffn / ops.ffn_gp, themselves pinned by the reference fixtures); and the mix is linear
+    in probs."""
+    from bayeslms_amd import ops
+    torch.manual_seed(8)
+    T, B, D, F = 128, 64, 512, 4096
+
+    def P(*shape, s=0.05):
+        return (torch.randn(*shape, device=dev) * s).requires_grad_(True)
+    w1, b1, wg, bg, w2, b2 = P(F, D), P(F), P(F, D), P(F), P(D, F), P(D)
+    coef = torch.rand(4, F, device=dev).requires_grad_(True)
+    x = torch.randn(T, B, D, device=dev).requires_grad_(True)
+    g = torch.randn(T, B, D, device=dev)
+    params = [x, w1, b1, wg, bg, coef, w2, b2]
+
+    def run(fn):
+        for p in params:
+            p.grad = None
+        y = fn()
+        y.backward(g)
+        return y.detach(), [None if p.grad is None else p.grad.clone() for p in params]
+
+    def probs(a, b):
+        return torch.tensor([a, b], device=dev, requires_grad=True)
+    y10, g10 = run(lambda: ops.search_ffn(x, w1, b1, wg, bg, coef, probs(1.0, 0.0), w2, b2))
+    yf, gf = run(lambda: ops.ffn(x, w1, b1, w2, b2))
+    assert rel(y10, yf) < 1e-5
+    for i in (0, 1, 2, 6, 7):
+        assert grad_close(g10[i], gf[i], rtol=1e-4), i
+    y01, g01 = run(lambda: ops.search_ffn(x, w1, b1, wg, bg, coef, probs(0.0, 1.0), w2, b2))
+    yg, gg = run(lambda: ops.ffn_gp(x, wg, bg, coef, w2, b2))
+    assert rel(y01, yg) < 1e-5
+    for i in (0, 3, 4, 5, 6, 7):
+        assert grad_close(g01[i], gg[i], rtol=1e-4), i
+    pr = probs(0.3, 0.7)
+    y, _ = run(lambda: ops.search_ffn(x, w1, b1, wg, bg, coef, pr, w2, b2))
+    b2_only = b2.detach().view(1, 1, D)
+    want = 0.3 * (y10 - b2_only) + 0.7 * (y01 - b2_only) + b2_only  # lin2 is affine: the bias enters once
+    assert rel(y, want) < 1e-4
+    # d loss / d probs = <g, lin2-without-bias(branch)>
+    dp = torch.stack([(g.double() * (y10 - b2_only).double()).sum(), (g.double() * (y01 - b2_only).double()).sum()]).float()
+    assert grad_close(pr.grad, dp, rtol=2e-3), (pr.grad, dp)
+
+
+def test_lstm_search_full_size_limit(dev):
+    """cfg2 shape (T = 35, B = 64, H = 1024): with probs = (1,0) on every gate the search cell IS a plain LSTM
+    layer with bias 2*bias_ih -- outputs, state and input/weight gradients against ops.lstm_layer (the fused
+    LSTM path pinned by the reference fixtures)."""
+    from bayeslms_amd import ops
+    torch.manual_seed(9)
+    T, B, H = 35, 64, 1024
+    s = 1.0 / H ** 0.5
+    w_ih = ((torch.rand(4 * H, H, device=dev) * 2 - 1) * s).requires_grad_(True)
+    w_hh = ((torch.rand(4 * H, H, device=dev) * 2 - 1) * s).requires_grad_(True)
+    b = (torch.randn(4 * H, device=dev) * 0.1).requires_grad_(True)
+    wb_ih, wb_hh = torch.randn(4 * H, H, device=dev) * s, torch.randn(4 * H, H, device=dev) * s
+    bb = torch.randn(4 * H, device=dev) * 0.1
+    x = torch.randn(T, B, H, device=dev).requires_grad_(True)
+    h0, c0 = torch.randn(B, H, device=dev) * 0.3, torch.randn(B, H, device=dev) * 0.3
+    gy = torch.randn(T, B, H, device=dev)
+    probs = torch.tensor([[1.0, 0.0]] * 4, device=dev)
+    y, hT, cT = ops.lstm_search_layer(x, h0, c0, torch.cat([w_ih, wb_ih]), torch.cat([w_hh, wb_hh]), torch.cat([b * 2.0, bb]), probs)
+    (y * gy).sum().backward()
+    got = [t.grad.clone() for t in (x, w_ih, w_hh, b)]
+    for t in (x, w_ih, w_hh, b):
+        t.grad = None
+    zero = torch.zeros_like(b)
+    y2, hT2, cT2 = ops.lstm_layer(x, h0, c0, w_ih, w_hh, b * 2.0, zero)
+    (y2 * gy).sum().backward()
+    assert rel(y, y2) < 1e-5 and rel(hT, hT2) < 1e-5 and rel(cT, cT2) < 1e-5
+    for a, t in zip(got, (x, w_ih, w_hh, b)):
+        assert grad_close(a, t.grad, rtol=1e-4)
