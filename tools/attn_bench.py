@@ -1,8 +1,7 @@
 """Times the causal attention kernels (forward, backward) at the cfg3 shape, with and without dropout."""
-import sys, time
+import sys
 import torch
 sys.path.insert(0, ".")
-from bayeslms_amd import ops
 from bayeslms_amd._lib import lib, check, ptr, stream
 
 def main():
