@@ -91,6 +91,7 @@ SIGNATURES = {
     "blm_mix2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
     "blm_mix2_partials": (_i64, [_i, _i, _i]),
     "blm_mix2_bwd": (_i, [_vp] * 8 + [_i, _i, _i, _f, _rngp, _i, _i, _vp]),
+    "blm_mix2_gp_bwd": (_i, [_vp] * 11 + [_i, _i, _i, _f, _rngp, _i, _i, _vp]),
     "blm_lstm_search_cell_fwd": (_i, [_vp] * 7 + [_i, _i, _vp]),
     "blm_lstm_search_cell_partials": (_i64, [_i, _i]),
     "blm_lstm_search_cell_bwd": (_i, [_vp] * 10 + [_i, _i, _vp]),

@@ -52,12 +52,17 @@ __global__ __launch_bounds__(TPB) void mix2_fwd_kernel(const float* __restrict__
   }
 }
 
-// g = dout * keep;  da = p0 g (* mul_a);  db = p1 g;  partial[2*block + {0,1}] = sum g a, sum g b
+// g = dout * keep;  da = p0 g (* mul_a);  db = p1 g;  partial[2*block + {0,1}] = sum g a, sum g b.
+// GP: branch b is a GPNN mixture of its saved pre-activation z_b (coef (4,N)): db = p1 g mixture'(z_b) is what the
+// next GEMMs need, and dhk (optional) keeps p1 g for the coefficient gradient -- the separate GP backward pass
+// (another read of 2 and write of 1 activation-sized tensors) disappears.
+template <bool GP>
 __global__ __launch_bounds__(TPB) void mix2_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ a,
                                                        const float* __restrict__ b, const float* __restrict__ probs,
                                                        const float* __restrict__ mul_a, float* __restrict__ da,
                                                        float* __restrict__ db, float* __restrict__ partial, long rows,
-                                                       DropKey dk) {
+                                                       DropKey dk, const float* __restrict__ z_b,
+                                                       const float* __restrict__ coef, float* __restrict__ dhk) {
   __shared__ float red[TPB / 64];
   const float p0 = probs[0], p1 = probs[1];
   const int B = dk.B, D = dk.D;
@@ -80,7 +85,14 @@ __global__ __launch_bounds__(TPB) void mix2_bwd_kernel(const float* __restrict__
         m.x *= p0 * g.x; m.y *= p0 * g.y; m.z *= p0 * g.z; m.w *= p0 * g.w;
         *reinterpret_cast<float4*>(da + o) = m;
       }
-      if (db) *reinterpret_cast<float4*>(db + o) = make_float4(p1 * g.x, p1 * g.y, p1 * g.z, p1 * g.w);
+      float4 gb = make_float4(p1 * g.x, p1 * g.y, p1 * g.z, p1 * g.w);
+      if constexpr (GP) {
+        if (dhk) *reinterpret_cast<float4*>(dhk + o) = gb;
+        const float4 z = *reinterpret_cast<const float4*>(z_b + o);
+        gb.x *= dgp_mix(z.x, coef, D, j); gb.y *= dgp_mix(z.y, coef, D, j + 1);
+        gb.z *= dgp_mix(z.z, coef, D, j + 2); gb.w *= dgp_mix(z.w, coef, D, j + 3);
+      }
+      if (db) *reinterpret_cast<float4*>(db + o) = gb;
     }
   } else {
     const long total = rows * B * D;
@@ -90,7 +102,12 @@ __global__ __launch_bounds__(TPB) void mix2_bwd_kernel(const float* __restrict__
       sa += g * a[i];
       sb += g * b[i];
       if (da) da[i] = p0 * g * (mul_a ? mul_a[i] : 1.f);
-      if (db) db[i] = p1 * g;
+      float gb = p1 * g;
+      if constexpr (GP) {
+        if (dhk) dhk[i] = gb;
+        gb *= dgp_mix(z_b[i], coef, D, (int)(i - rb * D));
+      }
+      if (db) db[i] = gb;
     }
   }
   const float ta = block_sum<TPB / 64>(sa, red);
@@ -222,8 +239,20 @@ extern "C" int blm_mix2_bwd(const float* dout, const float* a, const float* b, c
   if (!dout || !a || !b || !probs || !partial || rows < 0 || B < 0 || N < 0)
     return blm_fail(BLM_ERR_INVALID, "blm_mix2_bwd: bad arguments");
   if (drop_p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_mix2_bwd: dropout needs rng");
-  hipLaunchKernelGGL(mix2_bwd_kernel, dim3(mix_grid(rows, B, N)), dim3(TPB), 0, ST, dout, a, b, probs, mul_a, da, db, partial,
-                     (long)rows, make_key(drop_p, rng, B, N, col_offset, global_cols));
+  hipLaunchKernelGGL(mix2_bwd_kernel<false>, dim3(mix_grid(rows, B, N)), dim3(TPB), 0, ST, dout, a, b, probs, mul_a, da, db,
+                     partial, (long)rows, make_key(drop_p, rng, B, N, col_offset, global_cols), nullptr, nullptr, nullptr);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_mix2_gp_bwd(const float* dout, const float* a, const float* b, const float* probs, const float* mul_a,
+                               const float* z_b, const float* coef, float* da, float* dz_b, float* dhk, float* partial, int rows,
+                               int B, int N, float drop_p, const blm_rng* rng, int col_offset, int global_cols, void* stream) {
+  if (!dout || !a || !b || !probs || !z_b || !coef || !partial || rows < 0 || B < 0 || N < 0)
+    return blm_fail(BLM_ERR_INVALID, "blm_mix2_gp_bwd: bad arguments");
+  if (drop_p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_mix2_gp_bwd: dropout needs rng");
+  hipLaunchKernelGGL(mix2_bwd_kernel<true>, dim3(mix_grid(rows, B, N)), dim3(TPB), 0, ST, dout, a, b, probs, mul_a, da, dz_b,
+                     partial, (long)rows, make_key(drop_p, rng, B, N, col_offset, global_cols), z_b, coef, dhk);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }

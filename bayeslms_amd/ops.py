@@ -1264,16 +1264,19 @@ class _SearchFFN(torch.autograd.Function):
         dz1 = torch.empty(M, F_, device=dev, dtype=torch.float32)
         dzg = torch.empty(M, F_, device=dev, dtype=torch.float32)
         dp, drng, dco, dgc = _drop_args(drop, B)
-        check(lib().blm_mix2_bwd(ptr(ds), ptr(h1), ptr(hg), ptr(probs), ptr(a1), ptr(dz1), ptr(dzg), ptr(partial), rows, B,
-                                 F_, dp, drng, dco, dgc, st), "blm_mix2_bwd")
+        # one pass: dz1 = p0 g GELU'(z1), dzg = p1 g mixture'(zg), the two mixing-weight partials, and -- only when
+        # the coefficients want their gradient -- dhg = p1 g for blm_gp_coef_grad
+        dhg = torch.empty(M, F_, device=dev, dtype=torch.float32) if coef.requires_grad else None
+        check(lib().blm_mix2_gp_bwd(ptr(ds), ptr(h1), ptr(hg), ptr(probs), ptr(a1), ptr(zg), ptr(coef), ptr(dz1), ptr(dzg),
+                                    ptr(dhg), ptr(partial), rows, B, F_, dp, drng, dco, dgc, st), "blm_mix2_gp_bwd")
         dprobs = _reduce_partials(partial, 2) if ctx.needs_input_grad[6] else None
         dcoef = None
-        if coef.requires_grad:  # needs the gradient of the GP output (dzg still holds it)
+        if coef.requires_grad:
             buf, _, dcoef = _wgrad_target(coef)
             if dcoef is not None:
                 buf.zero_()
-            check(lib().blm_gp_coef_grad(ptr(dzg), ptr(zg), ptr(buf), M, F_, st), "blm_gp_coef_grad")
-        check(lib().blm_gp_mix_bwd(ptr(dzg), ptr(zg), ptr(coef), ptr(dzg), M, F_, st), "blm_gp_mix_bwd")  # in place
+            check(lib().blm_gp_coef_grad(ptr(dhg), ptr(zg), ptr(buf), M, F_, st), "blm_gp_coef_grad")
+            del dhg
         if w2.requires_grad:
             gemm(L.GEMM_TN, dy, s, _grad_buf(w2), N2, F_, M, N2, F_, F_, accumulate=True,
                  colsum_a=_grad_buf(b2) if b2.requires_grad else None)

@@ -363,6 +363,13 @@ int blm_mix2_bwd(const float* dout, const float* a, const float* b, const float*
                  float* db, float* partial, int rows, int B, int N, float drop_p, const blm_rng* rng, int col_offset,
                  int global_cols, void* stream);
 
+/* blm_mix2_bwd for a GP branch b = sum_i act_i(z_b) coef[i] (GaussTransSearchEncoderLayer, model_search_bayes.py:
+ * 234-236): dz_b = probs[1]*g*mixture'(z_b) directly (no separate blm_gp_mix_bwd pass over the activations);
+ * dhk (may be NULL) = probs[1]*g, the gradient w.r.t. the mixture value that blm_gp_coef_grad needs. */
+int blm_mix2_gp_bwd(const float* dout, const float* a, const float* b, const float* probs, const float* mul_a,
+                    const float* z_b, const float* coef, float* da, float* dz_b, float* dhk, float* partial, int rows, int B,
+                    int N, float drop_p, const blm_rng* rng, int col_offset, int global_cols, void* stream);
+
 /* BayesLSTMSearchCell.bayeslstm pointwise part (model_search_bayes.py:686-710).  z8 = xw8 + hw8 is
  * (B, 8H) with row layout [i f g o | i' f' g' o'] (standard gates, then the four `Bayes` maps);
  * probs (4,2) on the device, rows i,f,g,o:
