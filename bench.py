@@ -20,6 +20,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# dmabuf IPC between the ranks' processes (RCCL / tensor sharing): must be in the environment before HIP starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -194,6 +196,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()  # rank 0 is still evaluating / printing: nobody tears the communicator down under it
         dist.destroy_process_group()
 
 
