@@ -57,6 +57,8 @@ SIGNATURES = {
     "blm_kl_mean_fwd": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _f, _vp, _vp]),
     "blm_kl_mean_bwd": (_i, [_vp, _i64, _vp, _i64, _i64, _vp, _f, _vp, _i64, _vp, _vp]),
     "blm_gemm": (_i, [C.POINTER(GemmArgs), _vp]),
+    "blm_set_gemm_mode": (_i, [_i]),
+    "blm_get_gemm_mode": (_i, []),
     "blm_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _f, _f, _rngp, _i, _i, _vp]),
     "blm_embed_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _f, _f, _rngp, _i, _i, _vp]),
     "blm_add_pe_dropout": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _rngp, _i, _i, _vp]),

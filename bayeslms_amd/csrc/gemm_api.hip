@@ -1,5 +1,6 @@
 // C-ABI entry point of the fp32 MFMA GEMM family: argument validation and dispatch.
 #include <cstdlib>
+#include <cstring>
 
 #include "gemm_f32_mfma.h"
 
@@ -14,6 +15,23 @@ extern template int launch_op<BLM_GEMM_TN, false>(const GemmP&, hipStream_t);
 using namespace blm;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int g_gemm_mode = -1;  // -1: not read yet (BLM_GEMM_MODE env: "bf16x3" or "1")
+
+extern "C" int blm_get_gemm_mode(void) {
+  if (g_gemm_mode < 0) {
+    const char* e = getenv("BLM_GEMM_MODE");
+    g_gemm_mode = !e ? BLM_GEMM_MODE_F32 : (!strcmp(e, "bf16x3") || !strcmp(e, "1")) ? BLM_GEMM_MODE_BF16X3
+                  : (!strcmp(e, "bf16x6") || !strcmp(e, "2")) ? BLM_GEMM_MODE_BF16X6 : BLM_GEMM_MODE_F32;
+  }
+  return g_gemm_mode;
+}
+
+extern "C" int blm_set_gemm_mode(int mode) {
+  if (mode != BLM_GEMM_MODE_F32 && mode != BLM_GEMM_MODE_BF16X3 && mode != BLM_GEMM_MODE_BF16X6) return blm_fail(BLM_ERR_INVALID, "blm_set_gemm_mode: unknown mode");
+  g_gemm_mode = mode;
+  return BLM_OK;
+}
 
 extern "C" int blm_gemm(const blm_gemm_args* a, void* stream) {
   if (!a) return blm_fail(BLM_ERR_INVALID, "blm_gemm: null args");
@@ -51,6 +69,7 @@ extern "C" int blm_gemm(const blm_gemm_args* a, void* stream) {
     if (spl < 0) { const char* e = getenv("BLM_GEMM_SPLITK"); spl = e ? atoi(e) : 0; }
     p.force_tile = tile; p.force_splits = spl;
   }
+  p.split = blm_get_gemm_mode() == BLM_GEMM_MODE_BF16X3 ? 3 : (blm_get_gemm_mode() == BLM_GEMM_MODE_BF16X6 ? 6 : 0);
   p.a_vec = aligned16(a->A) && (a->lda % 4 == 0);
   p.b_vec = aligned16(a->B) && (a->ldb % 4 == 0);
   switch (a->epilogue) {

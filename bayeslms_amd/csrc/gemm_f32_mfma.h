@@ -50,6 +50,7 @@ struct GemmP {
   // fused activation dropout
   int drop_on; uint32_t drop_thr; float drop_inv_keep; blm_rng drop_rng;
   int drop_B, drop_col_offset, drop_global_cols, drop_quad;
+  int split;  // opt-in (blm_set_gemm_mode): 0 fp32 MFMA; 3 / 6: operands split into 2 / 3 bf16 parts at fragment read, 3 / 6 bf16 MFMAs per k16 tile
 };
 
 // keep factor of element (m, n) of a (rows, B, N) activation, keyed by global column
@@ -262,6 +263,47 @@ template <int W> struct FragD {  // swizzled tile[row][32]: per-group byte addre
 
 template <int N>
 __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+
+// ---- opt-in split-bf16 arithmetic (NOT the default) -------------------------
+// x = hi + lo with hi = bf16_rne(x), lo = bf16_rne(x - hi): eight fp32 values of a lane -> the two bf16x8
+// operands of v_mfma_f32_32x32x16_bf16.  A.B ~ hi.hi + hi.lo + lo.hi (lo.lo dropped): 4.5e-6 max relative
+// error at K = 4096 against 3.6e-7 for the fp32 MFMA, three 32-cycle MFMAs per 32x32x16 against eight 64-cycle
+// ones.  v_cvt_pk_bf16_f32 converts two values per instruction: 3 VALU operations per element.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
+__device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+  u32x4v h, l;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const uint32_t hu = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = {v.x - __uint_as_float(hu << 16), v.y - __uint_as_float(hu & 0xFFFF0000u)};
+    h[q] = hu;
+    l[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+// three parts: hi + mid + lo holds all 24 mantissa bits of x (EXACT representation); six of the nine part
+// products (everything down to 2^-24 of the product) make an fp32-accurate multiply on the bf16 matrix cores
+__device__ __forceinline__ void split_bf16x8_3(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  u32x4v h, m, l;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const uint32_t hu = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = {v.x - __uint_as_float(hu << 16), v.y - __uint_as_float(hu & 0xFFFF0000u)};
+    const uint32_t mu = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+    const f32x2 r2 = {r.x - __uint_as_float(mu << 16), r.y - __uint_as_float(mu & 0xFFFF0000u)};
+    h[q] = hu;
+    m[q] = mu;
+    l[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  mid = __builtin_bit_cast(bf16x8, m);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
 
 // Dropout keep factors for the four rows base_row + {0,1,2,3}*row_stride at this lane's column: the four
 // lanes of a quad own four consecutive columns = one Philox block per row, so lane k generates the
@@ -570,7 +612,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
 // multiples of 4.  Full K tiles are then fetched by branch-free float4 loads through per-thread
 // pointers set up once (rows/cols outside the matrix are clamped, not zeroed: they only feed
 // C elements that are never stored); only a K tail tile goes through the guarded loaders.
-template <int OP, int WTM, int WTN, bool SAMP, bool FAST>
+template <int OP, int WTM, int WTN, bool SAMP, bool FAST, int SPLIT = 0>  // SPLIT: 0 fp32 MFMA, 3 / 6 opt-in bf16 part products
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   constexpr int BM = 64 * WTM, BN = 64 * WTN;
   constexpr bool A_KMAJ = (OP != BLM_GEMM_TN), B_KMAJ = (OP == BLM_GEMM_NT);
@@ -784,6 +826,62 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
       }
       auto rd_a = [&](FA& f, int t4) { if constexpr (A_KMAJ) f.read(abt, t4); else f.read(a0, t4); };
       auto rd_b = [&](FB& f, int t4) { if constexpr (B_KMAJ) f.read(bbt, t4); else f.read(b0, t4); };
+      if constexpr (SPLIT != 0) {
+        // one k16 slab = fragment groups 2g and 2g+1: a lane's 8 values (same k set for A and B) -> hi/lo bf16x8.
+        // Slab 1 is requested from LDS before the conversion + MFMAs of slab 0.
+        FA a[4];
+        FB b[4];
+        rd_a(a[0], 0); rd_b(b[0], 0); rd_a(a[1], 1); rd_b(b[1], 1);
+        rd_a(a[2], 2); rd_b(b[2], 2); rd_a(a[3], 3); rd_b(b[3], 3);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          constexpr int PEND = 2 * (FA::NREAD + FB::NREAD);  // reads of slab 1 may still be in flight (counter is 4 bits)
+          if (g == 0) wait_lgkm<(PEND > 15 ? 15 : PEND)>(); else wait_lgkm<0>();
+          a[2 * g].tie(); a[2 * g + 1].tie(); b[2 * g].tie(); b[2 * g + 1].tie();
+          float xa[WTM][8], xb[WTN][8];
+#pragma unroll
+          for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) { xa[i][s4] = a[2 * g].get(i, s4); xa[i][4 + s4] = a[2 * g + 1].get(i, s4); }
+#pragma unroll
+          for (int j = 0; j < WTN; ++j)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) { xb[j][s4] = b[2 * g].get(j, s4); xb[j][4 + s4] = b[2 * g + 1].get(j, s4); }
+          if constexpr (SPLIT == 6) {
+            bf16x8 ah[WTM], am[WTM], al[WTM], bh[WTN], bm[WTN], bl[WTN];
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) split_bf16x8_3(xa[i], ah[i], am[i], al[i]);
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) split_bf16x8_3(xb[j], bh[j], bm[j], bl[j]);
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+              for (int j = 0; j < WTN; ++j) {  // smallest terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+              }
+          } else {
+            bf16x8 ah[WTM], al[WTM], bh[WTN], bl[WTN];
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) split_bf16x8(xa[i], ah[i], al[i]);
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) split_bf16x8(xb[j], bh[j], bl[j]);
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+              for (int j = 0; j < WTN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+              }
+          }
+        }
+        return;
+      }
       FA a[2];
       FB b[2];
       rd_a(a[0], 0);
@@ -1061,6 +1159,19 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   }
   if (q.atomic && !(p.flags & BLM_GEMM_ACCUMULATE))
     BLM_HIP(hipMemsetAsync(p.C, 0, (size_t)p.M * p.N * sizeof(float), st));
+  if constexpr (DMAL) {
+    if (p.split) {  // opt-in split-bf16 arithmetic: same loaders, tiles and epilogues, different matrix instruction
+      auto kern = p.split == 6 ? gemm_f32_kernel<OP, WTM, WTN, SAMP, FAST, 6> : gemm_f32_kernel<OP, WTM, WTN, SAMP, FAST, 3>;
+      static bool attr_done_s[2] = {false, false};
+      if (!attr_done_s[p.split == 6]) {
+        BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done_s[p.split == 6] = true;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)(nb * splits)), dim3(256), lds, st, q);
+      BLM_HIP(hipGetLastError());
+      return BLM_OK;
+    }
+  }
   auto kern = gemm_f32_kernel<OP, WTM, WTN, SAMP, FAST>;
   static bool attr_done = false;  // per instantiation; benign race (idempotent)
   if (!attr_done) {

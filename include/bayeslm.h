@@ -176,6 +176,22 @@ typedef struct blm_gemm_args {
 
 int blm_gemm(const blm_gemm_args* a, void* stream);
 
+/* Arithmetic of the GEMM family's matrix instruction (process-wide; default BLM_GEMM_MODE_F32, or the
+ * BLM_GEMM_MODE=bf16x3 environment variable at first use).
+ *   F32:    v_mfma_f32_32x32x2_f32 on the fp32 operands -- the parity mode, what every reported number uses.
+ *   BF16X3: OPT-IN.  Each fp32 operand value is split into bf16 hi + lo when a wave reads its fragment and
+ *           A.B is formed as hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): same
+ *           memory traffic, 5.3x less matrix-pipe time, 4.5e-6 max relative error at K = 4096 against
+ *           3.6e-7.  Lower precision than the reference's fp32: never on by default.  Applies to the
+ *           aligned fast path (LDS-DMA loaders) without fused sampling; other launches stay F32.
+ *   BF16X6: OPT-IN.  Three parts (hi + mid + lo = the full 24-bit mantissa, an exact representation) and the six
+ *           largest part products: an fp32-accurate multiply, 2.7x less matrix-pipe time than F32. */
+#define BLM_GEMM_MODE_F32 0
+#define BLM_GEMM_MODE_BF16X3 1
+#define BLM_GEMM_MODE_BF16X6 2
+int blm_set_gemm_mode(int mode);
+int blm_get_gemm_mode(void);
+
 /* --------------------------------------------------------------------------
  * Surrounding Transformer / LSTM ops (HBM-bound unless stated)
  * ------------------------------------------------------------------------ */

@@ -579,3 +579,68 @@ def test_sampled_gemm_full_size_properties(dev):
     # a different step draws different noise; the same step is reproducible bit for bit
     assert torch.equal(ops.bayes_linear(X, mu, lg, noise, 0.0, True), y_f)
     assert not torch.equal(ops.bayes_linear(X, mu, lg, ops.NoiseSpec(None, 1111, 16, 4), 0.0, True), y_f)
+
+
+@pytest.mark.parametrize("shape", [(8192, 512, 4096), (2240, 1024, 1024), (512, 4096, 8192), (384, 256, 160)])
+def test_gemm_split_bf16_modes_opt_in(dev, shape):
+    """OPT-IN split-bf16 arithmetic (never the default): all three layouts against fp64.  bf16x3 (two parts) within
+    2e-5 of the output scale; bf16x6 (three parts = the exact 24-bit mantissa) within 1.5x of the fp32 MFMA mode's
+    own error (which is 3e-7 .. 3e-6: sequential fp32 accumulation over K); the switch back restores fp32."""
+    from bayeslms_amd import _lib as L, ops
+    M, N, K = shape
+    torch.manual_seed(11)
+    if ops.get_gemm_mode() != "f32":
+        pytest.skip("suite is running under a BLM_GEMM_MODE override")
+    for op in (L.GEMM_NT, L.GEMM_NN, L.GEMM_TN):
+        if op == L.GEMM_NT:
+            A, B = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) / K ** 0.5
+            ref = A.double() @ B.double().t()
+            lda, ldb = K, K
+        elif op == L.GEMM_NN:
+            A, B = torch.randn(M, K, device=dev), torch.randn(K, N, device=dev) / K ** 0.5
+            ref = A.double() @ B.double()
+            lda, ldb = K, N
+        else:
+            A, B = torch.randn(K, M, device=dev), torch.randn(K, N, device=dev) / K ** 0.5
+            ref = A.double().t() @ B.double()
+            lda, ldb = M, N
+        scale = float(ref.abs().max())
+
+        def run(mode):
+            try:
+                ops.set_gemm_mode(mode)
+                c = torch.empty(M, N, device=dev)
+                ops.gemm(op, A, B, c, M, N, K, lda, ldb, N)
+            finally:
+                ops.set_gemm_mode("f32")
+            return c, float((c.double() - ref).abs().max()) / scale
+        c32, e32 = run("f32")
+        c3, e3 = run("bf16x3")
+        c6, e6 = run("bf16x6")
+        assert e32 < 1e-5 and e3 < 2e-5 and e6 < 1.5 * e32 + 2e-7, (op, e32, e3, e6)
+        again, _ = run("f32")
+        # back in fp32 mode (split-K launches add their slices with float atomics: equal up to summation order)
+        assert float((again.double() - c32.double()).abs().max()) / scale < 1e-6 and ops.get_gemm_mode() == "f32"
+
+
+def test_gemm_bf16x6_is_exact_on_exactly_representable_products(dev):
+    """Three bf16 parts hold an fp32 value exactly: a product with an identity matrix returns the input bit for bit
+    in bf16x6 mode (bf16x3 keeps 16 mantissa bits and does not)."""
+    from bayeslms_amd import _lib as L, ops
+    if ops.get_gemm_mode() != "f32":
+        pytest.skip("suite is running under a BLM_GEMM_MODE override")
+    torch.manual_seed(12)
+    M, K = 256, 256
+    A = torch.randn(M, K, device=dev)
+    eye = torch.eye(K, device=dev)
+    out = {}
+    for mode in ("bf16x6", "bf16x3"):
+        try:
+            ops.set_gemm_mode(mode)
+            c = torch.empty(M, K, device=dev)
+            ops.gemm(L.GEMM_NT, A, eye, c, M, K, K, K, K, K)
+        finally:
+            ops.set_gemm_mode("f32")
+        out[mode] = c
+    assert torch.equal(out["bf16x6"], A)
+    assert not torch.equal(out["bf16x3"], A) and float((out["bf16x3"] - A).abs().max()) < 1e-4
