@@ -251,7 +251,10 @@ def main():
             "final_loss": round(final_loss, 4), "eval_ppl": round(eval_ppl, 2),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(e)}
         else:
             out["cpu_baseline"] = None
         mode = ops.get_gemm_mode()
@@ -259,7 +262,11 @@ def main():
         if mode != "f32":  # only under an explicit BLM_GEMM_MODE override: say so where the judge looks
             out["dtype"] = "f32 operands split into bf16 parts (%s), fp32 accumulate -- NOT the fp32 parity mode" % mode
         elif world == 1 and not args.no_opt_in:
-            out["opt_in"] = opt_in_modes(model, tr, train, get_batch, steps_total, args, ops, engine)
+            try:  # an extra: it must never cost the headline line
+                out["opt_in"] = opt_in_modes(model, tr, train, get_batch, steps_total, args, ops, engine)
+            except Exception as e:  # noqa: BLE001
+                ops.set_gemm_mode("f32")
+                out["opt_in"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()  # rank 0 is still evaluating / printing: nobody tears the communicator down under it
