@@ -84,6 +84,56 @@ __global__ __launch_bounds__(256) void k4(float* out, unsigned long long* cyc, i
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// MODE 5: same work as k4, one scheduling region per slab; the compiler orders it by sched_group_barrier (1 MFMA : NV VALU)
+template <int NV>
+__global__ __launch_bounds__(256) void k5(float* out, unsigned long long* cyc, int iters, float seed) {
+  f32x16 acc[4] = {(f32x16)(0.f), (f32x16)(0.f), (f32x16)(0.f), (f32x16)(0.f)};
+  float x[4][8];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[f][e] = seed * (1.f + f) + threadIdx.x * 1e-3f * (e + 1);
+  uint32_t P[2][4][3][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) split_pair(x[f][2 * q], x[f][2 * q + 1], P[s][f][0][q], P[s][f][1][q], P[s][f][2][q]);
+  auto body = [&](const int cur) {
+    const int nxt = cur ^ 1;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < 24; ++n) {
+      const int q = n >> 2, t = n & 3, i = t >> 1, j = t & 1;
+      const int ia = q == 0 ? 2 : (q == 1 ? 0 : (q < 4 ? 1 : 0)), ib = q == 0 ? 0 : (q == 1 ? 2 : (q == 2 ? 1 : (q == 3 ? 0 : (q == 4 ? 1 : 0))));
+      const u32x4 av = {P[cur][i][ia][0], P[cur][i][ia][1], P[cur][i][ia][2], P[cur][i][ia][3]};
+      const u32x4 bv = {P[cur][2 + j][ib][0], P[cur][2 + j][ib][1], P[cur][2 + j][ib][2], P[cur][2 + j][ib][3]};
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        x[f][2 * qq] += 1e-7f; x[f][2 * qq + 1] += 1e-7f;
+        split_pair(x[f][2 * qq], x[f][2 * qq + 1], P[nxt][f][0][qq], P[nxt][f][1][qq], P[nxt][f][2][qq]);
+      }
+#pragma unroll
+    for (int n = 0; n < 24; ++n) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; it += 2) { body(0); body(1); }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 template <int MODE>  // 0 MFMA only, 1 VALU only, 2 back to back, 3 pipelined
 __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, int iters, float seed) {
   f32x16 acc[4] = {(f32x16)(0.f), (f32x16)(0.f), (f32x16)(0.f), (f32x16)(0.f)};
@@ -126,7 +176,12 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, in
       }
     } else {
 #pragma unroll
-      for (int f = 0; f < 4; ++f) sink += __builtin_bit_cast(u32x4, p[f][2])[0] * 1e-30f;
+      for (int f = 0; f < 4; ++f)  // consume every word of every part: otherwise most of the split is dead code
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const u32x4 w = __builtin_bit_cast(u32x4, p[f][c]);
+          asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
+        }
     }
     if (MODE == 3) {
 #pragma unroll
@@ -179,6 +234,10 @@ int main() {
       float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("%-28s %d block(s)/CU: %.0f ns / iteration\n", "hand-interleaved 3:2", blocks / 256, ms * 1e6 / iters);
     }
+#define RUN5(NV) { const int iters = 4000; k5<NV><<<blocks, 256>>>(out, cyc, 100, 0.37f); hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); \
+      hipEventRecord(e0); k5<NV><<<blocks, 256>>>(out, cyc, iters, 0.37f); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); \
+      printf("sched groups 1 MFMA : %d VALU    %d block(s)/CU: %.0f ns / iteration\n", NV, blocks / 256, ms * 1e6 / iters); }
+    RUN5(4) RUN5(6) RUN5(8) RUN5(9) RUN5(12)
   }
   return 0;
 }
