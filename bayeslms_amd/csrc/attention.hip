@@ -229,7 +229,8 @@ __global__ __launch_bounds__(ATT_T) void attn_bwd_kernel(const AttnP p) {
 static int fill(AttnP& p, int T, int B, int nhead, int head_dim, float pdrop, const blm_rng* rng, int col_offset,
                 const char* who) {
   if (T < 0 || B < 0 || nhead <= 0) return blm_fail(BLM_ERR_INVALID, "%s: bad shape", who);
-  if (T > ATT_T) return blm_fail(BLM_ERR_UNSUPPORTED, "%s: T=%d > %d not supported in this build", who, T, ATT_T);
+  if (T > ATT_T && head_dim != 64)  // head_dim 64 has the chunked matrix-core path for any length (attention_mfma.hip)
+    return blm_fail(BLM_ERR_UNSUPPORTED, "%s: T=%d > %d needs head_dim 64 (got %d)", who, T, ATT_T, head_dim);
   if (!(head_dim == 4 || head_dim == 8 || head_dim == 16 || head_dim == 32 || head_dim == 64))
     return blm_fail(BLM_ERR_UNSUPPORTED, "%s: head_dim %d not in {4,8,16,32,64}", who, head_dim);
   if (pdrop > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "%s: dropout needs rng", who);

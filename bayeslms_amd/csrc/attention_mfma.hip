@@ -417,6 +417,228 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnM p) {
   if (kt < ntile) attn_dkv_pass(p, Qs, Os, lse_s, del_s, kt, ntile, ka, va, b, off, bh, lane, li, lh);
 }
 
+
+// ------------------------------------------------------------------ sequences longer than 128 tokens
+// Same tiles and operand orientation, with a flash-style outer loop: a workgroup owns 128 queries (keys) = one
+// 32-row tile per wave and walks the 128-row chunks of the other side through LDS -- the forward with an online
+// softmax (running max / sum per lane = per query, accumulators rescaled when the max moves), the backward passes
+// with the saved log-sum-exp.  Not tuned like the T <= 128 kernels above (one chunk in LDS at a time, two barriers
+// per chunk): it exists so that long hypotheses and --seq_len > 128 run on the same path (the reference takes any
+// length up to its 5000-row positional table, model.py:97-103).
+template <int NT>
+__device__ __forceinline__ void fetch_rows_at(float4 (&v)[2048 / NT], const float* src, long ld, int T, int B, int b, int off, int row0) {
+  const bool al = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)(ld * 4) | (uintptr_t)(off * 4)) & 15) == 0;
+#pragma unroll
+  for (int u = 0; u < 2048 / NT; ++u) {
+    const int i = threadIdx.x + NT * u, row = i >> 4, c = (i & 15) << 2;
+    const float* s = src + ((long)min(row0 + row, T - 1) * B + b) * ld + off + c;
+    if (al) v[u] = *reinterpret_cast<const float4*>(s);
+    else v[u] = make_float4(s[0], s[1], s[2], s[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnM p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Ks = sm;
+  float* Vs = sm + AT * LS;
+  const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
+  const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int qb = gridDim.y - 1 - blockIdx.y;  // the longest query blocks first
+  const int qt = 4 * qb + wave, q = 32 * qt + li, qc = min(q, T - 1);
+  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
+  float qa[32];
+  fetch_op(qa, p.q + ((long)qc * p.B + b) * p.ld + off + 32 * lh);
+#pragma unroll
+  for (int s = 0; s < 32; ++s) qa[s] *= p.scale;
+  float m = -INFINITY, l = 0.f;
+  f32x16 ot[2] = {(f32x16)(0.f), (f32x16)(0.f)};
+#pragma unroll 1
+  for (int kc = 0; kc <= qb; ++kc) {
+    __syncthreads();  // every wave is done with the previous chunk
+    {
+      float4 kk[8], vv[8];
+      fetch_rows_at<256>(kk, p.k, p.ld, T, p.B, b, off, 128 * kc);
+      fetch_rows_at<256>(vv, p.v, p.ld, T, p.B, b, off, 128 * kc);
+      put_rows<256>(Ks, kk, T - 128 * kc, 1.f);
+      put_rows<256>(Vs, vv, T - 128 * kc, 1.f);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < 4; ++kt) {
+      const int gk0 = 128 * kc + 32 * kt;       // first key of the tile
+      if (gk0 > 32 * qt + 31 || gk0 >= T) break;  // wave-uniform: above the diagonal / past the sequence
+      f32x16 st = tile_rows_x_regs(Ks, 32 * kt, qa, li, lh);
+      float tm = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (gk0 + mrow(r, lh) > q) st[r] = -INFINITY;  // causal (also hides keys >= T for valid queries)
+        tm = fmaxf(tm, st[r]);
+      }
+      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+      const float mn = fmaxf(m, tm);  // finite: key gk0 <= q of some lane half is always unmasked in a processed tile
+      const float alpha = __expf(m - mn);
+      float ts = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] = __expf(st[r] - mn);
+        ts += st[r];
+      }
+      ts += __shfl_xor(ts, 32, 64);
+      l = l * alpha + ts;
+      m = mn;
+      ot[0] *= alpha;
+      ot[1] *= alpha;
+      if (p.drop) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float kp[4];
+          keep_row4(p, bh * T + qc, gk0 + 8 * g + 4 * lh, kp);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) st[4 * g + e] *= kp[e];
+        }
+      }
+      acc_xt_regs(ot, Vs, 32 * kt, st, li, lh);
+    }
+  }
+  if (q < T) {
+    store_t(p.out + ((long)q * p.B + b) * ((long)p.nhead * HD) + off, ot, lh, 1.f / l);
+    if (p.lse && lh == 0) p.lse[(long)blockIdx.x * T + q] = m + __logf(l);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_long_kernel(const AttnM p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Ks = sm;
+  float* Vs = sm + AT * LS;
+  const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
+  const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const long dmodel = (long)p.nhead * HD;
+  const int qb = gridDim.y - 1 - blockIdx.y;
+  const int qt = 4 * qb + wave, q = 32 * qt + li, qc = min(q, T - 1);
+  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
+  float qa[32], da[32];
+  float delta = 0.f;
+  {
+    const long r0 = (long)qc * p.B + b;
+    float oa[32];
+    fetch_op(qa, p.q + r0 * p.ld + off + 32 * lh);
+    fetch_op(da, p.dout + r0 * dmodel + off + 32 * lh);
+    fetch_op(oa, p.o_in + r0 * dmodel + off + 32 * lh);
+#pragma unroll
+    for (int s = 0; s < 32; ++s) { delta += da[s] * oa[s]; qa[s] *= p.scale; }
+  }
+  delta += __shfl_xor(delta, 32, 64);
+  const float lse = p.lse[(long)blockIdx.x * T + qc];
+  f32x16 dqt[2] = {(f32x16)(0.f), (f32x16)(0.f)};
+#pragma unroll 1
+  for (int kc = 0; kc <= qb; ++kc) {
+    __syncthreads();
+    {
+      float4 kk[8], vv[8];
+      fetch_rows_at<256>(kk, p.k, p.ld, T, p.B, b, off, 128 * kc);
+      fetch_rows_at<256>(vv, p.v, p.ld, T, p.B, b, off, 128 * kc);
+      put_rows<256>(Ks, kk, T - 128 * kc, 1.f);
+      put_rows<256>(Vs, vv, T - 128 * kc, 1.f);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < 4; ++kt) {
+      const int gk0 = 128 * kc + 32 * kt;
+      if (gk0 > 32 * qt + 31 || gk0 >= T) break;
+      f32x16 st, dp;
+      tile2_rows_x_regs(st, dp, Ks, Vs, 32 * kt, qa, da, li, lh);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float kp[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.drop) keep_row4(p, bh * T + qc, gk0 + 8 * g + 4 * lh, kp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float pr = gk0 + mrow(r, lh) <= q ? __expf(st[r] - lse) : 0.f;
+          st[r] = pr * (dp[r] * kp[e] - delta);  // dS^T
+        }
+      }
+      acc_xt_regs(dqt, Ks, 32 * kt, st, li, lh);
+    }
+  }
+  if (q < T) store_t(p.dq + ((long)q * p.B + b) * p.ldd + off, dqt, lh, p.scale);
+}
+
+// lane = key; walks the query chunks kb .. last (queries >= the key)
+__global__ __launch_bounds__(256) void attn_bwd_dkv_long_kernel(const AttnM p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Qs = sm;            // Q * scale
+  float* Os = sm + AT * LS;  // dO
+  float* lse_s = sm + 2 * AT * LS;
+  float* del_s = lse_s + AT;
+  const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
+  const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const long dmodel = (long)p.nhead * HD;
+  const int kb = blockIdx.y;  // key block 0 meets every query chunk: the longest first
+  const int nqc = (T + 127) >> 7;
+  const int kt = 4 * kb + wave, key = 32 * kt + li, kc = min(key, T - 1);
+  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
+  float ka[32], va[32];
+  fetch_op(ka, p.k + ((long)kc * p.B + b) * p.ld + off + 32 * lh);
+  fetch_op(va, p.v + ((long)kc * p.B + b) * p.ld + off + 32 * lh);
+  f32x16 dkt[2] = {(f32x16)(0.f), (f32x16)(0.f)}, dvt[2] = {(f32x16)(0.f), (f32x16)(0.f)};
+#pragma unroll 1
+  for (int qcn = kb; qcn < nqc; ++qcn) {
+    __syncthreads();
+    {
+      float4 qq[8], dd[8];
+      fetch_rows_at<256>(qq, p.q, p.ld, T, p.B, b, off, 128 * qcn);
+      fetch_rows_at<256>(dd, p.dout, dmodel, T, p.B, b, off, 128 * qcn);
+      put_rows<256>(Qs, qq, T - 128 * qcn, p.scale);
+      put_rows<256>(Os, dd, T - 128 * qcn, 1.f);
+    }
+    {  // delta[q] = rowsum(dO * O), lse[q] of this chunk's rows: two threads per row
+      const int row = threadIdx.x >> 1, half = threadIdx.x & 1, grow = 128 * qcn + row, rc = min(grow, T - 1);
+      const float* ds = p.dout + ((long)rc * p.B + b) * dmodel + off + (HD / 2) * half;
+      const float* os = p.o_in + ((long)rc * p.B + b) * dmodel + off + (HD / 2) * half;
+      float d = 0.f;
+      for (int c = 0; c < HD / 2; ++c) d += ds[c] * os[c];
+      d += __shfl_xor(d, 1);
+      if (half == 0) {
+        lse_s[row] = grow < T ? p.lse[(long)blockIdx.x * T + rc] : 0.f;
+        del_s[row] = grow < T ? d : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int qt = 0; qt < 4; ++qt) {
+      const int gq0 = 128 * qcn + 32 * qt;           // first query of the tile
+      if (gq0 >= T) break;                           // wave-uniform
+      if (gq0 + 31 < 32 * kt) continue;              // every query of the tile is below every key of this wave
+      f32x16 sc, dp;  // S[q][key], dP[q][key]: q in registers
+      tile2_rows_x_regs(sc, dp, Qs, Os, 32 * qt, ka, va, li, lh);
+      f32x16 pd;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float kp[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.drop) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            kp[e] = philox_bits1_rolled(p.rng, (bh * T + min(gq0 + 8 * g + 4 * lh + e, T - 1)) * (uint64_t)T + kc) >= p.thr ? p.inv_keep : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e, lr = 32 * qt + mrow(r, lh), qr = 128 * qcn + lr;
+          const float pr = (qr >= key && qr < T) ? __expf(sc[r] - lse_s[lr]) : 0.f;
+          pd[r] = pr * kp[e];
+          sc[r] = pr * (dp[r] * kp[e] - del_s[lr]);  // dS[q][key]
+        }
+      }
+      acc_xt_regs(dvt, Os, 32 * qt, pd, li, lh);
+      acc_xt_regs(dkt, Qs, 32 * qt, sc, li, lh);
+    }
+  }
+  if (key < T) {
+    store_t(p.dk + ((long)key * p.B + b) * p.ldd + off, dkt, lh, 1.f);
+    store_t(p.dv + ((long)key * p.B + b) * p.ldd + off, dvt, lh, 1.f);
+  }
+}
+
 }  // namespace blm
 
 using namespace blm;
@@ -446,7 +668,18 @@ int blm_attn_fwd_mfma(const float* q, const float* k, const float* v, int64_t ld
   p.q = q; p.k = k; p.v = v; p.ld = ld; p.out = out; p.lse = lse;
   const size_t lds = (size_t)2 * AT * LS * sizeof(float);
   static bool once = false;
-  if (!once) { int rc = set_lds(attn_fwd_mfma_kernel, lds); if (rc) return rc; once = true; }
+  if (!once) {
+    int rc = set_lds(attn_fwd_mfma_kernel, lds);
+    if (rc) return rc;
+    rc = set_lds(attn_fwd_long_kernel, lds);
+    if (rc) return rc;
+    once = true;
+  }
+  if (T > AT) {  // flash-style chunk loop, one workgroup per (batch column, head, 128-query block)
+    hipLaunchKernelGGL(attn_fwd_long_kernel, dim3(B * nhead, (T + AT - 1) / AT), dim3(256), lds, st, p);
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
+  }
   hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * nhead), dim3(256), lds, st, p);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
@@ -466,7 +699,19 @@ int blm_attn_bwd_mfma(const float* q, const float* k, const float* v, int64_t ld
     if (rc) return rc;
     rc = set_lds(attn_bwd_dkv_mfma_kernel, lds2);
     if (rc) return rc;
+    rc = set_lds(attn_bwd_dq_long_kernel, lds1);
+    if (rc) return rc;
+    rc = set_lds(attn_bwd_dkv_long_kernel, lds2);
+    if (rc) return rc;
     once = true;
+  }
+  if (T > AT) {
+    const dim3 grid(B * nhead, (T + AT - 1) / AT);
+    hipLaunchKernelGGL(attn_bwd_dq_long_kernel, grid, dim3(256), lds1, st, p);
+    BLM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(attn_bwd_dkv_long_kernel, grid, dim3(256), lds2, st, p);
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
   }
   hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(B * nhead), dim3(256), lds1, st, p);
   BLM_HIP(hipGetLastError());

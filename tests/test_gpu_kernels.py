@@ -346,7 +346,9 @@ def test_add_dropout_ln(dev, D):
 
 
 @pytest.mark.parametrize("T,B,nhead,hd", [(6, 3, 4, 4), (100, 2, 2, 32), (128, 3, 2, 64), (33, 2, 1, 16), (33, 2, 2, 64),
-                                          (1, 1, 1, 64), (97, 1, 3, 64)])
+                                          (1, 1, 1, 64), (97, 1, 3, 64),
+                                          # longer than 128: the chunked (flash-style) matrix-core kernels
+                                          (129, 2, 2, 64), (200, 1, 3, 64), (256, 2, 1, 64), (301, 1, 2, 64), (515, 1, 1, 64)])
 def test_attention_matches_oracle(dev, T, B, nhead, hd):
     ops = ops_mod()
     d = nhead * hd
@@ -370,7 +372,8 @@ def test_attention_matches_oracle(dev, T, B, nhead, hd):
     assert rel(torch.cat([t.grad for t in q3], -1), qr.grad) < 2e-5
 
 
-@pytest.mark.parametrize("T,B,nhead,hd", [(8, 2, 2, 4), (96, 2, 2, 64), (50, 3, 1, 64), (128, 1, 2, 64)])
+@pytest.mark.parametrize("T,B,nhead,hd", [(8, 2, 2, 4), (96, 2, 2, 64), (50, 3, 1, 64), (128, 1, 2, 64), (160, 2, 1, 64),
+                                          (203, 1, 2, 64)])
 def test_attention_dropout_uses_philox_mask(dev, T, B, nhead, hd):
     """Probability dropout (VALU kernels for small heads, MFMA kernels for head_dim 64; T % 4 != 0
     takes the per-element Philox path)."""
@@ -644,3 +647,12 @@ def test_gemm_bf16x6_is_exact_on_exactly_representable_products(dev):
         out[mode] = c
     assert torch.equal(out["bf16x6"], A)
     assert not torch.equal(out["bf16x3"], A) and float((out["bf16x3"] - A).abs().max()) < 1e-4
+
+
+def test_attention_long_sequence_unsupported_head_dim_is_loud(dev):
+    """T > 128 needs head_dim 64 (the chunked matrix-core kernels); other head sizes say so instead of computing."""
+    ops = ops_mod()
+    from bayeslms_amd._lib import BayesLMError
+    qkv = torch.randn(130, 1, 3 * 32, device=dev, requires_grad=True)
+    with pytest.raises(BayesLMError, match="head_dim 64"):
+        ops.attention(qkv, 1)

@@ -793,3 +793,35 @@ def test_cfg3_full_model_backward_matches_oracle(dev):
         assert grad_close(p.grad, leaf[k].grad), k
         checked += 1
     assert checked > 70
+
+
+def test_transformer_longer_than_128_tokens(dev):
+    """Windows / hypotheses longer than 128 tokens take the chunked attention kernels: logits, loss and every
+    gradient of a Bayesian Transformer at T = 200 against the CPU oracle (the reference accepts any length up to
+    its 5000-row positional table, model.py:97-103)."""
+    from bayeslms_amd import model as M, ops
+    from oracle import bayes_oracle as O
+    torch.manual_seed(21)
+    V, d, nhead, ff, L, T, B = 60, 128, 2, 64, 2, 200, 2
+    m = M.BayesTransformerModel(V, d, nhead, ff, L, 0.0, True, "FFN").to(dev)
+    zero_dropout(m)  # layer 0 is built with a hard-coded 0.2 (model.py:1202)
+    src, tgt = torch.randint(0, V, (T, B)), torch.randint(0, V, (T * B,))
+    eps = torch.randn(d, ff)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    m.eval()
+    with torch.no_grad():
+        assert rel(m(src.to(dev)), O.transformer_lm(src, sd, nhead, None)) < TOL
+    m.train()
+    m.transformerlayers[0].linear2.eps_override = eps.to(dev)
+    logits = m(src.to(dev))
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    want = O.transformer_lm(src, leaf, nhead, eps)
+    assert rel(logits, want) < TOL
+    mle, _ = ops.cross_entropy(logits.clone().view(-1, V), tgt.to(dev))
+    mle.backward()
+    O.cross_entropy_mean(want.view(-1, V), tgt).backward()
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or leaf[k].grad is None:
+            continue
+        assert grad_close(p.grad, leaf[k].grad), k

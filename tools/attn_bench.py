@@ -5,7 +5,8 @@ sys.path.insert(0, ".")
 from bayeslms_amd._lib import lib, check, ptr, stream
 
 def main():
-    T, B, nh, hd = 128, 64, 8, 64
+    import os
+    T, B, nh, hd = int(os.environ.get("T", "128")), int(os.environ.get("B", "64")), 8, 64
     d = nh * hd
     dev = "cuda"
     qkv = torch.randn(T, B, 3 * d, device=dev)
