@@ -1,7 +1,8 @@
 // Fused causal self-attention, forward and backward, one workgroup per (batch column, head).
 // Scores, softmax, probability dropout and P.V never leave the CU: K/V (forward) and then Q/dO
 // (backward) tiles sit in LDS, each lane owns one query (or key) row in registers, LDS reads are
-// wave-uniform broadcasts.  T <= 128, head_dim in {4,8,16,32,64}.
+// wave-uniform broadcasts.  T <= 128, head_dim in {4,8,16,32,64}; every other shape (head_dim up to 512, any T) goes
+// through the untiled one-wave-per-row kernels at the end of this file.
 //
 // Replaces model.py:889-920 (MultiheadAttention.forward core: scale, bmm, +mask, softmax, dropout,
 // bmm) and the same lines of BayesMultiheadAttention (:990-1011), plus their autograd.
@@ -226,13 +227,163 @@ __global__ __launch_bounds__(ATT_T) void attn_bwd_kernel(const AttnP p) {
   }
 }
 
+
+// ------------------------------------------------------------------ generic fallback: any head_dim <= 512, any T
+// One wave per query (forward, dQ) or per key (dK/dV): the lanes share the head's features (feature f = lane + 64 j),
+// every score is a wave reduction, softmax is online.  No LDS, no tiling: a correctness path for the shapes the
+// tiled kernels do not take (train.py's own defaults give head_dim 100: --emsize 200 --nhead 2, train.py:36-44),
+// not a fast one.  The recipes' head_dim 64 never comes here.
+constexpr int GEN_MAXJ = 8;  // features per lane: head_dim <= 512
+
+__global__ __launch_bounds__(64) void attn_fwd_generic_kernel(const AttnP p, int hd) {
+  const int q = blockIdx.x, bhl = blockIdx.y, b = bhl / p.nhead, head = bhl % p.nhead, off = head * hd;
+  const int lane = threadIdx.x, T = p.T;
+  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
+  const int nj = (hd + 63) >> 6;
+  float qv[GEN_MAXJ], acc[GEN_MAXJ];
+#pragma unroll
+  for (int j = 0; j < GEN_MAXJ; ++j) {
+    const int f = lane + 64 * j;
+    qv[j] = (j < nj && f < hd) ? p.q[((long)q * p.B + b) * p.ld + off + f] * p.scale : 0.f;
+    acc[j] = 0.f;
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int key = 0; key <= q; ++key) {
+    const float* kr = p.k + ((long)key * p.B + b) * p.ld + off;
+    const float* vr = p.v + ((long)key * p.B + b) * p.ld + off;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < GEN_MAXJ; ++j) {
+      const int f = lane + 64 * j;
+      if (j < nj && f < hd) s += qv[j] * kr[f];
+    }
+    s = wave_sum(s);
+    const float mn = fmaxf(m, s), alpha = __expf(m - mn), e = __expf(s - mn);
+    l = l * alpha + e;
+    m = mn;
+    const float w = e * (p.drop ? keep_at(p, (bh * T + q) * (uint64_t)T + key) : 1.f);
+#pragma unroll
+    for (int j = 0; j < GEN_MAXJ; ++j) {
+      const int f = lane + 64 * j;
+      if (j < nj && f < hd) acc[j] = acc[j] * alpha + w * vr[f];
+    }
+  }
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int j = 0; j < GEN_MAXJ; ++j) {
+    const int f = lane + 64 * j;
+    if (j < nj && f < hd) p.out[((long)q * p.B + b) * ((long)p.nhead * hd) + off + f] = acc[j] * inv;
+  }
+  if (p.lse && lane == 0) p.lse[(long)bhl * T + q] = m + __logf(l);
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_dq_generic_kernel(const AttnP p, int hd) {
+  const int q = blockIdx.x, bhl = blockIdx.y, b = bhl / p.nhead, head = bhl % p.nhead, off = head * hd;
+  const int lane = threadIdx.x, T = p.T;
+  const long dmodel = (long)p.nhead * hd;
+  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
+  const int nj = (hd + 63) >> 6;
+  float qv[GEN_MAXJ], dov[GEN_MAXJ], acc[GEN_MAXJ];
+  float delta = 0.f;
+#pragma unroll
+  for (int j = 0; j < GEN_MAXJ; ++j) {
+    const int f = lane + 64 * j;
+    const bool ok = j < nj && f < hd;
+    qv[j] = ok ? p.q[((long)q * p.B + b) * p.ld + off + f] * p.scale : 0.f;
+    dov[j] = ok ? p.dout[((long)q * p.B + b) * dmodel + off + f] : 0.f;
+    if (ok) delta += dov[j] * p.o_in[((long)q * p.B + b) * dmodel + off + f];
+    acc[j] = 0.f;
+  }
+  delta = wave_sum(delta);
+  const float lse = p.lse[(long)bhl * T + q];
+  for (int key = 0; key <= q; ++key) {
+    const float* kr = p.k + ((long)key * p.B + b) * p.ld + off;
+    const float* vr = p.v + ((long)key * p.B + b) * p.ld + off;
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int j = 0; j < GEN_MAXJ; ++j) {
+      const int f = lane + 64 * j;
+      if (j < nj && f < hd) { s += qv[j] * kr[f]; dp += dov[j] * vr[f]; }
+    }
+    s = wave_sum(s);
+    dp = wave_sum(dp);
+    const float keep = p.drop ? keep_at(p, (bh * T + q) * (uint64_t)T + key) : 1.f;
+    const float ds = __expf(s - lse) * (dp * keep - delta);
+#pragma unroll
+    for (int j = 0; j < GEN_MAXJ; ++j) {
+      const int f = lane + 64 * j;
+      if (j < nj && f < hd) acc[j] += ds * kr[f];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < GEN_MAXJ; ++j) {
+    const int f = lane + 64 * j;
+    if (j < nj && f < hd) p.dq[((long)q * p.B + b) * p.ldd + off + f] = acc[j] * p.scale;
+  }
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_dkv_generic_kernel(const AttnP p, int hd) {
+  const int key = blockIdx.x, bhl = blockIdx.y, b = bhl / p.nhead, head = bhl % p.nhead, off = head * hd;
+  const int lane = threadIdx.x, T = p.T;
+  const long dmodel = (long)p.nhead * hd;
+  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
+  const int nj = (hd + 63) >> 6;
+  float kv[GEN_MAXJ], vv[GEN_MAXJ], dk[GEN_MAXJ], dv[GEN_MAXJ];
+#pragma unroll
+  for (int j = 0; j < GEN_MAXJ; ++j) {
+    const int f = lane + 64 * j;
+    const bool ok = j < nj && f < hd;
+    kv[j] = ok ? p.k[((long)key * p.B + b) * p.ld + off + f] : 0.f;
+    vv[j] = ok ? p.v[((long)key * p.B + b) * p.ld + off + f] : 0.f;
+    dk[j] = dv[j] = 0.f;
+  }
+  for (int q = key; q < T; ++q) {
+    const float* qr = p.q + ((long)q * p.B + b) * p.ld + off;
+    const float* dor = p.dout + ((long)q * p.B + b) * dmodel + off;
+    const float* orow = p.o_in + ((long)q * p.B + b) * dmodel + off;
+    float s = 0.f, dp = 0.f, delta = 0.f;
+    float qs[GEN_MAXJ], dof[GEN_MAXJ];
+#pragma unroll
+    for (int j = 0; j < GEN_MAXJ; ++j) {
+      const int f = lane + 64 * j;
+      const bool ok = j < nj && f < hd;
+      qs[j] = ok ? qr[f] * p.scale : 0.f;
+      dof[j] = ok ? dor[f] : 0.f;
+      s += qs[j] * kv[j];
+      dp += dof[j] * vv[j];
+      if (ok) delta += dof[j] * orow[f];
+    }
+    s = wave_sum(s);
+    dp = wave_sum(dp);
+    delta = wave_sum(delta);
+    const float keep = p.drop ? keep_at(p, (bh * T + q) * (uint64_t)T + key) : 1.f;
+    const float pr = __expf(s - p.lse[(long)bhl * T + q]);
+    const float pk = pr * keep, ds = pr * (dp * keep - delta);
+#pragma unroll
+    for (int j = 0; j < GEN_MAXJ; ++j) {
+      dv[j] += pk * dof[j];
+      dk[j] += ds * qs[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < GEN_MAXJ; ++j) {
+    const int f = lane + 64 * j;
+    if (j < nj && f < hd) {
+      p.dk[((long)key * p.B + b) * p.ldd + off + f] = dk[j];
+      p.dv[((long)key * p.B + b) * p.ldd + off + f] = dv[j];
+    }
+  }
+}
+
+static bool tiled_ok(int T, int head_dim) {  // the LDS-tiled VALU kernels: T <= 128, head_dim a power of two up to 64
+  return T <= ATT_T && (head_dim == 4 || head_dim == 8 || head_dim == 16 || head_dim == 32 || head_dim == 64);
+}
+
 static int fill(AttnP& p, int T, int B, int nhead, int head_dim, float pdrop, const blm_rng* rng, int col_offset,
                 const char* who) {
   if (T < 0 || B < 0 || nhead <= 0) return blm_fail(BLM_ERR_INVALID, "%s: bad shape", who);
-  if (T > ATT_T && head_dim != 64)  // head_dim 64 has the chunked matrix-core path for any length (attention_mfma.hip)
-    return blm_fail(BLM_ERR_UNSUPPORTED, "%s: T=%d > %d needs head_dim 64 (got %d)", who, T, ATT_T, head_dim);
-  if (!(head_dim == 4 || head_dim == 8 || head_dim == 16 || head_dim == 32 || head_dim == 64))
-    return blm_fail(BLM_ERR_UNSUPPORTED, "%s: head_dim %d not in {4,8,16,32,64}", who, head_dim);
+  if (head_dim <= 0 || head_dim > 64 * GEN_MAXJ)
+    return blm_fail(BLM_ERR_UNSUPPORTED, "%s: head_dim %d not in 1..%d", who, head_dim, 64 * GEN_MAXJ);
   if (pdrop > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "%s: dropout needs rng", who);
   p.T = T; p.B = B; p.nhead = nhead;
   p.scale = 1.0f / sqrtf((float)head_dim);
@@ -283,6 +434,11 @@ extern "C" int blm_attn_fwd(const float* q, const float* k, const float* v, int6
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (use_mfma(head_dim)) return blm_attn_fwd_mfma(q, k, v, ld_qkv, out, lse, T, B, nhead, pdrop, rng, col_offset, st);
   p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.out = out; p.lse = lse;
+  if (!tiled_ok(T, head_dim)) {  // any other head size / longer sequences: one wave per query
+    hipLaunchKernelGGL(attn_fwd_generic_kernel, dim3(T, B * nhead), dim3(64), 0, st, p, head_dim);
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
+  }
   const size_t lds = (size_t)2 * T * head_dim * sizeof(float);
   DISPATCH_HD(attn_fwd_kernel, lds)
   BLM_HIP(hipGetLastError());
@@ -306,6 +462,13 @@ extern "C" int blm_attn_bwd(const float* q, const float* k, const float* v, int6
     return blm_attn_bwd_mfma(q, k, v, ld_qkv, out, dout, lse, dq, dk, dv, ld_dqkv, T, B, nhead, pdrop, rng, col_offset, st);
   p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.o_in = out; p.dout = dout; p.lse = const_cast<float*>(lse);
   p.dq = dq; p.dk = dk; p.dv = dv; p.ldd = ld_dqkv;
+  if (!tiled_ok(T, head_dim)) {
+    hipLaunchKernelGGL(attn_bwd_dq_generic_kernel, dim3(T, B * nhead), dim3(64), 0, st, p, head_dim);
+    BLM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(attn_bwd_dkv_generic_kernel, dim3(T, B * nhead), dim3(64), 0, st, p, head_dim);
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
+  }
   const size_t lds = ((size_t)2 * T * head_dim + 2 * T) * sizeof(float);
   DISPATCH_HD(attn_bwd_kernel, lds)
   BLM_HIP(hipGetLastError());

@@ -30,6 +30,7 @@ def L():
 
 def rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
+    a, b = a.detach(), b.detach()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
@@ -348,7 +349,10 @@ def test_add_dropout_ln(dev, D):
 @pytest.mark.parametrize("T,B,nhead,hd", [(6, 3, 4, 4), (100, 2, 2, 32), (128, 3, 2, 64), (33, 2, 1, 16), (33, 2, 2, 64),
                                           (1, 1, 1, 64), (97, 1, 3, 64),
                                           # longer than 128: the chunked (flash-style) matrix-core kernels
-                                          (129, 2, 2, 64), (200, 1, 3, 64), (256, 2, 1, 64), (301, 1, 2, 64), (515, 1, 1, 64)])
+                                          (129, 2, 2, 64), (200, 1, 3, 64), (256, 2, 1, 64), (301, 1, 2, 64), (515, 1, 1, 64),
+                                          # any other head size / length: the untiled one-wave-per-row kernels
+                                          # (train.py's defaults give head_dim 100)
+                                          (35, 2, 2, 100), (20, 1, 3, 7), (150, 2, 2, 32), (140, 1, 1, 100), (9, 2, 1, 130)])
 def test_attention_matches_oracle(dev, T, B, nhead, hd):
     ops = ops_mod()
     d = nhead * hd
@@ -373,7 +377,7 @@ def test_attention_matches_oracle(dev, T, B, nhead, hd):
 
 
 @pytest.mark.parametrize("T,B,nhead,hd", [(8, 2, 2, 4), (96, 2, 2, 64), (50, 3, 1, 64), (128, 1, 2, 64), (160, 2, 1, 64),
-                                          (203, 1, 2, 64)])
+                                          (203, 1, 2, 64), (30, 2, 2, 100), (131, 1, 1, 32)])
 def test_attention_dropout_uses_philox_mask(dev, T, B, nhead, hd):
     """Probability dropout (VALU kernels for small heads, MFMA kernels for head_dim 64; T % 4 != 0
     takes the per-element Philox path)."""
@@ -649,10 +653,10 @@ def test_gemm_bf16x6_is_exact_on_exactly_representable_products(dev):
     assert not torch.equal(out["bf16x3"], A) and float((out["bf16x3"] - A).abs().max()) < 1e-4
 
 
-def test_attention_long_sequence_unsupported_head_dim_is_loud(dev):
-    """T > 128 needs head_dim 64 (the chunked matrix-core kernels); other head sizes say so instead of computing."""
+def test_attention_unsupported_head_dim_is_loud(dev):
+    """head_dim above 512 is refused with a message instead of computing something else."""
     ops = ops_mod()
     from bayeslms_amd._lib import BayesLMError
-    qkv = torch.randn(130, 1, 3 * 32, device=dev, requires_grad=True)
-    with pytest.raises(BayesLMError, match="head_dim 64"):
+    qkv = torch.randn(4, 1, 3 * 520, device=dev, requires_grad=True)
+    with pytest.raises(BayesLMError, match="head_dim"):
         ops.attention(qkv, 1)
