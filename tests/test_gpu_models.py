@@ -825,3 +825,38 @@ def test_transformer_longer_than_128_tokens(dev):
         if k == "decoder.weight" or leaf[k].grad is None:
             continue
         assert grad_close(p.grad, leaf[k].grad), k
+
+
+@pytest.mark.parametrize("margs", [
+    # train.py's own defaults for the sizes (emsize 200, nhid 200, nlayers 2, nhead 2 -> head_dim 100; untied)
+    ["--model", "Transformer", "--uncertainty", "Bayesian", "--T_bayes_pos", "FFN"],
+    ["--model", "LSTM", "--uncertainty", "Bayesian", "--L_bayes_pos", "3"],
+    # windows longer than 128 tokens
+    ["--model", "Transformer", "--emsize", "128", "--nhid", "64", "--nhead", "2", "--seq_len", "150", "--tied",
+     "--uncertainty", "Bayesian", "--T_bayes_pos", "MHA"],
+])
+def test_train_cli_reference_default_shapes(dev, margs, tmp_path, capsys):
+    """Shapes outside the tuned kernels (odd head size, hidden size not a multiple of 32, windows > 128 tokens)
+    train through the same CLI: one epoch, finite and decreasing loss."""
+    import re
+    import numpy as np
+    from bayeslms_amd import train as T
+    rng = np.random.RandomState(1)
+    words = ["<s>", "<unk>"] + ["w%03d" % i for i in range(2, 30)]
+
+    def text(n):
+        lines = []
+        for _ in range(n):
+            a, ln = rng.randint(2, 30), rng.randint(3, 9)
+            lines.append(" ".join(words[2 + (a - 2 + k) % 28] for k in range(ln)))
+        return "\n".join(lines) + "\n"
+    d = str(tmp_path)
+    _write_corpus({"words": words, "train_txt": text(900), "valid_txt": text(200), "test_txt": text(200)}, d)
+    base = ["--data", d, "--epochs", "2", "--batch-size", "4", "--dropout", "0.1", "--lr", "0.5" if "LSTM" in margs else "0.1",
+            "--clip", "1.0", "--cuda", "--save", d + "/m.pt", "--log-interval", "50"]
+    if "--seq_len" not in margs:
+        base += ["--seq_len", "7"]
+    T.main(base + margs)
+    out = capsys.readouterr().out
+    vals = [float(x) for x in re.findall(r"valid loss\s+([0-9.]+)", out)]
+    assert len(vals) == 2 and vals[1] < vals[0] and vals[1] < 3.4 and np.isfinite(vals).all(), out[-500:]
