@@ -292,12 +292,12 @@ __device__ __forceinline__ void split_bf16x8_3(const float (&x)[8], bf16x8& hi, 
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const f32x2 v = {x[2 * q], x[2 * q + 1]};
-    const uint32_t hu = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-    const f32x2 r = {v.x - __uint_as_float(hu << 16), v.y - __uint_as_float(hu & 0xFFFF0000u)};
-    const uint32_t mu = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
-    const f32x2 r2 = {r.x - __uint_as_float(mu << 16), r.y - __uint_as_float(mu & 0xFFFF0000u)};
-    h[q] = hu;
-    m[q] = mu;
+    const bf16x2 hb = __builtin_convertvector(v, bf16x2);
+    const f32x2 r = {v.x - (float)hb[0], v.y - (float)hb[1]};
+    const bf16x2 mb = __builtin_convertvector(r, bf16x2);
+    const f32x2 r2 = {r.x - (float)mb[0], r.y - (float)mb[1]};
+    h[q] = __builtin_bit_cast(uint32_t, hb);
+    m[q] = __builtin_bit_cast(uint32_t, mb);
     l[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
   }
   hi = __builtin_bit_cast(bf16x8, h);
