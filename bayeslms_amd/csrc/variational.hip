@@ -201,7 +201,10 @@ extern "C" int blm_kl_mean_fwd(const float* mu, int64_t ld_mu, const float* lgst
   if (!mu || !lgstd || !out || rows <= 0 || cols <= 0 || ld_mu < cols)
     return blm_fail(BLM_ERR_INVALID, "blm_kl_mean_fwd: bad arguments");
   const float scale = 0.5f * weight / ((float)rows * (float)cols);
-  hipLaunchKernelGGL(kl_fwd_kernel, dim3(grid_for(rows * cols)), dim3(TPB), 0, static_cast<hipStream_t>(stream), mu,
+  // every block ends in ONE float atomic on the same address: 256 blocks (one per CU) instead of 2048 cut the
+  // launch from 32 to a few microseconds (the atomics serialise in L2)
+  const int kl_grid = grid_for(rows * cols) < 256 ? grid_for(rows * cols) : 256;
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3(kl_grid), dim3(TPB), 0, static_cast<hipStream_t>(stream), mu,
                      (long)ld_mu, lgstd, (long)rows, (long)cols, minus_one ? 1.0f : 0.0f, scale, out);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
