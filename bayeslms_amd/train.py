@@ -54,6 +54,8 @@ def build_parser():
     p.add_argument('--prior2_path', default='steps/pytorchnn/prior/transformer2/', type=str)
     # new, optional
     p.add_argument('--fused-sampling', type=int, default=0, help='1: eps generated inside the GEMM tile loader')
+    p.add_argument('--gemm-mode', type=str, default='f32', choices=['f32', 'bf16x6', 'bf16x3'],
+                   help='new, optional: opt-in split-bf16 arithmetic of the GEMM family (DESIGN.md section 7); default fp32 MFMA')
     return p
 
 
@@ -147,8 +149,10 @@ def main(argv=None):
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
 
-    from . import data as D, engine
+    from . import data as D, engine, ops
     from .model import repackage_hidden
+    if args.gemm_mode != 'f32':
+        ops.set_gemm_mode(args.gemm_mode)
 
     say('Configurations')
     for k, v in vars(args).items():

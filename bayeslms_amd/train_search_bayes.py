@@ -64,6 +64,8 @@ def build_parser():
     p.add_argument('--wdecay', type=float, default=5e-7)
     p.add_argument('--arch_wdecay', type=float, default=1e-3)
     p.add_argument('--arch_lr', type=float, default=3e-3)
+    p.add_argument('--gemm-mode', type=str, default='f32', choices=['f32', 'bf16x6', 'bf16x3'],
+                   help='new, optional: opt-in split-bf16 arithmetic of the GEMM family (DESIGN.md section 7); default fp32 MFMA')
     return p
 
 
@@ -139,8 +141,10 @@ def main(argv=None):
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(device)
 
-    from . import data as D, engine
+    from . import data as D, engine, ops
     from .architect import Architect
+    if args.gemm_mode != 'f32':
+        ops.set_gemm_mode(args.gemm_mode)
     from .model import repackage_hidden
 
     print('Configurations')
