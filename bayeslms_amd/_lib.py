@@ -98,6 +98,8 @@ SIGNATURES = {
     "blm_lstm_search_cell_partials": (_i64, [_i, _i]),
     "blm_lstm_search_cell_bwd": (_i, [_vp] * 10 + [_i, _i, _vp]),
     "blm_lstm_search_step_fwd": (_i, [_vp] * 8 + [_i, _i, _vp]),
+    "blm_lstm_search_step_partials": (_i64, [_i, _i]),
+    "blm_lstm_search_step_bwd": (_i, [_vp] * 11 + [_i, _i, _vp]),
     "blm_lstm_step_dh": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "blm_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp]),
     "blm_clip_sgd_multi_wd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _i, _f, _f, _vp]),

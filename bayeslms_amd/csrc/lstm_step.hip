@@ -261,8 +261,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int g = 0; g < 4; ++g) e_z4[g] = p.zprev[eo + (long)g * H];
     }
+    if (p.ovr != 8) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) e_g[g] = p.ga[eo + (long)g * H];
+      for (int g = 0; g < 4; ++g) e_g[g] = p.ga[eo + (long)g * H];
+    }
+  }
+  // ovr == 8: the architecture-search cell (search.hip search_cell_bwd_kernel) fused behind the product: ga / dg_out
+  // have 8H-float rows [i f g o | i' f' g' o'], coef = the (4,2) mixing weights, dact_out = per-block partials of their gradient
+  float e_a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, e_p8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (p.ovr == 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e_p8[k] = p.coef[k];
+    if (eok) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e_a8[k] = p.ga[(long)eb * 8 * H + ek + (long)k * H];
+    }
   }
 
   // staging roles: one instruction moves 2 rows x 4 quarters x 128 B
@@ -328,6 +341,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * lq + r) * BRSTR + li] = acc[r];
   __syncthreads();
+  if (p.ovr == 8) {  // wave-uniform.  Every thread stays for the block reduction of the mixing-weight partials.
+    const float dh8 = (red[(0 * 16 + brow) * BRSTR + ecol] + red[(1 * 16 + brow) * BRSTR + ecol]) +
+                      (red[(2 * 16 + brow) * BRSTR + ecol] + red[(3 * 16 + brow) * BRSTR + ecol]);
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (eok) {
+      const float gi = e_a8[0] * e_p8[0] + e_a8[4] * e_p8[1], gf = e_a8[1] * e_p8[2] + e_a8[5] * e_p8[3];
+      const float gg = e_a8[2] * e_p8[4] + e_a8[6] * e_p8[5], go = e_a8[3] * e_p8[6] + e_a8[7] * e_p8[7];
+      const float tc = tanhf(e_c);
+      const float dhv = dh8 + e_dy;
+      const float dc = e_dcn + dhv * go * (1.f - tc * tc);
+      const float dgate[4] = {dc * gg, dc * e_cp, dc * gi, dhv * tc};
+      p.dc_prev[ei] = dc * gf;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float av = e_a8[k + 4 * q];
+          const float dact = k == 2 ? 1.f - av * av : av * (1.f - av);
+          p.dg_out[(long)eb * 8 * H + ek + (long)(k + 4 * q) * H] = dgate[k] * e_p8[2 * k + q] * dact;
+          s8[2 * k + q] = dgate[k] * av;
+        }
+    }
+    __syncthreads();  // everybody has read its dh: the reduction buffer is free again
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float w = wave_sum(s8[k]);
+      if (lane == 0) sm[wave * 8 + k] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8)
+      p.dact_out[8L * ((long)blockIdx.y * gridDim.x + blockIdx.x) + threadIdx.x] =
+          (sm[threadIdx.x] + sm[8 + threadIdx.x]) + (sm[16 + threadIdx.x] + sm[24 + threadIdx.x]);
+    return;
+  }
   if (!eok) return;
   const float dh = (red[(0 * 16 + brow) * BRSTR + ecol] + red[(1 * 16 + brow) * BRSTR + ecol]) +
                    (red[(2 * 16 + brow) * BRSTR + ecol] + red[(3 * 16 + brow) * BRSTR + ecol]);
@@ -487,6 +534,24 @@ extern "C" int blm_lstm_step_bwd_gp(const float* dgates_t, const float* w_hh_t, 
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_bwd: needs H % 32 == 0 and 16-byte aligned dgates_t / w_hh_t");
   LstmBwdP p{dgates_t, w_hh_t, dy_prev, dc_next, c_prev, c, gates_act, dgates_out, dc_prev, dh_out, z_prev, coef4, dact_out,
              dz_out, (dgates_out && gate_ovr >= 0) ? gate_ovr : -1, B, H, 4 * H};
+  return launch_step_bwd(p, stream);
+}
+
+extern "C" int64_t blm_lstm_search_step_partials(int B, int H) {
+  if (B < 0 || H < 0) return 0;
+  return 8 * (int64_t)(H / 16) * ((B + 15) / 16);
+}
+
+extern "C" int blm_lstm_search_step_bwd(const float* dz8_t, const float* w8_t, const float* dy_prev, const float* dc_next,
+                                        const float* c_prev, const float* c, const float* acts8, const float* probs,
+                                        float* dz8_out, float* dc_prev, float* partial, int B, int H, void* stream) {
+  if (!dz8_t || !w8_t || !c_prev || !c || !acts8 || !probs || !dz8_out || !dc_prev || !partial || B < 0 || H < 0)
+    return blm_fail(BLM_ERR_INVALID, "blm_lstm_search_step_bwd: bad arguments");
+  if ((long)B * H == 0) return BLM_OK;
+  if (H % 16 != 0 || !al16(dz8_t) || !al16(w8_t))
+    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_search_step_bwd: needs H % 16 == 0 and 16-byte aligned dz8_t / w8_t");
+  LstmBwdP p{dz8_t, w8_t, dy_prev, dc_next, c_prev, c, acts8, dz8_out, dc_prev, nullptr, nullptr, probs, partial, nullptr, 8,
+             B, H, 8 * H};
   return launch_step_bwd(p, stream);
 }
 

@@ -1371,24 +1371,45 @@ class _LSTMSearchLayer(torch.autograd.Function):
         dhr = [torch.empty(B, H, device=dev, dtype=torch.float32) for _ in range(2)]
         dh_rec = _f32(dhT.contiguous(), "dhT") if dhT is not None else None
         dc = _f32(dcT.contiguous(), "dcT") if dcT is not None else None
-        # skinny recurrent dgrad: one launch per step on the LSTM step kernel (fixed summation order, no
-        # split-K memset + atomics) against the weight transposed once per window; blm_gemm otherwise
+        # H % 16 == 0: one launch per step -- the skinny recurrent dgrad dh = dz8 . W8 on the LSTM step kernel (fixed
+        # summation order, no split-K memset + atomics) against the weight transposed once per window, with the
+        # search cell's backward of the previous step fused behind it; otherwise cell kernel + blm_gemm per step
         fused = H % 16 == 0
+        part2 = None
         if fused:
             w_t = torch.empty(H, 8 * H, device=dev, dtype=torch.float32)
             check(lib().blm_transpose(ptr(w8_hh), ptr(w_t), 8 * H, H, st), "blm_transpose")
-        for t in range(T - 1, -1, -1):
-            k = t & 1
-            check(lib().blm_lstm_search_cell_bwd(ptr(dy[t]), ptr(dh_rec), ptr(dc), ptr(cs[t]), ptr(cs[t + 1]), ptr(acts[t]),
-                                                 ptr(probs), ptr(dz[t]), ptr(dcb[k]), ptr(part[t]), B, H, st),
+            part = torch.empty(1, npart, device=dev, dtype=torch.float32)
+            check(lib().blm_lstm_search_cell_bwd(ptr(dy[T - 1]), ptr(dh_rec), ptr(dc), ptr(cs[T - 1]), ptr(cs[T]),
+                                                 ptr(acts[T - 1]), ptr(probs), ptr(dz[T - 1]), ptr(dcb[0]), ptr(part[0]), B, H, st),
                   "blm_lstm_search_cell_bwd")
-            dc = dcb[k]
-            if fused:
-                check(lib().blm_lstm_step_dh(ptr(dz[t]), ptr(w_t), ptr(dhr[k]), B, H, 8 * H, st), "blm_lstm_step_dh")
-            else:
+            nstep = int(lib().blm_lstm_search_step_partials(B, H))
+            part2 = torch.empty(max(T - 1, 1), nstep, device=dev, dtype=torch.float32)
+            k = 0
+            for t in range(T - 1, 0, -1):
+                check(lib().blm_lstm_search_step_bwd(ptr(dz[t]), ptr(w_t), ptr(dy[t - 1]), ptr(dcb[k]), ptr(cs[t - 1]), ptr(cs[t]),
+                                                     ptr(acts[t - 1]), ptr(probs), ptr(dz[t - 1]), ptr(dcb[k ^ 1]),
+                                                     ptr(part2[t - 1]), B, H, st), "blm_lstm_search_step_bwd")
+                k ^= 1
+            check(lib().blm_lstm_step_dh(ptr(dz[0]), ptr(w_t), ptr(dhr[0]), B, H, 8 * H, st), "blm_lstm_step_dh")
+            dh_rec, dc = dhr[0], dcb[k]
+            if T == 1:
+                part2 = None
+        else:
+            for t in range(T - 1, -1, -1):
+                k = t & 1
+                check(lib().blm_lstm_search_cell_bwd(ptr(dy[t]), ptr(dh_rec), ptr(dc), ptr(cs[t]), ptr(cs[t + 1]), ptr(acts[t]),
+                                                     ptr(probs), ptr(dz[t]), ptr(dcb[k]), ptr(part[t]), B, H, st),
+                      "blm_lstm_search_cell_bwd")
+                dc = dcb[k]
                 gemm(L.GEMM_NN, dz[t], w8_hh, dhr[k], B, H, 8 * H, 8 * H, H, H)
-            dh_rec = dhr[k]
-        dprobs = _reduce_partials(part, 8).view(4, 2) if ctx.needs_input_grad[6] else None
+                dh_rec = dhr[k]
+        dprobs = None
+        if ctx.needs_input_grad[6]:
+            dprobs = _reduce_partials(part, 8)
+            if part2 is not None:
+                dprobs = dprobs + _reduce_partials(part2, 8)
+            dprobs = dprobs.view(4, 2)
         dw_ih = dw_hh = db = dx = None
         M = T * B
         if ctx.needs_input_grad[4]:

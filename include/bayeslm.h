@@ -407,6 +407,15 @@ int blm_lstm_search_cell_bwd(const float* dh, const float* dh2, const float* dc_
 int blm_lstm_search_step_fwd(const float* xw8_t, const float* w8_hh, const float* h_prev, const float* c_prev,
                              const float* probs, float* h, float* c, float* acts8, int B, int H, void* stream);
 
+/* Backward of one search-cell time step in a single launch (blm_lstm_step_bwd with the search cell fused behind the
+ * product): dh = dz8_t (B,8H) . w8_t (H,8H)^T, then blm_lstm_search_cell_bwd of the previous step with dh + dy_prev:
+ * dz8_out (B,8H), dc_prev (B,H) and blm_lstm_search_step_partials(B,H) per-block partials of d probs
+ * (partial[8*j + 2k + s]); dh never reaches memory.  H % 16 == 0, 16-byte aligned operands. */
+int64_t blm_lstm_search_step_partials(int B, int H);
+int blm_lstm_search_step_bwd(const float* dz8_t, const float* w8_t, const float* dy_prev, const float* dc_next,
+                             const float* c_prev, const float* c, const float* acts8, const float* probs, float* dz8_out,
+                             float* dc_prev, float* partial, int B, int H, void* stream);
+
 /* The skinny recurrent dgrad of one search-cell step on the blm_lstm_step_bwd kernel (no cell fused):
  *   dh_out (B,H) = dz (B,G) . w_t (H,G)^T      w_t = the stacked recurrent weight (G,H) TRANSPOSED
  * One launch, fixed summation order, no memset / atomics.  Needs H % 16 == 0, G % 64 == 0, 16-byte
