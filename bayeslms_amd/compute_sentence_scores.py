@@ -269,6 +269,8 @@ def build_parser():
                    '0: one launch per hypothesis like the reference')
     p.add_argument('--mc-samples', type=int, default=0, help='S > 0: average sentence probabilities over S weight samples')
     p.add_argument('--batch-tokens', type=int, default=8192, help='Transformer scoring: padded tokens per batch across utterances')
+    p.add_argument('--gemm-mode', type=str, default='f32', choices=['f32', 'bf16x6', 'bf16x3'],
+                   help='opt-in split-bf16 arithmetic of the GEMM family (DESIGN.md section 7); default fp32 MFMA')
     return p
 
 
@@ -279,6 +281,9 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit("bayeslms_amd scoring needs an MI355X: there is no CPU path")
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    if args.gemm_mode != 'f32':
+        from . import ops
+        ops.set_gemm_mode(args.gemm_mode)
     vocab = read_vocab(args.vocabulary)
     model_1, model_2 = build_models(args, len(vocab))
     load_partial(model_1, args.model_path)
