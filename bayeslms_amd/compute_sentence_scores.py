@@ -10,6 +10,7 @@ import argparse
 import os
 from collections import OrderedDict
 
+import numpy as np
 import torch
 
 
@@ -181,13 +182,15 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
         pairs = [p for _, _, ps in group for p in ps]
         lens = [len(x) for x, _ in pairs]
         Tm, N = max(lens), len(pairs)
-        data = torch.zeros(Tm, N, dtype=torch.int64)
-        tgt = torch.zeros(Tm, N, dtype=torch.int64)
+        # one host buffer [data | targets | lengths] -> ONE host-to-device copy per batch
+        host = np.zeros((2 * Tm + 1, N), dtype=np.int64)
         for n, (x, t) in enumerate(pairs):
-            data[:lens[n], n] = torch.tensor(x, dtype=torch.int64)
-            tgt[:lens[n], n] = torch.tensor(t, dtype=torch.int64)
-        data, tgt = data.to(device), tgt.to(device)
-        mask = (torch.arange(Tm, device=device).unsqueeze(1) < torch.tensor(lens, device=device).unsqueeze(0)).float()
+            host[:lens[n], n] = x
+            host[Tm:Tm + lens[n], n] = t
+        host[2 * Tm] = lens
+        dev_buf = torch.from_numpy(host).to(device, non_blocking=True)
+        data, tgt = dev_buf[:Tm], dev_buf[Tm:2 * Tm].contiguous()
+        mask = (torch.arange(Tm, device=device).unsqueeze(1) < dev_buf[2 * Tm].unsqueeze(0)).float()
         hN = tuple(h.expand(-1, N, -1).contiguous() for h in hidden) if is_rnn else None
         h2N = tuple(h.expand(-1, N, -1).contiguous() for h in hidden_2) if hidden_2 is not None else None
         sent = []
@@ -201,11 +204,24 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
             tot = sent[0]
         else:
             tot = -(torch.logsumexp(-torch.stack(sent), 0) - torch.log(torch.tensor(float(S), device=device)))
-        tot = tot.tolist()
+        # the scores stay on the device: no host sync per batch (the LSTM path launches one small batch per
+        # utterance); they are read back together in flush()
+        pending.append((group, tot))
+        if len(pending) >= 1024:
+            flush()
+
+    pending = []
+
+    def flush():
+        if not pending:
+            return
+        flat = torch.cat([t for _, t in pending]).tolist()
         o = 0
-        for key, hyps, ps in group:
-            scores[key] = [(h, float(v)) for h, v in zip(hyps, tot[o:o + len(hyps)])]
-            o += len(hyps)
+        for group, _ in pending:
+            for key, hyps, ps in group:
+                scores[key] = [(h, float(v)) for h, v in zip(hyps, flat[o:o + len(hyps)])]
+                o += len(hyps)
+        pending.clear()
 
     with torch.no_grad():
         group, g_cols, g_tmax = [], 0, 0
@@ -230,6 +246,7 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
             g_cols, g_tmax = g_cols + len(pairs), max(g_tmax, tmax)
         if group:
             score_group(group, None, None)
+        flush()
     if mc_samples > 0:
         model.noise_state.dropout_off = False
         model.eval()
