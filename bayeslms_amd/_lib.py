@@ -142,7 +142,10 @@ def stream():
 
 
 def ptr(t):
-    return None if t is None else t.data_ptr()
+    """Device address of a tensor (None -> NULL); plain integers (ops._P row addresses) pass through."""
+    if t is None or isinstance(t, int):
+        return t
+    return t.data_ptr()
 
 
 def dev_tensor(t, name="tensor", dtype=torch.float32):

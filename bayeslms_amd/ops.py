@@ -107,6 +107,19 @@ def _f32(t, name):
     return dev_tensor(t, name, torch.float32)
 
 
+class _P:
+    """Row addresses of a contiguous tensor: ``_P(t)[i]`` == ``t[i].data_ptr()`` without building a view per time step
+    (six views per LSTM step cost more host time than the 12 us kernel they feed)."""
+    __slots__ = ("b", "s")
+
+    def __init__(self, t):
+        self.b = t.data_ptr()
+        self.s = t.stride(0) * t.element_size()
+
+    def __getitem__(self, i):
+        return self.b + i * self.s
+
+
 # ----------------------------------------------------------------------------
 # per-kernel timing with HIP events on the launch stream (bench.py's live roofline numbers)
 # ----------------------------------------------------------------------------
@@ -832,11 +845,14 @@ class _LSTMLayer(torch.autograd.Function):
         # one launch per step (recurrent product + cell, blm_lstm_step_fwd) when the shape allows it,
         # else skinny GEMM + cell kernel
         fused_step = H % 32 == 0 and w_hh.data_ptr() % 16 == 0 and hs.data_ptr() % 16 == 0 and w_hh.is_contiguous()
+        xw_p, hs_p, cs_p, ga_p, w_p = _P(xw), _P(hs), _P(cs), _P(ga), ptr(w_hh)
+        nz_p = None if noise_rows is None else _P(noise_rows)
+        step_fwd = lib().blm_lstm_step_fwd
         for t in range(T):
-            nz = None if noise_rows is None else ptr(noise_rows[t])
+            nz = None if nz_p is None else nz_p[t]
             if fused_step:
-                check(lib().blm_lstm_step_fwd(ptr(xw[t]), ptr(w_hh), ptr(hs[t]), ptr(cs[t]), ptr(hs[t + 1]),
-                                              ptr(cs[t + 1]), ptr(ga[t]), nz, B, H, st), "blm_lstm_step_fwd")
+                check(step_fwd(xw_p[t], w_p, hs_p[t], cs_p[t], hs_p[t + 1], cs_p[t + 1], ga_p[t], nz, B, H, st),
+                      "blm_lstm_step_fwd")
                 continue
             gemm(L.GEMM_NT, hs[t], w_hh, hw, B, G, H, H, H, G)
             check(lib().blm_lstm_cell_fwd(ptr(xw[t]), ptr(hw), ptr(cs[t]), ptr(hs[t + 1]), ptr(cs[t + 1]), ptr(ga[t]),
@@ -876,10 +892,12 @@ class _LSTMLayer(torch.autograd.Function):
             check(lib().blm_lstm_cell_bwd2(ptr(dh), ptr(dy[T - 1]), ptr(dcs[0]), ptr(cs[T - 1]), ptr(cs[T]), ptr(ga[T - 1]),
                                            ptr(dgates[T - 1]), ptr(dcs[1]), B, H, st), "blm_lstm_cell_bwd2")
             k = 1
+            dg_p, dy_p, cs_p, ga_p, dcs_p, wt_p = _P(dgates), _P(dy), _P(cs), _P(ga), _P(dcs), ptr(w_t)
+            dhr_p = _P(dhr) if noise else None
+            step_bwd = lib().blm_lstm_step_bwd
             for t in range(T - 1, 0, -1):
-                check(lib().blm_lstm_step_bwd(ptr(dgates[t]), ptr(w_t), ptr(dy[t - 1]), ptr(dcs[k]), ptr(cs[t - 1]),
-                                              ptr(cs[t]), ptr(ga[t - 1]), ptr(dgates[t - 1]), ptr(dcs[k ^ 1]),
-                                              ptr(dhr[t - 1]) if noise else None, B, H, st), "blm_lstm_step_bwd")
+                check(step_bwd(dg_p[t], wt_p, dy_p[t - 1], dcs_p[k], cs_p[t - 1], cs_p[t], ga_p[t - 1], dg_p[t - 1], dcs_p[k ^ 1],
+                               dhr_p[t - 1] if noise else None, B, H, st), "blm_lstm_step_bwd")
                 k ^= 1
             dh = torch.empty(B, H, device=dev, dtype=torch.float32)
             check(lib().blm_lstm_step_bwd(ptr(dgates[0]), ptr(w_t), None, None, None, None, None, None, None, ptr(dh),
@@ -945,10 +963,13 @@ class _LSTMRecurrentGP(torch.autograd.Function):
         ga = torch.empty(T, B, G, device=dev, dtype=torch.float32)
         zs = torch.empty(T, B, G if ovr == 4 else H, device=dev, dtype=torch.float32) if ovr >= 0 else None
         st = stream()
+        xw_p, hs_p, cs_p, ga_p = _P(xw), _P(hs), _P(cs), _P(ga)
+        zs_p = None if zs is None else _P(zs)
+        w_p, co_p, rb_p = ptr(w_rec), ptr(coef4), ptr(rbias)
+        step_fwd = lib().blm_lstm_step_fwd_gp
         for t in range(T):
-            check(lib().blm_lstm_step_fwd_gp(ptr(xw[t]), ptr(w_rec), ptr(hs[t]), ptr(cs[t]), ptr(hs[t + 1]), ptr(cs[t + 1]),
-                                             ptr(ga[t]), None, ovr, ptr(coef4), ptr(rbias), None if zs is None else ptr(zs[t]),
-                                             B, H, st), "blm_lstm_step_fwd_gp")
+            check(step_fwd(xw_p[t], w_p, hs_p[t], cs_p[t], hs_p[t + 1], cs_p[t + 1], ga_p[t], None, ovr, co_p, rb_p,
+                           None if zs_p is None else zs_p[t], B, H, st), "blm_lstm_step_fwd_gp")
         ctx.save_for_backward(hs, cs, ga, w_rec, *([zs, coef4] if ovr >= 0 else []))
         ctx.ovr = ovr
         return hs[1:], hs[T], cs[T]
@@ -991,11 +1012,16 @@ class _LSTMRecurrentGP(torch.autograd.Function):
                       "blm_gp_mix_bwd")
         A = dzs if ovr == 4 else dgates
         k = 1
+        A_p, dy_p, cs_p, ga_p, dg_p, dcs_p = _P(A), _P(dy), _P(cs), _P(ga), _P(dgates), _P(dcs)
+        zs_p = None if zs is None else _P(zs)
+        da_p = None if dact is None else _P(dact)
+        dzs_p = None if dzs is None else _P(dzs)
+        wt_p, co_p = ptr(w_t), ptr(coef4)
+        step_bwd = lib().blm_lstm_step_bwd_gp
         for t in range(T - 1, 0, -1):
-            check(lib().blm_lstm_step_bwd_gp(ptr(A[t]), ptr(w_t), ptr(dy[t - 1]), ptr(dcs[k]), ptr(cs[t - 1]), ptr(cs[t]),
-                                             ptr(ga[t - 1]), ptr(dgates[t - 1]), ptr(dcs[k ^ 1]), None, ovr, ptr(coef4),
-                                             None if zs is None else ptr(zs[t - 1]), None if dact is None else ptr(dact[t - 1]),
-                                             None if dzs is None else ptr(dzs[t - 1]), B, H, st), "blm_lstm_step_bwd_gp")
+            check(step_bwd(A_p[t], wt_p, dy_p[t - 1], dcs_p[k], cs_p[t - 1], cs_p[t], ga_p[t - 1], dg_p[t - 1], dcs_p[k ^ 1], None,
+                           ovr, co_p, None if zs_p is None else zs_p[t - 1], None if da_p is None else da_p[t - 1],
+                           None if dzs_p is None else dzs_p[t - 1], B, H, st), "blm_lstm_step_bwd_gp")
             k ^= 1
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32)
         check(lib().blm_lstm_step_bwd(ptr(A[0]), ptr(w_t), None, None, None, None, None, None, None, ptr(dh0), B, H, st),
@@ -1342,10 +1368,12 @@ class _LSTMSearchLayer(torch.autograd.Function):
         cs[0].copy_(c0)
         acts = torch.empty(T, B, 8 * H, device=dev, dtype=torch.float32) if need_bwd else None
         if H % 32 == 0:  # one launch per step: recurrent product over the stacked weight + the search cell
+            xw_p, hs_p, cs_p, w_p, pr_p = _P(xw), _P(hs), _P(cs), ptr(w8_hh), ptr(probs)
+            ac_p = _P(acts) if need_bwd else None
+            step_fwd = lib().blm_lstm_search_step_fwd
             for t in range(T):
-                check(lib().blm_lstm_search_step_fwd(ptr(xw[t]), ptr(w8_hh), ptr(hs[t]), ptr(cs[t]), ptr(probs), ptr(hs[t + 1]),
-                                                     ptr(cs[t + 1]), ptr(acts[t]) if need_bwd else None, B, H, st),
-                      "blm_lstm_search_step_fwd")
+                check(step_fwd(xw_p[t], w_p, hs_p[t], cs_p[t], pr_p, hs_p[t + 1], cs_p[t + 1], ac_p[t] if need_bwd else None, B, H,
+                               st), "blm_lstm_search_step_fwd")
         else:
             hw = torch.empty(B, 8 * H, device=dev, dtype=torch.float32)
             for t in range(T):
@@ -1386,10 +1414,12 @@ class _LSTMSearchLayer(torch.autograd.Function):
             nstep = int(lib().blm_lstm_search_step_partials(B, H))
             part2 = torch.empty(max(T - 1, 1), nstep, device=dev, dtype=torch.float32)
             k = 0
+            dz_p, dy_p, cs_p, ac_p, p2_p = _P(dz), _P(dy), _P(cs), _P(acts), _P(part2)
+            dcb_p, wt_p, pr_p = (ptr(dcb[0]), ptr(dcb[1])), ptr(w_t), ptr(probs)
+            step_bwd = lib().blm_lstm_search_step_bwd
             for t in range(T - 1, 0, -1):
-                check(lib().blm_lstm_search_step_bwd(ptr(dz[t]), ptr(w_t), ptr(dy[t - 1]), ptr(dcb[k]), ptr(cs[t - 1]), ptr(cs[t]),
-                                                     ptr(acts[t - 1]), ptr(probs), ptr(dz[t - 1]), ptr(dcb[k ^ 1]),
-                                                     ptr(part2[t - 1]), B, H, st), "blm_lstm_search_step_bwd")
+                check(step_bwd(dz_p[t], wt_p, dy_p[t - 1], dcb_p[k], cs_p[t - 1], cs_p[t], ac_p[t - 1], pr_p, dz_p[t - 1],
+                               dcb_p[k ^ 1], p2_p[t - 1], B, H, st), "blm_lstm_search_step_bwd")
                 k ^= 1
             check(lib().blm_lstm_step_dh(ptr(dz[0]), ptr(w_t), ptr(dhr[0]), B, H, 8 * H, st), "blm_lstm_step_dh")
             dh_rec, dc = dhr[0], dcb[k]
