@@ -137,8 +137,20 @@ def check(rc, what=""):
                                                           lib().blm_last_error().decode("utf-8", "replace")))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_dev_index = None
+
+
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's CURRENT stream on this process's GPU (one process per GPU: the device index is read once).
+    ``torch.cuda.current_stream()`` costs ~17 us per call (device-index resolution); the raw query is < 1 us, and an
+    op makes this call for every kernel it launches."""
+    global _dev_index
+    if _raw_stream is None:
+        return torch.cuda.current_stream().cuda_stream
+    if _dev_index is None:
+        _dev_index = torch.cuda.current_device()
+    return _raw_stream(_dev_index)
 
 
 def ptr(t):

@@ -190,6 +190,7 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
         host[2 * Tm] = lens
         dev_buf = torch.from_numpy(host).to(device, non_blocking=True)
         data, tgt = dev_buf[:Tm], dev_buf[Tm:2 * Tm].contiguous()
+        last_batch[0] = data
         mask = (torch.arange(Tm, device=device).unsqueeze(1) < dev_buf[2 * Tm].unsqueeze(0)).float()
         hN = tuple(h.expand(-1, N, -1).contiguous() for h in hidden) if is_rnn else None
         h2N = tuple(h.expand(-1, N, -1).contiguous() for h in hidden_2) if hidden_2 is not None else None
@@ -211,6 +212,7 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
             flush()
 
     pending = []
+    last_batch = [None]
 
     def flush():
         if not pending:
@@ -232,7 +234,7 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
                 # carry = state after the FIRST hypothesis alone, mean weights (reference :271-274)
                 was_training = model.training
                 model.eval()
-                x0 = torch.tensor(pairs[0][0], dtype=torch.int64, device=device).view(-1, 1)
+                x0 = last_batch[0][:len(pairs[0][0]), 0:1].contiguous()  # hypothesis 0 of the batch just scored: already on the device
                 _, hidden = model(x0, hidden)
                 if model_2 is not None:
                     _, hidden_2 = model_2(x0, hidden_2)
