@@ -465,6 +465,19 @@ extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const 
   return BLM_OK;
 }
 
+extern "C" int blm_lstm_seq_fwd(const float* xw, const float* w_hh, float* hs, float* cs, float* gates_act,
+                                const float* noise_rows, int T, int B, int H, void* stream) {
+  if (T < 0) return blm_fail(BLM_ERR_INVALID, "blm_lstm_seq_fwd: bad arguments");
+  const size_t bh = (size_t)B * H, bg = 4 * bh;
+  for (int t = 0; t < T; ++t) {
+    const int rc = blm_lstm_step_fwd(xw + t * bg, w_hh, hs + t * bh, cs + t * bh, hs + (t + 1) * bh, cs + (t + 1) * bh,
+                                     gates_act ? gates_act + t * bg : nullptr, noise_rows ? noise_rows + (size_t)t * H : nullptr,
+                                     B, H, stream);
+    if (rc) return rc;
+  }
+  return BLM_OK;
+}
+
 extern "C" int blm_lstm_search_step_fwd(const float* xw8_t, const float* w8_hh, const float* h_prev, const float* c_prev,
                                         const float* probs, float* h, float* c, float* acts8, int B, int H, void* stream) {
   if (!xw8_t || !w8_hh || !h_prev || !c_prev || !probs || !h || !c || B < 0 || H < 0)

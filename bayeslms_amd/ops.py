@@ -845,20 +845,16 @@ class _LSTMLayer(torch.autograd.Function):
         # one launch per step (recurrent product + cell, blm_lstm_step_fwd) when the shape allows it,
         # else skinny GEMM + cell kernel
         fused_step = H % 32 == 0 and w_hh.data_ptr() % 16 == 0 and hs.data_ptr() % 16 == 0 and w_hh.is_contiguous()
-        xw_p, hs_p, cs_p, ga_p, w_p = _P(xw), _P(hs), _P(cs), _P(ga), ptr(w_hh)
-        nz_p = None if noise_rows is None else _P(noise_rows)
-        step_fwd = lib().blm_lstm_step_fwd
-        for t in range(T):
-            nz = None if nz_p is None else nz_p[t]
-            if fused_step:
-                check(step_fwd(xw_p[t], w_p, hs_p[t], cs_p[t], hs_p[t + 1], cs_p[t + 1], ga_p[t], nz, B, H, st),
-                      "blm_lstm_step_fwd")
-                continue
-            gemm(L.GEMM_NT, hs[t], w_hh, hw, B, G, H, H, H, G)
-            check(lib().blm_lstm_cell_fwd(ptr(xw[t]), ptr(hw), ptr(cs[t]), ptr(hs[t + 1]), ptr(cs[t + 1]), ptr(ga[t]),
-                                          B, H, st), "blm_lstm_cell_fwd")
-            if nz is not None:
-                check(lib().blm_add_rowvec(ptr(hs[t + 1]), nz, B, H, st), "blm_add_rowvec")
+        if fused_step:  # the whole layer from one call: T launches issued by the library
+            check(lib().blm_lstm_seq_fwd(ptr(xw), ptr(w_hh), ptr(hs), ptr(cs), ptr(ga), ptr(noise_rows), T, B, H, st),
+                  "blm_lstm_seq_fwd")
+        else:
+            for t in range(T):
+                gemm(L.GEMM_NT, hs[t], w_hh, hw, B, G, H, H, H, G)
+                check(lib().blm_lstm_cell_fwd(ptr(xw[t]), ptr(hw), ptr(cs[t]), ptr(hs[t + 1]), ptr(cs[t + 1]), ptr(ga[t]),
+                                              B, H, st), "blm_lstm_cell_fwd")
+                if noise_rows is not None:
+                    check(lib().blm_add_rowvec(ptr(hs[t + 1]), ptr(noise_rows[t]), B, H, st), "blm_add_rowvec")
         ctx.save_for_backward(x, hs, cs, ga, w_ih, w_hh)
         ctx.has_noise = noise_rows is not None
         return hs[1:], hs[T], cs[T]

@@ -296,6 +296,13 @@ int blm_clip_sgd_multi(float* const* params, const float* const* grads, float* c
 int blm_lstm_step_fwd(const float* xw_t, const float* w_hh, const float* h_prev, const float* c_prev, float* h,
                       float* c, float* gates_act, const float* h_noise, int B, int H, void* stream);
 
+/* The T forward steps of one layer from ONE call (T launches of blm_lstm_step_fwd issued by the library: a scoring
+ * pass has nothing to hide the caller's per-call cost behind).  xw (T,B,4H); hs, cs (T+1,B,H) with row 0 = the
+ * initial state, rows 1..T written; gates_act (T,B,4H) or NULL; noise_rows (T,H) or NULL.  Same shape rule and
+ * status codes as blm_lstm_step_fwd (nothing is launched when the first step is unsupported). */
+int blm_lstm_seq_fwd(const float* xw, const float* w_hh, float* hs, float* cs, float* gates_act, const float* noise_rows,
+                     int T, int B, int H, void* stream);
+
 /* Backward of one LSTM time step in a single launch:
  *   dh = dgates_t[b,4H] . w_hh[4H,H]   (w_hh passed TRANSPOSED: w_hh_t (H,4H), see blm_transpose)
  * then, when dgates_out != NULL, the cell backward of the previous step (blm_lstm_cell_bwd2 with
