@@ -300,6 +300,7 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit("bayeslms_amd scoring needs an MI355X: there is no CPU path")
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(device)  # one process per GPU: kernels go to the current device's stream
     if args.gemm_mode != 'f32':
         from . import ops
         ops.set_gemm_mode(args.gemm_mode)
