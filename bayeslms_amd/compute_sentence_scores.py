@@ -150,14 +150,26 @@ def _batch_nll(model, data, target_flat, model_type, hidden, model_2, hidden_2, 
     return nll.view(data.shape[0], data.shape[1])
 
 
+def _carry(model, x0, hidden):
+    """State after running x0 (T,1) from ``hidden`` in eval mode: the recurrent stack only -- every LSTM family here is
+    embedding -> self.rnn -> dropout -> decoder (model.py:217-229 and its siblings), and the decoder's (T,V) logits
+    are not needed for the state."""
+    from . import ops
+    if hasattr(model, "rnn") and hasattr(model, "encoder") and not model.training:
+        emb = ops.embed(x0, model.encoder.weight, None, 1.0, ops.NO_DROP)
+        return model.rnn(emb, hidden)[1]
+    return model(x0, hidden)[1]
+
+
 def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None, alpha=0.0, mc_samples=0, seed=1111,
                            batch_tokens=8192):
     """the N hypotheses of an utterance are padded into ONE (T_max, N) batch instead
     of N separate launches.  Exact for causal Transformers (padding sits after every real token) and
-    for LSTMs (all hypotheses start from the same carried state, the carry itself is taken from a
-    B = 1 pass over the first hypothesis exactly as the reference does, :271-274).  Transformers carry
-    no state between utterances, so consecutive utterances are packed into one batch up to
-    ``batch_tokens`` padded tokens (20-best lists alone are launch bound).
+    for LSTMs (all hypotheses of an utterance start from the same carried state; the carry is the state after
+    a B = 1 pass over the previous utterance's first hypothesis exactly as the reference does, :271-274).
+    Consecutive utterances are packed into one batch up to ``batch_tokens`` padded tokens (20-best lists alone are
+    launch bound): Transformers carry no state; for LSTMs the carries depend on first hypotheses only, so they
+    are computed first in one sequential pass and every column of a packed batch starts from its own carry.
 
     mc_samples = S > 0 (new, default off; not in the reference, which scores with mean weights):
     S passes with the variational weights sampled (dropout off) and the sentence PROBABILITIES
@@ -190,10 +202,14 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
         host[2 * Tm] = lens
         dev_buf = torch.from_numpy(host).to(device, non_blocking=True)
         data, tgt = dev_buf[:Tm], dev_buf[Tm:2 * Tm].contiguous()
-        last_batch[0] = data
         mask = (torch.arange(Tm, device=device).unsqueeze(1) < dev_buf[2 * Tm].unsqueeze(0)).float()
-        hN = tuple(h.expand(-1, N, -1).contiguous() for h in hidden) if is_rnn else None
-        h2N = tuple(h.expand(-1, N, -1).contiguous() for h in hidden_2) if hidden_2 is not None else None
+        hN = h2N = None
+        if is_rnn:  # every column starts from the state carried into ITS utterance
+            counts = [len(ps) for _, _, ps in group]
+            hN = tuple(torch.cat([hidden[u][i].expand(-1, c, -1) for u, c in enumerate(counts)], 1).contiguous() for i in (0, 1))
+            if hidden_2 is not None:
+                h2N = tuple(torch.cat([hidden_2[u][i].expand(-1, c, -1) for u, c in enumerate(counts)], 1).contiguous()
+                            for i in (0, 1))
         sent = []
         for _ in range(S):
             if mc_samples > 0:
@@ -212,7 +228,6 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
             flush()
 
     pending = []
-    last_batch = [None]
 
     def flush():
         if not pending:
@@ -226,28 +241,42 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
         pending.clear()
 
     with torch.no_grad():
-        group, g_cols, g_tmax = [], 0, 0
-        for key, hyps in nbest.items():
-            pairs = [get_input_and_target(h, vocab) for h in hyps]
-            if is_rnn:
-                score_group([(key, hyps, pairs)], hidden, hidden_2)
-                # carry = state after the FIRST hypothesis alone, mean weights (reference :271-274)
-                was_training = model.training
-                model.eval()
-                x0 = last_batch[0][:len(pairs[0][0]), 0:1].contiguous()  # hypothesis 0 of the batch just scored: already on the device
-                _, hidden = model(x0, hidden)
+        items = list(nbest.items())
+        carries, carries_2 = None, None
+        if is_rnn and items:
+            # Pass 1 -- the carry chain.  The state entering utterance u is the state after the FIRST hypothesis of
+            # utterance u-1 alone, mean weights (reference :271-274): it depends on first hypotheses only, so the chain
+            # is walked once (B = 1, one host-to-device copy for all of them) and every utterance's hypotheses are
+            # scored afterwards in cross-utterance batches, each column starting from its utterance's carry.
+            was_training = model.training
+            model.eval()
+            firsts = [get_input_and_target(hyps[0], vocab)[0] for _, hyps in items]
+            offs = np.cumsum([0] + [len(f) for f in firsts])
+            stream_ids = torch.from_numpy(np.concatenate([np.asarray(f, dtype=np.int64) for f in firsts])).to(device)
+            carries, carries_2 = [], ([] if model_2 is not None else None)
+            for u in range(len(items)):
+                carries.append(hidden)
+                x0 = stream_ids[offs[u]:offs[u + 1]].view(-1, 1)
+                hidden = _carry(model, x0, hidden)
                 if model_2 is not None:
-                    _, hidden_2 = model_2(x0, hidden_2)
-                model.train(was_training)
-                continue
+                    carries_2.append(hidden_2)
+                    hidden_2 = _carry(model_2, x0, hidden_2)
+            model.train(was_training)
+        group, g_h, g_h2, g_cols, g_tmax = [], [], [], 0, 0
+        for u, (key, hyps) in enumerate(items):  # tokenised lazily: the host work overlaps the batches already in flight
+            pairs = [get_input_and_target(h, vocab) for h in hyps]
             tmax = max(len(x) for x, _ in pairs)
             if group and max(g_tmax, tmax) * (g_cols + len(pairs)) > batch_tokens:
-                score_group(group, None, None)
-                group, g_cols, g_tmax = [], 0, 0
+                score_group(group, g_h if is_rnn else None, g_h2 if (is_rnn and model_2 is not None) else None)
+                group, g_h, g_h2, g_cols, g_tmax = [], [], [], 0, 0
             group.append((key, hyps, pairs))
+            if is_rnn:
+                g_h.append(carries[u])
+                if model_2 is not None:
+                    g_h2.append(carries_2[u])
             g_cols, g_tmax = g_cols + len(pairs), max(g_tmax, tmax)
         if group:
-            score_group(group, None, None)
+            score_group(group, g_h if is_rnn else None, g_h2 if (is_rnn and model_2 is not None) else None)
         flush()
     if mc_samples > 0:
         model.noise_state.dropout_off = False
