@@ -161,6 +161,45 @@ def _carry(model, x0, hidden):
     return model(x0, hidden)[1]
 
 
+def _carry_chain(model, stream_ids, offs, hidden, max_tokens=8192):
+    """-> [state entering utterance u] for the concatenated first hypotheses ``stream_ids`` (utterance u = tokens
+    offs[u]:offs[u+1]).  The chain is one long B = 1 sequence: it is run in segments of whole utterances (<= max_tokens
+    tokens) through the recurrent stack, and the states at the utterance boundaries are tapped out of the fused LSTM
+    layers (ops.state_tap) -- one call per segment instead of one per utterance.  Cells that run step-wise do not
+    report their states: those models walk the chain utterance by utterance."""
+    from . import ops
+    n = len(offs) - 1
+    carries = []
+    u = 0
+    nlayers = hidden[0].shape[0]
+    tappable = hasattr(model, "rnn") and hasattr(model, "encoder") and not model.training
+    while u < n:
+        v = u + 1
+        while v < n and offs[v + 1] - offs[u] <= max_tokens:
+            v += 1
+        if tappable:
+            seg = stream_ids[offs[u]:offs[v]].view(-1, 1)
+            bounds = torch.as_tensor([offs[k + 1] - offs[u] - 1 for k in range(u, v)], dtype=torch.int64, device=seg.device)
+            with ops.state_tap(bounds) as tap:
+                emb = ops.embed(seg, model.encoder.weight, None, 1.0, ops.NO_DROP)
+                last = model.rnn(emb, hidden)[1]
+            if len(tap.layers) == nlayers:
+                hb = torch.stack([h for h, _ in tap.layers])  # (L, n_utt, 1, H)
+                cb = torch.stack([c for _, c in tap.layers])
+                carries.append(hidden)
+                for k in range(v - u - 1):
+                    carries.append((hb[:, k].contiguous(), cb[:, k].contiguous()))
+                hidden = last
+                u = v
+                continue
+            tappable = False  # a step-wise cell: no taps -- redo this segment (and the rest) utterance by utterance
+        for k in range(u, v):
+            carries.append(hidden)
+            hidden = _carry(model, stream_ids[offs[k]:offs[k + 1]].view(-1, 1), hidden)
+        u = v
+    return carries
+
+
 def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None, alpha=0.0, mc_samples=0, seed=1111,
                            batch_tokens=8192):
     """the N hypotheses of an utterance are padded into ONE (T_max, N) batch instead
@@ -253,14 +292,8 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
             firsts = [get_input_and_target(hyps[0], vocab)[0] for _, hyps in items]
             offs = np.cumsum([0] + [len(f) for f in firsts])
             stream_ids = torch.from_numpy(np.concatenate([np.asarray(f, dtype=np.int64) for f in firsts])).to(device)
-            carries, carries_2 = [], ([] if model_2 is not None else None)
-            for u in range(len(items)):
-                carries.append(hidden)
-                x0 = stream_ids[offs[u]:offs[u + 1]].view(-1, 1)
-                hidden = _carry(model, x0, hidden)
-                if model_2 is not None:
-                    carries_2.append(hidden_2)
-                    hidden_2 = _carry(model_2, x0, hidden_2)
+            carries = _carry_chain(model, stream_ids, offs, hidden)
+            carries_2 = _carry_chain(model_2, stream_ids, offs, hidden_2) if model_2 is not None else None
             model.train(was_training)
         group, g_h, g_h2, g_cols, g_tmax = [], [], [], 0, 0
         for u, (key, hyps) in enumerate(items):  # tokenised lazily: the host work overlaps the batches already in flight

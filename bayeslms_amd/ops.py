@@ -818,6 +818,30 @@ def philox_normal(n, seed, stream_id, step, device="cuda"):
 # ----------------------------------------------------------------------------
 # 2-layer LSTM stack as _VF.lstm computes it (model.py:812), explicit cell
 # ----------------------------------------------------------------------------
+_STATE_TAP = None
+
+
+class state_tap:
+    """Inference helper: inside the context every fused LSTM layer forward also records its (h, c) AFTER the time
+    steps ``idx`` (int64 device tensor) -- the scorer walks the carry chain of a whole n-best file as one long B = 1
+    sequence and reads the states at the utterance boundaries (compute_sentence_scores.py).  ``layers`` holds one
+    (h (n,B,H), c (n,B,H)) pair per layer call, in call order; step-wise cells do not report (the caller checks)."""
+
+    def __init__(self, idx):
+        self.idx = idx + 1  # row t+1 of the (T+1,B,H) state buffers = state after step t
+        self.layers = []
+
+    def __enter__(self):
+        global _STATE_TAP
+        _STATE_TAP = self
+        return self
+
+    def __exit__(self, *exc):
+        global _STATE_TAP
+        _STATE_TAP = None
+        return False
+
+
 class _LSTMLayer(torch.autograd.Function):
     """One layer over T steps.  Input GEMM batched over T (M = T*B), recurrent GEMM + fused cell per
     step.  Weights arrive already sampled (W = mu + noise on the gate rows)."""
@@ -855,6 +879,8 @@ class _LSTMLayer(torch.autograd.Function):
                                               B, H, st), "blm_lstm_cell_fwd")
                 if noise_rows is not None:
                     check(lib().blm_add_rowvec(ptr(hs[t + 1]), ptr(noise_rows[t]), B, H, st), "blm_add_rowvec")
+        if _STATE_TAP is not None:
+            _STATE_TAP.layers.append((hs.index_select(0, _STATE_TAP.idx), cs.index_select(0, _STATE_TAP.idx)))
         ctx.save_for_backward(x, hs, cs, ga, w_ih, w_hh)
         ctx.has_noise = noise_rows is not None
         return hs[1:], hs[T], cs[T]
@@ -966,6 +992,8 @@ class _LSTMRecurrentGP(torch.autograd.Function):
         for t in range(T):
             check(step_fwd(xw_p[t], w_p, hs_p[t], cs_p[t], hs_p[t + 1], cs_p[t + 1], ga_p[t], None, ovr, co_p, rb_p,
                            None if zs_p is None else zs_p[t], B, H, st), "blm_lstm_step_fwd_gp")
+        if _STATE_TAP is not None:
+            _STATE_TAP.layers.append((hs.index_select(0, _STATE_TAP.idx), cs.index_select(0, _STATE_TAP.idx)))
         ctx.save_for_backward(hs, cs, ga, w_rec, *([zs, coef4] if ovr >= 0 else []))
         ctx.ovr = ovr
         return hs[1:], hs[T], cs[T]

@@ -860,3 +860,45 @@ def test_train_cli_reference_default_shapes(dev, margs, tmp_path, capsys):
     out = capsys.readouterr().out
     vals = [float(x) for x in re.findall(r"valid loss\s+([0-9.]+)", out)]
     assert len(vals) == 2 and vals[1] < vals[0] and vals[1] < 3.4 and np.isfinite(vals).all(), out[-500:]
+
+
+@pytest.mark.parametrize("family", ["gauss53", "gauss33", "gauss6360", "variational11", "bayes3", "plain"])
+def test_lstm_scorer_batched_equals_reference_loop(dev, family):
+    """LSTM n-best scoring: the carry chain walked as one long sequence (states tapped at the utterance boundaries,
+    or utterance by utterance for the step-wise cells) + cross-utterance batches with per-column initial state must
+    give the scores of the reference's one-hypothesis-at-a-time loop (hidden carried from the first hypothesis)."""
+    import random
+    from collections import OrderedDict
+    from bayeslms_amd import compute_sentence_scores as S, model as M
+    torch.manual_seed(31)
+    V, H = 60, 32
+    words = ["w%d" % i for i in range(V - 2)]
+    vocab = {w: i + 2 for i, w in enumerate(words)}
+    vocab["<s>"], vocab["<unk>"] = 0, 1
+    if family.startswith("gauss"):
+        m = M.GaussRNNModel("LSTM", V, H, H, 2, 0.0, True, family[5:])
+    elif family == "variational11":
+        m = M.VariationalRNNModel("LSTM", V, H, H, 2, 0.0, True, "11")
+    elif family == "bayes3":
+        m = M.BayesRNNModel("LSTM", V, H, H, 2, 0.0, True, 3)
+    else:
+        m = M.RNNModel("LSTM", V, H, H, 2, 0.0, True)
+    m = m.to(dev)
+    rnd = random.Random(3)
+    nbest = OrderedDict()
+    for u in range(7):
+        base = [rnd.choice(words) for _ in range(rnd.randint(1, 9))]
+        hyps = []
+        for _ in range(rnd.randint(1, 5)):
+            h = list(base)
+            if rnd.random() < 0.7:
+                h = h + [rnd.choice(words) for _ in range(rnd.randint(0, 3))]
+            hyps.append(" ".join(h))
+        nbest["utt%d" % u] = hyps
+    want = S.compute_scores(nbest, m, vocab, "LSTM", dev)
+    for bt in (8192, 40):  # everything in one batch / a few utterances per batch
+        got = S.compute_scores_batched(nbest, m, vocab, "LSTM", dev, batch_tokens=bt)
+        assert list(got) == list(want)
+        for k in want:
+            for (h1, a), (h2, b) in zip(got[k], want[k]):
+                assert h1 == h2 and abs(a - b) <= 1e-4 * max(1.0, abs(b)), (family, bt, k, a, b)
