@@ -864,7 +864,6 @@ class _LSTMLayer(torch.autograd.Function):
         hs[0].copy_(h0)
         cs[0].copy_(c0)
         ga = torch.empty(T, B, G, device=dev, dtype=torch.float32)
-        hw = torch.empty(B, G, device=dev, dtype=torch.float32)
         st = stream()
         # one launch per step (recurrent product + cell, blm_lstm_step_fwd) when the shape allows it,
         # else skinny GEMM + cell kernel
@@ -873,6 +872,7 @@ class _LSTMLayer(torch.autograd.Function):
             check(lib().blm_lstm_seq_fwd(ptr(xw), ptr(w_hh), ptr(hs), ptr(cs), ptr(ga), ptr(noise_rows), T, B, H, st),
                   "blm_lstm_seq_fwd")
         else:
+            hw = torch.empty(B, G, device=dev, dtype=torch.float32)
             for t in range(T):
                 gemm(L.GEMM_NT, hs[t], w_hh, hw, B, G, H, H, H, G)
                 check(lib().blm_lstm_cell_fwd(ptr(xw[t]), ptr(hw), ptr(cs[t]), ptr(hs[t + 1]), ptr(cs[t + 1]), ptr(ga[t]),
