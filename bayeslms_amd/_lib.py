@@ -91,6 +91,7 @@ SIGNATURES = {
     "blm_gp_mix_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "blm_add_rowvec": (_i, [_vp, _vp, _i, _i, _vp]),
     "blm_axpy": (_i, [_vp, _vp, _i64, _f, _vp]),
+    "blm_rows_gather_add": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _vp]),
     "blm_mix2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
     "blm_mix2_partials": (_i64, [_i, _i, _i]),
     "blm_mix2_bwd": (_i, [_vp] * 8 + [_i, _i, _i, _f, _rngp, _i, _i, _vp]),

@@ -693,6 +693,29 @@ static int grid_for(long items) {
 using namespace blm;
 #define ST static_cast<hipStream_t>(stream)
 
+// dst[v,:] += src[slot[v],:] for the vocabulary rows v that took part in this step (slot[v] >= 0): the late,
+// compact half of the tied embedding gradient joins the flat gradient buffer after its all-reduce.
+__global__ __launch_bounds__(TPB) void rows_gather_add_kernel(float* __restrict__ dst, const int64_t* __restrict__ slot,
+                                                              const float* __restrict__ src, long V, int D, long n_src) {
+  const int lane = threadIdx.x & 63;
+  const long v = (long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+  if (v >= V) return;
+  const long s = slot[v];
+  if (s < 0 || s >= n_src) return;
+  float* d = dst + v * D;
+  const float* r = src + s * D;
+  if ((D & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0) {
+    for (int j = lane * 4; j < D; j += 256) {
+      float4 a = *reinterpret_cast<const float4*>(d + j);
+      const float4 b = *reinterpret_cast<const float4*>(r + j);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      *reinterpret_cast<float4*>(d + j) = a;
+    }
+  } else {
+    for (int j = lane; j < D; j += 64) d[j] += r[j];
+  }
+}
+
 extern "C" int blm_embed_fwd(const int64_t* ids, const float* enc, const float* pe, float* out, int T, int B, int D,
                              int64_t vocab, float scale, float p, const blm_rng* rng, int col_offset, int global_cols,
                              void* stream) {
@@ -976,6 +999,16 @@ extern "C" int blm_axpy(const float* x, float* y, int64_t n, float a, void* stre
   if (!x || !y || n < 0) return blm_fail(BLM_ERR_INVALID, "blm_axpy: bad arguments");
   if (n == 0) return BLM_OK;
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, x, y, (long)n, a);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_rows_gather_add(float* dst, const int64_t* slot, const float* src, int64_t V, int D, int64_t n_src,
+                                   void* stream) {
+  if (!dst || !slot || !src || V < 0 || D <= 0 || n_src < 0) return blm_fail(BLM_ERR_INVALID, "blm_rows_gather_add: bad arguments");
+  if (V == 0 || n_src == 0) return BLM_OK;
+  hipLaunchKernelGGL(rows_gather_add_kernel, dim3((unsigned)((V + 3) / 4)), dim3(TPB), 0, ST, dst, slot, src, (long)V, D,
+                     (long)n_src);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }

@@ -8,6 +8,7 @@ side stream as soon as backward has produced them (reverse parameter order), ove
 remaining backward GEMMs; then one fused global-norm clip + SGD-momentum kernel pass over the
 three flat buffers (train.py:419-420,466 semantics, averaged over ranks).
 """
+import contextlib
 import math
 
 import torch
@@ -46,20 +47,32 @@ class FlatBuffers:
 class GradReducer:
     """Bucketed asynchronous all-reduce of a flat gradient buffer.
 
-    ``mark_ready(param)`` is called by the backward kernels' launchers (ops._notify_grad) once a
-    parameter's gradient has been enqueued; a parameter with several contributions (tied
-    embedding/decoder: decoder wgrad first, embedding scatter last) is ready after the last one.
-    When every parameter of a bucket is ready the bucket is all-reduced (sum) on ``comm_stream``
-    behind an event recorded on the compute stream.  Works on any device / backend (the gloo tests
-    drive it with CPU tensors); on the GPU the backend is "nccl" = RCCL.
+    ``mark_ready(param)`` is called once per gradient contribution: by the backward kernels' launchers
+    (ops._notify, for gradients the wgrad kernels accumulate in place) and by a post-accumulate-grad hook on
+    every parameter (``hook_autograd``, for gradients autograd's AccumulateGrad adds: LSTM weights, GP
+    coefficients, VNN noise rows, ...).  A parameter with several contributions is ready after the last one;
+    how many there are is counted in the first step (calibration: everything is reduced at ``finish()``).
+    When every parameter of a bucket is ready the bucket is all-reduced (sum) on ``comm_stream`` behind an
+    event recorded on the compute stream.  Safety rules (a stale or racing all-reduce makes ranks diverge
+    silently, so none of these is inferred):
+      * a parameter that was never marked in the calibration step holds its bucket back until ``finish()``;
+      * a contribution that arrives after its bucket was launched raises (the write pattern changed:
+        rebuild the Trainer or pass ``overlap=False``);
+      * ``overlap=False`` reduces every bucket at ``finish()``.
+    Works on any device / backend (the gloo tests drive it with CPU tensors); on the GPU the backend is
+    "nccl" = RCCL.
     """
 
-    def __init__(self, flat, bucket_bytes=32 << 20, group=None, expected=None):
+    def __init__(self, flat, bucket_bytes=32 << 20, group=None, expected=None, overlap=True):
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuda = flat.flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.cuda else None
+        self.overlap = overlap
+        self.late = None  # LateRows, set by the Trainer
+        self.measure = False  # record (backward end, communication end) event pairs on the compute stream
+        self.exposed_events = []
         # buckets = contiguous runs of parameters, built from the END of the buffer (backward order)
         per = max(1, bucket_bytes // 4)
         self.buckets = []  # (start, end, [param indices])
@@ -73,22 +86,30 @@ class GradReducer:
         for b, (_, _, ids) in enumerate(self.buckets):
             for i in ids:
                 self.bucket_of[id(flat.params[i])] = b
-        # how many backward kernels write each gradient is learnt from the first step (calibration:
-        # count notifications, reduce everything at finish()); ``expected`` can pin it up front
         self.expected = {id(p): 0 for p in flat.params}
         self.calibrating = expected is None
         for p, n in (expected or {}).items():
             self.expected[id(p)] = n
-        if expected is not None:
-            for k in self.expected:
-                self.expected[k] = self.expected[k] or 1
+        self._hooks = []
         self.reset()
+
+    def hook_autograd(self):
+        """Every leaf parameter reports the gradients autograd accumulates into it (AccumulateGrad does not run for
+        the ``None`` our in-place wgrad Functions return, so nothing is counted twice)."""
+        if self._hooks:
+            return
+        for p in self.flat.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self.mark_ready))
+
+    def unhook(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     def reset(self):
         self.seen = {k: 0 for k in self.expected}
-        # parameters nothing ever writes (expected 0 after calibration) never hold a bucket back
-        self.pending = [sum(1 for i in ids if self.calibrating or self.expected[id(self.flat.params[i])] > 0)
-                        for _, _, ids in self.buckets]
+        # a never-marked parameter keeps its bucket for finish(): "never written" is not "ready"
+        self.pending = [len(ids) for _, _, ids in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.handles = []
 
@@ -97,9 +118,16 @@ class GradReducer:
         if k not in self.seen:
             return
         self.seen[k] += 1
-        if self.calibrating or self.seen[k] != self.expected[k]:
+        if self.calibrating or not self.overlap:
             return
         b = self.bucket_of[k]
+        if self.launched[b]:
+            raise ops.BayesLMError(
+                "GradReducer: a gradient of a %s parameter was written after its bucket had been all-reduced (the "
+                "set of backward kernels changed since the calibration step); build the Trainer with overlap=False "
+                "for models whose graph changes between steps" % (tuple(param.shape),))
+        if self.seen[k] != self.expected[k]:
+            return
         self.pending[b] -= 1
         if self.pending[b] == 0:
             self._launch(b)
@@ -111,7 +139,9 @@ class GradReducer:
         if self.world == 1:
             return
         s, e, _ = self.buckets[b]
-        view = self.flat.flat_grad[s:e]
+        self._all_reduce(self.flat.flat_grad[s:e])
+
+    def _all_reduce(self, view):
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -127,13 +157,127 @@ class GradReducer:
         if self.calibrating:
             self.expected = dict(self.seen)
             self.calibrating = False
+        ev0 = None
+        if self.measure and self.cuda:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream())
         for b in range(len(self.buckets)):
             self._launch(b)
         for h in self.handles:
             h.wait()
         if self.cuda and self.world > 1:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record(torch.cuda.current_stream())
+            self.exposed_events.append((ev0, ev1))
+        if self.late is not None:
+            self.late.apply()
         self.reset()
+
+    def comm_exposed_ms(self):
+        """Average time per step the compute stream sat between the last backward kernel and the end of the
+        gradient exchange (what the overlap did not hide).  Synchronises."""
+        if not self.exposed_events:
+            return None
+        torch.cuda.synchronize()
+        v = [a.elapsed_time(b) for a, b in self.exposed_events]
+        return sum(v) / len(v)
+
+
+class LateRows:
+    """The embedding half of the (usually tied) encoder gradient, exchanged as a compact matrix.
+
+    The tied encoder/decoder weight (model.py:1240; V x d = 67.6 MB at cfg3) gets its gradient from the FIRST
+    backward kernel (decoder wgrad) and from the LAST one (embedding scatter), so as one tensor its all-reduce
+    starts when backward is over and is fully exposed.  Here the decoder contribution is reduced with the
+    other buckets while backward runs, and the embedding contribution -- at most T*B distinct rows per rank --
+    goes to a compact (U, d) matrix, U = number of distinct token ids of the GLOBAL batch this step, which is
+    all-reduced at the end of backward and added into the flat gradient (blm_rows_gather_add).  The row
+    numbering is agreed at the START of the step, off the critical path: ids are all-gathered on the
+    communication stream, presence bitmap -> prefix sum -> slot per vocabulary row (fixed-size tensor ops, no
+    host synchronisation); only U travels to the host (pinned copy + event, read when backward reaches the
+    embedding).  The sums are the same as the dense exchange's (order of float additions aside).
+    """
+
+    def __init__(self, reducer, weight):
+        self.red = reducer
+        self.weight = weight
+        V, D = weight.shape
+        self.V, self.D = V, D
+        dev = weight.device
+        self.cuda = weight.is_cuda
+        self.gworld = dist.get_world_size(reducer.group)
+        # persistent buffers (allocated on the compute stream's pool, used on both streams under events)
+        self.buf = torch.zeros(V * D, device=dev, dtype=weight.dtype)
+        self.mark = torch.zeros(V, device=dev, dtype=torch.int64)
+        self.csum = torch.zeros(V, device=dev, dtype=torch.int64)
+        self.slot_of_vocab = torch.full((V,), -1, device=dev, dtype=torch.int64)
+        self.slots = self.allids = None
+        self.count_host = torch.zeros(1, dtype=torch.int64, pin_memory=self.cuda)
+        self.event = torch.cuda.Event() if self.cuda else None
+        self.ids = None
+        self.U = 0
+        self.used = False
+
+    def begin(self, ids):
+        """Step start: agree on the compact row numbering of this step's global batch."""
+        red = self.red
+        self.ids, self.used, self.U = ids, False, 0
+        n = ids.numel()
+        if self.slots is None or self.slots.numel() != n:
+            self.slots = torch.empty(n, device=ids.device, dtype=torch.int64)
+            self.allids = torch.empty(self.gworld * n, device=ids.device, dtype=torch.int64)
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            red.comm_stream.wait_event(ev)
+            ctx = torch.cuda.stream(red.comm_stream)
+        else:
+            ctx = contextlib.nullcontext()
+        with ctx:
+            mine = ids.reshape(-1).clamp(0, self.V - 1)
+            dist.all_gather_into_tensor(self.allids, mine, group=red.group)
+            self.mark.zero_()
+            self.mark.index_fill_(0, self.allids, 1)
+            torch.cumsum(self.mark, 0, out=self.csum)
+            self.slot_of_vocab.copy_(self.csum).sub_(1)
+            self.slot_of_vocab.masked_fill_(self.mark == 0, -1)
+            torch.index_select(self.slot_of_vocab, 0, mine, out=self.slots)
+            self.count_host.copy_(self.csum[-1:], non_blocking=True)
+            if self.cuda:
+                self.event.record(red.comm_stream)
+
+    def sink(self, weight, ids):
+        """ops.set_embed_grad_sink callback (runs inside backward, at the embedding's node)."""
+        if weight is not self.weight or self.ids is None or self.used or ids.data_ptr() != self.ids.data_ptr() \
+                or ids.shape != self.ids.shape:
+            return None
+        self.used = True
+        if self.cuda:
+            self.event.synchronize()  # the host needs U; the GPU passed this point at the start of the step
+            torch.cuda.current_stream().wait_event(self.event)
+        self.U = int(self.count_host.item())
+        view = self.buf[: self.U * self.D]
+        view.zero_()
+        return view, self.slots.view(ids.shape), self.U, self._done
+
+    def _done(self):
+        self.red._all_reduce(self.buf[: self.U * self.D])
+
+    def apply(self):
+        """After the exchange: flat gradient rows += compact rows."""
+        if not self.used or self.U == 0:
+            self.ids = None
+            return
+        g = self.weight.grad
+        src = self.buf[: self.U * self.D].view(self.U, self.D)
+        if self.cuda:
+            ops.rows_gather_add(g, self.slot_of_vocab, src, self.U)
+        else:
+            rows = torch.nonzero(self.slot_of_vocab >= 0).reshape(-1)
+            g.index_add_(0, rows, src[self.slot_of_vocab[rows]])
+        self.ids = None
 
 
 class Trainer:
@@ -141,15 +285,22 @@ class Trainer:
     + clip + SGD, as train.py:315-420 does, for any of the model families."""
 
     def __init__(self, model, lr, clip, momentum=0.9, kl_scale=0.0, seed=1111, rank=0, world=1, global_batch=None,
-                 bucket_bytes=32 << 20, fused_kl=True, weight_decay=0.0):
+                 bucket_bytes=32 << 20, fused_kl=True, weight_decay=0.0, overlap=True, late_rows=True):
         self.model = model
         self.lr, self.clip, self.momentum = lr, clip, momentum
         self.weight_decay = weight_decay  # torch.optim.SGD(weight_decay=...) of train_search_bayes.py:391-392
         self.kl_scale = kl_scale
         self.rank, self.world = rank, world
         self.flat = FlatBuffers(model)
-        self.reducer = GradReducer(self.flat, bucket_bytes)
+        self.reducer = GradReducer(self.flat, bucket_bytes, overlap=overlap)
         ops.set_grad_ready_hook(self.reducer.mark_ready if world > 1 else None)
+        ops.set_embed_grad_sink(None)
+        if world > 1:
+            self.reducer.hook_autograd()
+            enc = getattr(getattr(model, "encoder", None), "weight", None)
+            if late_rows and enc is not None and any(enc is p for p in self.flat.params) and dist.is_initialized():
+                self.reducer.late = LateRows(self.reducer, enc)
+                ops.set_embed_grad_sink(self.reducer.late.sink)
         self.table = ops.PtrTable([self.flat.flat_param], [self.flat.flat_grad], [self.flat.flat_mom])
         self.step_no = 0
         self.first = True
@@ -176,6 +327,8 @@ class Trainer:
         B = data.shape[1]
         m.set_columns(self.rank * B, self.world * B)
         self.flat.zero_grad()
+        if self.reducer.late is not None:
+            self.reducer.late.begin(data)
         fused = self.fused_kl and kl_fn is not None and len(self.kl_layers) > 0 and getattr(kl_fn, "fusable", False)
         for lyr in self.kl_layers:
             lyr.fused_kl_lambda = self.kl_scale if fused else 0.0

@@ -19,7 +19,7 @@ from ._lib import BayesLMError, check, dev_tensor, lib, ptr, stream
 
 __all__ = ["Drop", "NoiseSpec", "linear", "bayes_linear", "ffn", "ffn_gp", "attention", "attention_qkv", "add_dropout_ln",
            "embed", "add_pe", "dropout", "cross_entropy", "kl_mean", "philox_normal", "sample_weight", "sampled", "lstm_layer", "lstm_cell", "gp_mix", "add_rowvec",
-           "clip_sgd", "gemm", "PtrTable", "set_grad_ready_hook", "KernelTimer", "set_kernel_timer"]
+           "clip_sgd", "gemm", "PtrTable", "set_grad_ready_hook", "set_embed_grad_sink", "rows_gather_add", "KernelTimer", "set_kernel_timer"]
 
 
 # ----------------------------------------------------------------------------
@@ -85,6 +85,26 @@ def set_grad_ready_hook(fn):
     data-parallel reducer uses it to start bucket all-reduces while backward is still running)."""
     global _GRAD_HOOK
     _GRAD_HOOK = fn
+
+
+_EMBED_SINK = None
+
+
+def set_embed_grad_sink(fn):
+    """Data-parallel training only.  ``fn(weight, ids)`` is asked by the embedding backward where its rows go: None =
+    scatter into weight.grad as usual; or (buffer, slot_ids, n_rows, done) = scatter dy rows into the compact
+    (n_rows, D) ``buffer`` at row ``slot_ids[t,b]`` and call ``done()`` once the kernel is enqueued (engine.LateRows:
+    the embedding half of the tied encoder/decoder gradient is exchanged as the rows this step touched)."""
+    global _EMBED_SINK
+    _EMBED_SINK = fn
+
+
+def rows_gather_add(dst, slot, src, n_src):
+    """dst[v,:] += src[slot[v],:] where 0 <= slot[v] < n_src."""
+    L.require_gfx950()
+    V, D = dst.shape
+    check(lib().blm_rows_gather_add(ptr(dst), ptr(dev_tensor(slot, "slot", torch.int64)), ptr(src), V, D, int(n_src),
+                                    stream()), "blm_rows_gather_add")
 
 
 def _notify(*params):
@@ -639,6 +659,14 @@ class _Embed(torch.autograd.Function):
             T, B = ids.shape
             V, D = weight.shape
             r = drop.rng() if drop.on else None
+            sink = _EMBED_SINK(weight, ids) if (_EMBED_SINK is not None and weight.is_leaf) else None
+            if sink is not None:
+                buf, slots, nrows, done = sink
+                check(lib().blm_embed_bwd(ptr(slots), ptr(dy), ptr(buf), T, B, D, int(nrows), float(scale),
+                                          float(drop.p), C.byref(r) if r is not None else None, drop.col_offset,
+                                          drop.global_cols or B, stream()), "blm_embed_bwd")
+                done()
+                return None, None, None, None, None
             check(lib().blm_embed_bwd(ptr(ids), ptr(dy), ptr(_grad_buf(weight)), T, B, D, V, float(scale),
                                       float(drop.p), C.byref(r) if r is not None else None, drop.col_offset,
                                       drop.global_cols or B, stream()), "blm_embed_bwd")

@@ -8,6 +8,9 @@ One step = forward + CE + KL*seq_len/len(train_data) + backward + gradient all-r
 + global-norm clip + SGD, nothing skipped.  Prints ONE JSON line on rank 0.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...        (starts its own N ranks: a torch.distributed.run child process, before
+                                         this process has touched the GPU; the child's JSON line and exit code are
+                                         relayed)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -43,10 +46,56 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-opt-in", action="store_true",
                     help="skip the extra, separately reported runs in the opt-in split-bf16 GEMM modes (N = 1 only)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip extra_configs (BASELINE configs[1] and configs[4] legs, reported after the headline)")
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="columns per GPU (default = the named config)")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "rehearsing several ranks on one GPU)")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="launch plumbing only (spawn, rendezvous, barrier, max-over-ranks, one JSON line from rank 0) "
+                         "with NO GPU work: what the CPU-side test of `--gpus N` self-launch runs")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from ONE process: run the N ranks as a child `torch.distributed.run` and relay its
+    output and exit code.  This process has not made (and never makes) a GPU call -- a process that has initialised
+    HIP must not be replaced or forked into ranks."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for line in proc.stdout:  # the ranks' stdout: rank 0's JSON line (anything else is passed through as well)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def rehearse_launch(args, world, rank):
+    """No GPU: every step of the multi-rank protocol around the timed region, on CPU tensors."""
+    dist.init_process_group("gloo" if args.backend == "nccl" else args.backend)
+    dist.barrier()
+    t0 = time.perf_counter()
+    x = torch.ones(1 << 16)
+    for _ in range(args.steps):
+        dist.all_reduce(x)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "train_tokens_per_sec", "value": None, "unit": "tokens/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * float(t) / max(args.steps, 1), 3),
+                          "rehearsal": "launch plumbing only, no GPU work: NOT a measurement"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def cpu_baseline(cols=32, steps=3):
@@ -148,12 +197,16 @@ _kl_fn.fusable = True
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))  # before any GPU call of this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N` or under "
+                         "torch.distributed.run --nproc-per-node N with the same N)" % (args.gpus, world))
+    if args.rehearse_launch:
+        return rehearse_launch(args, world, rank)
     ndev = torch.cuda.device_count()
     local = local % max(ndev, 1)  # rehearsal of several ranks on one GPU (gloo); one GPU per rank otherwise
     torch.cuda.set_device(local)
@@ -197,6 +250,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    tr.reducer.measure = world > 1  # event pair per step: last backward kernel -> end of the gradient exchange
     t0 = time.perf_counter()
     for i in range(args.warmup, steps_total):
         loss = one(i, True)
@@ -206,6 +260,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.set_kernel_timer(None)
+    tr.reducer.measure = False
+    comm_exposed = tr.reducer.comm_exposed_ms()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -249,6 +305,14 @@ def main():
             "roofline": roof,
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kt.items()},
             "final_loss": round(final_loss, 4), "eval_ppl": round(eval_ppl, 2),
+            # rank 0, per step: time the compute stream waited between its last backward kernel and the end of the
+            # gradient exchange (bucketed all-reduce + the compact embedding-row exchange); null at N = 1
+            "comm_exposed_ms": None if comm_exposed is None else round(comm_exposed, 4),
+            "comm": None if world == 1 else {
+                "backend": args.backend, "bucket_mb": 32, "buckets": len(tr.reducer.buckets),
+                "grad_bytes": int(tr.flat.total * 4),
+                "late_rows": tr.reducer.late is not None,
+                "late_rows_last_step": None if tr.reducer.late is None else int(tr.reducer.late.U)},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -364,6 +364,10 @@ int blm_add_rowvec(float* x, const float* v, int B, int H, void* stream);
 
 /* y (+)= a*x elementwise helpers used by the host glue. */
 int blm_axpy(const float* x, float* y, int64_t n, float a, void* stream);
+/* dst[v,:] += src[slot[v],:] for every v in [0,V) with 0 <= slot[v] < n_src (rows of D floats).  Data-parallel
+ * training reduces the embedding half of the tied encoder/decoder gradient (model.py:1240; the last tensor backward
+ * finishes) as a compact matrix of the rows this step touched; this adds it back (engine.LateRows). */
+int blm_rows_gather_add(float* dst, const int64_t* slot, const float* src, int64_t V, int D, int64_t n_src, void* stream);
 
 /* --------------------------------------------------------------------------
  * Architecture search (model_search_bayes.py, architect.py,

@@ -20,11 +20,32 @@ def _free_port():
     return p
 
 
-def _build(dev):
+FAMILIES = ["tlm_ffn", "rnn_none", "rnn_bayes3", "rnn_gauss33", "rnn_var11", "tlm_gauss3"]
+
+
+def _build(dev, family="tlm_ffn"):
+    """-> (model, kl_fn or None, is_rnn).  The LSTM families get their weight gradients from autograd's
+    AccumulateGrad (ops._LSTMLayer / _LSTMRecurrentGP return them) -- the ADVICE r1 case: readiness of those
+    must come from the post-accumulate hooks, never from a missing notification."""
     from bayeslms_amd import model as M
     torch.manual_seed(5)
-    m = M.BayesTransformerModel(150, 32, 4, 64, 2, 0.2, True, "FFN")
-    return m.to(dev)
+    V = 150
+    if family == "tlm_ffn":
+        return M.BayesTransformerModel(V, 32, 4, 64, 2, 0.2, True, "FFN").to(dev), _kl, False
+    if family == "tlm_gauss3":
+        m = M.GaussTransformerModel(V, 32, 4, 64, 2, 0.2, True, 3).to(dev)
+        return m, (lambda mm: mm.transformerlayers[0].gpnn.kl_divergence()), False
+    if family == "rnn_none":
+        return M.RNNModel("LSTM", V, 32, 32, 2, 0.2, True).to(dev), None, True
+    if family == "rnn_bayes3":
+        return M.BayesRNNModel("LSTM", V, 32, 32, 2, 0.2, True, 3).to(dev), (lambda mm: mm.rnn.kl_divergence()), True
+    if family == "rnn_gauss33":
+        m = M.GaussRNNModel("LSTM", V, 32, 32, 2, 0.2, True, "33").to(dev)
+        return m, (lambda mm: mm.rnn.rnn[0].gpnn.kl_divergence()), True
+    if family == "rnn_var11":
+        m = M.VariationalRNNModel("LSTM", V, 32, 32, 2, 0.2, True, "11").to(dev)
+        return m, (lambda mm: sum(mm.rnn.rnn[c].vnn.kl_divergence() for c in (0, 1))), True
+    raise ValueError(family)
 
 
 def _kl(model):
@@ -34,32 +55,44 @@ def _kl(model):
 _kl.fusable = True
 
 
-def _run(rank, world, port, ret):
+def _run(rank, world, port, ret, family="tlm_ffn"):
     import torch.distributed as dist
     from bayeslms_amd import data as D, engine
+    from bayeslms_amd.model import repackage_hidden
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     stream = torch.randint(0, 150, (8 * 61,), generator=torch.Generator().manual_seed(1))
     train = D.batchify(stream, 8, dev, rank, world)
-    m = _build(dev)
+    m, kl_fn, is_rnn = _build(dev, family)
     tr = engine.Trainer(m, lr=0.2, clip=0.5, kl_scale=0.01, seed=1111, rank=rank, world=world, bucket_bytes=8192)
+    if world > 1:
+        assert tr.reducer.late is not None and len(tr.reducer.buckets) > 2
     losses = []
-    for i in range(3):
+    hidden = m.init_hidden(train.shape[1]) if is_rnn else None
+    for i in range(4):
         data, tgt = D.get_batch(train, i * 12, 12)
-        loss, kl, _ = tr.step(data, tgt, kl_fn=_kl)
+        loss, kl, hidden = tr.step(data, tgt, hidden=hidden, kl_fn=kl_fn)
+        if hidden is not None:
+            hidden = repackage_hidden(hidden)
         losses.append(float(loss))
+    if world > 1:
+        # after calibration every parameter that receives a gradient is counted, whichever way it arrives
+        silent = [tuple(p.shape) for p in tr.flat.params if tr.reducer.expected[id(p)] == 0 and p.grad.abs().sum() > 0]
+        assert not silent, silent
+        assert tr.reducer.late.U > 0
     ret[(world, rank)] = (losses, tr.flat.flat_param.detach().cpu().clone())
     if world > 1:
         dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_rank_on_the_global_batch():
+@pytest.mark.parametrize("family", FAMILIES)
+def test_two_ranks_equal_one_rank_on_the_global_batch(family):
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        _spawn(1, ret)
-        _spawn(2, ret)
+        _spawn(1, ret, family)
+        _spawn(2, ret, family)
         l1, p1 = ret[(1, 0)]
         l2a, p2a = ret[(2, 0)]
         l2b, p2b = ret[(2, 1)]
@@ -71,9 +104,9 @@ def test_two_ranks_equal_one_rank_on_the_global_batch():
     assert err < 1e-4, err
 
 
-def _spawn(world, ret):
+def _spawn(world, ret, family="tlm_ffn"):
     port = _free_port()
-    mp.spawn(_run, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_run, args=(world, port, ret, family), nprocs=world, join=True)
 
 
 def _rccl_one_rank(port, ret):
@@ -101,7 +134,7 @@ def _rccl_one_rank(port, ret):
         ok_identity = bool(torch.equal(x.cpu(), torch.arange(1024, dtype=torch.float32)))
         stream = torch.randint(0, 150, (8 * 61,), generator=torch.Generator().manual_seed(1))
         train = D.batchify(stream, 8, dev)
-        m = _build(dev)
+        m, _, _ = _build(dev)
         tr = engine.Trainer(m, lr=0.2, clip=0.5, kl_scale=0.01, seed=1111, rank=0, world=2, bucket_bytes=8192)
         tr.reducer.world = 2  # grad-ready hooks on, bucketed collectives issued over RCCL (1-rank group: identity)
         losses = []
@@ -126,3 +159,25 @@ def test_rccl_backend_single_rank_smoke():
         assert p.exitcode == 0
         ok, losses, finite = ret["rccl"]
         assert ok and finite and all(v == v for v in losses) and losses[-1] < losses[0] + 1.0
+
+
+def test_bench_gpus2_self_launch_rehearsal_on_one_device():
+    """`python bench.py --gpus 2` from one process: two ranks share this box's single GPU (gloo transport; RCCL
+    refuses two ranks on one device), the real trainer step incl. the bucketed exchange and the compact
+    embedding-row exchange, one JSON line with n_gpus 2 and comm_exposed_ms."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "2", "--batch", "8", "--no-cpu-baseline", "--no-opt-in", "--no-extra"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0
+    assert out["comm_exposed_ms"] is not None and out["comm"]["late_rows"] and out["comm"]["late_rows_last_step"] > 0

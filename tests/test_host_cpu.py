@@ -11,6 +11,8 @@ import torch.multiprocessing as mp
 
 from conftest import load_golden
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_corpus_and_batchify_match_reference():
     from bayeslms_amd import data
@@ -159,3 +161,125 @@ def test_grad_reducer_gloo_world2():
         ret = mgr.dict()
         mp.spawn(_reducer_worker, args=(world, port, ret), nprocs=world, join=True)
         assert all(ret.get(r) for r in range(world))
+
+
+def _late_rows_worker(rank, world, port, ret):
+    """Tied encoder gradient in two parts (engine.LateRows) over gloo with CPU tensors: the decoder contribution
+    goes through the bucketed all-reduce, the embedding rows through the compact exchange; the sum must equal the
+    dense all-reduce of both."""
+    import torch.distributed as dist
+    from bayeslms_amd import engine
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    V, D, T, B = 40, 6, 5, 3
+    torch.manual_seed(0)
+    net = torch.nn.ModuleDict({"encoder": torch.nn.Embedding(V, D), "other": torch.nn.Linear(D, 7)})
+    flat = engine.FlatBuffers(net)
+    red = engine.GradReducer(flat, bucket_bytes=256)
+    enc = net["encoder"].weight
+    red.late = engine.LateRows(red, enc)
+    for step in range(3):
+        g = torch.Generator().manual_seed(100 * step + rank)
+        ids = torch.randint(0, V, (T, B), generator=g)
+        dy = torch.randn(T, B, D, generator=g)
+        dec = torch.randn(V, D, generator=g)
+        flat.zero_grad()
+        red.late.begin(ids)
+        # backward order: other (last layer), decoder contribution into the tied weight, ..., embedding rows last
+        for p in net["other"].parameters():
+            p.grad.add_(1.0 + rank)
+            red.mark_ready(p)
+        enc.grad.add_(dec)
+        red.mark_ready(enc)
+        sink = red.late.sink(enc, ids)
+        assert sink is not None
+        buf, slots, U, done = sink
+        assert slots.shape == ids.shape and int(slots.min()) >= 0 and int(slots.max()) < U <= min(V, world * T * B)
+        buf.view(U, D).index_add_(0, slots.reshape(-1), dy.reshape(-1, D))
+        done()
+        assert red.late.sink(enc, ids) is None  # a second embedding lookup of the same step takes the dense path
+        red.finish()
+        # dense reference: every rank's (decoder + scattered rows), summed over ranks
+        want = torch.zeros(V, D)
+        for r in range(world):
+            g = torch.Generator().manual_seed(100 * step + r)
+            ids_r = torch.randint(0, V, (T, B), generator=g)
+            dy_r = torch.randn(T, B, D, generator=g)
+            dec_r = torch.randn(V, D, generator=g)
+            want += dec_r
+            want.index_add_(0, ids_r.reshape(-1), dy_r.reshape(-1, D))
+        assert torch.allclose(enc.grad, want, atol=1e-5), (rank, step, float((enc.grad - want).abs().max()))
+        for p in net["other"].parameters():
+            assert torch.allclose(p.grad, torch.full_like(p.grad, sum(1.0 + r for r in range(world))))
+    assert red.expected[id(enc)] == 1  # the embedding half no longer counts as a writer of the flat slot
+    ret[rank] = True
+    dist.destroy_process_group()
+
+
+def test_late_rows_gloo_world2():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_late_rows_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert all(ret.get(r) for r in range(world))
+
+
+def test_grad_reducer_never_infers_readiness():
+    """a parameter nobody marked in the calibration step holds its bucket until finish(); a write that
+    arrives after its bucket went out raises instead of racing the all-reduce."""
+    from bayeslms_amd import engine, BayesLMError
+    net = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 8))
+    flat = engine.FlatBuffers(net)
+    red = engine.GradReducer(flat, bucket_bytes=1 << 20)  # one bucket
+    p = flat.params
+    for q in p[1:]:  # calibration: p[0] is never written
+        red.mark_ready(q)
+    red.finish()
+    assert red.expected[id(p[0])] == 0
+    for q in p[1:]:
+        red.mark_ready(q)
+    assert not any(red.launched)  # the silent parameter keeps the bucket back
+    red.mark_ready(p[0])          # ... and if it does get a gradient later, the bucket still waits for finish()
+    assert not any(red.launched)
+    red.finish()
+    # two buckets: a late second write into an already reduced bucket is an error, not a race
+    red = engine.GradReducer(flat, bucket_bytes=64)
+    assert len(red.buckets) > 1
+    for q in reversed(p):
+        red.mark_ready(q)
+    red.finish()
+    for i in red.buckets[0][2]:   # first bucket in backward order = the tail of the buffer
+        red.mark_ready(p[i])
+    assert red.launched[0] and red.bucket_of[id(p[-1])] == 0
+    with pytest.raises(BayesLMError):
+        red.mark_ready(p[-1])
+    red.reset()
+    # hook_autograd: AccumulateGrad reports through the post-accumulate hook
+    red.hook_autograd()
+    x = torch.randn(4, 8)
+    net(x).sum().backward()
+    assert all(red.seen[id(q)] == 1 for q in p)
+    red.unhook()
+
+
+def test_bench_self_launches_its_ranks_from_one_process():
+    """VERDICT r1 / ADVICE: `python bench.py --gpus N` must start its own ranks (a torch.distributed.run child, before
+    any GPU call) instead of exiting.  CPU side: the launch plumbing only (--rehearse-launch: no GPU work)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--rehearse-launch"], capture_output=True, text=True, timeout=600, env=env,
+                       cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] is None
+    # a WORLD_SIZE / --gpus mismatch is an error, not a silently different run
+    env["WORLD_SIZE"] = "3"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd="/tmp")
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
