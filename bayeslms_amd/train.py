@@ -129,8 +129,26 @@ def kl_selector(args):
     return fn
 
 
-def main(argv=None):
+def _print_coef_mean(args, model, say):
+    """train.py:483-494 / :529-540: the per-epoch print of the GP activation-mixture coefficients, averaged
+    over units (one value per basis activation)."""
+    sd = model.state_dict()
+    if args.model == 'Transformer' and args.uncertainty == 'Gaussian' and args.T_gauss_pos <= 3:
+        say(sd['transformerlayers.0.gpnn.coef_mean'].mean(dim=1))
+    elif args.model == 'LSTM' and args.uncertainty == 'Gaussian' and int(args.L_gauss_pos[1]) <= 3:
+        g = args.L_gauss_pos
+        cells = [0] if len(g) < 3 else ([1] if len(g) == 3 else [0, 1])
+        for c in cells:
+            say(sd['rnn.rnn.%d.gpnn.coef_mean' % c].mean(dim=1))
+
+
+def main(argv=None, history=None):
+    """``history`` (optional dict) receives what the log lines print with two decimals at full precision:
+    interval_loss, valid_loss, halved_epochs, test_loss."""
     args = build_parser().parse_args(argv)
+    if history is None:
+        history = {}
+    history.update({"interval_loss": [], "valid_loss": [], "halved_epochs": [], "test_loss": None})
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -201,6 +219,7 @@ def main(argv=None):
             total_loss = total_loss + loss  # stays on the device: one host sync per log interval (train.py:422 syncs per step)
             if batch % args.log_interval == 0 and batch > 0:
                 cur = float(total_loss) / args.log_interval
+                history["interval_loss"].append(cur)
                 elapsed = time.time() - start
                 say('| epoch {:3d} | {:5d}/{:5d} batches | lr {:02.3f} | ms/batch {:5.2f} | loss {:5.2f} | '
                     'kl_loss {:5.4} | ppl {:8.2f}'.format(epoch, batch, len(train_data) // args.seq_len, lr,
@@ -222,6 +241,8 @@ def main(argv=None):
             say('| end of epoch {:3d} | time: {:5.2f}s | valid loss {:5.2f} | valid ppl {:8.2f}'.format(
                 epoch, time.time() - t0, val_loss, math.exp(val_loss)))
             say('-' * 89)
+            history["valid_loss"].append(val_loss)
+            _print_coef_mean(args, model, say)
             if not best_val or val_loss < best_val:
                 if is_main:
                     with open(args.save, 'wb') as f:
@@ -229,6 +250,7 @@ def main(argv=None):
                 best_val = val_loss
             else:  # train.py:503-508: halve LR, fresh SGD (momentum reset), reload best
                 lr /= 2.
+                history["halved_epochs"].append(epoch)
                 trainer.reset_optimizer(lr)
                 if world > 1:
                     dist.barrier()
@@ -252,7 +274,9 @@ def main(argv=None):
             own = model.state_dict()
             for k, v in sd.items():
                 own[k].copy_(v)
+    _print_coef_mean(args, model, say)
     test_loss = engine.evaluate(model, test_data, args.seq_len)
+    history["test_loss"] = test_loss
     say('=' * 89)
     say('| End of training | test loss {:5.2f} | test ppl {:8.2f}'.format(test_loss, math.exp(test_loss)))
     say('=' * 89)

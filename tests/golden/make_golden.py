@@ -445,6 +445,120 @@ def f6_train_checkpoint():
                  **{"sd/" + k: npy(v) for k, v in sd.items() if not k.endswith("pos_encoder.pe")})
 
 
+# runs INSIDE the child process before the reference's train.py: instruments torch / math (not the reference) so that
+# the quantities train.py only prints with two decimals are kept at full precision
+_TRAIN_PROBE = r"""
+import math, os, runpy, sys
+import numpy as np, torch
+rec = {"exp": [], "bwd": [], "snaps": [], "sgd_lr": []}
+_exp = math.exp
+def _rexp(x):
+    rec["exp"].append(float(x)); return _exp(x)
+math.exp = _rexp                       # train.py prints math.exp(cur_loss / val_loss / test_loss)
+_bw = torch.Tensor.backward
+def _rbw(self, *a, **k):
+    rec["bwd"].append(float(self.detach())); return _bw(self, *a, **k)
+torch.Tensor.backward = _rbw           # loss.backward(): the total loss of every step
+_ev = torch.nn.Module.eval
+def _rev(self):
+    if hasattr(self, "encoder") and hasattr(self, "decoder"):
+        rec["snaps"].append({k: v.detach().clone().numpy() for k, v in self.state_dict().items()})
+    return _ev(self)
+torch.nn.Module.eval = _rev            # evaluate() starts with model.eval(): parameters at the end of every epoch
+_sgd = torch.optim.SGD.__init__
+def _rsgd(self, params, *a, **k):
+    rec["sgd_lr"].append(float(k.get("lr", a[0] if a else 0.0))); return _sgd(self, params, *a, **k)
+torch.optim.SGD.__init__ = _rsgd       # a fresh optimizer per LR halving
+script, out = sys.argv[1], sys.argv[2]
+sys.argv = [script] + sys.argv[3:]
+g = runpy.run_path(script, run_name="__main__")
+kw = {"exp": np.array(rec["exp"]), "bwd": np.array(rec["bwd"]), "sgd_lr": np.array(rec["sgd_lr"]),
+      "final_lr": np.float64(g["lr"]), "counter": np.int64(g["counter"]), "best_val_loss": np.float64(g["best_val_loss"]),
+      "test_loss": np.float64(g["test_loss"]), "rows": np.int64(len(g["train_data"]))}
+for i, sd in enumerate(rec["snaps"]):
+    for k, v in sd.items():
+        if not k.endswith("pos_encoder.pe"):
+            kw["snap%d/%s" % (i, k)] = v
+np.savez(out, **kw)
+"""
+
+
+def f6_train_trajectory():
+    """SURVEY 8(c) F6: RNG-free runs of the reference's own train.py (dropout 0, nothing sampled: --uncertainty none;
+    Bayesian LSTM position 5 = KL in the loss but no draw, model.py:716; the GP families, whose GPNN.sample is never
+    raised by train.py) from an initial state saved here and loaded through its --prior True path (train.py:239-258).
+    Kept at full precision: the total loss of every step, the interval means / valid losses / test loss train.py
+    prints, the parameters at the end of every epoch, the LR halvings."""
+    import re
+    import subprocess
+    lr_l, lr_t = os.environ.get("TRAJ_LR_LSTM", "1.5"), os.environ.get("TRAJ_LR_TLM", "0.4")
+    common = ["--epochs", os.environ.get("TRAJ_EPOCHS", "6"), "--batch-size", "4", "--seq_len", "7", "--dropout", "0.0", "--clip", "1.0", "--tied",
+              "--log-interval", "10", "--prior", "True"]
+    for tag, lr, margs, build in (
+        ("lstm_none", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "none"],
+         lambda V: ref.RNNModel("LSTM", V, 12, 12, 2, 0.0, True)),
+        ("tlm_none", lr_t, ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                      "--uncertainty", "none"],
+         lambda V: ref.TransformerModel(V, 16, 4, 32, 2, 0.0, "gelu", True)),
+        ("lstm_bayes5", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Bayesian",
+                         "--L_bayes_pos", "5"],
+         lambda V: ref.BayesRNNModel("LSTM", V, 12, 12, 2, 0.0, True, 5)),
+        ("tlm_gauss3", lr_t, ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                        "--uncertainty", "Gaussian", "--T_gauss_pos", "3"],
+         lambda V: ref.GaussTransformerModel(V, 16, 4, 32, 2, 0.0, True, 3)),
+        ("lstm_gauss33", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Gaussian",
+                          "--L_gauss_pos", "33"],
+         lambda V: ref.GaussRNNModel("LSTM", V, 12, 12, 2, 0.0, True, "33")),
+        ("lstm_var00", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Variational",
+                        "--L_v_pos", "00"],
+         lambda V: ref.VariationalRNNModel("LSTM", V, 12, 12, 2, 0.0, True, "00")),
+    ):
+        with tempfile.TemporaryDirectory() as dtmp:
+            words, texts = _tiny_corpus(dtmp)
+            torch.manual_seed(61)
+            with contextlib.redirect_stdout(io.StringIO()):
+                m0 = build(len(words))
+            prior_dir = os.path.join(dtmp, "prior")
+            os.makedirs(prior_dir)
+            init = {k: v.detach().clone() for k, v in m0.state_dict().items()}
+            torch.save(init, os.path.join(prior_dir, "model.pt"))
+            probe = os.path.join(dtmp, "probe.py")
+            open(probe, "w").write(_TRAIN_PROBE)
+            out_npz = os.path.join(dtmp, "rec.npz")
+            cmd = [sys.executable, probe, os.path.join(REF, "train.py"), out_npz, "--data", dtmp, "--lr", lr,
+                   "--save", os.path.join(dtmp, "model.pt"), "--prior_path", prior_dir] + common + margs
+            env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=REF, OMP_NUM_THREADS="1")
+            run = subprocess.run(cmd, cwd=dtmp, env=env, capture_output=True, text=True)
+            assert run.returncode == 0, run.stderr[-3000:]
+            log = run.stdout
+            z = np.load(out_npz)
+            ppl_lines = [ln for ln in log.splitlines() if " ppl " in ln]
+            assert len(ppl_lines) == len(z["exp"]), (len(ppl_lines), len(z["exp"]))
+            interval, valid, test = [], [], None
+            for ln, v in zip(ppl_lines, z["exp"]):
+                if "batches" in ln:
+                    interval.append(v)
+                elif "end of epoch" in ln:
+                    valid.append(v)
+                elif "End of training" in ln:
+                    test = v
+            kl_printed = [float(x) for x in re.findall(r"kl_loss\s+([0-9.eE+-]+)", log)]
+            nsnap = 1 + max(int(k[4:].split("/")[0]) for k in z.files if k.startswith("snap"))
+            assert nsnap == len(valid) + 1 and abs(test - float(z["test_loss"])) == 0.0
+            halved = [i + 1 for i in range(len(valid)) if i > 0 and not valid[i] < min(valid[:i])]
+            assert len(z["sgd_lr"]) == 1 + len(halved) and len(halved) >= 1, (valid, z["sgd_lr"])
+            margins = [abs(valid[i] - min(valid[:i])) / min(valid[:i]) for i in range(1, len(valid))]
+            print(tag, "valid", [round(float(v), 4) for v in valid], "halved at", halved, "test", round(float(test), 4),
+                  "min decision margin %.1e" % min(margins))
+            kw = {"init/" + k: npy(v) for k, v in init.items() if not k.endswith("pos_encoder.pe")}
+            kw.update({k: z[k] for k in z.files if k.startswith("snap")})
+            save("train_traj_" + tag, words=np.array(words), train_txt=np.array(texts["train"]),
+                 valid_txt=np.array(texts["valid"]), test_txt=np.array(texts["test"]), argv=np.array(common + margs + ["--lr", lr]),
+                 step_loss=z["bwd"], interval_loss=np.array(interval), valid_loss=np.array(valid), test_loss=np.float64(test),
+                 kl_printed=np.array(kl_printed), sgd_lr=z["sgd_lr"], halved_epochs=np.array(halved, dtype=np.int64),
+                 final_lr=z["final_lr"], rows=z["rows"], **kw)
+
+
 def f5_gauss_variational_rnn():
     V, H, T, B = 40, 12, 5, 3
     for gp in ("33", "31", "13", "23", "43", "330", "6360", "3333", "53", "73", "00"):
@@ -776,6 +890,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "interp":
         f7_scorer_interp()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "traj":
+        f6_train_trajectory()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "late":
         f6_train_checkpoint()
         f7_scorer()
@@ -798,3 +915,4 @@ if __name__ == "__main__":
     f9_search_models()
     f9_search_loop()
     f9_search_bayes_tlm()
+    f6_train_trajectory()

@@ -1,0 +1,40 @@
+"""GPU: `bayeslms_amd.train` (the train.py-compatible CLI, everything through the C ABI) from the SAME initial state,
+corpus and flags as RNG-free runs of the reference's own train.py (tests/golden/train_traj_*.npz):
+valid loss of every epoch and the test loss <= 1e-4 relative, the same LR-halving epochs, final parameters <= 1e-3,
+per-interval training loss <= 1e-3 (train.py:306-438, 464-519)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_train_traj_oracle import TAGS, load_traj, write_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_train_cli_reproduces_reference_train_py_trajectory(tag, tmp_path, capsys):
+    from bayeslms_amd import train as T
+    z, args, init, snaps = load_traj(tag)
+    d = str(tmp_path)
+    write_corpus(z, d)
+    prior = os.path.join(d, "prior")
+    os.makedirs(prior)
+    torch.save(init, os.path.join(prior, "model.pt"))
+    save = os.path.join(d, "model.pt")
+    argv = [str(a) for a in z["argv"]] + ["--data", d, "--save", save, "--prior_path", prior, "--cuda"]
+    hist = {}
+    T.main(argv, history=hist)
+    out = capsys.readouterr().out
+    assert list(hist["halved_epochs"]) == list(z["halved_epochs"]), (hist["valid_loss"], list(z["valid_loss"]))
+    assert np.allclose(hist["valid_loss"], z["valid_loss"], rtol=1e-4), (hist["valid_loss"], list(z["valid_loss"]))
+    assert abs(hist["test_loss"] - float(z["test_loss"])) <= 1e-4 * float(z["test_loss"])
+    assert np.allclose(hist["interval_loss"], z["interval_loss"], rtol=1e-3)
+    final = torch.load(save, map_location="cpu")
+    ref = snaps[-1]  # parameters train.py evaluated on the test set = its best checkpoint
+    for k, v in ref.items():
+        scale = float(v.abs().max()) + 1e-12
+        assert float((final[k] - v).abs().max()) <= 1e-3 * scale, k
+    if "Gaussian" in args["uncertainty"]:
+        assert out.count("tensor([") == len(z["valid_loss"]) + 1  # the coef_mean print, per epoch and at the end

@@ -1,0 +1,79 @@
+"""CPU: the oracle's restatement of the reference training loop (oracle/train_oracle.py) against full-precision
+trajectories of the reference's OWN train.py (tests/golden/train_traj_*.npz): per-step loss,
+per-interval log means, valid loss of every epoch, which epochs halved the LR, parameters after every epoch,
+test loss."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+TAGS = ["lstm_none", "tlm_none", "lstm_bayes5", "tlm_gauss3", "lstm_gauss33", "lstm_var00"]
+
+
+def load_traj(tag):
+    z = np.load(os.path.join(GOLDEN, "train_traj_%s.npz" % tag), allow_pickle=False)
+    argv = [str(a) for a in z["argv"]]
+    args = {}
+    i = 0
+    while i < len(argv):
+        k = argv[i].lstrip("-").replace("-", "_")
+        if i + 1 < len(argv) and not argv[i + 1].startswith("--"):
+            args[k] = argv[i + 1]
+            i += 2
+        else:
+            args[k] = True
+            i += 1
+    init = {k[5:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith("init/")}
+    nsnap = 1 + max(int(k[4:].split("/")[0]) for k in z.files if k.startswith("snap"))
+    snaps = [{k.split("/", 1)[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith("snap%d/" % s)}
+             for s in range(nsnap)]
+    return z, args, init, snaps
+
+
+def write_corpus(z, d):
+    with open(os.path.join(d, "words.txt"), "w") as f:
+        for i, w in enumerate(z["words"]):
+            f.write("%s %d\n" % (w, i))
+    for split in ("train", "valid", "test"):
+        with open(os.path.join(d, split + ".txt"), "w") as f:
+            f.write(str(z[split + "_txt"]))
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_oracle_training_loop_matches_reference_train_py(tag, tmp_path):
+    from bayeslms_amd import data as D
+    from oracle import bayes_oracle as O, train_oracle as TO
+    z, args, init, snaps = load_traj(tag)
+    write_corpus(z, str(tmp_path))
+    corpus = D.Corpus(str(tmp_path))
+    bsz, seq_len = int(args["batch_size"]), int(args["seq_len"])
+    train = TO.batchify(corpus.train, bsz)
+    assert len(train) == int(z["rows"])
+    valid, test = TO.batchify(corpus.valid, 20), TO.batchify(corpus.test, 20)  # eval_batch_size, train.py:182
+    sd = dict(init)
+    sd["decoder.weight"] = sd["encoder.weight"]  # --tied
+    if args["model"] == "Transformer":
+        sd["pos_encoder.pe"] = O.positional_table(5000, int(args["emsize"]))
+    fwd, kl, is_rnn = TO.family(args)
+    torch.set_num_threads(1)
+    r = TO.train_run(sd, fwd, kl, is_rnn, train, valid, test, seq_len=seq_len, lr=float(args["lr"]),
+                     clip=float(args["clip"]), epochs=int(args["epochs"]), log_interval=int(args["log_interval"]),
+                     nlayers=int(args["nlayers"]), nhid=int(args["nhid"]))
+    ref_step = z["step_loss"]
+    got = np.array(r["step_loss"])
+    assert got.shape == ref_step.shape
+    assert np.abs(got[:20] - ref_step[:20]).max() <= 2e-5 * np.abs(ref_step[:20]).max()
+    assert np.abs(got - ref_step).max() <= 1e-3 * np.abs(ref_step).max()
+    assert np.allclose(r["interval_loss"], z["interval_loss"], rtol=1e-3)
+    assert list(r["halved_epochs"]) == list(z["halved_epochs"])
+    assert np.allclose(r["sgd_lr"], z["sgd_lr"]) and r["final_lr"] == float(z["final_lr"])
+    assert np.allclose(r["valid_loss"], z["valid_loss"], rtol=1e-4)
+    assert abs(r["test_loss"] - float(z["test_loss"])) <= 1e-4 * float(z["test_loss"])
+    assert len(r["snapshots"]) == len(snaps)
+    for mine, ref in zip(r["snapshots"], snaps):
+        for k, v in mine.items():
+            scale = float(ref[k].abs().max()) + 1e-12
+            assert float((v - ref[k]).abs().max()) <= 1e-3 * scale, k
