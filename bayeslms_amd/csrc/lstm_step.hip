@@ -18,6 +18,8 @@
 // Per step and workgroup: 128 KB of h and 128 KB of W_hh (L2/MALL resident across steps), 128 MFMA
 // per wave.  H % 32 == 0 and 16-byte aligned operands are required (blm_lstm_step_fwd returns
 // BLM_ERR_UNSUPPORTED otherwise and the host uses blm_gemm + blm_lstm_cell_fwd).
+#include <cstdlib>
+
 #include "blm_device.h"
 #include "blm_host.h"
 
@@ -27,7 +29,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int LSTR = 68;                  // staged tile row stride (floats): 64 k + 4 pad
 constexpr int TILE = 32 * LSTR;           // one 32-row operand tile
-constexpr int WAVE_LDS = 2 * 2 * TILE;    // 2 buffers x (h tile + W tile)
+constexpr int WAVE_LDS = 2 * TILE;        // h tile + W tile
 constexpr int RSTR = 40;                  // reduction row stride
 
 struct LstmStepP {
@@ -40,34 +42,50 @@ struct LstmStepP {
   const float* rbias;   //   the mixture (coef (4,4H), z (B,4H)) before it is added to xw (model.py:1744-1752)
   int B, H;
   const float* probs;   // NS = 8 (architecture-search cell, model_search_bayes.py:686-710): (4,2) mixing weights on the device
+#ifdef BLM_LSTM_PROF
+  long long* prof;      // tools/lstm_step_prof.hip only: 8 wall-clock stamps (10 ns units) per wave
+  int alias;            // timing-only: 1 = every workgroup reads the W rows of unit block 0, 2 = also the h rows of batch row 0
+#endif
 };
+
+#ifdef BLM_LSTM_PROF
+#define LSTM_STAMP(i) do { if (lane == 0) stamps[i] = wall_clock64(); } while (0)
+#else
+#define LSTM_STAMP(i) do { } while (0)
+#endif
 
 // NS = number of gate streams per hidden unit: 4 (LSTM: i f g o) or 8 (search cell: i f g o | i' f' g' o', every
 // gate the probs-weighted mix of the two activations).  A workgroup owns 32 / NS units = 32 rows of the weight.
-template <int RING, int NS = 4>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_step_fwd_kernel(const LstmStepP p) {
+// RING = chunks of global loads in flight per wave (1, 2 or 4 register sets of 16 KB); REFILL = false when the whole
+// K run of a lane fits the ring (nchunk == RING: every load of the step is issued before the first wait, the launch ->
+// first-byte latency is paid once and the rest streams in under the MFMAs).
+// NW = waves per workgroup = K slices: 4 (one wave per SIMD, two staging buffers each) or 8 (two waves per SIMD with one
+// staging buffer each: while one wave of a SIMD stages its next chunk through LDS -- 16 ds_write_b128 + 16 ds_read_b128
+// that a single in-order wave cannot overlap with its own dependent MFMA chain -- the other one keeps the matrix pipe busy).
+template <int RING, int NS = 4, bool REFILL = true, int NW = 4>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_step_fwd_kernel(const LstmStepP p) {
   constexpr int U = 32 / NS;  // hidden units per workgroup
+  // ONE staging buffer per wave (LDS runs a wave's instructions in order and the fragments are in registers before the
+  // MFMAs start, so the next chunk may overwrite the tile): 70 KB per 4-wave workgroup and <= 256 VGPRs per wave, i.e. TWO
+  // workgroups fit a CU -- the step kernels of two independent recurrences (the layers of a stack, run as a wavefront on
+  // two streams) overlap each other's launch gaps and load latencies.
+  constexpr int NBUF = 1;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   const int j0 = blockIdx.x * U, b0 = blockIdx.y * 32;
   const int H = p.H, B = p.B;
-  const int Kw = H >> 2, Kh = Kw >> 1, kbase = wave * Kw;
+  const int Kw = H / NW, Kh = Kw >> 1, kbase = wave * Kw;
   const int nchunk = (Kh + 31) >> 5;
-  float* base = sm + wave * WAVE_LDS;
+  float* base = sm + wave * (NBUF * 2 * TILE);
+#ifdef BLM_LSTM_PROF
+  long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  LSTM_STAMP(0);
 
-  // epilogue operands first: their latency hides behind the whole K loop
   const int brow = threadIdx.x / U, eu = threadIdx.x % U;
   const int eb = b0 + brow, ej = j0 + eu;
   const bool eok = eb < B && brow < 32;
   float xg[NS], cprev = 0.f;
-#pragma unroll
-  for (int g = 0; g < NS; ++g) xg[g] = 0.f;
-  if (eok) {
-    const long o = (long)eb * NS * H + ej;
-#pragma unroll
-    for (int g = 0; g < NS; ++g) xg[g] = p.xw[o + (long)g * H];
-    cprev = p.cprev[(long)eb * H + ej];
-  }
 
   // staging roles: one instruction moves 4 rows x 2 halves x 128 B
   const int srow = lane >> 4, shalf = (lane >> 3) & 1, spart = lane & 7;
@@ -76,15 +94,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int row = 4 * q + srow;
+#ifdef BLM_LSTM_PROF
+    arow[q] = p.hprev + (long)(p.alias >= 2 ? 0 : min(b0 + row, B - 1)) * H + kbase + shalf * Kh + 4 * spart;
+    wrow[q] = p.whh + ((long)(row / U) * H + (p.alias >= 1 ? 0 : j0) + (row % U)) * H + kbase + shalf * Kh + 4 * spart;
+#else
     arow[q] = p.hprev + (long)min(b0 + row, B - 1) * H + kbase + shalf * Kh + 4 * spart;
     wrow[q] = p.whh + ((long)(row / U) * H + j0 + (row % U)) * H + kbase + shalf * Kh + 4 * spart;
+#endif
   }
   const int soff = srow * LSTR + shalf * 32 + 4 * spart;
   // register ring of RING chunks: with one wave per SIMD the only way to cover the L2/MALL latency is
   // to keep RING x 16 KB per wave of loads in flight while the matrix core works on a chunk.  The loop
   // body is branch free (tail lanes and the refill past the last chunk read a clamped, valid address)
   // so that the s_waitcnt in front of each put() only waits for ITS chunk.
-  float4 ra0[8], rw0[8], ra1[8], rw1[8];
+  float4 ra[RING][8], rw[RING][8];
   auto fetch = [&](float4 (&a)[8], float4 (&w)[8], int c) {
     const int off = min(32 * min(c, nchunk - 1) + 4 * spart, Kh - 4) - 4 * spart;
 #pragma unroll
@@ -104,7 +127,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       *reinterpret_cast<float4*>(d + 4 * q * LSTR) = make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
       *reinterpret_cast<float4*>(d + TILE + 4 * q * LSTR) = make_float4(in ? y.x : 0.f, in ? y.y : 0.f, in ? y.z : 0.f, in ? y.w : 0.f);
     }
-    fetch(a, w, c + RING);
+    if (c == 0) {  // the first chunk's bytes have landed (its LDS writes are issued)
+      LSTM_STAMP(1);
+#ifdef BLM_LSTM_PROF
+      if (lane == 0) stamps[6] = clock64();
+#endif
+    }
+    if constexpr (REFILL) fetch(a, w, c + RING);
     // the tiles are wave private: LDS executes a wave's instructions in order, so the reads below see
     // the writes above without a workgroup barrier; the fence only pins the compiler's order
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -126,23 +155,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __builtin_amdgcn_wave_barrier();
   };
-  fetch(ra0, rw0, 0);
-  if (RING == 2) fetch(ra1, rw1, 1);
+#pragma unroll
+  for (int r = 0; r < RING; ++r) fetch(ra[r], rw[r], r);
+  // epilogue operands AFTER the ring's first loads: vmcnt retires in order, so anything issued before chunk 0 would be
+  // waited for with it, and xw_t / c_{t-1} are first-touch lines (HBM latency) while h and W_hh come from L2.  Issued
+  // here their latency hides behind the whole K loop.
+#pragma unroll
+  for (int g = 0; g < NS; ++g) xg[g] = 0.f;
+  if (eok) {
+    const long o = (long)eb * NS * H + ej;
+#pragma unroll
+    for (int g = 0; g < NS; ++g) xg[g] = p.xw[o + (long)g * H];
+    cprev = p.cprev[(long)eb * H + ej];
+  }
+  if constexpr (REFILL) {
 #pragma unroll 1
-  for (int cc = 0; cc < nchunk; cc += RING) {  // nchunk % RING == 0 (host picks RING)
-    chunk(ra0, rw0, 0, cc);
-    if (RING == 2) chunk(ra1, rw1, 1, cc + 1);
+    for (int cc = 0; cc < nchunk; cc += RING) {  // nchunk % RING == 0 (host picks RING)
+#pragma unroll
+      for (int r = 0; r < RING; ++r) chunk(ra[r], rw[r], r & (NBUF - 1), cc + r);
+    }
+  } else {  // nchunk == RING
+#pragma unroll
+    for (int r = 0; r < RING; ++r) chunk(ra[r], rw[r], r & (NBUF - 1), r);
   }
 
-  // cross-wave reduction of the four K quarters: red[wave][batch row][gate row]
+  // cross-wave reduction of the NW K slices: red[wave][batch row][gate row]
+  LSTM_STAMP(2);
+#ifdef BLM_LSTM_PROF
+  if (lane == 0) stamps[7] = clock64();
+#endif
   __syncthreads();  // every wave is done with its staging tiles: the reduction buffer overlays them
-  float* red = sm;  // 4 x 32 x RSTR floats = 20 KB
+  LSTM_STAMP(3);
+  float* red = sm;  // NW x 32 x RSTR floats = 20 / 40 KB
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
     red[(wave * 32 + row) * RSTR + li] = acc[r];
   }
   __syncthreads();
+  LSTM_STAMP(4);
+#ifdef BLM_LSTM_PROF
+  struct ProfTail {
+    const LstmStepP& p; long long* st; int wave, lane;
+    __device__ ~ProfTail() {
+      if (p.prof && lane == 0) {
+        st[5] = wall_clock64();
+        long long* o = p.prof + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = st[i];
+      }
+    }
+  } prof_tail{p, stamps, wave, lane};
+#endif
   if (eok) {
     float hw[NS];
 #pragma unroll
@@ -150,6 +213,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int n = g * U + eu;
       hw[g] = (red[(0 * 32 + brow) * RSTR + n] + red[(1 * 32 + brow) * RSTR + n]) +
               (red[(2 * 32 + brow) * RSTR + n] + red[(3 * 32 + brow) * RSTR + n]);
+      if constexpr (NW == 8)
+        hw[g] += (red[(4 * 32 + brow) * RSTR + n] + red[(5 * 32 + brow) * RSTR + n]) +
+                 (red[(6 * 32 + brow) * RSTR + n] + red[(7 * 32 + brow) * RSTR + n]);
     }
     const long i = (long)eb * H + ej, o = (long)eb * NS * H + ej;
     if constexpr (NS == 8) {  // search cell: eight activations, four probs-weighted mixes (search.hip search_cell_fwd_kernel)
@@ -218,7 +284,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int BSTR = 152;                 // staged row stride (floats)
 constexpr int BQ = 36;                    // quarter offset inside a row
 constexpr int BTILE = 16 * BSTR;
-constexpr int BWAVE_LDS = 2 * 2 * BTILE;  // 2 buffers x (dgates tile + W^T tile)
+constexpr int BWAVE_LDS = 2 * BTILE;      // dgates tile + W^T tile
 constexpr int BRSTR = 20;                 // reduction row stride
 
 struct LstmBwdP {
@@ -233,51 +299,26 @@ struct LstmBwdP {
   int G;                                  // contraction length = row length of dg and wt: 4H (LSTM), 8H (search cell)
 };
 
-template <int RING>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_step_bwd_kernel(const LstmBwdP p) {
+template <int RING, bool REFILL = true, int NW = 4>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_step_bwd_kernel(const LstmBwdP p) {
+  constexpr int NBUF = 1;  // see the forward kernel; NW = 8 (two waves per SIMD): plain / GP cells only
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
   const int k0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
   const int H = p.H, B = p.B;
   const long G = p.G, G4 = 4L * H;       // G4: row length of the cell arrays (ga, dg_out, zprev of mode 4)
-  const int Kw = p.G >> 2;                // contraction run of one wave
+  const int Kw = p.G / NW;                // contraction run of one wave
   const int Kq = Kw >> 2;                 // ... and of one lane quarter
   const int nchunk = (Kq + 31) >> 5;
-  float* base = sm + wave * BWAVE_LDS;
+  float* base = sm + wave * (NBUF * 2 * BTILE);
 
-  // epilogue operands first
+  // epilogue roles (their operand loads are issued behind the first ring fetch)
   const int brow = threadIdx.x >> 4, ecol = threadIdx.x & 15;
   const int eb = b0 + brow, ek = k0 + ecol;
-  const bool eok = eb < B;
+  const bool eok = eb < B && brow < 16;
   const long ei = (long)eb * H + ek, eo = (long)eb * G4 + ek;
   float e_dy = 0.f, e_dcn = 0.f, e_cp = 0.f, e_c = 0.f, e_z = 0.f, e_g[4] = {0.f, 0.f, 0.f, 0.f}, e_z4[4] = {0.f, 0.f, 0.f, 0.f};
-  if (eok && p.dg_out) {
-    if (p.dy) e_dy = p.dy[ei];
-    if (p.dc_next) e_dcn = p.dc_next[ei];
-    e_cp = p.cprev[ei];
-    e_c = p.c[ei];
-    if (p.ovr >= 0 && p.ovr < 4) e_z = p.zprev[ei];
-    if (p.ovr == 4) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) e_z4[g] = p.zprev[eo + (long)g * H];
-    }
-    if (p.ovr != 8) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) e_g[g] = p.ga[eo + (long)g * H];
-    }
-  }
-  // ovr == 8: the architecture-search cell (search.hip search_cell_bwd_kernel) fused behind the product: ga / dg_out
-  // have 8H-float rows [i f g o | i' f' g' o'], coef = the (4,2) mixing weights, dact_out = per-block partials of their gradient
   float e_a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, e_p8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (p.ovr == 8) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) e_p8[k] = p.coef[k];
-    if (eok) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) e_a8[k] = p.ga[(long)eb * 8 * H + ek + (long)k * H];
-    }
-  }
-
   // staging roles: one instruction moves 2 rows x 4 quarters x 128 B
   const int srow = lane >> 5, squart = (lane >> 3) & 3, spart = lane & 7;
   const float* arow[8];
@@ -289,7 +330,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     wrow[q] = p.wt + (long)(k0 + row) * G + (long)wave * Kw + squart * Kq + 4 * spart;
   }
   const int soff = srow * BSTR + squart * BQ + 4 * spart;
-  float4 ra0[8], rw0[8], ra1[8], rw1[8];
+  float4 ra[RING][8], rw[RING][8];
   auto fetch = [&](float4 (&a)[8], float4 (&w)[8], int c) {
     const int off = min(32 * min(c, nchunk - 1) + 4 * spart, Kq - 4) - 4 * spart;
 #pragma unroll
@@ -308,7 +349,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       *reinterpret_cast<float4*>(d + 2 * q * BSTR) = make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
       *reinterpret_cast<float4*>(d + BTILE + 2 * q * BSTR) = make_float4(in ? y.x : 0.f, in ? y.y : 0.f, in ? y.z : 0.f, in ? y.w : 0.f);
     }
-    fetch(a, w, c + RING);
+    if constexpr (REFILL) fetch(a, w, c + RING);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // wave-private tiles, in-order LDS: see the forward kernel
     __builtin_amdgcn_wave_barrier();
     const float* at = base + buf * 2 * BTILE + li * BSTR + lq * BQ;
@@ -328,16 +369,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __builtin_amdgcn_wave_barrier();
   };
-  fetch(ra0, rw0, 0);
-  if (RING == 2) fetch(ra1, rw1, 1);
+#pragma unroll
+  for (int r = 0; r < RING; ++r) fetch(ra[r], rw[r], r);
+  // epilogue operands behind the ring's first loads (in-order vmcnt: see the forward kernel)
+  if (eok && p.dg_out) {
+    if (p.dy) e_dy = p.dy[ei];
+    if (p.dc_next) e_dcn = p.dc_next[ei];
+    e_cp = p.cprev[ei];
+    e_c = p.c[ei];
+    if (p.ovr >= 0 && p.ovr < 4) e_z = p.zprev[ei];
+    if (p.ovr == 4) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) e_z4[g] = p.zprev[eo + (long)g * H];
+    }
+    if (p.ovr != 8) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) e_g[g] = p.ga[eo + (long)g * H];
+    }
+  }
+  // ovr == 8: the architecture-search cell (search.hip search_cell_bwd_kernel) fused behind the product: ga / dg_out
+  // have 8H-float rows [i f g o | i' f' g' o'], coef = the (4,2) mixing weights, dact_out = per-block partials of their gradient
+  if (p.ovr == 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e_p8[k] = p.coef[k];
+    if (eok) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e_a8[k] = p.ga[(long)eb * 8 * H + ek + (long)k * H];
+    }
+  }
+
+  if constexpr (REFILL) {
 #pragma unroll 1
-  for (int cc = 0; cc < nchunk; cc += RING) {
-    chunk(ra0, rw0, 0, cc);
-    if (RING == 2) chunk(ra1, rw1, 1, cc + 1);
+    for (int cc = 0; cc < nchunk; cc += RING) {
+#pragma unroll
+      for (int r = 0; r < RING; ++r) chunk(ra[r], rw[r], r & (NBUF - 1), cc + r);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RING; ++r) chunk(ra[r], rw[r], r & (NBUF - 1), r);
   }
 
   __syncthreads();
-  float* red = sm;  // 4 x 16 x BRSTR floats, overlays the staging tiles
+  float* red = sm;  // NW x 16 x BRSTR floats, overlays the staging tiles
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * lq + r) * BRSTR + li] = acc[r];
   __syncthreads();
@@ -376,8 +449,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     return;
   }
   if (!eok) return;
-  const float dh = (red[(0 * 16 + brow) * BRSTR + ecol] + red[(1 * 16 + brow) * BRSTR + ecol]) +
-                   (red[(2 * 16 + brow) * BRSTR + ecol] + red[(3 * 16 + brow) * BRSTR + ecol]);
+  float dh = (red[(0 * 16 + brow) * BRSTR + ecol] + red[(1 * 16 + brow) * BRSTR + ecol]) +
+             (red[(2 * 16 + brow) * BRSTR + ecol] + red[(3 * 16 + brow) * BRSTR + ecol]);
+  if constexpr (NW == 8)
+    dh += (red[(4 * 16 + brow) * BRSTR + ecol] + red[(5 * 16 + brow) * BRSTR + ecol]) +
+          (red[(6 * 16 + brow) * BRSTR + ecol] + red[(7 * 16 + brow) * BRSTR + ecol]);
   if (p.dh_out) p.dh_out[ei] = dh;
   if (p.dg_out) {  // cell backward of the step that produced h_{t-1} (elementwise.hip lstm_cell_bwd_kernel)
     const float gi = e_g[0], gf = e_g[1], gg = e_g[2], go = e_g[3];
@@ -427,6 +503,15 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 using namespace blm;
 
+static int lstm_waves() {  // BLM_LSTM_WAVES=4|8 (A/B measurements)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("BLM_LSTM_WAVES");
+    v = e ? atoi(e) : 4;
+  }
+  return v;
+}
+
 extern "C" int blm_lstm_step_fwd_gp(const float*, const float*, const float*, const float*, float*, float*, float*, const float*, int,
                                     const float*, const float*, float*, int, int, void*);
 extern "C" int blm_lstm_step_bwd_gp(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
@@ -449,18 +534,28 @@ extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const 
   if (H % 32 != 0 || !al16(w_hh) || !al16(h_prev))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_fwd: needs H % 32 == 0 and 16-byte aligned h_prev / w_hh");
   LstmStepP p{xw_t, w_hh, h_prev, c_prev, h, c, gates_act, h_noise, coef4, z_out, gate_ovr < 0 ? -1 : gate_ovr, rbias, B, H, nullptr};
-  const size_t lds = (size_t)4 * WAVE_LDS * sizeof(float);
+  const size_t lds4 = (size_t)4 * WAVE_LDS * sizeof(float), lds8 = 2 * lds4;
   static bool once = false;
   if (!once) {
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<1, 4, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
     once = true;
   }
   const int nchunk = (H / 8 + 31) / 32;  // 32-k chunks per lane half of a wave's K quarter
   const dim3 grid(H / 8, (B + 31) / 32), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (nchunk % 2 == 0) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4>), grid, block, lds, st, p);
-  else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 4>), grid, block, lds, st, p);
+  if (H % 64 == 0 && lstm_waves() == 8) {  // two waves per SIMD, K in eighths; one workgroup per CU
+    const int nc8 = (H / 16 + 31) / 32;
+    if (nc8 == 2) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, false, 8>), grid, dim3(512), lds8, st, p);
+    else if (nc8 % 2 == 0) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, true, 8>), grid, dim3(512), lds8, st, p);
+    else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 4, true, 8>), grid, dim3(512), lds8, st, p);
+  } else if (nchunk == 2) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, false>), grid, block, lds4, st, p);
+  else if (nchunk % 2 == 0) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4>), grid, block, lds4, st, p);
+  else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 4>), grid, block, lds4, st, p);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }
@@ -511,18 +606,24 @@ extern "C" int blm_transpose(const float* in, float* out, int rows, int cols, vo
 }
 
 static int launch_step_bwd(const LstmBwdP& p, void* stream) {
-  const size_t lds = (size_t)4 * BWAVE_LDS * sizeof(float);
+  const size_t lds4 = (size_t)4 * BWAVE_LDS * sizeof(float), lds8 = 2 * lds4;
   static bool once = false;
   if (!once) {
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((lstm_step_bwd_kernel<2, true, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((lstm_step_bwd_kernel<1, true, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
     once = true;
   }
   const int nchunk = (p.G / 16 + 31) / 32;  // 32-k chunks per lane quarter of a wave's contraction run
   const dim3 grid(p.H / 16, (p.B + 15) / 16), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (nchunk % 2 == 0) hipLaunchKernelGGL(lstm_step_bwd_kernel<2>, grid, block, lds, st, p);
-  else hipLaunchKernelGGL(lstm_step_bwd_kernel<1>, grid, block, lds, st, p);
+  if (p.G % 128 == 0 && p.ovr != 8 && lstm_waves() == 8) {
+    const int nc8 = (p.G / 32 + 31) / 32;
+    if (nc8 % 2 == 0) hipLaunchKernelGGL((lstm_step_bwd_kernel<2, true, 8>), grid, dim3(512), lds8, st, p);
+    else hipLaunchKernelGGL((lstm_step_bwd_kernel<1, true, 8>), grid, dim3(512), lds8, st, p);
+  } else if (nchunk % 2 == 0) hipLaunchKernelGGL(lstm_step_bwd_kernel<2>, grid, block, lds4, st, p);
+  else hipLaunchKernelGGL(lstm_step_bwd_kernel<1>, grid, block, lds4, st, p);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }
