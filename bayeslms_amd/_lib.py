@@ -17,8 +17,8 @@ ERR_INVALID, ERR_ABI, ERR_HIP, ERR_UNSUPPORTED = -1, -2, -3, -4  # blm_status (i
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_MUL_DGELU, EPI_BAYES_WGRAD, EPI_GP_MIX, EPI_MUL_DGP_MIX = range(7)
 GEMM_ACCUMULATE = 1
-STREAM_WEIGHT = 0x1000
-STREAM_DROPOUT = 0x2000
+STREAM_WEIGHT = 0x10000000   # stream class in the top 4 bits, tensor / site id in the low 28: the classes cannot alias
+STREAM_DROPOUT = 0x20000000
 
 c_fp = C.POINTER(C.c_float)
 c_i64p = C.POINTER(C.c_int64)
@@ -166,6 +166,9 @@ def dev_tensor(t, name="tensor", dtype=torch.float32):
     """Product-path guard: fp32 (or int64) contiguous tensor on the GPU."""
     if not t.is_cuda:
         raise BayesLMError("%s must live on the GPU: bayeslms_amd has no CPU path" % name)
+    if _dev_index is not None and t.device.index != _dev_index:
+        raise BayesLMError("%s lives on cuda:%d but this process launches on cuda:%d (one process per GPU: call "
+                           "torch.cuda.set_device before the first kernel)" % (name, t.device.index, _dev_index))
     if t.dtype != dtype:
         raise BayesLMError("%s must be %s, got %s" % (name, dtype, t.dtype))
     return t if t.is_contiguous() else t.contiguous()

@@ -210,9 +210,11 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
     launch bound): Transformers carry no state; for LSTMs the carries depend on first hypotheses only, so they
     are computed first in one sequential pass and every column of a packed batch starts from its own carry.
 
-    mc_samples = S > 0 (new, default off; not in the reference, which scores with mean weights):
+    mc_samples = S > 0 (new, default off; not in the reference, which scores with mean weights, :225):
     S passes with the variational weights sampled (dropout off) and the sentence PROBABILITIES
-    averaged, score = -log(mean_s exp(-NLL_s))."""
+    averaged, score = -log(mean_s exp(-NLL_s)).  Sample s is ONE model for the whole n-best list: its
+    eps comes from Philox step s of every variational tensor's stream (seed, tensor id, step = s), so the scores do not
+    depend on how utterances are packed into batches; an LSTM's carried state stays the mean-weight one."""
     model.eval()
     if model_2 is not None:
         model_2.eval()
@@ -225,11 +227,9 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
         model.train()
         model.noise_state.dropout_off = True
         model.set_seed(seed)
-    step = 0
 
     def score_group(group, hidden, hidden_2):
         """group = [(key, hyps, pairs)]; one padded batch over all their hypotheses."""
-        nonlocal step
         pairs = [p for _, _, ps in group for p in ps]
         lens = [len(x) for x, _ in pairs]
         Tm, N = max(lens), len(pairs)
@@ -250,10 +250,9 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
                 h2N = tuple(torch.cat([hidden_2[u][i].expand(-1, c, -1) for u, c in enumerate(counts)], 1).contiguous()
                             for i in (0, 1))
         sent = []
-        for _ in range(S):
+        for smp in range(S):
             if mc_samples > 0:
-                model.set_step(step)
-                step += 1
+                model.set_step(smp)
             nll = _batch_nll(model, data, tgt.view(-1), model_type, hN, model_2, h2N, alpha)
             sent.append((nll * mask).sum(0))
         if S == 1:

@@ -76,6 +76,8 @@ def bind_state(model, state):
         if isinstance(m, _Site):
             m._state = state
             m._site_base = 16 * idx
+    if 16 * (idx + 1) >= (1 << 28):  # ids live in the low 28 bits of the Philox stream word (_lib.STREAM_*)
+        raise BayesLMError("model has too many modules for the noise-stream id field")
     return state
 
 

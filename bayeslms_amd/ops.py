@@ -763,6 +763,8 @@ class _CrossEntropy(torch.autograd.Function):
         L.require_gfx950()
         check(lib().blm_ce_fwd_bwd(ptr(logits), V, ptr(targets), ptr(nll), ptr(lse), ptr(loss),
                                    ptr(logits) if fuse else None, 1.0 / M, M, V, stream()), "blm_ce_fwd_bwd")
+        if fuse:  # the buffer now holds the gradient: any other autograd consumer of the logits must fail, not read it
+            torch.autograd.graph.increment_version(logits)
         ctx.meta = (logits, targets, lse, fuse, M, V)
         ctx.mark_non_differentiable(nll)
         return loss / M, nll
@@ -775,11 +777,16 @@ class _CrossEntropy(torch.autograd.Function):
         g = _f32(g.reshape(1), "g")
         check(lib().blm_ce_bwd(ptr(logits), V, ptr(targets), ptr(lse), ptr(g), 1.0 / M, ptr(logits), M, V, stream()),
               "blm_ce_bwd")
+        torch.autograd.graph.increment_version(logits)
         return logits, None, None
 
 
 def cross_entropy(logits, targets, unit_grad=False):
-    """-> (mean NLL, per-token NLL).  In grad mode the logits buffer is consumed by the gradient."""
+    """-> (mean NLL, per-token NLL).  In grad mode the logits buffer is CONSUMED: it is overwritten with the gradient
+    (its version counter is bumped, so another autograd use of the same tensor raises instead of reading gradients;
+    read anything else you need from the logits BEFORE calling this).  ``unit_grad=True`` is the trainers' contract
+    only: the loss enters the objective with coefficient exactly 1 (train.py:412) and the upstream gradient is not
+    looked at."""
     return _CrossEntropy.apply(logits, targets, unit_grad)
 
 

@@ -38,8 +38,8 @@ typedef enum blm_status {
 
 /* Philox4x32-10 stream ids: counter = (block_lo, block_hi, stream, step),
  * key = seed.  Must match oracle/philox.py. */
-#define BLM_STREAM_WEIGHT  0x1000u  /* + tensor id */
-#define BLM_STREAM_DROPOUT 0x2000u  /* + site id   */
+#define BLM_STREAM_WEIGHT  0x10000000u  /* class in the top 4 bits + tensor id (low 28 bits) */
+#define BLM_STREAM_DROPOUT 0x20000000u  /* + site id */
 
 typedef struct blm_rng {
   uint64_t seed;    /* Philox key                                             */

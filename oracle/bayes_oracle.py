@@ -462,3 +462,53 @@ def variational_rnn_lm(x, hidden, sd, v_pos, eps=None):
             lg = sd[pre + "vnn.hidden_lgstd"]
             kl = kl + torch.mean(hm ** 2 - lg * 2.0 + torch.exp(hm * 2) - 1) / 2.0
     return F.linear(y, sd["decoder.weight"], sd["decoder.bias"]), (torch.stack(hs), torch.stack(cs)), kl
+
+
+# ----------------------------------------------------------------------------
+# Monte-Carlo weight-sample scoring (BASELINE.json configs[4]; NOT in the reference, which scores with mean
+# weights, compute_sentence_scores_bayes_jianwei.py:225 -- SURVEY.md 8(e) defines it: S forward passes with the
+# variational weights sampled, dropout off, sentence PROBABILITIES averaged)
+# ----------------------------------------------------------------------------
+def mc_sentence_score(nll_samples):
+    """nll_samples: (S,) sentence NLLs (sum of token NLL) under S weight samples -> -log(mean_s exp(-NLL_s))."""
+    v = torch.as_tensor(nll_samples, dtype=torch.float64)
+    return float(-(torch.logsumexp(-v, 0) - math.log(v.numel())))
+
+
+def mc_scores(nbest, vocab, sd, family, S, seed, tensor_ids, nhead=4, pos=3, get_input_and_target=None):
+    """Oracle of compute_scores_batched(mc_samples=S).  ``family``: "tlm_ffn" (eps of layer-0 linear2) or "lstm_bayes"
+    (the 8 tensors in LSTM_EPS_ORDER).  ``tensor_ids``: Philox tensor id of each variational tensor (the engine's
+    module numbering, host-side information); sample s uses philox.normal(n, seed, STREAM_WEIGHT + id, step = s).
+    LSTM: the state carried between utterances is the mean-weight state after the first hypothesis (:271-274).
+    -> [(key-n, score)]"""
+    from . import philox as P
+    is_rnn = family == "lstm_bayes"
+    eps = []
+    for smp in range(S):
+        if is_rnn:
+            eps.append([torch.from_numpy(P.normal(sd["rnn." + k].numel(), seed, P.STREAM_WEIGHT + tid, smp)).view_as(sd["rnn." + k])
+                        for k, tid in zip(LSTM_EPS_ORDER, tensor_ids)])
+        else:
+            w = sd["transformerlayers.0.linear2.weight_lgstd"]
+            eps.append(torch.from_numpy(P.normal(w.numel(), seed, P.STREAM_WEIGHT + tensor_ids[0], smp)).view_as(w))
+    out = []
+    H = sd["rnn.weight_hh_mean_1"].shape[1] if is_rnn else 0
+    hid = (torch.zeros(2, 1, H), torch.zeros(2, 1, H)) if is_rnn else None
+    for key, hyps in nbest.items():
+        first = None
+        for n, hyp in enumerate(hyps, 1):
+            x, t = get_input_and_target(hyp, vocab)
+            xs, ts = torch.tensor(x).view(-1, 1), torch.tensor(t)
+            nlls = []
+            for smp in range(S):
+                if is_rnn:
+                    logits, _ = bayes_rnn_lm(xs, hid, sd, pos, eps[smp])
+                else:
+                    logits = transformer_lm(xs, sd, nhead, eps[smp])
+                nlls.append(float(sentence_score(logits, ts)))
+            if is_rnn and first is None:
+                _, first = bayes_rnn_lm(xs, hid, sd, pos, None)
+            out.append(("%s-%d" % (key, n), mc_sentence_score(nlls)))
+        if is_rnn:
+            hid = first
+    return out

@@ -24,8 +24,8 @@ W1 = np.uint32(0xBB67AE85)
 MASK = np.uint64(0xFFFFFFFF)
 
 # stream ids (must match include/bayeslm.h BLM_STREAM_*)
-STREAM_WEIGHT = 0x1000   # + tensor_id
-STREAM_DROPOUT = 0x2000  # + site_id
+STREAM_WEIGHT = 0x10000000   # class in the top 4 bits + tensor_id (28 bits)
+STREAM_DROPOUT = 0x20000000  # + site_id
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):

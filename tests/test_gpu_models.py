@@ -340,10 +340,64 @@ def test_scorer_cli_matches_reference_output(dev, tag, tmp_path):
         assert [a[0] for a in got] == [b[0] for b in want]
         for a, b in zip(got, want):
             assert abs(float(a[1]) - float(b[1])) <= 1e-3 * max(1.0, abs(float(b[1]))), (batched, a, b)
-    # Monte-Carlo weight sampling (new option): finite, close to the mean-weight scores for small sigmas
+    # Monte-Carlo weight sampling through the CLI (oracle comparison: test_mc_sample_scoring_matches_oracle)
     S.main(argv + ["--mc-samples", "4"])
     mc = [float(ln.split()[1]) for ln in open(os.path.join(d, "out.txt")).read().splitlines()]
     assert len(mc) == len(want) and all(v == v and v >= 0 for v in mc)
+
+
+@pytest.mark.parametrize("tag", ["tlm_ffn", "lstm_bayes3"])
+def test_mc_sample_scoring_matches_oracle(dev, tag):
+    """BASELINE.json configs[4]: n-best scoring with S Monte-Carlo weight samples.  Not in the reference (it scores
+    with mean weights, :225); SURVEY 8(e) defines it.  Against the CPU oracle: sample s draws eps from Philox step s
+    of each variational tensor's stream, score = -log mean_s exp(-NLL_s); S = 8 to 1e-3.  With sigma -> 0 and S = 1
+    the scores are the reference scorer's own file.  The result must not depend on how utterances are batched."""
+    import collections
+    from bayeslms_amd import compute_sentence_scores as S, model as M
+    from oracle import bayes_oracle as O
+    g, sd, _ = load_golden("scorer_" + tag)
+    vocab = {w: i for i, w in enumerate(g["words"])}
+    V = len(vocab)
+    nbest = collections.OrderedDict()
+    for line in str(g["nbest_txt"]).splitlines():
+        parts = line.strip().split(' ', 1)
+        key, hyp = (parts[0], parts[1]) if len(parts) == 2 else (line.strip(), ' ')
+        nbest.setdefault(key.rsplit('-', 1)[0], []).append(hyp)
+    if tag == "tlm_ffn":
+        m = M.BayesTransformerModel(V, 16, 4, 32, 2, 0.5, True, "FFN")
+        fam, mtype = "tlm_ffn", "Transformer"
+        ids = [m.transformerlayers[0].linear2._site_base]
+    else:
+        m = M.BayesRNNModel("LSTM", V, 12, 12, 2, 0.5, True, 3)
+        fam, mtype = "lstm_bayes", "LSTM"
+        ids = [m.rnn._site_base + k for k in range(8)]
+    own = m.state_dict()
+    own.update({k: v for k, v in sd.items() if k in own and tuple(v.shape) == tuple(own[k].shape)})
+    m.load_state_dict(own)
+    m = m.to(dev)
+    osd = {k: v.clone() for k, v in sd.items()}
+    if fam == "tlm_ffn":
+        osd["pos_encoder.pe"] = O.positional_table(5000, 16)
+    seed, NS = 4242, 8
+    want = O.mc_scores(nbest, vocab, osd, fam, NS, seed, ids, get_input_and_target=S.get_input_and_target)
+    for batch_tokens in (8192, 16):  # everything in one packed batch / (almost) one utterance per batch
+        got = S.compute_scores_batched(nbest, m, vocab, mtype, dev, mc_samples=NS, seed=seed, batch_tokens=batch_tokens)
+        flat = [("%s-%d" % (k, n), v) for k, hv in got.items() for n, (_, v) in enumerate(hv, 1)]
+        assert [k for k, _ in flat] == [k for k, _ in want]
+        for (k, a), (_, b) in zip(flat, want):
+            assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (batch_tokens, k, a, b)
+    # the samples matter: S = 8 differs from the mean-weight scores of the reference file
+    ref = [float(ln.split()[1]) for ln in str(g["scores_txt"]).splitlines()]
+    assert any(abs(a - b) > 1e-4 for (_, a), b in zip(flat, ref))
+    # sigma -> 0, S = 1: exactly the mean-weight model = the reference scorer's file
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if "lgstd" in k:
+                p.fill_(-50.0)
+    got = S.compute_scores_batched(nbest, m, vocab, mtype, dev, mc_samples=1, seed=seed)
+    flat = [v for hv in got.values() for _, v in hv]
+    for a, b in zip(flat, ref):
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(b))
 
 
 @pytest.mark.parametrize("tag", ["tlm_ffn_interp", "lstm_bayes3_interp"])

@@ -364,3 +364,44 @@ def test_vtransformer_matches_reference(v_pos):
     torch.testing.assert_close(O.transformer_lm(g["src"], sd, int(g["nhead"]), None), g["logits_eval"], **TOL)
     nl = len({k.split(".")[1] for k in sd if k.startswith("transformerlayers.")})
     assert nl == {0: 4, 1: 4, 2: 3, 3: 3}[v_pos]  # the reference's layer-count arithmetic (model.py:2822-2843)
+
+
+def _nbest_of(g):
+    import collections
+    nbest = collections.OrderedDict()
+    for line in str(g["nbest_txt"]).splitlines():
+        parts = line.strip().split(' ', 1)
+        key, hyp = (parts[0], parts[1]) if len(parts) == 2 else (line.strip(), ' ')
+        nbest.setdefault(key.rsplit('-', 1)[0], []).append(hyp)
+    return nbest
+
+
+def test_mc_sentence_score_is_log_mean_exp():
+    import math
+    assert abs(O.mc_sentence_score([3.25]) - 3.25) < 1e-12                    # S = 1: the sample's NLL
+    assert abs(O.mc_sentence_score([2.0, 2.0, 2.0]) - 2.0) < 1e-12            # identical samples
+    want = -math.log((math.exp(-1.0) + math.exp(-2.0) + math.exp(-4.0)) / 3)  # probabilities averaged, not NLLs
+    assert abs(O.mc_sentence_score([1.0, 2.0, 4.0]) - want) < 1e-12
+    assert O.mc_sentence_score([1.0, 2.0, 4.0]) < (1.0 + 2.0 + 4.0) / 3       # Jensen
+
+
+@pytest.mark.parametrize("tag", ["tlm_ffn", "lstm_bayes3"])
+def test_mc_scoring_oracle_degenerates_to_reference_scores(tag):
+    """sigma -> 0 (log-sigma = -50): every weight sample IS the mean weight, so the Monte-Carlo oracle with any S
+    must reproduce the score file the reference scorer wrote; and with the fixture's real sigmas the S-sample score
+    differs from the mean-weight one but stays a proper log-mean-exp of its per-sample scores."""
+    from bayeslms_amd import compute_sentence_scores as S
+    g, sd, _ = load_golden("scorer_" + tag)
+    vocab = {w: i for i, w in enumerate(g["words"])}
+    want = [(ln.split()[0], float(ln.split()[1])) for ln in str(g["scores_txt"]).splitlines()]
+    fam = "lstm_bayes" if tag.startswith("lstm") else "tlm_ffn"
+    ids = list(range(8)) if fam == "lstm_bayes" else [0]
+    cold = {k: (torch.full_like(v, -50.0) if "lgstd" in k else v) for k, v in sd.items()}
+    got = O.mc_scores(_nbest_of(g), vocab, cold, fam, 3, 1111, ids, get_input_and_target=S.get_input_and_target)
+    assert [k for k, _ in got] == [k for k, _ in want]
+    for (_, a), (_, b) in zip(got, want):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b))
+    one = O.mc_scores(_nbest_of(g), vocab, sd, fam, 1, 1111, ids, get_input_and_target=S.get_input_and_target)
+    four = O.mc_scores(_nbest_of(g), vocab, sd, fam, 4, 1111, ids, get_input_and_target=S.get_input_and_target)
+    assert any(abs(a - b) > 1e-6 for (_, a), (_, b) in zip(one, want))  # the noise does reach the scores
+    assert all(v == v and v >= 0 for _, v in four)
