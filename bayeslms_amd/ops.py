@@ -904,8 +904,13 @@ class _LSTMLayer(torch.autograd.Function):
         # else skinny GEMM + cell kernel
         fused_step = H % 32 == 0 and w_hh.data_ptr() % 16 == 0 and hs.data_ptr() % 16 == 0 and w_hh.is_contiguous()
         if fused_step:  # the whole layer from one call: T launches issued by the library
+            ev = _TIMER.bracket("lstm_seq_fwd T=%d" % T) if _TIMER is not None else None
+            if ev:
+                ev[0].record()
             check(lib().blm_lstm_seq_fwd(ptr(xw), ptr(w_hh), ptr(hs), ptr(cs), ptr(ga), ptr(noise_rows), T, B, H, st),
                   "blm_lstm_seq_fwd")
+            if ev:
+                ev[1].record()
         else:
             hw = torch.empty(B, G, device=dev, dtype=torch.float32)
             for t in range(T):
@@ -946,6 +951,9 @@ class _LSTMLayer(torch.autograd.Function):
             # of step t-1 fused behind it (blm_lstm_step_bwd); W_hh is transposed once per layer
             w_t = torch.empty(H, G, device=dev, dtype=torch.float32)
             check(lib().blm_transpose(ptr(w_hh), ptr(w_t), G, H, st), "blm_transpose")
+            ev = _TIMER.bracket("lstm_seq_bwd T=%d" % T) if _TIMER is not None else None
+            if ev:
+                ev[0].record()
             check(lib().blm_lstm_cell_bwd2(ptr(dh), ptr(dy[T - 1]), ptr(dcs[0]), ptr(cs[T - 1]), ptr(cs[T]), ptr(ga[T - 1]),
                                            ptr(dgates[T - 1]), ptr(dcs[1]), B, H, st), "blm_lstm_cell_bwd2")
             k = 1
@@ -959,6 +967,8 @@ class _LSTMLayer(torch.autograd.Function):
             dh = torch.empty(B, H, device=dev, dtype=torch.float32)
             check(lib().blm_lstm_step_bwd(ptr(dgates[0]), ptr(w_t), None, None, None, None, None, None, None, ptr(dh),
                                           B, H, st), "blm_lstm_step_bwd")
+            if ev:
+                ev[1].record()
             dc = dcs[k]
         else:
             # recurrent dh of every step accumulates (split-K atomics) into one pre-zeroed buffer: a

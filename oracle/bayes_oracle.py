@@ -62,9 +62,10 @@ def causal_mask(T):
     return torch.triu(m, diagonal=1)
 
 
-def attention_core(q, k, v, nhead, mask):
+def attention_core(q, k, v, nhead, mask, drop_p=0.0):
     """q,k,v: (T,B,d) already projected.  Head index = b*nhead + head
-    (model.py:889-920).  Returns (T,B,d) before o_net."""
+    (model.py:889-920).  Returns (T,B,d) before o_net.  ``drop_p`` > 0: the reference's dropout on the attention
+    probabilities (:913), torch's generator -- only the CPU-baseline timing of bench.py turns it on."""
     T, B, d = q.shape
     hd = d // nhead
     q = q * (float(hd) ** -0.5)
@@ -75,11 +76,13 @@ def attention_core(q, k, v, nhead, mask):
     if mask is not None:
         s = s + mask.unsqueeze(0)
     p = torch.softmax(s, dim=-1)
+    if drop_p > 0.0:
+        p = F.dropout(p, drop_p, True)
     o = torch.bmm(p, v)
     return o.transpose(0, 1).contiguous().view(T, B, d)
 
 
-def mha(x, sd, pre, nhead, mask, eps=None):
+def mha(x, sd, pre, nhead, mask, eps=None, drop_p=0.0):
     """MultiheadAttention (fused qkv_net, model.py:871-928) or
     BayesMultiheadAttention (separate q/k/v nets, Bayesian o_net,
     model.py:971-1019), chosen by which keys exist under ``pre``."""
@@ -93,7 +96,7 @@ def mha(x, sd, pre, nhead, mask, eps=None):
         q = F.linear(x, sd[pre + "q_net.weight"], sd[pre + "q_net.bias"])
         k = F.linear(x, sd[pre + "k_net.weight"], sd[pre + "k_net.bias"])
         v = F.linear(x, sd[pre + "v_net.weight"], sd[pre + "v_net.bias"])
-    a = attention_core(q, k, v, nhead, mask)
+    a = attention_core(q, k, v, nhead, mask, drop_p)
     if pre + "o_net.weight_mean" in sd:
         return bayes_linear(a, sd[pre + "o_net.weight_mean"], sd[pre + "o_net.weight_lgstd"], eps)
     if pre + "out_proj.weight" in sd:
@@ -122,7 +125,7 @@ def gpnn2(x, sd, pre, eps=None, gelu=False):
     return F.linear(a / math.sqrt(fm.shape[1]), sd[pre + "coef.weight"], sd[pre + "coef.bias"])
 
 
-def encoder_layer(x, sd, pre, nhead, mask, eps=None):
+def encoder_layer(x, sd, pre, nhead, mask, eps=None, drop_p=0.0):
     """Post-LN block (model.py:1037-1046, 1162-1176, 2274-2295).  ``eps`` is the
     single draw this layer makes: for the FFN position it belongs to linear2,
     for the MHA position to o_net.  A layer with ``gpnn.*`` keys is the
@@ -130,8 +133,9 @@ def encoder_layer(x, sd, pre, nhead, mask, eps=None):
     train.py GPNN.sample stays False so its forward is deterministic."""
     d = x.shape[-1]
     att_eps = eps if pre + "self_attn.o_net.weight_mean" in sd else None
-    a = mha(x, sd, pre + "self_attn.", nhead, mask, att_eps)
-    x = F.layer_norm(x + a, (d,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])
+    dr = (lambda t: F.dropout(t, drop_p, True)) if drop_p > 0.0 else (lambda t: t)  # model.py:1041-1045 sites
+    a = mha(x, sd, pre + "self_attn.", nhead, mask, att_eps, drop_p)
+    x = F.layer_norm(x + dr(a), (d,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])
     if pre + "gpnn.weights_mean" in sd:
         z = F.linear(x, sd[pre + "gpnn.weights_mean"], sd[pre + "gpnn.bias_mean"])
         h = gp_mixture(z, sd[pre + "gpnn.coef_mean"], ["tanh", "sigmoid", "relu", "gelu"])
@@ -139,14 +143,15 @@ def encoder_layer(x, sd, pre, nhead, mask, eps=None):
         h = gpnn2(x, sd, pre + "gpnn.", eps, gelu=True)
     else:
         h = F.gelu(F.linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"]))
+    h = dr(h)
     if pre + "linear2.weight_mean" in sd:
         f = bayes_linear(h, sd[pre + "linear2.weight_mean"], sd[pre + "linear2.weight_lgstd"], eps)
     else:
         f = F.linear(h, sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
-    return F.layer_norm(x + f, (d,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])
+    return F.layer_norm(x + dr(f), (d,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])
 
 
-def transformer_lm(src, sd, nhead, eps=None):
+def transformer_lm(src, sd, nhead, eps=None, drop_p=0.0):
     """BayesTransformerModel / TransformerModel / GaussTransformerModel forward
     with dropout off (model.py:1274-1309, 159-171).  src (T,B) int64 -> logits
     (T,B,V).  ``eps``: the one N(0,1) draw of the Bayesian tensor (layer-0
@@ -157,13 +162,15 @@ def transformer_lm(src, sd, nhead, eps=None):
     if "embed_mean" in sd:  # 'EMB' (model.py:1286-1290)
         x = F.linear(x, sampled_weight(sd["embed_mean"], sd["embed_lgstd"], eps))
     x = x + sd["pos_encoder.pe"][:T]
+    if drop_p > 0.0:  # PositionalEncoding's dropout (model.py:116-117); parity paths run with drop_p = 0
+        x = F.dropout(x, drop_p, True)
     mask = causal_mask(T)
     # nn.TransformerEncoder keys are transformerlayers.layers.N.*, ours .N.*
     base = "transformerlayers.layers." if any(k.startswith("transformerlayers.layers.") for k in sd) \
         else "transformerlayers."
     i = 0
     while (base + "%d.norm1.weight" % i) in sd:
-        x = encoder_layer(x, sd, base + "%d." % i, nhead, mask, eps if i == 0 else None)
+        x = encoder_layer(x, sd, base + "%d." % i, nhead, mask, eps if i == 0 else None, drop_p)
         i += 1
     if "embed_mean" in sd:  # model.py:1302-1304 (mean weights, transposed)
         x = F.linear(x, sd["embed_mean"].t())
@@ -308,9 +315,9 @@ def clip_and_sgd(params, grads, bufs, lr, clip, momentum=0.9):
     return total
 
 
-def transformer_train_loss(src, targets, sd, nhead, bayes_pos, eps, kl_scale):
+def transformer_train_loss(src, targets, sd, nhead, bayes_pos, eps, kl_scale, drop_p=0.0):
     """loss = CE_mean + KL * seq_len/len(train_data) (train.py:332-412)."""
-    logits = transformer_lm(src, sd, nhead, eps)
+    logits = transformer_lm(src, sd, nhead, eps, drop_p)
     mle = cross_entropy_mean(logits, targets)
     kl = kl_transformer(sd, bayes_pos) * kl_scale
     return mle + kl, mle, kl

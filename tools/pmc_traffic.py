@@ -8,17 +8,33 @@ import csv
 import json
 import sys
 
-KERNEL = "void blm::gemm_f32_kernel<0, 2, 2, false, true>(blm::GemmP)"
+KERNEL = "void blm::gemm_f32_kernel<0, 2, 2, false, true"  # + the GEMM-mode parameter, prefix match
 GRID = "65536"
 
 
 def avg(path, counter):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-         if r["Kernel_Name"] == KERNEL and r["Grid_Size"] == GRID and r["Counter_Name"] == counter]
+         if r["Kernel_Name"].startswith(KERNEL) and r["Grid_Size"] == GRID and r["Counter_Name"] == counter]
     return sum(v) / len(v), len(v)
 
 
+def mfma_util(path, out):
+    """Third pass (SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE): matrix-pipe utilisation of the same launches."""
+    rows = [r for r in csv.DictReader(open(path)) if r["Kernel_Name"].startswith(KERNEL) and r["Grid_Size"] == GRID]
+    busy = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES"]
+    act = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == "GRBM_GUI_ACTIVE"]
+    b, a = sum(busy) / len(busy), sum(act) / len(act)
+    res = {"kernel": KERNEL + ", ...>", "grid_threads": int(GRID), "launches": len(busy), "SQ_VALU_MFMA_BUSY_CYCLES": b,
+           "GRBM_GUI_ACTIVE_sum_over_8_XCDs": a, "mfma_pipe_utilisation": b / ((a / 8) * 256 * 4),
+           "note": "utilisation = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE/8) * 256 CUs * 4 SIMDs); expected busy cycles for "
+                   "34.36 GFLOP at 64 cycles per v_mfma_f32_32x32x2_f32 = 5.369e+08"}
+    json.dump(res, open(out, "w"), indent=1)
+    print(res)
+
+
 def main():
+    if sys.argv[1] == "mfma":
+        return mfma_util(sys.argv[2], sys.argv[3])
     f, nf = avg(sys.argv[1], "FETCH_SIZE")
     w, nw = avg(sys.argv[2], "WRITE_SIZE")
     M, N, K = 8192, 512, 4096
