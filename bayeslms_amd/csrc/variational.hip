@@ -127,6 +127,36 @@ __global__ __launch_bounds__(TPB) void kl_fwd_kernel(const float* __restrict__ m
   if (threadIdx.x == 0) atomicAdd(out, t * scale);
 }
 
+// Contiguous case (ld == cols: the whole tensor, or a window of full rows): no index arithmetic, 16-byte loads, four
+// independent load pairs in flight per thread (the scalar kernel above spends its time in 64-bit divisions and one
+// dependent load per iteration: 16.8 MB took 24-32 us = 6-9 % of the HBM rate).
+__global__ __launch_bounds__(TPB) void kl_fwd_flat4_kernel(const float4* __restrict__ mu, const float4* __restrict__ lg, long n4,
+                                                           float minus, float scale, float* out) {
+  __shared__ float red[TPB / 64];
+  float acc = 0.f;
+  const long stride = (long)gridDim.x * TPB;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n4; i += 4 * stride) {
+    float4 m[4], l[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long j = i + u * stride;
+      const bool in = j < n4;
+      m[u] = in ? mu[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      l[u] = in ? lg[j] : make_float4(0.f, 0.f, 0.f, 0.f);  // exp(0)^2 - 2*0 + 0 - minus: corrected below
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i + u * stride < n4) {
+        const float s0 = __expf(l[u].x), s1 = __expf(l[u].y), s2 = __expf(l[u].z), s3 = __expf(l[u].w);
+        acc += (m[u].x * m[u].x - 2.f * l[u].x + s0 * s0 - minus) + (m[u].y * m[u].y - 2.f * l[u].y + s1 * s1 - minus) +
+               (m[u].z * m[u].z - 2.f * l[u].z + s2 * s2 - minus) + (m[u].w * m[u].w - 2.f * l[u].w + s3 * s3 - minus);
+      }
+    }
+  }
+  const float t = block_sum<TPB / 64>(acc, red);
+  if (threadIdx.x == 0) atomicAdd(out, t * scale);
+}
+
 __global__ __launch_bounds__(TPB) void kl_bwd_kernel(const float* __restrict__ mu, long ld, const float* __restrict__ lg,
                                                      long rows, long cols, const float* g_dev, float scale,
                                                      float* dmu, long ld_dmu, float* dlg) {
@@ -204,6 +234,15 @@ extern "C" int blm_kl_mean_fwd(const float* mu, int64_t ld_mu, const float* lgst
   // every block ends in ONE float atomic on the same address: 256 blocks (one per CU) instead of 2048 cut the
   // launch from 32 to a few microseconds (the atomics serialise in L2)
   const int kl_grid = grid_for(rows * cols) < 256 ? grid_for(rows * cols) : 256;
+  if (ld_mu == cols && (rows * cols) % 4 == 0 && al16(mu) && al16(lgstd)) {
+    const long n4 = rows * cols / 4;
+    const int g4 = grid_for(n4 / 4 + 1) < 512 ? grid_for(n4 / 4 + 1) : 512;
+    hipLaunchKernelGGL(kl_fwd_flat4_kernel, dim3(g4), dim3(TPB), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(mu), reinterpret_cast<const float4*>(lgstd), n4,
+                       minus_one ? 1.0f : 0.0f, scale, out);
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
+  }
   hipLaunchKernelGGL(kl_fwd_kernel, dim3(kl_grid), dim3(TPB), 0, static_cast<hipStream_t>(stream), mu,
                      (long)ld_mu, lgstd, (long)rows, (long)cols, minus_one ? 1.0f : 0.0f, scale, out);
   BLM_HIP(hipGetLastError());

@@ -162,8 +162,8 @@ class _ProjHolder(nn.Module):
         self.weight, self.bias = lin.weight, lin.bias
         self.in_features, self.out_features = in_f, out_f
 
-    def forward(self, x):
-        return ops.linear(x, self.weight, self.bias)
+    def forward(self, x, link=None):
+        return ops.linear(x, self.weight, self.bias, link)
 
 
 def _need_causal(attn_mask):
@@ -190,9 +190,9 @@ class MultiheadAttention(_Site):
         nn.init.constant_(self.qkv_net.bias, 0.)
         nn.init.constant_(self.o_net.bias, 0.)
 
-    def forward(self, query, key=None, value=None, key_padding_mask=None, need_weights=True, attn_mask=None):
+    def forward(self, query, key=None, value=None, key_padding_mask=None, need_weights=True, attn_mask=None, _link=None):
         _need_causal(attn_mask)
-        qkv = self.qkv_net(query)
+        qkv = self.qkv_net(query, _link)  # _link: ops.ResidualLink of the enclosing post-LN block (new, optional)
         a = ops.attention(qkv, self.num_heads, self._drop(self.dropout))
         return self.o_net(a), None
 
@@ -213,10 +213,12 @@ class BayesMultiheadAttention(_Site):
         self.v_net = _ProjHolder(embed_dim, embed_dim)
         self.o_net = BayesLinear(embed_dim, embed_dim)
 
-    def forward(self, query, key=None, value=None, key_padding_mask=None, need_weights=True, attn_mask=None):
+    def forward(self, query, key=None, value=None, key_padding_mask=None, need_weights=True, attn_mask=None, _link=None):
         _need_causal(attn_mask)
         key = query if key is None else key
         value = query if value is None else value
+        # three projections read the block input: its gradient has several producers, so the residual link (valid only
+        # when the linked op is the ONLY other consumer of x) is not used here
         a = ops.attention_qkv(self.q_net(query), self.k_net(key), self.v_net(value), self.num_heads,
                               self._drop(self.dropout))
         return self.o_net(a), None
@@ -233,15 +235,16 @@ class _PostLNLayer(_Site):
         self.p = dropout
 
     def forward(self, src, src_mask=None):
-        a = self.self_attn(src, src, src, attn_mask=src_mask)[0]
-        x = ops.add_dropout_ln(src, a, self.norm1.weight, self.norm1.bias, self.norm1.eps, self._drop(self.p, 1))
+        lk1, lk2 = ops.ResidualLink(), ops.ResidualLink()  # residual + branch gradients meet inside the dgrad GEMMs
+        a = self.self_attn(src, src, src, attn_mask=src_mask, _link=lk1)[0]
+        x = ops.add_dropout_ln(src, a, self.norm1.weight, self.norm1.bias, self.norm1.eps, self._drop(self.p, 1), lk1)
         l2 = self.linear2
         if isinstance(l2, BayesLinear):
             f = ops.ffn(x, self.linear1.weight, self.linear1.bias, l2.weight_mean, None, l2.weight_lgstd, l2.noise(),
-                        l2.fused_kl_lambda, self._st().fused, self._drop(self.p, 0))
+                        l2.fused_kl_lambda, self._st().fused, self._drop(self.p, 0), lk2)
         else:
-            f = ops.ffn(x, self.linear1.weight, self.linear1.bias, l2.weight, l2.bias, drop=self._drop(self.p, 0))
-        return ops.add_dropout_ln(x, f, self.norm2.weight, self.norm2.bias, self.norm2.eps, self._drop(self.p, 2))
+            f = ops.ffn(x, self.linear1.weight, self.linear1.bias, l2.weight, l2.bias, drop=self._drop(self.p, 0), link=lk2)
+        return ops.add_dropout_ln(x, f, self.norm2.weight, self.norm2.bias, self.norm2.eps, self._drop(self.p, 2), lk2)
 
 
 class StandardTransformerEncoderLayer(_PostLNLayer):
@@ -475,15 +478,17 @@ class GaussTransformerEncoderLayer(_Site):
         self.p = dropout
 
     def forward(self, src, src_mask=None):
-        a = self.self_attn(src, src, src, attn_mask=src_mask)[0]
-        x = ops.add_dropout_ln(src, a, self.norm1.weight, self.norm1.bias, self.norm1.eps, self._drop(self.p, 1))
+        lk1, lk2 = ops.ResidualLink(), ops.ResidualLink()
+        a = self.self_attn(src, src, src, attn_mask=src_mask, _link=lk1)[0]
+        x = ops.add_dropout_ln(src, a, self.norm1.weight, self.norm1.bias, self.norm1.eps, self._drop(self.p, 1), lk1)
         g = self.gpnn
         if self.gauss_pos == 4:  # GPNN2: 150 random features, then its own Linear to dim_feedforward
             f = self.linear2(ops.dropout(g(x), self._drop(self.p, 0)))
+            lk2 = None
         else:
             f = ops.ffn_gp(x, g.weights_mean, g.bias_mean, g.coef_mean, self.linear2.weight, self.linear2.bias,
-                           self._drop(self.p, 0))
-        return ops.add_dropout_ln(x, f, self.norm2.weight, self.norm2.bias, self.norm2.eps, self._drop(self.p, 2))
+                           self._drop(self.p, 0), lk2)
+        return ops.add_dropout_ln(x, f, self.norm2.weight, self.norm2.bias, self.norm2.eps, self._drop(self.p, 2), lk2)
 
 
 class GaussTransformerModel(_LMHead):

@@ -17,7 +17,7 @@ import torch
 from . import _lib as L
 from ._lib import BayesLMError, check, dev_tensor, lib, ptr, stream
 
-__all__ = ["Drop", "NoiseSpec", "linear", "bayes_linear", "ffn", "ffn_gp", "attention", "attention_qkv", "add_dropout_ln",
+__all__ = ["Drop", "NoiseSpec", "ResidualLink", "linear", "bayes_linear", "ffn", "ffn_gp", "attention", "attention_qkv", "add_dropout_ln",
            "embed", "add_pe", "dropout", "cross_entropy", "kl_mean", "philox_normal", "sample_weight", "sampled", "lstm_layer", "lstm_cell", "gp_mix", "add_rowvec",
            "clip_sgd", "gemm", "PtrTable", "set_grad_ready_hook", "set_embed_grad_sink", "rows_gather_add", "KernelTimer", "set_kernel_timer"]
 
@@ -140,6 +140,29 @@ class _P:
         return self.b + i * self.s
 
 
+class ResidualLink:
+    """Joins the two backward paths of a post-LN residual block  out = LN(x + drop(f(x)))  (model.py:1041-1045).
+    Autograd would add the residual path's gradient (from the LayerNorm backward) and the branch's input gradient
+    (the last dgrad GEMM of f) with a separate elementwise pass over (T,B,d) -- 12 launches per cfg3 step.  The
+    same ``link`` object is handed to ``add_dropout_ln(..., link=)`` and to the first op of the branch
+    (``linear`` / ``ffn`` / ``ffn_gp`` ``link=``): the LayerNorm backward (which always runs first: it consumes the
+    branch's output) parks its dx here, and the branch's dgrad GEMM ACCUMULATES into that buffer instead of
+    producing a second tensor (stream order keeps this safe: every earlier use of the buffer is already enqueued).
+    Explicit per-block objects, no global matching.  Contract: the linked op is the ONLY consumer of x besides the
+    LayerNorm residual (with a third consumer autograd may already have summed the parked tensor into a new one)."""
+    __slots__ = ("dx",)
+
+    def __init__(self):
+        self.dx = None
+
+    def take(self, like):
+        """The parked residual gradient if it fits ``like`` (then this path returns no gradient of its own)."""
+        d, self.dx = self.dx, None
+        if d is not None and d.shape == like.shape and d.is_contiguous():
+            return d
+        return None
+
+
 # ----------------------------------------------------------------------------
 # per-kernel timing with HIP events on the launch stream (bench.py's live roofline numbers)
 # ----------------------------------------------------------------------------
@@ -239,14 +262,14 @@ def _colsum_into(dy2, M, N, out, accumulate=True):
 # ----------------------------------------------------------------------------
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, link=None):
         x = _f32(x, "x")
         N, K = w.shape
         M = x.numel() // K
         y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
         gemm(L.GEMM_NT, x, w, y, M, N, K, K, K, N, epilogue=L.EPI_BIAS if b is not None else L.EPI_NONE, bias=b)
         ctx.save_for_backward(x)
-        ctx.w, ctx.b = w, b
+        ctx.w, ctx.b, ctx.link = w, b, link
         return y
 
     @staticmethod
@@ -258,8 +281,12 @@ class _Linear(torch.autograd.Function):
         M = x.numel() // K
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            gemm(L.GEMM_NN, dy, w, dx, M, K, N, N, K, K)
+            parked = ctx.link.take(x) if ctx.link is not None else None
+            if parked is not None:  # residual block: add into the LayerNorm backward's dx (ResidualLink)
+                gemm(L.GEMM_NN, dy, w, parked, M, K, N, N, K, K, accumulate=True)
+            else:
+                dx = torch.empty_like(x)
+                gemm(L.GEMM_NN, dy, w, dx, M, K, N, N, K, K)
         dw = db = None
         fuse_b = w.requires_grad and b is not None and b.requires_grad and b.is_leaf
         if w.requires_grad:
@@ -269,12 +296,12 @@ class _Linear(torch.autograd.Function):
             buf, acc, db = _wgrad_target(b)
             _colsum_into(dy, M, N, buf, accumulate=acc)
         _notify(w, b)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def linear(x, w, b=None):
+def linear(x, w, b=None, link=None):
     w = _f32(w, "weight")
-    return _Linear.apply(x, w, b)
+    return _Linear.apply(x, w, b, link)
 
 
 # ----------------------------------------------------------------------------
@@ -387,7 +414,8 @@ def bayes_linear(x, mu, lgstd, noise=None, kl_lambda=0.0, fused=False):
 # ----------------------------------------------------------------------------
 class _FFN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, lgstd2, noise, kl_lambda, fused, drop):
+    def forward(ctx, x, w1, b1, w2, b2, lgstd2, noise, kl_lambda, fused, drop, link=None):
+        ctx.link = link
         x = _f32(x, "x")
         F_, D = w1.shape  # (ff, d)
         N2 = w2.shape[0]
@@ -454,13 +482,17 @@ class _FFN(torch.autograd.Function):
         _notify(w1, b1)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            gemm(L.GEMM_NN, dz, w1, dx, M, D, F_, F_, D, D)
-        return (dx,) + (None,) * 9
+            parked = ctx.link.take(x) if ctx.link is not None else None
+            if parked is not None:
+                gemm(L.GEMM_NN, dz, w1, parked, M, D, F_, F_, D, D, accumulate=True)
+            else:
+                dx = torch.empty_like(x)
+                gemm(L.GEMM_NN, dz, w1, dx, M, D, F_, F_, D, D)
+        return (dx,) + (None,) * 10
 
 
-def ffn(x, w1, b1, w2, b2=None, lgstd2=None, noise=None, kl_lambda=0.0, fused=False, drop=NO_DROP):
-    return _FFN.apply(x, w1, b1, w2, b2, lgstd2, noise, kl_lambda, fused, drop)
+def ffn(x, w1, b1, w2, b2=None, lgstd2=None, noise=None, kl_lambda=0.0, fused=False, drop=NO_DROP, link=None):
+    return _FFN.apply(x, w1, b1, w2, b2, lgstd2, noise, kl_lambda, fused, drop, link)
 
 
 class _FFNGP(torch.autograd.Function):
@@ -468,7 +500,8 @@ class _FFNGP(torch.autograd.Function):
     (model.py:2283): GPNN replaces GELU(linear1(x)); acts = tanh, sigmoid, relu, gelu (model.py:2263)."""
 
     @staticmethod
-    def forward(ctx, x, wg, bg, coef, w2, b2, drop):
+    def forward(ctx, x, wg, bg, coef, w2, b2, drop, link=None):
+        ctx.link = link
         x = _f32(x, "x")
         F_, D = wg.shape
         N2 = w2.shape[0]
@@ -508,13 +541,17 @@ class _FFNGP(torch.autograd.Function):
         _notify(coef, w2, b2, wg, bg)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            gemm(L.GEMM_NN, dz, wg, dx, M, D, F_, F_, D, D)
-        return (dx,) + (None,) * 6
+            parked = ctx.link.take(x) if ctx.link is not None else None
+            if parked is not None:
+                gemm(L.GEMM_NN, dz, wg, parked, M, D, F_, F_, D, D, accumulate=True)
+            else:
+                dx = torch.empty_like(x)
+                gemm(L.GEMM_NN, dz, wg, dx, M, D, F_, F_, D, D)
+        return (dx,) + (None,) * 7
 
 
-def ffn_gp(x, wg, bg, coef, w2, b2, drop=NO_DROP):
-    return _FFNGP.apply(x, wg, bg, coef, w2, b2, drop)
+def ffn_gp(x, wg, bg, coef, w2, b2, drop=NO_DROP, link=None):
+    return _FFNGP.apply(x, wg, bg, coef, w2, b2, drop, link)
 
 
 # ----------------------------------------------------------------------------
@@ -587,7 +624,8 @@ def attention_qkv(q, k, v, nhead, drop=NO_DROP):
 # ----------------------------------------------------------------------------
 class _AddDropLN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y, gamma, beta, eps, drop):
+    def forward(ctx, x, y, gamma, beta, eps, drop, link=None):
+        ctx.link = link
         x, y = _f32(x, "x"), _f32(y, "y")
         D = x.shape[-1]
         B = x.shape[-2]
@@ -622,11 +660,13 @@ class _AddDropLN(torch.autograd.Function):
                                            float(drop.p), C.byref(r) if r is not None else None, drop.col_offset,
                                            drop.global_cols or B, stream()), "blm_add_dropout_ln_bwd")
         _notify(gamma, beta)
-        return dx, (dy if dy is not None else dx), None, None, None, None
+        if ctx.link is not None and ctx.needs_input_grad[0]:
+            ctx.link.dx = dx  # the branch's first op adds its input gradient into this buffer (ResidualLink)
+        return dx, (dy if dy is not None else dx), None, None, None, None, None
 
 
-def add_dropout_ln(x, y, gamma, beta, eps=1e-5, drop=NO_DROP):
-    return _AddDropLN.apply(x, y, gamma, beta, eps, drop)
+def add_dropout_ln(x, y, gamma, beta, eps=1e-5, drop=NO_DROP, link=None):
+    return _AddDropLN.apply(x, y, gamma, beta, eps, drop, link)
 
 
 # ----------------------------------------------------------------------------

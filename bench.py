@@ -396,7 +396,7 @@ def main():
         flops = 2.0 * M_ * N_ * K_  # 2*M*N*K per forward launch
         roof = None
         traffic = None  # HBM bytes per launch from the PMC passes committed under profiles/ (not collected live)
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_sampled_gemm_fwd.json")
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_sampled_gemm_fwd.json")
         if os.path.exists(pmc) and Bc == B_PER_GPU and not model.noise_state.fused:
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
         if "sampled_gemm_fwd" in kt:
