@@ -19,6 +19,8 @@
 //    or a quad exchange (key orientation).
 //
 // Replaces model.py:889-920 / :990-1011 and their autograd.
+#include <cstdlib>
+
 #include "blm_device.h"
 #include "blm_host.h"
 
@@ -45,7 +47,17 @@ struct AttnM {
   float inv_keep;
   int col_offset;
   int drop;
+#ifdef BLM_ATTN_PROF
+  long long* prof;  // tools/attn_prof.hip only: 8 wall-clock stamps (10 ns) per wave
+#endif
 };
+
+#ifdef BLM_ATTN_PROF
+__device__ long long* g_attn_stamps;  // per-thread pointer is awkward across helpers: stamps live in registers of lane 0
+#define ATTN_STAMP(arr, i) do { if ((threadIdx.x & 63) == 0) (arr)[i] = wall_clock64(); } while (0)
+#else
+#define ATTN_STAMP(arr, i) do { } while (0)
+#endif
 
 // rows [0,T) x 64 floats of a (T,B,*) tensor -> dst[row*LS + c] (* mul); rows [T,128) zeroed.
 // Split in an issue half (16 independent float4 loads per thread) and an LDS-write half so a kernel
@@ -53,21 +65,21 @@ struct AttnM {
 // nothing else to hide the memory latency behind (PMC: waves of the first version were parked on
 // s_waitcnt for half of their lifetime).
 template <int NT>
-__device__ __forceinline__ void fetch_rows(float4 (&v)[2048 / NT], const float* src, long ld, int T, int B, int b, int off) {
+__device__ __forceinline__ void fetch_rows(float4 (&v)[2048 / NT], const float* src, long ld, int T, int B, int b, int off, int tid) {
   const bool al = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)(ld * 4) | (uintptr_t)(off * 4)) & 15) == 0;
 #pragma unroll
   for (int u = 0; u < 2048 / NT; ++u) {
-    const int i = threadIdx.x + NT * u, row = i >> 4, c = (i & 15) << 2;
+    const int i = tid + NT * u, row = i >> 4, c = (i & 15) << 2;
     const float* s = src + ((long)min(row, T - 1) * B + b) * ld + off + c;
     if (al) v[u] = *reinterpret_cast<const float4*>(s);
     else v[u] = make_float4(s[0], s[1], s[2], s[3]);
   }
 }
 template <int NT>
-__device__ __forceinline__ void put_rows(float* dst, const float4 (&v)[2048 / NT], int T, float mul) {
+__device__ __forceinline__ void put_rows(float* dst, const float4 (&v)[2048 / NT], int T, float mul, int tid) {
 #pragma unroll
   for (int u = 0; u < 2048 / NT; ++u) {
-    const int i = threadIdx.x + NT * u, row = i >> 4, c = (i & 15) << 2;
+    const int i = tid + NT * u, row = i >> 4, c = (i & 15) << 2;
     const float m = row < T ? mul : 0.f;
     float* d = dst + row * LS + c;
     d[0] = v[u].x * m; d[1] = v[u].y * m; d[2] = v[u].z * m; d[3] = v[u].w * m;
@@ -172,7 +184,11 @@ __device__ __forceinline__ void store_t(float* dst_row, const f32x16 (&acc)[2], 
 
 // ------------------------------------------------------------------ forward
 __device__ __forceinline__ void attn_fwd_pass(const AttnM& p, const float* Ks, const float* Vs, int qt, float (&qreg)[32],
-                                              int b, int off, uint64_t bh, int li, int lh) {
+                                              int b, int off, uint64_t bh, int li, int lh, int bhid
+#ifdef BLM_ATTN_PROF
+                                              , long long (&stamps)[8]
+#endif
+                                              ) {
   const int T = p.T;
   const int q = 32 * qt + li;
   const bool qok = q < T;
@@ -193,6 +209,7 @@ __device__ __forceinline__ void attn_fwd_pass(const AttnM& p, const float* Ks, c
     }
   }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
+  ATTN_STAMP(stamps, 3);
   float l = 0.f;
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
@@ -206,6 +223,7 @@ __device__ __forceinline__ void attn_fwd_pass(const AttnM& p, const float* Ks, c
   }
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.f / l;
+  ATTN_STAMP(stamps, 4);
   f32x16 ot[2] = {(f32x16)(0.f), (f32x16)(0.f)};
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
@@ -220,46 +238,71 @@ __device__ __forceinline__ void attn_fwd_pass(const AttnM& p, const float* Ks, c
       acc_xt_regs(ot, Vs, 32 * kt, st[kt], li, lh);
     }
   }
+  ATTN_STAMP(stamps, 5);
   if (qok) {
     store_t(p.out + ((long)q * p.B + b) * ((long)p.nhead * HD) + off, ot, lh, 1.f);
-    if (p.lse && lh == 0) p.lse[(long)blockIdx.x * T + q] = m + __logf(l);
+    if (p.lse && lh == 0) p.lse[(long)bhid * T + q] = m + __logf(l);
   }
+  ATTN_STAMP(stamps, 6);
 }
 
 // 4 waves, one query tile each: the kernel is bound by its load -> compute -> store latency chain, not
 // by the matrix pipe (9 us of MFMA in 40), so twice the waves per workgroup (twice the loads in flight,
 // half the serial work per wave) beat the balanced two-tiles-per-wave split of the causal triangle.
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnM p) {
+// HPW = heads per workgroup.  HPW = 2 (even B * nhead): 8 waves, the second head's waves take the query tiles in the
+// opposite order, so the two waves that share a SIMD (w and w + 4) hold causal tiles {3 - w, w} = 5 tile-steps on every
+// SIMD.  With one head per workgroup the two co-resident workgroups of a CU put BOTH 4-step waves on SIMD 0 and both
+// 1-step waves on SIMD 3: 8 tile-steps of MFMA + softmax on the critical SIMD against 5 here.
+template <int HPW>
+__global__ __launch_bounds__(256 * HPW) void attn_fwd_mfma_kernel(const AttnM p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Ks = sm;
-  float* Vs = sm + AT * LS;
-  const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
-  const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int hsel = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  const int bhid = blockIdx.x * HPW + hsel;
+  float* Ks = sm + hsel * 2 * AT * LS;
+  float* Vs = Ks + AT * LS;
+  const int b = bhid / p.nhead, head = bhid % p.nhead, off = head * HD;
+  const int T = p.T, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int ntile = (T + 31) >> 5;
-  const int qt = 3 - wave;  // the longest tile on the first wave
+  const int qt = hsel ? wave : 3 - wave;  // the longest tile on the first wave (second head: on the last)
   float qa[32];
+#ifdef BLM_ATTN_PROF
+  long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  ATTN_STAMP(stamps, 0);
   {
     float4 kk[8], vv[8];
-    fetch_rows<256>(kk, p.k, p.ld, T, p.B, b, off);
-    fetch_rows<256>(vv, p.v, p.ld, T, p.B, b, off);
+    fetch_rows<256>(kk, p.k, p.ld, T, p.B, b, off, tid);
+    fetch_rows<256>(vv, p.v, p.ld, T, p.B, b, off, tid);
     fetch_op(qa, p.q + ((long)min(32 * qt + li, T - 1) * p.B + b) * p.ld + off + 32 * lh);
-    put_rows<256>(Ks, kk, T, 1.f);
-    put_rows<256>(Vs, vv, T, 1.f);
+    put_rows<256>(Ks, kk, T, 1.f, tid);
+    put_rows<256>(Vs, vv, T, 1.f, tid);
   }
+  ATTN_STAMP(stamps, 1);
   __syncthreads();
+  ATTN_STAMP(stamps, 2);
   const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
-  if (qt < ntile) attn_fwd_pass(p, Ks, Vs, qt, qa, b, off, bh, li, lh);
+#ifdef BLM_ATTN_PROF
+  if (qt < ntile) attn_fwd_pass(p, Ks, Vs, qt, qa, b, off, bh, li, lh, bhid, stamps);
+  if (p.prof && lane == 0) {
+    long long* o = p.prof + ((long)blockIdx.x * 4 * HPW + (threadIdx.x >> 6)) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = stamps[i];
+    o[7] = qt;
+  }
+#else
+  if (qt < ntile) attn_fwd_pass(p, Ks, Vs, qt, qa, b, off, bh, li, lh, bhid);
+#endif
 }
 
 // ------------------------------------------------------------------ backward: dQ (lane = query)
 __device__ __forceinline__ void attn_dq_pass(const AttnM& p, const float* Ks, const float* Vs, int qt, float (&qreg)[32],
-                                             const float (&doreg)[32], float delta, int b, int off, uint64_t bh, int li, int lh) {
+                                             const float (&doreg)[32], float delta, int b, int off, uint64_t bh, int li, int lh,
+                                             int bhid) {
   const int T = p.T;
   const int q = 32 * qt + li, qc = min(q, T - 1);
 #pragma unroll
   for (int s = 0; s < 32; ++s) qreg[s] *= p.scale;
   delta += __shfl_xor(delta, 32, 64);
-  const float lse = p.lse[(long)blockIdx.x * T + qc];
+  const float lse = p.lse[(long)bhid * T + qc];
   f32x16 dqt[2] = {(f32x16)(0.f), (f32x16)(0.f)};
 #pragma unroll 1
   for (int kt = 0; kt <= qt; ++kt) {
@@ -282,34 +325,37 @@ __device__ __forceinline__ void attn_dq_pass(const AttnM& p, const float* Ks, co
   if (q < T) store_t(p.dq + ((long)q * p.B + b) * p.ldd + off, dqt, lh, p.scale);
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnM p) {
+template <int HPW>
+__global__ __launch_bounds__(256 * HPW) void attn_bwd_dq_mfma_kernel(const AttnM p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Ks = sm;
-  float* Vs = sm + AT * LS;
-  const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
-  const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int hsel = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  const int bhid = blockIdx.x * HPW + hsel;
+  float* Ks = sm + hsel * 2 * AT * LS;
+  float* Vs = Ks + AT * LS;
+  const int b = bhid / p.nhead, head = bhid % p.nhead, off = head * HD;
+  const int T = p.T, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const long dmodel = (long)p.nhead * HD;
   const int ntile = (T + 31) >> 5;
-  const int qt = 3 - wave;  // one query tile per wave, the longest first
+  const int qt = hsel ? wave : 3 - wave;  // one query tile per wave; SIMD-balanced pairs with HPW = 2 (forward kernel)
   float qa[32], da[32];
   float delta = 0.f;
   {
     const long r0 = (long)min(32 * qt + li, T - 1) * p.B + b;
     float4 kk[8], vv[8];
     float oa[32];
-    fetch_rows<256>(kk, p.k, p.ld, T, p.B, b, off);
-    fetch_rows<256>(vv, p.v, p.ld, T, p.B, b, off);
+    fetch_rows<256>(kk, p.k, p.ld, T, p.B, b, off, tid);
+    fetch_rows<256>(vv, p.v, p.ld, T, p.B, b, off, tid);
     fetch_op(qa, p.q + r0 * p.ld + off + 32 * lh);
     fetch_op(da, p.dout + r0 * dmodel + off + 32 * lh);
     fetch_op(oa, p.o_in + r0 * dmodel + off + 32 * lh);
-    put_rows<256>(Ks, kk, T, 1.f);
-    put_rows<256>(Vs, vv, T, 1.f);
+    put_rows<256>(Ks, kk, T, 1.f, tid);
+    put_rows<256>(Vs, vv, T, 1.f, tid);
 #pragma unroll
     for (int s = 0; s < 32; ++s) delta += da[s] * oa[s];
   }
   __syncthreads();
   const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
-  if (qt < ntile) attn_dq_pass(p, Ks, Vs, qt, qa, da, delta, b, off, bh, li, lh);
+  if (qt < ntile) attn_dq_pass(p, Ks, Vs, qt, qa, da, delta, b, off, bh, li, lh, bhid);
 }
 
 // ------------------------------------------------------------------ backward: dK, dV (lane = key)
@@ -369,33 +415,36 @@ __device__ __forceinline__ void attn_dkv_pass(const AttnM& p, const float* Qs, c
   }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnM p) {
+template <int HPW>
+__global__ __launch_bounds__(256 * HPW) void attn_bwd_dkv_mfma_kernel(const AttnM p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Qs = sm;               // Q * scale
-  float* Os = sm + AT * LS;     // dO
-  float* lse_s = sm + 2 * AT * LS;
+  const int hsel = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  const int bhid = blockIdx.x * HPW + hsel;
+  float* Qs = sm + hsel * (2 * AT * LS + 2 * AT);  // Q * scale
+  float* Os = Qs + AT * LS;                        // dO
+  float* lse_s = Qs + 2 * AT * LS;
   float* del_s = lse_s + AT;
-  const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * HD;
-  const int T = p.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int b = bhid / p.nhead, head = bhid % p.nhead, off = head * HD;
+  const int T = p.T, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const long dmodel = (long)p.nhead * HD;
   const int ntile = (T + 31) >> 5;
-  const int kt = wave;  // key tile kt meets query tiles kt..ntile-1: one per wave, the longest first
+  const int kt = hsel ? 3 - wave : wave;  // key tile kt meets query tiles kt..ntile-1: one per wave; SIMD-balanced with HPW = 2
   float ka[32], va[32];
   {
     const long r0 = (long)min(32 * kt + li, T - 1) * p.B + b;
     float4 qq[8], dd[8];
-    fetch_rows<256>(qq, p.q, p.ld, T, p.B, b, off);
-    fetch_rows<256>(dd, p.dout, dmodel, T, p.B, b, off);
+    fetch_rows<256>(qq, p.q, p.ld, T, p.B, b, off, tid);
+    fetch_rows<256>(dd, p.dout, dmodel, T, p.B, b, off, tid);
     fetch_op(ka, p.k + r0 * p.ld + off + 32 * lh);
     fetch_op(va, p.v + r0 * p.ld + off + 32 * lh);
-    put_rows<256>(Qs, qq, T, p.scale);
-    put_rows<256>(Os, dd, T, 1.f);
+    put_rows<256>(Qs, qq, T, p.scale, tid);
+    put_rows<256>(Os, dd, T, 1.f, tid);
   }
   {  // delta[q] = rowsum(dO * O), lse[q]: two threads per row (half a row each, 2 x 8 float4 in flight)
-    const int row = threadIdx.x >> 1, half = threadIdx.x & 1, rc = min(row, T - 1);
+    const int row = tid >> 1, half = tid & 1, rc = min(row, T - 1);
     const float* ds = p.dout + ((long)rc * p.B + b) * dmodel + off + (HD / 2) * half;
     const float* os = p.o_in + ((long)rc * p.B + b) * dmodel + off + (HD / 2) * half;
-    const float ls = p.lse[(long)blockIdx.x * T + rc];
+    const float ls = p.lse[(long)bhid * T + rc];
     float d = 0.f;
     if ((((uintptr_t)ds | (uintptr_t)os) & 15) == 0) {
       float4 dv4[HD / 8], ov4[HD / 8];
@@ -459,8 +508,8 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnM p) {
       float4 kk[8], vv[8];
       fetch_rows_at<256>(kk, p.k, p.ld, T, p.B, b, off, 128 * kc);
       fetch_rows_at<256>(vv, p.v, p.ld, T, p.B, b, off, 128 * kc);
-      put_rows<256>(Ks, kk, T - 128 * kc, 1.f);
-      put_rows<256>(Vs, vv, T - 128 * kc, 1.f);
+      put_rows<256>(Ks, kk, T - 128 * kc, 1.f, threadIdx.x);
+      put_rows<256>(Vs, vv, T - 128 * kc, 1.f, threadIdx.x);
     }
     __syncthreads();
 #pragma unroll 1
@@ -537,8 +586,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_long_kernel(const AttnM p) {
       float4 kk[8], vv[8];
       fetch_rows_at<256>(kk, p.k, p.ld, T, p.B, b, off, 128 * kc);
       fetch_rows_at<256>(vv, p.v, p.ld, T, p.B, b, off, 128 * kc);
-      put_rows<256>(Ks, kk, T - 128 * kc, 1.f);
-      put_rows<256>(Vs, vv, T - 128 * kc, 1.f);
+      put_rows<256>(Ks, kk, T - 128 * kc, 1.f, threadIdx.x);
+      put_rows<256>(Vs, vv, T - 128 * kc, 1.f, threadIdx.x);
     }
     __syncthreads();
 #pragma unroll 1
@@ -589,8 +638,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_long_kernel(const AttnM p) {
       float4 qq[8], dd[8];
       fetch_rows_at<256>(qq, p.q, p.ld, T, p.B, b, off, 128 * qcn);
       fetch_rows_at<256>(dd, p.dout, dmodel, T, p.B, b, off, 128 * qcn);
-      put_rows<256>(Qs, qq, T - 128 * qcn, p.scale);
-      put_rows<256>(Os, dd, T - 128 * qcn, 1.f);
+      put_rows<256>(Qs, qq, T - 128 * qcn, p.scale, threadIdx.x);
+      put_rows<256>(Os, dd, T - 128 * qcn, 1.f, threadIdx.x);
     }
     {  // delta[q] = rowsum(dO * O), lse[q] of this chunk's rows: two threads per row
       const int row = threadIdx.x >> 1, half = threadIdx.x & 1, grow = 128 * qcn + row, rc = min(grow, T - 1);
@@ -643,6 +692,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_long_kernel(const AttnM p) {
 
 using namespace blm;
 
+static int attn_hpw() {  // BLM_ATTN_HPW=1|2: heads per workgroup of the T <= 128 kernels (A/B measurements; default 2)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("BLM_ATTN_HPW");
+    v = e ? atoi(e) : 2;
+  }
+  return v;
+}
+
 static void fill_m(AttnM& p, int T, int B, int nhead, float pdrop, const blm_rng* rng, int col_offset) {
   p.T = T; p.B = B; p.nhead = nhead;
   p.scale = 0.125f;  // 64^-0.5
@@ -669,7 +727,9 @@ int blm_attn_fwd_mfma(const float* q, const float* k, const float* v, int64_t ld
   const size_t lds = (size_t)2 * AT * LS * sizeof(float);
   static bool once = false;
   if (!once) {
-    int rc = set_lds(attn_fwd_mfma_kernel, lds);
+    int rc = set_lds(attn_fwd_mfma_kernel<1>, lds);
+    if (rc) return rc;
+    rc = set_lds(attn_fwd_mfma_kernel<2>, 2 * lds);
     if (rc) return rc;
     rc = set_lds(attn_fwd_long_kernel, lds);
     if (rc) return rc;
@@ -680,7 +740,8 @@ int blm_attn_fwd_mfma(const float* q, const float* k, const float* v, int64_t ld
     BLM_HIP(hipGetLastError());
     return BLM_OK;
   }
-  hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * nhead), dim3(256), lds, st, p);
+  if ((B * nhead) % 2 == 0 && attn_hpw() == 2) hipLaunchKernelGGL(attn_fwd_mfma_kernel<2>, dim3(B * nhead / 2), dim3(512), 2 * lds, st, p);
+  else hipLaunchKernelGGL(attn_fwd_mfma_kernel<1>, dim3(B * nhead), dim3(256), lds, st, p);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }
@@ -695,9 +756,13 @@ int blm_attn_bwd_mfma(const float* q, const float* k, const float* v, int64_t ld
   const size_t lds1 = (size_t)2 * AT * LS * sizeof(float), lds2 = lds1 + 2 * AT * sizeof(float);
   static bool once = false;
   if (!once) {
-    int rc = set_lds(attn_bwd_dq_mfma_kernel, lds1);
+    int rc = set_lds(attn_bwd_dq_mfma_kernel<1>, lds1);
     if (rc) return rc;
-    rc = set_lds(attn_bwd_dkv_mfma_kernel, lds2);
+    rc = set_lds(attn_bwd_dkv_mfma_kernel<1>, lds2);
+    if (rc) return rc;
+    rc = set_lds(attn_bwd_dq_mfma_kernel<2>, 2 * lds1);
+    if (rc) return rc;
+    rc = set_lds(attn_bwd_dkv_mfma_kernel<2>, 2 * lds2);
     if (rc) return rc;
     rc = set_lds(attn_bwd_dq_long_kernel, lds1);
     if (rc) return rc;
@@ -713,9 +778,15 @@ int blm_attn_bwd_mfma(const float* q, const float* k, const float* v, int64_t ld
     BLM_HIP(hipGetLastError());
     return BLM_OK;
   }
-  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(B * nhead), dim3(256), lds1, st, p);
-  BLM_HIP(hipGetLastError());
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(B * nhead), dim3(256), lds2, st, p);
+  if ((B * nhead) % 2 == 0 && attn_hpw() == 2) {
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<2>, dim3(B * nhead / 2), dim3(512), 2 * lds1, st, p);
+    BLM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<2>, dim3(B * nhead / 2), dim3(512), 2 * lds2, st, p);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<1>, dim3(B * nhead), dim3(256), lds1, st, p);
+    BLM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<1>, dim3(B * nhead), dim3(256), lds2, st, p);
+  }
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }
