@@ -269,6 +269,64 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 
+// ------------------------------------------------------------------ forward step, tiny batches (B <= 4)
+// The n-best scorer walks its carry chain as ONE long B = 1 sequence (compute_sentence_scores.py, reference :271-274):
+// thousands of dependent steps whose matrix is 4H x H but whose batch is a single row.  A 32 x 32 MFMA tile is 97 % idle
+// there and the staged-tile kernel above still pays its whole load -> LDS -> MFMA -> LDS-reduce chain (~11 us).  Here a
+// WAVE owns one hidden unit: its four gate rows of W_hh (4 x H floats, 16 KB at H = 1024) stream through registers as
+// 16-byte loads, all issued before the first use, against the B rows of h; four wave reductions; lane 0 does the
+// cell.  No LDS, no barrier, 4 H / 256 floats per lane: the step is launch + one L2 round trip.
+template <int BB>
+__global__ __launch_bounds__(256) void lstm_step_fwd_gemv_kernel(const LstmStepP p) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + wave;
+  const int H = p.H, B = p.B;
+  if (j >= H) return;
+  float acc[4][BB];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int b = 0; b < BB; ++b) acc[g][b] = 0.f;
+  const float* wr = p.whh + (long)j * H;
+  const long gs = (long)H * H;  // gate block stride
+#pragma unroll 4
+  for (int k0 = lane * 4; k0 < H; k0 += 256) {
+    float4 w[4], hv[BB];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) w[g] = *reinterpret_cast<const float4*>(wr + g * gs + k0);
+#pragma unroll
+    for (int b = 0; b < BB; ++b) hv[b] = *reinterpret_cast<const float4*>(p.hprev + (long)min(b, B - 1) * H + k0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int b = 0; b < BB; ++b)
+        acc[g][b] += w[g].x * hv[b].x + w[g].y * hv[b].y + w[g].z * hv[b].z + w[g].w * hv[b].w;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int b = 0; b < BB; ++b) acc[g][b] = wave_sum(acc[g][b]);
+  if (lane == 0) {
+#pragma unroll
+    for (int b = 0; b < BB; ++b) {
+      if (b < B) {
+        const long i = (long)b * H + j, o = (long)b * 4 * H + j;
+        const float gi = sigmoidf_(p.xw[o] + acc[0][b]), gf = sigmoidf_(p.xw[o + H] + acc[1][b]);
+        const float gg = tanhf(p.xw[o + 2L * H] + acc[2][b]), go = sigmoidf_(p.xw[o + 3L * H] + acc[3][b]);
+        const float cn = gf * p.cprev[i] + gi * gg;
+        p.c[i] = cn;
+        p.h[i] = go * tanhf(cn) + (p.hnoise ? p.hnoise[j] : 0.f);
+        if (p.ga) {
+          p.ga[o] = gi;
+          p.ga[o + H] = gf;
+          p.ga[o + 2L * H] = gg;
+          p.ga[o + 3L * H] = go;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ backward step
 // dh_{t-1} = dgates_t . W_hh  (B x 4H times 4H x H), fused with the cell backward of step t-1, so that
 // one launch per time step replaces cell kernel + memset + split-K GEMM and dh never visits HBM.
@@ -503,6 +561,15 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 using namespace blm;
 
+static int lstm_gemv() {  // BLM_LSTM_GEMV=0 disables the tiny-batch step kernel (A/B measurements)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("BLM_LSTM_GEMV");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
 static int lstm_waves() {  // BLM_LSTM_WAVES=4|8 (A/B measurements)
   static int v = -1;
   if (v < 0) {
@@ -534,6 +601,15 @@ extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const 
   if (H % 32 != 0 || !al16(w_hh) || !al16(h_prev))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_fwd: needs H % 32 == 0 and 16-byte aligned h_prev / w_hh");
   LstmStepP p{xw_t, w_hh, h_prev, c_prev, h, c, gates_act, h_noise, coef4, z_out, gate_ovr < 0 ? -1 : gate_ovr, rbias, B, H, nullptr};
+  if (gate_ovr < 0 && B <= 4 && H % 4 == 0 && lstm_gemv()) {  // tiny batches (the scorer's carry chain): one wave per hidden unit
+    const dim3 g((H + 3) / 4), blk(256);
+    hipStream_t s0 = (hipStream_t)stream;
+    if (B == 1) hipLaunchKernelGGL(lstm_step_fwd_gemv_kernel<1>, g, blk, 0, s0, p);
+    else if (B == 2) hipLaunchKernelGGL(lstm_step_fwd_gemv_kernel<2>, g, blk, 0, s0, p);
+    else hipLaunchKernelGGL(lstm_step_fwd_gemv_kernel<4>, g, blk, 0, s0, p);
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
+  }
   const size_t lds4 = (size_t)4 * WAVE_LDS * sizeof(float), lds8 = 2 * lds4;
   static bool once = false;
   if (!once) {

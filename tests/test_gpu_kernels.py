@@ -467,10 +467,12 @@ def test_lstm_layer_matches_oracle(dev):
         assert rel(a.grad, b.grad) < 5e-5, name
 
 
-@pytest.mark.parametrize("T,B,E,H", [(5, 64, 48, 256), (4, 20, 32, 96), (3, 70, 40, 320), (3, 1, 16, 32)])
+@pytest.mark.parametrize("T,B,E,H", [(5, 64, 48, 256), (4, 20, 32, 96), (3, 70, 40, 320), (3, 1, 16, 32), (6, 2, 16, 64),
+                                     (6, 3, 24, 96), (4, 4, 32, 1024), (5, 1, 64, 1024), (3, 5, 16, 64)])
 def test_lstm_layer_fused_step_matches_oracle(dev, T, B, E, H):
     """H % 32 == 0 takes blm_lstm_step_fwd (one launch per step: MFMA recurrent product + cell):
-    ragged batch tiles (20, 70, 1), K tails (H/8 = 12, 40), and the accumulate-in-place backward."""
+    ragged batch tiles (20, 70, 1), K tails (H/8 = 12, 40), and the accumulate-in-place backward.  B <= 4 forwards run
+    the tiny-batch kernel (one wave per hidden unit, the scorer's carry chain), B = 5 the MFMA one again."""
     ops = ops_mod()
     g = torch.Generator().manual_seed(12)
     mk = lambda *s: torch.randn(*s, generator=g) * 0.2  # noqa: E731
