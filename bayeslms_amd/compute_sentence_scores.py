@@ -323,6 +323,31 @@ def write_scores(scores, path):
                 f.write('%s %.4f\n' % ('-'.join([key, str(idx)]), s))
 
 
+def interpolate_scores(nolm_path, lmonly_path, nn_path, nnweight, out_path):
+    """Stage 7 of lmrescore_nbest_pytorchnn_cuda.sh (:221-229) without the paste | awk hop: per n-best entry
+    score = graph + nnweight * nn + (1 - nnweight) * lm, from the three 'key value' files the script pastes
+    (lmwt.nolm, lmwt.lmonly, lmwt.nn).  Keys are taken from the first file; lines are matched by position, as paste
+    does; numbers are printed the way awk prints them (OFMT %.6g).  Host text processing, offered so that the scorer
+    process can leave lmwt.interp.<w> behind itself."""
+    def col(path):
+        with open(path, 'r', encoding='utf-8') as f:
+            return [ln.split() for ln in f if ln.strip()]
+    a, b, c = col(nolm_path), col(lmonly_path), col(nn_path)
+    if not (len(a) == len(b) == len(c)):
+        raise SystemExit("interpolate_scores: %d / %d / %d lines in %s, %s, %s" % (len(a), len(b), len(c), nolm_path,
+                                                                                   lmonly_path, nn_path))
+    w = float(nnweight)
+    with open(out_path, 'w', encoding='utf-8') as f:
+        for x, y, z in zip(a, b, c):
+            score = float(x[1]) + w * float(z[1]) + (1.0 - w) * float(y[1])
+            f.write("%s %s\n" % (x[0], _awk_num(score)))
+
+
+def _awk_num(v):
+    """awk's print conversion: integers print as integers, everything else with OFMT = %.6g."""
+    return "%d" % v if v == int(v) and abs(v) < 1e16 else "%.6g" % v
+
+
 def build_parser():
     p = argparse.ArgumentParser(description="Compute sentence scores of nbest lists with a trained neural LM (MI355X engine).")
     p.add_argument('--nbest-list', type=str, required=True)
@@ -351,6 +376,11 @@ def build_parser():
     p.add_argument('--batch-tokens', type=int, default=8192, help='Transformer scoring: padded tokens per batch across utterances')
     p.add_argument('--gemm-mode', type=str, default='f32', choices=['f32', 'bf16x6', 'bf16x3'],
                    help='opt-in split-bf16 arithmetic of the GEMM family (DESIGN.md section 7); default fp32 MFMA')
+    p.add_argument('--interp-nolm', type=str, default='', help='lmwt.nolm of the rescoring script (graph scores): with '
+                   '--interp-lmonly, --interp-nnweight and --interp-out the scorer also writes the stage-7 file')
+    p.add_argument('--interp-lmonly', type=str, default='')
+    p.add_argument('--interp-nnweight', type=float, default=0.8)
+    p.add_argument('--interp-out', type=str, default='')
     return p
 
 
@@ -381,6 +411,9 @@ def main(argv=None):
         scores = compute_scores(nbest, model_1, vocab, args.model, device, model_2, args.inter_alpha)
     write_scores(scores, args.outfile)
     print("Write to %s" % args.outfile)
+    if args.interp_out:
+        interpolate_scores(args.interp_nolm, args.interp_lmonly, args.outfile, args.interp_nnweight, args.interp_out)
+        print("Write to %s" % args.interp_out)
 
 
 if __name__ == '__main__':

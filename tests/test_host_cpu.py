@@ -283,3 +283,33 @@ def test_bench_self_launches_its_ranks_from_one_process():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        timeout=600, env=env, cwd="/tmp")
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+
+
+def test_stage7_score_interpolation_matches_awk(tmp_path):
+    """the awk hop of lmrescore_nbest_pytorchnn_cuda.sh:221-229 (graph + w * nn + (1 - w) * lm per n-best
+    entry, printed by awk's rules) done by the scorer process; checked against awk itself when the box has one."""
+    import shutil
+    import subprocess
+    from bayeslms_amd import compute_sentence_scores as S
+    rng = np.random.RandomState(4)
+    keys = ["utt%d-A-%d" % (u, n) for u in range(5) for n in range(1, 5)]
+    d = str(tmp_path)
+    cols = {}
+    for name, scale in (("nolm", 40.0), ("lmonly", 25.0), ("nn", 30.0)):
+        cols[name] = [round(float(v), 4) for v in rng.rand(len(keys)) * scale]
+        cols[name][3] = 12.0  # an integer-valued score: awk prints it without a decimal point
+        with open(os.path.join(d, "lmwt." + name), "w") as f:
+            for k, v in zip(keys, cols[name]):
+                f.write("%s %s\n" % (k, ("%.4f" % v) if name == "nn" else repr(v)))
+    out = os.path.join(d, "lmwt.interp.0.8")
+    S.interpolate_scores(os.path.join(d, "lmwt.nolm"), os.path.join(d, "lmwt.lmonly"), os.path.join(d, "lmwt.nn"), 0.8, out)
+    got = [ln.split() for ln in open(out).read().splitlines()]
+    assert [g[0] for g in got] == keys
+    for g, a, b, c in zip(got, cols["nolm"], cols["lmonly"], cols["nn"]):
+        assert abs(float(g[1]) - (a + 0.8 * c + 0.2 * b)) <= 5e-6 * max(1.0, abs(a + 0.8 * c + 0.2 * b))
+    assert S._awk_num(12.0) == "12" and S._awk_num(0.5) == "0.5" and S._awk_num(1234567.25) == "1.23457e+06"
+    if shutil.which("awk") and shutil.which("paste"):
+        cmd = ("paste %s/lmwt.nolm %s/lmwt.lmonly %s/lmwt.nn | awk -v w=0.8 '{ print $1, $2 + (w * $6) + ((1 - w) * $4); }'"
+               % (d, d, d))
+        ref = subprocess.run(cmd, shell=True, capture_output=True, text=True, check=True).stdout
+        assert open(out).read() == ref
