@@ -63,6 +63,7 @@ SIGNATURES = {
     "blm_embed_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _f, _f, _rngp, _i, _i, _vp]),
     "blm_add_pe_dropout": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
     "blm_dropout": (_i, [_vp, _vp, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
+    "blm_dropout_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
     "blm_add_dropout_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _rngp, _i, _i, _vp]),
     "blm_ln_bwd_ws_floats": (_i64, [_i, _i]),
     "blm_add_dropout_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _rngp, _i, _i, _vp]),

@@ -13,6 +13,7 @@ struct DropKey {
   float inv_keep;  // 1/(1-p)
   int B, D, col_offset, global_cols;
   bool on;
+  int row0;        // global index of the call's first row (a (rows, B, D) block of a longer tensor: chunked LSTM stacks)
 };
 
 __host__ static DropKey make_key(float p, const blm_rng* rng, int B, int D, int col_offset, int global_cols) {
@@ -29,14 +30,14 @@ __host__ static DropKey make_key(float p, const blm_rng* rng, int B, int D, int 
 // Scale factors (0 or 1/(1-p)) for the 4 consecutive features j..j+3 (j % 4 == 0, D % 4 == 0) of local (row, b).
 __device__ __forceinline__ float4 keep4(const DropKey& k, int row, int b, int j) {
   if (!k.on) return make_float4(1.f, 1.f, 1.f, 1.f);
-  const uint64_t g = ((uint64_t)row * k.global_cols + (uint64_t)(k.col_offset + b)) * (uint64_t)k.D + (uint64_t)j;
+  const uint64_t g = ((uint64_t)(row + k.row0) * k.global_cols + (uint64_t)(k.col_offset + b)) * (uint64_t)k.D + (uint64_t)j;
   const u32x4 u = philox_block(k.rng, g >> 2);
   return make_float4(u.x >= k.thr ? k.inv_keep : 0.f, u.y >= k.thr ? k.inv_keep : 0.f,
                      u.z >= k.thr ? k.inv_keep : 0.f, u.w >= k.thr ? k.inv_keep : 0.f);
 }
 __device__ __forceinline__ float keep1(const DropKey& k, int row, int b, int j) {
   if (!k.on) return 1.f;
-  const uint64_t g = ((uint64_t)row * k.global_cols + (uint64_t)(k.col_offset + b)) * (uint64_t)k.D + (uint64_t)j;
+  const uint64_t g = ((uint64_t)(row + k.row0) * k.global_cols + (uint64_t)(k.col_offset + b)) * (uint64_t)k.D + (uint64_t)j;
   const u32x4 u = philox_block(k.rng, g >> 2);
   const int c = (int)(g & 3);
   const uint32_t bits = c == 0 ? u.x : (c == 1 ? u.y : (c == 2 ? u.z : u.w));

@@ -753,6 +753,19 @@ extern "C" int blm_dropout(const float* x, float* y, int rows, int B, int D, flo
   return BLM_OK;
 }
 
+extern "C" int blm_dropout_rows(const float* x, float* y, int rows, int row0, int B, int D, float p, const blm_rng* rng,
+                                int col_offset, int global_cols, void* stream) {
+  if (!x || !y || rows < 0 || row0 < 0 || B < 0 || D < 0) return blm_fail(BLM_ERR_INVALID, "blm_dropout_rows: bad arguments");
+  if (p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_dropout_rows: dropout needs rng");
+  const long n = (long)rows * B * D;
+  if (n == 0) return BLM_OK;
+  DropKey dk = make_key(p, rng, B, D, col_offset, global_cols);
+  dk.row0 = row0;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4 + 1)), dim3(TPB), 0, ST, x, y, (long)rows, dk);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
 extern "C" int blm_add_pe_dropout(const float* x, const float* pe, float* out, int T, int B, int D, float p,
                                   const blm_rng* rng, int col_offset, int global_cols, void* stream) {
   if (!x || !pe || !out || T < 0 || B < 0 || D < 0) return blm_fail(BLM_ERR_INVALID, "blm_add_pe_dropout: bad arguments");

@@ -715,6 +715,11 @@ class Bayes2LSTM(_Site):
             hx = (z, z)
         w = self._weights()
         h0, c0 = hx
+        l1 = (w[("weight_ih", 1)], w[("weight_hh", 1)], w[("bias_ih", 1)], w[("bias_hh", 1)])
+        l2 = (w[("weight_ih", 2)], w[("weight_hh", 2)], w[("bias_ih", 2)], w[("bias_hh", 2)])
+        if ops.lstm_stack2_ok(inputs, l1[1], l2[1], l2[0]):  # the two layers as a wavefront on two streams
+            y, (h1, h2), (c1, c2) = ops.lstm_stack2(inputs, h0, c0, l1, l2)
+            return y, (torch.stack([h1, h2]), torch.stack([c1, c2]))
         y, h1, c1 = ops.lstm_layer(inputs, h0[0], c0[0], w[("weight_ih", 1)], w[("weight_hh", 1)], w[("bias_ih", 1)],
                                    w[("bias_hh", 1)])
         y, h2, c2 = ops.lstm_layer(y, h0[1], c0[1], w[("weight_ih", 2)], w[("weight_hh", 2)], w[("bias_ih", 2)],
@@ -769,6 +774,12 @@ class _LSTMParams(_Site):
 
     def forward(self, x, hx):
         h0, c0 = hx
+        if self.nlayers == 2:
+            l1 = tuple(getattr(self, "%s_l0" % n) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+            l2 = tuple(getattr(self, "%s_l1" % n) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+            if ops.lstm_stack2_ok(x, l1[1], l2[1], l2[0]):  # wavefront on two streams, inter-layer dropout per chunk
+                y, (h1, h2), (c1, c2) = ops.lstm_stack2(x, h0, c0, l1, l2, self._drop(self.p, 0))
+                return y, (torch.stack([h1, h2]), torch.stack([c1, c2]))
         hs, cs = [], []
         for k in range(self.nlayers):
             x, h, c = ops.lstm_layer(x, h0[k], c0[k], getattr(self, "weight_ih_l%d" % k), getattr(self, "weight_hh_l%d" % k),

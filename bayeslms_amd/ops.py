@@ -18,7 +18,7 @@ from . import _lib as L
 from ._lib import BayesLMError, check, dev_tensor, lib, ptr, stream
 
 __all__ = ["Drop", "NoiseSpec", "ResidualLink", "linear", "bayes_linear", "ffn", "ffn_gp", "attention", "attention_qkv", "add_dropout_ln",
-           "embed", "add_pe", "dropout", "cross_entropy", "kl_mean", "philox_normal", "sample_weight", "sampled", "lstm_layer", "lstm_cell", "gp_mix", "add_rowvec",
+           "embed", "add_pe", "dropout", "cross_entropy", "kl_mean", "philox_normal", "sample_weight", "sampled", "lstm_layer", "lstm_stack2", "lstm_stack2_ok", "set_lstm_wavefront", "lstm_cell", "gp_mix", "add_rowvec",
            "clip_sgd", "gemm", "PtrTable", "set_grad_ready_hook", "set_embed_grad_sink", "rows_gather_add", "KernelTimer", "set_kernel_timer"]
 
 
@@ -760,15 +760,16 @@ class _Dropout(torch.autograd.Function):
         return _dropout_apply(_f32(dy, "dy"), ctx.drop), None
 
 
-def _dropout_apply(x, drop):
+def _dropout_apply(x, drop, row0=0, out=None):
+    """``row0``: x is the block of rows [row0, row0 + rows) of a longer (T, B, D) tensor and gets THAT block's mask."""
     D = x.shape[-1]
     B = x.shape[-2] if x.dim() >= 2 else 1
     rows = x.numel() // (B * D)
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
     L.require_gfx950()
     r = drop.rng()
-    check(lib().blm_dropout(ptr(x), ptr(y), rows, B, D, float(drop.p), C.byref(r), drop.col_offset,
-                            drop.global_cols or B, stream()), "blm_dropout")
+    check(lib().blm_dropout_rows(ptr(x), ptr(y), rows, int(row0), B, D, float(drop.p), C.byref(r), drop.col_offset,
+                                 drop.global_cols or B, stream()), "blm_dropout_rows")
     return y
 
 
@@ -1042,6 +1043,200 @@ def lstm_layer(x, h0, c0, w_ih, w_hh, b_ih, b_hh, noise_rows=None):
     """One LSTM layer over T steps.  ``noise_rows`` (T, H), optional: row t is added to every batch row
     of h_t after the cell and carried into step t+1 (VLSTMCell, reference model.py:2523-2527)."""
     return _LSTMLayer.apply(x, h0, c0, w_ih, w_hh, b_ih, b_hh, noise_rows)
+
+
+_SIDE_STREAM = None
+
+
+def _side_stream():
+    global _SIDE_STREAM
+    if _SIDE_STREAM is None:
+        _SIDE_STREAM = torch.cuda.Stream()
+    return _SIDE_STREAM
+
+
+def _stack_chunks(T):
+    """Time chunks of the layer wavefront: layer 2 runs one chunk behind layer 1.  Small enough that the lag is a
+    small part of T, large enough that the per-chunk input GEMM (M = chunk * B rows) and the host's event traffic stay
+    cheap."""
+    c = min(32, max(4, (T + 7) // 8))
+    return [(t0, min(T, t0 + c)) for t0 in range(0, T, c)]
+
+
+class _LSTMStack2(torch.autograd.Function):
+    """Two stacked LSTM layers as a WAVEFRONT on two streams (what _VF.lstm / nn.LSTM(num_layers=2) compute,
+    model.py:812, :35).  A fused step kernel occupies the chip for ~11 us but is bound by its launch -> load -> MFMA ->
+    store latency chain, and two of them fit a CU (70 KB LDS, <= 256 VGPRs each): the steps of layer 2 over time chunk c
+    run on a side stream WHILE layer 1 walks chunk c + 1 on the main stream (a step PAIR takes 15.4 us forward /
+    17.4 us backward against 21.7 / 26.5 us back to back; tools/lstm_step_bench.py).  Per chunk: layer 1's steps, event,
+    [inter-layer dropout of that chunk, RNNModel only], layer 2's input GEMM over the chunk's rows, layer 2's steps.
+    Backward mirrors it (layer 2's chain leads on the side stream, layer 1 follows a chunk behind behind the dgrad
+    GEMM of the chunk); the weight-gradient GEMMs stay batched over all T at the end.  Same kernels and the same
+    arithmetic per step as two ops.lstm_layer calls: results are bit-identical to them."""
+
+    @staticmethod
+    def forward(ctx, x, h0a, c0a, h0b, c0b, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, drop):
+        x = _f32(x, "x")
+        T, B, E = x.shape
+        H = w_hh1.shape[1]
+        G = 4 * H
+        dev = x.device
+        st = stream
+        lib_ = lib()
+        bias1, bias2 = b_ih1.clone(), b_ih2.clone()
+        check(lib_.blm_axpy(ptr(b_hh1), ptr(bias1), G, 1.0, st()), "blm_axpy")
+        check(lib_.blm_axpy(ptr(b_hh2), ptr(bias2), G, 1.0, st()), "blm_axpy")
+        xw1 = torch.empty(T, B, G, device=dev, dtype=torch.float32)
+        gemm(L.GEMM_NT, x, w_ih1, xw1, T * B, G, E, E, E, G, epilogue=L.EPI_BIAS, bias=bias1)
+        new = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
+        hs1, cs1, ga1 = new(T + 1, B, H), new(T + 1, B, H), new(T, B, G)
+        hs2, cs2, ga2 = new(T + 1, B, H), new(T + 1, B, H), new(T, B, G)
+        xw2 = new(T, B, G)
+        x2 = new(T, B, H) if drop.on else None  # layer 2's input = drop(h1) (nn.LSTM's inter-layer dropout)
+        hs1[0].copy_(h0a)
+        cs1[0].copy_(c0a)
+        hs2[0].copy_(h0b)
+        cs2[0].copy_(c0b)
+        main, side = torch.cuda.current_stream(), _side_stream()
+        tev = _TIMER.bracket("lstm_stack2_fwd T=%d" % T) if _TIMER is not None else None
+        if tev:
+            tev[0].record()
+        side.wait_stream(main)
+        bh, bg = B * H * 4, B * G * 4  # bytes per time row
+        p_xw1, p_xw2 = xw1.data_ptr(), xw2.data_ptr()
+        p = {k: v.data_ptr() for k, v in (("hs1", hs1), ("cs1", cs1), ("ga1", ga1), ("hs2", hs2), ("cs2", cs2), ("ga2", ga2))}
+        for (t0, t1) in _stack_chunks(T):
+            n = t1 - t0
+            check(lib_.blm_lstm_seq_fwd(p_xw1 + t0 * bg, ptr(w_hh1), p["hs1"] + t0 * bh, p["cs1"] + t0 * bh, p["ga1"] + t0 * bg,
+                                        None, n, B, H, st()), "blm_lstm_seq_fwd")
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                inp = hs1[t0 + 1:t1 + 1]
+                if drop.on:
+                    inp = _dropout_apply(inp, drop, row0=t0, out=x2[t0:t1])
+                gemm(L.GEMM_NT, inp, w_ih2, xw2[t0:t1], n * B, G, H, H, H, G, epilogue=L.EPI_BIAS, bias=bias2)
+                check(lib_.blm_lstm_seq_fwd(p_xw2 + t0 * bg, ptr(w_hh2), p["hs2"] + t0 * bh, p["cs2"] + t0 * bh,
+                                            p["ga2"] + t0 * bg, None, n, B, H, st()), "blm_lstm_seq_fwd")
+        main.wait_stream(side)
+        if tev:
+            tev[1].record()
+        if _STATE_TAP is not None:
+            _STATE_TAP.layers.append((hs1.index_select(0, _STATE_TAP.idx), cs1.index_select(0, _STATE_TAP.idx)))
+            _STATE_TAP.layers.append((hs2.index_select(0, _STATE_TAP.idx), cs2.index_select(0, _STATE_TAP.idx)))
+        ctx.save_for_backward(x, hs1, cs1, ga1, hs2, cs2, ga2, x2, w_ih1, w_hh1, w_ih2, w_hh2)
+        ctx.drop = drop
+        return hs2[1:], hs1[T], cs1[T], hs2[T], cs2[T]
+
+    @staticmethod
+    def backward(ctx, dy, dh1T, dc1T, dh2T, dc2T):
+        x, hs1, cs1, ga1, hs2, cs2, ga2, x2, w_ih1, w_hh1, w_ih2, w_hh2 = ctx.saved_tensors
+        drop = ctx.drop
+        T, B, E = x.shape
+        H = w_hh1.shape[1]
+        G = 4 * H
+        dev = x.device
+        lib_ = lib()
+        st = stream
+        dy = _f32(dy, "dy")
+        new = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
+        zeros = lambda *sh: torch.zeros(*sh, device=dev, dtype=torch.float32)  # noqa: E731
+
+        def state(dhT, dcT, w_hh):
+            dh = zeros(B, H) if dhT is None else _f32(dhT, "dhT").clone()
+            dcs = new(2, B, H)
+            if dcT is None:
+                dcs[0].zero_()
+            else:
+                dcs[0].copy_(_f32(dcT, "dcT"))
+            w_t = new(H, G)
+            check(lib_.blm_transpose(ptr(w_hh), ptr(w_t), G, H, st()), "blm_transpose")
+            return {"dh": dh, "dcs": dcs, "k": 0, "w_t": w_t, "dg": new(T, B, G)}
+        s1, s2 = state(dh1T, dc1T, w_hh1), state(dh2T, dc2T, w_hh2)
+        dy1 = new(T, B, H)  # gradient reaching layer 1's outputs = layer 2's input gradient
+        bh, bg = B * H * 4, B * G * 4
+
+        def chain(s, dyp, cs, ga, t_hi, t_lo):
+            """dgates[t] for t = t_hi-1 .. t_lo (descending) of one layer: the first launch of the whole chain is the plain
+            cell backward of step T-1, every other one the fused step (dh_t = dgates[t+1] . W_hh, then the cell of step t)."""
+            dg, dcs, w_t = s["dg"].data_ptr(), s["dcs"].data_ptr(), s["w_t"].data_ptr()
+            pcs, pga = cs.data_ptr(), ga.data_ptr()
+            for t in range(t_hi - 1, t_lo - 1, -1):
+                k = s["k"]
+                if t == T - 1:
+                    check(lib_.blm_lstm_cell_bwd2(ptr(s["dh"]), dyp + t * bh, dcs + k * bh, pcs + t * bh, pcs + (t + 1) * bh,
+                                                  pga + t * bg, dg + t * bg, dcs + (k ^ 1) * bh, B, H, st()), "blm_lstm_cell_bwd2")
+                else:
+                    check(lib_.blm_lstm_step_bwd(dg + (t + 1) * bg, w_t, dyp + t * bh, dcs + k * bh, pcs + t * bh, pcs + (t + 1) * bh,
+                                                 pga + t * bg, dg + t * bg, dcs + (k ^ 1) * bh, None, B, H, st()), "blm_lstm_step_bwd")
+                s["k"] = k ^ 1
+        main, side = torch.cuda.current_stream(), _side_stream()
+        dh01, dh02 = new(B, H), new(B, H)  # allocated on the main stream's pool, like everything else both streams touch
+        tev = _TIMER.bracket("lstm_stack2_bwd T=%d" % T) if _TIMER is not None else None
+        if tev:
+            tev[0].record()
+        side.wait_stream(main)
+        for (t0, t1) in reversed(_stack_chunks(T)):
+            with torch.cuda.stream(side):
+                chain(s2, dy.data_ptr(), cs2, ga2, t1, t0)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            main.wait_event(ev)
+            n = t1 - t0
+            gemm(L.GEMM_NN, s2["dg"][t0:t1], w_ih2, dy1[t0:t1], n * B, H, G, G, H, H)
+            if drop.on:
+                _dropout_apply(dy1[t0:t1], drop, row0=t0, out=dy1[t0:t1])
+            chain(s1, dy1.data_ptr(), cs1, ga1, t1, t0)
+        # gradient w.r.t. the initial states: dh_{-1} = dgates[0] . W_hh
+        for s, strm, d in ((s2, side, dh02), (s1, main, dh01)):
+            with torch.cuda.stream(strm):
+                check(lib_.blm_lstm_step_bwd(ptr(s["dg"][0]), ptr(s["w_t"]), None, None, None, None, None, None, None, ptr(d),
+                                             B, H, st()), "blm_lstm_step_bwd")
+        main.wait_stream(side)
+        if tev:
+            tev[1].record()
+        dc02, dc01 = s2["dcs"][s2["k"]], s1["dcs"][s1["k"]]
+        dg1, dg2 = s1["dg"], s2["dg"]
+        inp2 = x2 if drop.on else hs1[1:]
+        dx = torch.empty_like(x)
+        gemm(L.GEMM_NN, dg1, w_ih1, dx, T * B, E, G, G, E, E)
+        dw_ih1, dw_hh1, dw_ih2, dw_hh2 = torch.empty_like(w_ih1), torch.empty_like(w_hh1), torch.empty_like(w_ih2), torch.empty_like(w_hh2)
+        gemm(L.GEMM_TN, dg1, x, dw_ih1, G, E, T * B, G, E, E)
+        gemm(L.GEMM_TN, dg1, hs1, dw_hh1, G, H, T * B, G, H, H)  # hs[0:T] = h_{t-1}
+        gemm(L.GEMM_TN, dg2, inp2, dw_ih2, G, H, T * B, G, H, H)
+        gemm(L.GEMM_TN, dg2, hs2, dw_hh2, G, H, T * B, G, H, H)
+        db1, db2 = new(G), new(G)
+        _colsum_into(dg1, T * B, G, db1, accumulate=False)
+        _colsum_into(dg2, T * B, G, db2, accumulate=False)
+        return dx, dh01, dc01, dh02, dc02, dw_ih1, dw_hh1, db1, db1, dw_ih2, dw_hh2, db2, db2, None
+
+
+def lstm_stack2_ok(x, w_hh1, w_hh2, w_ih2):
+    """Shapes the layer wavefront takes: fused step kernels (H % 32 == 0, aligned, contiguous) and equal hidden sizes."""
+    T, B, _ = x.shape
+    H = w_hh1.shape[1]
+    return (T >= 8 and H % 32 == 0 and w_hh2.shape[1] == H and w_ih2.shape[1] == H and w_hh1.is_contiguous() and w_hh2.is_contiguous()
+            and w_hh1.data_ptr() % 16 == 0 and w_hh2.data_ptr() % 16 == 0 and (B * H) % 4 == 0 and _STACK2_ON)
+
+
+# Measured at cfg2 (T 35, B 64, H 1024; rocprofv3 trace + tools/bench_lstm.py): the chains do overlap (16-18 us per step PAIR),
+# but layer 2's per-chunk input GEMM (M = 320 rows: 36-46 us at 67 TF, against 70 us for ONE batched GEMM over all T) and the
+# one-chunk lag give the gain back: forward 935 us against 862 us, backward 1001 against 1008 us.  Off by default.
+_STACK2_ON = False
+
+
+def set_lstm_wavefront(on):
+    """True: two-layer LSTM stacks run as a wavefront on two streams (ops.lstm_stack2); default off (see above)."""
+    global _STACK2_ON
+    _STACK2_ON = bool(on)
+
+
+def lstm_stack2(x, h0, c0, layer1, layer2, drop=NO_DROP):
+    """Two stacked LSTM layers; ``h0`` / ``c0`` are (2, B, H), ``layer*`` = (w_ih, w_hh, b_ih, b_hh), ``drop`` the
+    inter-layer dropout (nn.LSTM's; NO_DROP for _VF.lstm(dropout=0.)).  -> (y (T,B,H), (h1T, h2T), (c1T, c2T))"""
+    y, h1, c1, h2, c2 = _LSTMStack2.apply(x, h0[0], c0[0], h0[1], c0[1], *layer1, *layer2, drop)
+    return y, (h1, h2), (c1, c2)
 
 
 class _LSTMRecurrentGP(torch.autograd.Function):

@@ -217,6 +217,10 @@ int blm_add_pe_dropout(const float* x, const float* pe, float* out, int T, int B
  * x is (rows, B, D) with the same global-column keying as above. */
 int blm_dropout(const float* x, float* y, int rows, int B, int D, float p, const blm_rng* rng, int col_offset,
                 int global_cols, void* stream);
+/* The same on rows [row0, row0 + rows) of a longer (T, B, D) tensor: x / y point at the block, the keep mask is the one
+ * blm_dropout would give those rows (the layer wavefront of a 2-layer LSTM applies the inter-layer dropout chunk by chunk). */
+int blm_dropout_rows(const float* x, float* y, int rows, int row0, int B, int D, float p, const blm_rng* rng, int col_offset,
+                     int global_cols, void* stream);
 
 /* Post-LN residual block tail (model.py:1041-1042,1044-1045):
  *   s = x + drop(y);  out = LayerNorm(s) * gamma + beta

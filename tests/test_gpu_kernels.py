@@ -662,3 +662,42 @@ def test_attention_unsupported_head_dim_is_loud(dev):
     qkv = torch.randn(4, 1, 3 * 520, device=dev, requires_grad=True)
     with pytest.raises(BayesLMError, match="head_dim"):
         ops.attention(qkv, 1)
+
+
+@pytest.mark.parametrize("T,B,E,H,p", [(12, 5, 24, 32, 0.0), (17, 3, 16, 64, 0.3), (35, 64, 1024, 1024, 0.0), (40, 1, 32, 64, 0.0)])
+def test_lstm_stack2_wavefront_equals_two_sequential_layers(dev, T, B, E, H, p):
+    """ops.lstm_stack2 (two layers as a wavefront on two streams, layer 2 one time chunk behind, inter-layer dropout
+    applied chunk by chunk with the whole tensor's mask) runs the same kernels on the same operands as two
+    ops.lstm_layer calls with ops.dropout between them: outputs and final states are bit-identical, gradients equal to summation order."""
+    ops = ops_mod()
+    ops.set_lstm_wavefront(True)
+    g = torch.Generator().manual_seed(21)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.2).to(dev)  # noqa: E731
+    x, h0, c0 = mk(T, B, E), mk(2, B, H), mk(2, B, H)
+    l1 = [mk(4 * H, E), mk(4 * H, H) * 0.5, mk(4 * H), mk(4 * H)]
+    l2 = [mk(4 * H, H), mk(4 * H, H) * 0.5, mk(4 * H), mk(4 * H)]
+    gy, gh, gc = mk(T, B, H), mk(2, B, H), mk(2, B, H)
+    drop = ops.Drop(p, 77, 3, 5, 0, B) if p > 0 else ops.NO_DROP
+
+    def run(wavefront):
+        leaves = [t.clone().requires_grad_(True) for t in [x, h0, c0] + l1 + l2]
+        xx, hh, cc = leaves[:3]
+        a1, a2 = leaves[3:7], leaves[7:11]
+        if wavefront:
+            assert ops.lstm_stack2_ok(xx, a1[1], a2[1], a2[0])
+            y, (h1, h2), (c1, c2) = ops.lstm_stack2(xx, hh, cc, a1, a2, drop)
+        else:
+            y1, h1, c1 = ops.lstm_layer(xx, hh[0], cc[0], *a1)
+            y, h2, c2 = ops.lstm_layer(ops.dropout(y1, drop), hh[1], cc[1], *a2)
+        loss = (y * gy).sum() + (h1 * gh[0]).sum() + (h2 * gh[1]).sum() + (c1 * gc[0]).sum() + (c2 * gc[1]).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        return [y.detach(), h1.detach(), c1.detach(), h2.detach(), c2.detach()] + [t.grad for t in leaves]
+    a, b = run(True), run(False)
+    ops.set_lstm_wavefront(False)
+    names = "y h1 c1 h2 c2 dx dh0 dc0 dw_ih1 dw_hh1 db_ih1 db_hh1 dw_ih2 dw_hh2 db_ih2 db_hh2".split()
+    for u, v, n in zip(a, b, names):
+        if n.startswith("d"):  # layer 1's dy comes out of a dgrad GEMM per chunk instead of one over all T (different tile /
+            assert rel(u, v) < 2e-5, n  # split-K summation order); the batched wgrad GEMMs use float atomics
+        else:
+            assert torch.equal(u, v), n

@@ -9,7 +9,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from bayeslms_amd import engine, model as M  # noqa: E402
+from bayeslms_amd import engine, model as M, ops  # noqa: E402
 from bayeslms_amd.data import batchify, get_batch, synthetic_corpus  # noqa: E402
 
 
@@ -25,16 +25,24 @@ def main():
     kl_fn.fusable = False
     hidden = m.init_hidden(B)
     t0 = None
+    if os.environ.get("WAVEFRONT", "0") == "1":
+        ops.set_lstm_wavefront(True)
+    timer = ops.KernelTimer()
     for i in range(steps + warm):
         if i == warm:
             torch.cuda.synchronize()
+            ops.set_kernel_timer(timer)
             t0 = time.perf_counter()
         data, tgt = get_batch(train, i * T, T)
         hidden = M.repackage_hidden(hidden)
         loss, kl, hidden = tr.step(data, tgt, hidden, kl_fn)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    ops.set_kernel_timer(None)
     print("cfg2 Bayes LSTM pos3 2x1024 B64 T35 V33000: %.2f ms/step, %.0f tokens/s, loss %.4f" % (1e3 * dt, T * B / dt, float(loss)))
+    for k, v in timer.summary().items():
+        if k.startswith("lstm"):
+            print("   %-24s %.1f us per launch bracket (n=%d)" % (k, 1e3 * v["avg_ms"], v["n"]))
 
 
 if __name__ == "__main__":
