@@ -135,19 +135,29 @@ def compute_scores(nbest, model, vocab, model_type, device, model_2=None, alpha=
     return scores
 
 
-def _batch_nll(model, data, target_flat, model_type, hidden, model_2, hidden_2, alpha):
-    """Per-token NLL (T, N) of a padded batch of hypotheses (all columns start from the same state)."""
+def _batch_nll(model, data, target_flat, model_type, hidden, model_2, hidden_2, alpha, rows=None):
+    """Per-token NLL of a padded batch of hypotheses (all columns start from the same state): (T, N), or -- with
+    ``rows`` (flat indices t*N + n of the real tokens) -- one value per selected row, the decoder being applied to those
+    rows only (model._ProjHolder.rows)."""
     from . import ops
-    if model_type == 'Transformer':
-        out = model(data)
-    else:
-        out, _ = model(data, hidden)
-    if model_2 is not None:
-        out2 = model_2(data) if model_type == 'Transformer' else model_2(data, hidden_2)[0]
-        _, nll = ops.cross_entropy_interp(out.view(-1, out.shape[-1]), out2.view(-1, out2.shape[-1]), alpha, target_flat)
-    else:
-        _, nll = ops.cross_entropy(out.view(-1, out.shape[-1]), target_flat)
-    return nll.view(data.shape[0], data.shape[1])
+    for m in (model, model_2):
+        if m is not None:
+            m.decoder.rows = rows
+    try:
+        if model_type == 'Transformer':
+            out = model(data)
+        else:
+            out, _ = model(data, hidden)
+        if model_2 is not None:
+            out2 = model_2(data) if model_type == 'Transformer' else model_2(data, hidden_2)[0]
+            _, nll = ops.cross_entropy_interp(out.view(-1, out.shape[-1]), out2.view(-1, out2.shape[-1]), alpha, target_flat)
+        else:
+            _, nll = ops.cross_entropy(out.view(-1, out.shape[-1]), target_flat)
+    finally:
+        for m in (model, model_2):
+            if m is not None:
+                m.decoder.rows = None
+    return nll if rows is not None else nll.view(data.shape[0], data.shape[1])
 
 
 def _carry(model, x0, hidden):
@@ -233,15 +243,25 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
         pairs = [p for _, _, ps in group for p in ps]
         lens = [len(x) for x, _ in pairs]
         Tm, N = max(lens), len(pairs)
-        # one host buffer [data | targets | lengths] -> ONE host-to-device copy per batch
-        host = np.zeros((2 * Tm + 1, N), dtype=np.int64)
+        # one host buffer [data | real-token rows | their targets | hypothesis ends] -> ONE host-to-device copy per batch.
+        # Only the REAL tokens reach the decoder GEMM and the cross entropy (the bulk of the work: 2*d*V flops per token):
+        # the decoder gathers rows t*N + n, n-major, so a hypothesis' tokens are contiguous and its score is a difference
+        # of a running sum (padding was 40-50 % of a batch of AMI-shaped hypotheses).
+        R = int(sum(lens))
+        host = np.zeros(Tm * N + 2 * R + N, dtype=np.int64)
+        dat = host[:Tm * N].reshape(Tm, N)
+        sel, tsel, ends = host[Tm * N:Tm * N + R], host[Tm * N + R:Tm * N + 2 * R], host[Tm * N + 2 * R:]
+        o = 0
         for n, (x, t) in enumerate(pairs):
-            host[:lens[n], n] = x
-            host[Tm:Tm + lens[n], n] = t
-        host[2 * Tm] = lens
+            ln = lens[n]
+            dat[:ln, n] = x
+            sel[o:o + ln] = np.arange(ln, dtype=np.int64) * N + n
+            tsel[o:o + ln] = t
+            o += ln
+            ends[n] = o
         dev_buf = torch.from_numpy(host).to(device, non_blocking=True)
-        data, tgt = dev_buf[:Tm], dev_buf[Tm:2 * Tm].contiguous()
-        mask = (torch.arange(Tm, device=device).unsqueeze(1) < dev_buf[2 * Tm].unsqueeze(0)).float()
+        data = dev_buf[:Tm * N].view(Tm, N)
+        d_sel, d_tsel, d_ends = dev_buf[Tm * N:Tm * N + R], dev_buf[Tm * N + R:Tm * N + 2 * R], dev_buf[Tm * N + 2 * R:]
         hN = h2N = None
         if is_rnn:  # every column starts from the state carried into ITS utterance
             counts = [len(ps) for _, _, ps in group]
@@ -253,8 +273,10 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
         for smp in range(S):
             if mc_samples > 0:
                 model.set_step(smp)
-            nll = _batch_nll(model, data, tgt.view(-1), model_type, hN, model_2, h2N, alpha)
-            sent.append((nll * mask).sum(0))
+            nll = _batch_nll(model, data, d_tsel, model_type, hN, model_2, h2N, alpha, rows=d_sel)  # (R,)
+            run = torch.cumsum(nll.double(), 0)
+            hi = run[d_ends - 1]
+            sent.append((hi - torch.cat([hi.new_zeros(1), hi[:-1]])).float())
         if S == 1:
             tot = sent[0]
         else:

@@ -162,7 +162,13 @@ class _ProjHolder(nn.Module):
         self.weight, self.bias = lin.weight, lin.bias
         self.in_features, self.out_features = in_f, out_f
 
+    rows = None  # inference only (the n-best scorer): apply the projection to these flat rows of x, not to all of them
+
     def forward(self, x, link=None):
+        if self.rows is not None:
+            if torch.is_grad_enabled():
+                raise BayesLMError("_ProjHolder.rows is an inference-only row selection")
+            x = x.reshape(-1, x.shape[-1]).index_select(0, self.rows)
         return ops.linear(x, self.weight, self.bias, link)
 
 
