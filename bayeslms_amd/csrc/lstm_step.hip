@@ -62,8 +62,12 @@ struct LstmStepP {
 // NW = waves per workgroup = K slices: 4 (one wave per SIMD, two staging buffers each) or 8 (two waves per SIMD with one
 // staging buffer each: while one wave of a SIMD stages its next chunk through LDS -- 16 ds_write_b128 + 16 ds_read_b128
 // that a single in-order wave cannot overlap with its own dependent MFMA chain -- the other one keeps the matrix pipe busy).
-template <int RING, int NS = 4, bool REFILL = true, int NW = 4>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_step_fwd_kernel(const LstmStepP p) {
+// PIPE (RING = 2, even nchunk): the K loop is software pipelined inside the wave -- while the 32 dependent MFMAs of
+// chunk c execute, the wave issues chunk c + 1's LDS writes, the ring refill and chunk c + 1's fragment reads BETWEEN
+// them (a dependent MFMA stalls the in-order wave for ~60 cycles at issue: room for one LDS instruction per MFMA), into a
+// second fragment register set.  ~310 VGPRs: one workgroup per CU.
+template <int RING, int NS = 4, bool REFILL = true, int NW = 4, bool PIPE = false>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 1 : 2, PIPE ? 1 : 2))) void lstm_step_fwd_kernel(const LstmStepP p) {
   constexpr int U = 32 / NS;  // hidden units per workgroup
   // ONE staging buffer per wave (LDS runs a wave's instructions in order and the fragments are in registers before the
   // MFMAs start, so the next chunk may overwrite the tile): 70 KB per 4-wave workgroup and <= 256 VGPRs per wave, i.e. TWO
@@ -168,7 +172,100 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int g = 0; g < NS; ++g) xg[g] = p.xw[o + (long)g * H];
     cprev = p.cprev[(long)eb * H + ej];
   }
-  if constexpr (REFILL) {
+  if constexpr (PIPE) {
+    static_assert(RING == 2 && NBUF == 1, "the pipelined loop walks chunk pairs through one staging tile");
+    float4 fa[2][8], fw[2][8];  // fragment sets: one feeds the MFMAs while the other is filled
+    float* dst = base + soff;
+    const float* at = base + li * LSTR + lh * 32;
+    const float* wt = at + TILE;
+    auto put2 = [&](float4 (&a)[8], float4 (&w)[8], int c, int q0) {  // 4 ds_write_b128: rows q0, q0 + 1 of both tiles
+      const bool in = 32 * c + 4 * spart < Kh;
+#pragma unroll
+      for (int q = q0; q < q0 + 2; ++q) {
+        const float4 x = a[q], y = w[q];
+        *reinterpret_cast<float4*>(dst + 4 * q * LSTR) = make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
+        *reinterpret_cast<float4*>(dst + TILE + 4 * q * LSTR) = make_float4(in ? y.x : 0.f, in ? y.y : 0.f, in ? y.z : 0.f, in ? y.w : 0.f);
+      }
+    };
+    auto refill2 = [&](float4 (&a)[8], float4 (&w)[8], int c, int q0) {  // 4 global loads of chunk c into the freed registers
+      const int off = min(32 * min(c, nchunk - 1) + 4 * spart, Kh - 4) - 4 * spart;
+#pragma unroll
+      for (int q = q0; q < q0 + 2; ++q) {
+        a[q] = *reinterpret_cast<const float4*>(arow[q] + off);
+        w[q] = *reinterpret_cast<const float4*>(wrow[q] + off);
+      }
+    };
+    auto get2 = [&](float4 (&fa_)[8], float4 (&fw_)[8], int j0) {  // 4 ds_read_b128
+#pragma unroll
+      for (int j = j0; j < j0 + 2; ++j) {
+        fa_[j] = *reinterpret_cast<const float4*>(at + 4 * j);
+        fw_[j] = *reinterpret_cast<const float4*>(wt + 4 * j);
+      }
+    };
+    auto mfma4 = [&](const float4& a, const float4& w) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
+    };
+    // MFMAs of the fragments in (ca, cw) interleaved with the staging of chunk cn (registers a, w) into (na, nw): 32 slots
+    // of ONE MFMA + ONE LDS instruction (+ one refill load), each its own scheduling region so that the order survives
+    auto comp = [](const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); };
+    auto comb = [&](const float4 (&ca)[8], const float4 (&cw)[8], float4 (&a)[8], float4 (&w)[8], int cn, float4 (&na)[8],
+                    float4 (&nw)[8]) {
+      const bool in = 32 * cn + 4 * spart < Kh;
+      const int off = min(32 * min(cn + RING, nchunk - 1) + 4 * spart, Kh - 4) - 4 * spart;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(ca[k >> 2], k & 3), comp(cw[k >> 2], k & 3), acc, 0, 0, 0);
+        if (k < 16) {  // ds_write_b128 of the next chunk: k even -> h tile row q, k odd -> W tile row q
+          const int q = k >> 1;
+          if ((k & 1) == 0) {
+            const float4 x = a[q];
+            *reinterpret_cast<float4*>(dst + 4 * q * LSTR) = make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
+            if constexpr (REFILL) a[q] = *reinterpret_cast<const float4*>(arow[q] + off);
+          } else {
+            const float4 y = w[q];
+            *reinterpret_cast<float4*>(dst + TILE + 4 * q * LSTR) = make_float4(in ? y.x : 0.f, in ? y.y : 0.f, in ? y.z : 0.f, in ? y.w : 0.f);
+            if constexpr (REFILL) w[q] = *reinterpret_cast<const float4*>(wrow[q] + off);
+          }
+          if (k == 15) {  // the tile is complete before it is read back (compiler order only; LDS is in order per wave)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        } else {        // ds_read_b128 of the next chunk's fragments
+          const int j = (k - 16) >> 1;
+          if ((k & 1) == 0) na[j] = *reinterpret_cast<const float4*>(at + 4 * j);
+          else nw[j] = *reinterpret_cast<const float4*>(wt + 4 * j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+    // prologue: chunk 0 staged alone
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      put2(ra[0], rw[0], 0, 2 * j);
+      if constexpr (REFILL) refill2(ra[0], rw[0], RING, 2 * j);
+    }
+    LSTM_STAMP(1);
+#ifdef BLM_LSTM_PROF
+    if (lane == 0) stamps[6] = clock64();
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) get2(fa[0], fw[0], 2 * j);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int cc = 0; cc + 2 < nchunk; cc += 2) {
+      comb(fa[0], fw[0], ra[1], rw[1], cc + 1, fa[1], fw[1]);
+      comb(fa[1], fw[1], ra[0], rw[0], cc + 2, fa[0], fw[0]);
+    }
+    comb(fa[0], fw[0], ra[1], rw[1], nchunk - 1, fa[1], fw[1]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mfma4(fa[1][j], fw[1][j]);
+  } else if constexpr (REFILL) {
 #pragma unroll 1
     for (int cc = 0; cc < nchunk; cc += RING) {  // nchunk % RING == 0 (host picks RING)
 #pragma unroll
@@ -357,8 +454,8 @@ struct LstmBwdP {
   int G;                                  // contraction length = row length of dg and wt: 4H (LSTM), 8H (search cell)
 };
 
-template <int RING, bool REFILL = true, int NW = 4>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_step_bwd_kernel(const LstmBwdP p) {
+template <int RING, bool REFILL = true, int NW = 4, bool PIPE = false>  // PIPE: software-pipelined K loop, see the forward kernel
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 1 : 2, PIPE ? 1 : 2))) void lstm_step_bwd_kernel(const LstmBwdP p) {
   constexpr int NBUF = 1;  // see the forward kernel; NW = 8 (two waves per SIMD): plain / GP cells only
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
@@ -456,7 +553,75 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   }
 
-  if constexpr (REFILL) {
+  if constexpr (PIPE) {
+    static_assert(RING == 2 && NBUF == 1 && REFILL, "the pipelined loop walks chunk pairs through one staging tile");
+    float4 fa[2][8], fw[2][8];
+    float* dst = base + soff;
+    const float* at = base + li * BSTR + lq * BQ;
+    const float* wt = at + BTILE;
+    auto comp = [](const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); };
+    // 32 slots of ONE MFMA + ONE LDS instruction (+ one refill load), each its own scheduling region
+    auto comb = [&](const float4 (&ca)[8], const float4 (&cw)[8], float4 (&a)[8], float4 (&w)[8], int cn, float4 (&na)[8],
+                    float4 (&nw)[8]) {
+      const bool in = 32 * cn + 4 * spart < Kq;
+      const int off = min(32 * min(cn + RING, nchunk - 1) + 4 * spart, Kq - 4) - 4 * spart;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(ca[k >> 2], k & 3), comp(cw[k >> 2], k & 3), acc, 0, 0, 0);
+        if (k < 16) {
+          const int q = k >> 1;
+          if ((k & 1) == 0) {
+            const float4 x = a[q];
+            *reinterpret_cast<float4*>(dst + 2 * q * BSTR) = make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
+            a[q] = *reinterpret_cast<const float4*>(arow[q] + off);
+          } else {
+            const float4 y = w[q];
+            *reinterpret_cast<float4*>(dst + BTILE + 2 * q * BSTR) = make_float4(in ? y.x : 0.f, in ? y.y : 0.f, in ? y.z : 0.f, in ? y.w : 0.f);
+            w[q] = *reinterpret_cast<const float4*>(wrow[q] + off);
+          }
+          if (k == 15) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        } else {
+          const int j = (k - 16) >> 1;
+          if ((k & 1) == 0) na[j] = *reinterpret_cast<const float4*>(at + 4 * j);
+          else nw[j] = *reinterpret_cast<const float4*>(wt + 4 * j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+    {  // prologue: chunk 0 staged alone
+      const bool in = 4 * spart < Kq;
+      const int off = min(32 * min(RING, nchunk - 1) + 4 * spart, Kq - 4) - 4 * spart;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 x = ra[0][q], y = rw[0][q];
+        *reinterpret_cast<float4*>(dst + 2 * q * BSTR) = make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
+        *reinterpret_cast<float4*>(dst + BTILE + 2 * q * BSTR) = make_float4(in ? y.x : 0.f, in ? y.y : 0.f, in ? y.z : 0.f, in ? y.w : 0.f);
+        ra[0][q] = *reinterpret_cast<const float4*>(arow[q] + off);
+        rw[0][q] = *reinterpret_cast<const float4*>(wrow[q] + off);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        fa[0][j] = *reinterpret_cast<const float4*>(at + 4 * j);
+        fw[0][j] = *reinterpret_cast<const float4*>(wt + 4 * j);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll 1
+    for (int cc = 0; cc + 2 < nchunk; cc += 2) {
+      comb(fa[0], fw[0], ra[1], rw[1], cc + 1, fa[1], fw[1]);
+      comb(fa[1], fw[1], ra[0], rw[0], cc + 2, fa[0], fw[0]);
+    }
+    comb(fa[0], fw[0], ra[1], rw[1], nchunk - 1, fa[1], fw[1]);
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(fa[1][k >> 2], k & 3), comp(fw[1][k >> 2], k & 3), acc, 0, 0, 0);
+  } else if constexpr (REFILL) {
 #pragma unroll 1
     for (int cc = 0; cc < nchunk; cc += RING) {
 #pragma unroll
@@ -570,6 +735,15 @@ static int lstm_gemv() {  // BLM_LSTM_GEMV=0 disables the tiny-batch step kernel
   return v;
 }
 
+static int lstm_pipe() {  // BLM_LSTM_PIPE=0|1: software-pipelined K loop of the step kernels (A/B measurements)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("BLM_LSTM_PIPE");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
 static int lstm_waves() {  // BLM_LSTM_WAVES=4|8 (A/B measurements)
   static int v = -1;
   if (v < 0) {
@@ -616,6 +790,7 @@ extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const 
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, true, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<1, 4, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
@@ -629,7 +804,8 @@ extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const 
     if (nc8 == 2) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, false, 8>), grid, dim3(512), lds8, st, p);
     else if (nc8 % 2 == 0) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, true, 8>), grid, dim3(512), lds8, st, p);
     else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 4, true, 8>), grid, dim3(512), lds8, st, p);
-  } else if (nchunk == 2) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, false>), grid, block, lds4, st, p);
+  } else if (nchunk % 2 == 0 && nchunk >= 4 && lstm_pipe()) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, true, 4, true>), grid, block, lds4, st, p);
+  else if (nchunk == 2) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, false>), grid, block, lds4, st, p);
   else if (nchunk % 2 == 0) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4>), grid, block, lds4, st, p);
   else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 4>), grid, block, lds4, st, p);
   BLM_HIP(hipGetLastError());
@@ -687,6 +863,7 @@ static int launch_step_bwd(const LstmBwdP& p, void* stream) {
   if (!once) {
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((lstm_step_bwd_kernel<2, true, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((lstm_step_bwd_kernel<2, true, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((lstm_step_bwd_kernel<1, true, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
     once = true;
@@ -698,7 +875,8 @@ static int launch_step_bwd(const LstmBwdP& p, void* stream) {
     const int nc8 = (p.G / 32 + 31) / 32;
     if (nc8 % 2 == 0) hipLaunchKernelGGL((lstm_step_bwd_kernel<2, true, 8>), grid, dim3(512), lds8, st, p);
     else hipLaunchKernelGGL((lstm_step_bwd_kernel<1, true, 8>), grid, dim3(512), lds8, st, p);
-  } else if (nchunk % 2 == 0) hipLaunchKernelGGL(lstm_step_bwd_kernel<2>, grid, block, lds4, st, p);
+  } else if (nchunk % 2 == 0 && nchunk >= 4 && lstm_pipe()) hipLaunchKernelGGL((lstm_step_bwd_kernel<2, true, 4, true>), grid, block, lds4, st, p);
+  else if (nchunk % 2 == 0) hipLaunchKernelGGL(lstm_step_bwd_kernel<2>, grid, block, lds4, st, p);
   else hipLaunchKernelGGL(lstm_step_bwd_kernel<1>, grid, block, lds4, st, p);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
