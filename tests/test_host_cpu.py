@@ -155,8 +155,9 @@ def _reducer_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_grad_reducer_gloo_world2():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 3])
+def test_grad_reducer_gloo_world2(world):
+    port = _free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_reducer_worker, args=(world, port, ret), nprocs=world, join=True)
@@ -215,8 +216,9 @@ def _late_rows_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_late_rows_gloo_world2():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4])
+def test_late_rows_gloo_world2(world):
+    port = _free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_late_rows_worker, args=(world, port, ret), nprocs=world, join=True)
