@@ -1210,19 +1210,48 @@ int launch_op(const GemmP& p, hipStream_t st) {
     if (b128 >= 96) small_m = small_n = false;
     else if (t12 >= 64) { small_m = true; small_n = false; }
     else small_m = small_n = true;
-  } else if (p.K <= 1024 && b128 >= 256 && b128 < 1024 && p.M >= 128 && p.N >= 128) {
-    small_m = true; small_n = false;
+  } else if (p.K <= 1024 && b128 >= 256 && p.M >= 128 && p.N >= 128) {
+    // short reductions cannot be split: pick the tile whose grid fills whole rounds of the 512 workgroup slots
+    auto fill = [](long g) { return (double)g / (double)(((g + 511) / 512) * 512); };
+    const long t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128), t11 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    if (b128 < 1024) {
+      small_m = true; small_n = false;
+      // 2240x4096x1024 (LSTM input GEMM): 1120 tiles of 64x128 = 2.2 rounds (117 TF), 2240 of 64x64 = 4.4 (127 TF)
+      if (fill(t11) > fill(t12) + 0.1) small_n = true;
+    } else if (fill(t12) > fill(b128) + 0.05) {  // decoder forward at M = 2240: 4644 tiles = 9.07 rounds -> 64x128 tiles (+2 %)
+      small_m = true; small_n = false;
+    }
   }
   if (OP == BLM_GEMM_TN && p.epi == BLM_EPI_BAYES_WGRAD && !(can_split && p.K >= 2048)) small_m = small_n = true;
+  // measured on the cfg2 shapes (M = T*B = 2240; CFG=2 tools/gemm_sweep.sh), which the rules above -- tuned at M = 8192 --
+  // served badly:
+  //  * weight gradients with a medium reduction (2048 <= K < 4096: no 4-slice rule) whose 128x128 grid fills the 512
+  //    workgroup slots badly -- 256 tiles = half of them (dW_ih / dW_hh 4096x1024x2240: 115 TF), 2064 tiles = 4.03 rounds
+  //    (decoder dW 33000x1024x2240: 120 TF) -- run on 64x128 tiles, twice the workgroups (126 TF both);
+  //  * input gradients with a medium reduction and a 128x128 grid under one round (dX 2240x1024x4096: 144 tiles, 7 K
+  //    slices with atomics: 101 TF) run on 128x64 tiles when those fill a round (288 tiles x the slice count of the fill rule: 115 TF); a very long
+  //    reduction (decoder dX, K = 33000) keeps the split 128x128 form (131 TF against 126).
+  GemmP pf = p;
+  if (can_split && p.K >= 2048 && p.M > 64 && p.N > 64 && b128 >= 96) {
+    if (OP == BLM_GEMM_TN && p.K < 4096) {
+      const long t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
+      auto fill = [](long g) { return (double)g / (double)(((g + 511) / 512) * 512); };
+      if (fill(t12) > fill(b128) + 0.05) { small_m = true; small_n = false; }
+    } else if (OP == BLM_GEMM_NN && p.K <= 8192 && b128 < 256) {
+      const long t21 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
+      if (t21 >= 256) { small_m = false; small_n = true; }
+    }
+  }
   if (p.force_tile == 11) { small_m = small_n = true; }
   else if (p.force_tile == 12) { small_m = true; small_n = false; }
   else if (p.force_tile == 21) { small_m = false; small_n = true; }
   else if (p.force_tile == 22) { small_m = small_n = false; }
-  if (!p.fast) return launch_cfg<OP, 1, 1, SAMP, false>(p, st);  // odd shapes/alignments: guarded loaders only
-  if (small_m && small_n) return launch_cfg<OP, 1, 1, SAMP, true>(p, st);
-  if (small_m) return launch_cfg<OP, 1, 2, SAMP, true>(p, st);
-  if (small_n) return launch_cfg<OP, 2, 1, SAMP, true>(p, st);
-  return launch_cfg<OP, 2, 2, SAMP, true>(p, st);
+  if (p.force_splits > 0) pf.force_splits = p.force_splits;
+  if (!p.fast) return launch_cfg<OP, 1, 1, SAMP, false>(pf, st);  // odd shapes/alignments: guarded loaders only
+  if (small_m && small_n) return launch_cfg<OP, 1, 1, SAMP, true>(pf, st);
+  if (small_m) return launch_cfg<OP, 1, 2, SAMP, true>(pf, st);
+  if (small_n) return launch_cfg<OP, 2, 1, SAMP, true>(pf, st);
+  return launch_cfg<OP, 2, 2, SAMP, true>(pf, st);
 }
 
 }  // namespace blm

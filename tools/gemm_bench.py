@@ -20,6 +20,14 @@ SHAPES = [  # (name, op, M, N, K)
     ("qkv_wgrad  TN", L.GEMM_TN, 1536, 512, M), ("o_wgrad    TN", L.GEMM_TN, 512, 512, M),
     ("dec_wgrad  TN", L.GEMM_TN, 33000, 512, M),
 ]
+M2 = 2240  # BASELINE configs[1] (LSTM 2x1024, T 35 x B 64): CFG=2 selects these
+SHAPES2 = [
+    ("c2dec_fwd   NT", L.GEMM_NT, M2, 33000, 1024), ("c2dec_dgrad NN", L.GEMM_NN, M2, 1024, 33000),
+    ("c2dec_wgrad TN", L.GEMM_TN, 33000, 1024, M2), ("c2in_fwd    NT", L.GEMM_NT, M2, 4096, 1024),
+    ("c2in_dgrad  NN", L.GEMM_NN, M2, 1024, 4096), ("c2in_wgrad  TN", L.GEMM_TN, 4096, 1024, M2),
+]
+if os.environ.get("CFG") == "2":
+    SHAPES = SHAPES2
 
 
 def main():
