@@ -1210,7 +1210,7 @@ int launch_op(const GemmP& p, hipStream_t st) {
     if (b128 >= 96) small_m = small_n = false;
     else if (t12 >= 64) { small_m = true; small_n = false; }
     else small_m = small_n = true;
-  } else if (p.K <= 1024 && b128 >= 256 && p.M >= 128 && p.N >= 128) {
+  } else if (p.K < 2048 && b128 >= 256 && p.M >= 128 && p.N >= 128) {  // (K = 1536: the qkv input gradient, 122 -> 112 us)
     // short reductions cannot be split: pick the tile whose grid fills whole rounds of the 512 workgroup slots
     auto fill = [](long g) { return (double)g / (double)(((g + 511) / 512) * 512); };
     const long t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128), t11 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
@@ -1222,7 +1222,13 @@ int launch_op(const GemmP& p, hipStream_t st) {
       small_m = true; small_n = false;
     }
   }
-  if (OP == BLM_GEMM_TN && p.epi == BLM_EPI_BAYES_WGRAD && !(can_split && p.K >= 2048)) small_m = small_n = true;
+  // measured INSIDE the cfg3 step (tools/step_breakdown.py under BLM_GEMM_TILE; the stand-alone sweep runs colder and ranks
+  // these differently): a forward product whose 128x128 grid is exactly half a round (8192 x 512: 256 tiles, one workgroup
+  // = one wave per SIMD on every CU) and whose K is too short to split runs 4-5 % faster on 128x64 tiles = 512 workgroups,
+  // two waves per SIMD (Bayesian FFN linear2 forward, the roofline kernel: 271 -> 257 us = 134 TF)
+  if (OP == BLM_GEMM_NT && !small_m && !small_n && b128 >= 256 && b128 < 384 && p.K >= 2048 && p.K <= 8192) small_n = true;
+  // the Bayesian wgrad epilogue (Philox + two outputs per element) is lighter per workgroup on 64x64 tiles (338 -> 315 us)
+  if (OP == BLM_GEMM_TN && p.epi == BLM_EPI_BAYES_WGRAD) small_m = small_n = true;
   // measured on the cfg2 shapes (M = T*B = 2240; CFG=2 tools/gemm_sweep.sh), which the rules above -- tuned at M = 8192 --
   // served badly:
   //  * weight gradients with a medium reduction (2048 <= K < 4096: no 4-slice rule) whose 128x128 grid fills the 512
