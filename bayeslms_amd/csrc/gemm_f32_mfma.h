@@ -1144,7 +1144,7 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   // weight-gradient layout with a long reduction: 4 K slices even when the output grid alone fills the
   // chip -- the workgroups of one slice then share the same rows of both operands in L2
   // (decoder dW 33000x512x8192: 102 -> 120 TFLOP/s, tools/gemm_sweep.sh)
-  if (OP == BLM_GEMM_TN && can_split && p.K >= 4096 && splits < 4) splits = 4;
+  if (OP == BLM_GEMM_TN && can_split && p.K >= 4096 && splits < 4) splits = p.epi == BLM_EPI_BAYES_WGRAD ? 2 : 4;  // (in-situ: 308 -> 292 us with 2)
   if (p.force_splits > 0 && can_split) splits = p.force_splits;
   q.splits = splits;
   q.kper = splits > 1 ? ((p.K + splits - 1) / splits + BK - 1) / BK * BK : (p.K > 0 ? p.K : 1);

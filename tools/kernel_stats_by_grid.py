@@ -1,7 +1,7 @@
 """Per (kernel, grid size) duration summary of a rocprofv3 --kernel-trace CSV.  The GEMM template is
 one symbol for many shapes, so the plain --stats table averages them together; this table keeps the
 launches of one shape apart (the roofline kernel of bench.py -- Bayesian FFN linear2 forward,
-M=8192 N=512 K=4096 -- is gemm_f32_kernel<0, 2, 2, false, true> with 65536 threads = 256 tiles).
+M=8192 N=512 K=4096 -- is gemm_f32_kernel<0, 2, 1, false, true> with 131072 threads = 512 tiles of 128x64).
 Usage: python tools/kernel_stats_by_grid.py <kernel_trace.csv> <out.csv>"""
 import collections
 import csv

@@ -2,14 +2,14 @@
 collected separately), corrected as MI355X_MICROARCH.md prescribes for gfx950:
 bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Usage:
   python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
-The kernel is the Bayesian FFN linear2 forward GEMM: gemm_f32_kernel<0,2,2,false,true> launched with
-65536 threads (256 output tiles, no split-K); epilogue NONE distinguishes it from the bias launches, checked through the launch count."""
+The kernel is the Bayesian FFN linear2 forward GEMM: gemm_f32_kernel<0,2,1,false,true> (128x64 tiles) launched with
+131072 threads (512 output tiles, no split-K); the six linear2 forwards of a step (one sampled, five with bias) share the shape."""
 import csv
 import json
 import sys
 
-KERNEL = "void blm::gemm_f32_kernel<0, 2, 2, false, true"  # + the GEMM-mode parameter, prefix match
-GRID = "65536"
+KERNEL = "void blm::gemm_f32_kernel<0, 2, 1, false, true"  # 128x64 tiles; + the GEMM-mode parameter, prefix match
+GRID = "131072"  # 512 workgroups = 64 x 8 tiles
 
 
 def avg(path, counter):
