@@ -15,19 +15,33 @@ def main():
     train = batchify(stream, B, dev)
     torch.manual_seed(1111)
     gauss = len(sys.argv) > 1 and sys.argv[1] == "gauss"
-    model = (M.GaussTransformerModel(V, D, H, FF, NL, 0.2, True, 3) if gauss else M.BayesTransformerModel(V, D, H, FF, NL, 0.2, True, "FFN")).to(dev)
+    lstm = len(sys.argv) > 1 and sys.argv[1] == "lstm"  # BASELINE configs[1]: Bayesian LSTM pos 3, T 35
+    if lstm:
+        T = 35
+        train = batchify(synthetic_corpus(V, B * ((steps + 12) * T + 1) + 17, seed=1111), B, dev)
+        model = M.BayesRNNModel("LSTM", V, 1024, 1024, 2, 0.2, True, 3).to(dev)
+        kl_fn = lambda mm: mm.rnn.kl_divergence()
+        kl_fn.fusable = False
+    else:
+        model = (M.GaussTransformerModel(V, D, H, FF, NL, 0.2, True, 3) if gauss else M.BayesTransformerModel(V, D, H, FF, NL, 0.2, True, "FFN")).to(dev)
+        kl_fn = (lambda mm: mm.transformerlayers[0].gpnn.kl_divergence()) if gauss else (lambda mm: mm.transformerlayers[0].linear2.kl_divergence())
+        kl_fn.fusable = not gauss
     tr = engine.Trainer(model, lr=0.1, clip=0.25, kl_scale=float(T) / train.size(0), seed=1111)
-    kl_fn = (lambda mm: mm.transformerlayers[0].gpnn.kl_divergence()) if gauss else (lambda mm: mm.transformerlayers[0].linear2.kl_divergence())
-    kl_fn.fusable = not gauss
     timer = ops.KernelTimer(all_gemms=True)
-    for i in range(steps + 2):
+    warm = 12 if lstm else 2
+    hidden = model.init_hidden(B) if lstm else None
+    for i in range(steps + warm):
         data, targets = get_batch(train, i * T, T)
-        ops.set_kernel_timer(timer if i >= 2 else None)
-        tr.step(data, targets, kl_fn=kl_fn)
+        ops.set_kernel_timer(timer if i >= warm else None)
+        if lstm:
+            hidden = M.repackage_hidden(hidden)
+        _, _, hidden = tr.step(data, targets, hidden=hidden, kl_fn=kl_fn)
     ops.set_kernel_timer(None)
     rows = []
     for tag, r in timer.summary().items():
         m = re.match(r"(\w+) (\d+)x(\d+)x(\d+)", tag)
+        if m is None:  # non-GEMM brackets (LSTM step sequences)
+            continue
         fl = 2.0 * int(m.group(2)) * int(m.group(3)) * int(m.group(4))
         rows.append((r["avg_ms"] * r["n"] / steps, tag, r["n"] / steps, r["avg_ms"], fl / (r["avg_ms"] * 1e-3) / 1e12))
     rows.sort(reverse=True)
