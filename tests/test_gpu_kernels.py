@@ -117,6 +117,40 @@ def test_gemm_random_shapes_all_paths(dev):
         assert err < 2e-5, (idx, op, M, N, K, pad_a, pad_b, pad_c, acc, bias is not None, err)
 
 
+@pytest.mark.parametrize("op,M,N,K,acc,bias", [
+    ("TN", 4096, 1024, 2240, True, False),    # medium-K weight gradient whose 128x128 grid is half a round -> 64x128 tiles
+    ("TN", 8200, 1024, 2240, True, False),    # ... and one that leaves a nearly empty last round
+    ("NN", 2240, 1024, 4096, False, False),   # input gradient under one round -> 128x64 tiles + the fill rule's K slices
+    ("NN", 2240, 1024, 33000, False, False),  # very long reduction: stays on split 128x128 tiles
+    ("NT", 2240, 4096, 1024, False, True),    # short K: 64x64 tiles fill the rounds better than 64x128
+    ("NT", 2240, 9000, 1024, False, True),    # short K, large grid: 64x128 instead of 128x128
+    ("NT", 8192, 512, 4096, False, False),    # the roofline shape: 128x64 tiles = 512 workgroups
+    ("NT", 8192, 512, 4096, False, True),
+    ("NN", 8192, 512, 1536, True, False),     # K = 1536: unsplittable, 64x128 tiles
+    ("TN", 512, 4096, 8192, True, False),
+])
+def test_gemm_tile_rule_shapes(dev, op, M, N, K, acc, bias):
+    """The shapes the round-2 tile / split rules single out (gemm_f32_mfma.h launch_op), against fp64 on the device."""
+    ops, lib = ops_mod(), L()
+    g = torch.Generator(device=dev).manual_seed(M + 3 * N + 7 * K)
+    rn = lambda r, c: torch.randn(r, c, device=dev, generator=g)  # noqa: E731
+    if op == "NT":
+        A, B, code = rn(M, K), rn(N, K), lib.GEMM_NT
+        ref = A.double() @ B.double().t()
+    elif op == "NN":
+        A, B, code = rn(M, K), rn(K, N), lib.GEMM_NN
+        ref = A.double() @ B.double()
+    else:
+        A, B, code = rn(K, M), rn(K, N), lib.GEMM_TN
+        ref = A.double().t() @ B.double()
+    C = rn(M, N)
+    bv = torch.randn(N, device=dev, generator=g) if bias else None
+    want = ref + (C.double() if acc else 0) + (bv.double() if bias else 0)
+    ops.gemm(code, A, B, C, M, N, K, A.stride(0), B.stride(0), N, accumulate=acc,
+             epilogue=lib.EPI_BIAS if bias else lib.EPI_NONE, bias=bv)
+    assert rel(C, want) < 1e-5
+
+
 def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric B catches a transposed C write (cdna guide section 3)."""
     ops, lib = ops_mod(), L()
