@@ -33,6 +33,16 @@ class Variational(C.Structure):
                 ("rng", Rng)]
 
 
+class VarItem(C.Structure):
+    """blm_var_item: one tensor of a variational group (include/bayeslm.h)."""
+    _fields_ = [("mu", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64), ("v", Variational), ("w_out", C.c_void_p),
+                ("kl_weight", C.c_float), ("kl_minus", C.c_float), ("dw", C.c_void_p), ("dmu", C.c_void_p),
+                ("dlgstd", C.c_void_p)]
+
+
+VAR_GROUP_MAX = 16
+
+
 class GemmArgs(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("op", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64),
@@ -53,6 +63,8 @@ SIGNATURES = {
     "blm_query": (_i, [_i, C.c_char_p, C.POINTER(_i), C.POINTER(_i)]),
     "blm_sample_weight": (_i, [_vp, _i64, _i64, _varp, _vp, _vp, _f, _vp]),
     "blm_sample_weight_bwd": (_i, [_vp, _i64, _i64, _varp, _vp, _vp, _vp]),
+    "blm_variational_group_fwd": (_i, [C.POINTER(VarItem), _i, _vp, _vp]),
+    "blm_variational_group_bwd": (_i, [C.POINTER(VarItem), _i, _vp, _vp]),
     "blm_philox_normal": (_i, [_vp, _i64, _rngp, _vp]),
     "blm_kl_mean_fwd": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _f, _vp, _vp]),
     "blm_kl_mean_bwd": (_i, [_vp, _i64, _vp, _i64, _i64, _vp, _f, _vp, _i64, _vp, _vp]),

@@ -170,6 +170,145 @@ __global__ __launch_bounds__(TPB) void kl_bwd_kernel(const float* __restrict__ m
   }
 }
 
+// ---- all variational tensors of a module in one launch (blm_variational_group_fwd / _bwd) -----------------
+struct VarGroupP {
+  blm_var_item it[BLM_VAR_GROUP_MAX];
+  int vec[BLM_VAR_GROUP_MAX];  // float4 path: cols % 4 == 0 and every pointer of the item 16-byte aligned
+  float* kl_out;
+  const float* g;
+};
+
+__device__ __forceinline__ float eps_at(const blm_variational& v, unsigned idx) {
+  if (v.eps) return v.eps[idx];
+  const float4 z = philox_normal4(v.rng, (uint64_t)(idx >> 2));
+  const int c = (int)(idx & 3);
+  return c == 0 ? z.x : (c == 1 ? z.y : (c == 2 ? z.z : z.w));
+}
+
+// grid (GX, items): blockIdx.y picks the item (block-uniform branches only), blockIdx.x strides over its elements.
+__global__ __launch_bounds__(TPB) void var_group_fwd_kernel(const VarGroupP p) {
+  __shared__ float red[TPB / 64];
+  const blm_var_item& it = p.it[blockIdx.y];
+  const blm_variational& v = it.v;
+  const unsigned cols = (unsigned)it.cols, stride = gridDim.x * TPB;
+  const bool kl_on = it.kl_weight != 0.f && v.lgstd;
+  float* __restrict__ w = it.w_out;
+  float klp = 0.f;
+  if (p.vec[blockIdx.y]) {
+    const unsigned c4n = cols >> 2, total = (unsigned)it.rows * c4n;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+      const unsigned r = i / c4n, c = (i - r * c4n) << 2;
+      float4 m = *reinterpret_cast<const float4*>(it.mu + (size_t)r * cols + c);
+      const unsigned rel = r - (unsigned)v.row_lo;
+      if (v.lgstd && rel < (unsigned)v.srows) {
+        const unsigned idx = rel * cols + c;
+        const float4 lg = *reinterpret_cast<const float4*>(v.lgstd + idx);
+        const float sx = __expf(lg.x), sy = __expf(lg.y), sz = __expf(lg.z), sw = __expf(lg.w);
+        if (kl_on)
+          klp += (m.x * m.x - 2.f * lg.x + sx * sx - it.kl_minus) + (m.y * m.y - 2.f * lg.y + sy * sy - it.kl_minus) +
+                 (m.z * m.z - 2.f * lg.z + sz * sz - it.kl_minus) + (m.w * m.w - 2.f * lg.w + sw * sw - it.kl_minus);
+        if (w) {
+          float4 z;
+          if (v.eps) z = *reinterpret_cast<const float4*>(v.eps + idx);
+          else z = philox_normal4(v.rng, (uint64_t)(idx >> 2));
+          m.x += sx * z.x; m.y += sy * z.y; m.z += sz * z.z; m.w += sw * z.w;
+        }
+      }
+      if (w) *reinterpret_cast<float4*>(w + (size_t)r * cols + c) = m;
+    }
+  } else {
+    const unsigned total = (unsigned)it.rows * cols;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+      const unsigned r = i / cols;
+      float m = it.mu[i];
+      const unsigned rel = r - (unsigned)v.row_lo;
+      if (v.lgstd && rel < (unsigned)v.srows) {
+        const unsigned idx = rel * cols + (i - r * cols);
+        const float lg = v.lgstd[idx], sg = __expf(lg);
+        if (kl_on) klp += m * m - 2.f * lg + sg * sg - it.kl_minus;
+        if (w) m += sg * eps_at(v, idx);
+      }
+      if (w) w[i] = m;
+    }
+  }
+  if (kl_on) {  // block-uniform
+    const float t = block_sum<TPB / 64>(klp, red);
+    if (threadIdx.x == 0 && t != 0.f)
+      atomicAdd(p.kl_out, t * (0.5f * it.kl_weight / ((float)v.srows * (float)cols)));
+  }
+}
+
+__global__ __launch_bounds__(TPB) void var_group_bwd_kernel(const VarGroupP p) {
+  const blm_var_item& it = p.it[blockIdx.y];
+  const blm_variational& v = it.v;
+  const unsigned cols = (unsigned)it.cols, stride = gridDim.x * TPB;
+  const float* __restrict__ dw = it.dw;
+  float* __restrict__ dmu = it.dmu;
+  float* __restrict__ dlg = it.dlgstd;
+  // KL part: g * kl_weight / n on the noisy rows (0 when there is no KL gradient for this item)
+  const float gk = (p.g && it.kl_weight != 0.f && v.lgstd && v.srows > 0) ? p.g[0] * it.kl_weight / ((float)v.srows * (float)cols) : 0.f;
+  if (!dw && gk == 0.f) return;
+  // without dW only the noisy rows have anything to add
+  const unsigned r_lo = dw ? 0u : (unsigned)v.row_lo, nrows = dw ? (unsigned)it.rows : (unsigned)v.srows;
+  if (p.vec[blockIdx.y]) {
+    const unsigned c4n = cols >> 2, total = nrows * c4n;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+      const unsigned r = r_lo + i / c4n, c = (i % c4n) << 2;
+      const size_t o = (size_t)r * cols + c;
+      float4 g = dw ? *reinterpret_cast<const float4*>(dw + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const unsigned rel = r - (unsigned)v.row_lo;
+      const bool noisy = v.lgstd && rel < (unsigned)v.srows;
+      if (noisy && dlg) {
+        const unsigned idx = rel * cols + c;
+        const float4 lg = *reinterpret_cast<const float4*>(v.lgstd + idx);
+        const float sx = __expf(lg.x), sy = __expf(lg.y), sz = __expf(lg.z), sw = __expf(lg.w);
+        float4 d = *reinterpret_cast<float4*>(dlg + idx);
+        if (dw) {
+          float4 z;
+          if (v.eps) z = *reinterpret_cast<const float4*>(v.eps + idx);
+          else z = philox_normal4(v.rng, (uint64_t)(idx >> 2));
+          d.x += g.x * z.x * sx; d.y += g.y * z.y * sy; d.z += g.z * z.z * sz; d.w += g.w * z.w * sw;
+        }
+        if (gk != 0.f) {
+          d.x += gk * (sx * sx - 1.0f); d.y += gk * (sy * sy - 1.0f); d.z += gk * (sz * sz - 1.0f); d.w += gk * (sw * sw - 1.0f);
+        }
+        *reinterpret_cast<float4*>(dlg + idx) = d;
+      }
+      if (dmu) {
+        float4 a = *reinterpret_cast<float4*>(dmu + o);
+        a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+        if (noisy && gk != 0.f) {
+          const float4 m = *reinterpret_cast<const float4*>(it.mu + o);
+          a.x += gk * m.x; a.y += gk * m.y; a.z += gk * m.z; a.w += gk * m.w;
+        }
+        *reinterpret_cast<float4*>(dmu + o) = a;
+      }
+    }
+  } else {
+    const unsigned total = nrows * cols;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+      const unsigned r = r_lo + i / cols, c = i % cols;
+      const size_t o = (size_t)r * cols + c;
+      const float g = dw ? dw[o] : 0.f;
+      const unsigned rel = r - (unsigned)v.row_lo;
+      const bool noisy = v.lgstd && rel < (unsigned)v.srows;
+      if (noisy && dlg) {
+        const unsigned idx = rel * cols + c;
+        const float sg = __expf(v.lgstd[idx]);
+        float d = dlg[idx];
+        if (dw) d += g * eps_at(v, idx) * sg;
+        if (gk != 0.f) d += gk * (sg * sg - 1.0f);
+        dlg[idx] = d;
+      }
+      if (dmu) {
+        float a = dmu[o] + g;
+        if (noisy && gk != 0.f) a += gk * it.mu[o];
+        dmu[o] = a;
+      }
+    }
+  }
+}
+
 static int grid_for(long work_items) {
   long g = (work_items + TPB - 1) / TPB;
   if (g > 2048) g = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
@@ -201,6 +340,64 @@ extern "C" int blm_sample_weight(const float* mu, int64_t rows, int64_t cols, co
   else
     hipLaunchKernelGGL(sample_weight_scalar, dim3(grid_for(rows * cols)), dim3(TPB), 0, st, mu, (long)rows, (long)cols,
                        *v, w_out, kl_out, kl_scale);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+static int var_group_pack(const blm_var_item* items, int32_t n, bool bwd, VarGroupP& p, long& most, const char* who) {
+  if (!items || n < 0 || n > BLM_VAR_GROUP_MAX) return blm_fail(BLM_ERR_INVALID, "%s: 0..%d items", who, BLM_VAR_GROUP_MAX);
+  most = 0;
+  for (int i = 0; i < n; ++i) {
+    const blm_var_item& it = items[i];
+    if (!it.mu || it.rows <= 0 || it.cols <= 0 || it.rows * it.cols >= (1LL << 31))
+      return blm_fail(BLM_ERR_INVALID, "%s: item %d: bad tensor (mu, rows, cols; at most 2^31 - 1 elements)", who, i);
+    if (it.v.lgstd && (it.v.row_lo < 0 || it.v.srows < 0 || (int64_t)it.v.row_lo + it.v.srows > it.rows))
+      return blm_fail(BLM_ERR_INVALID, "%s: item %d: noisy row window outside W", who, i);
+    if (it.kl_weight != 0.f && !it.v.lgstd) return blm_fail(BLM_ERR_INVALID, "%s: item %d: KL requested without lgstd", who, i);
+    if (bwd && it.dlgstd && !it.v.lgstd) return blm_fail(BLM_ERR_INVALID, "%s: item %d: dlgstd without lgstd", who, i);
+    p.it[i] = it;
+    bool vec = it.cols % 4 == 0 && al16(it.mu) && (!it.v.lgstd || al16(it.v.lgstd)) && (!it.v.eps || al16(it.v.eps));
+    if (bwd) vec = vec && (!it.dw || al16(it.dw)) && (!it.dmu || al16(it.dmu)) && (!it.dlgstd || al16(it.dlgstd));
+    else vec = vec && (!it.w_out || al16(it.w_out));
+    p.vec[i] = vec ? 1 : 0;
+    const long work = it.rows * it.cols / (vec ? 4 : 1);
+    if (work > most) most = work;
+  }
+  return BLM_OK;
+}
+
+extern "C" int blm_variational_group_fwd(const blm_var_item* items, int32_t n, float* kl_out, void* stream) {
+  VarGroupP p;
+  long most = 0;
+  const int rc = var_group_pack(items, n, false, p, most, "blm_variational_group_fwd");
+  if (rc != BLM_OK) return rc;
+  bool any_kl = false;
+  for (int i = 0; i < n; ++i) any_kl = any_kl || items[i].kl_weight != 0.f;
+  if (any_kl && !kl_out) return blm_fail(BLM_ERR_INVALID, "blm_variational_group_fwd: an item has a KL weight but kl_out is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (kl_out) BLM_HIP(hipMemsetAsync(kl_out, 0, sizeof(float), st));
+  if (n == 0) return BLM_OK;
+  p.kl_out = kl_out;
+  p.g = nullptr;
+  // every KL block ends in one float atomic on the same word (they serialise in L2): <= 256 blocks per item
+  long gx = (most + 4 * TPB - 1) / (4 * TPB);
+  gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+  hipLaunchKernelGGL(var_group_fwd_kernel, dim3((unsigned)gx, (unsigned)n), dim3(TPB), 0, st, p);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_variational_group_bwd(const blm_var_item* items, int32_t n, const float* kl_grad, void* stream) {
+  VarGroupP p;
+  long most = 0;
+  const int rc = var_group_pack(items, n, true, p, most, "blm_variational_group_bwd");
+  if (rc != BLM_OK) return rc;
+  if (n == 0) return BLM_OK;
+  p.kl_out = nullptr;
+  p.g = kl_grad;
+  long gx = (most + 4 * TPB - 1) / (4 * TPB);
+  gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+  hipLaunchKernelGGL(var_group_bwd_kernel, dim3((unsigned)gx, (unsigned)n), dim3(TPB), 0, static_cast<hipStream_t>(stream), p);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }

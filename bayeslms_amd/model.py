@@ -672,6 +672,7 @@ class Bayes2LSTM(_Site):
                 self.register_parameter("bias_hh_lgstd_%d" % layer, mk(R))
                 self.register_parameter("bias_ih_lgstd_%d" % layer, mk(R))
         self.eps_override = None  # list of 8 tensors in the reference's draw order (model.py:668-703)
+        self._kl_cache = None     # (KL of the last training forward, noise step, parameter versions): see _weights
 
     _ORDER = ("weight_hh", "weight_ih", "bias_hh", "bias_ih")
 
@@ -679,6 +680,23 @@ class Bayes2LSTM(_Site):
         """The 8 tensors _VF.lstm gets (model.py:705-732), sampled on the gate rows in train mode."""
         out = {}
         pos, H = self.position, self.hidden_size
+        self._kl_cache = None
+        if 1 <= pos <= 4 and self.training:
+            # one launch samples all 8 tensors and leaves the KL term of layer 1 (kl_divergence below) behind
+            E = self.input_size
+            cnt = {"weight": float(H * (H + E)), "bias": float(2 * H)}
+            specs, keys = [], []
+            for k, (layer, name) in enumerate((ly, nm) for ly in (1, 2) for nm in self._ORDER):
+                mu = getattr(self, "%s_mean_%d" % (name, layer))
+                lg = getattr(self, "%s_lgstd_%d" % (name, layer))
+                ov = self.eps_override[k] if self.eps_override is not None else None
+                klw = lg.numel() / cnt[name.split("_")[0]] if layer == 1 else 0.0
+                specs.append((mu, lg, self._noise(k, ov), (pos - 1) * H, klw, 0.0))
+                keys.append((name, layer))
+            ws, kl = ops.variational_group(specs)
+            if torch.is_grad_enabled():
+                self._kl_cache = (kl, self._st().step, tuple(sp[j]._version for sp in specs[:4] for j in (0, 1)))
+            return dict(zip(keys, ws))
         k = 0
         for layer in (1, 2):
             for name in self._ORDER:
@@ -708,6 +726,11 @@ class Bayes2LSTM(_Site):
             return torch.mean(wm ** 2. - wl * 2. + torch.exp(wl * 2)) / 2. + torch.mean(bm ** 2. - bl * 2. + torch.exp(bl * 2)) / 2.
         lo = (pos - 1) * H
         nw, nb = H * (H + E), 2 * H  # the reference concatenates hh|ih before taking the mean
+        cache, self._kl_cache = getattr(self, "_kl_cache", None), None
+        if cache is not None and pos <= 4 and self.training and torch.is_grad_enabled() and cache[1] == self._st().step:
+            ps = [getattr(self, "%s_%s_1" % (name, kind)) for name in self._ORDER for kind in ("mean", "lgstd")]
+            if cache[2] == tuple(p._version for p in ps):  # same parameters as the forward that sampled them
+                return cache[0]
         kl = ops.kl_mean(self.weight_hh_mean_1, self.weight_hh_lgstd_1, lo, count=nw)
         kl = kl + ops.kl_mean(self.weight_ih_mean_1, self.weight_ih_lgstd_1, lo, count=nw)
         kl = kl + ops.kl_mean(self.bias_hh_mean_1, self.bias_hh_lgstd_1, lo, count=nb)

@@ -352,6 +352,74 @@ def sampled(mu, lgstd, noise, row_lo=0):
     return _SampleWeight.apply(mu, lgstd, noise, row_lo)
 
 
+class _VarGroup(torch.autograd.Function):
+    """Every variational tensor of a module in ONE launch per direction (blm_variational_group_fwd / _bwd): the
+    samples W_i, the module's KL term as a by-product of the same pass, and in backward dmu / dlgstd of all items with
+    the KL gradient folded in.  ``specs``: (mu, lgstd, noise, row_lo, kl_weight, kl_minus) per item; ``params`` repeats
+    the mu / lgstd tensors so that autograd sees them."""
+
+    @staticmethod
+    def forward(ctx, specs, *params):
+        L.require_gfx950()
+        n = len(specs)
+        items = (L.VarItem * n)()
+        outs = []
+        any_kl = any(sp[4] != 0.0 for sp in specs)
+        kl = torch.empty((), device=specs[0][0].device, dtype=torch.float32) if any_kl else None
+        for it, (mu, lg, noise, row_lo, klw, klm) in zip(items, specs):
+            mu, lg = _f32(mu, "mu"), _f32(lg, "lgstd")
+            W = torch.empty_like(mu)
+            it.mu, it.rows = ptr(mu), mu.shape[0]
+            it.cols = mu.numel() // mu.shape[0]
+            it.v = _variational(lg, noise, row_lo, lg.shape[0])
+            it.w_out, it.kl_weight, it.kl_minus = ptr(W), float(klw), float(klm)
+            outs.append(W)
+        check(lib().blm_variational_group_fwd(items, n, ptr(kl), stream()), "blm_variational_group_fwd")
+        ctx.specs = specs
+        if kl is None:
+            kl = torch.zeros((), device=specs[0][0].device, dtype=torch.float32)
+            ctx.mark_non_differentiable(kl)
+        return (*outs, kl)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        specs = ctx.specs
+        n = len(specs)
+        items = (L.VarItem * n)()
+        keep, touched = [], []
+        for it, (mu, lg, noise, row_lo, klw, klm), dW in zip(items, specs, grads[:n]):
+            if dW is not None:
+                dW = _f32(dW, "dW")
+                keep.append(dW)
+            it.mu, it.rows = ptr(mu), mu.shape[0]
+            it.cols = mu.numel() // mu.shape[0]
+            it.v = _variational(lg, noise, row_lo, lg.shape[0])
+            it.kl_weight, it.kl_minus = float(klw), float(klm)
+            it.dw = ptr(dW)
+            it.dmu = ptr(_grad_buf(mu)) if mu.requires_grad else None
+            it.dlgstd = ptr(_grad_buf(lg)) if lg.requires_grad else None
+            touched += [mu, lg]
+        g = grads[n]
+        if g is not None:
+            g = _f32(g.reshape(1), "g")
+        check(lib().blm_variational_group_bwd(items, n, ptr(g), stream()), "blm_variational_group_bwd")
+        _notify(*touched)
+        return (None,) * (1 + 2 * n)
+
+
+def variational_group(specs):
+    """specs: [(mu, lgstd, noise, row_lo, kl_weight, kl_minus)] -> ([W_i], kl).  W_i = mu_i with noise on the rows
+    [row_lo, row_lo + lgstd.shape[0]); kl = sum_i kl_weight_i * mean_i(mu_s^2 - 2 lgstd + exp(2 lgstd) - kl_minus) / 2
+    over the noisy rows (0 when no item carries a weight).  One launch forward, one backward."""
+    if len(specs) > L.VAR_GROUP_MAX or any(sp[0].numel() >= 2 ** 31 or sp[2] is None for sp in specs):
+        raise BayesLMError("variational_group: at most %d sampled tensors of < 2^31 elements" % L.VAR_GROUP_MAX)
+    flat = []
+    for sp in specs:
+        flat += [sp[0], sp[1]]
+    out = _VarGroup.apply(specs, *flat)
+    return list(out[:-1]), out[-1]
+
+
 class _BayesLinear(torch.autograd.Function):
     """``fused=True``: eps is generated inside the GEMM tile loader (no W in HBM) in forward and
     dgrad; ``fused=False``: one materialisation pass writes W, then plain GEMMs.  The wgrad GEMM's

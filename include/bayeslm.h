@@ -107,6 +107,32 @@ int blm_kl_mean_fwd(const float* mu, int64_t ld_mu, const float* lgstd, int64_t 
 int blm_kl_mean_bwd(const float* mu, int64_t ld_mu, const float* lgstd, int64_t rows, int64_t cols,
                     const float* g_dev, float weight, float* dmu, int64_t ld_dmu, float* dlgstd, void* stream);
 
+/* All variational tensors of a module in ONE launch per direction (Bayes2LSTM samples 8 tensors and takes the KL
+ * of 4 of them every step, model.py:668-732 + :734-765: 8 + 4 + 4 + 8 launches of the single-tensor entry points).
+ * Item i:  W_i = mu_i (+ exp(lgstd_i) * eps on the rows [row_lo, row_lo + srows))      -> w_out (NULL: KL only)
+ *          *kl_out += kl_weight_i * sum(mu_s^2 - 2 lgstd + exp(2 lgstd) - kl_minus_i) / (2 * srows * cols)
+ *                     (kl_weight 0: no KL from this item; kl_weight = n / count re-bases the mean, model.py:737-740).
+ * blm_variational_group_fwd sets *kl_out = 0 first (kl_out may be NULL when no item has a KL weight).
+ * Backward, g = *kl_grad (device scalar, NULL = no KL gradient), n = srows * cols:
+ *          dmu_i    += dw_i                          (all rows; dw NULL: skipped)
+ *          dmu_i    += g * kl_weight_i * mu / n      (noisy rows)
+ *          dlgstd_i += dw_i * eps * exp(lgstd) + g * kl_weight_i * (exp(2 lgstd) - 1) / n
+ * = blm_sample_weight_bwd + blm_kl_mean_bwd of every item.  At most BLM_VAR_GROUP_MAX items. */
+#define BLM_VAR_GROUP_MAX 16
+typedef struct blm_var_item {
+  const float* mu;
+  int64_t rows, cols;
+  blm_variational v;
+  float* w_out;
+  float kl_weight;
+  float kl_minus;
+  const float* dw;
+  float* dmu;
+  float* dlgstd;
+} blm_var_item;
+int blm_variational_group_fwd(const blm_var_item* items, int32_t n, float* kl_out, void* stream);
+int blm_variational_group_bwd(const blm_var_item* items, int32_t n, const float* kl_grad, void* stream);
+
 /* --------------------------------------------------------------------------
  * fp32 MFMA GEMM family (v_mfma_f32_32x32x2_f32, LDS tiled)
  * ------------------------------------------------------------------------ */

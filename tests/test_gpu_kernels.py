@@ -322,6 +322,55 @@ def test_kl_mean_window_and_minus_one(dev):
     assert rel(mu.grad, mu_c.grad) < 1e-5 and rel(lg.grad, lg_c.grad) < 1e-5
 
 
+@pytest.mark.parametrize("inject", [True, False])
+def test_variational_group_equals_single_tensor_ops(dev, inject):
+    """blm_variational_group_fwd/_bwd (all tensors of a module in one launch, KL and its gradient folded in) against
+    the single-tensor entry points on the same items: float4 and scalar items, row windows, a bias vector, items with
+    and without a KL weight, an item whose sample is not used downstream (no dW)."""
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64, 32, 16, 16, 0.5, 0.0), (64, 40, 16, 16, 1.5, 0.0), (64, 1, 16, 16, 0.25, 0.0), (7, 5, 0, 7, 2.0, 1.0),
+              (48, 8, 0, 48, 0.0, 0.0), (4096, 1024, 2048, 1024, 0.75, 0.0), (33, 3, 30, 3, 0.0, 0.0)]
+    def build():
+        gen = torch.Generator().manual_seed(12)
+        items = []
+        for k, (rows, cols, lo, srows, klw, klm) in enumerate(shapes):
+            mu = torch.randn(rows, cols, generator=gen)
+            lg = torch.rand(srows, cols, generator=gen) - 2.0
+            if cols == 1:
+                mu, lg = mu.squeeze(-1), lg.squeeze(-1)
+            eps = torch.randn(lg.shape, generator=gen)
+            noise = ops.NoiseSpec(eps=eps.to(dev)) if inject else ops.NoiseSpec(None, 1234, 40 + k, 3)
+            items.append((torch.nn.Parameter(mu.to(dev)), torch.nn.Parameter(lg.to(dev)), noise, lo, klw, klm))
+        return items
+    gy = [torch.randn(r, c, generator=g).squeeze(-1).to(dev) if c == 1 else torch.randn(r, c, generator=g).to(dev)
+          for r, c, *_ in shapes]
+    unused = 4  # this item's sample gets no gradient
+    # grouped
+    a = build()
+    Ws, kl = ops.variational_group(a)
+    loss = sum((W * y).sum() for k, (W, y) in enumerate(zip(Ws, gy)) if k != unused) + 3.0 * kl
+    loss.backward()
+    # single-tensor ops
+    b = build()
+    Ws1 = [ops.sampled(mu, lg, noise, lo) for mu, lg, noise, lo, _, _ in b]
+    kl1 = sum(ops.kl_mean(mu, lg, lo, minus_one=bool(klm)) * klw for mu, lg, _, lo, klw, klm in b if klw != 0.0)
+    loss1 = sum((W * y).sum() for k, (W, y) in enumerate(zip(Ws1, gy)) if k != unused) + 3.0 * kl1
+    loss1.backward()
+    for W, W1 in zip(Ws, Ws1):
+        assert torch.equal(W, W1)
+    assert abs(float(kl) - float(kl1)) < 1e-5 * abs(float(kl1))
+    for k, ((mu, lg, *_), (mu1, lg1, *_)) in enumerate(zip(a, b)):
+        if k == unused and shapes[k][4] == 0.0:
+            assert mu.grad is None or float(mu.grad.abs().max()) == 0.0
+            continue
+        assert rel(mu.grad, mu1.grad) < 1e-6, k
+        assert rel(lg.grad, lg1.grad) < 1e-6, k
+    # the group refuses what it cannot hold
+    with pytest.raises(Exception):
+        ops.variational_group([a[0]] * 17)
+
+
 # ------------------------------------------------------------------ surrounding ops
 def test_embed_pe_dropout0(dev):
     ops = ops_mod()
