@@ -81,6 +81,9 @@ SIGNATURES = {
     "blm_add_dropout_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
     "blm_attn_fwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
     "blm_attn_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
+    "blm_attn_bwd_ws": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _rngp, _i, _i, _vp,
+                            _i64, _vp]),
+    "blm_attn_bwd_ws_floats": (_i64, [_i, _i, _i, _i]),
     "blm_ce_fwd_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "blm_ce_interp_fwd": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _i, _i, _vp]),
     "blm_ce_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _f, _vp, _i, _i, _vp]),

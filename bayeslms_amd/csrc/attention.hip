@@ -405,7 +405,8 @@ int blm_attn_fwd_mfma(const float* q, const float* k, const float* v, int64_t ld
                       int nhead, float pdrop, const blm_rng* rng, int col_offset, hipStream_t st);
 int blm_attn_bwd_mfma(const float* q, const float* k, const float* v, int64_t ld, const float* out, const float* dout,
                       const float* lse, float* dq, float* dk, float* dv, int64_t ldd, int T, int B, int nhead,
-                      float pdrop, const blm_rng* rng, int col_offset, hipStream_t st);
+                      float pdrop, const blm_rng* rng, int col_offset, float* ws, hipStream_t st);
+int64_t blm_attn_bwd_mfma_ws_floats(int T, int B, int nhead);
 static bool use_mfma(int head_dim) {
   static int off = -1;
   if (off < 0) { const char* e = getenv("BLM_ATTN_VALU"); off = (e && atoi(e)) ? 1 : 0; }
@@ -445,10 +446,23 @@ extern "C" int blm_attn_fwd(const float* q, const float* k, const float* v, int6
   return BLM_OK;
 }
 
+extern "C" int64_t blm_attn_bwd_ws_floats(int T, int B, int nhead, int head_dim) {
+  if (T <= 0 || B <= 0 || nhead <= 0 || !use_mfma(head_dim)) return 0;
+  return blm_attn_bwd_mfma_ws_floats(T, B, nhead);
+}
+
 extern "C" int blm_attn_bwd(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out,
                             const float* dout, const float* lse, float* dq, float* dk, float* dv, int64_t ld_dqkv, int T,
                             int B, int nhead, int head_dim, float pdrop, const blm_rng* rng, int col_offset,
                             int global_cols, void* stream) {
+  return blm_attn_bwd_ws(q, k, v, ld_qkv, out, dout, lse, dq, dk, dv, ld_dqkv, T, B, nhead, head_dim, pdrop, rng, col_offset,
+                         global_cols, nullptr, 0, stream);
+}
+
+extern "C" int blm_attn_bwd_ws(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out,
+                               const float* dout, const float* lse, float* dq, float* dk, float* dv, int64_t ld_dqkv, int T,
+                               int B, int nhead, int head_dim, float pdrop, const blm_rng* rng, int col_offset,
+                               int global_cols, float* ws, int64_t ws_floats, void* stream) {
   (void)global_cols;
   if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv) return blm_fail(BLM_ERR_INVALID, "blm_attn_bwd: null operand");
   AttnP p{};
@@ -458,8 +472,10 @@ extern "C" int blm_attn_bwd(const float* q, const float* k, const float* v, int6
     return blm_fail(BLM_ERR_INVALID, "blm_attn_bwd: leading dimension too small");
   if ((long)T * B == 0) return BLM_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (use_mfma(head_dim))
-    return blm_attn_bwd_mfma(q, k, v, ld_qkv, out, dout, lse, dq, dk, dv, ld_dqkv, T, B, nhead, pdrop, rng, col_offset, st);
+  if (use_mfma(head_dim)) {
+    if (ws && ws_floats < blm_attn_bwd_mfma_ws_floats(T, B, nhead)) return blm_fail(BLM_ERR_INVALID, "blm_attn_bwd_ws: workspace smaller than blm_attn_bwd_ws_floats()");
+    return blm_attn_bwd_mfma(q, k, v, ld_qkv, out, dout, lse, dq, dk, dv, ld_dqkv, T, B, nhead, pdrop, rng, col_offset, ws, st);
+  }
   p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.o_in = out; p.dout = dout; p.lse = const_cast<float*>(lse);
   p.dq = dq; p.dk = dk; p.dv = dv; p.ldd = ld_dqkv;
   if (!tiled_ok(T, head_dim)) {

@@ -39,6 +39,7 @@ struct AttnM {
   float* lse;
   const float *o_in, *dout;
   float *dq, *dk, *dv;
+  float* ds;  // optional (B*nhead, T, T) workspace: the dK/dV kernel leaves dS there and dQ = dS K needs no recomputation
   long ldd;
   int T, B, nhead;
   float scale;
@@ -358,10 +359,78 @@ __global__ __launch_bounds__(256 * HPW) void attn_bwd_dq_mfma_kernel(const AttnM
   if (qt < ntile) attn_dq_pass(p, Ks, Vs, qt, qa, da, delta, b, off, bh, li, lh, bhid);
 }
 
+// ------------------------------------------------------------------ backward: dQ from the saved dS (lane = query)
+// dQ[q][:] = scale * sum_key dS[q][key] K[key][:] with dS read back from the workspace the dK/dV pass filled: no
+// second recomputation of S, dP, the probabilities and their dropout masks (the stand-alone dQ kernel above spends
+// 64 of its 96 MFMAs per tile pair and all of its vector work on exactly that).  Same tile ownership as the forward.
+__device__ __forceinline__ void load_ds_rows(const AttnM& p, float4 (&dsr)[4][4], int bhid, int qt, int ntile, int li, int lh) {
+  const int T = p.T;
+  const int qc = min(32 * qt + li, T - 1);
+  const float* drow = p.ds + ((long)bhid * T + qc) * T;
+  const bool vec = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(p.ds) & 15) == 0;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int k0 = 32 * kt + 8 * g + 4 * lh;  // this lane's accumulator registers 4g..4g+3 = keys k0..k0+3
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kt <= qt && qt < ntile) {  // wave-uniform
+        if (vec) {
+          if (k0 < T) v = *reinterpret_cast<const float4*>(drow + k0);
+        } else {
+          if (k0 < T) v.x = drow[k0];
+          if (k0 + 1 < T) v.y = drow[k0 + 1];
+          if (k0 + 2 < T) v.z = drow[k0 + 2];
+          if (k0 + 3 < T) v.w = drow[k0 + 3];
+        }
+      }
+      dsr[kt][g] = v;
+    }
+  }
+}
+__device__ __forceinline__ void dq_from_ds(const AttnM& p, const float* Ks, const float4 (&dsr)[4][4], int qt, int b, int off, int li, int lh) {
+  f32x16 dqt[2] = {(f32x16)(0.f), (f32x16)(0.f)};
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    if (kt <= qt) {
+      f32x16 st;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        st[4 * g] = dsr[kt][g].x; st[4 * g + 1] = dsr[kt][g].y; st[4 * g + 2] = dsr[kt][g].z; st[4 * g + 3] = dsr[kt][g].w;
+      }
+      acc_xt_regs(dqt, Ks, 32 * kt, st, li, lh);
+    }
+  }
+  const int q = 32 * qt + li;
+  if (q < p.T) store_t(p.dq + ((long)q * p.B + b) * p.ldd + off, dqt, lh, p.scale);
+}
+
+template <int HPW>
+__global__ __launch_bounds__(256 * HPW) void attn_bwd_dq_ds_kernel(const AttnM p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int hsel = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  const int bhid = blockIdx.x * HPW + hsel;
+  float* Ks = sm + hsel * AT * LS;
+  const int b = bhid / p.nhead, head = bhid % p.nhead, off = head * HD;
+  const int T = p.T, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int ntile = (T + 31) >> 5;
+  const int qt = hsel ? wave : 3 - wave;
+  float4 dsr[4][4];
+  {
+    float4 kk[8];
+    fetch_rows<256>(kk, p.k, p.ld, T, p.B, b, off, tid);
+    load_ds_rows(p, dsr, bhid, qt, ntile, li, lh);
+    put_rows<256>(Ks, kk, T, 1.f, tid);
+  }
+  __syncthreads();
+  if (qt < ntile) dq_from_ds(p, Ks, dsr, qt, b, off, li, lh);
+}
+
 // ------------------------------------------------------------------ backward: dK, dV (lane = key)
 __device__ __forceinline__ void attn_dkv_pass(const AttnM& p, const float* Qs, const float* Os, const float* lse_s,
                                               const float* del_s, int kt, int ntile, const float (&kreg)[32],
-                                              const float (&vreg)[32], int b, int off, uint64_t bh, int lane, int li, int lh) {
+                                              const float (&vreg)[32], int b, int off, uint64_t bh, int lane, int li, int lh,
+                                              int bhid) {
   const int T = p.T;
   const int key = 32 * kt + li, kc = min(key, T - 1);
   f32x16 dkt[2] = {(f32x16)(0.f), (f32x16)(0.f)}, dvt[2] = {(f32x16)(0.f), (f32x16)(0.f)};
@@ -406,6 +475,19 @@ __device__ __forceinline__ void attn_dkv_pass(const AttnM& p, const float* Qs, c
         sc[r] = pr * (dp[r] * kp[e] - del_s[qr]);  // dS[q][key]
       }
     }
+    if (p.ds && key < T) {  // dS[q][key], row-major per head: 32 lanes = 32 consecutive keys of one query row
+      // 32-bit element offsets off the uniform base (the host checks that the workspace is under 4 GB): one VGPR per
+      // address instead of two -- the HPW = 2 kernel sits at its 256-register budget
+      const uint32_t o0 = ((uint32_t)bhid * T + 32 * qt + 4 * lh) * T + key;
+      if (32 * qt + 32 <= T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p.ds[o0 + (uint32_t)(((r & 3) + 8 * (r >> 2)) * T)] = sc[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (32 * qt + mrow(r, lh) < T) p.ds[o0 + (uint32_t)(((r & 3) + 8 * (r >> 2)) * T)] = sc[r];
+      }
+    }
     acc_xt_regs(dvt, Os, 32 * qt, pd, li, lh);
     acc_xt_regs(dkt, Qs, 32 * qt, sc, li, lh);
   }
@@ -415,7 +497,9 @@ __device__ __forceinline__ void attn_dkv_pass(const AttnM& p, const float* Qs, c
   }
 }
 
-template <int HPW>
+// DQ: the workgroup also produces dQ of its heads from the dS tiles its own waves have just written (they are in this
+// XCD's L2): no third launch, no second load of K (the wave's key tile goes from its operand registers to LDS).
+template <int HPW, bool DQ = false>
 __global__ __launch_bounds__(256 * HPW) void attn_bwd_dkv_mfma_kernel(const AttnM p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int hsel = threadIdx.x >> 8, tid = threadIdx.x & 255;
@@ -463,9 +547,22 @@ __global__ __launch_bounds__(256 * HPW) void attn_bwd_dkv_mfma_kernel(const Attn
   }
   __syncthreads();
   const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
-  if (kt < ntile) attn_dkv_pass(p, Qs, Os, lse_s, del_s, kt, ntile, ka, va, b, off, bh, lane, li, lh);
+  if (kt < ntile) attn_dkv_pass(p, Qs, Os, lse_s, del_s, kt, ntile, ka, va, b, off, bh, lane, li, lh, bhid);
+  if constexpr (DQ) {
+    // __syncthreads() carries workgroup-scope release / acquire fences: the dS tiles of every wave of this workgroup
+    // (same CU, same write-through L1) are visible to the loads below.  An agent-scope fence here would write the
+    // XCD's whole L2 back (measured: 245 us per launch instead of 75).
+    __syncthreads();   // ... and nobody reads Qs / dOs any more
+    float* Ks = Qs;    // K rows of the head, row-major like the staged tiles (stride LS)
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) Ks[(32 * kt + li) * LS + 32 * lh + s2] = ka[s2];
+    const int qt = hsel ? wave : 3 - wave;  // query tile of the forward: 5 tile-steps per SIMD again
+    float4 dsr[4][4];
+    load_ds_rows(p, dsr, bhid, qt, ntile, li, lh);
+    __syncthreads();
+    if (qt < ntile) dq_from_ds(p, Ks, dsr, qt, b, off, li, lh);
+  }
 }
-
 
 // ------------------------------------------------------------------ sequences longer than 128 tokens
 // Same tiles and operand orientation, with a flash-style outer loop: a workgroup owns 128 queries (keys) = one
@@ -746,13 +843,20 @@ int blm_attn_fwd_mfma(const float* q, const float* k, const float* v, int64_t ld
   return BLM_OK;
 }
 
+// floats of workspace the T <= 128 backward can use (0: the path has no use for one)
+int64_t blm_attn_bwd_mfma_ws_floats(int T, int B, int nhead) {
+  const int64_t n = (int64_t)B * nhead * T * T;
+  return (T <= AT && n < (1LL << 30)) ? n : 0;  // the kernels address it with 32-bit byte offsets
+}
+
 int blm_attn_bwd_mfma(const float* q, const float* k, const float* v, int64_t ld, const float* out, const float* dout,
                       const float* lse, float* dq, float* dk, float* dv, int64_t ldd, int T, int B, int nhead,
-                      float pdrop, const blm_rng* rng, int col_offset, hipStream_t st) {
+                      float pdrop, const blm_rng* rng, int col_offset, float* ws, hipStream_t st) {
   AttnM p{};
   fill_m(p, T, B, nhead, pdrop, rng, col_offset);
   p.q = q; p.k = k; p.v = v; p.ld = ld; p.o_in = out; p.dout = dout; p.lse = const_cast<float*>(lse);
   p.dq = dq; p.dk = dk; p.dv = dv; p.ldd = ldd;
+  p.ds = blm_attn_bwd_mfma_ws_floats(T, B, nhead) > 0 ? ws : nullptr;
   const size_t lds1 = (size_t)2 * AT * LS * sizeof(float), lds2 = lds1 + 2 * AT * sizeof(float);
   static bool once = false;
   if (!once) {
@@ -768,6 +872,14 @@ int blm_attn_bwd_mfma(const float* q, const float* k, const float* v, int64_t ld
     if (rc) return rc;
     rc = set_lds(attn_bwd_dkv_long_kernel, lds2);
     if (rc) return rc;
+    rc = set_lds(attn_bwd_dq_ds_kernel<1>, lds1 / 2);
+    if (rc) return rc;
+    rc = set_lds(attn_bwd_dq_ds_kernel<2>, lds1);
+    if (rc) return rc;
+    rc = set_lds(attn_bwd_dkv_mfma_kernel<1, true>, lds2);
+    if (rc) return rc;
+    rc = set_lds(attn_bwd_dkv_mfma_kernel<2, true>, 2 * lds2);
+    if (rc) return rc;
     once = true;
   }
   if (T > AT) {
@@ -778,7 +890,25 @@ int blm_attn_bwd_mfma(const float* q, const float* k, const float* v, int64_t ld
     BLM_HIP(hipGetLastError());
     return BLM_OK;
   }
-  if ((B * nhead) % 2 == 0 && attn_hpw() == 2) {
+  const bool two = (B * nhead) % 2 == 0 && attn_hpw() == 2;
+  static int fuse = -1;  // BLM_ATTN_FUSE_DQ=0: dQ = dS K as a separate launch (A/B measurements)
+  if (fuse < 0) { const char* e = getenv("BLM_ATTN_FUSE_DQ"); fuse = e ? atoi(e) : 1; }
+  if (p.ds && fuse) {  // ONE launch: dK/dV, dS through the workspace, dQ = dS K by the same workgroup
+    if (two) hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<2, true>), dim3(B * nhead / 2), dim3(512), 2 * lds2, st, p);
+    else hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<1, true>), dim3(B * nhead), dim3(256), lds2, st, p);
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
+  }
+  if (p.ds) {  // dK/dV first (it leaves dS in the workspace), then dQ = dS K
+    if (two) hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<2>, dim3(B * nhead / 2), dim3(512), 2 * lds2, st, p);
+    else hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<1>, dim3(B * nhead), dim3(256), lds2, st, p);
+    BLM_HIP(hipGetLastError());
+    if (two) hipLaunchKernelGGL(attn_bwd_dq_ds_kernel<2>, dim3(B * nhead / 2), dim3(512), lds1, st, p);
+    else hipLaunchKernelGGL(attn_bwd_dq_ds_kernel<1>, dim3(B * nhead), dim3(256), lds1 / 2, st, p);
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
+  }
+  if (two) {
     hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<2>, dim3(B * nhead / 2), dim3(512), 2 * lds1, st, p);
     BLM_HIP(hipGetLastError());
     hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<2>, dim3(B * nhead / 2), dim3(512), 2 * lds2, st, p);

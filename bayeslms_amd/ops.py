@@ -12,6 +12,8 @@ There is no CPU path: every entry point raises on non-GPU tensors.
 import ctypes as C
 from dataclasses import dataclass
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -668,13 +670,19 @@ class _Attention(torch.autograd.Function):
             dq, dk, dv = (torch.empty(T, B, d, device=a.device, dtype=torch.float32) for _ in range(3))
             ldd = d
         r = drop.rng() if drop.on else None
-        check(lib().blm_attn_bwd(q.data_ptr(), kk.data_ptr(), vv.data_ptr(), ld, ptr(out), ptr(dout), ptr(lse),
-                                 dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ldd, T, B, nhead, d // nhead,
-                                 float(drop.p), C.byref(r) if r is not None else None, drop.col_offset,
-                                 drop.global_cols or B, stream()), "blm_attn_bwd")
+        # scratch for dS (B*nhead, T, T): the dK/dV kernel leaves it there, dQ = dS K needs no second recomputation
+        nws = int(lib().blm_attn_bwd_ws_floats(T, B, nhead, d // nhead)) if _ATTN_WS else 0
+        ws = torch.empty(nws, device=a.device, dtype=torch.float32) if nws > 0 else None
+        check(lib().blm_attn_bwd_ws(q.data_ptr(), kk.data_ptr(), vv.data_ptr(), ld, ptr(out), ptr(dout), ptr(lse),
+                                    dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ldd, T, B, nhead, d // nhead,
+                                    float(drop.p), C.byref(r) if r is not None else None, drop.col_offset,
+                                    drop.global_cols or B, ptr(ws), nws, stream()), "blm_attn_bwd_ws")
         if packed:
             return dqkv, None, None, None, None
         return dq, dk, dv, None, None
+
+
+_ATTN_WS = os.environ.get("BLM_ATTN_WS", "1") != "0"  # 0: the two-recomputation backward (A/B measurements)
 
 
 def attention(qkv, nhead, drop=NO_DROP):

@@ -33,6 +33,9 @@ import torch.distributed as dist  # noqa: E402
 V, D_MODEL, NHEAD, D_FF, NLAYERS, T, B_PER_GPU = 33000, 512, 8, 4096, 6, 128, 64
 DROPOUT, LR, CLIP = 0.2, 0.1, 1.0
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# forward FLOPs per token L(2d*3d + 4Td + 2d^2 + 4d*ff) + 2dV = 98.28 M, training = 3x
+STEP_FLOPS_PER_TOKEN = 3 * (NLAYERS * (2 * D_MODEL * 3 * D_MODEL + 4 * T * D_MODEL + 2 * D_MODEL * D_MODEL + 4 * D_MODEL * D_FF)
+                            + 2 * D_MODEL * V)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (the opt-in split modes are priced against this one)
 
 
@@ -417,6 +420,11 @@ def main():
                        "global_batch": Bc * world, "seq_len": T, "parallelism": "dp%d" % world,
                        "fused_sampling": bool(model.noise_state.fused)},
             "roofline": roof,
+            # whole step against the same peak: SURVEY 8(d) model FLOPs, 3 x (L(2d3d + 4Td + 2d^2 + 4d ff) + 2dV) per token
+            "step_roofline": {"bound": "mfma", "model_flops_per_token": STEP_FLOPS_PER_TOKEN,
+                              "achieved": round(STEP_FLOPS_PER_TOKEN * tokens / world / elapsed / 1e12, 2),
+                              "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
+                              "frac": round(STEP_FLOPS_PER_TOKEN * tokens / world / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kt.items()},
             "final_loss": round(final_loss, 4), "eval_ppl": round(eval_ppl, 2),
             # rank 0, per step: time the compute stream waited between its last backward kernel and the end of the

@@ -273,6 +273,14 @@ int blm_attn_fwd(const float* q, const float* k, const float* v, int64_t ld_qkv,
 int blm_attn_bwd(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out, const float* dout,
                  const float* lse, float* dq, float* dk, float* dv, int64_t ld_dqkv, int T, int B, int nhead,
                  int head_dim, float p, const blm_rng* rng, int col_offset, int global_cols, void* stream);
+/* The same backward with a caller-owned scratch buffer of blm_attn_bwd_ws_floats() floats (0: this shape has no use
+ * for one): the dK/dV kernel leaves dS (B*nhead, T, T) there and dQ = dS K is one small product instead of a second
+ * recomputation of the probabilities and their dropout masks.  ws == NULL is blm_attn_bwd.  Same results. */
+int64_t blm_attn_bwd_ws_floats(int T, int B, int nhead, int head_dim);
+int blm_attn_bwd_ws(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out, const float* dout,
+                    const float* lse, float* dq, float* dk, float* dv, int64_t ld_dqkv, int T, int B, int nhead,
+                    int head_dim, float p, const blm_rng* rng, int col_offset, int global_cols, float* ws,
+                    int64_t ws_floats, void* stream);
 
 /* Cross entropy over materialised logits (M, V) (train.py:233,332;
  * compute_sentence_scores_bayes_jianwei.py:168):

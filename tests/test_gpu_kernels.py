@@ -487,6 +487,28 @@ def test_attention_dropout_uses_philox_mask(dev, T, B, nhead, hd):
     assert rel(qd.grad, qr.grad) < 2e-5
 
 
+@pytest.mark.parametrize("T,B,nhead,p", [(128, 4, 8, 0.2), (128, 3, 1, 0.0), (97, 1, 3, 0.3), (50, 3, 2, 0.4), (33, 2, 2, 0.0),
+                                         (1, 1, 1, 0.0), (64, 2, 2, 0.1), (130, 2, 2, 0.2)])
+def test_attention_backward_workspace_path_equals_recomputation(dev, monkeypatch, T, B, nhead, p):
+    """blm_attn_bwd_ws (dK/dV pass leaves dS in the scratch buffer, dQ = dS K by the same workgroup) against blm_attn_bwd
+    (two recomputations): one or two heads per workgroup, partial tiles, T % 4 != 0, dropout on/off; T > 128 asks for no
+    workspace and runs the chunked kernels either way."""
+    ops = ops_mod()
+    hd, d = 64, nhead * 64
+    assert int(L().lib().blm_attn_bwd_ws_floats(T, B, nhead, hd)) == (B * nhead * T * T if T <= 128 else 0)
+    g = torch.Generator().manual_seed(T * 7 + B)
+    qkv = torch.randn(T, B, 3 * d, generator=g).to(dev)
+    go = torch.randn(T, B, d, generator=g).to(dev)
+    drop = ops.Drop(p, 99, 4, 6, 0, B) if p > 0 else ops.NO_DROP
+    grads = []
+    for ws in (True, False):
+        monkeypatch.setattr(ops, "_ATTN_WS", ws)
+        x = qkv.clone().requires_grad_(True)
+        ops.attention(x, nhead, drop).backward(go)
+        grads.append(x.grad)
+    assert rel(grads[0], grads[1]) < 2e-6
+
+
 @pytest.mark.parametrize("M,V", [(5, 7), (18, 50), (64, 33000), (3, 1001), (9, 40), (4, 12288), (5, 12284), (3, 50000), (2, 70000)])
 def test_cross_entropy(dev, M, V):
     ops = ops_mod()
