@@ -26,6 +26,7 @@
 namespace blm {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bu32x4 = __attribute__((ext_vector_type(4))) unsigned int;  // raw_buffer_load_b128 result
 
 constexpr int LSTR = 68;                  // staged tile row stride (floats): 64 k + 4 pad
 constexpr int TILE = 32 * LSTR;           // one 32-row operand tile
@@ -66,7 +67,11 @@ struct LstmStepP {
 // chunk c execute, the wave issues chunk c + 1's LDS writes, the ring refill and chunk c + 1's fragment reads BETWEEN
 // them (a dependent MFMA stalls the in-order wave for ~60 cycles at issue: room for one LDS instruction per MFMA), into a
 // second fragment register set.  ~310 VGPRs: one workgroup per CU.
-template <int RING, int NS = 4, bool REFILL = true, int NW = 4, bool PIPE = false>
+// TAIL = false (the lane's K run is a whole number of 32-float chunks, e.g. H % 256 == 0 with 4 waves): no zero-fill
+// selects in front of the LDS writes and wave-uniform chunk offsets.  On gfx950 every vector instruction is paid in
+// matrix time (tools/mfma_valu_overlap.hip): the 64 v_cndmask + 16 64-bit address adds per chunk of the general form
+// were ~ 18 % on top of its 32 MFMAs.
+template <int RING, int NS = 4, bool REFILL = true, int NW = 4, bool PIPE = false, bool TAIL = true>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 1 : 2, PIPE ? 1 : 2))) void lstm_step_fwd_kernel(const LstmStepP p) {
   constexpr int U = 32 / NS;  // hidden units per workgroup
   // ONE staging buffer per wave (LDS runs a wave's instructions in order and the fragments are in registers before the
@@ -93,19 +98,33 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
 
   // staging roles: one instruction moves 4 rows x 2 halves x 128 B
   const int srow = lane >> 4, shalf = (lane >> 3) & 1, spart = lane & 7;
-  const float* arow[8];
-  const float* wrow[8];
+  // buffer loads: descriptor (scalar registers, built from kernel arguments) + one 32-bit byte offset per staged row
+  // + a scalar offset for the wave's K slice and the chunk: a chunk step costs no vector instruction (hipcc turns
+  // base + zext(offset) of a plain pointer into 64-bit vector adds once the offsets are hoisted out of the loop)
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.hprev), 0, B * H * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.whh), 0, NS * H * H * 4, 0x00020000);
+  const int kb4 = __builtin_amdgcn_readfirstlane(kbase * 4);
+  uint32_t aoff[8], woff[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int row = 4 * q + srow;
 #ifdef BLM_LSTM_PROF
-    arow[q] = p.hprev + (long)(p.alias >= 2 ? 0 : min(b0 + row, B - 1)) * H + kbase + shalf * Kh + 4 * spart;
-    wrow[q] = p.whh + ((long)(row / U) * H + (p.alias >= 1 ? 0 : j0) + (row % U)) * H + kbase + shalf * Kh + 4 * spart;
+    aoff[q] = (uint32_t)(((long)(p.alias >= 2 ? 0 : min(b0 + row, B - 1)) * H + shalf * Kh + 4 * spart) * 4);
+    woff[q] = (uint32_t)((((long)(row / U) * H + (p.alias >= 1 ? 0 : j0) + (row % U)) * H + shalf * Kh + 4 * spart) * 4);
 #else
-    arow[q] = p.hprev + (long)min(b0 + row, B - 1) * H + kbase + shalf * Kh + 4 * spart;
-    wrow[q] = p.whh + ((long)(row / U) * H + j0 + (row % U)) * H + kbase + shalf * Kh + 4 * spart;
+    aoff[q] = (uint32_t)(((long)min(b0 + row, B - 1) * H + shalf * Kh + 4 * spart) * 4);
+    woff[q] = (uint32_t)((((long)(row / U) * H + j0 + (row % U)) * H + shalf * Kh + 4 * spart) * 4);
 #endif
   }
+  auto ldg = [](__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff) {
+    const bu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  };
+  // zero-fill of the K tail (TAIL only): component-wise selects, a select of whole float4 lvalues would demote the ring to scratch
+  auto fill = [](const float4& x, bool in) {
+    if constexpr (TAIL) return make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
+    else return x;
+  };
   const int soff = srow * LSTR + shalf * 32 + 4 * spart;
   // register ring of RING chunks: with one wave per SIMD the only way to cover the L2/MALL latency is
   // to keep RING x 16 KB per wave of loads in flight while the matrix core works on a chunk.  The loop
@@ -113,11 +132,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
   // so that the s_waitcnt in front of each put() only waits for ITS chunk.
   float4 ra[RING][8], rw[RING][8];
   auto fetch = [&](float4 (&a)[8], float4 (&w)[8], int c) {
-    const int off = min(32 * min(c, nchunk - 1) + 4 * spart, Kh - 4) - 4 * spart;
+    if constexpr (TAIL) {
+      const int off = min(32 * min(c, nchunk - 1) + 4 * spart, Kh - 4) - 4 * spart;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      a[q] = *reinterpret_cast<const float4*>(arow[q] + off);
-      w[q] = *reinterpret_cast<const float4*>(wrow[q] + off);
+      for (int q = 0; q < 8; ++q) {
+        a[q] = ldg(arsrc, aoff[q] + 4u * off, kb4);
+        w[q] = ldg(wrsrc, woff[q] + 4u * off, kb4);
+      }
+    } else {
+      const int so = kb4 + 128 * min(c, nchunk - 1);  // wave-uniform
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        a[q] = ldg(arsrc, aoff[q], so);
+        w[q] = ldg(wrsrc, woff[q], so);
+      }
     }
   };
   f32x16 acc = (f32x16)(0.f);
@@ -126,10 +154,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
     const bool in = 32 * c + 4 * spart < Kh;  // K tail of the last chunk -> zeros
     float* d = base + buf * 2 * TILE + soff;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {  // component-wise selects: a select of whole float4 lvalues would demote the ring to scratch
-      const float4 x = a[q], y = w[q];
-      *reinterpret_cast<float4*>(d + 4 * q * LSTR) = make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
-      *reinterpret_cast<float4*>(d + TILE + 4 * q * LSTR) = make_float4(in ? y.x : 0.f, in ? y.y : 0.f, in ? y.z : 0.f, in ? y.w : 0.f);
+    for (int q = 0; q < 8; ++q) {
+      *reinterpret_cast<float4*>(d + 4 * q * LSTR) = fill(a[q], in);
+      *reinterpret_cast<float4*>(d + TILE + 4 * q * LSTR) = fill(w[q], in);
     }
     if (c == 0) {  // the first chunk's bytes have landed (its LDS writes are issued)
       LSTM_STAMP(1);
@@ -182,17 +209,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
       const bool in = 32 * c + 4 * spart < Kh;
 #pragma unroll
       for (int q = q0; q < q0 + 2; ++q) {
-        const float4 x = a[q], y = w[q];
-        *reinterpret_cast<float4*>(dst + 4 * q * LSTR) = make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
-        *reinterpret_cast<float4*>(dst + TILE + 4 * q * LSTR) = make_float4(in ? y.x : 0.f, in ? y.y : 0.f, in ? y.z : 0.f, in ? y.w : 0.f);
+        *reinterpret_cast<float4*>(dst + 4 * q * LSTR) = fill(a[q], in);
+        *reinterpret_cast<float4*>(dst + TILE + 4 * q * LSTR) = fill(w[q], in);
       }
     };
     auto refill2 = [&](float4 (&a)[8], float4 (&w)[8], int c, int q0) {  // 4 global loads of chunk c into the freed registers
-      const int off = min(32 * min(c, nchunk - 1) + 4 * spart, Kh - 4) - 4 * spart;
+      const int offu = 32 * min(c, nchunk - 1);
+      const int off = TAIL ? min(offu + 4 * spart, Kh - 4) - 4 * spart : 0;
 #pragma unroll
       for (int q = q0; q < q0 + 2; ++q) {
-        a[q] = *reinterpret_cast<const float4*>(arow[q] + off);
-        w[q] = *reinterpret_cast<const float4*>(wrow[q] + off);
+        if constexpr (TAIL) { a[q] = ldg(arsrc, aoff[q] + 4u * off, kb4); w[q] = ldg(wrsrc, woff[q] + 4u * off, kb4); }
+        else { a[q] = ldg(arsrc, aoff[q], kb4 + 4 * offu); w[q] = ldg(wrsrc, woff[q], kb4 + 4 * offu); }
       }
     };
     auto get2 = [&](float4 (&fa_)[8], float4 (&fw_)[8], int j0) {  // 4 ds_read_b128
@@ -214,20 +241,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
     auto comb = [&](const float4 (&ca)[8], const float4 (&cw)[8], float4 (&a)[8], float4 (&w)[8], int cn, float4 (&na)[8],
                     float4 (&nw)[8]) {
       const bool in = 32 * cn + 4 * spart < Kh;
-      const int off = min(32 * min(cn + RING, nchunk - 1) + 4 * spart, Kh - 4) - 4 * spart;
+      const int offu = 32 * min(cn + RING, nchunk - 1);
+      const int off = TAIL ? min(offu + 4 * spart, Kh - 4) - 4 * spart : 0;
+      const int so = TAIL ? kb4 : kb4 + 4 * offu;
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(ca[k >> 2], k & 3), comp(cw[k >> 2], k & 3), acc, 0, 0, 0);
         if (k < 16) {  // ds_write_b128 of the next chunk: k even -> h tile row q, k odd -> W tile row q
           const int q = k >> 1;
           if ((k & 1) == 0) {
-            const float4 x = a[q];
-            *reinterpret_cast<float4*>(dst + 4 * q * LSTR) = make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
-            if constexpr (REFILL) a[q] = *reinterpret_cast<const float4*>(arow[q] + off);
+            *reinterpret_cast<float4*>(dst + 4 * q * LSTR) = fill(a[q], in);
+            if constexpr (REFILL) a[q] = ldg(arsrc, TAIL ? aoff[q] + 4u * off : aoff[q], so);
           } else {
-            const float4 y = w[q];
-            *reinterpret_cast<float4*>(dst + TILE + 4 * q * LSTR) = make_float4(in ? y.x : 0.f, in ? y.y : 0.f, in ? y.z : 0.f, in ? y.w : 0.f);
-            if constexpr (REFILL) w[q] = *reinterpret_cast<const float4*>(wrow[q] + off);
+            *reinterpret_cast<float4*>(dst + TILE + 4 * q * LSTR) = fill(w[q], in);
+            if constexpr (REFILL) w[q] = ldg(wrsrc, TAIL ? woff[q] + 4u * off : woff[q], so);
           }
           if (k == 15) {  // the tile is complete before it is read back (compiler order only; LDS is in order per wave)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -454,7 +481,8 @@ struct LstmBwdP {
   int G;                                  // contraction length = row length of dg and wt: 4H (LSTM), 8H (search cell)
 };
 
-template <int RING, bool REFILL = true, int NW = 4, bool PIPE = false>  // PIPE: software-pipelined K loop, see the forward kernel
+// PIPE: software-pipelined K loop; TAIL = false: whole 32-float chunks only (no zero-fill selects, scalar chunk offsets) -- see the forward kernel
+template <int RING, bool REFILL = true, int NW = 4, bool PIPE = false, bool TAIL = true>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 1 : 2, PIPE ? 1 : 2))) void lstm_step_bwd_kernel(const LstmBwdP p) {
   constexpr int NBUF = 1;  // see the forward kernel; NW = 8 (two waves per SIMD): plain / GP cells only
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -476,22 +504,40 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
   float e_a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, e_p8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // staging roles: one instruction moves 2 rows x 4 quarters x 128 B
   const int srow = lane >> 5, squart = (lane >> 3) & 3, spart = lane & 7;
-  const float* arow[8];
-  const float* wrow[8];
+  // buffer loads (descriptor + 32-bit row offset + scalar slice / chunk offset): see the forward kernel
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dg), 0, B * p.G * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, H * p.G * 4, 0x00020000);
+  const int kb4 = __builtin_amdgcn_readfirstlane(wave * Kw * 4);
+  uint32_t aoff[8], woff[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int row = 2 * q + srow;
-    arow[q] = p.dg + (long)min(b0 + row, B - 1) * G + (long)wave * Kw + squart * Kq + 4 * spart;
-    wrow[q] = p.wt + (long)(k0 + row) * G + (long)wave * Kw + squart * Kq + 4 * spart;
+    aoff[q] = (uint32_t)(((long)min(b0 + row, B - 1) * G + squart * Kq + 4 * spart) * 4);
+    woff[q] = (uint32_t)(((long)(k0 + row) * G + squart * Kq + 4 * spart) * 4);
   }
+  auto ldg = [](__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff) {
+    const bu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  };
+  auto fill = [](const float4& x, bool in) {
+    if constexpr (TAIL) return make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
+    else return x;
+  };
+  // chunk c of every staged row: per-lane clamp in the tail form, one scalar offset otherwise
+  auto chunk_off = [&](int c, uint32_t& voff_add, int& so) {
+    const int offu = 32 * min(c, nchunk - 1);
+    if constexpr (TAIL) { voff_add = 4u * (uint32_t)(min(offu + 4 * spart, Kq - 4) - 4 * spart); so = kb4; }
+    else { voff_add = 0u; so = kb4 + 4 * offu; }
+  };
   const int soff = srow * BSTR + squart * BQ + 4 * spart;
   float4 ra[RING][8], rw[RING][8];
   auto fetch = [&](float4 (&a)[8], float4 (&w)[8], int c) {
-    const int off = min(32 * min(c, nchunk - 1) + 4 * spart, Kq - 4) - 4 * spart;
+    uint32_t va; int so;
+    chunk_off(c, va, so);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      a[q] = *reinterpret_cast<const float4*>(arow[q] + off);
-      w[q] = *reinterpret_cast<const float4*>(wrow[q] + off);
+      a[q] = ldg(arsrc, aoff[q] + va, so);
+      w[q] = ldg(wrsrc, woff[q] + va, so);
     }
   };
   f32x4 acc = (f32x4)(0.f);
@@ -500,9 +546,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
     float* d = base + buf * 2 * BTILE + soff;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const float4 x = a[q], y = w[q];
-      *reinterpret_cast<float4*>(d + 2 * q * BSTR) = make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
-      *reinterpret_cast<float4*>(d + BTILE + 2 * q * BSTR) = make_float4(in ? y.x : 0.f, in ? y.y : 0.f, in ? y.z : 0.f, in ? y.w : 0.f);
+      *reinterpret_cast<float4*>(d + 2 * q * BSTR) = fill(a[q], in);
+      *reinterpret_cast<float4*>(d + BTILE + 2 * q * BSTR) = fill(w[q], in);
     }
     if constexpr (REFILL) fetch(a, w, c + RING);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // wave-private tiles, in-order LDS: see the forward kernel
@@ -564,20 +609,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
     auto comb = [&](const float4 (&ca)[8], const float4 (&cw)[8], float4 (&a)[8], float4 (&w)[8], int cn, float4 (&na)[8],
                     float4 (&nw)[8]) {
       const bool in = 32 * cn + 4 * spart < Kq;
-      const int off = min(32 * min(cn + RING, nchunk - 1) + 4 * spart, Kq - 4) - 4 * spart;
+      uint32_t va; int so;
+      chunk_off(cn + RING, va, so);
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(ca[k >> 2], k & 3), comp(cw[k >> 2], k & 3), acc, 0, 0, 0);
         if (k < 16) {
           const int q = k >> 1;
           if ((k & 1) == 0) {
-            const float4 x = a[q];
-            *reinterpret_cast<float4*>(dst + 2 * q * BSTR) = make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
-            a[q] = *reinterpret_cast<const float4*>(arow[q] + off);
+            *reinterpret_cast<float4*>(dst + 2 * q * BSTR) = fill(a[q], in);
+            a[q] = ldg(arsrc, aoff[q] + va, so);
           } else {
-            const float4 y = w[q];
-            *reinterpret_cast<float4*>(dst + BTILE + 2 * q * BSTR) = make_float4(in ? y.x : 0.f, in ? y.y : 0.f, in ? y.z : 0.f, in ? y.w : 0.f);
-            w[q] = *reinterpret_cast<const float4*>(wrow[q] + off);
+            *reinterpret_cast<float4*>(dst + BTILE + 2 * q * BSTR) = fill(w[q], in);
+            w[q] = ldg(wrsrc, woff[q] + va, so);
           }
           if (k == 15) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -594,14 +638,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
     };
     {  // prologue: chunk 0 staged alone
       const bool in = 4 * spart < Kq;
-      const int off = min(32 * min(RING, nchunk - 1) + 4 * spart, Kq - 4) - 4 * spart;
+      uint32_t va; int so;
+      chunk_off(RING, va, so);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const float4 x = ra[0][q], y = rw[0][q];
-        *reinterpret_cast<float4*>(dst + 2 * q * BSTR) = make_float4(in ? x.x : 0.f, in ? x.y : 0.f, in ? x.z : 0.f, in ? x.w : 0.f);
-        *reinterpret_cast<float4*>(dst + BTILE + 2 * q * BSTR) = make_float4(in ? y.x : 0.f, in ? y.y : 0.f, in ? y.z : 0.f, in ? y.w : 0.f);
-        ra[0][q] = *reinterpret_cast<const float4*>(arow[q] + off);
-        rw[0][q] = *reinterpret_cast<const float4*>(wrow[q] + off);
+        *reinterpret_cast<float4*>(dst + 2 * q * BSTR) = fill(ra[0][q], in);
+        *reinterpret_cast<float4*>(dst + BTILE + 2 * q * BSTR) = fill(rw[0][q], in);
+        ra[0][q] = ldg(arsrc, aoff[q] + va, so);
+        rw[0][q] = ldg(wrsrc, woff[q] + va, so);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -744,6 +788,15 @@ static int lstm_pipe() {  // BLM_LSTM_PIPE=0|1: software-pipelined K loop of the
   return v;
 }
 
+static int lstm_tail() {  // BLM_LSTM_TAIL=1: always the general (K tail) form of the pipelined kernels (A/B measurements, tests)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("BLM_LSTM_TAIL");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 static int lstm_waves() {  // BLM_LSTM_WAVES=4|8 (A/B measurements)
   static int v = -1;
   if (v < 0) {
@@ -772,8 +825,8 @@ extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const 
       (gate_ovr == 4 && !rbias))
     return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_fwd: bad arguments");
   if ((long)B * H == 0) return BLM_OK;
-  if (H % 32 != 0 || !al16(w_hh) || !al16(h_prev))
-    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_fwd: needs H % 32 == 0 and 16-byte aligned h_prev / w_hh");
+  if (H % 32 != 0 || !al16(w_hh) || !al16(h_prev) || 16.0 * H * H >= 4294967296.0 || 4.0 * B * H >= 4294967296.0)  // 32-bit byte offsets
+    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_fwd: needs H % 32 == 0, 16-byte aligned h_prev / w_hh and operands under 4 GB");
   LstmStepP p{xw_t, w_hh, h_prev, c_prev, h, c, gates_act, h_noise, coef4, z_out, gate_ovr < 0 ? -1 : gate_ovr, rbias, B, H, nullptr};
   if (gate_ovr < 0 && B <= 4 && H % 4 == 0 && lstm_gemv()) {  // tiny batches (the scorer's carry chain): one wave per hidden unit
     const dim3 g((H + 3) / 4), blk(256);
@@ -791,6 +844,7 @@ extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const 
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, true, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, true, 4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<1, 4, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
@@ -804,8 +858,10 @@ extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const 
     if (nc8 == 2) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, false, 8>), grid, dim3(512), lds8, st, p);
     else if (nc8 % 2 == 0) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, true, 8>), grid, dim3(512), lds8, st, p);
     else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 4, true, 8>), grid, dim3(512), lds8, st, p);
-  } else if (nchunk % 2 == 0 && nchunk >= 4 && lstm_pipe()) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, true, 4, true>), grid, block, lds4, st, p);
-  else if (nchunk == 2) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, false>), grid, block, lds4, st, p);
+  } else if (nchunk % 2 == 0 && nchunk >= 4 && lstm_pipe()) {
+    if (H % 256 == 0 && !lstm_tail()) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, true, 4, true, false>), grid, block, lds4, st, p);  // whole chunks only
+    else hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, true, 4, true>), grid, block, lds4, st, p);
+  } else if (nchunk == 2) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, false>), grid, block, lds4, st, p);
   else if (nchunk % 2 == 0) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4>), grid, block, lds4, st, p);
   else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 4>), grid, block, lds4, st, p);
   BLM_HIP(hipGetLastError());
@@ -830,20 +886,23 @@ extern "C" int blm_lstm_search_step_fwd(const float* xw8_t, const float* w8_hh, 
   if (!xw8_t || !w8_hh || !h_prev || !c_prev || !probs || !h || !c || B < 0 || H < 0)
     return blm_fail(BLM_ERR_INVALID, "blm_lstm_search_step_fwd: bad arguments");
   if ((long)B * H == 0) return BLM_OK;
-  if (H % 32 != 0 || !al16(w8_hh) || !al16(h_prev))
-    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_search_step_fwd: needs H % 32 == 0 and 16-byte aligned h_prev / w8_hh");
+  if (H % 32 != 0 || !al16(w8_hh) || !al16(h_prev) || 32.0 * H * H >= 4294967296.0 || 4.0 * B * H >= 4294967296.0)
+    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_search_step_fwd: needs H % 32 == 0, 16-byte aligned h_prev / w8_hh and operands under 4 GB");
   LstmStepP p{xw8_t, w8_hh, h_prev, c_prev, h, c, acts8, nullptr, nullptr, nullptr, -1, nullptr, B, H, probs};
   const size_t lds = (size_t)4 * WAVE_LDS * sizeof(float);
   static bool once = false;
   if (!once) {
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 8, true, 4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     once = true;
   }
   const int nchunk = (H / 8 + 31) / 32;
   const dim3 grid(H / 4, (B + 31) / 32), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (nchunk % 2 == 0) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 8>), grid, block, lds, st, p);
+  if (nchunk % 2 == 0 && nchunk >= 4 && H % 256 == 0 && lstm_pipe() && !lstm_tail())  // pipelined K loop, whole chunks (see blm_lstm_step_fwd)
+    hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 8, true, 4, true, false>), grid, block, lds, st, p);
+  else if (nchunk % 2 == 0) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 8>), grid, block, lds, st, p);
   else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 8>), grid, block, lds, st, p);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
@@ -858,12 +917,15 @@ extern "C" int blm_transpose(const float* in, float* out, int rows, int cols, vo
 }
 
 static int launch_step_bwd(const LstmBwdP& p, void* stream) {
+  if (4.0 * p.H * p.G >= 4294967296.0 || 4.0 * p.B * p.G >= 4294967296.0)  // the kernels address both operands with 32-bit byte offsets
+    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_bwd: operands of 4 GB and more are not supported by the fused step");
   const size_t lds4 = (size_t)4 * BWAVE_LDS * sizeof(float), lds8 = 2 * lds4;
   static bool once = false;
   if (!once) {
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((lstm_step_bwd_kernel<2, true, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((lstm_step_bwd_kernel<2, true, 4, true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((lstm_step_bwd_kernel<2, true, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((lstm_step_bwd_kernel<1, true, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
     once = true;
@@ -875,7 +937,10 @@ static int launch_step_bwd(const LstmBwdP& p, void* stream) {
     const int nc8 = (p.G / 32 + 31) / 32;
     if (nc8 % 2 == 0) hipLaunchKernelGGL((lstm_step_bwd_kernel<2, true, 8>), grid, dim3(512), lds8, st, p);
     else hipLaunchKernelGGL((lstm_step_bwd_kernel<1, true, 8>), grid, dim3(512), lds8, st, p);
-  } else if (nchunk % 2 == 0 && nchunk >= 4 && lstm_pipe()) hipLaunchKernelGGL((lstm_step_bwd_kernel<2, true, 4, true>), grid, block, lds4, st, p);
+  } else if (nchunk % 2 == 0 && nchunk >= 4 && lstm_pipe()) {
+    if (p.G % 512 == 0 && !lstm_tail()) hipLaunchKernelGGL((lstm_step_bwd_kernel<2, true, 4, true, false>), grid, block, lds4, st, p);  // whole chunks only
+    else hipLaunchKernelGGL((lstm_step_bwd_kernel<2, true, 4, true>), grid, block, lds4, st, p);
+  }
   else if (nchunk % 2 == 0) hipLaunchKernelGGL(lstm_step_bwd_kernel<2>, grid, block, lds4, st, p);
   else hipLaunchKernelGGL(lstm_step_bwd_kernel<1>, grid, block, lds4, st, p);
   BLM_HIP(hipGetLastError());
