@@ -173,7 +173,7 @@ template <int W, int S> struct FragG<true, W, S> {
   // base = byte address of (row = lane&31 of MFMA tile 0, k = 4*half)
   __device__ __forceinline__ void read(uint32_t base, int t) {
 #pragma unroll
-    for (int i = 0; i < W; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(v[i]) : "v"(base + (uint32_t)((32 * i * KS + 8 * t) * 4)));
+    for (int i = 0; i < W; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[i]) : "v"(base), "n"((32 * i * KS + 8 * t) * 4));
   }
   __device__ __forceinline__ float get(int i, int s) const { return v[i][s]; }
   __device__ __forceinline__ void tie() {
@@ -181,18 +181,24 @@ template <int W, int S> struct FragG<true, W, S> {
     for (int i = 0; i < W; ++i) asm volatile("" : "+v"(v[i]));
   }
 };
+// The per-step addresses are base + a compile-time constant: they travel in the instruction's 16-bit offset field, not in
+// vector registers (ds_read2_b32's two 8-bit offsets cannot hold a row stride, hence two ds_read_b32 per step): no
+// vector add per read in a rolled loop, no hoisted address register per read in an unrolled one.
 template <int S> struct FragG<false, 2, S> {
-  static constexpr int NREAD = 4;
-  f32x2 v[4];
+  static constexpr int NREAD = 8;
+  float v[4][2];
   // base = byte address of (k row = 4*half, column = lane&31 of MFMA tile 0); tile 1 is 32 floats further
   __device__ __forceinline__ void read(uint32_t base, int t) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) asm volatile("ds_read2_b32 %0, %1 offset1:32" : "=v"(v[s]) : "v"(base + (uint32_t)((8 * t + s) * S * 4)));
+    for (int s = 0; s < 4; ++s) {
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[s][0]) : "v"(base), "n"((8 * t + s) * S * 4));
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[s][1]) : "v"(base), "n"((8 * t + s) * S * 4 + 128));
+    }
   }
-  __device__ __forceinline__ float get(int i, int s) const { return i == 0 ? v[s].x : v[s].y; }
+  __device__ __forceinline__ float get(int i, int s) const { return v[s][i]; }
   __device__ __forceinline__ void tie() {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(v[s]));
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(v[s][0]), "+v"(v[s][1]));
   }
 };
 template <int S> struct FragG<false, 1, S> {
@@ -200,7 +206,7 @@ template <int S> struct FragG<false, 1, S> {
   float v[4];
   __device__ __forceinline__ void read(uint32_t base, int t) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) asm volatile("ds_read_b32 %0, %1" : "=v"(v[s]) : "v"(base + (uint32_t)((8 * t + s) * S * 4)));
+    for (int s = 0; s < 4; ++s) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[s]) : "v"(base), "n"((8 * t + s) * S * 4));
   }
   __device__ __forceinline__ float get(int, int s) const { return v[s]; }
   __device__ __forceinline__ void tie() {
@@ -252,7 +258,7 @@ template <int W> struct FragD {  // swizzled tile[row][32]: per-group byte addre
   f32x4 v[W];
   __device__ __forceinline__ void read(const uint32_t (&bt)[4], int t) {
 #pragma unroll
-    for (int i = 0; i < W; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(v[i]) : "v"(bt[t] + (uint32_t)(4096 * i)));
+    for (int i = 0; i < W; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[i]) : "v"(bt[t]), "n"(4096 * i));
   }
   __device__ __forceinline__ float get(int i, int s) const { return v[i][s]; }
   __device__ __forceinline__ void tie() {
@@ -261,8 +267,8 @@ template <int W> struct FragD {  // swizzled tile[row][32]: per-group byte addre
   }
 };
 
-template <int N>
-__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+template <int N>  // the counter has 4 bits: more than 15 reads in flight -> wait for "at most 15" (one read early: LDS returns in order)
+__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N > 15 ? 15 : N)); }
 
 // ---- opt-in split-bf16 arithmetic (NOT the default) -------------------------
 // x = hi + lo with hi = bf16_rne(x), lo = bf16_rne(x - hi): eight fp32 values of a lane -> the two bf16x8
@@ -940,8 +946,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     if constexpr (DMA) {
       const uint32_t la = __builtin_amdgcn_readfirstlane(lds_u32(As + buf * TA) + (uint32_t)(NQA * wave) * 1024u);
       const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_u32(Bs + buf * TB) + (uint32_t)(NQB * wave) * 1024u);
-      const float* sa = p.A + (A_KMAJ ? (long)ktile * BK : (long)ktile * BK * p.lda);  // wave uniform: stays in SGPRs
-      const float* sb = p.B + (B_KMAJ ? (long)ktile * BK : (long)ktile * BK * p.ldb);
+      // wave uniform by construction; hipcc does not always keep the 64-bit row-stride product in scalar registers once
+      // the loop is unrolled (an "s" asm operand must BE one), so the halves go through readfirstlane
+      auto uni = [](const float* q) {
+        const uint64_t v = reinterpret_cast<uint64_t>(q);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+      };
+      const float* sa = uni(p.A + (A_KMAJ ? (long)ktile * BK : (long)ktile * BK * p.lda));
+      const float* sb = uni(p.B + (B_KMAJ ? (long)ktile * BK : (long)ktile * BK * p.ldb));
 #pragma unroll
       for (int q = 0; q < NQA; ++q) glds16s(sa, dsa[q], la + 1024u * q);
 #pragma unroll
@@ -970,12 +983,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     // tile kt+1 travels global -> LDS (other buffer) while tile kt is multiplied; the counted wait
     // retires this wave's DMA, the barrier everybody's, and also fences the reads of the buffer that the
     // next iteration overwrites
-    for (; kt + 1 < tfull; ++kt) {
-      const int cur = (kt - t0) & 1;
-      dma_issue(cur ^ 1, kt + 1);
+    // Two tiles per trip: tile kt sits in buffer (kt - t0) & 1, so inside the trip the buffer index is a compile-time
+    // constant and every LDS fragment address is base + immediate -- no vector adds in the loop (on gfx950 each vector
+    // instruction is paid in matrix time, tools/mfma_valu_overlap.hip).
+    auto dma_step = [&](int cur, int next_tile) {
+      dma_issue(cur ^ 1, next_tile);
       compute_dma(cur);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+    };
+    for (; kt + 2 < tfull; kt += 2) {
+      dma_step(0, kt + 1);
+      dma_step(1, kt + 2);
+    }
+    if (kt + 1 < tfull) {
+      dma_step(0, kt + 1);
+      ++kt;
     }
   } else if constexpr (FAST && !SAMP && WTM == 2 && WTN == 2) {  // smaller tiles: the second register set would cost them a workgroup per CU
     // Steady state with the global loads TWO K tiles ahead (two register sets, LDS still double
