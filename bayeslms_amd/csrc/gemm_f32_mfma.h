@@ -986,11 +986,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     // Two tiles per trip: tile kt sits in buffer (kt - t0) & 1, so inside the trip the buffer index is a compile-time
     // constant and every LDS fragment address is base + immediate -- no vector adds in the loop (on gfx950 each vector
     // instruction is paid in matrix time, tools/mfma_valu_overlap.hip).
+    // (Measured and not kept: three LDS stages for the 24 KB tiles, tile kt+2 in flight while kt is multiplied -- the
+    // roofline shape does not move, +0.3 %, and the launches that ran three workgroups per CU lose one: -3 ... -8 %.
+    // The wait in front of the barrier is not what the loop loses.)
     auto dma_step = [&](int cur, int next_tile) {
+      BLM_PF_NOW(ta)
       dma_issue(cur ^ 1, next_tile);
       compute_dma(cur);
+      BLM_PF_NOW(tb)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      BLM_PF_NOW(tc)
       __syncthreads();
+      BLM_PF_NOW(td)
+      BLM_PF_ADD()
     };
     for (; kt + 2 < tfull; kt += 2) {
       dma_step(0, kt + 1);
