@@ -1000,13 +1000,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
       BLM_PF_NOW(td)
       BLM_PF_ADD()
     };
-    for (; kt + 2 < tfull; kt += 2) {
-      dma_step(0, kt + 1);
-      dma_step(1, kt + 2);
-    }
-    if (kt + 1 < tfull) {
-      dma_step(0, kt + 1);
-      ++kt;
+    if constexpr (SPLIT != 0) {  // opt-in split-bf16 kernels: the two-tile body demotes their fragment arrays to scratch
+      for (; kt + 1 < tfull; ++kt) dma_step((kt - t0) & 1, kt + 1);
+    } else {
+      for (; kt + 2 < tfull; kt += 2) {
+        dma_step(0, kt + 1);
+        dma_step(1, kt + 2);
+      }
+      if (kt + 1 < tfull) {
+        dma_step(0, kt + 1);
+        ++kt;
+      }
     }
   } else if constexpr (FAST && !SAMP && WTM == 2 && WTN == 2) {  // smaller tiles: the second register set would cost them a workgroup per CU
     // Steady state with the global loads TWO K tiles ahead (two register sets, LDS still double
