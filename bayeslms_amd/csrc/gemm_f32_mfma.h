@@ -636,11 +636,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   float* const Bs = smem + 2 * TA;
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
-  // contiguous run of tile ids; n is fastest so neighbours reuse the same A panel out of that XCD's L2.
+  // contiguous run of tile ids.
   const int nb = p.gm * p.gn, bid = blockIdx.x % nb, ks = blockIdx.x / nb;
   const int q = nb >> 3, rem = nb & 7, xcd = bid & 7;
   const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-  const int m0 = (id / p.gn) * BM, n0 = (id % p.gn) * BN;
+  // Inside the run, groups of 8 row blocks with the row block fastest: the 64 workgroups an XCD holds at a time are an
+  // 8 x 8 block of tiles -- 8 A panels + 8 B panels of unique operand rows per K step, every line wanted by 8
+  // workgroups at once -- whatever gn is (n fastest made a round 2 x 32 tiles at gn = 32 and 1 x 64 at the decoder's
+  // gn = 258, where every row block streamed the whole weight again: 4.3 GB of reads for 84 MB of operands).
+  // (gn <= 8 keeps n fastest: the same 8 x 8 set per round, and measured 20 % fewer fetched bytes than the row-block-fastest
+  // placement of the same tiles on the CUs -- PMC FETCH_SIZE, roofline shape.)
+  constexpr int GROUP = 8;
+  int mt, nt;
+  if (p.gn <= GROUP) {
+    mt = id / p.gn;
+    nt = id - mt * p.gn;
+  } else {
+    const int per = GROUP * p.gn, grp = id / per, first = grp * GROUP, gsz = min(p.gm - first, GROUP), in = id - grp * per;
+    mt = first + in % gsz;
+    nt = in / gsz;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -689,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   }
 
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool do_cs = !A_KMAJ && p.colsum_a != nullptr && (id % p.gn) == 0;  // one N-tile column of blocks does it
+  const bool do_cs = !A_KMAJ && p.colsum_a != nullptr && n0 == 0;  // one N-tile column of blocks does it
 
   auto fetch_fast = [&](int kt) {
     if constexpr (FAST) {
