@@ -101,8 +101,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
   // buffer loads: descriptor (scalar registers, built from kernel arguments) + one 32-bit byte offset per staged row
   // + a scalar offset for the wave's K slice and the chunk: a chunk step costs no vector instruction (hipcc turns
   // base + zext(offset) of a plain pointer into 64-bit vector adds once the offsets are hoisted out of the loop)
-  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.hprev), 0, B * H * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.whh), 0, NS * H * H * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.hprev), 0, (int)(4u * (uint32_t)B * (uint32_t)H), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.whh), 0, (int)(4u * NS * (uint32_t)H * (uint32_t)H), 0x00020000);  // < 4 GB (host check)
   const int kb4 = __builtin_amdgcn_readfirstlane(kbase * 4);
   uint32_t aoff[8], woff[8];
 #pragma unroll
@@ -505,8 +505,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
   // staging roles: one instruction moves 2 rows x 4 quarters x 128 B
   const int srow = lane >> 5, squart = (lane >> 3) & 3, spart = lane & 7;
   // buffer loads (descriptor + 32-bit row offset + scalar slice / chunk offset): see the forward kernel
-  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dg), 0, B * p.G * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, H * p.G * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dg), 0, (int)(4u * (uint32_t)B * (uint32_t)p.G), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, (int)(4u * (uint32_t)H * (uint32_t)p.G), 0x00020000);
   const int kb4 = __builtin_amdgcn_readfirstlane(wave * Kw * 4);
   uint32_t aoff[8], woff[8];
 #pragma unroll
