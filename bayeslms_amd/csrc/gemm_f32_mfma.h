@@ -1295,14 +1295,24 @@ int launch_op(const GemmP& p, hipStream_t st) {
   //    slices with atomics: 101 TF) run on 128x64 tiles when those fill a round (288 tiles x the slice count of the fill rule: 115 TF); a very long
   //    reduction (decoder dX, K = 33000) keeps the split 128x128 form (131 TF against 126).
   GemmP pf = p;
+  // Re-swept in situ (tools/step_breakdown.py lstm under BLM_GEMM_TILE / BLM_GEMM_SPLITK) once the K loops had lost their
+  // vector instructions -- the small tiles, three to five workgroups per CU, gained most:
+  //  * medium-reduction weight gradients on UNSPLIT 64x64 tiles when those give at least two rounds (decoder dW
+  //    33000x1024x2240: 1235 -> 1151 us, dW_ih / dW_hh 4096x1024x2240: 149.5 -> 145.5 us);
+  //  * dX 2240x1024x4096 on 64x64 tiles x 4 K slices (168.9 -> 158.4 us), decoder dX 2240x1024x33000 on 64x128 tiles x 8
+  //    slices (1124 -> 1097 us).
   if (can_split && p.K >= 2048 && p.M > 64 && p.N > 64 && b128 >= 96) {
+    const long t11 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64), t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
     if (OP == BLM_GEMM_TN && p.K < 4096) {
-      const long t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
       auto fill = [](long g) { return (double)g / (double)(((g + 511) / 512) * 512); };
-      if (fill(t12) > fill(b128) + 0.05) { small_m = true; small_n = false; }
+      if (t11 >= 1024 && p.epi == BLM_EPI_NONE) { small_m = small_n = true; pf.force_splits = 1; }
+      else if (fill(t12) > fill(b128) + 0.05) { small_m = true; small_n = false; }
     } else if (OP == BLM_GEMM_NN && p.K <= 8192 && b128 < 256) {
       const long t21 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
-      if (t21 >= 256) { small_m = false; small_n = true; }
+      if (t11 >= 512 && p.K >= 4096) { small_m = small_n = true; pf.force_splits = 4; }
+      else if (t21 >= 256) { small_m = false; small_n = true; }
+    } else if (OP == BLM_GEMM_NN && p.K > 8192 && b128 < 256 && t12 >= 256) {
+      small_m = true; small_n = false; pf.force_splits = 8;
     }
   }
   if (p.force_tile == 11) { small_m = small_n = true; }
