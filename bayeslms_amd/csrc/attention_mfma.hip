@@ -109,7 +109,7 @@ __device__ __forceinline__ constexpr int mrow(int r, int h) { return (r & 3) + 8
 __device__ __forceinline__ void keep_row4(const AttnM& p, uint64_t grow, int c0, float (&k)[4]) {
   const uint64_t g = grow * (uint64_t)p.T + (uint64_t)c0;
   if ((p.T & 3) == 0) {
-    const u32x4 u = philox4x32_10_rolled((uint32_t)(g >> 2), (uint32_t)(g >> 34), p.rng.stream, p.rng.step,
+    const u32x4 u = philox4x32_10((uint32_t)(g >> 2), (uint32_t)(g >> 34), p.rng.stream, p.rng.step,
                                          (uint32_t)p.rng.seed, (uint32_t)(p.rng.seed >> 32));
     k[0] = u.x >= p.thr ? p.inv_keep : 0.f; k[1] = u.y >= p.thr ? p.inv_keep : 0.f;
     k[2] = u.z >= p.thr ? p.inv_keep : 0.f; k[3] = u.w >= p.thr ? p.inv_keep : 0.f;
@@ -448,7 +448,7 @@ __device__ __forceinline__ void attn_dkv_pass(const AttnM& p, const float* Qs, c
         const int qrow = min(q0 + kq, T - 1);
         if ((T & 3) == 0) {
           const uint64_t gidx = (bh * T + qrow) * (uint64_t)T + (uint64_t)(min(key, T - 1) & ~3);
-          const u32x4 u = philox4x32_10_rolled((uint32_t)(gidx >> 2), (uint32_t)(gidx >> 34), p.rng.stream, p.rng.step,
+          const u32x4 u = philox4x32_10((uint32_t)(gidx >> 2), (uint32_t)(gidx >> 34), p.rng.stream, p.rng.step,
                                                (uint32_t)p.rng.seed, (uint32_t)(p.rng.seed >> 32));
 #define BLM_QB(x, j) (uint32_t) __builtin_amdgcn_mov_dpp((int)(x), (j) * 0x55, 0xF, 0xF, true)
 #define BLM_KP(j)                                                                                         \
