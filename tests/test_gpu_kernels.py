@@ -573,7 +573,10 @@ def test_lstm_layer_matches_oracle(dev):
 
 
 @pytest.mark.parametrize("T,B,E,H", [(5, 64, 48, 256), (4, 20, 32, 96), (3, 70, 40, 320), (3, 1, 16, 32), (6, 2, 16, 64),
-                                     (6, 3, 24, 96), (4, 4, 32, 1024), (5, 1, 64, 1024), (3, 5, 16, 64)])
+                                     (6, 3, 24, 96), (4, 4, 32, 1024), (5, 1, 64, 1024), (3, 5, 16, 64),
+                                     # the software-pipelined K loops: whole chunks only (H % 256 == 0: no zero fill, scalar
+                                     # chunk offsets) with ragged batch tiles, and the general form with a K tail (H = 1856)
+                                     (3, 37, 32, 1024), (2, 33, 32, 2048), (2, 9, 32, 1536), (2, 5, 32, 1856), (2, 8, 32, 1280)])
 def test_lstm_layer_fused_step_matches_oracle(dev, T, B, E, H):
     """H % 32 == 0 takes blm_lstm_step_fwd (one launch per step: MFMA recurrent product + cell):
     ragged batch tiles (20, 70, 1), K tails (H/8 = 12, 40), and the accumulate-in-place backward.  B <= 4 forwards run
