@@ -33,4 +33,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and rf["launches"] == 3
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.4 < rf["frac"] < 1.0  # north-star floor: 0.40
     assert abs(rf["achieved"] - 2.0 * 8192 * 512 * 4096 / (rf["avg_launch_ms"] * 1e-3) / 1e12) < 0.5
+    sr = out["step_roofline"]  # whole step: SURVEY 8(d) model FLOPs per token over the measured step time
+    assert sr["model_flops_per_token"] == 294838272 and sr["peak"] == 157.3
+    assert abs(sr["achieved"] - 294838272 * out["value"] / 1e12) < 0.01 * sr["achieved"] and abs(sr["frac"] - sr["achieved"] / 157.3) < 1e-3
     assert out["value"] > 2.0e5  # a silent fallback (vendor / eager path) or a broken kernel shows up here
