@@ -60,8 +60,61 @@ def main():
                 bad += 1
                 print("SCRATCH IN LOOP", kern, i, t)
         print(f, "counted-wait regions:", regions)
+        bad += valu_in_loops(lines, r"^(_ZN3blm15gemm_f32_kernelILi\dELi\dELi\dELb0ELb1ELi0E\S+):", "global_load_lds", 4)
+    bad += audit_lstm()
     print("OK" if bad == 0 else "%d problems" % bad)
     return 1 if bad else 0
+
+
+def valu_in_loops(lines, kern_re, must_have, limit):
+    """On gfx950 a vector instruction in a matrix loop is paid in matrix time (tools/mfma_valu_overlap.hip): in every
+    steady-state loop (a backward branch spanning >= 32 MFMAs and at least one `must_have` instruction) of the
+    kernels matching kern_re, count the non-MFMA v_* instructions and flag more than `limit` per trip."""
+    bad, kern = 0, None
+    labels = {}
+    for i, l in enumerate(lines):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            labels[m.group(1)] = i
+    starts = [(i, re.match(r"^(_Z\S+):", l).group(1)) for i, l in enumerate(lines) if re.match(r"^(_Z\S+):", l)]
+    back, best = [], {}
+    for i, l in enumerate(lines):
+        m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            back.append((labels[m.group(1)], i))
+    for a, i in back:
+        if any((a2, i2) != (a, i) and a <= a2 and i2 <= i for a2, i2 in back):  # innermost loops only
+            continue
+        owner = [k for s0, k in starts if s0 < a]
+        if not owner or not re.match(kern_re, owner[-1] + ":"):
+            continue
+        body = [x.strip() for x in lines[a:i]]
+        nm = sum(1 for x in body if x.startswith("v_mfma"))
+        if nm < 32 or not any(x.startswith(must_have) for x in body):
+            continue
+        valu = sum(1 for x in body if x.startswith("v_") and not x.startswith("v_mfma"))
+        if owner[-1] not in best or nm > best[owner[-1]][0]:
+            best[owner[-1]] = (nm, valu)
+    for k, (nm, valu) in best.items():  # the steady-state loop = the innermost one with the most MFMAs (remainder steps run once)
+        print("  %-70s loop of %3d MFMAs: %d vector instructions" % (k[:70], nm, valu))
+        if valu > limit:
+            bad += 1
+            print("VECTOR INSTRUCTIONS IN A MATRIX LOOP", k, valu)
+    return bad
+
+
+def audit_lstm():
+    """The software-pipelined LSTM step kernels without a K tail must have NO vector instruction in their K loops."""
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "lstm_step.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I",
+                               os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-Wno-pass-failed",
+                               os.path.join(ROOT, "bayeslms_amd", "csrc", "lstm_step.hip"), "-o", out],
+                              stderr=subprocess.DEVNULL)
+        lines = open(out).read().split("\n")
+    # <RING 2, ..., NW 4, PIPE true, TAIL false>
+    return (valu_in_loops(lines, r"^(_ZN3blm20lstm_step_fwd_kernelILi2ELi\dELb1ELi4ELb1ELb0E\S+):", "buffer_load", 0) +
+            valu_in_loops(lines, r"^(_ZN3blm20lstm_step_bwd_kernelILi2ELb1ELi4ELb1ELb0E\S+):", "buffer_load", 0))
 
 
 if __name__ == "__main__":
