@@ -984,8 +984,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   const int kbeg = ks * p.kper, kend = min(p.K, kbeg + p.kper);
   const int t0 = kbeg / BK, t1 = (kend + BK - 1) / BK;
   const int tfull = FAST ? min(t1, p.K / BK) : t0;  // tiles [t0, tfull) go through the fast loaders
-  if (t0 < tfull) fetch_fast(t0); else fetch_slow(t0 * BK);
-  stash(0, t0 * BK, t0 < tfull);
+  if constexpr (DMA) {
+    // the first tile takes the DMA path too: no per-thread operand pointers, no register staging in these kernels at all
+    // (a 16-tile reduction spends a sixth of its life around the K loop)
+    if (t0 < tfull) {
+      dma_issue(0, t0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      fetch_slow(t0 * BK);
+      stash(0, t0 * BK, false);
+    }
+  } else {
+    if (t0 < tfull) fetch_fast(t0); else fetch_slow(t0 * BK);
+    stash(0, t0 * BK, t0 < tfull);
+  }
   __syncthreads();
   int kt = t0;
 #ifdef BLM_GEMM_PROF
