@@ -185,33 +185,71 @@ template <int W, int S> struct FragG<true, W, S> {
 // vector registers (ds_read2_b32's two 8-bit offsets cannot hold a row stride, hence two ds_read_b32 per step): no
 // vector add per read in a rolled loop, no hoisted address register per read in an unrolled one.
 template <int S> struct FragG<false, 2, S> {
-  static constexpr int NREAD = 8;
-  float v[4][2];
+  // Row strides that are a multiple of 64 floats (the unpadded LDS-DMA images: S = 64 or 128): ds_read2st64_b32 takes
+  // two offsets in units of 256 bytes, i.e. two K ROWS of one column per instruction -- half the LDS read instructions
+  // of the two-ds_read_b32 form, offsets still immediates (one extra base register for the second MFMA tile).
+  static constexpr bool ST64 = S % 64 == 0;
+  static constexpr int NREAD = ST64 ? 4 : 8;
+  float v[4][2];    // [k step][tile]   (general form)
+  f32x2 w[2][2];    // [tile][k-step pair] (ST64 form)
   // base = byte address of (k row = 4*half, column = lane&31 of MFMA tile 0); tile 1 is 32 floats further
   __device__ __forceinline__ void read(uint32_t base, int t) {
+    if constexpr (ST64) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[s][0]) : "v"(base), "n"((8 * t + s) * S * 4));
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[s][1]) : "v"(base), "n"((8 * t + s) * S * 4 + 128));
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(w[i][h]) : "v"(base + 128u * i),
+                       "n"((8 * t + 2 * h) * (S / 64)), "n"((8 * t + 2 * h + 1) * (S / 64)));
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[s][0]) : "v"(base), "n"((8 * t + s) * S * 4));
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[s][1]) : "v"(base), "n"((8 * t + s) * S * 4 + 128));
+      }
     }
   }
-  __device__ __forceinline__ float get(int i, int s) const { return v[s][i]; }
+  __device__ __forceinline__ float get(int i, int s) const {
+    if constexpr (ST64) return (s & 1) ? w[i][s >> 1].y : w[i][s >> 1].x;
+    else return v[s][i];
+  }
   __device__ __forceinline__ void tie() {
+    if constexpr (ST64) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(v[s][0]), "+v"(v[s][1]));
+      for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(w[i][0]), "+v"(w[i][1]));
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(v[s][0]), "+v"(v[s][1]));
+    }
   }
 };
 template <int S> struct FragG<false, 1, S> {
-  static constexpr int NREAD = 4;
+  static constexpr bool ST64 = S % 64 == 0;  // see FragG<false, 2, S>
+  static constexpr int NREAD = ST64 ? 2 : 4;
   float v[4];
+  f32x2 w[2];
   __device__ __forceinline__ void read(uint32_t base, int t) {
+    if constexpr (ST64) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[s]) : "v"(base), "n"((8 * t + s) * S * 4));
+      for (int h = 0; h < 2; ++h)
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(w[h]) : "v"(base), "n"((8 * t + 2 * h) * (S / 64)),
+                     "n"((8 * t + 2 * h + 1) * (S / 64)));
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[s]) : "v"(base), "n"((8 * t + s) * S * 4));
+    }
   }
-  __device__ __forceinline__ float get(int, int s) const { return v[s]; }
+  __device__ __forceinline__ float get(int, int s) const {
+    if constexpr (ST64) return (s & 1) ? w[s >> 1].y : w[s >> 1].x;
+    else return v[s];
+  }
   __device__ __forceinline__ void tie() {
+    if constexpr (ST64) {
+      asm volatile("" : "+v"(w[0]), "+v"(w[1]));
+    } else {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(v[s]));
+      for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(v[s]));
+    }
   }
 };
 // ---- LDS-DMA loaders ----------------------------------------------------------------------------
