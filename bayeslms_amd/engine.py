@@ -73,13 +73,27 @@ class GradReducer:
         self.late = None  # LateRows, set by the Trainer
         self.measure = False  # record (backward end, communication end) event pairs on the compute stream
         self.exposed_events = []
-        # buckets = contiguous runs of parameters, built from the END of the buffer (backward order)
+        # buckets = contiguous runs of parameters, built from the END of the buffer (backward order).  Two refinements
+        # for what is exposed at the end of backward:
+        #  * a tensor of a bucket's size or more travels ALONE (the tied encoder / decoder weight, 67.6 MB at cfg3: with
+        #    LateRows its dense half is complete after the FIRST backward kernel -- sharing a bucket with the first
+        #    layer's parameters would hold it, and 100+ MB of all-reduce, until the last one);
+        #  * the parameters that become ready last (the lowest offsets) go in quarter-size buckets: the final all-reduce,
+        #    which nothing can hide, moves 8 MB instead of 32.
         per = max(1, bucket_bytes // 4)
+        n = len(flat.params)
+        sizes = [(flat.offsets[i + 1] if i + 1 < n else flat.total) - flat.offsets[i] for i in range(n)]
+        first_small = next((i for i in range(n) if sizes[i] < per), n)  # first parameter behind the leading big tensor(s)
+        tail_end = flat.offsets[first_small] + 2 * per if first_small < n else 0  # offsets below this: quarter-size buckets
         self.buckets = []  # (start, end, [param indices])
         idxs, end = [], flat.total
-        for i in range(len(flat.params) - 1, -1, -1):
+        for i in range(n - 1, -1, -1):
+            if sizes[i] >= per and idxs:  # close the run behind a big tensor first
+                self.buckets.append((flat.offsets[i + 1], end, list(idxs)))
+                idxs, end = [], flat.offsets[i + 1]
             idxs.append(i)
-            if end - flat.offsets[i] >= per or i == 0:
+            limit = per // 4 if (flat.offsets[i] < tail_end and sizes[i] < per) else per
+            if end - flat.offsets[i] >= max(1, limit) or i == 0:
                 self.buckets.append((flat.offsets[i], end, list(idxs)))
                 idxs, end = [], flat.offsets[i]
         self.bucket_of = {}

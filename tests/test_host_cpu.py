@@ -315,3 +315,36 @@ def test_stage7_score_interpolation_matches_awk(tmp_path):
                % (d, d, d))
         ref = subprocess.run(cmd, shell=True, capture_output=True, text=True, check=True).stdout
         assert open(out).read() == ref
+
+
+def test_reducer_bucket_layout_big_tensor_alone_and_small_final_buckets():
+    """What is exposed at the end of backward is the LAST bucket to become ready (the lowest offsets of the flat
+    buffer): quarter-size buckets there; a tensor of a bucket's size or more (the tied encoder / decoder weight) travels
+    alone, so that its dense half -- complete after the first backward kernel -- is not held back by other parameters."""
+    import torch
+    from bayeslms_amd import engine
+
+    class Head(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.big = torch.nn.Parameter(torch.zeros(40000))
+            self.bias = torch.nn.Parameter(torch.zeros(33))
+
+    class M(torch.nn.Module):  # the layers first, the big (tied) tensor and the decoder bias at the end, as in the LMs
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(n)) for n in (300, 500, 700, 900, 1100, 1300, 1500,
+                                                                                          1700, 1900, 2100, 2300, 2500)])
+            self.head = Head()
+    flat = engine.FlatBuffers(M())
+    red = engine.GradReducer(flat, bucket_bytes=4 * 4000)  # 4000 floats per bucket
+    spans = [(s, e) for s, e, _ in red.buckets]
+    assert spans[0][1] == flat.total and spans[-1][0] == 0
+    assert all(spans[i][0] == spans[i + 1][1] for i in range(len(spans) - 1))  # contiguous cover, backward order
+    ids = [i for _, _, i in red.buckets]
+    big = [k for k, p in enumerate(flat.params) if p.numel() == 40000][0]
+    assert [big] in ids  # alone
+    # the parameters below 2 buckets' worth of offsets are cut at a quarter of the size: the final bucket is small
+    assert spans[-1][1] - spans[-1][0] <= 2000 and len(red.buckets) >= 5
+    # every parameter is in exactly one bucket
+    assert sorted(i for b in ids for i in b) == list(range(len(flat.params)))
