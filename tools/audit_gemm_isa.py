@@ -60,7 +60,7 @@ def main():
                 bad += 1
                 print("SCRATCH IN LOOP", kern, i, t)
         print(f, "counted-wait regions:", regions)
-        bad += valu_in_loops(lines, r"^(_ZN3blm15gemm_f32_kernelILi\dELi\dELi\dELb0ELb1ELi0E\S+):", "global_load_lds", 4)
+        bad += valu_in_loops(lines, r"^(_ZN3blm15gemm_f32_kernelILi\dELi\dELi\dELb0ELb1ELi0E\S+):", "global_load_lds", 4 if f != "gemm_tn" else 16)  # TN: + the bias-gradient column sums' branch and the second tile's read bases
     bad += audit_lstm()
     print("OK" if bad == 0 else "%d problems" % bad)
     return 1 if bad else 0
@@ -82,8 +82,11 @@ def valu_in_loops(lines, kern_re, must_have, limit):
         m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
         if m and m.group(1) in labels and labels[m.group(1)] < i:
             back.append((labels[m.group(1)], i))
-    for a, i in back:
-        if any((a2, i2) != (a, i) and a <= a2 and i2 <= i for a2, i2 in back):  # innermost loops only
+    def mfmas(a, i):
+        return sum(1 for x in lines[a:i] if x.strip().startswith("v_mfma"))
+    heavy = [(a, i) for a, i in back if mfmas(a, i) >= 32]
+    for a, i in heavy:
+        if any((a2, i2) != (a, i) and a <= a2 and i2 <= i for a2, i2 in heavy):  # innermost matrix loops only
             continue
         owner = [k for s0, k in starts if s0 < a]
         if not owner or not re.match(kern_re, owner[-1] + ":"):
