@@ -1107,11 +1107,11 @@ class _LSTMLayer(torch.autograd.Function):
         dx = torch.empty_like(x)
         gemm(L.GEMM_NN, dgates, w_ih, dx, T * B, E, G, G, E, E)
         dw_ih = torch.empty_like(w_ih)
-        gemm(L.GEMM_TN, dgates, x, dw_ih, G, E, T * B, G, E, E)
+        db = torch.zeros(G, device=dev, dtype=torch.float32)
+        # the bias gradient = column sums of dgates, taken from the A tiles this weight-gradient GEMM stages anyway
+        gemm(L.GEMM_TN, dgates, x, dw_ih, G, E, T * B, G, E, E, colsum_a=db)
         dw_hh = torch.empty_like(w_hh)
         gemm(L.GEMM_TN, dgates, hs, dw_hh, G, H, T * B, G, H, H)  # hs[0:T] = h_{t-1}
-        db = torch.empty(G, device=dev, dtype=torch.float32)
-        _colsum_into(dgates, T * B, G, db, accumulate=False)
         return dx, dh, dc, dw_ih, dw_hh, db, db, d_noise
 
 
