@@ -5,6 +5,7 @@ set -e
 OTHER=$1; shift
 LIB=bayeslms_amd/libbayeslm_hip.so
 cp $LIB /tmp/lib_new.so
+trap 'cp /tmp/lib_new.so $LIB' EXIT  # whatever happens, the in-tree library is the one that was there
 for rep in 1 2; do
   cp /tmp/lib_new.so $LIB; echo "== new (rep $rep)"; "$@"
   cp $OTHER $LIB; echo "== old (rep $rep)"; "$@"
