@@ -432,6 +432,8 @@ def main():
             "comm_exposed_ms": None if comm_exposed is None else round(comm_exposed, 4),
             "comm": None if world == 1 else {
                 "backend": args.backend, "bucket_mb": 32, "buckets": len(tr.reducer.buckets),
+                # the bucket that becomes ready last (layer 0's first parameters): the all-reduce nothing can hide
+                "last_bucket_mb": round((tr.reducer.buckets[-1][1] - tr.reducer.buckets[-1][0]) * 4 / 1e6, 2),
                 "grad_bytes": int(tr.flat.total * 4),
                 "late_rows": tr.reducer.late is not None,
                 "late_rows_last_step": None if tr.reducer.late is None else int(tr.reducer.late.U)},
