@@ -135,21 +135,32 @@ def compute_scores(nbest, model, vocab, model_type, device, model_2=None, alpha=
     return scores
 
 
+_PACKED = os.environ.get("BLM_SCORER_PACKED", "1") != "0"  # 0: padded (T, N) activations in the Transformer stacks (A/B)
+
+
 def _batch_nll(model, data, target_flat, model_type, hidden, model_2, hidden_2, alpha, rows=None):
     """Per-token NLL of a padded batch of hypotheses (all columns start from the same state): (T, N), or -- with
     ``rows`` (flat indices t*N + n of the real tokens) -- one value per selected row, the decoder being applied to those
     rows only (model._ProjHolder.rows)."""
     from . import ops
+    import contextlib
+    # Transformers whose operations outside the attention core are all token-wise keep ONLY the real tokens' rows through
+    # the whole stack (ops.packed_tokens): the rows arrive at the decoder already selected, in the order of ``rows``
+    packed = (rows is not None and model_type == 'Transformer' and _PACKED and getattr(model, "supports_packed", False)
+              and (model_2 is None or getattr(model_2, "supports_packed", False)))
     for m in (model, model_2):
         if m is not None:
-            m.decoder.rows = rows
+            m.decoder.rows = None if packed else rows
     try:
-        if model_type == 'Transformer':
-            out = model(data)
-        else:
-            out, _ = model(data, hidden)
+        with (ops.packed_tokens(rows, data.shape[0], data.shape[1]) if packed else contextlib.nullcontext()):
+            if model_type == 'Transformer':
+                out = model(data)
+            else:
+                out, _ = model(data, hidden)
+            out2 = None
+            if model_2 is not None:
+                out2 = model_2(data) if model_type == 'Transformer' else model_2(data, hidden_2)[0]
         if model_2 is not None:
-            out2 = model_2(data) if model_type == 'Transformer' else model_2(data, hidden_2)[0]
             _, nll = ops.cross_entropy_interp(out.view(-1, out.shape[-1]), out2.view(-1, out2.shape[-1]), alpha, target_flat)
         else:
             _, nll = ops.cross_entropy(out.view(-1, out.shape[-1]), target_flat)

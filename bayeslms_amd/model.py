@@ -199,7 +199,11 @@ class MultiheadAttention(_Site):
     def forward(self, query, key=None, value=None, key_padding_mask=None, need_weights=True, attn_mask=None, _link=None):
         _need_causal(attn_mask)
         qkv = self.qkv_net(query, _link)  # _link: ops.ResidualLink of the enclosing post-LN block (new, optional)
-        a = ops.attention(qkv, self.num_heads, self._drop(self.dropout))
+        pk = ops.packing()  # scorer: compact real-token rows everywhere but inside the attention core
+        if pk is not None:
+            a = pk.pack(ops.attention(pk.unpack(qkv), self.num_heads, self._drop(self.dropout)))
+        else:
+            a = ops.attention(qkv, self.num_heads, self._drop(self.dropout))
         return self.o_net(a), None
 
 
@@ -225,8 +229,12 @@ class BayesMultiheadAttention(_Site):
         value = query if value is None else value
         # three projections read the block input: its gradient has several producers, so the residual link (valid only
         # when the linked op is the ONLY other consumer of x) is not used here
-        a = ops.attention_qkv(self.q_net(query), self.k_net(key), self.v_net(value), self.num_heads,
-                              self._drop(self.dropout))
+        q, k, v = self.q_net(query), self.k_net(key), self.v_net(value)
+        pk = ops.packing()
+        if pk is not None:
+            a = pk.pack(ops.attention_qkv(pk.unpack(q), pk.unpack(k), pk.unpack(v), self.num_heads, self._drop(self.dropout)))
+        else:
+            a = ops.attention_qkv(q, k, v, self.num_heads, self._drop(self.dropout))
         return self.o_net(a), None
 
 
@@ -302,6 +310,8 @@ class _LMHead(_Site):
 class BayesTransformerModel(_LMHead):
     """Reference model.py:1179-1309.  Only layer 0 is Bayesian and it is built with a hard-coded
     dropout of 0.2 (model.py:1202,1207); any other ``bayes_pos`` string builds zero layers."""
+    supports_packed = True  # ops.packed_tokens (scorer): everything outside the attention core is token-wise
+
 
     def __init__(self, ntoken, ninp, nhead, nhid, nlayers, dropout=0.5, tie_weights=False, bayes_pos=None):
         super().__init__()
@@ -344,6 +354,8 @@ class BayesTransformerModel(_LMHead):
             # gather * sqrt(d) + positional table + dropout in one kernel (model.py:1284,1293)
             x = ops.embed(src, self.encoder.weight, self.pos_encoder.table(), scale,
                           self.pos_encoder._drop(self.pos_encoder.p))
+        if ops.packing() is not None:
+            x = ops.packing().pack(x)
         for layer in self.transformerlayers:
             x = layer(x, src_mask=self.src_mask)
         if self.bayes_embed:
@@ -500,6 +512,8 @@ class GaussTransformerEncoderLayer(_Site):
 class GaussTransformerModel(_LMHead):
     """Reference model.py:2298-2364: layer 0 is the GP layer for gauss_pos 0..3 (built with the
     model's dropout), gauss_pos > 4 builds an all-standard stack."""
+    supports_packed = True  # ops.packed_tokens (scorer): everything outside the attention core is token-wise
+
 
     def __init__(self, ntoken, ninp, nhead, nhid, nlayers, dropout=0.5, tie_weights=False, gauss_pos=4):
         super().__init__()
@@ -523,6 +537,8 @@ class GaussTransformerModel(_LMHead):
             raise BayesLMError("has_mask=False: the fused attention kernel is causal only")
         x = ops.embed(src, self.encoder.weight, self.pos_encoder.table(), math.sqrt(self.ninp),
                       self.pos_encoder._drop(self.pos_encoder.p))
+        if ops.packing() is not None:
+            x = ops.packing().pack(x)
         for layer in self.transformerlayers:
             x = layer(x, src_mask=True)
         return self.decoder(x)
@@ -599,6 +615,9 @@ class _TorchMHAParams(_Site):
     def forward(self, query, key=None, value=None, attn_mask=None, **_):
         _need_causal(attn_mask)
         qkv = ops.linear(query, self.in_proj_weight, self.in_proj_bias)
+        pk = ops.packing()
+        if pk is not None:
+            return self.out_proj(pk.pack(ops.attention(pk.unpack(qkv), self.num_heads, self._drop(self.dropout)))), None
         return self.out_proj(ops.attention(qkv, self.num_heads, self._drop(self.dropout))), None
 
 
@@ -618,6 +637,8 @@ class _TorchEncoder(nn.Module):
 class TransformerModel(_LMHead):
     """Baseline (reference model.py:120-171): the state_dict keys are nn.TransformerEncoder's
     (``transformerlayers.layers.N.self_attn.in_proj_weight`` ...), post-LN, GELU."""
+    supports_packed = True  # ops.packed_tokens (scorer): everything outside the attention core is token-wise
+
 
     def __init__(self, ntoken, ninp, nhead, nhid, nlayers, dropout=0.5, activation="relu", tie_weights=False):
         super().__init__()
@@ -636,6 +657,8 @@ class TransformerModel(_LMHead):
             raise BayesLMError("has_mask=False: the fused attention kernel is causal only")
         x = ops.embed(src, self.encoder.weight, self.pos_encoder.table(), math.sqrt(self.ninp),
                       self.pos_encoder._drop(self.pos_encoder.p))
+        if ops.packing() is not None:
+            x = ops.packing().pack(x)
         for layer in self.transformerlayers.layers:
             x = layer(x, src_mask=True)
         return self.decoder(x)

@@ -971,6 +971,45 @@ def philox_normal(n, seed, stream_id, step, device="cuda"):
 # 2-layer LSTM stack as _VF.lstm computes it (model.py:812), explicit cell
 # ----------------------------------------------------------------------------
 _STATE_TAP = None
+_PACK = None
+
+
+class packed_tokens:
+    """Inference helper (the n-best scorer): inside the context the Transformer stacks keep their activations as a
+    compact (R, 1, d) matrix of the REAL tokens of a padded (T, N) batch of hypotheses -- every token-wise operation
+    (projections, feed-forward, layer norms, decoder) then runs on R rows instead of T * N (padding is 40-50 % of a
+    batch of AMI-shaped hypotheses); only the attention core sees the padded layout (scatter before, gather after; the
+    padding rows hold zeros and, the attention being causal and column-wise, never reach a real token).
+    ``sel`` (R,) int64: flat indices t * N + n of the real tokens, in the order the caller wants the rows."""
+
+    def __init__(self, sel, T, N):
+        self.sel, self.T, self.N = sel, int(T), int(N)
+
+    def __enter__(self):
+        global _PACK
+        if torch.is_grad_enabled():
+            raise BayesLMError("ops.packed_tokens is an inference-only layout")
+        _PACK = self
+        return self
+
+    def __exit__(self, *exc):
+        global _PACK
+        _PACK = None
+        return False
+
+    def pack(self, x):
+        """(T, N, W) -> (R, 1, W)"""
+        return x.reshape(self.T * self.N, x.shape[-1]).index_select(0, self.sel).unsqueeze(1)
+
+    def unpack(self, xc):
+        """(R, 1, W) -> (T, N, W), zeros in the padding"""
+        out = xc.new_zeros(self.T * self.N, xc.shape[-1])
+        out.index_copy_(0, self.sel, xc.reshape(-1, xc.shape[-1]))
+        return out.view(self.T, self.N, -1)
+
+
+def packing():
+    return _PACK
 
 
 class state_tap:

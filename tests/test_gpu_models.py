@@ -956,3 +956,36 @@ def test_lstm_scorer_batched_equals_reference_loop(dev, family):
         for k in want:
             for (h1, a), (h2, b) in zip(got[k], want[k]):
                 assert h1 == h2 and abs(a - b) <= 1e-4 * max(1.0, abs(b)), (family, bt, k, a, b)
+
+
+@pytest.mark.parametrize("kind", ["bayes_ffn", "bayes_mha", "gauss3", "plain", "interp", "mc"])
+def test_scorer_packed_tokens_equal_padded_layout(dev, kind, monkeypatch):
+    """ops.packed_tokens (the Transformer stacks keep only the real tokens' rows; attention alone sees the padded batch)
+    against the padded layout: same scores for every hypothesis -- head_dim 64 (matrix-core attention), ragged
+    hypotheses, two interpolated models, Monte-Carlo weight samples."""
+    from collections import OrderedDict
+    import numpy as np
+    from bayeslms_amd import compute_sentence_scores as S, model as M
+    V = 97
+    torch.manual_seed(3)
+    mk = {"bayes_ffn": lambda: M.BayesTransformerModel(V, 128, 2, 256, 2, 0.5, True, "FFN"),
+          "bayes_mha": lambda: M.BayesTransformerModel(V, 128, 2, 256, 2, 0.5, True, "MHA"),
+          "gauss3": lambda: M.GaussTransformerModel(V, 128, 2, 256, 2, 0.5, True, 3),
+          "plain": lambda: M.TransformerModel(V, 128, 2, 256, 2, 0.5, "gelu", True)}
+    m1 = mk["bayes_ffn" if kind in ("interp", "mc") else kind]().to(dev)
+    m2 = mk["plain"]().to(dev) if kind == "interp" else None
+    vocab = {"<s>": 0, "<unk>": 1}
+    vocab.update({"w%d" % i: i for i in range(2, V)})
+    rnd = np.random.RandomState(5)
+    nbest = OrderedDict()
+    for u in range(7):
+        nbest["utt%d" % u] = [" ".join("w%d" % rnd.randint(2, V) for _ in range(rnd.randint(1, 14))) for _ in range(rnd.randint(1, 6))]
+    out = []
+    for packed in (True, False):
+        monkeypatch.setattr(S, "_PACKED", packed)
+        sc = S.compute_scores_batched(nbest, m1, vocab, "Transformer", dev, model_2=m2, alpha=0.3 if m2 is not None else 0.0,
+                                      mc_samples=3 if kind == "mc" else 0, seed=9, batch_tokens=150)
+        out.append([s for key in nbest for _, s in sc[key]])
+    a, b = np.asarray(out[0]), np.asarray(out[1])
+    assert a.shape == b.shape and len(a) == sum(len(h) for h in nbest.values())
+    np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-5)
