@@ -13,6 +13,9 @@ sys.path.insert(0, ".")
 from bayeslms_amd import compute_sentence_scores as css, model as M  # noqa: E402
 
 
+BT = int(__import__('os').environ.get('BATCH_TOKENS', '8192'))  # padded tokens per batch (compute_scores_batched default)
+
+
 def main():
     dev = torch.device("cuda:0")
     V = 33000
@@ -39,15 +42,15 @@ def main():
     for mtype, model in models:
         sub = OrderedDict(list(nbest.items())[:4])
         css.compute_scores(sub, model, vocab, mtype, dev)
-        css.compute_scores_batched(sub, model, vocab, mtype, dev)
+        css.compute_scores_batched(sub, model, vocab, mtype, dev, batch_tokens=BT)
         torch.cuda.synchronize()
         t0 = time.perf_counter(); css.compute_scores(sub, model, vocab, mtype, dev); torch.cuda.synchronize()
         t_loop = (time.perf_counter() - t0) / (4 * n_hyp)
-        t0 = time.perf_counter(); sb = css.compute_scores_batched(nbest, model, vocab, mtype, dev); torch.cuda.synchronize()
+        t0 = time.perf_counter(); sb = css.compute_scores_batched(nbest, model, vocab, mtype, dev, batch_tokens=BT); torch.cuda.synchronize()
         t_b = (time.perf_counter() - t0) / total
         line = f"{mtype:12s} loop {1 / t_loop:8.0f} hyp/s   batched {1 / t_b:8.0f} hyp/s"
         if mtype == "Transformer":
-            t0 = time.perf_counter(); css.compute_scores_batched(nbest, model, vocab, mtype, dev, mc_samples=8); torch.cuda.synchronize()
+            t0 = time.perf_counter(); css.compute_scores_batched(nbest, model, vocab, mtype, dev, mc_samples=8, batch_tokens=BT); torch.cuda.synchronize()
             line += f"   batched, 8 MC weight samples {total / (time.perf_counter() - t0):8.0f} hyp/s"
         print(line)
 
