@@ -9,7 +9,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbayeslm_hip.so")
+# BLM_LIB=/path/to/another/libbayeslm_hip.so selects a different BUILD of the same library (same-box A/B runs of
+# tools/ab_lib.sh) without touching the in-tree file; it is still the HIP library or nothing -- there is no fallback
+LIB_PATH = os.environ.get("BLM_LIB") or os.path.join(_HERE, "libbayeslm_hip.so")
 
 ABI_VERSION = 1
 OK = 0

@@ -7,6 +7,7 @@ interpolation with a second model (:157-168), LSTM hidden state carried to the n
 the FIRST hypothesis of the previous one (:271-274).
 """
 import argparse
+import math
 import os
 from collections import OrderedDict
 
@@ -255,6 +256,8 @@ def compute_scores_batched(nbest, model, vocab, model_type, device, model_2=None
         """group = [(key, hyps, pairs)]; one padded batch over all their hypotheses."""
         pairs = [p for _, _, ps in group for p in ps]
         lens = [len(x) for x, _ in pairs]
+        if min(lens) < 1:  # the running-sum difference below indexes ends - 1: an empty row would read the batch total
+            raise ValueError("score_group: a hypothesis without tokens (every n-best entry carries at least '<s>')")
         Tm, N = max(lens), len(pairs)
         # one host buffer [data | real-token rows | their targets | hypothesis ends] -> ONE host-to-device copy per batch.
         # Only the REAL tokens reach the decoder GEMM and the cross entropy (the bulk of the work: 2*d*V flops per token):
@@ -372,14 +375,22 @@ def interpolate_scores(nolm_path, lmonly_path, nn_path, nnweight, out_path):
         raise SystemExit("interpolate_scores: %d / %d / %d lines in %s, %s, %s" % (len(a), len(b), len(c), nolm_path,
                                                                                    lmonly_path, nn_path))
     w = float(nnweight)
-    with open(out_path, 'w', encoding='utf-8') as f:
-        for x, y, z in zip(a, b, c):
-            score = float(x[1]) + w * float(z[1]) + (1.0 - w) * float(y[1])
-            f.write("%s %s\n" % (x[0], _awk_num(score)))
+    rows = []
+    for i, (x, y, z) in enumerate(zip(a, b, c)):
+        if not (x[0] == y[0] == z[0]):  # paste would silently mix the scores of different n-best entries
+            raise SystemExit("interpolate_scores: line %d holds different keys: %s (%s), %s (%s), %s (%s)"
+                             % (i + 1, x[0], nolm_path, y[0], lmonly_path, z[0], nn_path))
+        rows.append((x[0], float(x[1]) + w * float(z[1]) + (1.0 - w) * float(y[1])))
+    with open(out_path, 'w', encoding='utf-8') as f:  # written only once every line has been checked
+        for key, score in rows:
+            f.write("%s %s\n" % (key, _awk_num(score)))
 
 
 def _awk_num(v):
-    """awk's print conversion: integers print as integers, everything else with OFMT = %.6g."""
+    """awk's print conversion: integers print as integers, everything else with OFMT = %.6g; nan / inf as awk
+    spells them."""
+    if not math.isfinite(v):
+        return "nan" if v != v else ("inf" if v > 0 else "-inf")
     return "%d" % v if v == int(v) and abs(v) < 1e16 else "%.6g" % v
 
 

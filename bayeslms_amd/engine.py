@@ -71,6 +71,7 @@ class GradReducer:
         self.comm_stream = torch.cuda.Stream() if self.cuda else None
         self.overlap = overlap
         self.late = None  # LateRows, set by the Trainer
+        self.no_dense = set()  # buckets whose only tensor gets ALL of its gradient through LateRows (untied encoder)
         self.measure = False  # record (backward end, communication end) event pairs on the compute stream
         self.exposed_events = []
         # buckets = contiguous runs of parameters, built from the END of the buffer (backward order).  Two refinements
@@ -126,6 +127,8 @@ class GradReducer:
         self.pending = [len(ids) for _, _, ids in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.handles = []
+        self.last_reduced_elems = getattr(self, "reduced_elems", 0)  # elements the finished step exchanged
+        self.reduced_elems = 0
 
     def mark_ready(self, param):
         k = id(param)
@@ -152,10 +155,13 @@ class GradReducer:
         self.launched[b] = True
         if self.world == 1:
             return
+        if b in self.no_dense and self.late is not None and self.late.used:
+            return  # nothing dense was written: the compact exchange carries the whole gradient of this tensor
         s, e, _ = self.buckets[b]
         self._all_reduce(self.flat.flat_grad[s:e])
 
     def _all_reduce(self, view):
+        self.reduced_elems += view.numel()
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -171,6 +177,13 @@ class GradReducer:
         if self.calibrating:
             self.expected = dict(self.seen)
             self.calibrating = False
+            if self.late is not None and self.late.used:
+                # an UNTIED encoder weight under LateRows has no dense contribution at all (the tied one has the
+                # decoder's): when it travels alone, its bucket would be all-reduced as zeros, fully exposed
+                k = id(self.late.weight)
+                b = self.bucket_of.get(k)
+                if b is not None and self.expected[k] == 0 and len(self.buckets[b][2]) == 1:
+                    self.no_dense.add(b)
         ev0 = None
         if self.measure and self.cuda:
             ev0 = torch.cuda.Event(enable_timing=True)

@@ -10,9 +10,9 @@ the Functions return ``None`` for parameters.
 There is no CPU path: every entry point raises on non-GPU tensors.
 """
 import ctypes as C
-from dataclasses import dataclass
-
 import os
+import threading
+from dataclasses import dataclass
 
 import torch
 
@@ -146,19 +146,37 @@ class ResidualLink:
     """Joins the two backward paths of a post-LN residual block  out = LN(x + drop(f(x)))  (model.py:1041-1045).
     Autograd would add the residual path's gradient (from the LayerNorm backward) and the branch's input gradient
     (the last dgrad GEMM of f) with a separate elementwise pass over (T,B,d) -- 12 launches per cfg3 step.  The
-    same ``link`` object is handed to ``add_dropout_ln(..., link=)`` and to the first op of the branch
-    (``linear`` / ``ffn`` / ``ffn_gp`` ``link=``): the LayerNorm backward (which always runs first: it consumes the
-    branch's output) parks its dx here, and the branch's dgrad GEMM ACCUMULATES into that buffer instead of
-    producing a second tensor (stream order keeps this safe: every earlier use of the buffer is already enqueued).
-    Explicit per-block objects, no global matching.  Contract: the linked op is the ONLY consumer of x besides the
-    LayerNorm residual (with a third consumer autograd may already have summed the parked tensor into a new one)."""
-    __slots__ = ("dx",)
+    same ``link`` object is handed to the first op of the branch (``linear`` / ``ffn`` / ``ffn_gp`` ``link=``) and to
+    ``add_dropout_ln(..., link=)``.  The branch op ARMS the link in its forward with the identity of its input; the
+    LayerNorm (whose forward runs after the branch, whose backward runs before it) uses the link only when exactly ONE
+    op armed it for the very tensor it adds as the residual.  Then its backward parks dx here and returns NO gradient
+    for x; the branch's dgrad GEMM accumulates into the parked buffer (stream order: every earlier use is enqueued)
+    and returns THAT as its input gradient.  Autograd therefore sees one producer for the pair, so any further
+    consumer of x (a hook, a tap on the layer input, a layer variant that reuses it) is summed in correctly whatever
+    order the nodes run in; when the link is not armed, or armed twice, or for another tensor, both ops fall back to
+    returning their own gradients.  Explicit per-block objects, no global matching."""
+    __slots__ = ("dx", "armed", "key")
 
     def __init__(self):
         self.dx = None
+        self.armed = 0
+        self.key = None
+
+    @staticmethod
+    def _key(x):
+        return (x.data_ptr(), tuple(x.shape), x.is_contiguous())
+
+    def arm(self, x):
+        """Branch op, forward: 'my backward will run and will fold its input gradient into a parked buffer for x'."""
+        self.armed += 1
+        self.key = self._key(x)
+
+    def joins(self, x):
+        """LayerNorm, forward: is exactly one branch op waiting for this residual's gradient?"""
+        return self.armed == 1 and self.key == self._key(x)
 
     def take(self, like):
-        """The parked residual gradient if it fits ``like`` (then this path returns no gradient of its own)."""
+        """The parked residual gradient if it fits ``like`` (the branch then returns it, completed, as its dx)."""
         d, self.dx = self.dx, None
         if d is not None and d.shape == like.shape and d.is_contiguous():
             return d
@@ -272,6 +290,8 @@ class _Linear(torch.autograd.Function):
         gemm(L.GEMM_NT, x, w, y, M, N, K, K, K, N, epilogue=L.EPI_BIAS if b is not None else L.EPI_NONE, bias=b)
         ctx.save_for_backward(x)
         ctx.w, ctx.b, ctx.link = w, b, link
+        if link is not None and ctx.needs_input_grad[0]:
+            link.arm(x)
         return y
 
     @staticmethod
@@ -286,6 +306,7 @@ class _Linear(torch.autograd.Function):
             parked = ctx.link.take(x) if ctx.link is not None else None
             if parked is not None:  # residual block: add into the LayerNorm backward's dx (ResidualLink)
                 gemm(L.GEMM_NN, dy, w, parked, M, K, N, N, K, K, accumulate=True)
+                dx = parked
             else:
                 dx = torch.empty_like(x)
                 gemm(L.GEMM_NN, dy, w, dx, M, K, N, N, K, K)
@@ -487,6 +508,8 @@ class _FFN(torch.autograd.Function):
     def forward(ctx, x, w1, b1, w2, b2, lgstd2, noise, kl_lambda, fused, drop, link=None):
         ctx.link = link
         x = _f32(x, "x")
+        if link is not None and ctx.needs_input_grad[0]:
+            link.arm(x)
         F_, D = w1.shape  # (ff, d)
         N2 = w2.shape[0]
         M = x.numel() // D
@@ -555,6 +578,7 @@ class _FFN(torch.autograd.Function):
             parked = ctx.link.take(x) if ctx.link is not None else None
             if parked is not None:
                 gemm(L.GEMM_NN, dz, w1, parked, M, D, F_, F_, D, D, accumulate=True)
+                dx = parked
             else:
                 dx = torch.empty_like(x)
                 gemm(L.GEMM_NN, dz, w1, dx, M, D, F_, F_, D, D)
@@ -573,6 +597,8 @@ class _FFNGP(torch.autograd.Function):
     def forward(ctx, x, wg, bg, coef, w2, b2, drop, link=None):
         ctx.link = link
         x = _f32(x, "x")
+        if link is not None and ctx.needs_input_grad[0]:
+            link.arm(x)
         F_, D = wg.shape
         N2 = w2.shape[0]
         M = x.numel() // D
@@ -614,6 +640,7 @@ class _FFNGP(torch.autograd.Function):
             parked = ctx.link.take(x) if ctx.link is not None else None
             if parked is not None:
                 gemm(L.GEMM_NN, dz, wg, parked, M, D, F_, F_, D, D, accumulate=True)
+                dx = parked
             else:
                 dx = torch.empty_like(x)
                 gemm(L.GEMM_NN, dz, wg, dx, M, D, F_, F_, D, D)
@@ -701,8 +728,8 @@ def attention_qkv(q, k, v, nhead, drop=NO_DROP):
 class _AddDropLN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, gamma, beta, eps, drop, link=None):
-        ctx.link = link
         x, y = _f32(x, "x"), _f32(y, "y")
+        ctx.link = link if (link is not None and link.joins(x)) else None
         D = x.shape[-1]
         B = x.shape[-2]
         rows = x.numel() // (B * D)
@@ -736,9 +763,11 @@ class _AddDropLN(torch.autograd.Function):
                                            float(drop.p), C.byref(r) if r is not None else None, drop.col_offset,
                                            drop.global_cols or B, stream()), "blm_add_dropout_ln_bwd")
         _notify(gamma, beta)
+        dres = dx
         if ctx.link is not None and ctx.needs_input_grad[0]:
-            ctx.link.dx = dx  # the branch's first op adds its input gradient into this buffer (ResidualLink)
-        return dx, (dy if dy is not None else dx), None, None, None, None, None
+            ctx.link.dx = dx  # the branch's first op completes this buffer and returns it as ITS dx (ResidualLink)
+            dres = None
+        return dres, (dy if dy is not None else dx), None, None, None, None, None
 
 
 def add_dropout_ln(x, y, gamma, beta, eps=1e-5, drop=NO_DROP, link=None):
@@ -971,7 +1000,7 @@ def philox_normal(n, seed, stream_id, step, device="cuda"):
 # 2-layer LSTM stack as _VF.lstm computes it (model.py:812), explicit cell
 # ----------------------------------------------------------------------------
 _STATE_TAP = None
-_PACK = None
+_PACK = threading.local()  # per thread: two scorers on two threads never see each other's layout
 
 
 class packed_tokens:
@@ -980,21 +1009,23 @@ class packed_tokens:
     (projections, feed-forward, layer norms, decoder) then runs on R rows instead of T * N (padding is 40-50 % of a
     batch of AMI-shaped hypotheses); only the attention core sees the padded layout (scatter before, gather after; the
     padding rows hold zeros and, the attention being causal and column-wise, never reach a real token).
-    ``sel`` (R,) int64: flat indices t * N + n of the real tokens, in the order the caller wants the rows."""
+    ``sel`` (R,) int64: flat indices t * N + n of the real tokens, in the order the caller wants the rows.
+    The layout is thread-local and does not nest.  (The scorer also sets ``decoder.rows`` on the model it scores with:
+    a model object serves one scoring call at a time.)"""
 
     def __init__(self, sel, T, N):
         self.sel, self.T, self.N = sel, int(T), int(N)
 
     def __enter__(self):
-        global _PACK
         if torch.is_grad_enabled():
             raise BayesLMError("ops.packed_tokens is an inference-only layout")
-        _PACK = self
+        if getattr(_PACK, "cur", None) is not None:
+            raise BayesLMError("ops.packed_tokens does not nest")
+        _PACK.cur = self
         return self
 
     def __exit__(self, *exc):
-        global _PACK
-        _PACK = None
+        _PACK.cur = None
         return False
 
     def pack(self, x):
@@ -1009,7 +1040,7 @@ class packed_tokens:
 
 
 def packing():
-    return _PACK
+    return getattr(_PACK, "cur", None)
 
 
 class state_tap:

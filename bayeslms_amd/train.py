@@ -56,6 +56,17 @@ def build_parser():
     p.add_argument('--fused-sampling', type=int, default=0, help='1: eps generated inside the GEMM tile loader')
     p.add_argument('--gemm-mode', type=str, default='f32', choices=['f32', 'bf16x6', 'bf16x3'],
                    help='new, optional: opt-in split-bf16 arithmetic of the GEMM family (DESIGN.md section 7); default fp32 MFMA')
+    p.add_argument('--dist-backend', type=str, default='nccl',
+                   help='new, optional (under torchrun): torch.distributed backend; nccl = RCCL over xGMI, one GPU per rank; '
+                        'gloo lets several ranks rehearse on one GPU')
+    p.add_argument('--dp-overlap', type=int, default=1,
+                   help='new, optional: 1 = bucket all-reduces start while backward is still running, 0 = all after backward')
+    p.add_argument('--dp-late-rows', type=int, default=1,
+                   help='new, optional: 1 = the embedding half of the encoder gradient travels as the compact matrix of the '
+                        'rows the global batch touched (engine.LateRows), 0 = dense')
+    p.add_argument('--history', type=str, default='',
+                   help='new, optional: rank 0 writes what the log lines print with two decimals (interval / valid / test '
+                        'loss, LR-halving epochs, ms per batch) at full precision to this JSON file')
     return p
 
 
@@ -142,13 +153,49 @@ def _print_coef_mean(args, model, say):
             say(sd['rnn.rnn.%d.gpnn.coef_mean' % c].mean(dim=1))
 
 
+class ValidationSchedule:
+    """The end-of-epoch decision of train.py:496-512 -- keep the checkpoint when the validation loss improved, else
+    halve the learning rate (fresh SGD, reload the best checkpoint), stop after 8 halvings -- taken ONCE for the job.
+    Every rank evaluates the same validation stream, but an under-filled evaluation GEMM sums its K slices with float
+    atomics, so two ranks may see losses that differ in the last bits; a rank-local ``val_loss < best_val`` could then
+    halve the LR on one rank only, or leave the ranks in different epochs with the next all-reduce hanging.  ``update``
+    therefore replaces every rank's value by rank 0's (one 8-byte broadcast per epoch) before it is compared, logged
+    or stored, so all ranks walk the same branch by construction."""
+
+    def __init__(self, lr, world=1, device=None, group=None, patience=8):
+        self.lr, self.world, self.device, self.group = lr, world, device, group
+        self.best_val = None
+        self.counter = 0
+        self.patience = patience
+
+    def agree(self, value):
+        """rank 0's ``value`` on every rank (identity for a single process)."""
+        if self.world <= 1:
+            return float(value)
+        on_dev = dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device if on_dev else "cpu")
+        dist.broadcast(t, src=0, group=self.group)
+        return float(t.item())
+
+    def update(self, val_loss):
+        """-> (the job's validation loss, improved, stop).  ``improved`` False means: lr has been halved."""
+        val_loss = self.agree(val_loss)
+        improved = (not self.best_val) or val_loss < self.best_val  # train.py:497
+        if improved:
+            self.best_val = val_loss
+        else:
+            self.lr /= 2.
+            self.counter += 1
+        return val_loss, improved, self.counter == self.patience
+
+
 def main(argv=None, history=None):
     """``history`` (optional dict) receives what the log lines print with two decimals at full precision:
     interval_loss, valid_loss, halved_epochs, test_loss."""
     args = build_parser().parse_args(argv)
     if history is None:
         history = {}
-    history.update({"interval_loss": [], "valid_loss": [], "halved_epochs": [], "test_loss": None})
+    history.update({"interval_loss": [], "valid_loss": [], "halved_epochs": [], "test_loss": None, "ms_per_batch": []})
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -162,10 +209,16 @@ def main(argv=None, history=None):
     torch.manual_seed(args.seed)
     if not args.cuda or not torch.cuda.is_available():
         raise SystemExit("bayeslms_amd.train needs --cuda and an MI355X: there is no CPU path")
+    if args.dist_backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)  # rehearsal: several ranks share a GPU (RCCL refuses that)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from . import data as D, engine, ops
     from .model import repackage_hidden
@@ -204,7 +257,7 @@ def main(argv=None, history=None):
     kl_fn = kl_selector(args)
     kl_scale = float(args.seq_len) / float(len(train_data))  # KL / len(train_data) * seq_len (train.py:338)
     trainer = engine.Trainer(model, lr=args.lr, clip=args.clip, momentum=0.9, kl_scale=kl_scale, seed=args.seed,
-                             rank=rank, world=world)
+                             rank=rank, world=world, overlap=bool(args.dp_overlap), late_rows=bool(args.dp_late_rows))
     is_rnn = args.model != 'Transformer'
 
     def train_epoch(epoch, lr):
@@ -218,9 +271,14 @@ def main(argv=None, history=None):
             loss, kl, hidden = trainer.step(data, targets, hidden, kl_fn)
             total_loss = total_loss + loss  # stays on the device: one host sync per log interval (train.py:422 syncs per step)
             if batch % args.log_interval == 0 and batch > 0:
+                if world > 1:  # the mean over the GLOBAL batch, as the single-process log line prints it
+                    total_loss = total_loss.detach().clone()
+                    dist.all_reduce(total_loss)
+                    total_loss = total_loss / world
                 cur = float(total_loss) / args.log_interval
                 history["interval_loss"].append(cur)
                 elapsed = time.time() - start
+                history["ms_per_batch"].append(elapsed * 1000 / args.log_interval)
                 say('| epoch {:3d} | {:5d}/{:5d} batches | lr {:02.3f} | ms/batch {:5.2f} | loss {:5.2f} | '
                     'kl_loss {:5.4} | ppl {:8.2f}'.format(epoch, batch, len(train_data) // args.seq_len, lr,
                                                           elapsed * 1000 / args.log_interval, cur,
@@ -228,39 +286,34 @@ def main(argv=None, history=None):
                 total_loss = 0.
                 start = time.time()
 
-    lr = args.lr
-    best_val = None
-    counter = 0
+    sched = ValidationSchedule(args.lr, world, device)
     say("Start training")
     try:
         for epoch in range(1, args.epochs + 1):
             t0 = time.time()
-            train_epoch(epoch, lr)
-            val_loss = engine.evaluate(model, val_data, args.seq_len)
+            train_epoch(epoch, sched.lr)
+            val_loss, improved, stop = sched.update(engine.evaluate(model, val_data, args.seq_len))
             say('-' * 89)
             say('| end of epoch {:3d} | time: {:5.2f}s | valid loss {:5.2f} | valid ppl {:8.2f}'.format(
                 epoch, time.time() - t0, val_loss, math.exp(val_loss)))
             say('-' * 89)
             history["valid_loss"].append(val_loss)
             _print_coef_mean(args, model, say)
-            if not best_val or val_loss < best_val:
+            if improved:
                 if is_main:
                     with open(args.save, 'wb') as f:
                         torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, f)
-                best_val = val_loss
             else:  # train.py:503-508: halve LR, fresh SGD (momentum reset), reload best
-                lr /= 2.
                 history["halved_epochs"].append(epoch)
-                trainer.reset_optimizer(lr)
+                trainer.reset_optimizer(sched.lr)
                 if world > 1:
-                    dist.barrier()
+                    dist.barrier()  # rank 0's checkpoint of an earlier epoch is on disk before anyone reads it
                 with torch.no_grad():
                     sd = torch.load(args.save, map_location='cpu')
                     own = model.state_dict()
                     for k, v in sd.items():
                         own[k].copy_(v)
-                counter += 1
-            if counter == 8:
+            if stop:
                 break
     except KeyboardInterrupt:
         say('-' * 89)
@@ -275,12 +328,17 @@ def main(argv=None, history=None):
             for k, v in sd.items():
                 own[k].copy_(v)
     _print_coef_mean(args, model, say)
-    test_loss = engine.evaluate(model, test_data, args.seq_len)
+    test_loss = sched.agree(engine.evaluate(model, test_data, args.seq_len))
     history["test_loss"] = test_loss
     say('=' * 89)
     say('| End of training | test loss {:5.2f} | test ppl {:8.2f}'.format(test_loss, math.exp(test_loss)))
     say('=' * 89)
+    if args.history and is_main:
+        import json
+        with open(args.history, 'w') as f:
+            json.dump(history, f)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     return test_loss
 

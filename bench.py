@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="columns per GPU (default = the named config)")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "rehearsing several ranks on one GPU)")
+    ap.add_argument("--dp-overlap", type=int, default=1, help="N > 1: 0 = every bucket all-reduced after backward")
+    ap.add_argument("--dp-late-rows", type=int, default=1, help="N > 1: 0 = the tied encoder gradient travels dense")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launch plumbing only (spawn, rendezvous, barrier, max-over-ranks, one JSON line from rank 0) "
                          "with NO GPU work: what the CPU-side test of `--gpus N` self-launch runs")
@@ -347,7 +349,8 @@ def main():
     if args.fused_sampling >= 0:
         model.set_fused_sampling(bool(args.fused_sampling))
     kl_scale = float(T) / float(train.size(0))  # train.py:342: / len(train_data) * seq_len
-    tr = engine.Trainer(model, lr=LR, clip=CLIP, kl_scale=kl_scale, seed=1111, rank=rank, world=world)
+    tr = engine.Trainer(model, lr=LR, clip=CLIP, kl_scale=kl_scale, seed=1111, rank=rank, world=world,
+                        overlap=bool(args.dp_overlap), late_rows=bool(args.dp_late_rows))
 
     def kl_fn(mm):
         return mm.transformerlayers[0].linear2.kl_divergence()
@@ -431,7 +434,10 @@ def main():
             # gradient exchange (bucketed all-reduce + the compact embedding-row exchange); null at N = 1
             "comm_exposed_ms": None if comm_exposed is None else round(comm_exposed, 4),
             "comm": None if world == 1 else {
-                "backend": args.backend, "bucket_mb": 32, "buckets": len(tr.reducer.buckets),
+                "backend": args.backend, "overlap": bool(args.dp_overlap), "buckets": len(tr.reducer.buckets),
+                # sizes in backward (launch) order: full 32 MB runs, big tensors alone, quarter-size tail buckets
+                "bucket_mb": [round((e - s) * 4 / 1e6, 2) for s, e, _ in tr.reducer.buckets],
+                "exchanged_mb_last_step": round(tr.reducer.last_reduced_elems * 4 / 1e6, 2),
                 # the bucket that becomes ready last (layer 0's first parameters): the all-reduce nothing can hide
                 "last_bucket_mb": round((tr.reducer.buckets[-1][1] - tr.reducer.buckets[-1][0]) * 4 / 1e6, 2),
                 "grad_bytes": int(tr.flat.total * 4),

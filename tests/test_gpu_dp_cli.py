@@ -1,0 +1,79 @@
+"""GPU: the data-parallel entry point users start -- `torchrun ... -m bayeslms_amd.train` -- as two ranks sharing this
+box's GPU (`--dist-backend gloo`; RCCL refuses two ranks on one device), `--batch-size` = the fixture's GLOBAL batch:
+the same LR-halving epochs, valid / test loss (1e-4) and final checkpoint (1e-3) as the single-process CLI AND as the
+RNG-free trajectory of the reference's own train.py (tests/golden/train_traj_*.npz; train.py:306-438, 464-519).
+The ranks are child processes of a `torch.distributed.run` child: nothing is forked from or exec'ed over this
+(GPU-initialised) test process."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from test_train_traj_oracle import load_traj, write_corpus
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cli(world, argv, hist, extra=()):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    if world == 1:
+        cmd = [sys.executable, "-m", "bayeslms_amd.train"]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "-m", "bayeslms_amd.train"]
+    r = subprocess.run(cmd + argv + ["--history", hist] + list(extra), capture_output=True, text=True, timeout=900,
+                       env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    return json.load(open(hist)), r.stdout
+
+
+@pytest.mark.parametrize("tag", ["lstm_none", "tlm_none"])
+def test_torchrun_two_rank_cli_equals_one_rank_and_reference_trajectory(tag, tmp_path):
+    z, args, init, snaps = load_traj(tag)
+    d = str(tmp_path)
+    write_corpus(z, d)
+    prior = os.path.join(d, "prior")
+    os.makedirs(prior)
+    torch.save(init, os.path.join(prior, "model.pt"))
+    base = [str(a) for a in z["argv"]] + ["--data", d, "--prior_path", prior, "--cuda"]
+    assert int(args["batch_size"]) % 2 == 0
+    runs = {}
+    for world, extra in ((1, ()), (2, ("--dist-backend", "gloo")), (-2, ("--dist-backend", "gloo", "--dp-overlap", "0",
+                                                                          "--dp-late-rows", "0"))):
+        save = os.path.join(d, "model_w%d.pt" % world)
+        hist, out = _cli(abs(world), base + ["--save", save], os.path.join(d, "hist_w%d.json" % world), extra)
+        runs[world] = (hist, torch.load(save, map_location="cpu"), out)
+    ref_final = snaps[-1]  # parameters train.py evaluated on the test set = its best checkpoint
+    for world, (hist, final, out) in runs.items():
+        assert list(hist["halved_epochs"]) == list(z["halved_epochs"]), (world, hist["valid_loss"], list(z["valid_loss"]))
+        assert np.allclose(hist["valid_loss"], z["valid_loss"], rtol=1e-4), (world, hist["valid_loss"])
+        assert abs(hist["test_loss"] - float(z["test_loss"])) <= 1e-4 * float(z["test_loss"]), world
+        assert np.allclose(hist["interval_loss"], z["interval_loss"], rtol=1e-3), world  # mean over the GLOBAL batch
+        for k, v in ref_final.items():
+            assert float((final[k] - v).abs().max()) <= 1e-3 * (float(v.abs().max()) + 1e-12), (world, k)
+        assert out.count("| end of epoch") == len(z["valid_loss"])  # rank 0 alone prints
+    h1, f1, _ = runs[1]
+    for world in (2, -2):
+        h2, f2, _ = runs[world]
+        assert np.allclose(h2["valid_loss"], h1["valid_loss"], rtol=1e-4) and h2["halved_epochs"] == h1["halved_epochs"]
+        for k, v in f1.items():
+            assert float((f2[k] - v).abs().max()) <= 1e-3 * (float(v.abs().max()) + 1e-12), (world, k)

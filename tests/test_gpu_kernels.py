@@ -809,3 +809,60 @@ def test_lstm_stack2_wavefront_equals_two_sequential_layers(dev, T, B, E, H, p):
             assert rel(u, v) < 2e-5, n  # split-K summation order); the batched wgrad GEMMs use float atomics
         else:
             assert torch.equal(u, v), n
+
+
+# ------------------------------------------------------------------ residual link
+@pytest.mark.parametrize("branch", ["linear", "ffn", "ffn_gp"])
+@pytest.mark.parametrize("case", ["block", "third_consumer", "armed_twice", "other_tensor"])
+def test_residual_link_gradients_equal_the_unlinked_path(dev, branch, case):
+    """out = LN(x + f(x)) with the branch's dgrad GEMM folding into the LayerNorm backward's dx (ops.ResidualLink) must
+    give the same gradients as plain autograd -- also when x has a THIRD consumer (a tap on the layer input), when two
+    ops arm one link, and when the LayerNorm's residual is not the tensor the branch read (the link then stands down)."""
+    ops = ops_mod()
+    torch.manual_seed(3)
+    T, B, D, F_ = 6, 5, 32, 64
+    x0 = torch.randn(T, B, D, device=dev)
+    w1, b1 = torch.randn(F_, D, device=dev) * 0.2, torch.randn(F_, device=dev) * 0.1
+    w2, b2 = torch.randn(D, F_, device=dev) * 0.2, torch.randn(D, device=dev) * 0.1
+    wl, bl = torch.randn(D, D, device=dev) * 0.2, torch.randn(D, device=dev) * 0.1
+    coef = torch.randn(4, F_, device=dev) * 0.5
+    gamma, beta = torch.rand(D, device=dev) + 0.5, torch.randn(D, device=dev) * 0.1
+    r = torch.randn(T, B, D, device=dev)
+    tap = torch.randn(T, B, D, device=dev)
+
+    def run(linked):
+        ps = [t.clone().requires_grad_(True) for t in (x0, w1, b1, w2, b2, wl, bl, coef, gamma, beta)]
+        x, W1, B1, W2, B2, WL, BL, CF, G, Bt = ps
+        xs = x * 1.0  # non-leaf layer input, as inside a stack
+        lk = ops.ResidualLink() if linked else None
+
+        def f(inp, link):
+            if branch == "linear":
+                return ops.linear(inp, WL, BL, link)
+            if branch == "ffn":
+                return ops.ffn(inp, W1, B1, W2, B2, link=link)
+            return ops.ffn_gp(inp, W1, B1, CF, W2, B2, link=link)
+        y = f(xs, lk)
+        res = xs
+        if case == "armed_twice":
+            y = y + f(xs, lk)
+        if case == "other_tensor":
+            res = xs * 2.0
+        out = ops.add_dropout_ln(res, y, G, Bt, 1e-5, ops.NO_DROP, lk)
+        loss = (out * r).sum()
+        if case == "third_consumer":
+            loss = loss + (xs * tap).sum() + (xs.tanh() * tap).sum()
+        loss.backward()
+        return [p.grad for p in ps]
+    got, want = run(True), run(False)
+    used = {"linear": (0, 5, 6, 8, 9), "ffn": (0, 1, 2, 3, 4, 8, 9), "ffn_gp": (0, 1, 2, 3, 4, 7, 8, 9)}[branch]
+    for i in used:
+        assert got[i] is not None and want[i] is not None, i
+        assert rel(got[i], want[i]) < 2e-5, (i, rel(got[i], want[i]))
+    # and against torch's own autograd for the plain block (fp32 CPU)
+    if case == "third_consumer" and branch == "linear":
+        xc = x0.cpu().clone().requires_grad_(True)
+        xs = xc * 1.0
+        out = torch.nn.functional.layer_norm(xs + torch.nn.functional.linear(xs, wl.cpu(), bl.cpu()), (D,), gamma.cpu(), beta.cpu())
+        ((out * r.cpu()).sum() + (xs * tap.cpu()).sum() + (xs.tanh() * tap.cpu()).sum()).backward()
+        assert rel(got[0], xc.grad) < 1e-4

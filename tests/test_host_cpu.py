@@ -348,3 +348,156 @@ def test_reducer_bucket_layout_big_tensor_alone_and_small_final_buckets():
     assert spans[-1][1] - spans[-1][0] <= 2000 and len(red.buckets) >= 5
     # every parameter is in exactly one bucket
     assert sorted(i for b in ids for i in b) == list(range(len(flat.params)))
+
+
+def _schedule_worker(rank, world, port, ret):
+    """Every rank feeds ValidationSchedule ITS OWN validation loss: rank r's values are rank 0's plus a last-bits
+    perturbation chosen so that a rank-local `val_loss < best_val` would flip on epochs 2 and 4."""
+    import torch.distributed as dist
+    from bayeslms_amd.train import ValidationSchedule
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    base = [5.0, 4.0, 4.0 - 1e-7, 3.9999999, 3.5, 3.6, 3.6, 3.6, 3.6, 3.6, 3.6, 3.6, 3.6]
+    bump = [0.0, 0.0, 3e-7, -2e-7, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+    sched = ValidationSchedule(1.0, world)
+    local = ValidationSchedule(1.0, 1)  # what a rank deciding for itself would have done
+    trace, ltrace = [], []
+    for v, b in zip(base, bump):
+        mine = v + (b if rank else 0.0)
+        val, improved, stop = sched.update(mine)
+        trace.append((val, improved, stop, sched.lr))
+        lv, li, ls = local.update(mine)
+        ltrace.append((li, ls, local.lr))
+        if stop:
+            break
+    ret[rank] = (trace, ltrace, sched.agree(100.0 + rank))
+    dist.destroy_process_group()
+
+
+def test_validation_decision_is_rank0s_on_every_rank():
+    """VERDICT r2 Weak #1: save / halve-LR / early-stop must not be decided per rank."""
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_schedule_worker, args=(world, port, ret), nprocs=world, join=True)
+        (t0, l0, a0), (t1, l1, a1) = ret[0], ret[1]
+    assert t0 == t1 and a0 == a1 == 100.0          # identical values, branches, LR and stop epoch
+    assert [x[:2] for x in l0] != [x[:2] for x in l1]  # ... where rank-local decisions WOULD have split
+    assert t0[-1][2] and len(t0) == 12 and t0[-1][3] == 1.0 / 2 ** 8  # 8 halvings end the run (train.py:511)
+    # the single-process schedule is the reference's: improved iff val < best, first epoch always saves
+    from bayeslms_amd.train import ValidationSchedule
+    s = ValidationSchedule(0.1)
+    assert s.update(3.0)[1] and not s.update(3.0)[1] and s.lr == 0.05 and s.update(2.0)[1] and s.lr == 0.05
+
+
+def _untied_late_rows_worker(rank, world, port, ret):
+    """an UNTIED encoder weight under LateRows gets its whole gradient through the compact exchange; its
+    bucket (the tensor travels alone) must not be all-reduced densely as zeros."""
+    import torch.distributed as dist
+    from bayeslms_amd import engine
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    V, D, T, B = 64, 8, 5, 3
+    torch.manual_seed(0)
+    net = torch.nn.ModuleDict({"encoder": torch.nn.Embedding(V, D), "other": torch.nn.Linear(D, 7)})
+    flat = engine.FlatBuffers(net)
+    red = engine.GradReducer(flat, bucket_bytes=256)
+    enc = net["encoder"].weight
+    red.late = engine.LateRows(red, enc)
+    dense_elems = []
+    for step in range(3):
+        g = torch.Generator().manual_seed(100 * step + rank)
+        ids = torch.randint(0, V, (T, B), generator=g)
+        dy = torch.randn(T, B, D, generator=g)
+        flat.zero_grad()
+        red.late.begin(ids)
+        for p in net["other"].parameters():
+            p.grad.add_(1.0 + rank)
+            red.mark_ready(p)
+        buf, slots, U, done = red.late.sink(enc, ids)
+        buf.view(U, D).index_add_(0, slots.reshape(-1), dy.reshape(-1, D))
+        done()
+        red.finish()
+        dense_elems.append(red.last_reduced_elems - U * D)
+        want = torch.zeros(V, D)
+        for r in range(world):
+            g = torch.Generator().manual_seed(100 * step + r)
+            ids_r = torch.randint(0, V, (T, B), generator=g)
+            want.index_add_(0, ids_r.reshape(-1), torch.randn(T, B, D, generator=g).reshape(-1, D))
+        assert torch.allclose(enc.grad, want, atol=1e-5)
+    assert red.expected[id(enc)] == 0 and red.bucket_of[id(enc)] in red.no_dense
+    other = sum((p.numel() + 3) // 4 * 4 for p in net["other"].parameters())
+    assert dense_elems[0] == other and dense_elems[1:] == [other, other], (dense_elems, other, V * D)
+    # the sink refusing (a second lookup, foreign ids) puts the step back on the dense path
+    flat.zero_grad()
+    red.late.begin(ids)
+    for p in net["other"].parameters():
+        red.mark_ready(p)
+    enc.grad.add_(float(rank + 1))
+    red.mark_ready(enc)
+    red.finish()
+    assert torch.allclose(enc.grad, torch.full_like(enc.grad, float(sum(range(1, world + 1)))))
+    ret[rank] = True
+    dist.destroy_process_group()
+
+
+def test_late_rows_untied_encoder_skips_the_dense_all_reduce():
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_untied_late_rows_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert all(ret.get(r) for r in range(2))
+
+
+def test_stage7_interpolation_nonfinite_scores_and_key_mismatch(tmp_path):
+    """a nan / inf n-best score prints as awk prints it instead of aborting the file; lines whose keys differ
+    between the three pasted files are an error naming the key, and nothing is written."""
+    from bayeslms_amd import compute_sentence_scores as S
+    d = str(tmp_path)
+    assert S._awk_num(float("nan")) == "nan" and S._awk_num(float("inf")) == "inf" and S._awk_num(float("-inf")) == "-inf"
+    files = {"nolm": ["a-1 1.5", "a-2 inf", "a-3 2"], "lmonly": ["a-1 2.5", "a-2 1", "a-3 nan"], "nn": ["a-1 3.0", "a-2 1", "a-3 1"]}
+    for k, v in files.items():
+        open(os.path.join(d, k), "w").write("\n".join(v) + "\n")
+    out = os.path.join(d, "out")
+    S.interpolate_scores(os.path.join(d, "nolm"), os.path.join(d, "lmonly"), os.path.join(d, "nn"), 0.5, out)
+    assert open(out).read().split() == ["a-1", "4.25", "a-2", "inf", "a-3", "nan"]
+    open(os.path.join(d, "nn"), "w").write("a-1 3.0\nb-2 1\na-3 1\n")
+    os.remove(out)
+    with pytest.raises(SystemExit) as e:
+        S.interpolate_scores(os.path.join(d, "nolm"), os.path.join(d, "lmonly"), os.path.join(d, "nn"), 0.5, out)
+    assert "b-2" in str(e.value) and "line 2" in str(e.value) and not os.path.exists(out)
+
+
+def test_recipe_command_lines_parse_unchanged():
+    """North star: 'keeping the run_nnlm_* CLI surface'.  The argument lists of the reference recipes -- the flags of
+    run_nnlm_ami_tm.sh:89-110 and run_nnlm_ami_lstm.sh:89-110 in their order, with the values the scripts assign at
+    :17-35 / :18-34 (note `--epoch`, an argparse prefix of --epochs) -- and of the rescoring script's scorer call
+    (lmrescore_nbest_pytorchnn_cuda.sh:200-218) go through build_parser() and land on the reference's semantics;
+    the engine's own new flags stay at their defaults."""
+    from bayeslms_amd import train as T, compute_sentence_scores as S
+    tm = ("--data data/pytorchnn_ami --model Transformer --emsize 512 --nhid 4096 --nlayers 6 --nhead 8 --lr 0.1 "
+          "--dropout 0.2 --seq_len 100 --clip 1.0 --batch-size 32 --epoch 32 --seed 1111 --save exp/tfm/model.pt "
+          "--prior False --prior_path steps/pytorchnn/prior/transformer --uncertainty Gaussian --T_bayes_pos FFN "
+          "--T_gauss_pos 1 --T_v_pos 0 --tied --cuda").split()
+    a = T.build_parser().parse_args(tm)
+    assert (a.model, a.emsize, a.nhid, a.nlayers, a.nhead, a.seq_len, a.batch_size) == ("Transformer", 512, 4096, 6, 8, 100, 32)
+    assert a.epochs == 32 and a.T_bayes_pos == "FFN" and a.uncertainty == "Gaussian" and a.T_gauss_pos == 1 and a.tied
+    assert a.cuda and a.clip == 1.0 and a.lr == 0.1 and a.dropout == 0.2 and a.T_v_pos == 0 and a.prior == "False"
+    assert a.dist_backend == "nccl" and a.dp_overlap == 1 and a.dp_late_rows == 1 and a.gemm_mode == "f32" and not a.history
+    assert T.build_model(a, 50).__class__.__name__ == "GaussTransformerModel" and T.kl_selector(a) is not None
+    lstm = ("--data data/pytorchnn_ami --model LSTM --emsize 1024 --nhid 1024 --nlayers 2 --nhead 8 --lr 5 --dropout 0.2 "
+            "--seq_len 100 --clip 1.0 --batch-size 32 --epoch 32 --seed 1111 --save exp/lstm/model.pt --uncertainty Gaussian "
+            "--L_bayes_pos 0 --L_gauss_pos 00 --L_v_pos 00 --prior False --prior_path steps/pytorchnn/prior/lstm --tied "
+            "--mark marks --cuda").split()
+    a = T.build_parser().parse_args(lstm)
+    assert (a.model, a.emsize, a.nhid, a.nlayers, a.seq_len, a.batch_size, a.lr) == ("LSTM", 1024, 1024, 2, 100, 32, 5.0)
+    assert a.L_gauss_pos == "00" and a.L_v_pos == "00" and a.L_bayes_pos == 0 and a.mark == "marks" and a.epochs == 32
+    for k, v in (("--uncertainty", "Bayesian"), ("--L_bayes_pos", "3")):  # the configuration BASELINE configs[1] names
+        lstm[lstm.index(k) + 1] = v
+    a = T.build_parser().parse_args(lstm)
+    assert a.uncertainty == "Bayesian" and a.L_bayes_pos == 3 and T.kl_selector(a) is not None
+    sc = ("--nbest-list nbest.1/words_text --outfile nbest.1/lmwt.nn --vocabulary data/pytorchnn_ami/words.txt --model-path "
+          "exp/tfm/model.pt --model Transformer --emsize 512 --nhid 4096 --nlayers 6 --nhead 8 --uncertainty Gaussian "
+          "--L_bayes_pos 0 --T_bayes_pos FFN --L_v_pos 00 --T_v_pos 0 --L_gauss_pos 00 --T_gauss_pos 1 "
+          "--interpolation_flag 0 --inter_alpha 0.8").split()
+    b = S.build_parser().parse_args(sc)
+    assert b.model == "Transformer" and b.T_gauss_pos == 1 and b.batched == 1 and b.mc_samples == 0 and b.inter_alpha == 0.8
