@@ -56,6 +56,10 @@ class GemmArgs(C.Structure):
                 ("colsum_a", C.c_void_p)]
 
 
+class GemmPlan(C.Structure):
+    _fields_ = [("tile", C.c_int32), ("splits", C.c_int32), ("source", C.c_int32), ("model_us", C.c_float)]
+
+
 # name -> (restype, argtypes); every symbol include/bayeslm.h declares
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 _rngp, _varp = C.POINTER(Rng), C.POINTER(Variational)
@@ -73,6 +77,11 @@ SIGNATURES = {
     "blm_gemm": (_i, [C.POINTER(GemmArgs), _vp]),
     "blm_set_gemm_mode": (_i, [_i]),
     "blm_get_gemm_mode": (_i, []),
+    "blm_gemm_plan_query": (_i, [C.POINTER(GemmArgs), C.POINTER(GemmPlan)]),
+    "blm_gemm_plan_model_us": (_i, [C.POINTER(GemmArgs), _i, _i, C.POINTER(C.c_float)]),
+    "blm_gemm_plan_override": (_i, [_i, _i]),
+    "blm_gemm_plan_set": (_i, [_i] * 8),
+    "blm_gemm_plan_clear": (_i, [_i]),
     "blm_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _f, _f, _rngp, _i, _i, _vp]),
     "blm_embed_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _f, _f, _rngp, _i, _i, _vp]),
     "blm_add_pe_dropout": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _rngp, _i, _i, _vp]),

@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "gemm_f32_mfma.h"
+#include "gemm_plan.h"
 
 namespace blm {
 extern template int launch_op<BLM_GEMM_NT, false>(const GemmP&, hipStream_t);
@@ -63,12 +64,6 @@ extern "C" int blm_gemm(const blm_gemm_args* a, void* stream) {
   if (a->colsum_a && a->op != BLM_GEMM_TN) return blm_fail(BLM_ERR_INVALID, "blm_gemm: colsum_a needs op TN");
   p.drop_quad = (a->N % 4 == 0);
   p.eps_quad = (a->epilogue == BLM_EPI_BAYES_WGRAD && a->N % 4 == 0 && !blm::INTERLEAVE && !a->var_c.eps) ? 1 : 0;
-  {
-    static int tile = -1, spl = -1;  // tuning overrides, read once
-    if (tile < 0) { const char* e = getenv("BLM_GEMM_TILE"); tile = e ? atoi(e) : 0; }
-    if (spl < 0) { const char* e = getenv("BLM_GEMM_SPLITK"); spl = e ? atoi(e) : 0; }
-    p.force_tile = tile; p.force_splits = spl;
-  }
   p.split = blm_get_gemm_mode() == BLM_GEMM_MODE_BF16X3 ? 3 : (blm_get_gemm_mode() == BLM_GEMM_MODE_BF16X6 ? 6 : 0);
   p.a_vec = aligned16(a->A) && (a->lda % 4 == 0);
   p.b_vec = aligned16(a->B) && (a->ldb % 4 == 0);
@@ -108,6 +103,12 @@ extern "C" int blm_gemm(const blm_gemm_args* a, void* stream) {
     // the LDS-DMA loaders address an operand with 32-bit byte offsets from a scalar base
     const long arows = a->op == BLM_GEMM_TN ? a->K : a->M, brows = a->op == BLM_GEMM_NT ? a->N : a->K;
     if (arows * (long)a->lda * 4 >= (1L << 32) || brows * (long)a->ldb * 4 >= (1L << 32)) p.fast = false;
+  }
+  {
+    const PlanKey key = plan_key(a);
+    if ((key.fast != 0) != (p.fast != 0)) return blm_fail(BLM_ERR_INVALID, "blm_gemm: planner and launcher disagree on the fast path");
+    const Plan pl = choose_plan(key);
+    p.plan_tile = pl.tile; p.plan_splits = pl.splits;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (p.colsum_a && !p.fast) {  // odd shapes: the guarded-loader kernel does not fuse it

@@ -44,7 +44,7 @@ struct GemmP {
   int a_vec, b_vec, fast, vec_epi;
   int gm, gn;
   int eps_quad;                  // Bayesian wgrad: eps drawn once per 4 columns and shared inside the quad (N % 4 == 0, Philox mode)
-  int force_tile, force_splits;  // tuning overrides (BLM_GEMM_TILE / BLM_GEMM_SPLITK env), 0 = heuristic
+  int plan_tile, plan_splits;    // gemm_plan.hip: 11 / 12 / 21 / 22 and the number of K slices (>= 1)
   float* colsum_a;  // TN only: += column sums of A (= bias gradient of the layer whose wgrad this is)
   int splits, kper, atomic;  // split-K: block ks covers k in [ks*kper, (ks+1)*kper), partial sums by float atomics
   // fused activation dropout
@@ -1212,43 +1212,10 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   GemmP q = p;
   q.gm = (p.M + BM - 1) / BM;
   q.gn = (p.N + BN - 1) / BN;
-  // split-K when the output grid leaves most of the 256 CUs idle and K is long: partial sums meet
-  // in C through float atomics (only for the plain epilogue; C is zeroed first unless accumulating)
   const long nb = (long)q.gm * q.gn;
-  int splits = 1;
-  // the Bayesian wgrad epilogue is linear in dW (KL terms from the first slice only): it splits too,
-  // but only when accumulating (its second output has no zeroing pass here)
-  const bool can_split = !SAMP && ((p.epi == BLM_EPI_NONE && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N)) ||
-                                   (p.epi == BLM_EPI_BAYES_WGRAD && (p.flags & BLM_GEMM_ACCUMULATE)));
-  const bool small_out = (long)p.M * p.N <= (1L << 20);  // e.g. the LSTM recurrent GEMMs (64 x 4096): zeroing C is free
-  const int min_k = small_out ? 128 : 512;               // K per split
-  // forward layout, one full round of the chip (>= 256 tiles): no split unless K is very long -- within
-  // 1.5% of the 2-slice time at K = 4096 without the memset, the atomics and the second copy of the
-  // output (235 -> 218 MB of HBM traffic on the Bayesian FFN forward; what remains above the
-  // algorithmic 159 MB is W fetched once per XCD L2).  dgrad (NN) keeps the 2 slices: +4% in the step.
-  const bool one_round_ok = OP == BLM_GEMM_NN ? nb < 384 : (nb < 256 || (nb < 384 && p.K > 8192));
-  if (can_split && one_round_ok && p.K >= (small_out ? 512 : 2048)) {
-    if (nb <= 96) {
-      splits = 8;  // 8 slices = one per XCD: measured best for small output grids
-    } else {
-      // 512 workgroup slots (2 per CU): pick the slice count whose grid fills whole rounds of them --
-      // 144 tiles x 4 slices = 576 workgroups leave a second round 1/8 full (NN 2240x1024x33000: 75 TF),
-      // x 7 = 1008 fill two rounds; a small penalty per slice prefers the fewest slices among equals
-      double best = -1.0;
-      for (int sp = 1; sp <= 8; ++sp) {
-        if (sp > 1 && p.K / sp < min_k) break;
-        const long g = nb * sp, rounds = (g + 511) / 512;
-        const double u = (double)g / (double)(rounds * 512) - 0.01 * sp;
-        if (u > best + 1e-9) { best = u; splits = sp; }
-      }
-    }
-    while (splits > 1 && p.K / splits < min_k) --splits;
-  }
-  // weight-gradient layout with a long reduction: 4 K slices even when the output grid alone fills the
-  // chip -- the workgroups of one slice then share the same rows of both operands in L2
-  // (decoder dW 33000x512x8192: 102 -> 120 TFLOP/s, tools/gemm_sweep.sh)
-  if (OP == BLM_GEMM_TN && can_split && p.K >= 4096 && splits < 4) splits = p.epi == BLM_EPI_BAYES_WGRAD ? 2 : 4;  // (in-situ: 308 -> 292 us with 2)
-  if (p.force_splits > 0 && can_split) splits = p.force_splits;
+  // K slices as planned (gemm_plan.hip: legality -- plain or Bayesian-wgrad epilogue, dense or accumulated C -- is the
+  // planner's); partial sums meet in C through float atomics, C is zeroed first unless accumulating
+  const int splits = p.plan_splits > 1 ? p.plan_splits : 1;
   q.splits = splits;
   q.kper = splits > 1 ? ((p.K + splits - 1) / splits + BK - 1) / BK * BK : (p.K > 0 ? p.K : 1);
   q.atomic = splits > 1;
@@ -1289,94 +1256,14 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
 
 template <int OP, bool SAMP>
 int launch_op(const GemmP& p, hipStream_t st) {
-  // Tile choice: 128x128 when it fills the chip (>= 256 blocks) or the problem is large in both
-  // dimensions; otherwise shrink the dimension that leaves CUs idle.
-  const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  bool small_m = p.M <= 64, small_n = p.N <= 64;
-  if (!small_m && !small_n && b128 < 256) {
-    if (p.M <= p.N) small_m = true; else small_n = true;
-    const long b2 = (long)((p.M + (small_m ? 63 : 127)) / (small_m ? 64 : 128)) *
-                    ((p.N + (small_n ? 63 : 127)) / (small_n ? 64 : 128));
-    if (b2 < 256) small_m = small_n = true;
+  // tile and K slices: gemm_plan.hip (override > measured plan table > cost model), already legal for this call
+  if (!p.fast) return launch_cfg<OP, 1, 1, SAMP, false>(p, st);  // odd shapes/alignments: guarded loaders only
+  switch (p.plan_tile) {
+    case 11: return launch_cfg<OP, 1, 1, SAMP, true>(p, st);
+    case 12: return launch_cfg<OP, 1, 2, SAMP, true>(p, st);
+    case 21: return launch_cfg<OP, 2, 1, SAMP, true>(p, st);
+    default: return launch_cfg<OP, 2, 2, SAMP, true>(p, st);
   }
-  // measured on MI355X (tools/gemm_sweep.sh, cfg3 shapes):
-  //  * split-K capable launches with a long K keep the biggest tile that still gives >= 64 output
-  //    tiles and let split-K fill the chip (wgrads: 128x128 +8%, qkv wgrad 64x128 x 8 slices +40%);
-  //  * short-K launches (K <= 1024) whose 128x128 grid is less than two full rounds of the chip run
-  //    better on 64x128 tiles (qkv / out-proj forward, out-proj dgrad: +10..25%);
-  //  * the Bayesian wgrad splits like the plain ones when it accumulates (its epilogue is linear in
-  //    dW); without split-K it runs best on 64x64 tiles.
-  const bool can_split = !SAMP && ((p.epi == BLM_EPI_NONE && ((p.flags & BLM_GEMM_ACCUMULATE) || p.ldc == p.N)) ||
-                                   (p.epi == BLM_EPI_BAYES_WGRAD && (p.flags & BLM_GEMM_ACCUMULATE)));
-  if (can_split && p.K >= 2048 && p.M > 64 && p.N > 64) {
-    const long t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
-    if (b128 >= 96) small_m = small_n = false;
-    else if (t12 >= 64) {  // a tall output keeps the long tile side on its rows (qkv wgrad 1536x512x8192, in situ: 112.9 -> 109.7 us)
-      if (p.M > p.N) { small_m = false; small_n = true; } else { small_m = true; small_n = false; }
-    }
-    else small_m = small_n = true;
-  } else if (p.K < 2048 && b128 >= 256 && p.M >= 128 && p.N >= 128) {  // (K = 1536: the qkv input gradient, 122 -> 112 us)
-    // short reductions cannot be split: pick the tile whose grid fills whole rounds of the 512 workgroup slots
-    auto fill = [](long g) { return (double)g / (double)(((g + 511) / 512) * 512); };
-    const long t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128), t11 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
-    if (b128 < 1024) {
-      small_m = true; small_n = false;
-      // 2240x4096x1024 (LSTM input GEMM): 1120 tiles of 64x128 = 2.2 rounds (117 TF), 2240 of 64x64 = 4.4 (127 TF)
-      if (fill(t11) > fill(t12) + 0.1) small_n = true;
-    } else if (fill(t12) > fill(b128) + 0.05 || p.K <= 512) {
-      // decoder forward at M = 2240: 4644 tiles = 9.07 rounds -> 64x128 tiles (+2 %).  K <= 512 (16 K tiles per workgroup:
-      // prologue and epilogue are a sixth of its life): three 64x128 workgroups per CU overlap them better than two
-      // 128x128 ones -- in situ with the vector-free loop: FFN linear1 forward 319.6 -> 309.9 us, linear2 dgrad 288.7 -> 276.6,
-      // decoder forward 2130 -> 2083 us
-      small_m = true; small_n = false;
-    }
-  }
-  // measured INSIDE the cfg3 step (tools/step_breakdown.py under BLM_GEMM_TILE; the stand-alone sweep runs colder and ranks
-  // these differently): a forward product whose 128x128 grid is exactly half a round (8192 x 512: 256 tiles, one workgroup
-  // = one wave per SIMD on every CU) and whose K is too short to split runs 4-5 % faster on 128x64 tiles = 512 workgroups,
-  // two waves per SIMD (Bayesian FFN linear2 forward, the roofline kernel: 271 -> 257 us = 134 TF)
-  if (OP == BLM_GEMM_NT && !small_m && !small_n && b128 >= 256 && b128 < 384 && p.K >= 2048 && p.K <= 8192) small_n = true;
-  // the Bayesian wgrad epilogue (Philox + two outputs per element) is lighter per workgroup on 64x64 tiles (338 -> 315 us)
-  if (OP == BLM_GEMM_TN && p.epi == BLM_EPI_BAYES_WGRAD) small_m = small_n = true;
-  // measured on the cfg2 shapes (M = T*B = 2240; CFG=2 tools/gemm_sweep.sh), which the rules above -- tuned at M = 8192 --
-  // served badly:
-  //  * weight gradients with a medium reduction (2048 <= K < 4096: no 4-slice rule) whose 128x128 grid fills the 512
-  //    workgroup slots badly -- 256 tiles = half of them (dW_ih / dW_hh 4096x1024x2240: 115 TF), 2064 tiles = 4.03 rounds
-  //    (decoder dW 33000x1024x2240: 120 TF) -- run on 64x128 tiles, twice the workgroups (126 TF both);
-  //  * input gradients with a medium reduction and a 128x128 grid under one round (dX 2240x1024x4096: 144 tiles, 7 K
-  //    slices with atomics: 101 TF) run on 128x64 tiles when those fill a round (288 tiles x the slice count of the fill rule: 115 TF); a very long
-  //    reduction (decoder dX, K = 33000) keeps the split 128x128 form (131 TF against 126).
-  GemmP pf = p;
-  // Re-swept in situ (tools/step_breakdown.py lstm under BLM_GEMM_TILE / BLM_GEMM_SPLITK) once the K loops had lost their
-  // vector instructions -- the small tiles, three to five workgroups per CU, gained most:
-  //  * medium-reduction weight gradients on UNSPLIT 64x64 tiles when those give at least two rounds (decoder dW
-  //    33000x1024x2240: 1235 -> 1151 us, dW_ih / dW_hh 4096x1024x2240: 149.5 -> 145.5 us);
-  //  * dX 2240x1024x4096 on 64x64 tiles x 4 K slices (168.9 -> 158.4 us), decoder dX 2240x1024x33000 on 64x128 tiles x 8
-  //    slices (1124 -> 1097 us).
-  if (can_split && p.K >= 2048 && p.M > 64 && p.N > 64 && b128 >= 96) {
-    const long t11 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64), t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
-    if (OP == BLM_GEMM_TN && p.K < 4096) {
-      auto fill = [](long g) { return (double)g / (double)(((g + 511) / 512) * 512); };
-      if (t11 >= 1024 && p.epi == BLM_EPI_NONE) { small_m = small_n = true; pf.force_splits = 1; }
-      else if (fill(t12) > fill(b128) + 0.05) { small_m = true; small_n = false; }
-    } else if (OP == BLM_GEMM_NN && p.K <= 8192 && b128 < 256) {
-      const long t21 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
-      if (t11 >= 512 && p.K >= 4096) { small_m = small_n = true; pf.force_splits = 4; }
-      else if (t21 >= 256) { small_m = false; small_n = true; }
-    } else if (OP == BLM_GEMM_NN && p.K > 8192 && b128 < 256 && t12 >= 256) {
-      small_m = true; small_n = false; pf.force_splits = 8;
-    }
-  }
-  if (p.force_tile == 11) { small_m = small_n = true; }
-  else if (p.force_tile == 12) { small_m = true; small_n = false; }
-  else if (p.force_tile == 21) { small_m = false; small_n = true; }
-  else if (p.force_tile == 22) { small_m = small_n = false; }
-  if (p.force_splits > 0) pf.force_splits = p.force_splits;
-  if (!p.fast) return launch_cfg<OP, 1, 1, SAMP, false>(pf, st);  // odd shapes/alignments: guarded loaders only
-  if (small_m && small_n) return launch_cfg<OP, 1, 1, SAMP, true>(pf, st);
-  if (small_m) return launch_cfg<OP, 1, 2, SAMP, true>(pf, st);
-  if (small_n) return launch_cfg<OP, 2, 1, SAMP, true>(pf, st);
-  return launch_cfg<OP, 2, 2, SAMP, true>(pf, st);
 }
 
 }  // namespace blm

@@ -1,0 +1,294 @@
+// Launch planning of the fp32 MFMA GEMM family (host code): tile shape x split-K count for one blm_gemm call.
+//
+// The reference leaves this choice to the vendor BLAS behind F.linear (model.py:1127-1129 and every other call site);
+// here it is explicit and inspectable (blm_gemm_plan_query runs without a GPU):
+//   1. a process-wide override (blm_gemm_plan_override / BLM_GEMM_TILE, BLM_GEMM_SPLITK): tuning tools only;
+//   2. the plan table: exact (layout, M, N, K, epilogue, accumulate) keys with the plan that was fastest INSIDE the
+//      step it belongs to (tools/gemm_tune.py times every candidate in situ -- stand-alone timings run colder and rank
+//      the tiles differently -- and writes gemm_plans.inc; blm_gemm_plan_set adds entries at run time);
+//   3. the cost model below for every other shape.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "blm_host.h"
+#include "gemm_plan.h"
+
+namespace blm {
+
+namespace {
+
+struct Entry { int op, M, N, K, epi, acc, tile, splits; };
+
+const Entry kBuiltin[] = {
+#include "gemm_plans.inc"
+    {-1, 0, 0, 0, 0, 0, 0, 0}};
+
+std::mutex g_mu;
+std::vector<Entry> g_runtime;   // blm_gemm_plan_set
+bool g_builtin_on = true;       // blm_gemm_plan_clear switches the built-in table off as well (model only)
+int g_force_tile = -1, g_force_splits = -1;  // -1: environment not read yet
+
+// ---- cost model -------------------------------------------------------------------------------------------------
+// A workgroup is 4 waves, one per SIMD; per K tile of 32 a wave issues wtm*wtn*16 v_mfma_f32_32x32x2_f32 of 64 cycles.
+// occ workgroups share a CU (LDS: 32 / 48 / 48 / 64 KB of 160), so a full round of 256*occ workgroups costs
+// occ * kt * 1024*wtm*wtn cycles of matrix issue per SIMD, stretched by the tile's efficiency e(o) = einf * o / (o + a)
+// at o co-resident workgroups (one wave per SIMD hides nothing, five hide almost everything), plus a fixed cost per
+// co-resident workgroup (prologue, epilogue, C store); the last, partly filled round runs o = ceil(rest / 256) per CU.
+// Operand / output streaming enters as a soft maximum (near that bound the plan still matters), split-K adds the atomic
+// read-modify-write of C once per slice and a zeroing pass when C is not accumulated into.  The constants are a
+// least-squares fit (tools/gemm_fit.py) to the stand-alone sweep of tools/gemm_tune.py --grid on one MI355X -- 2160
+// shapes x 4 tiles x up to 8 slice counts = 50,784 timings, median |log error| 4 %; the model's PICK reaches 98.5 % of
+// the best candidate's rate on average, >= 0.79 on every shape above 30 us (profiles/r03_gemm_model_fit.txt).
+struct TileModel { int tile, wtm, wtn, occ; };
+const TileModel kTiles[4] = {{11, 1, 1, 5}, {12, 1, 2, 3}, {21, 2, 1, 3}, {22, 2, 2, 2}};
+struct ModelK {
+  double cyc_per_us;      // nominal matrix-pipe clock; einf absorbs the clock under load
+  double einf[3][4];      // [layout][tile]: efficiency of the MFMA issue with many co-resident workgroups
+  double a[4];            // e(o) = einf * o / (o + a)
+  double t0[4];           // fixed cost of the first round (us)
+  double t0r[4];          // ... of every further round
+  double launch_us;
+  double atomic_bpus;     // bytes of C per microsecond through float atomics
+  double memset_bpus, memset_us;
+  double hbm_bpus;        // streaming rate of A + B + C
+  double t0o[4];          // fixed cost per co-resident workgroup of a round (us)
+};
+ModelK g_model = {
+    2400.0,
+    {{0.9918, 1.0855, 1.0856, 1.0509}, {0.9913, 1.0854, 1.0891, 1.0538}, {0.9553, 1.0427, 1.0461, 1.0242}},
+    {0.2799, 0.3217, 0.3185, 0.1961},
+    {0.119, 0.195, 0.057, 1.587},
+    {0.000, 0.000, 0.000, 0.000},
+    3.843,
+    3.567e+06,
+    1.441e+07, 2.239,
+    4.565e+06,
+    {0.331, 1.440, 1.302, 2.817},
+};
+
+double model_us(const PlanKey& k, const TileModel& t, int S) {
+  const ModelK& m = g_model;
+  const int ti = (int)(&t - kTiles);
+  const long BM = 64 * t.wtm, BN = 64 * t.wtn;
+  const long tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
+  const long G = tiles * S;
+  const long kper = (k.K + S - 1) / S;
+  const double kt = (double)((kper + 31) / 32);
+  const double tk = kt * 1024.0 * t.wtm * t.wtn / m.cyc_per_us;  // matrix issue time of one workgroup on its SIMDs
+  const long slots = 256L * t.occ;
+  const long full = G / slots, rem = G - full * slots;
+  auto eff = [&](double o) { return m.einf[k.op][ti] * o / (o + m.a[ti]); };
+  const double t_full = (double)t.occ * tk / eff((double)t.occ) + m.t0o[ti] * t.occ;
+  double us = m.launch_us;
+  if (full > 0) us += m.t0[ti] + t_full + (double)(full - 1) * (m.t0r[ti] + t_full);
+  if (rem > 0) {
+    const double o = (double)((rem + 255) / 256);
+    us += (full > 0 ? m.t0r[ti] : m.t0[ti]) + o * tk / eff(o) + m.t0o[ti] * o;
+  }
+  const double bytes = 4.0 * ((double)k.M * k.K + (double)k.N * k.K + (double)k.M * k.N * (k.acc ? 2.0 : 1.0));
+  const double mem = m.launch_us + bytes / m.hbm_bpus;
+  us = std::cbrt(us * us * us + mem * mem * mem);
+  if (S > 1) {
+    us += (double)S * (double)k.M * k.N * 4.0 / m.atomic_bpus;
+    if (!k.acc) us += m.memset_us + (double)k.M * k.N * 4.0 / m.memset_bpus;
+  }
+  return us;
+}
+
+Plan model_plan(const PlanKey& k) {
+  Plan best{11, 1, 0};
+  double bt = 1e30;
+  for (const TileModel& t : kTiles) {
+    if (!k.fast && t.tile != 11) continue;
+    for (int S = 1; S <= 16; ++S) {
+      if (S > 1 && (!k.can_split || k.K / S < 128)) break;
+      if (S == 5 || S == 7 || (S > 8 && S != 12 && S != 16)) continue;  // the slice counts the sweep measured
+      const double us = model_us(k, t, S) * (1.0 + 0.002 * S);  // among equals, the fewest slices
+      if (us < bt) { bt = us; best.tile = t.tile; best.splits = S; }
+    }
+  }
+  return best;
+}
+
+
+// ---- the round-2 hand-placed rules, kept ONLY as the yardstick of tools/gemm_tune.py's A/B (BLM_GEMM_PLAN=legacy) ----
+Plan legacy_plan(const PlanKey& p) {
+  const int OP = p.op;
+  const bool can_split = p.can_split != 0;
+  const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  bool small_m = p.M <= 64, small_n = p.N <= 64;
+  int force_splits = 0;
+  if (!small_m && !small_n && b128 < 256) {
+    if (p.M <= p.N) small_m = true; else small_n = true;
+    const long b2 = (long)((p.M + (small_m ? 63 : 127)) / (small_m ? 64 : 128)) * ((p.N + (small_n ? 63 : 127)) / (small_n ? 64 : 128));
+    if (b2 < 256) small_m = small_n = true;
+  }
+  auto fill = [](long g) { return (double)g / (double)(((g + 511) / 512) * 512); };
+  if (can_split && p.K >= 2048 && p.M > 64 && p.N > 64) {
+    const long t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
+    if (b128 >= 96) small_m = small_n = false;
+    else if (t12 >= 64) { if (p.M > p.N) { small_m = false; small_n = true; } else { small_m = true; small_n = false; } }
+    else small_m = small_n = true;
+  } else if (p.K < 2048 && b128 >= 256 && p.M >= 128 && p.N >= 128) {
+    const long t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128), t11 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    if (b128 < 1024) { small_m = true; small_n = false; if (fill(t11) > fill(t12) + 0.1) small_n = true; }
+    else if (fill(t12) > fill(b128) + 0.05 || p.K <= 512) { small_m = true; small_n = false; }
+  }
+  if (OP == BLM_GEMM_NT && !small_m && !small_n && b128 >= 256 && b128 < 384 && p.K >= 2048 && p.K <= 8192) small_n = true;
+  if (OP == BLM_GEMM_TN && p.epi == BLM_EPI_BAYES_WGRAD) small_m = small_n = true;
+  if (can_split && p.K >= 2048 && p.M > 64 && p.N > 64 && b128 >= 96) {
+    const long t11 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64), t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
+    if (OP == BLM_GEMM_TN && p.K < 4096) {
+      if (t11 >= 1024 && p.epi == BLM_EPI_NONE) { small_m = small_n = true; force_splits = 1; }
+      else if (fill(t12) > fill(b128) + 0.05) { small_m = true; small_n = false; }
+    } else if (OP == BLM_GEMM_NN && p.K <= 8192 && b128 < 256) {
+      const long t21 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
+      if (t11 >= 512 && p.K >= 4096) { small_m = small_n = true; force_splits = 4; }
+      else if (t21 >= 256) { small_m = false; small_n = true; }
+    } else if (OP == BLM_GEMM_NN && p.K > 8192 && b128 < 256 && t12 >= 256) {
+      small_m = true; small_n = false; force_splits = 8;
+    }
+  }
+  if (!p.fast) small_m = small_n = true;
+  const int BM = small_m ? 64 : 128, BN = small_n ? 64 : 128;
+  const long nb = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  int splits = 1;
+  const bool small_out = (long)p.M * p.N <= (1L << 20);
+  const int min_k = small_out ? 128 : 512;
+  const bool one_round_ok = OP == BLM_GEMM_NN ? nb < 384 : (nb < 256 || (nb < 384 && p.K > 8192));
+  if (can_split && one_round_ok && p.K >= (small_out ? 512 : 2048)) {
+    if (nb <= 96) splits = 8;
+    else {
+      double best = -1.0;
+      for (int sp = 1; sp <= 8; ++sp) {
+        if (sp > 1 && p.K / sp < min_k) break;
+        const long g = nb * sp, rounds = (g + 511) / 512;
+        const double u = (double)g / (double)(rounds * 512) - 0.01 * sp;
+        if (u > best + 1e-9) { best = u; splits = sp; }
+      }
+    }
+    while (splits > 1 && p.K / splits < min_k) --splits;
+  }
+  if (OP == BLM_GEMM_TN && can_split && p.K >= 4096 && splits < 4) splits = p.epi == BLM_EPI_BAYES_WGRAD ? 2 : 4;
+  if (force_splits > 0 && can_split) splits = force_splits;
+  return Plan{small_m ? (small_n ? 11 : 12) : (small_n ? 21 : 22), splits, 3};
+}
+
+const Entry* find(const PlanKey& k) {
+  for (auto it = g_runtime.rbegin(); it != g_runtime.rend(); ++it)
+    if (it->op == k.op && it->M == k.M && it->N == k.N && it->K == k.K && it->epi == k.epi && it->acc == k.acc) return &*it;
+  if (g_builtin_on)
+    for (const Entry* e = kBuiltin; e->op >= 0; ++e)
+      if (e->op == k.op && e->M == k.M && e->N == k.N && e->K == k.K && e->epi == k.epi && e->acc == k.acc) return e;
+  return nullptr;
+}
+
+void read_env() {
+  if (g_force_tile >= 0) return;
+  const char* e = getenv("BLM_GEMM_TILE");
+  g_force_tile = e ? atoi(e) : 0;
+  e = getenv("BLM_GEMM_SPLITK");
+  g_force_splits = e ? atoi(e) : 0;
+}
+
+bool valid_tile(int t) { return t == 11 || t == 12 || t == 21 || t == 22; }
+
+}  // namespace
+
+double plan_model_us(const PlanKey& k, int tile, int splits) {
+  for (const TileModel& t : kTiles)
+    if (t.tile == tile) return model_us(k, t, splits < 1 ? 1 : splits);
+  return -1.0;
+}
+
+Plan choose_plan(const PlanKey& k) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  read_env();
+  static int legacy = -1;
+  if (legacy < 0) { const char* e = getenv("BLM_GEMM_PLAN"); legacy = (e && !strcmp(e, "legacy")) ? 1 : ((e && !strcmp(e, "model")) ? 2 : 0); }
+  Plan p = legacy == 1 ? legacy_plan(k) : model_plan(k);
+  if (const Entry* e = legacy == 0 ? find(k) : nullptr) { p.tile = e->tile; p.splits = e->splits; p.source = 1; }
+  if (g_force_tile > 0 && valid_tile(g_force_tile)) { p.tile = g_force_tile; p.source = 2; }
+  if (g_force_splits > 0) { p.splits = g_force_splits; p.source = 2; }
+  // legality, whatever the source said
+  if (!k.fast) p.tile = 11;
+  if (!k.can_split) p.splits = 1;
+  if (p.splits < 1) p.splits = 1;
+  while (p.splits > 1 && k.K / p.splits < 32) --p.splits;
+  return p;
+}
+
+}  // namespace blm
+
+using namespace blm;
+
+static int key_of(const blm_gemm_args* a, PlanKey* k) {
+  if (!a) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_query: null args");
+  if (a->abi_version != BLM_ABI_VERSION) return blm_fail(BLM_ERR_ABI, "blm_gemm_plan_query: abi_version mismatch");
+  if (a->op < BLM_GEMM_NT || a->op > BLM_GEMM_TN || a->M <= 0 || a->N <= 0 || a->K < 0)
+    return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_query: bad op or shape");
+  *k = plan_key(a);
+  return BLM_OK;
+}
+
+blm::PlanKey blm::plan_key(const blm_gemm_args* a) {
+  PlanKey k{};
+  k.op = a->op; k.M = a->M; k.N = a->N; k.K = a->K; k.epi = a->epilogue;
+  k.acc = (a->flags & BLM_GEMM_ACCUMULATE) ? 1 : 0;
+  const bool samp = a->var_b.lgstd != nullptr;
+  // split-K: partial sums meet in C through float atomics -- only for the plain epilogue (C zeroed first unless
+  // accumulating, which needs a dense C) and for the Bayesian wgrad epilogue, which is linear in dW (KL terms from the
+  // first slice only) but has no zeroing pass for its second output
+  k.can_split = !samp && ((a->epilogue == BLM_EPI_NONE && (k.acc || a->ldc == a->N)) || (a->epilogue == BLM_EPI_BAYES_WGRAD && k.acc));
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const int ac = a->op == BLM_GEMM_TN ? a->M : a->K, bc = a->op == BLM_GEMM_NT ? a->K : a->N;
+  k.fast = al16(a->A) && al16(a->B) && a->lda % 4 == 0 && a->ldb % 4 == 0 && ac % 4 == 0 && bc % 4 == 0 && ac >= 4 && bc >= 4;
+  const long arows = a->op == BLM_GEMM_TN ? a->K : a->M, brows = a->op == BLM_GEMM_NT ? a->N : a->K;
+  if (arows * (long)a->lda * 4 >= (1L << 32) || brows * (long)a->ldb * 4 >= (1L << 32)) k.fast = 0;
+  return k;
+}
+
+extern "C" int blm_gemm_plan_query(const blm_gemm_args* a, blm_gemm_plan* out) {
+  PlanKey k;
+  if (int rc = key_of(a, &k)) return rc;
+  if (!out) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_query: null out");
+  const Plan p = choose_plan(k);
+  out->tile = p.tile; out->splits = p.splits; out->source = p.source;
+  out->model_us = (float)plan_model_us(k, p.tile, p.splits);
+  return BLM_OK;
+}
+
+extern "C" int blm_gemm_plan_model_us(const blm_gemm_args* a, int tile, int splits, float* us) {
+  PlanKey k;
+  if (int rc = key_of(a, &k)) return rc;
+  const double v = plan_model_us(k, tile, splits);
+  if (v < 0 || !us) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_model_us: unknown tile %d", tile);
+  *us = (float)v;
+  return BLM_OK;
+}
+
+extern "C" int blm_gemm_plan_override(int tile, int splits) {
+  if (tile != 0 && !valid_tile(tile)) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_override: tile must be 0, 11, 12, 21 or 22");
+  if (splits < 0 || splits > 64) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_override: splits out of range");
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_force_tile = tile; g_force_splits = splits;
+  return BLM_OK;
+}
+
+extern "C" int blm_gemm_plan_set(int op, int M, int N, int K, int epilogue, int accumulate, int tile, int splits) {
+  if (op < BLM_GEMM_NT || op > BLM_GEMM_TN || !valid_tile(tile) || splits < 1 || splits > 64)
+    return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_set: bad op, tile or split count");
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_runtime.push_back(Entry{op, M, N, K, epilogue, accumulate ? 1 : 0, tile, splits});
+  return BLM_OK;
+}
+
+extern "C" int blm_gemm_plan_clear(int keep_builtin) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_runtime.clear();
+  g_builtin_on = keep_builtin != 0;
+  return BLM_OK;
+}

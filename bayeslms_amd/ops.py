@@ -304,7 +304,13 @@ class _Linear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             parked = ctx.link.take(x) if ctx.link is not None else None
-            if parked is not None:  # residual block: add into the LayerNorm backward's dx (ResidualLink)
+            if parked is not None and parked.data_ptr() == dy.data_ptr():
+                # this op feeds the LayerNorm directly and no dropout sits between them: the LayerNorm backward hands ONE
+                # buffer out as dx and dy, and a GEMM cannot accumulate into its own A operand
+                dx = torch.empty_like(x)
+                gemm(L.GEMM_NN, dy, w, dx, M, K, N, N, K, K)
+                dx.add_(parked)
+            elif parked is not None:  # residual block: add into the LayerNorm backward's dx (ResidualLink)
                 gemm(L.GEMM_NN, dy, w, parked, M, K, N, N, K, K, accumulate=True)
                 dx = parked
             else:

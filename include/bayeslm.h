@@ -218,6 +218,30 @@ int blm_gemm(const blm_gemm_args* a, void* stream);
 int blm_set_gemm_mode(int mode);
 int blm_get_gemm_mode(void);
 
+/* Launch plan of a blm_gemm call: block tile (11 = 64x64, 12 = 64x128, 21 = 128x64, 22 = 128x128 rows x cols) and
+ * number of K slices (> 1: partial sums meet in C through float atomics).  The reference leaves this to the vendor
+ * BLAS behind F.linear (model.py:1127-1129); here it is one explicit rule for every shape (csrc/gemm_plan.hip):
+ * override > plan table (exact-shape entries measured inside the benchmark / recipe steps, csrc/gemm_plans.inc,
+ * written by tools/gemm_tune.py) > cost model (workgroup-slot rounds x per-tile matrix-pipe efficiency).
+ * All of this is host code: none of the functions below touches the GPU. */
+typedef struct blm_gemm_plan {
+  int32_t tile;
+  int32_t splits;
+  int32_t source;   /* 0 cost model, 1 plan table, 2 override */
+  float model_us;   /* the cost model's estimate for this plan */
+} blm_gemm_plan;
+/* The plan blm_gemm would use for `a` (pointers are only inspected for alignment). */
+int blm_gemm_plan_query(const blm_gemm_args* a, blm_gemm_plan* out);
+/* The cost model's estimate (microseconds) of `a` under a given tile / slice count. */
+int blm_gemm_plan_model_us(const blm_gemm_args* a, int tile, int splits, float* us);
+/* Tuning tools: force a tile and / or a slice count for every call of this process (0 = no override; also read once
+ * from BLM_GEMM_TILE / BLM_GEMM_SPLITK). */
+int blm_gemm_plan_override(int tile, int splits);
+/* Add (or supersede) a plan-table entry at run time; blm_gemm_plan_clear drops the run-time entries and, with
+ * keep_builtin == 0, switches the built-in table off as well (cost model only). */
+int blm_gemm_plan_set(int op, int M, int N, int K, int epilogue, int accumulate, int tile, int splits);
+int blm_gemm_plan_clear(int keep_builtin);
+
 /* --------------------------------------------------------------------------
  * Surrounding Transformer / LSTM ops (HBM-bound unless stated)
  * ------------------------------------------------------------------------ */
