@@ -63,6 +63,9 @@ __device__ __forceinline__ float gemm_keep(const GemmP& p, int m, int n) {
 constexpr int BK = 32;
 #ifdef BLM_GEMM_PROF
 static __device__ unsigned long long blm_prof[4];  // per translation unit (debug build only)
+// life of every workgroup of the LAST launch (tools/gemm_drift_probe.py): [4*bid] = wall clock (10 ns) at entry,
+// [+1] at the end of the K loop, [+2] HW_ID (CU / SE / slot), [+3] XCC_ID
+static __device__ long long blm_wg_life[4 * 8192];
 #endif
 // Epilogue-only switch kept from an experiment (two MFMA tiles of a wave interleaved by rows 2x+t
 // instead of stacked 32t+x; measured neutral on MI355X): the operand paths below are the stacked form.
@@ -700,6 +703,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+#ifdef BLM_GEMM_PROF
+  if (t == 0 && blockIdx.x < 8192) {
+    blm_wg_life[4 * blockIdx.x] = wall_clock64();
+    blm_wg_life[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+    blm_wg_life[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+  }
+#endif
 
   float4 ra[NA], rb[NB], rl[SAMP ? NB : 1];
   const float* pa[FAST ? NA : 1];
@@ -1025,6 +1035,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   if constexpr (DMA) {
     // the first tile takes the DMA path too: no per-thread operand pointers, no register staging in these kernels at all
     // (a 16-tile reduction spends a sixth of its life around the K loop)
+#ifdef BLM_GEMM_FIRST_TILE_REG  // traffic A/B only (tools/traffic_probe.sh): the first tile through registers, as before 6cbf842
+    if (t0 < tfull) fetch_fast(t0); else fetch_slow(t0 * BK);
+    stash(0, t0 * BK, t0 < tfull);
+#else
     if (t0 < tfull) {
       dma_issue(0, t0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1032,6 +1046,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
       fetch_slow(t0 * BK);
       stash(0, t0 * BK, false);
     }
+#endif
   } else {
     if (t0 < tfull) fetch_fast(t0); else fetch_slow(t0 * BK);
     stash(0, t0 * BK, t0 < tfull);
@@ -1068,7 +1083,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
       BLM_PF_NOW(td)
       BLM_PF_ADD()
     };
-    if constexpr (SPLIT != 0) {  // opt-in split-bf16 kernels: the two-tile body demotes their fragment arrays to scratch
+#ifdef BLM_GEMM_ONE_TILE_TRIP  // traffic A/B only: the rolled loop for every kernel
+    constexpr bool kRolled = true;
+#else
+    constexpr bool kRolled = SPLIT != 0;
+#endif
+    if constexpr (kRolled) {  // opt-in split-bf16 kernels: the two-tile body demotes their fragment arrays to scratch
       for (; kt + 1 < tfull; ++kt) dma_step((kt - t0) & 1, kt + 1);
     } else {
       for (; kt + 2 < tfull; kt += 2) {
@@ -1145,6 +1165,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     }
   }
 #ifdef BLM_GEMM_PROF
+  if (t == 0 && blockIdx.x < 8192) blm_wg_life[4 * blockIdx.x + 1] = wall_clock64();
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(&blm_prof[0], pf_compute); atomicAdd(&blm_prof[1], pf_stash); atomicAdd(&blm_prof[2], pf_barrier); atomicAdd(&blm_prof[3], pf_n);
   }
@@ -1249,6 +1270,13 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
                                 (int)lds));
     attr_done = true;
   }
+  // HBM-side traffic of a launch with two or more workgroups per CU (tools/traffic_probe.sh, request-size PMC counters,
+  // profiles/r03_gemm_traffic_*.txt): the B panels are fetched TWICE per XCD once K exceeds ~1400 -- the arbiter serves the
+  // oldest ready wave first, so the workgroup that reached a CU first runs well ahead of its co-resident neighbour, and the
+  // panel lines the late half needs have left the XCD's 4 MB L2 (window = 4 MB / 6 KB of panel data per k = ~700 k) by
+  // the time it asks.  128x128 tiles (one workgroup per CU, lock step) read exactly the operands.  Measured and not kept:
+  // padding the LDS request so that a one-round grid spreads evenly (no change), wave-priority turns between the
+  // co-resident workgroups (-25 % of the surplus at K = 4096, more at 8192, step +0.3 %).  The bytes cost no time (1.5 TB/s).
   hipLaunchKernelGGL(kern, dim3((unsigned)(nb * splits)), dim3(256), lds, st, q);
   BLM_HIP(hipGetLastError());
   return BLM_OK;

@@ -36,6 +36,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dens
 # forward FLOPs per token L(2d*3d + 4Td + 2d^2 + 4d*ff) + 2dV = 98.28 M, training = 3x
 STEP_FLOPS_PER_TOKEN = 3 * (NLAYERS * (2 * D_MODEL * 3 * D_MODEL + 4 * T * D_MODEL + 2 * D_MODEL * D_MODEL + 4 * D_MODEL * D_FF)
                             + 2 * D_MODEL * V)
+PMC_TRAFFIC_FILE = "r03_pmc_sampled_gemm_fwd.json"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (the opt-in split modes are priced against this one)
 
 
@@ -147,11 +148,29 @@ def cpu_baseline(cols=B_PER_GPU, steps=5, warm=2):
                       % (DROPOUT, T, cols, steps, warm, ncores)}
 
 
-def _train_leg(model, kl_fn, seq, Bc, lr, steps, warm, dev, engine, ops, timed_tags=False):
+def tlm_flops_per_token(T_, V_=V, L_=NLAYERS, d=D_MODEL, ff=D_FF, train=True):
+    """forward FLOPs per token L(2d*3d + 4Td + 2d^2 + 4d*ff) + 2dV; training = 3x."""
+    f = L_ * (2 * d * 3 * d + 4 * T_ * d + 2 * d * d + 4 * d * ff) + 2 * d * V_
+    return 3 * f if train else f
+
+
+def lstm_flops_per_token(V_, E=1024, H=1024, L_=2, train=True):
+    """forward FLOPs per token of the 2-layer LSTM LM: 2 layers x 2(E+H)4H + 2HV; training = 3x."""
+    f = L_ * 2 * (E + H) * 4 * H + 2 * H * V_
+    return 3 * f if train else f
+
+
+def _frac(flops_per_token, tokens_per_s):
+    tf = flops_per_token * tokens_per_s / 1e12
+    return {"bound": "mfma", "model_flops_per_token": int(flops_per_token), "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+
+
+def _train_leg(model, kl_fn, seq, Bc, lr, steps, warm, dev, engine, ops, timed_tags=False, vocab=V, flops_per_token=None):
     """tokens/s of engine.Trainer steps on a synthetic AMI-shaped stream (same step as the headline)."""
     from bayeslms_amd.data import batchify, get_batch, synthetic_corpus
     from bayeslms_amd.model import repackage_hidden
-    stream = synthetic_corpus(V, Bc * ((steps + warm) * seq + 1) + 17, seed=1111)
+    stream = synthetic_corpus(vocab, Bc * ((steps + warm) * seq + 1) + 17, seed=1111)
     train = batchify(stream, Bc, dev)
     tr = engine.Trainer(model, lr=lr, clip=CLIP, kl_scale=float(seq) / train.size(0), seed=1111)
     is_rnn = hasattr(model, "init_hidden")
@@ -171,89 +190,301 @@ def _train_leg(model, kl_fn, seq, Bc, lr, steps, warm, dev, engine, ops, timed_t
     ops.set_kernel_timer(None)
     out = {"value": round(steps * seq * Bc / el, 1), "unit": "tokens/s", "ms_per_step": round(1e3 * el / steps, 3),
            "steps": steps, "warmup": warm, "final_loss": round(float(loss), 4)}
+    if flops_per_token:
+        out["step_roofline"] = _frac(flops_per_token, out["value"])
     return out, (timer.summary() if timer is not None else {})
 
 
-def extra_configs(dev, args, engine, M, ops):
-    """Reported AFTER the headline, never part of `value`: the other BASELINE.json configurations that fit one GPU,
-    under the same clock as the headline run (VERDICT r1 #4).  fp32, same Trainer step, synthetic data."""
+def _eval_leg(model, seq, dev, engine, vocab, flops_per_token, windows=12):
+    """engine.evaluate (train.py:441-458: eval batch 20, mean weights) on held-out synthetic text: tokens/s."""
+    from bayeslms_amd.data import batchify, synthetic_corpus
+    valid = batchify(synthetic_corpus(vocab, 20 * (windows * seq + 1), seed=2222), 20, dev)
+    engine.evaluate(model, valid[: 2 * seq + 1], seq)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = engine.evaluate(model, valid, seq)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tps = (valid.size(0) - 1) * 20 / el
+    return {"value": round(tps, 1), "unit": "tokens/s", "eval_batch": 20, "seq_len": seq, "loss": round(loss, 4),
+            "step_roofline": _frac(flops_per_token, tps)}
+
+
+def lstm_cpu_baseline(steps=3, warm=1):
+    """BASELINE.json configs[0] on the host cores: the oracle's LSTM training step (fwd + CE + bwd + clip + SGD, dropout
+    0.2 from torch's generator) at the reference's own CPU-runnable size -- 2 x 1024, V = 10,000, batch 20, seq_len 35."""
+    from bayeslms_amd import model as M
+    from bayeslms_amd.data import synthetic_corpus
+    from oracle import bayes_oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    ncores = min(avail, 16)
+    torch.set_num_threads(ncores)
+    torch.manual_seed(1111)
+    Vc, Bc, Tc = 10000, 20, 35
+    m = M.RNNModel("LSTM", Vc, 1024, 1024, 2, 0.2, True)
+    names = [k for k, _ in m.named_parameters() if k != "decoder.weight"]
+    sd = {k: v.detach().clone().requires_grad_(k in names) for k, v in m.state_dict().items()}
+    sd["decoder.weight"] = sd["encoder.weight"]
+    del m
+    total = warm + steps
+    stream = synthetic_corpus(Vc, Bc * (Tc * total + 1), seed=1111)
+    data = stream[: Bc * (Tc * total + 1) // Bc * Bc].view(Bc, -1).t().contiguous()
+    hidden = (torch.zeros(2, Bc, 1024), torch.zeros(2, Bc, 1024))
+    bufs = [None] * len(names)
+    times = []
+    for s_ in range(total):
+        src, tgt = data[s_ * Tc:(s_ + 1) * Tc], data[s_ * Tc + 1:(s_ + 1) * Tc + 1].reshape(-1)
+        t0 = time.perf_counter()
+        for k in names:
+            sd[k].grad = None
+        hidden = tuple(h.detach() for h in hidden)
+        logits, hidden = O.rnn_lm_train(src, hidden, sd, 0.2)
+        loss = torch.nn.functional.cross_entropy(logits.view(-1, Vc), tgt)
+        loss.backward()
+        O.clip_and_sgd([sd[k] for k in names], [sd[k].grad for k in names], bufs, 1.0, CLIP)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times[warm:])[steps // 2]
+    return {"value": round(Bc * Tc / med, 1), "unit": "tokens/s", "cores": ncores, "kind": "port",
+            "sample": "oracle/bayes_oracle.py LSTM train step (fwd+CE+bwd+clip+SGD, dropout 0.2 on), 2x1024 V=10000 batch 20 "
+                      "seq_len 35, median of %d steps after %d warm-up, %d threads; BASELINE.md has the reference itself at 935 "
+                      "tokens/s on the build container's 8 cores" % (steps, warm, ncores)}
+
+
+def synthetic_nbest(n_utt, n_hyp, vocab_size, seed=7):
+    """SURVEY 8(d) scoring workload: n_utt utterances x n_hyp-best, hypothesis length 1 + Poisson(7) clipped to [1, 60]
+    (AMI-shaped), the hypotheses of an utterance differing in up to three words.  -> (OrderedDict, vocab dict, n tokens)"""
     import random
     from collections import OrderedDict
-    from types import SimpleNamespace
-    from bayeslms_amd import compute_sentence_scores as css, train as TR
-    res = []
-    ns = lambda **k: SimpleNamespace(**{**dict(model="Transformer", uncertainty="none", T_bayes_pos="none", L_bayes_pos=0,  # noqa: E731
-                                               T_gauss_pos=3, L_gauss_pos="00", L_v_pos="11", T_v_pos=0), **k})
-    steps = max(args.steps, 5)
-    # --- configs[1]: Bayesian LSTM LM (--uncertainty Bayesian --L_bayes_pos 3), 2x1024, B 64, T 35, V 33k
-    torch.manual_seed(1111)
-    m = M.BayesRNNModel("LSTM", V, 1024, 1024, 2, DROPOUT, True, 3).to(dev)
-    r, kt = _train_leg(m, TR.kl_selector(ns(model="LSTM", uncertainty="Bayesian", L_bayes_pos=3)), 35, B_PER_GPU, 1.0, 2 * steps,
-                       max(args.warmup, 20), dev, engine, ops, timed_tags=True)
-    Tl = 35
-    fwd = kt.get("lstm_seq_fwd T=%d" % Tl, {}).get("avg_ms")
-    bwd = kt.get("lstm_seq_bwd T=%d" % Tl, {}).get("avg_ms")
-    floor_us = 2.0 * B_PER_GPU * 4096 * 1024 / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6  # 0.54 GFLOP / 157.3 TF
-    r.update({"config": "BASELINE.json configs[1]: Bayesian LSTM LM (--uncertainty Bayesian --L_bayes_pos 3) 2x1024 tied, "
-                        "V=33000, batch 64, seq_len 35, dropout 0.2, clip 1.0, SGD momentum 0.9",
-              "lstm_step_fwd_us": None if fwd is None else round(1e3 * fwd / Tl, 2),
-              "lstm_step_bwd_us": None if bwd is None else round(1e3 * bwd / Tl, 2),
-              "lstm_step_mfma_floor_us": round(floor_us, 2),
-              "lstm_step_fwd_frac_of_floor": None if fwd is None else round(floor_us / (1e3 * fwd / Tl), 3)})
-    res.append(r)
-    # LSTM 20-best rescoring (mean weights; the carried state makes it the latency-bound scorer)
-    rnd = random.Random(7)
-    words = ["w%d" % i for i in range(V - 2)]
+    import numpy as np
+    rnd = random.Random(seed)
+    rs = np.random.RandomState(seed)
+    words = ["w%d" % i for i in range(vocab_size - 2)]
     vocab = {w: i + 2 for i, w in enumerate(words)}
     vocab["<s>"], vocab["<unk>"] = 0, 1
-    n_utt, n_hyp = 300, 20
-    nbest = OrderedDict()
+    nbest, ntok = OrderedDict(), 0
     for u in range(n_utt):
-        base = [rnd.choice(words) for _ in range(rnd.randint(1, 16))]  # AMI-shaped: short conversational utterances
+        ln = int(np.clip(1 + rs.poisson(7), 1, 60))
+        base = [rnd.choice(words) for _ in range(ln)]
         hyps = []
         for _ in range(n_hyp):
             h = list(base)
             for _ in range(rnd.randint(0, 3)):
                 h[rnd.randrange(len(h))] = rnd.choice(words)
             hyps.append(" ".join(h))
+            ntok += len(h) + 1  # + the sentence end the scorer appends
         nbest["utt%04d" % u] = hyps
+    return nbest, vocab, ntok
+
+
+def cli_leg(dev, args, headline_ms):
+    """What a user of `python -m bayeslms_amd.train` sees: the CLI's own `ms/batch` log value on a synthetic corpus
+    written to disk in the reference's file format (words.txt, train/valid/test.txt), the headline configuration."""
+    import tempfile
+    from bayeslms_amd import train as TR
+    from bayeslms_amd.data import synthetic_corpus
+    nb = 45  # batches of the one epoch: log lines after 20 and 40
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "words.txt"), "w") as f:
+            f.write("<s> 0\n<unk> 1\n" + "".join("w%d %d\n" % (i, i) for i in range(2, V)))
+        for split, n, seed in (("train", B_PER_GPU * (nb * T + 1), 1111), ("valid", 20 * (2 * T + 1), 2222), ("test", 20 * (2 * T + 1), 3333)):
+            ids = synthetic_corpus(V, n, seed=seed).tolist()
+            with open(os.path.join(d, split + ".txt"), "w") as f:
+                line = []
+                for t in ids:
+                    if t == 0:
+                        f.write(" ".join(line) + "\n")
+                        line = []
+                    else:
+                        line.append("w%d" % t)
+                f.write(" ".join(line) + "\n")
+        hist = {}
+        argv = ["--data", d, "--cuda", "--model", "Transformer", "--emsize", str(D_MODEL), "--nhid", str(D_FF), "--nlayers",
+                str(NLAYERS), "--nhead", str(NHEAD), "--lr", str(LR), "--dropout", str(DROPOUT), "--seq_len", str(T), "--clip",
+                str(CLIP), "--batch-size", str(B_PER_GPU), "--epochs", "1", "--uncertainty", "Bayesian", "--T_bayes_pos", "FFN",
+                "--tied", "--log-interval", "20", "--save", os.path.join(d, "model.pt")]
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            TR.main(argv, history=hist)
+    ms = hist["ms_per_batch"][-1]  # the second interval: batches 21-40 (the first contains lazy initialisation)
+    return {"config": "python -m bayeslms_amd.train, the headline configuration on a synthetic corpus in the reference's file "
+                      "format: the CLI's own `ms/batch` log value (second log interval of 20 batches)",
+            "value": round(ms, 3), "unit": "ms/batch", "tokens_per_s": round(B_PER_GPU * T / ms * 1e3, 1),
+            "bench_ms_per_step": round(headline_ms, 3), "ratio_to_bench_step": round(ms / headline_ms, 4),
+            "valid_loss": round(hist["valid_loss"][-1], 4)}
+
+
+def search_leg(kind, dev, steps=8, warm=3):
+    """Architecture-search window (Architect.step on a validation window + network step) at the
+    reference's full sizes, under this run's clock (tools/bench_search.py is the stand-alone form)."""
+    import types
+    from bayeslms_amd import engine, model_search_bayes as S, train_search_bayes as TS
+    from bayeslms_amd.architect import Architect
+    from bayeslms_amd.model import repackage_hidden
+    torch.manual_seed(11)
+    if kind == "tlm":
+        Ts = T
+        m = S.GaussTransModelSearch(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, True).to(dev)
+        a = types.SimpleNamespace(model="Transformer", T_bayes_pos="FFN", uncertainty="none", L_bayes_pos=0)
+    else:
+        Ts = 35
+        m = S.BayesLSTMModelSearch("LSTM", V, 1024, 1024, 2, DROPOUT, True).to(dev)
+        a = types.SimpleNamespace(model="LSTM", T_bayes_pos="none", uncertainty="none", L_bayes_pos=1)
+    TS.freeze_unused(a, m)
+    kl_fn = TS.kl_selector(a)
+    arch = Architect(m, V, types.SimpleNamespace(wdecay=5e-7, clip=1.0, arch_lr=3e-3, arch_wdecay=1e-3))
+    tr = engine.Trainer(m, lr=0.1, clip=1.0, kl_scale=Ts / 65536.0, weight_decay=TS.SGD_WEIGHT_DECAY)
+    data = torch.randint(0, V, (Ts + 1, B_PER_GPU), device=dev)
+    x, y = data[:Ts], data[1:].reshape(-1)
+    hidden = m.init_hidden(B_PER_GPU) if kind == "lstm" else None
+    hv = m.init_hidden(B_PER_GPU) if kind == "lstm" else None
+    for s_ in range(warm + steps):
+        if s_ == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        m.train()
+        m.set_step(2 * s_ + 1)
+        arch.step(x, y, x, y, None, False, hv)
+        if kind == "tlm":
+            for layer in m.transformerlayers:
+                layer.gpnn.sample = True
+        else:
+            hidden = repackage_hidden(hidden)
+        _, _, hidden = tr.step(x, y, hidden, kl_fn, philox_step=2 * s_)
+        if kind == "tlm":
+            for layer in m.transformerlayers:
+                layer.gpnn.sample = False
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    name = ("GaussTransModelSearch 6L d=512 ff=4096 V=33000, T 128, B 64" if kind == "tlm"
+            else "BayesLSTMModelSearch E=H=1024 V=33000, T 35, B 64")
+    return {"config": "architecture search (train_search_bayes.py), %s: one window = Architect.step + network step" % name,
+            "value": round(Ts * B_PER_GPU / dt, 1), "unit": "tokens/s", "ms_per_window": round(1e3 * dt, 3), "windows": steps}
+
+
+def extra_configs(dev, args, engine, M, ops, headline_ms):
+    """Reported AFTER the headline, never part of `value`: the other BASELINE.json configurations that fit one GPU, the
+    reference recipes' own shape (run_nnlm_ami_{tm,lstm}.sh: --seq_len 100 --batch-size 32), evaluation, the CLI, n-best
+    rescoring and the architecture search, all under the same clock as the headline run.  fp32, same Trainer step,
+    synthetic data; every training / evaluation leg carries `step_roofline` = SURVEY 8(d) model FLOPs per token x
+    tokens/s against the fp32 MFMA peak."""
+    from types import SimpleNamespace
+    from collections import OrderedDict
+    from bayeslms_amd import compute_sentence_scores as css, train as TR
+    res = []
+    ns = lambda **k: SimpleNamespace(**{**dict(model="Transformer", uncertainty="none", T_bayes_pos="none", L_bayes_pos=0,  # noqa: E731
+                                               T_gauss_pos=3, L_gauss_pos="00", L_v_pos="11", T_v_pos=0), **k})
+    steps = max(args.steps, 5)
+    floor_us = lambda Bc: 2.0 * Bc * 4096 * 1024 / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6  # noqa: E731
+
+    def lstm_steps(r, kt, Tl, Bc):
+        fwd = kt.get("lstm_seq_fwd T=%d" % Tl, {}).get("avg_ms")
+        bwd = kt.get("lstm_seq_bwd T=%d" % Tl, {}).get("avg_ms")
+        r.update({"lstm_step_fwd_us": None if fwd is None else round(1e3 * fwd / Tl, 2),
+                  "lstm_step_bwd_us": None if bwd is None else round(1e3 * bwd / Tl, 2),
+                  "lstm_step_mfma_floor_us": round(floor_us(Bc), 2),
+                  "lstm_step_fwd_frac_of_floor": None if fwd is None else round(floor_us(Bc) / (1e3 * fwd / Tl), 3)})
+    # --- configs[0]: 2-layer 1024-hidden standard LSTM LM, V 10k, batch 20, seq_len 35 (the reference's CPU-runnable case)
+    torch.manual_seed(1111)
+    m = M.RNNModel("LSTM", 10000, 1024, 1024, 2, DROPOUT, True).to(dev)
+    r, kt = _train_leg(m, None, 35, 20, 1.0, 2 * steps, max(args.warmup, 20), dev, engine, ops, timed_tags=True, vocab=10000,
+                       flops_per_token=lstm_flops_per_token(10000))
+    r["config"] = ("BASELINE.json configs[0]: 2-layer 1024-hidden standard LSTM LM (--uncertainty none) tied, V=10000, batch 20, "
+                   "seq_len 35, dropout 0.2, clip 1.0, SGD momentum 0.9")
+    lstm_steps(r, kt, 35, 20)
+    if not args.no_cpu_baseline:
+        try:
+            r["cpu_baseline"] = lstm_cpu_baseline()
+        except Exception as e:  # noqa: BLE001
+            r["cpu_baseline"] = {"error": repr(e)}
+    res.append(r)
+    del m
+    # --- configs[1]: Bayesian LSTM LM (--uncertainty Bayesian --L_bayes_pos 3), 2x1024, B 64, T 35, V 33k
+    torch.manual_seed(1111)
+    m = M.BayesRNNModel("LSTM", V, 1024, 1024, 2, DROPOUT, True, 3).to(dev)
+    kl_lstm = TR.kl_selector(ns(model="LSTM", uncertainty="Bayesian", L_bayes_pos=3))
+    r, kt = _train_leg(m, kl_lstm, 35, B_PER_GPU, 1.0, 2 * steps, max(args.warmup, 20), dev, engine, ops, timed_tags=True,
+                       flops_per_token=lstm_flops_per_token(V))
+    r["config"] = ("BASELINE.json configs[1]: Bayesian LSTM LM (--uncertainty Bayesian --L_bayes_pos 3) 2x1024 tied, "
+                   "V=33000, batch 64, seq_len 35, dropout 0.2, clip 1.0, SGD momentum 0.9")
+    lstm_steps(r, kt, 35, B_PER_GPU)
+    res.append(r)
+    # the reference recipe's own shape (run_nnlm_ami_lstm.sh:24,100: --seq_len 100 --batch-size 32)
+    r, kt = _train_leg(m, kl_lstm, 100, 32, 1.0, steps, max(args.warmup, 8), dev, engine, ops, timed_tags=True,
+                       flops_per_token=lstm_flops_per_token(V))
+    r["config"] = ("recipe shape (run_nnlm_ami_lstm.sh: --seq_len 100 --batch-size 32): Bayesian LSTM LM --L_bayes_pos 3, 2x1024 "
+                   "tied, V=33000")
+    lstm_steps(r, kt, 100, 32)
+    res.append(r)
+    e = _eval_leg(m, 35, dev, engine, V, lstm_flops_per_token(V, train=False))
+    e["config"] = "evaluate() (train.py:441-458), the configs[1] LSTM, eval batch 20, seq_len 35, mean weights"
+    res.append(e)
+    # LSTM 20-best rescoring (mean weights; the carried state makes it the latency-bound scorer)
+    n_utt, n_hyp = 1000, 20
+    nbest, vocab, ntok = synthetic_nbest(n_utt, n_hyp, V)
     sub = OrderedDict(list(nbest.items())[:8])
 
-    def hyp_rate(model, mtype, mc):
+    def hyp_rate(model, mtype, mc, fl):
         css.compute_scores_batched(sub, model, vocab, mtype, dev, mc_samples=mc)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         css.compute_scores_batched(nbest, model, vocab, mtype, dev, mc_samples=mc)
         torch.cuda.synchronize()
-        return round(n_utt * n_hyp / (time.perf_counter() - t0), 1)
-    res.append({"config": "n-best rescoring with the configs[1] LSTM: %d utterances x %d-best, mean weights, hidden state carried "
-                          "across utterances (compute_sentence_scores --batched)" % (n_utt, n_hyp),
-                "value": hyp_rate(m, "LSTM", 0), "unit": "hypotheses/s"})
+        el = time.perf_counter() - t0
+        return {"value": round(n_utt * n_hyp / el, 1), "unit": "hypotheses/s", "tokens_per_s": round(ntok / el, 1),
+                "step_roofline": _frac(fl * max(mc, 1), ntok / el)}
+    wl = "%d utterances x %d-best, lengths 1 + Poisson(7) clipped to [1, 60] (SURVEY 8(d))" % (n_utt, n_hyp)
+    r = hyp_rate(m, "LSTM", 0, lstm_flops_per_token(V, train=False))
+    r["config"] = ("n-best rescoring with the configs[1] LSTM: %s, mean weights, hidden state carried across utterances "
+                   "(compute_sentence_scores --batched)" % wl)
+    res.append(r)
+    del m
+    torch.cuda.empty_cache()
+    # --- the reference recipe's own Transformer shape (run_nnlm_ami_tm.sh:22,98-99: --seq_len 100 --batch-size 32)
+    torch.manual_seed(1111)
+    m = M.BayesTransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, True, "FFN").to(dev)
+    r, _ = _train_leg(m, TR.kl_selector(ns(uncertainty="Bayesian", T_bayes_pos="FFN")), 100, 32, LR, steps, args.warmup, dev, engine,
+                      ops, flops_per_token=tlm_flops_per_token(100))
+    r["config"] = ("recipe shape (run_nnlm_ami_tm.sh: --seq_len 100 --batch-size 32): Bayesian Transformer LM --T_bayes_pos FFN, "
+                   "6L d_model=512 d_ff=4096 V=33000")
+    res.append(r)
+    e = _eval_leg(m, T, dev, engine, V, tlm_flops_per_token(T, train=False))
+    e["config"] = "evaluate() (train.py:441-458), the headline Transformer, eval batch 20, seq_len 128, mean weights"
+    res.append(e)
+    r = hyp_rate(m, "Transformer", 0, tlm_flops_per_token(8, train=False))
+    r["config"] = "configs[4] n-best rescoring, Bayesian Transformer-FFN, %s, mean weights" % wl
+    res.append(r)
+    r = hyp_rate(m, "Transformer", 8, tlm_flops_per_token(8, train=False))
+    r["config"] = ("configs[4] n-best rescoring, Bayesian Transformer-FFN, %s, 8 Monte-Carlo weight samples "
+                   "(score = -log mean_s exp(-NLL_s), oracle-checked)" % wl)
+    res.append(r)
     del m
     torch.cuda.empty_cache()
     # --- configs[4] training leg: GP Transformer (--uncertainty Gaussian --T_gauss_pos 3), cfg3 shape
     torch.manual_seed(1111)
     m = M.GaussTransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, True, 3).to(dev)
     r, _ = _train_leg(m, TR.kl_selector(ns(uncertainty="Gaussian", T_gauss_pos=3)), T, B_PER_GPU, LR, steps, args.warmup, dev,
-                      engine, ops)
+                      engine, ops, flops_per_token=tlm_flops_per_token(T))
     r["config"] = ("BASELINE.json configs[4] training leg on 1 GPU: GP Transformer LM (--uncertainty Gaussian --T_gauss_pos 3) 6L "
                    "d_model=512 d_ff=4096 V=33000, seq_len 128, batch 64")
     res.append(r)
-    res.append({"config": "configs[4] n-best rescoring, GP Transformer, %d x %d-best, mean weights (the reference's inference: "
-                          "GPNN.sample is never raised)" % (n_utt, n_hyp),
-                "value": hyp_rate(m, "Transformer", 0), "unit": "hypotheses/s"})
+    r = hyp_rate(m, "Transformer", 0, tlm_flops_per_token(8, train=False))
+    r["config"] = ("configs[4] n-best rescoring, GP Transformer, %s, mean weights (the reference's inference: GPNN.sample is "
+                   "never raised)" % wl)
+    res.append(r)
     del m
     torch.cuda.empty_cache()
-    # --- configs[4] inference leg with Monte-Carlo weight samples: needs a model whose weights ARE sampled
-    torch.manual_seed(1111)
-    m = M.BayesTransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, True, "FFN").to(dev)
-    res.append({"config": "configs[4] n-best rescoring, Bayesian Transformer-FFN, %d x %d-best, mean weights" % (n_utt, n_hyp),
-                "value": hyp_rate(m, "Transformer", 0), "unit": "hypotheses/s"})
-    res.append({"config": "configs[4] n-best rescoring, Bayesian Transformer-FFN, %d x %d-best, 8 Monte-Carlo weight samples "
-                          "(score = -log mean_s exp(-NLL_s), oracle-checked)" % (n_utt, n_hyp),
-                "value": hyp_rate(m, "Transformer", 8), "unit": "hypotheses/s"})
-    del m
-    torch.cuda.empty_cache()
+    # --- the CLI itself, and the architecture search (SURVEY 8(f)3)
+    for name, fn in (("cli", lambda: cli_leg(dev, args, headline_ms)), ("search_tlm", lambda: search_leg("tlm", dev)),
+                     ("search_lstm", lambda: search_leg("lstm", dev))):
+        try:
+            res.append(fn())
+        except Exception as e:  # noqa: BLE001
+            res.append({"config": name, "error": repr(e)})
+        torch.cuda.empty_cache()
     return res
 
 
@@ -401,16 +632,20 @@ def main():
         M_, N_, K_ = T * Bc, D_MODEL, D_FF
         flops = 2.0 * M_ * N_ * K_  # 2*M*N*K per forward launch
         roof = None
-        traffic = None  # HBM bytes per launch from the PMC passes committed under profiles/ (not collected live)
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_sampled_gemm_fwd.json")
+        # HBM bytes per launch: NOT collected in this run -- PMC counters need their own rocprofv3 passes (tools/profile_round.sh);
+        # the value is read from the summary committed under profiles/ and the line says so (`traffic_source`)
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
         if os.path.exists(pmc) and Bc == B_PER_GPU and not model.noise_state.fused:
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+            traffic_src = "profiles/" + PMC_TRAFFIC_FILE + " (separate rocprofv3 --pmc passes of this command, not collected live)"
         if "sampled_gemm_fwd" in kt:
             ms = kt["sampled_gemm_fwd"]["avg_ms"]
             ach = flops / (ms * 1e-3) / 1e12
             roof = {"kernel": "gemm_f32_kernel (Bayesian FFN linear2 forward, M=%d N=%d K=%d)" % (M_, N_, K_),
                     "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes": 4 * (M_ * K_ + N_ * K_ + M_ * N_),
                     "avg_launch_ms": round(ms, 4), "launches": kt["sampled_gemm_fwd"]["n"]}
         out = {
             "metric": "train_tokens_per_sec", "value": round(tokens / elapsed, 1), "unit": "tokens/s",
@@ -465,7 +700,7 @@ def main():
             try:  # extras must never cost the headline line
                 del tr, model
                 torch.cuda.empty_cache()
-                out["extra_configs"] = extra_configs(dev, args, engine, M, ops)
+                out["extra_configs"] = extra_configs(dev, args, engine, M, ops, out["ms_per_step"])
             except Exception as e:  # noqa: BLE001
                 out["extra_configs"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

@@ -257,6 +257,25 @@ def rnn_lm(x, hidden, sd):
     return logits, (torch.stack(hs), torch.stack(cs))
 
 
+def rnn_lm_train(x, hidden, sd, p):
+    """RNNModel.forward in training mode (model.py:61-66 with nn.LSTM(dropout=p), :35): dropout (torch's generator) on
+    the embeddings, between the LSTM layers and on the output.  Used for the CPU baseline timing of BASELINE configs[0]."""
+    y = F.dropout(F.embedding(x, sd["encoder.weight"]), p, True)
+    h0, c0 = hidden
+    hs, cs = [], []
+    layer = 0
+    while "rnn.weight_ih_l%d" % layer in sd:
+        if layer > 0:
+            y = F.dropout(y, p, True)
+        y, h, c = lstm_layer(y, h0[layer], c0[layer], sd["rnn.weight_ih_l%d" % layer], sd["rnn.weight_hh_l%d" % layer],
+                             sd["rnn.bias_ih_l%d" % layer], sd["rnn.bias_hh_l%d" % layer])
+        hs.append(h)
+        cs.append(c)
+        layer += 1
+    logits = F.linear(F.dropout(y, p, True), sd["decoder.weight"], sd["decoder.bias"])
+    return logits, (torch.stack(hs), torch.stack(cs))
+
+
 def kl_bayes2lstm(sd, pre, pos):
     """Bayes2LSTM.kl_divergence (model.py:734-765).  pos 1..4: layer-1 tensors only; weights and
     biases each get their own mean.  pos 5 (:746-755, as written): layer 1's [hh|ih] plus

@@ -629,6 +629,26 @@ def f5_gauss_variational_rnn():
         save("vtransformer_%d" % v_pos, src=npy(src), nhead=np.int64(4), logits_eval=npy(out), **pack_sd(m))
 
 
+def f5_vtransformer_11():
+    """`--T_v_pos 11`, the literal flag of BASELINE.json configs[4] (README.md:85-93 writes the option as 00/01/10/11):
+    model.py:2822-2843 handles 0..3 only, so the int 11 builds ZERO encoder layers -- embedding * sqrt(d) + positional
+    table straight into the tied decoder.  Eval logits, and one train-mode step (dropout 0: RNG-free) with every gradient."""
+    torch.manual_seed(82)
+    m = ref.VTransformerModel(50, 16, 4, 32, 4, 0.0, True, 11)
+    assert len(m.transformerlayers) == 0
+    src = torch.randint(0, 50, (6, 3))
+    tgt = torch.randint(0, 50, (18,))
+    m.eval()
+    with torch.no_grad():
+        out = m(src)
+    m.train()
+    lt = m(src)
+    mle = torch.nn.functional.cross_entropy(lt.view(-1, 50), tgt)
+    mle.backward()
+    save("vtransformer_11", src=npy(src), tgt=npy(tgt), nhead=np.int64(4), logits_eval=npy(out), logits_train=npy(lt),
+         mle=npy(mle), **pack_sd(m), **grads(m))
+
+
 def f5_gauss_rnn_gpnn2():
     """--L_gauss_pos with type digit 4: GPNN2 inside the GP-LSTM cells (model.py:1698-1702, 1763-1770).
     Every GPNN2 call of the time loop draws fresh frequencies in train mode; layer 0 runs all its steps
@@ -878,6 +898,9 @@ if __name__ == "__main__":
         f9_search_models()
         f9_search_loop()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "vt11":
+        f5_vtransformer_11()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "rnn_gpnn2":
         f5_gauss_rnn_gpnn2()
         sys.exit(0)
@@ -916,3 +939,4 @@ if __name__ == "__main__":
     f9_search_loop()
     f9_search_bayes_tlm()
     f6_train_trajectory()
+    f5_vtransformer_11()

@@ -704,6 +704,32 @@ def test_vtransformer_golden(dev, v_pos):
             m(torch.zeros(100, 1, dtype=torch.long, device=dev))
 
 
+def test_vtransformer_11_golden(dev):
+    """`--uncertainty Variational --T_v_pos 11`, the literal flags of BASELINE configs[4]: zero encoder layers
+    (model.py:2822-2843).  Eval logits, train-mode loss and every gradient against the reference's fixture."""
+    from bayeslms_amd import model as M, ops
+    g, sd, grad = load_golden("vtransformer_11")
+    V, d = sd["encoder.weight"].shape
+    m = M.VTransformerModel(V, d, int(g["nhead"]), 32, 4, 0.0, True, 11).to(dev)
+    assert len(m.transformerlayers) == 0
+    with torch.no_grad():
+        load_sd(m, sd)
+    m.eval()
+    with torch.no_grad():
+        assert rel(m(g["src"].to(dev)), g["logits_eval"]) < TOL
+    m.train()
+    lt = m(g["src"].to(dev))
+    assert rel(lt, g["logits_train"]) < TOL
+    mle, _ = ops.cross_entropy(lt.view(-1, V), g["tgt"].to(dev))
+    assert abs(float(mle) - float(g["mle"])) < TOL * abs(float(g["mle"]))
+    mle.backward()
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or k not in grad:
+            continue
+        assert p.grad is not None, k
+        assert grad_close(p.grad, grad[k]), k
+
+
 def test_full_size_cfg3_model_against_oracle(dev):
     """BASELINE.json configs[2] at its real dimensions (6L, d 512, ff 4096, 8 heads, V 33000, T 128;
     2 batch columns so the CPU oracle finishes in seconds): eval NLL and one train-mode loss +

@@ -366,6 +366,32 @@ def test_vtransformer_matches_reference(v_pos):
     assert nl == {0: 4, 1: 4, 2: 3, 3: 3}[v_pos]  # the reference's layer-count arithmetic (model.py:2822-2843)
 
 
+def test_vtransformer_11_builds_zero_layers_like_the_reference():
+    """`--T_v_pos 11` (the literal flag of BASELINE configs[4]): model.py:2822-2843 builds no encoder layer at all."""
+    g, sd, grad = load_golden("vtransformer_11")
+    assert not any(k.startswith("transformerlayers.") for k in sd)
+    torch.testing.assert_close(O.transformer_lm(g["src"], sd, int(g["nhead"]), None), g["logits_eval"], **TOL)
+    leaf = {k: v.clone().requires_grad_(v.dtype.is_floating_point and k != "pos_encoder.pe") for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    lt = O.transformer_lm(g["src"], leaf, int(g["nhead"]), None)
+    torch.testing.assert_close(lt, g["logits_train"], **TOL)
+    mle = O.cross_entropy_mean(lt, g["tgt"])
+    torch.testing.assert_close(mle, g["mle"], **TOL)
+    mle.backward()
+    for k, gv in grad.items():
+        if k != "decoder.weight":
+            torch.testing.assert_close(leaf[k].grad, gv, rtol=2e-4, atol=2e-6, msg=lambda m, k=k: k + ": " + m)
+    # the engine's class and the CLI dispatch build the same thing: same state-dict keys and shapes, no layers
+    from bayeslms_amd import model as M, train as T
+    m = M.VTransformerModel(50, 16, 4, 32, 4, 0.0, True, 11)
+    assert len(m.transformerlayers) == 0
+    shapes = lambda d: {k: tuple(v.shape) for k, v in d.items() if k != "pos_encoder.pe"}  # noqa: E731 (fixtures keep 64 rows of the table)
+    assert shapes(m.state_dict()) == shapes(sd) and "pos_encoder.pe" in m.state_dict()
+    a = T.build_parser().parse_args("--model Transformer --uncertainty Variational --T_v_pos 11 --emsize 16 --nhid 32 --nlayers 4 "
+                                    "--nhead 4 --tied".split())
+    assert len(T.build_model(a, 50).transformerlayers) == 0 and T.kl_selector(a) is None
+
+
 def _nbest_of(g):
     import collections
     nbest = collections.OrderedDict()
