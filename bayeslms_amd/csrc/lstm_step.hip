@@ -102,7 +102,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
   // + a scalar offset for the wave's K slice and the chunk: a chunk step costs no vector instruction (hipcc turns
   // base + zext(offset) of a plain pointer into 64-bit vector adds once the offsets are hoisted out of the loop)
   const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.hprev), 0, (int)(4u * (uint32_t)B * (uint32_t)H), 0x00020000);
+#ifdef BLM_LSTM_PROF
+  // timing-only alias 3: a zero-length descriptor -- every W_hh load returns 0 without touching memory, i.e. the upper bound of
+  // what taking the W fetch off the h_t -> h_{t+1} chain (prefetch before h arrives) could buy
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.whh), 0, p.alias == 3 ? 0 : (int)(4u * NS * (uint32_t)H * (uint32_t)H), 0x00020000);
+#else
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.whh), 0, (int)(4u * NS * (uint32_t)H * (uint32_t)H), 0x00020000);  // < 4 GB (host check)
+#endif
   const int kb4 = __builtin_amdgcn_readfirstlane(kbase * 4);
   uint32_t aoff[8], woff[8];
 #pragma unroll

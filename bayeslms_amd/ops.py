@@ -1207,11 +1207,16 @@ def _side_stream():
     return _SIDE_STREAM
 
 
+_STACK_CHUNK = int(os.environ.get("BLM_LSTM_WAVE_CHUNK", "0"))  # A/B knob: steps per wavefront chunk (0: the rule below)
+
+
 def _stack_chunks(T):
     """Time chunks of the layer wavefront: layer 2 runs one chunk behind layer 1.  Small enough that the lag is a
     small part of T, large enough that the per-chunk input GEMM (M = chunk * B rows) and the host's event traffic stay
     cheap."""
     c = min(32, max(4, (T + 7) // 8))
+    if _STACK_CHUNK > 0:
+        c = _STACK_CHUNK
     return [(t0, min(T, t0 + c)) for t0 in range(0, T, c)]
 
 
@@ -1365,23 +1370,34 @@ class _LSTMStack2(torch.autograd.Function):
 
 
 def lstm_stack2_ok(x, w_hh1, w_hh2, w_ih2):
-    """Shapes the layer wavefront takes: fused step kernels (H % 32 == 0, aligned, contiguous) and equal hidden sizes."""
+    """Shapes the layer wavefront takes: fused step kernels (H % 32 == 0, aligned, contiguous) and equal hidden sizes --
+    and, unless it was switched on or off explicitly, the shapes it PAYS for (see below)."""
     T, B, _ = x.shape
     H = w_hh1.shape[1]
-    return (T >= 8 and H % 32 == 0 and w_hh2.shape[1] == H and w_ih2.shape[1] == H and w_hh1.is_contiguous() and w_hh2.is_contiguous()
-            and w_hh1.data_ptr() % 16 == 0 and w_hh2.data_ptr() % 16 == 0 and (B * H) % 4 == 0 and _STACK2_ON)
+    if _STACK2_ON is None:
+        on = B <= 32 and T >= 64
+    else:
+        on = _STACK2_ON
+    return (on and T >= 8 and H % 32 == 0 and w_hh2.shape[1] == H and w_ih2.shape[1] == H and w_hh1.is_contiguous() and w_hh2.is_contiguous()
+            and w_hh1.data_ptr() % 16 == 0 and w_hh2.data_ptr() % 16 == 0 and (B * H) % 4 == 0)
 
 
-# Measured at cfg2 (T 35, B 64, H 1024; rocprofv3 trace + tools/bench_lstm.py): the chains do overlap (16-18 us per step PAIR),
-# but layer 2's per-chunk input GEMM (M = 320 rows: 36-46 us at 67 TF, against 70 us for ONE batched GEMM over all T) and the
-# one-chunk lag give the gain back: forward 935 us against 862 us, backward 1001 against 1008 us.  Off by default.
-_STACK2_ON = False
+# When does the wavefront pay?  A fused step kernel launches ceil(B / 32) * H / 8 workgroups (forward) -- at B <= 32 and
+# H = 1024 that is 128, HALF the chip -- and is bound by its launch -> load -> MFMA -> store latency chain, so two of them
+# side by side cost what one does.  Measured (tools/run_workload.py, same box, off / on):
+#   recipe shape (run_nnlm_ami_lstm.sh: T 100, B 32): 11.07 -> 9.96 ms per training step (289 k -> 321 k tokens/s);
+#   cfg2 (T 35, B 64: the kernels fill the chip, layer 2's per-chunk input GEMM of M = 320 rows and the one-chunk lag give the
+#   overlap back): 6.67 -> 6.75 ms;  cfg1 (T 35, B 20): 2.29 -> 2.30 ms.
+# Rule: on for B <= 32 and T >= 64; BLM_LSTM_WAVEFRONT=0|1 / set_lstm_wavefront(True | False) force it, None = rule.
+_env_wf = os.environ.get("BLM_LSTM_WAVEFRONT")
+_STACK2_ON = None if _env_wf is None else _env_wf == "1"
 
 
 def set_lstm_wavefront(on):
-    """True: two-layer LSTM stacks run as a wavefront on two streams (ops.lstm_stack2); default off (see above)."""
+    """True / False: two-layer LSTM stacks always / never run as a wavefront on two streams (ops.lstm_stack2); None: by the
+    measured rule above."""
     global _STACK2_ON
-    _STACK2_ON = bool(on)
+    _STACK2_ON = None if on is None else bool(on)
 
 
 def lstm_stack2(x, h0, c0, layer1, layer2, drop=NO_DROP):

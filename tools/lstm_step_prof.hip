@@ -12,7 +12,7 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int RING, bool REFILL, int NW, bool PIPE = false>
+template <int RING, bool REFILL, int NW, bool PIPE = false, bool TAIL = true>
 static void run(const char* name, int B, int H, int alias = 0) {
   const int steps = 64;
   float *xw, *w, *h[2], *c[2], *ga;
@@ -28,7 +28,7 @@ static void run(const char* name, int B, int H, int alias = 0) {
   CK(hipMalloc(&prof, per * steps * 8));
   CK(hipMemset(prof, 0, per * steps * 8));
   const size_t lds = (size_t)NW * WAVE_LDS * sizeof(float);
-  auto kern = lstm_step_fwd_kernel<RING, 4, REFILL, NW, PIPE>;
+  auto kern = lstm_step_fwd_kernel<RING, 4, REFILL, NW, PIPE, TAIL>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipStream_t st;
   CK(hipStreamCreate(&st));
@@ -70,5 +70,10 @@ int main() {
   run<2, false, 8>("8 waves ring 2 all   ", 64, 1024);
   run<2, true, 4>("4 waves ring 2, W aliased (L2-hot)      ", 64, 1024, 1);
   run<2, true, 4>("4 waves ring 2, W and h aliased (L2-hot)", 64, 1024, 2);
+  // the production form (pipelined, no-tail), and the upper bound of hiding the W fetch: W loads return 0 without memory access
+  run<2, true, 4, true, false>("PIPED no-tail (production)              ", 64, 1024);
+  run<2, true, 4, true, false>("PIPED no-tail, W loads cost nothing     ", 64, 1024, 3);
+  run<2, true, 4, true, false>("PIPED no-tail, B = 32                   ", 32, 1024);
+  run<2, true, 4, true, false>("PIPED no-tail, B = 32, W loads free     ", 32, 1024, 3);
   return 0;
 }
