@@ -203,7 +203,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
     const long o = (long)eb * NS * H + ej;
 #pragma unroll
     for (int g = 0; g < NS; ++g) xg[g] = p.xw[o + (long)g * H];
-    cprev = p.cprev[(long)eb * H + ej];
+    // ovr 5 (GPLSTMCell gate type 5, model.py:1759-1760): the cell state enters through the GPNN -- zsave holds
+    // c_{t-1} Wg^T (blm_lstm_step_dh, launched before this step); + bias -> z, kept for the backward pass
+    cprev = p.ovr == 5 ? p.zsave[(long)eb * H + ej] + p.rbias[ej] : p.cprev[(long)eb * H + ej];
   }
   if constexpr (PIPE) {
     static_assert(RING == 2 && NBUF == 1, "the pipelined loop walks chunk pairs through one staging tile");
@@ -379,6 +381,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
         s[g] = xg[g] + v;
       }
       float gi = sigmoidf_(s[0]), gf = sigmoidf_(s[1]), gg = tanhf(s[2]), go = sigmoidf_(s[3]);
+      if (p.ovr == 5) {  // wave-uniform: c_in = mixture(z)
+        p.zsave[i] = cprev;
+        cprev = gp_mix(cprev, p.coef, H, ej);
+      }
       if (p.ovr >= 0 && p.ovr < 4) {  // wave-uniform
         const float z = p.ovr == 0 ? s[0] : (p.ovr == 1 ? s[1] : (p.ovr == 2 ? s[2] : s[3]));
         const float a = gp_mix(z, p.coef, H, ej);
@@ -583,7 +589,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
     if (p.dc_next) e_dcn = p.dc_next[ei];
     e_cp = p.cprev[ei];
     e_c = p.c[ei];
-    if (p.ovr >= 0 && p.ovr < 4) e_z = p.zprev[ei];
+    if ((p.ovr >= 0 && p.ovr < 4) || p.ovr == 5) e_z = p.zprev[ei];
     if (p.ovr == 4) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) e_z4[g] = p.zprev[eo + (long)g * H];
@@ -729,6 +735,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
           (red[(6 * 16 + brow) * BRSTR + ecol] + red[(7 * 16 + brow) * BRSTR + ecol]);
   if (p.dh_out) p.dh_out[ei] = dh;
   if (p.dg_out) {  // cell backward of the step that produced h_{t-1} (elementwise.hip lstm_cell_bwd_kernel)
+    if (p.ovr == 5) e_cp = gp_mix(e_z, p.coef, H, ek);  // gate type 5: the cell saw the GPNN mixture of z = c_{t-2} Wg^T + b
     const float gi = e_g[0], gf = e_g[1], gg = e_g[2], go = e_g[3];
     const float tc = tanhf(e_c);
     const float dhv = dh + e_dy;
@@ -752,6 +759,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
       p.dz_out[eo + 3L * H] = o3 * dgp_mix(e_z4[3], p.coef, 4 * H, 3 * H + ek);
     }
     p.dc_prev[ei] = dc * gf;
+    if (p.ovr == 5) {  // d mixture value (for the coefficient gradient) and d z (the A operand of the next dc product)
+      p.dact_out[ei] = dc * gf;
+      p.dz_out[ei] = dc * gf * dgp_mix(e_z, p.coef, H, ek);
+    }
   }
 }
 
@@ -827,8 +838,8 @@ extern "C" int blm_lstm_step_fwd(const float* xw_t, const float* w_hh, const flo
 extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const float* h_prev, const float* c_prev, float* h,
                                     float* c, float* gates_act, const float* h_noise, int gate_ovr, const float* coef4,
                                     const float* rbias, float* z_out, int B, int H, void* stream) {
-  if (!xw_t || !w_hh || !h_prev || !c_prev || !h || !c || B < 0 || H < 0 || gate_ovr > 4 || (gate_ovr >= 0 && !coef4) ||
-      (gate_ovr == 4 && !rbias))
+  if (!xw_t || !w_hh || !h_prev || !c_prev || !h || !c || B < 0 || H < 0 || gate_ovr > 5 || (gate_ovr >= 0 && !coef4) ||
+      (gate_ovr >= 4 && !rbias) || (gate_ovr == 5 && !z_out))
     return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_fwd: bad arguments");
   if ((long)B * H == 0) return BLM_OK;
   if (H % 32 != 0 || !al16(w_hh) || !al16(h_prev) || 16.0 * H * H >= 4294967296.0 || 4.0 * B * H >= 4294967296.0)  // 32-bit byte offsets
@@ -965,8 +976,9 @@ extern "C" int blm_lstm_step_bwd_gp(const float* dgates_t, const float* w_hh_t, 
                                     float* dc_prev, float* dh_out, int gate_ovr, const float* coef4, const float* z_prev,
                                     float* dact_out, float* dz_out, int B, int H, void* stream) {
   if (!dgates_t || !w_hh_t || B < 0 || H < 0 || (!dgates_out && !dh_out) ||
-      (dgates_out && (!c_prev || !c || !gates_act || !dc_prev)) || gate_ovr > 4 ||
-      (dgates_out && gate_ovr >= 0 && (!coef4 || !z_prev)) || (dgates_out && gate_ovr == 4 && !dz_out))
+      (dgates_out && (!c_prev || !c || !gates_act || !dc_prev)) || gate_ovr > 5 ||
+      (dgates_out && gate_ovr >= 0 && (!coef4 || !z_prev)) || (dgates_out && gate_ovr >= 4 && !dz_out) ||
+      (dgates_out && gate_ovr == 5 && !dact_out))
     return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_bwd: bad arguments");
   if ((long)B * H == 0) return BLM_OK;
   if (H % 32 != 0 || !al16(dgates_t) || !al16(w_hh_t))

@@ -940,6 +940,13 @@ class GPLSTMCell(_LoopCell):
                 xw = self.gpnn(inputs) + self.bias_ih
                 y, hT, cT = ops.lstm_recurrent_gp(xw, hx, cx, self.weights_hh)
             return y, (hT, cT)
+        if gt == 5 and self.hidden_size % 64 == 0 and ops.lstm_recurrent_gp_supported(self.hidden_size, self.weights_hh):
+            # the cell state enters every step through the GPNN (model.py:1759-1760): a second recurrent product
+            # c_{t-1} Wg^T per step, launched in front of the fused step kernel, which applies bias + mixture
+            xw = ops.linear(inputs, self.weights_ih, 2.0 * self.bias_ih)  # bias_ih enters on both sides, as in the reference
+            y, hT, cT = ops.lstm_recurrent_gp(xw, hx, cx, self.weights_hh, self.gpnn.coef4(), 5, self.gpnn.bias_mean,
+                                              self.gpnn.weights_mean)
+            return y, (hT, cT)
         # input-side projection of all steps in one GEMM (the reference does it per step)
         xw_all = self.gpnn(inputs) if gt == 7 else ops.linear(inputs, self.weights_ih, self.bias_ih)
         outs = []

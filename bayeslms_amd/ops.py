@@ -1417,11 +1417,12 @@ class _LSTMRecurrentGP(torch.autograd.Function):
       -1    plain recurrence on a given xw (gate type 7: xw is the GPNN of the inputs)."""
 
     @staticmethod
-    def forward(ctx, xw, h0, c0, w_rec, coef4, ovr, rbias):
+    def forward(ctx, xw, h0, c0, w_rec, coef4, ovr, rbias, w_cell=None):
         xw, w_rec = _f32(xw, "xw"), _f32(w_rec, "w_rec")
         ovr = int(ovr)
         coef4 = _f32(coef4, "coef4") if ovr >= 0 else None
-        rbias = _f32(rbias, "rbias") if ovr == 4 else None
+        rbias = _f32(rbias, "rbias") if ovr >= 4 else None
+        w_cell = _f32(w_cell, "w_cell") if ovr == 5 else None
         T, B, G = xw.shape
         H = G // 4
         dev = xw.device
@@ -1437,19 +1438,26 @@ class _LSTMRecurrentGP(torch.autograd.Function):
         zs_p = None if zs is None else _P(zs)
         w_p, co_p, rb_p = ptr(w_rec), ptr(coef4), ptr(rbias)
         step_fwd = lib().blm_lstm_step_fwd_gp
+        step_dh = lib().blm_lstm_step_dh
+        wc_p = ptr(w_cell)
         for t in range(T):
+            if ovr == 5:  # z_t = c_{t-1} Wg^T: the second recurrent product of the step, one skinny launch in front of it
+                check(step_dh(cs_p[t], wc_p, zs_p[t], B, H, H, st), "blm_lstm_step_dh")
             check(step_fwd(xw_p[t], w_p, hs_p[t], cs_p[t], hs_p[t + 1], cs_p[t + 1], ga_p[t], None, ovr, co_p, rb_p,
                            None if zs_p is None else zs_p[t], B, H, st), "blm_lstm_step_fwd_gp")
         if _STATE_TAP is not None:
             _STATE_TAP.layers.append((hs.index_select(0, _STATE_TAP.idx), cs.index_select(0, _STATE_TAP.idx)))
-        ctx.save_for_backward(hs, cs, ga, w_rec, *([zs, coef4] if ovr >= 0 else []))
+        ctx.save_for_backward(hs, cs, ga, w_rec, *([zs, coef4] if ovr >= 0 else []), *([w_cell] if ovr == 5 else []))
         ctx.ovr = ovr
         return hs[1:], hs[T], cs[T]
 
     @staticmethod
     def backward(ctx, dy, dhT, dcT):
         ovr = ctx.ovr
-        if ovr >= 0:
+        w_cell = None
+        if ovr == 5:
+            hs, cs, ga, w_rec, zs, coef4, w_cell = ctx.saved_tensors
+        elif ovr >= 0:
             hs, cs, ga, w_rec, zs, coef4 = ctx.saved_tensors
         else:
             hs, cs, ga, w_rec = ctx.saved_tensors
@@ -1460,8 +1468,9 @@ class _LSTMRecurrentGP(torch.autograd.Function):
         dy = _f32(dy, "dy")
         st = stream()
         dgates = torch.empty(T, B, G, device=dev, dtype=torch.float32)
-        dact = torch.empty(T, B, H, device=dev, dtype=torch.float32) if 0 <= ovr < 4 else None
-        dzs = torch.empty(T, B, G, device=dev, dtype=torch.float32) if ovr == 4 else None  # A operands of the dh products
+        dact = torch.empty(T, B, H, device=dev, dtype=torch.float32) if (0 <= ovr < 4 or ovr == 5) else None
+        # A operands of the next products: ovr 4 -- d z of the hidden projection (B,4H); ovr 5 -- d z of the cell-state GPNN (B,H)
+        dzs = torch.empty(T, B, G if ovr == 4 else H, device=dev, dtype=torch.float32) if ovr >= 4 else None
         dh = torch.zeros(B, H, device=dev, dtype=torch.float32) if dhT is None else _f32(dhT, "dhT").clone()
         dcs = torch.zeros(2, B, H, device=dev, dtype=torch.float32)
         if dcT is not None:
@@ -1477,8 +1486,18 @@ class _LSTMRecurrentGP(torch.autograd.Function):
             check(lib().blm_gp_mix_bwd(ptr(dact[T - 1]), ptr(zs[T - 1]), ptr(coef4), ptr(dz), B, H, st), "blm_gp_mix_bwd")
             dgates[T - 1][:, ovr * H:(ovr + 1) * H].copy_(dz)
         else:
-            check(lib().blm_lstm_cell_bwd2(ptr(dh), ptr(dy[T - 1]), ptr(dcs[0]), ptr(cs[T - 1]), ptr(cs[T]), ptr(ga[T - 1]),
+            c_in = cs[T - 1]
+            if ovr == 5:  # the last step's cell saw the mixture of z_{T-1}
+                c_in = torch.empty(B, H, device=dev, dtype=torch.float32)
+                check(lib().blm_gp_mix_fwd(ptr(zs[T - 1]), ptr(coef4), ptr(c_in), B, H, st), "blm_gp_mix_fwd")
+            check(lib().blm_lstm_cell_bwd2(ptr(dh), ptr(dy[T - 1]), ptr(dcs[0]), ptr(c_in), ptr(cs[T]), ptr(ga[T - 1]),
                                            ptr(dgates[T - 1]), ptr(dcs[1]), B, H, st), "blm_lstm_cell_bwd2")
+            if ovr == 5:
+                w_cell_t = torch.empty(H, H, device=dev, dtype=torch.float32)
+                check(lib().blm_transpose(ptr(w_cell), ptr(w_cell_t), H, H, st), "blm_transpose")
+                dact[T - 1].copy_(dcs[1])
+                check(lib().blm_gp_mix_bwd(ptr(dcs[1]), ptr(zs[T - 1]), ptr(coef4), ptr(dzs[T - 1]), B, H, st), "blm_gp_mix_bwd")
+                check(lib().blm_lstm_step_dh(ptr(dzs[T - 1]), ptr(w_cell_t), ptr(dcs[1]), B, H, H, st), "blm_lstm_step_dh")
             if ovr == 4:
                 check(lib().blm_gp_mix_bwd(ptr(dgates[T - 1]), ptr(zs[T - 1]), ptr(coef4), ptr(dzs[T - 1]), B, G, st),
                       "blm_gp_mix_bwd")
@@ -1490,34 +1509,43 @@ class _LSTMRecurrentGP(torch.autograd.Function):
         dzs_p = None if dzs is None else _P(dzs)
         wt_p, co_p = ptr(w_t), ptr(coef4)
         step_bwd = lib().blm_lstm_step_bwd_gp
+        wct_p = ptr(w_cell_t) if ovr == 5 else None
+        step_dh = lib().blm_lstm_step_dh
         for t in range(T - 1, 0, -1):
             check(step_bwd(A_p[t], wt_p, dy_p[t - 1], dcs_p[k], cs_p[t - 1], cs_p[t], ga_p[t - 1], dg_p[t - 1], dcs_p[k ^ 1], None,
                            ovr, co_p, None if zs_p is None else zs_p[t - 1], None if da_p is None else da_p[t - 1],
                            None if dzs_p is None else dzs_p[t - 1], B, H, st), "blm_lstm_step_bwd_gp")
+            if ovr == 5:  # raw cell-state gradient of the earlier step: d z . Wg
+                check(step_dh(dzs_p[t - 1], wct_p, dcs_p[k ^ 1], B, H, H, st), "blm_lstm_step_dh")
             k ^= 1
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32)
         check(lib().blm_lstm_step_bwd(ptr(A[0]), ptr(w_t), None, None, None, None, None, None, None, ptr(dh0), B, H, st),
               "blm_lstm_step_bwd")
         dw = torch.empty_like(w_rec)
         gemm(L.GEMM_TN, A, hs, dw, G, H, T * B, G, H, H)  # hs[0:T] = h_{t-1}
-        dcoef = drb = None
-        if 0 <= ovr < 4:
+        dcoef = drb = dwc = None
+        if 0 <= ovr < 4 or ovr == 5:
             dcoef = torch.zeros_like(coef4)
             check(lib().blm_gp_coef_grad(ptr(dact), ptr(zs), ptr(dcoef), T * B, H, st), "blm_gp_coef_grad")
+        if ovr == 5:  # the cell-state GPNN's affine map, batched over all steps: dWg = dz^T c_{t-1}, db = column sums of dz
+            dwc = torch.empty_like(w_cell)
+            gemm(L.GEMM_TN, dzs, cs, dwc, H, H, T * B, H, H, H)  # cs[0:T] = c_{t-1}
+            drb = torch.empty(H, device=dev, dtype=torch.float32)
+            _colsum_into(dzs, T * B, H, drb, accumulate=False)
         elif ovr == 4:
             dcoef = torch.zeros_like(coef4)
             check(lib().blm_gp_coef_grad(ptr(dgates), ptr(zs), ptr(dcoef), T * B, G, st), "blm_gp_coef_grad")
             drb = torch.empty(G, device=dev, dtype=torch.float32)
             _colsum_into(dzs, T * B, G, drb, accumulate=False)
-        return dgates, dh0, dcs[k], dw, dcoef, None, drb
+        return dgates, dh0, dcs[k], dw, dcoef, None, drb, dwc
 
 
 def lstm_recurrent_gp_supported(H, w_rec):
     return H % 32 == 0
 
 
-def lstm_recurrent_gp(xw, h0, c0, w_rec, coef4=None, ovr=-1, rbias=None):
-    return _LSTMRecurrentGP.apply(xw, h0, c0, w_rec, coef4, ovr, rbias)
+def lstm_recurrent_gp(xw, h0, c0, w_rec, coef4=None, ovr=-1, rbias=None, w_cell=None):
+    return _LSTMRecurrentGP.apply(xw, h0, c0, w_rec, coef4, ovr, rbias, w_cell)
 
 
 # ----------------------------------------------------------------------------

@@ -384,7 +384,14 @@ int blm_lstm_step_bwd(const float* dgates_t, const float* w_hh_t, const float* d
  * gate_ovr = 4 is GPLSTMCell gate type 6 (model.py:1744-1752): the whole hidden projection
  * h_prev . w_hh^T + rbias (4H) passes through the mixture (coef4 (4,4H), z (B,4H)) before it is added
  * to xw_t; backward then also writes dz_out = dgates_out * mixture'(z_prev) (B,4H), which is the
- * dgates_t operand of the next (earlier) step's launch. */
+ * dgates_t operand of the next (earlier) step's launch.
+ * gate_ovr = 5 is GPLSTMCell gate type 5 (model.py:1759-1760, `cx = self.gpnn(cx)` in front of the cell update): a second
+ * recurrent product per step, c_{t-1} . Wg^T.  The caller computes it with blm_lstm_step_dh(c_prev, Wg, z_out, B, H, H)
+ * right before this launch; the step kernel adds rbias (H), stores z back into z_out and lets the mixture of z
+ * (coef4 (4,H)) take c_prev's place in  c' = f * c_in + i * g.  Backward (gate_ovr = 5, z_prev = that z): the cell
+ * backward uses mixture(z_prev) as its incoming cell state, writes dact_out = d c_in (B,H) (for blm_gp_coef_grad) and
+ * dz_out = d c_in * mixture'(z_prev) (B,H); the raw cell-state gradient of the earlier step is then
+ * blm_lstm_step_dh(dz_out, Wg^T, dc, B, H, H). */
 int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const float* h_prev, const float* c_prev, float* h,
                          float* c, float* gates_act, const float* h_noise, int gate_ovr, const float* coef4,
                          const float* rbias, float* z_out, int B, int H, void* stream);

@@ -565,11 +565,13 @@ def test_gauss_rnn_gpnn2_golden(dev, gp):
     assert torch.equal(a, b) and not torch.equal(a, c2)
 
 
-@pytest.mark.parametrize("gp", ["33", "13", "23", "43", "330", "3343", "31", "63", "6360", "73", "730", "6373"])
+@pytest.mark.parametrize("gp", ["33", "13", "23", "43", "330", "3343", "31", "63", "6360", "73", "730", "6373", "53", "51", "530",
+                                "5353", "5363"])
 def test_gauss_rnn_fused_steps_match_oracle(dev, gp):
     """H = 64: GP cells with a GPNN on one gate (types 1-4) take the fused step kernels (GPNN rows inside
     the recurrent weight, mixture as the gate activation, its derivative and the coefficient gradient
-    in the backward step).  Two windows with the carried hidden state; logits, KL, every gradient
+    in the backward step); gate type 5 (GPNN on the cell state, model.py:1759-1760) runs its second recurrent product
+    as one skinny launch in front of every step and the mixture / its derivative inside the step kernels.  Two windows with the carried hidden state; logits, KL, every gradient
     against the CPU oracle (which the golden tests pin to the reference)."""
     from bayeslms_amd import model as M, ops
     from oracle import bayes_oracle as O

@@ -2,14 +2,19 @@
 collected separately), corrected as MI355X_MICROARCH.md prescribes for gfx950:
 bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Usage:
   python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
-The kernel is the Bayesian FFN linear2 forward GEMM: gemm_f32_kernel<0,2,1,false,true> (128x64 tiles) launched with
-131072 threads (512 output tiles, no split-K); the six linear2 forwards of a step (one sampled, five with bias) share the shape."""
+The kernel is the Bayesian FFN linear2 forward GEMM: gemm_f32_kernel<0,1,1,false,true> (64x64 tiles) launched with
+262144 threads (1024 output tiles, no split-K); the six linear2 forwards of a step (one sampled, five with bias) share the
+shape.  KERNEL=... GRID=... in the environment select another instantiation."""
 import csv
 import json
+import os
 import sys
 
-KERNEL = "void blm::gemm_f32_kernel<0, 2, 1, false, true"  # 128x64 tiles; + the GEMM-mode parameter, prefix match
-GRID = "131072"  # 512 workgroups = 64 x 8 tiles
+# round 3: the plan table puts this launch on 64x64 tiles (gemm_plans.inc: {0, 8192, 512, 4096, ...} -> 11/1), 1024 workgroups
+KERNEL = "void blm::gemm_f32_kernel<0, 1, 1, false, true"  # + the GEMM-mode parameter, prefix match
+GRID = "262144"  # 1024 workgroups x 256 threads = 128 x 8 tiles
+KERNEL = os.environ.get("KERNEL", KERNEL)
+GRID = os.environ.get("GRID", GRID)
 
 
 def avg(path, counter):

@@ -2,7 +2,7 @@
 # Round profile set (run on the GPU box from the repo root): kernel trace + stats of the headline bench, and three
 # separate PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) as MI355X_MICROARCH.md prescribes.  Output: gpurun_out/prof_$1/
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -11,4 +11,23 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o bench -- $B --steps 4 --warmup 1 > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o bench -- $B --steps 4 --warmup 1 > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o bench -- $B --steps 4 --warmup 1 > $OUT/mfma.log 2>&1
-find $OUT -name "*.csv" | head -20
+# summaries for profiles/: kernel stats, stats by (kernel, grid), traffic / matrix-pipe utilisation of the roofline kernel
+F=$(find $OUT/fetch -name "*counter_collection.csv" | head -1); W=$(find $OUT/write -name "*counter_collection.csv" | head -1); M=$(find $OUT/mfma -name "*counter_collection.csv" | head -1)
+python3 tools/pmc_traffic.py $F $W $OUT/pmc_sampled_gemm_fwd.json
+python3 tools/pmc_traffic.py mfma $M $OUT/pmc_sampled_gemm_fwd_mfma_util.json
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/bench_cfg3_kernel_stats.csv
+python3 - $OUT <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+f = glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True)[0]
+agg = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    agg[(r["Kernel_Name"][:110], r["Grid_Size"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+rows = sorted(((sum(v), k, len(v)) for k, v in agg.items()), reverse=True)
+with open(out + "/bench_cfg3_kernel_stats_by_grid.csv", "w") as g:
+    g.write("kernel,grid_threads,calls,total_us,avg_us\n")
+    for tot, (k, grid), n in rows[:60]:
+        g.write('"%s",%s,%d,%.1f,%.2f\n' % (k, grid, n, tot / 1e3, tot / n / 1e3))
+PY
+find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +3M -delete
+ls $OUT
