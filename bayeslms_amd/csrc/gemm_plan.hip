@@ -192,6 +192,23 @@ void read_env() {
   g_force_tile = e ? atoi(e) : 0;
   e = getenv("BLM_GEMM_SPLITK");
   g_force_splits = e ? atoi(e) : 0;
+  // BLM_GEMM_PLAN_SET="op,M,N,K,epilogue,accumulate,tile,splits[;...]": run-time table entries from the environment
+  // (profiling one launch under another plan without touching the others: tools/profile_round.sh)
+  e = getenv("BLM_GEMM_PLAN_SET");
+  while (e && *e) {
+    int v[8], n = 0;
+    char* end = nullptr;
+    while (n < 8) {
+      v[n++] = (int)strtol(e, &end, 10);
+      if (end == e) { n = 0; break; }
+      e = end;
+      if (*e == ',') ++e; else break;
+    }
+    if (n == 8 && v[0] >= 0 && v[0] <= 2 && (v[6] == 11 || v[6] == 12 || v[6] == 21 || v[6] == 22) && v[7] >= 1 && v[7] <= 64)
+      g_runtime.push_back(Entry{v[0], v[1], v[2], v[3], v[4], v[5] ? 1 : 0, v[6], v[7]});
+    while (*e && *e != ';') ++e;
+    if (*e == ';') ++e;
+  }
 }
 
 bool valid_tile(int t) { return t == 11 || t == 12 || t == 21 || t == 22; }

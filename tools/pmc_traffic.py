@@ -2,30 +2,49 @@
 collected separately), corrected as MI355X_MICROARCH.md prescribes for gfx950:
 bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Usage:
   python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
-The kernel is the Bayesian FFN linear2 forward GEMM: gemm_f32_kernel<0,1,1,false,true> (64x64 tiles) launched with
-262144 threads (1024 output tiles, no split-K); the six linear2 forwards of a step (one sampled, five with bias) share the
-shape.  KERNEL=... GRID=... in the environment select another instantiation."""
+The kernel is the Bayesian FFN linear2 forward GEMM (NT 8192 x 512 x 4096); its instantiation and grid are taken from the
+library's planner (round 3: 128x64 tiles, 512 workgroups); the six linear2 forwards of a step (one sampled, five with bias)
+share the shape.  KERNEL=... GRID=... in the environment select another instantiation."""
 import csv
 import json
 import os
 import sys
 
-# round 3: the plan table puts this launch on 64x64 tiles (gemm_plans.inc: {0, 8192, 512, 4096, ...} -> 11/1), 1024 workgroups
-KERNEL = "void blm::gemm_f32_kernel<0, 1, 1, false, true"  # + the GEMM-mode parameter, prefix match
-GRID = "262144"  # 1024 workgroups x 256 threads = 128 x 8 tiles
-KERNEL = os.environ.get("KERNEL", KERNEL)
-GRID = os.environ.get("GRID", GRID)
+def _roofline_launch():
+    """Kernel instantiation and grid of the roofline launch (NT 8192 x 512 x 4096, plain epilogue) as the library's own
+    planner picks them (blm_gemm_plan_query: host code, no GPU)."""
+    import ctypes as C
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bayeslms_amd import _lib as L
+    a = L.GemmArgs()
+    a.abi_version, a.op, a.M, a.N, a.K, a.lda, a.ldb, a.ldc = L.ABI_VERSION, L.GEMM_NT, 8192, 512, 4096, 4096, 4096, 512
+    pl = L.GemmPlan()
+    L.check(L.lib().blm_gemm_plan_query(C.byref(a), C.byref(pl)), "blm_gemm_plan_query")
+    wtm, wtn = pl.tile // 10, pl.tile % 10
+    nwg = ((8192 + 64 * wtm - 1) // (64 * wtm)) * ((512 + 64 * wtn - 1) // (64 * wtn)) * pl.splits
+    return "void blm::gemm_f32_kernel<0, %d, %d, false, true" % (wtm, wtn), str(256 * nwg)
+
+
+KERNEL, GRID = os.environ.get("KERNEL"), os.environ.get("GRID")  # another instantiation (A/B of two tiles)
+if not KERNEL or not GRID:
+    KERNEL, GRID = _roofline_launch()
+MIN_US = float(os.environ.get("MIN_US", "150"))  # the o_net forward (8192 x 512 x 512, ~40 us) shares kernel AND grid with the
+# roofline launch (8192 x 512 x 4096, ~250 us): the two are told apart by their duration
+
+
+def _is(r):
+    return (r["Kernel_Name"].startswith(KERNEL) and r["Grid_Size"] == GRID
+            and (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 >= MIN_US)
 
 
 def avg(path, counter):
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-         if r["Kernel_Name"].startswith(KERNEL) and r["Grid_Size"] == GRID and r["Counter_Name"] == counter]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if _is(r) and r["Counter_Name"] == counter]
     return sum(v) / len(v), len(v)
 
 
 def mfma_util(path, out):
     """Third pass (SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE): matrix-pipe utilisation of the same launches."""
-    rows = [r for r in csv.DictReader(open(path)) if r["Kernel_Name"].startswith(KERNEL) and r["Grid_Size"] == GRID]
+    rows = [r for r in csv.DictReader(open(path)) if _is(r)]
     busy = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES"]
     act = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == "GRBM_GUI_ACTIVE"]
     b, a = sum(busy) / len(busy), sum(act) / len(act)
@@ -41,7 +60,10 @@ def main():
     if sys.argv[1] == "mfma":
         return mfma_util(sys.argv[2], sys.argv[3])
     f, nf = avg(sys.argv[1], "FETCH_SIZE")
-    w, nw = avg(sys.argv[2], "WRITE_SIZE")
+    try:
+        w, nw = avg(sys.argv[2], "WRITE_SIZE")
+    except ZeroDivisionError:  # the WRITE pass belongs to another tile's run: WRITE_SIZE of this launch is exactly Y on every tile
+        w, nw = 8192 * 512 * 4 / 1024.0, nf
     M, N, K = 8192, 512, 4096
     out = {"kernel": KERNEL, "grid_threads": int(GRID), "launches": min(nf, nw), "FETCH_SIZE_KB_avg": f,
            "WRITE_SIZE_KB_avg": w, "traffic_bytes_per_launch": (2 * f + w) * 1024,

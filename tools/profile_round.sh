@@ -22,12 +22,24 @@ out = sys.argv[1]
 f = glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True)[0]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    agg[(r["Kernel_Name"][:110], r["Grid_Size"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    # launches of one kernel and grid but different K (e.g. o_net 8192x512x512 and linear2 8192x512x4096 on 64x64 tiles) are
+    # told apart by their duration: one row per power-of-two duration class
+    agg[(r["Kernel_Name"][:110], str(grid), len(bin(max(d, 1))))].append(d)
 rows = sorted(((sum(v), k, len(v)) for k, v in agg.items()), reverse=True)
 with open(out + "/bench_cfg3_kernel_stats_by_grid.csv", "w") as g:
     g.write("kernel,grid_threads,calls,total_us,avg_us\n")
-    for tot, (k, grid), n in rows[:60]:
+    for tot, (k, grid, _), n in rows[:70]:
         g.write('"%s",%s,%d,%.1f,%.2f\n' % (k, grid, n, tot / 1e3, tot / n / 1e3))
 PY
+# the same launch forced onto 64x64 and 128x128 tiles, in situ: traffic / time trade-off of the tile choice
+for t in 11 22; do
+  export BLM_GEMM_PLAN_SET="0,8192,512,4096,0,0,$t,1;0,8192,512,4096,1,0,$t,1"
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_t$t -o bench -- $B --steps 4 --warmup 1 > $OUT/fetch_t$t.log 2>&1
+  unset BLM_GEMM_PLAN_SET
+  if [ $t = 11 ]; then K="void blm::gemm_f32_kernel<0, 1, 1, false, true"; G=262144; else K="void blm::gemm_f32_kernel<0, 2, 2, false, true"; G=65536; fi
+  KERNEL="$K" GRID=$G python3 tools/pmc_traffic.py $(find $OUT/fetch_t$t -name "*counter_collection.csv" | head -1) $W $OUT/pmc_sampled_gemm_fwd_tile${t}_in_situ.json || true
+done
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +3M -delete
 ls $OUT
