@@ -114,69 +114,6 @@ Plan model_plan(const PlanKey& k) {
 }
 
 
-// ---- the round-2 hand-placed rules, kept ONLY as the yardstick of tools/gemm_tune.py's A/B (BLM_GEMM_PLAN=legacy) ----
-Plan legacy_plan(const PlanKey& p) {
-  const int OP = p.op;
-  const bool can_split = p.can_split != 0;
-  const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  bool small_m = p.M <= 64, small_n = p.N <= 64;
-  int force_splits = 0;
-  if (!small_m && !small_n && b128 < 256) {
-    if (p.M <= p.N) small_m = true; else small_n = true;
-    const long b2 = (long)((p.M + (small_m ? 63 : 127)) / (small_m ? 64 : 128)) * ((p.N + (small_n ? 63 : 127)) / (small_n ? 64 : 128));
-    if (b2 < 256) small_m = small_n = true;
-  }
-  auto fill = [](long g) { return (double)g / (double)(((g + 511) / 512) * 512); };
-  if (can_split && p.K >= 2048 && p.M > 64 && p.N > 64) {
-    const long t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
-    if (b128 >= 96) small_m = small_n = false;
-    else if (t12 >= 64) { if (p.M > p.N) { small_m = false; small_n = true; } else { small_m = true; small_n = false; } }
-    else small_m = small_n = true;
-  } else if (p.K < 2048 && b128 >= 256 && p.M >= 128 && p.N >= 128) {
-    const long t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128), t11 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
-    if (b128 < 1024) { small_m = true; small_n = false; if (fill(t11) > fill(t12) + 0.1) small_n = true; }
-    else if (fill(t12) > fill(b128) + 0.05 || p.K <= 512) { small_m = true; small_n = false; }
-  }
-  if (OP == BLM_GEMM_NT && !small_m && !small_n && b128 >= 256 && b128 < 384 && p.K >= 2048 && p.K <= 8192) small_n = true;
-  if (OP == BLM_GEMM_TN && p.epi == BLM_EPI_BAYES_WGRAD) small_m = small_n = true;
-  if (can_split && p.K >= 2048 && p.M > 64 && p.N > 64 && b128 >= 96) {
-    const long t11 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64), t12 = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
-    if (OP == BLM_GEMM_TN && p.K < 4096) {
-      if (t11 >= 1024 && p.epi == BLM_EPI_NONE) { small_m = small_n = true; force_splits = 1; }
-      else if (fill(t12) > fill(b128) + 0.05) { small_m = true; small_n = false; }
-    } else if (OP == BLM_GEMM_NN && p.K <= 8192 && b128 < 256) {
-      const long t21 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
-      if (t11 >= 512 && p.K >= 4096) { small_m = small_n = true; force_splits = 4; }
-      else if (t21 >= 256) { small_m = false; small_n = true; }
-    } else if (OP == BLM_GEMM_NN && p.K > 8192 && b128 < 256 && t12 >= 256) {
-      small_m = true; small_n = false; force_splits = 8;
-    }
-  }
-  if (!p.fast) small_m = small_n = true;
-  const int BM = small_m ? 64 : 128, BN = small_n ? 64 : 128;
-  const long nb = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  int splits = 1;
-  const bool small_out = (long)p.M * p.N <= (1L << 20);
-  const int min_k = small_out ? 128 : 512;
-  const bool one_round_ok = OP == BLM_GEMM_NN ? nb < 384 : (nb < 256 || (nb < 384 && p.K > 8192));
-  if (can_split && one_round_ok && p.K >= (small_out ? 512 : 2048)) {
-    if (nb <= 96) splits = 8;
-    else {
-      double best = -1.0;
-      for (int sp = 1; sp <= 8; ++sp) {
-        if (sp > 1 && p.K / sp < min_k) break;
-        const long g = nb * sp, rounds = (g + 511) / 512;
-        const double u = (double)g / (double)(rounds * 512) - 0.01 * sp;
-        if (u > best + 1e-9) { best = u; splits = sp; }
-      }
-    }
-    while (splits > 1 && p.K / splits < min_k) --splits;
-  }
-  if (OP == BLM_GEMM_TN && can_split && p.K >= 4096 && splits < 4) splits = p.epi == BLM_EPI_BAYES_WGRAD ? 2 : 4;
-  if (force_splits > 0 && can_split) splits = force_splits;
-  return Plan{small_m ? (small_n ? 11 : 12) : (small_n ? 21 : 22), splits, 3};
-}
-
 const Entry* find(const PlanKey& k) {
   for (auto it = g_runtime.rbegin(); it != g_runtime.rend(); ++it)
     if (it->op == k.op && it->M == k.M && it->N == k.N && it->K == k.K && it->epi == k.epi && it->acc == k.acc) return &*it;
@@ -224,10 +161,10 @@ double plan_model_us(const PlanKey& k, int tile, int splits) {
 Plan choose_plan(const PlanKey& k) {
   std::lock_guard<std::mutex> lk(g_mu);
   read_env();
-  static int legacy = -1;
-  if (legacy < 0) { const char* e = getenv("BLM_GEMM_PLAN"); legacy = (e && !strcmp(e, "legacy")) ? 1 : ((e && !strcmp(e, "model")) ? 2 : 0); }
-  Plan p = legacy == 1 ? legacy_plan(k) : model_plan(k);
-  if (const Entry* e = legacy == 0 ? find(k) : nullptr) { p.tile = e->tile; p.splits = e->splits; p.source = 1; }
+  static int model_only = -1;  // BLM_GEMM_PLAN=model: the cost model alone (plan table off), for A/B runs
+  if (model_only < 0) { const char* e = getenv("BLM_GEMM_PLAN"); model_only = (e && !strcmp(e, "model")) ? 1 : 0; }
+  Plan p = model_plan(k);
+  if (const Entry* e = model_only ? nullptr : find(k)) { p.tile = e->tile; p.splits = e->splits; p.source = 1; }
   if (g_force_tile > 0 && valid_tile(g_force_tile)) { p.tile = g_force_tile; p.source = 2; }
   if (g_force_splits > 0) { p.splits = g_force_splits; p.source = 2; }
   // legality, whatever the source said

@@ -1,0 +1,118 @@
+"""CPU: the launch planner of the fp32 MFMA GEMM (csrc/gemm_plan.hip) is host code -- every rule of it can be checked
+without a GPU through blm_gemm_plan_query / _model_us / _override / _set / _clear (include/bayeslm.h)."""
+import ctypes as C
+import re
+
+import pytest
+
+from bayeslms_amd import _lib as L
+
+
+def args(op, m, n, k, epi=L.EPI_NONE, acc=False, ldc=None, misaligned=False):
+    a = L.GemmArgs()
+    a.abi_version = L.ABI_VERSION
+    a.op, a.M, a.N, a.K = op, m, n, k
+    a.lda = m if op == L.GEMM_TN else k
+    a.ldb = k if op == L.GEMM_NT else n
+    a.ldc = n if ldc is None else ldc
+    a.epilogue = epi
+    a.flags = L.GEMM_ACCUMULATE if acc else 0
+    a.A = 4 if misaligned else 0  # only inspected for alignment
+    return a
+
+
+def plan(a):
+    out = L.GemmPlan()
+    L.check(L.lib().blm_gemm_plan_query(C.byref(a), C.byref(out)), "blm_gemm_plan_query")
+    return out.tile, out.splits, out.source, out.model_us
+
+
+@pytest.fixture(autouse=True)
+def _clean():
+    lib = L.lib()
+    lib.blm_gemm_plan_override(0, 0)
+    lib.blm_gemm_plan_clear(1)
+    yield
+    lib.blm_gemm_plan_override(0, 0)
+    lib.blm_gemm_plan_clear(1)
+
+
+def table_entries():
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bayeslms_amd", "csrc", "gemm_plans.inc")
+    return [tuple(int(v) for v in m.groups()) for m in re.finditer(r"^\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\}", open(path).read(), re.M)]
+
+
+def test_every_plan_is_legal_and_deterministic():
+    dims = [1, 7, 64, 100, 512, 2240, 3200, 8192, 33000]
+    for op in (L.GEMM_NT, L.GEMM_NN, L.GEMM_TN):
+        for m in dims:
+            for n in dims:
+                for k in (1, 32, 500, 512, 4096, 33000):
+                    for epi, acc in ((L.EPI_NONE, False), (L.EPI_NONE, True), (L.EPI_BIAS, False)):
+                        a = args(op, m, n, k, epi, acc)
+                        t, s, src, us = plan(a)
+                        assert t in (11, 12, 21, 22) and 1 <= s <= 16 and src in (0, 1) and us > 0
+                        assert plan(a)[:2] == (t, s)
+                        if epi != L.EPI_NONE:
+                            assert s == 1  # partial sums cannot pass through a bias epilogue
+                        if s > 1:
+                            assert k // s >= 32
+                        fast = all(v % 4 == 0 and v >= 4 for v in ((m if op == L.GEMM_TN else k), (k if op == L.GEMM_NT else n)))
+                        if not fast:
+                            assert t == 11  # odd extents: only the guarded 64x64 kernel exists
+
+
+def test_split_k_needs_a_dense_or_accumulated_c_and_aligned_operands_get_all_tiles():
+    assert plan(args(L.GEMM_NN, 64, 4096, 8192))[1] > 1                      # skinny output, long K: slices fill the chip
+    assert plan(args(L.GEMM_NN, 64, 4096, 8192, ldc=8192))[1] == 1            # a strided C cannot be zeroed in one pass ...
+    assert plan(args(L.GEMM_NN, 64, 4096, 8192, ldc=8192, acc=True))[1] > 1   # ... unless it is accumulated into
+    assert plan(args(L.GEMM_NT, 8192, 4096, 4096, misaligned=True))[0] == 11
+    assert plan(args(L.GEMM_NT, 8192, 4096, 4096))[0] != 11                   # a big aligned product is not run on 64x64 tiles
+
+
+def test_plan_table_override_and_runtime_entries():
+    lib = L.lib()
+    ent = table_entries()
+    assert ent, "gemm_plans.inc holds the in-situ tuned shapes"
+    for op, m, n, k, epi, acc, t, s in ent:
+        a = args(op, m, n, k, epi, bool(acc))
+        if epi in (L.EPI_BIAS, L.EPI_BIAS_GELU):
+            a.bias = 16
+        got = plan(a)
+        assert got[:3] == (t, s, 1), (op, m, n, k, got)
+    op, m, n, k, epi, acc, t, s = ent[0]
+    a = args(op, m, n, k, epi, bool(acc))
+    lib.blm_gemm_plan_clear(0)  # cost model only
+    assert plan(a)[2] == 0
+    lib.blm_gemm_plan_clear(1)
+    assert plan(a)[2] == 1
+    L.check(lib.blm_gemm_plan_set(op, m, n, k, epi, acc, 22, 1), "set")  # a run-time entry supersedes the built-in one
+    assert plan(a)[:3] == (22, 1, 1)
+    L.check(lib.blm_gemm_plan_override(12, 0), "override")                   # the override beats both
+    assert plan(a)[0] == 12 and plan(a)[2] == 2
+    assert lib.blm_gemm_plan_override(13, 0) == L.ERR_INVALID and lib.blm_gemm_plan_set(0, 1, 1, 1, 0, 0, 22, 0) == L.ERR_INVALID
+    lib.blm_gemm_plan_override(0, 0)
+    lib.blm_gemm_plan_clear(1)
+    assert plan(a)[:3] == (t, s, 1)
+
+
+def test_cost_model_shape():
+    """Round-fill x per-tile efficiency: time grows with K, a second (partial) round costs, the model is finite everywhere."""
+    lib = L.lib()
+
+    def us(a, tile, s):
+        v = C.c_float()
+        L.check(lib.blm_gemm_plan_model_us(C.byref(a), tile, s, C.byref(v)), "model_us")
+        return v.value
+    a1, a2 = args(L.GEMM_NT, 8192, 512, 2048), args(L.GEMM_NT, 8192, 512, 4096)
+    for t in (11, 12, 21, 22):
+        assert 1.5 < us(a2, t, 1) / us(a1, t, 1) < 2.1
+    full, over = args(L.GEMM_NT, 128 * 32, 128 * 16, 4096), args(L.GEMM_NT, 128 * 33, 128 * 16, 4096)  # 512 / 528 tiles of 128x128
+    assert us(over, 22, 1) > 1.2 * us(full, 22, 1)  # 16 tiles spill into a second round of the 512 workgroup slots
+    lib.blm_gemm_plan_clear(0)
+    # the fitted model reproduces the measured preferences the round-2 rules were written around
+    assert plan(args(L.GEMM_NT, 8192, 512, 4096))[0] in (21, 12, 11)          # not 128x128: 256 tiles = one wave per SIMD
+    assert plan(args(L.GEMM_TN, 512, 512, 8192, acc=True))[1] >= 8            # o_net weight gradient: 16 / 64 tiles need K slices
+    assert plan(args(L.GEMM_NN, 2240, 1024, 33000))[1] >= 4                   # decoder input gradient at M = 2240
+    lib.blm_gemm_plan_clear(1)

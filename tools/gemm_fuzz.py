@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Randomised check of blm_gemm against fp64 over the whole launch heuristic: N shapes drawn from the ranges the tile /
 split rules branch on (tiny to 33000-wide, K from 1 to 33000, aligned and odd), all three layouts, accumulate on/off,
-bias epilogue.  usage: gemm_fuzz.py [count] [seed]"""
+bias epilogue.  usage: gemm_fuzz.py [count] [seed]
+       gemm_fuzz.py perf   PERFORMANCE regression check of the launch planner (csrc/gemm_plan.hip, cost model only: plan
+                           table off): on a log-spaced M x N x K grid (64 ... 33000, all three layouts) every candidate tile x
+                           slice count is timed and the planner's own choice must reach >= 0.6 of the best candidate's rate
+                           on every shape of 30 us and more (tools/gemm_tune.py --grid --coarse; the full 2160-shape sweep
+                           the model was fitted to: --grid alone)."""
 import os
 import random
 import sys
@@ -13,6 +18,10 @@ from bayeslms_amd import _lib as L, ops  # noqa: E402
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "perf":
+        import subprocess
+        sys.exit(subprocess.call([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune.py"), "--grid",
+                                  "--coarse", "--min-frac", "0.6"]))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     dev = torch.device("cuda:0")
