@@ -130,6 +130,15 @@ SIGNATURES = {
     "blm_lstm_search_step_partials": (_i64, [_i, _i]),
     "blm_lstm_search_step_bwd": (_i, [_vp] * 11 + [_i, _i, _vp]),
     "blm_lstm_step_dh": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "blm_lstm_step_dh_ld": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "blm_gpnn2_actsum_fwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _f, _i, _vp]),
+    "blm_gpnn2_actsum_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _f, _i, _vp]),
+    "blm_add_cols": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _vp]),
+    "blm_gpnn2_sample_steps": (_i, [_vp, _vp, _vp, _rngp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "blm_gpnn2_freq_grad": (_i, [_vp, _vp, _vp, _rngp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "blm_lstm_gpnn2_seq_fwd": (_i, [_vp, _vp, _vp, _i, _vp] + [_vp] * 8 + [_i] * 8 + [_vp]),
+    "blm_lstm_gpnn2_seq_bwd": (_i, [_vp, _vp, _vp, _i, _vp] + [_vp] * 9 + [_i] * 8 + [_vp]),
+    "blm_lstm_cell_ovr_bwd2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "blm_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp]),
     "blm_clip_sgd_multi_wd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _i, _f, _f, _vp]),
 }

@@ -633,7 +633,7 @@ __global__ __launch_bounds__(TPB) void lstm_cell_ovr_fwd_kernel(const float* __r
   }
 }
 
-__global__ __launch_bounds__(TPB) void lstm_cell_ovr_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc_next,
+__global__ __launch_bounds__(TPB) void lstm_cell_ovr_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dh2, const float* __restrict__ dc_next,
                                                                 const float* __restrict__ c_prev, const float* __restrict__ c,
                                                                 const float* __restrict__ ga, int gidx,
                                                                 float* __restrict__ dgates, float* __restrict__ d_ovr,
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(TPB) void lstm_cell_ovr_bwd_kernel(const float* __r
     const long b = i / H, j = i - b * H, o = b * 4 * H + j;
     const float gi = ga[o], gf = ga[o + H], gg = ga[o + 2 * H], go = ga[o + 3 * H];
     const float tc = tanhf(c[i]);
-    const float dhv = dh[i];
+    const float dhv = dh[i] + (dh2 ? dh2[i] : 0.f);
     const float dc = (dc_next ? dc_next[i] : 0.f) + dhv * go * (1.f - tc * tc);
     const float dgi = dc * gg, dgf = dc * c_prev[i], dgg = dc * gi, dgo = dhv * tc;  // w.r.t. activated gates
     dgates[o] = gidx == 0 ? 0.f : dgi * gi * (1.f - gi);
@@ -679,6 +679,60 @@ __global__ __launch_bounds__(TPB) void add_rowvec_kernel(float* __restrict__ x, 
 
 __global__ __launch_bounds__(TPB) void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float a) {
   for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) y[i] += a * x[i];
+}
+
+// GPNN2 random-feature head (model.py:2068-2076): s = (f + sum_{a in acts} a(f)) * scale for the M real feature columns,
+// s[:, M] = 1 (the column that carries coef.bias when the coefficient matrix is padded with it), zeros beyond; `acts` is a
+// bit set in the mixture's slot order (1 tanh, 2 sigmoid, 4 relu, 8 gelu).  ld_f / ld_s: row strides of f and s.
+__global__ __launch_bounds__(TPB) void gpnn2_actsum_fwd_kernel(const float* __restrict__ f, float* __restrict__ s, long rows, int M,
+                                                               int ld_f, int ld_s, float scale, int acts) {
+  const long total = rows * ld_s;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const long r = i / ld_s;
+    const int m = (int)(i - r * ld_s);
+    float v = m == M ? 1.f : 0.f;
+    if (m < M) {
+      const float z = f[r * ld_f + m];
+      v = z;
+      if (acts & 1) v += tanhf(z);
+      if (acts & 2) v += sigmoidf_(z);
+      if (acts & 4) v += fmaxf(z, 0.f);
+      if (acts & 8) v += gelu_erf(z);
+      v *= scale;
+    }
+    s[i] = v;
+  }
+}
+// df = ds * (1 + sum a'(f)) * scale on the real columns, 0 on the padding (df has row stride ld_s, like ds)
+__global__ __launch_bounds__(TPB) void gpnn2_actsum_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ f,
+                                                               float* __restrict__ df, long rows, int M, int ld_f, int ld_s,
+                                                               float scale, int acts) {
+  const long total = rows * ld_s;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const long r = i / ld_s;
+    const int m = (int)(i - r * ld_s);
+    float v = 0.f;
+    if (m < M) {
+      const float z = f[r * ld_f + m];
+      float d = 1.f;
+      if (acts & 1) { const float th = tanhf(z); d += 1.f - th * th; }
+      if (acts & 2) { const float sg = sigmoidf_(z); d += sg * (1.f - sg); }
+      if (acts & 4) d += z > 0.f ? 1.f : 0.f;
+      if (acts & 8) d += dgelu_erf(z);
+      v = ds[i] * d * scale;
+    }
+    df[i] = v;
+  }
+}
+// out[r, c] = a[r, c] + b[r, c] on column windows of wider matrices (row strides lda / ldb / ldo)
+__global__ __launch_bounds__(TPB) void add_cols_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                                       float* __restrict__ out, long ldo, long rows, int cols) {
+  const long total = rows * cols;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const long r = i / cols;
+    const int c = (int)(i - r * cols);
+    out[r * ldo + c] = a[r * lda + c] + b[r * ldb + c];
+  }
 }
 
 static int grid_for(long items) {
@@ -978,7 +1032,19 @@ extern "C" int blm_lstm_cell_ovr_bwd(const float* dh, const float* dc_next, cons
   if (!dh || !c_prev || !c || !gates_act || !dgates || !d_ovr || !dc_prev || B < 0 || H < 0 || gate_idx < 0 || gate_idx > 3)
     return blm_fail(BLM_ERR_INVALID, "blm_lstm_cell_ovr_bwd: bad arguments");
   if ((long)B * H == 0) return BLM_OK;
-  hipLaunchKernelGGL(lstm_cell_ovr_bwd_kernel, dim3(grid_for((long)B * H)), dim3(TPB), 0, ST, dh, dc_next, c_prev, c, gates_act,
+  hipLaunchKernelGGL(lstm_cell_ovr_bwd_kernel, dim3(grid_for((long)B * H)), dim3(TPB), 0, ST, dh, (const float*)nullptr, dc_next, c_prev,
+                     c, gates_act, gate_idx, dgates, d_ovr, dc_prev, B, H);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_lstm_cell_ovr_bwd2(const float* dh, const float* dh2, const float* dc_next, const float* c_prev, const float* c,
+                                      const float* gates_act, int gate_idx, float* dgates, float* d_ovr, float* dc_prev, int B,
+                                      int H, void* stream) {
+  if (!dh || !c_prev || !c || !gates_act || !dgates || !d_ovr || !dc_prev || B < 0 || H < 0 || gate_idx < 0 || gate_idx > 3)
+    return blm_fail(BLM_ERR_INVALID, "blm_lstm_cell_ovr_bwd2: bad arguments");
+  if ((long)B * H == 0) return BLM_OK;
+  hipLaunchKernelGGL(lstm_cell_ovr_bwd_kernel, dim3(grid_for((long)B * H)), dim3(TPB), 0, ST, dh, dh2, dc_next, c_prev, c, gates_act,
                      gate_idx, dgates, d_ovr, dc_prev, B, H);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
@@ -996,6 +1062,39 @@ extern "C" int blm_gp_mix_bwd(const float* dout, const float* z, const float* co
   if (!dout || !z || !coef || !dz || M < 0 || N < 0) return blm_fail(BLM_ERR_INVALID, "blm_gp_mix_bwd: bad arguments");
   if ((long)M * N == 0) return BLM_OK;
   hipLaunchKernelGGL(gp_mix_bwd_kernel, dim3(grid_for((long)M * N)), dim3(TPB), 0, ST, dout, z, coef, dz, (long)M * N, N);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_gpnn2_actsum_fwd(const float* f, float* s, int64_t rows, int M, int ld_f, int ld_s, float scale, int acts,
+                                    void* stream) {
+  if (!f || !s || rows < 0 || M < 0 || ld_f < M || ld_s < M || (acts & ~15))
+    return blm_fail(BLM_ERR_INVALID, "blm_gpnn2_actsum_fwd: bad arguments");
+  if (rows * (long)ld_s == 0) return BLM_OK;
+  hipLaunchKernelGGL(gpnn2_actsum_fwd_kernel, dim3(grid_for(rows * (long)ld_s)), dim3(TPB), 0, ST, f, s, (long)rows, M, ld_f, ld_s,
+                     scale, acts);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_gpnn2_actsum_bwd(const float* ds, const float* f, float* df, int64_t rows, int M, int ld_f, int ld_s, float scale,
+                                    int acts, void* stream) {
+  if (!ds || !f || !df || rows < 0 || M < 0 || ld_f < M || ld_s < M || (acts & ~15))
+    return blm_fail(BLM_ERR_INVALID, "blm_gpnn2_actsum_bwd: bad arguments");
+  if (rows * (long)ld_s == 0) return BLM_OK;
+  hipLaunchKernelGGL(gpnn2_actsum_bwd_kernel, dim3(grid_for(rows * (long)ld_s)), dim3(TPB), 0, ST, ds, f, df, (long)rows, M, ld_f,
+                     ld_s, scale, acts);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_add_cols(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int64_t rows, int cols,
+                            void* stream) {
+  if (!a || !b || !out || rows < 0 || cols < 0 || lda < cols || ldb < cols || ldo < cols)
+    return blm_fail(BLM_ERR_INVALID, "blm_add_cols: bad arguments");
+  if (rows * (long)cols == 0) return BLM_OK;
+  hipLaunchKernelGGL(add_cols_kernel, dim3(grid_for(rows * (long)cols)), dim3(TPB), 0, ST, a, (long)lda, b, (long)ldb, out, (long)ldo,
+                     (long)rows, cols);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }

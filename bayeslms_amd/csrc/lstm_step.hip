@@ -18,6 +18,7 @@
 // Per step and workgroup: 128 KB of h and 128 KB of W_hh (L2/MALL resident across steps), 128 MFMA
 // per wave.  H % 32 == 0 and 16-byte aligned operands are required (blm_lstm_step_fwd returns
 // BLM_ERR_UNSUPPORTED otherwise and the host uses blm_gemm + blm_lstm_cell_fwd).
+#include <cmath>
 #include <cstdlib>
 
 #include "blm_device.h"
@@ -491,6 +492,7 @@ struct LstmBwdP {
   int ovr;
   int B, H;
   int G;                                  // contraction length = row length of dg and wt: 4H (LSTM), 8H (search cell)
+  long ldo;                               // row stride of dh_out (blm_lstm_step_dh_ld: the product lands in a column window)
 };
 
 // PIPE: software-pipelined K loop; TAIL = false: whole 32-float chunks only (no zero-fill selects, scalar chunk offsets) -- see the forward kernel
@@ -733,7 +735,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
   if constexpr (NW == 8)
     dh += (red[(4 * 16 + brow) * BRSTR + ecol] + red[(5 * 16 + brow) * BRSTR + ecol]) +
           (red[(6 * 16 + brow) * BRSTR + ecol] + red[(7 * 16 + brow) * BRSTR + ecol]);
-  if (p.dh_out) p.dh_out[ei] = dh;
+  if (p.dh_out) p.dh_out[(long)eb * p.ldo + ek] = dh;
   if (p.dg_out) {  // cell backward of the step that produced h_{t-1} (elementwise.hip lstm_cell_bwd_kernel)
     if (p.ovr == 5) e_cp = gp_mix(e_z, p.coef, H, ek);  // gate type 5: the cell saw the GPNN mixture of z = c_{t-2} Wg^T + b
     const float gi = e_g[0], gf = e_g[1], gg = e_g[2], go = e_g[3];
@@ -984,7 +986,7 @@ extern "C" int blm_lstm_step_bwd_gp(const float* dgates_t, const float* w_hh_t, 
   if (H % 32 != 0 || !al16(dgates_t) || !al16(w_hh_t))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_bwd: needs H % 32 == 0 and 16-byte aligned dgates_t / w_hh_t");
   LstmBwdP p{dgates_t, w_hh_t, dy_prev, dc_next, c_prev, c, gates_act, dgates_out, dc_prev, dh_out, z_prev, coef4, dact_out,
-             dz_out, (dgates_out && gate_ovr >= 0) ? gate_ovr : -1, B, H, 4 * H};
+             dz_out, (dgates_out && gate_ovr >= 0) ? gate_ovr : -1, B, H, 4 * H, (long)H};
   return launch_step_bwd(p, stream);
 }
 
@@ -1002,16 +1004,67 @@ extern "C" int blm_lstm_search_step_bwd(const float* dz8_t, const float* w8_t, c
   if (H % 16 != 0 || !al16(dz8_t) || !al16(w8_t))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_search_step_bwd: needs H % 16 == 0 and 16-byte aligned dz8_t / w8_t");
   LstmBwdP p{dz8_t, w8_t, dy_prev, dc_next, c_prev, c, acts8, dz8_out, dc_prev, nullptr, nullptr, probs, partial, nullptr, 8,
-             B, H, 8 * H};
+             B, H, 8 * H, (long)H};
   return launch_step_bwd(p, stream);
 }
 
-extern "C" int blm_lstm_step_dh(const float* dz, const float* w_t, float* dh_out, int B, int H, int G, void* stream) {
-  if (!dz || !w_t || !dh_out || B < 0 || H < 0 || G < 0) return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_dh: bad arguments");
+extern "C" int blm_lstm_step_dh_ld(const float* dz, const float* w_t, float* dh_out, int64_t ldo, int B, int H, int G, void* stream) {
+  if (!dz || !w_t || !dh_out || B < 0 || H < 0 || G < 0 || ldo < H) return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_dh: bad arguments");
   if ((long)B * H == 0) return BLM_OK;
   if (H % 16 != 0 || G % 64 != 0 || G == 0 || !al16(dz) || !al16(w_t))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_dh: needs H % 16 == 0, G % 64 == 0 and 16-byte aligned dz / w_t");
   LstmBwdP p{dz, w_t, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dh_out, nullptr, nullptr, nullptr, nullptr, -1,
-             B, H, G};
+             B, H, G, (long)ldo};
   return launch_step_bwd(p, stream);
+}
+
+extern "C" int blm_lstm_step_dh(const float* dz, const float* w_t, float* dh_out, int B, int H, int G, void* stream) {
+  return blm_lstm_step_dh_ld(dz, w_t, dh_out, H, B, H, G, stream);
+}
+
+// ------------------------------------------------------------------ GPNN2 gate: the time loops (host side)
+// One C call per layer and direction instead of 11 ctypes calls per time step: the launches are 3-9 us each, the Python
+// side of a ctypes call costs about as much (the sequences themselves: ops._LSTMRecurrentGPNN2 / include/bayeslm.h).
+extern "C" int blm_lstm_gpnn2_seq_fwd(const float* xw, const float* w_hh, const float* FT, int nF, const float* cwp, float* hs,
+                                      float* cs, float* z4, float* ga, float* pre, float* feat, float* sact, float* aact, int gate,
+                                      int acts, int T, int B, int H, int M, int MP, int GP, void* stream) {
+  if (!xw || !w_hh || !FT || !cwp || !hs || !cs || !z4 || !ga || !pre || !feat || !sact || !aact || gate < 0 || gate > 3 || T < 0 ||
+      nF < 1 || (nF != 1 && nF != T))
+    return blm_fail(BLM_ERR_INVALID, "blm_lstm_gpnn2_seq_fwd: bad arguments");
+  const size_t bh = (size_t)B * H, bg = 4 * bh, off = (size_t)gate * H;
+  const float scale = 1.0f / sqrtf((float)M);
+  for (int t = 0; t < T; ++t) {
+    int rc = blm_lstm_step_dh(hs + t * bh, w_hh, z4 + t * bg, B, 4 * H, H, stream);
+    if (!rc) rc = blm_add_cols(xw + t * bg + off, 4 * H, z4 + t * bg + off, 4 * H, pre + t * bh, H, B, H, stream);
+    if (!rc) rc = blm_lstm_step_dh(pre + t * bh, FT + (size_t)(nF > 1 ? t : 0) * MP * H, feat + (size_t)t * B * MP, B, MP, H, stream);
+    if (!rc) rc = blm_gpnn2_actsum_fwd(feat + (size_t)t * B * MP, sact + (size_t)t * B * GP, B, M, MP, GP, scale, acts, stream);
+    if (!rc) rc = blm_lstm_step_dh(sact + (size_t)t * B * GP, cwp, aact + t * bh, B, H, GP, stream);
+    if (!rc) rc = blm_lstm_cell_ovr_fwd(xw + t * bg, z4 + t * bg, cs + t * bh, aact + t * bh, gate, hs + (t + 1) * bh, cs + (t + 1) * bh,
+                                        ga + t * bg, B, H, stream);
+    if (rc) return rc;
+  }
+  return BLM_OK;
+}
+
+extern "C" int blm_lstm_gpnn2_seq_bwd(const float* dy, const float* w_hh_t, const float* Fp, int nF, const float* cwt, const float* cs,
+                                      const float* ga, const float* feat, float* dh, float* dcs2, float* dgates, float* da, float* ds,
+                                      float* df, int gate, int acts, int T, int B, int H, int M, int MP, int GP, void* stream) {
+  if (!dy || !w_hh_t || !Fp || !cwt || !cs || !ga || !feat || !dh || !dcs2 || !dgates || !da || !ds || !df || gate < 0 || gate > 3 ||
+      T < 0 || nF < 1 || (nF != 1 && nF != T))
+    return blm_fail(BLM_ERR_INVALID, "blm_lstm_gpnn2_seq_bwd: bad arguments");
+  const size_t bh = (size_t)B * H, bg = 4 * bh, off = (size_t)gate * H;
+  const float scale = 1.0f / sqrtf((float)M);
+  int k = 0;  // dcs2 (2,B,H): dc ping-pong, [0] holds dc_T on entry; the final dc_0 is in dcs2[T & 1]
+  for (int t = T - 1; t >= 0; --t) {
+    int rc = blm_lstm_cell_ovr_bwd2(dh, dy + t * bh, dcs2 + k * bh, cs + t * bh, cs + (t + 1) * bh, ga + t * bg, gate, dgates + t * bg,
+                                    da + t * bh, dcs2 + (k ^ 1) * bh, B, H, stream);                                 // dh_t = recurrent part + dy_t
+    if (!rc) rc = blm_lstm_step_dh(da + t * bh, cwt, ds, B, GP, H, stream);                                        // d s = d a . [W | b]
+    if (!rc) rc = blm_gpnn2_actsum_bwd(ds, feat + (size_t)t * B * MP, df + (size_t)t * B * GP, B, M, MP, GP, scale, acts, stream);
+    if (!rc) rc = blm_lstm_step_dh_ld(df + (size_t)t * B * GP, Fp + (size_t)(nF > 1 ? t : 0) * H * GP, dgates + t * bg + off, 4 * H, B, H,
+                                      GP, stream);                                                                  // d pre -> gate's slot
+    if (!rc) rc = blm_lstm_step_dh(dgates + t * bg, w_hh_t, dh, B, H, 4 * H, stream);                               // dh_{t-1}
+    if (rc) return rc;
+    k ^= 1;
+  }
+  return BLM_OK;
 }

@@ -414,6 +414,110 @@ extern "C" int blm_sample_weight_bwd(const float* dw, int64_t rows, int64_t cols
   return BLM_OK;
 }
 
+// ---- GPNN2 inside the GP-LSTM cells: T frequency matrices per forward (model.py:2062-2065 at every call of the time loop)
+// F_t = mean + exp(lgstd) * eps_t, eps_t from the Philox stream (seed, stream, step0 + t) with the element index u * M + m
+// that blm_sample_weight uses, or from eps_all (T,H,M).  Written in the two operand layouts of the per-step products:
+// FT (T, MP, H) = F_t^T with zero rows m >= M, and Fp (T, H, GP) = F_t with zero columns m >= M.
+__global__ __launch_bounds__(TPB) void gpnn2_sample_steps_kernel(const float* __restrict__ mean, const float* __restrict__ lgstd,
+                                                                 const float* __restrict__ eps_all, blm_rng rng, int T, int H, int M,
+                                                                 int MP, int GP, float* __restrict__ FT, float* __restrict__ Fp) {
+  const long per = (long)H * GP, total = (long)T * per;
+  for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+    const int t = (int)(i / per);
+    const long r = i - (long)t * per;
+    const int u = (int)(r / GP), m = (int)(r - (long)u * GP);
+    float f = 0.f;
+    if (m < M) {
+      const unsigned idx = (unsigned)u * (unsigned)M + (unsigned)m;
+      float e;
+      if (eps_all) e = eps_all[((long)t * H + u) * M + m];
+      else {
+        blm_variational v{};
+        v.rng = rng;
+        v.rng.step = rng.step + (uint32_t)t;
+        e = eps_at(v, idx);
+      }
+      f = mean[idx] + __expf(lgstd[idx]) * e;
+    }
+    Fp[i] = f;
+    if (m < MP) FT[((long)t * MP + m) * H + u] = f;
+  }
+}
+
+// d mean[u,m] += sum_t G_t[u,m],  d lgstd[u,m] += exp(lgstd[u,m]) * sum_t eps_t[u,m] * G_t[u,m],  G_t = pre_t^T d f_t
+// (pre (T,B,H): the GPNN2's inputs; df (T,B,GP): the gradients of its features).  A block owns a 16 x 16 tile of (u, m).
+__global__ __launch_bounds__(256) void gpnn2_freq_grad_kernel(const float* __restrict__ pre, const float* __restrict__ df,
+                                                              const float* __restrict__ eps_all, blm_rng rng,
+                                                              const float* __restrict__ lgstd, float* __restrict__ dmean,
+                                                              float* __restrict__ dlgstd, int T, int B, int H, int M, int GP) {
+  __shared__ float sp[64][17], sd[64][17];
+  const int ui = threadIdx.x >> 4, mi = threadIdx.x & 15;
+  const int u0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int u = u0 + ui, m = m0 + mi;
+  const bool ok = u < H && m < M;
+  float am = 0.f, al = 0.f;
+  for (int t = 0; t < T; ++t) {
+    float dot = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+        const int b = e >> 4, c = e & 15;
+        const bool bin = b0 + b < B;
+        sp[b][c] = (bin && u0 + c < H) ? pre[((long)t * B + b0 + b) * H + u0 + c] : 0.f;
+        sd[b][c] = (bin && m0 + c < GP) ? df[((long)t * B + b0 + b) * GP + m0 + c] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int b = 0; b < 64; ++b) dot += sp[b][ui] * sd[b][mi];
+    }
+    if (ok) {
+      const unsigned idx = (unsigned)u * (unsigned)M + (unsigned)m;
+      float e;
+      if (eps_all) e = eps_all[((long)t * H + u) * M + m];
+      else {
+        blm_variational v{};
+        v.rng = rng;
+        v.rng.step = rng.step + (uint32_t)t;
+        e = eps_at(v, idx);
+      }
+      am += dot;
+      al += dot * e;
+    }
+  }
+  if (ok) {
+    const long idx = (long)u * M + m;
+    if (dmean) dmean[idx] += am;
+    if (dlgstd) dlgstd[idx] += al * __expf(lgstd[idx]);
+  }
+}
+
+extern "C" int blm_gpnn2_sample_steps(const float* mean, const float* lgstd, const float* eps_all, const blm_rng* rng0, int T,
+                                      int H, int M, int MP, int GP, float* FT, float* Fp, void* stream) {
+  if (!mean || !lgstd || (!eps_all && !rng0) || !FT || !Fp || T < 0 || H <= 0 || M <= 0 || MP < M || GP < MP)
+    return blm_fail(BLM_ERR_INVALID, "blm_gpnn2_sample_steps: bad arguments");
+  if (T == 0) return BLM_OK;
+  blm_rng r{};
+  if (rng0) r = *rng0;
+  hipLaunchKernelGGL(gpnn2_sample_steps_kernel, dim3(grid_for((long)T * H * GP)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
+                     mean, lgstd, eps_all, r, T, H, M, MP, GP, FT, Fp);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_gpnn2_freq_grad(const float* pre, const float* df, const float* eps_all, const blm_rng* rng0,
+                                   const float* lgstd, float* dmean, float* dlgstd, int T, int B, int H, int M, int GP,
+                                   void* stream) {
+  if (!pre || !df || (!eps_all && !rng0) || !lgstd || (!dmean && !dlgstd) || T < 0 || B < 0 || H <= 0 || M <= 0 || GP < M)
+    return blm_fail(BLM_ERR_INVALID, "blm_gpnn2_freq_grad: bad arguments");
+  if (T == 0 || B == 0) return BLM_OK;
+  blm_rng r{};
+  if (rng0) r = *rng0;
+  hipLaunchKernelGGL(gpnn2_freq_grad_kernel, dim3((H + 15) / 16, (M + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     pre, df, eps_all, r, lgstd, dmean, dlgstd, T, B, H, M, GP);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
 extern "C" int blm_philox_normal(float* out, int64_t n, const blm_rng* rng, void* stream) {
   if (!out || !rng || n < 0) return blm_fail(BLM_ERR_INVALID, "blm_philox_normal: bad arguments");
   if (n == 0) return BLM_OK;

@@ -459,6 +459,22 @@ class GPNN2(_Site):
         a = (z + mix) if self.skip_act else mix
         return self.coef(a * (1.0 / math.sqrt(self.n_MC_terms)))
 
+    def step_noises(self, T):
+        """The noise of calls 0..T-1 of one forward exactly as ``forward(x, call)`` would draw it (None: mean frequencies)."""
+        if not (self.training and not self.deterministic):
+            return None
+        out = []
+        for call in range(T):
+            ov = self.eps_override
+            if isinstance(ov, (list, tuple)):
+                ov = ov[call]
+            if ov is not None:
+                out.append(NoiseSpec(eps=ov))
+            else:
+                st = self._st()
+                out.append(NoiseSpec(None, st.seed, self._site_base, (st.step * 1024 + call) & 0xFFFFFFFF))
+        return out
+
     def reset_prior(self):
         self.frequency_mean_prior = torch.zeros_like(self.frequency_mean.data)
         self.frequency_lgstd_prior = torch.zeros_like(self.frequency_lgstd.data)
@@ -968,6 +984,14 @@ class GPLSTMCell(_LoopCell):
         input projection (6 / 7).  Step-wise, like the reference."""
         gt, H = self.gate_type, self.hidden_size
         T = inputs.shape[0]
+        gp = self.gpnn
+        if 1 <= gt <= 4 and gp.skip_act and ops.lstm_recurrent_gpnn2_supported(H, gp.n_MC_terms):
+            # the whole layer from one autograd node, six skinny launches per step (ops._LSTMRecurrentGPNN2)
+            xw = ops.linear(inputs, self.weights_ih, 2.0 * self.bias_ih)  # bias_ih enters on both sides, as in the reference
+            y, hT, cT = ops.lstm_recurrent_gpnn2(xw, hx, cx, self.weights_hh, gp.coef.weight, gp.coef.bias, gp.frequency_mean,
+                                                 gp.frequency_lgstd, gp.step_noises(T), gt - 1,
+                                                 sum(1 << GPNN._SLOT[a] for a in gp.act_set))
+            return y, (hT, cT)
         xw_all = None if gt == 7 else ops.linear(inputs, self.weights_ih, self.bias_ih)
         outs = []
         zero = None

@@ -10,6 +10,7 @@ the Functions return ``None`` for parameters.
 There is no CPU path: every entry point raises on non-GPU tensors.
 """
 import ctypes as C
+import math
 import os
 import threading
 from dataclasses import dataclass
@@ -1538,6 +1539,135 @@ class _LSTMRecurrentGP(torch.autograd.Function):
             drb = torch.empty(G, device=dev, dtype=torch.float32)
             _colsum_into(dzs, T * B, G, drb, accumulate=False)
         return dgates, dh0, dcs[k], dw, dcoef, None, drb, dwc
+
+
+class _LSTMRecurrentGPNN2(torch.autograd.Function):
+    """GP-LSTM cell whose gate ``g`` (0 i, 1 f, 2 g, 3 o) is a GPNN2 of that gate's pre-activation, with FRESH frequencies
+    at every time step (GPLSTMCell gate types 1-4 with type digit 4, model.py:1698-1702, 1763-1770; GPNN2 :2061-2076):
+        z4_t  = h_{t-1} W_hh^T                                   (B,4H)   blm_lstm_step_dh
+        pre_t = xw_t[:, g] + z4_t[:, g]                          (B,H)    blm_add_cols
+        f_t   = pre_t F_t,   F_t = mean + eps_t * exp(lgstd)     (B,M)    blm_lstm_step_dh on F_t^T
+        s_t   = (f_t + sum_a a(f_t)) / sqrt(M) | 1               (B,Mp)   blm_gpnn2_actsum_fwd
+        a_t   = s_t [coef.weight | coef.bias]^T                  (B,H)    blm_lstm_step_dh
+        cell update with a_t as gate g's activation                       blm_lstm_cell_ovr_fwd
+    Six skinny launches per step from ONE autograd node (the step-wise form paid ~10 launches plus ten autograd nodes per
+    step); every product has a fixed summation order (no split-K atomics).  The T frequency matrices are sampled up front in
+    one launch (blm_gpnn2_sample_steps) with the counters the step-wise path uses, so both paths see the same noise.
+    Backward mirrors it with five launches per step; the weight gradients are batched over all steps afterwards, the
+    per-step frequency gradients pre_t^T d f_t become d mean / d lgstd in one launch (blm_gpnn2_freq_grad, eps_t regenerated)."""
+
+    MP, GP = 160, 192  # feature columns padded to the products' tile rules (output % 16, contraction % 64); 150 MC terms
+
+    @staticmethod
+    def _noise(noises, dev):
+        """-> (eps_all (T,H,M) or None, rng of call 0 or None): injected tensors are stacked, Philox specs must be the
+        consecutive steps GPNN2.step_noises hands out."""
+        if noises is None:
+            return None, None
+        if noises[0].eps is not None:
+            return torch.stack([_f32(n.eps, "eps") for n in noises]).contiguous(), None
+        for t, n in enumerate(noises):
+            if n.eps is not None or n.seed != noises[0].seed or n.tensor_id != noises[0].tensor_id or n.step != ((noises[0].step + t) & 0xFFFFFFFF):
+                raise BayesLMError("lstm_recurrent_gpnn2: the per-step noise must be one Philox stream at consecutive steps")
+        return None, noises[0].rng()
+
+    @staticmethod
+    def forward(ctx, xw, h0, c0, w_hh, coef_w, coef_b, fmean, flgstd, noises, g, acts):
+        xw, w_hh = _f32(xw, "xw"), _f32(w_hh, "w_hh")
+        T, B, G4 = xw.shape
+        H = G4 // 4
+        M = fmean.shape[1]
+        MP, GP = _LSTMRecurrentGPNN2.MP, _LSTMRecurrentGPNN2.GP
+        if M >= MP or H % 64 != 0:
+            raise BayesLMError("lstm_recurrent_gpnn2: needs n_MC_terms < %d and H %% 64 == 0" % MP)
+        dev = xw.device
+        L.require_gfx950()
+        lib_, st = lib(), stream()
+        new = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
+        nF = T if noises is not None else 1
+        # F_t^T with zero rows m >= M (the w_t operand of the feature product) and F_t padded along m (the w_t operand of
+        # d pre = d f . F_t^T), all T of them in ONE launch, with the noise of calls 0..T-1 of the step-wise path
+        FT, Fp = new(nF, MP, H), new(nF, H, GP)
+        eps_all, rng0 = _LSTMRecurrentGPNN2._noise(noises, dev)
+        if noises is None:
+            eps_all = torch.zeros(1, H, M, device=dev, dtype=torch.float32)  # mean frequencies at every step
+        check(lib_.blm_gpnn2_sample_steps(ptr(_f32(fmean, "frequency_mean")), ptr(_f32(flgstd, "frequency_lgstd")), ptr(eps_all),
+                                          C.byref(rng0) if rng0 is not None else None, nF, H, M, MP, GP, ptr(FT), ptr(Fp), st),
+              "blm_gpnn2_sample_steps")
+        cwp = torch.zeros(H, GP, device=dev, dtype=torch.float32)      # [coef.weight | coef.bias | 0]
+        cwp[:, :M].copy_(coef_w)
+        cwp[:, M].copy_(coef_b)
+        hs, cs = new(T + 1, B, H), new(T + 1, B, H)
+        hs[0].copy_(h0)
+        cs[0].copy_(c0)
+        z4, ga = new(T, B, G4), new(T, B, G4)
+        pre, feat, sact, aact = new(T, B, H), new(T, B, MP), new(T, B, GP), new(T, B, H)
+        check(lib_.blm_lstm_gpnn2_seq_fwd(ptr(xw), ptr(w_hh), ptr(FT), nF, ptr(cwp), ptr(hs), ptr(cs), ptr(z4), ptr(ga), ptr(pre), ptr(feat),
+                                          ptr(sact), ptr(aact), g, acts, T, B, H, M, MP, GP, st), "blm_lstm_gpnn2_seq_fwd")
+        if _STATE_TAP is not None:
+            _STATE_TAP.layers.append((hs.index_select(0, _STATE_TAP.idx), cs.index_select(0, _STATE_TAP.idx)))
+        ctx.save_for_backward(hs, cs, ga, w_hh, pre, feat, sact, Fp, cwp)
+        ctx.meta = (g, acts, M, fmean, flgstd, noises, coef_w.requires_grad, coef_b.requires_grad)
+        return hs[1:], hs[T], cs[T]
+
+    @staticmethod
+    def backward(ctx, dy, dhT, dcT):
+        hs, cs, ga, w_hh, pre, feat, sact, Fp, cwp = ctx.saved_tensors
+        g, acts, M, fmean, flgstd, noises, need_cw, need_cb = ctx.meta
+        T, B, G4 = ga.shape
+        H = G4 // 4
+        MP, GP = _LSTMRecurrentGPNN2.MP, _LSTMRecurrentGPNN2.GP
+        dev = ga.device
+        dy = _f32(dy, "dy")
+        lib_, st = lib(), stream()
+        new = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
+        nF = Fp.shape[0]
+        w_t = new(H, G4)
+        check(lib_.blm_transpose(ptr(w_hh), ptr(w_t), G4, H, st), "blm_transpose")
+        cwt = new(GP, H)
+        check(lib_.blm_transpose(ptr(cwp), ptr(cwt), H, GP, st), "blm_transpose")
+        dgates, da, ds, df = new(T, B, G4), new(T, B, H), new(B, GP), new(T, B, GP)
+        dh = torch.zeros(B, H, device=dev, dtype=torch.float32) if dhT is None else _f32(dhT, "dhT").clone()
+        dcs = torch.zeros(2, B, H, device=dev, dtype=torch.float32)
+        if dcT is not None:
+            dcs[0].copy_(dcT)
+        scale = 1.0 / math.sqrt(M)
+        check(lib_.blm_lstm_gpnn2_seq_bwd(ptr(dy), ptr(w_t), ptr(Fp), nF, ptr(cwt), ptr(cs), ptr(ga), ptr(feat), ptr(dh), ptr(dcs),
+                                          ptr(dgates), ptr(da), ptr(ds), ptr(df), g, acts, T, B, H, M, MP, GP, st), "blm_lstm_gpnn2_seq_bwd")
+        k = T & 1
+        dw = torch.empty_like(w_hh)
+        gemm(L.GEMM_TN, dgates, hs, dw, G4, H, T * B, G4, H, H)  # hs[0:T] = h_{t-1}
+        dcw = dcb = None
+        if need_cw or need_cb:
+            dcwp = new(H, GP)
+            gemm(L.GEMM_TN, da, sact, dcwp, H, GP, T * B, H, GP, GP)  # column M of s is the constant 1: its row is d coef.bias
+            dcw = dcwp[:, :M].contiguous() if need_cw else None
+            dcb = dcwp[:, M].contiguous() if need_cb else None
+        if fmean.requires_grad or flgstd.requires_grad:
+            # d F_t = pre_t^T d f_t (contraction over the B rows of ONE step: the frequencies differ per step); d mean is their
+            # sum, d lgstd their eps_t-weighted sum times sigma -- one launch, eps_t regenerated from the Philox counters
+            eps_all, rng0 = _LSTMRecurrentGPNN2._noise(noises, dev)
+            if noises is None:  # mean frequencies (deterministic GPNN2): d mean only
+                eps_all = torch.zeros(1, H, M, device=dev, dtype=torch.float32)
+                pre_s, df_s, Tn = pre.reshape(1, T * B, H), df.reshape(1, T * B, GP), 1
+            else:
+                pre_s, df_s, Tn = pre, df, T
+            check(lib_.blm_gpnn2_freq_grad(ptr(pre_s), ptr(df_s), ptr(eps_all), C.byref(rng0) if rng0 is not None else None,
+                                           ptr(flgstd), ptr(_grad_buf(fmean)) if fmean.requires_grad else None,
+                                           ptr(_grad_buf(flgstd)) if (flgstd.requires_grad and noises is not None) else None,
+                                           Tn, pre_s.shape[1], H, M, GP, st), "blm_gpnn2_freq_grad")
+            _notify(fmean, flgstd)
+        return dgates, dh, dcs[k], dw, dcw, dcb, None, None, None, None, None
+
+
+def lstm_recurrent_gpnn2_supported(H, n_mc):
+    return H % 64 == 0 and n_mc < _LSTMRecurrentGPNN2.MP
+
+
+def lstm_recurrent_gpnn2(xw, h0, c0, w_hh, coef_w, coef_b, fmean, flgstd, noises, gate, acts):
+    """-> (y (T,B,H), hT, cT).  ``noises``: list of T NoiseSpec (training) or None (mean frequencies); ``acts``: bit set of the
+    GPNN2's activations in the mixture's slot order (1 tanh, 2 sigmoid, 4 relu, 8 gelu)."""
+    return _LSTMRecurrentGPNN2.apply(xw, h0, c0, w_hh, coef_w, coef_b, fmean, flgstd, noises, int(gate), int(acts))
 
 
 def lstm_recurrent_gp_supported(H, w_rec):

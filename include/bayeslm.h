@@ -424,6 +424,10 @@ int blm_lstm_cell_ovr_fwd(const float* xw, const float* hw, const float* c_prev,
 int blm_lstm_cell_ovr_bwd(const float* dh, const float* dc_next, const float* c_prev, const float* c,
                           const float* gates_act, int gate_idx, float* dgates, float* d_ovr, float* dc_prev, int B,
                           int H, void* stream);
+/* Same with the incoming hidden gradient as two addends (dh2 may be NULL), like blm_lstm_cell_bwd2. */
+int blm_lstm_cell_ovr_bwd2(const float* dh, const float* dh2, const float* dc_next, const float* c_prev, const float* c,
+                           const float* gates_act, int gate_idx, float* dgates, float* d_ovr, float* dc_prev, int B, int H,
+                           void* stream);
 /* Elementwise GPNN mixture on pre-activations z (M,N): out = sum_i act_i(z) coef[i,n];
  * backward dz = dout * sum_i act_i'(z) coef[i,n]   (model.py:1885-1899). */
 int blm_gp_mix_fwd(const float* z, const float* coef, float* out, int M, int N, void* stream);
@@ -501,6 +505,47 @@ int blm_lstm_search_step_bwd(const float* dz8_t, const float* w8_t, const float*
  * One launch, fixed summation order, no memset / atomics.  Needs H % 16 == 0, G % 64 == 0, 16-byte
  * aligned operands (BLM_ERR_UNSUPPORTED otherwise: use blm_gemm). */
 int blm_lstm_step_dh(const float* dz, const float* w_t, float* dh_out, int B, int H, int G, void* stream);
+/* The same product written into a column window of a wider matrix: dh_out has row stride ldo >= H. */
+int blm_lstm_step_dh_ld(const float* dz, const float* w_t, float* dh_out, int64_t ldo, int B, int H, int G, void* stream);
+
+/* GPNN2 (random-feature GP, model.py:2036-2076) between its two products: features f (rows, ld_f) -> s (rows, ld_s),
+ *   s[:, m] = (f + sum_{a in acts} a(f)) * scale   for m < M   (acts: bit set in the slot order 1 tanh, 2 sigmoid, 4 relu,
+ *   s[:, M] = 1, zeros beyond                                   8 gelu; model.py:2069-2075 with skip_act)
+ * The 1-column lets the caller fold coef.bias into a coefficient matrix padded to ld_s columns.  Backward:
+ *   df[:, m] = ds[:, m] * (1 + sum a'(f)) * scale for m < M, 0 on the padding; ds and df have row stride ld_s. */
+int blm_gpnn2_actsum_fwd(const float* f, float* s, int64_t rows, int M, int ld_f, int ld_s, float scale, int acts, void* stream);
+int blm_gpnn2_actsum_bwd(const float* ds, const float* f, float* df, int64_t rows, int M, int ld_f, int ld_s, float scale,
+                         int acts, void* stream);
+/* out[r, c] = a[r, c] + b[r, c] for r < rows, c < cols on column windows of wider matrices (row strides lda / ldb / ldo):
+ * the pre-activation of ONE gate, xw_t[:, gH:(g+1)H] + (h W_hh^T)[:, gH:(g+1)H], as a contiguous operand. */
+int blm_add_cols(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int64_t rows, int cols,
+                 void* stream);
+/* The T frequency matrices of one forward of a GPNN2 that is called at every time step (GPLSTMCell with type digit 4,
+ * model.py:1763-1770 -> :2062-2065): F_t = mean + exp(lgstd) * eps_t (H x M), eps_t = eps_all[t] (T,H,M) or the Philox
+ * stream (rng0->seed, rng0->stream, rng0->step + t) with blm_sample_weight's element order.  Outputs, zero padded:
+ * FT (T, MP, H) = F_t^T and Fp (T, H, GP) = F_t -- the operands of the per-step feature product and of its input gradient. */
+int blm_gpnn2_sample_steps(const float* mean, const float* lgstd, const float* eps_all, const blm_rng* rng0, int T, int H, int M,
+                           int MP, int GP, float* FT, float* Fp, void* stream);
+/* Their gradient in one launch: with G_t = pre_t^T df_t (pre (T,B,H) the GPNN2 inputs, df (T,B,GP) the feature gradients),
+ *   dmean += sum_t G_t,   dlgstd += exp(lgstd) * sum_t eps_t * G_t      (either may be NULL). */
+int blm_gpnn2_freq_grad(const float* pre, const float* df, const float* eps_all, const blm_rng* rng0, const float* lgstd,
+                        float* dmean, float* dlgstd, int T, int B, int H, int M, int GP, void* stream);
+/* The time loops of a GP-LSTM layer whose gate `gate` (0 i, 1 f, 2 g, 3 o) is a GPNN2 of its pre-activation with fresh
+ * frequencies per step (GPLSTMCell gate types 1-4, type digit 4; model.py:1763-1770), as ONE call per direction.  Per step
+ *   z4_t = h_{t-1} w_hh^T;  pre_t = xw_t[:, gate] + z4_t[:, gate];  f_t = pre_t F_t;  s_t = actsum(f_t) | 1;
+ *   a_t = s_t cwp^T;  cell update with a_t as that gate's activation        (cwp (H,GP) = [coef.weight | coef.bias | 0])
+ * FT (nF,MP,H) / Fp (nF,H,GP) from blm_gpnn2_sample_steps, nF = T or 1 (mean frequencies at every step).  Buffers
+ * (T rows each unless noted): hs, cs (T+1,B,H) with row 0 = initial state; z4, ga (B,4H); pre, aact (B,H); feat (B,MP);
+ * sact (B,GP).  Backward walks t = T-1..0: dh (B,H) holds dh_T on entry and dh_0 on exit, dcs2 (2,B,H) ping-pongs dc
+ * ([0] = dc_T on entry, dc_0 ends in [T & 1]); it fills dgates (T,B,4H) (= d xw, the gate's slot holding d pre),
+ * da (T,B,H), df (T,B,GP); ds (B,GP) is scratch; w_hh_t = w_hh^T (H,4H), cwt = cwp^T (GP,H).
+ * Needs H % 64 == 0, MP % 16 == 0, GP % 64 == 0, M < MP <= GP (BLM_ERR_UNSUPPORTED from the products otherwise). */
+int blm_lstm_gpnn2_seq_fwd(const float* xw, const float* w_hh, const float* FT, int nF, const float* cwp, float* hs, float* cs,
+                           float* z4, float* ga, float* pre, float* feat, float* sact, float* aact, int gate, int acts, int T, int B,
+                           int H, int M, int MP, int GP, void* stream);
+int blm_lstm_gpnn2_seq_bwd(const float* dy, const float* w_hh_t, const float* Fp, int nF, const float* cwt, const float* cs,
+                           const float* ga, const float* feat, float* dh, float* dcs2, float* dgates, float* da, float* ds,
+                           float* df, int gate, int acts, int T, int B, int H, int M, int MP, int GP, void* stream);
 
 /* torch.optim.Adam(lr, betas, eps, weight_decay) on one tensor (architect.py:33): g += wd*p;
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr * (m/(1-b1^step)) / (sqrt(v/(1-b2^step)) + eps).

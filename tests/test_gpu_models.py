@@ -617,6 +617,72 @@ def test_gauss_rnn_fused_steps_match_oracle(dev, gp):
         assert grad_close(p.grad, leaf[k].grad), k
 
 
+@pytest.mark.parametrize("gp", ["34", "14", "24", "44", "340", "3434", "3464"])
+def test_gauss_rnn_gpnn2_fused_steps_match_oracle(dev, gp):
+    """H = 64: GP cells whose gate is a GPNN2 of its pre-activation with fresh frequencies at every time step (type digit 4,
+    model.py:1763-1770) run from one autograd node with six skinny launches per step (ops._LSTMRecurrentGPNN2).  Injected
+    per-step eps, two windows with the carried state; logits and every gradient against the CPU oracle (which the
+    gauss_rnn_{34,14,...} fixtures pin to the reference); then Philox mode: same step -> same result, fused == step-wise."""
+    from bayeslms_amd import model as M, ops
+    from oracle import bayes_oracle as O
+    torch.manual_seed(13)
+    V, H, T, B = 30, 64, 5, 4
+    m = M.GaussRNNModel("LSTM", V, H, H, 2, 0.0, True, gp).to(dev)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if "weights" in k or "frequency_mean" in k:
+                p.mul_(3.0)
+    cells = [0] if len(gp) < 3 else ([1] if len(gp) == 3 else [c for c in (0, 1) if gp[2 * c + 1] == "4"])
+    fused = [c for c in cells if 1 <= m.rnn.rnn[c].gate_type <= 4]
+    assert fused and all(ops.lstm_recurrent_gpnn2_supported(H, m.rnn.rnn[c].gpnn.n_MC_terms) for c in fused)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(6)
+    x1, x2 = torch.randint(0, V, (T, B), generator=g), torch.randint(0, V, (T, B), generator=g)
+    tgt = torch.randint(0, V, (T * B,), generator=g)
+    nmc = m.rnn.rnn[cells[0]].gpnn.n_MC_terms
+    eps = [{c: [torch.randn(m.rnn.rnn[c].gpnn.input_dim, nmc, generator=g) for _ in range(T)] for c in cells} for _ in range(2)]
+    m.train()
+    hid = m.init_hidden(B)
+    outs = []
+    for w, x in enumerate((x1, x2)):
+        for c in cells:
+            m.rnn.rnn[c].gpnn.eps_override = [e.to(dev) for e in eps[w][c]]
+        logits, hid = m(x.to(dev), M.repackage_hidden(hid))
+        outs.append(logits.detach().clone())
+    mle, _ = ops.cross_entropy(logits.view(-1, V), tgt.to(dev))
+    mle.backward()
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    zeros = (torch.zeros(2, B, H), torch.zeros(2, B, H))
+    r1, hr = O.gauss_rnn_lm(x1, zeros, leaf, gp, eps[0])
+    r2, hr = O.gauss_rnn_lm(x2, tuple(h.detach() for h in hr), leaf, gp, eps[1])
+    assert rel(outs[0], r1) < TOL and rel(outs[1], r2) < TOL
+    O.cross_entropy_mean(r2.view(-1, V), tgt).backward()
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or leaf[k].grad is None:
+            continue
+        assert p.grad is not None, k
+        assert grad_close(p.grad, leaf[k].grad), k
+    # Philox mode: the fused layer draws the noise the step-wise layer draws (same counters per call)
+    for c in cells:
+        m.rnn.rnn[c].gpnn.eps_override = None
+    m.set_seed(3)
+    m.set_step(5)
+    with torch.no_grad():
+        a, _ = m(x1.to(dev), m.init_hidden(B))
+        b, _ = m(x1.to(dev), m.init_hidden(B))
+        orig = ops.lstm_recurrent_gpnn2_supported
+        ops.lstm_recurrent_gpnn2_supported = lambda *a_: False  # the step-wise loop of the same cells
+        try:
+            c2, _ = m(x1.to(dev), m.init_hidden(B))
+        finally:
+            ops.lstm_recurrent_gpnn2_supported = orig
+        assert rel(a, c2) < 1e-5
+        m.set_step(6)
+        d, _ = m(x1.to(dev), m.init_hidden(B))
+    assert torch.equal(a, b) and not torch.equal(a, d)
+
+
 @pytest.mark.parametrize("vp", ["00", "01", "10", "11"])
 def test_variational_rnn_golden(dev, vp):
     from bayeslms_amd import model as M, ops
