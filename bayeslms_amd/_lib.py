@@ -56,6 +56,14 @@ class GemmArgs(C.Structure):
                 ("colsum_a", C.c_void_p)]
 
 
+class Gpnn2Seq(C.Structure):
+    """blm_gpnn2_seq (include/bayeslm.h)."""
+    _fields_ = ([("abi_version", C.c_uint32), ("mode", C.c_int32), ("gate", C.c_int32), ("acts", C.c_int32)]
+                + [(n, C.c_int32) for n in ("T", "B", "H", "M", "MP", "GP", "nF")]
+                + [(n, C.c_void_p) for n in ("xw", "w_hh", "w_hh_t", "FT", "Fp", "cwp", "cwt", "hs", "cs", "ga", "z4", "pre", "feat",
+                                             "sact", "gout", "dy", "dh", "dcs2", "dgates", "da", "ds", "df")])
+
+
 class GemmPlan(C.Structure):
     _fields_ = [("tile", C.c_int32), ("splits", C.c_int32), ("source", C.c_int32), ("model_us", C.c_float)]
 
@@ -131,13 +139,14 @@ SIGNATURES = {
     "blm_lstm_search_step_bwd": (_i, [_vp] * 11 + [_i, _i, _vp]),
     "blm_lstm_step_dh": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "blm_lstm_step_dh_ld": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "blm_lstm_step_dh_act": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _i, _f, _i, _vp]),
     "blm_gpnn2_actsum_fwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _f, _i, _vp]),
     "blm_gpnn2_actsum_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _f, _i, _vp]),
     "blm_add_cols": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "blm_gpnn2_sample_steps": (_i, [_vp, _vp, _vp, _rngp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "blm_gpnn2_freq_grad": (_i, [_vp, _vp, _vp, _rngp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "blm_lstm_gpnn2_seq_fwd": (_i, [_vp, _vp, _vp, _i, _vp] + [_vp] * 8 + [_i] * 8 + [_vp]),
-    "blm_lstm_gpnn2_seq_bwd": (_i, [_vp, _vp, _vp, _i, _vp] + [_vp] * 9 + [_i] * 8 + [_vp]),
+    "blm_lstm_gpnn2_seq_fwd": (_i, [C.POINTER(Gpnn2Seq), _vp]),
+    "blm_lstm_gpnn2_seq_bwd": (_i, [C.POINTER(Gpnn2Seq), _vp]),
     "blm_lstm_cell_ovr_bwd2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "blm_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp]),
     "blm_clip_sgd_multi_wd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _i, _f, _f, _vp]),

@@ -493,7 +493,31 @@ struct LstmBwdP {
   int B, H;
   int G;                                  // contraction length = row length of dg and wt: 4H (LSTM), 8H (search cell)
   long ldo;                               // row stride of dh_out (blm_lstm_step_dh_ld: the product lands in a column window)
+  // blm_lstm_step_dh_act: the GPNN2 activation sum (elementwise.hip gpnn2_actsum_*) applied to the product on its way out
+  //   act_mode 1: the product is the feature matrix f -> act_feat[.., ld_f] = f,  dh_out = actsum(f) * scale | 1 | 0
+  //   act_mode 2: the product is d s               -> dh_out = d s * actsum'(act_feat) * scale on columns < act_M, else 0
+  float* act_feat;
+  int act_mode, act_M, act_ldf, acts;
+  float act_scale;
 };
+
+__device__ __forceinline__ float gpnn2_actsum_dev(float z, int acts) {
+  float v = z;
+  if (acts & 1) v += tanhf(z);
+  if (acts & 2) v += sigmoidf_(z);
+  if (acts & 4) v += fmaxf(z, 0.f);
+  if (acts & 8) v += gelu_erf(z);
+  return v;
+}
+__device__ __forceinline__ float gpnn2_dactsum_dev(float z, int acts) {
+  float d = 1.f;
+  if (acts & 1) { const float th = tanhf(z); d += 1.f - th * th; }
+  if (acts & 2) { const float sg = sigmoidf_(z); d += sg * (1.f - sg); }
+  if (acts & 4) d += z > 0.f ? 1.f : 0.f;
+  if (acts & 8) d += dgelu_erf(z);
+  return d;
+}
+
 
 // PIPE: software-pipelined K loop; TAIL = false: whole 32-float chunks only (no zero-fill selects, scalar chunk offsets) -- see the forward kernel
 template <int RING, bool REFILL = true, int NW = 4, bool PIPE = false, bool TAIL = true>
@@ -735,6 +759,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
   if constexpr (NW == 8)
     dh += (red[(4 * 16 + brow) * BRSTR + ecol] + red[(5 * 16 + brow) * BRSTR + ecol]) +
           (red[(6 * 16 + brow) * BRSTR + ecol] + red[(7 * 16 + brow) * BRSTR + ecol]);
+  if (p.act_mode == 1) {  // wave-uniform
+    p.act_feat[(long)eb * p.act_ldf + ek] = dh;
+    dh = ek < p.act_M ? gpnn2_actsum_dev(dh, p.acts) * p.act_scale : (ek == p.act_M ? 1.f : 0.f);
+  } else if (p.act_mode == 2) {
+    dh = ek < p.act_M ? dh * gpnn2_dactsum_dev(p.act_feat[(long)eb * p.act_ldf + ek], p.acts) * p.act_scale : 0.f;
+  }
   if (p.dh_out) p.dh_out[(long)eb * p.ldo + ek] = dh;
   if (p.dg_out) {  // cell backward of the step that produced h_{t-1} (elementwise.hip lstm_cell_bwd_kernel)
     if (p.ovr == 5) e_cp = gp_mix(e_z, p.coef, H, ek);  // gate type 5: the cell saw the GPNN mixture of z = c_{t-2} Wg^T + b
@@ -986,7 +1016,7 @@ extern "C" int blm_lstm_step_bwd_gp(const float* dgates_t, const float* w_hh_t, 
   if (H % 32 != 0 || !al16(dgates_t) || !al16(w_hh_t))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_bwd: needs H % 32 == 0 and 16-byte aligned dgates_t / w_hh_t");
   LstmBwdP p{dgates_t, w_hh_t, dy_prev, dc_next, c_prev, c, gates_act, dgates_out, dc_prev, dh_out, z_prev, coef4, dact_out,
-             dz_out, (dgates_out && gate_ovr >= 0) ? gate_ovr : -1, B, H, 4 * H, (long)H};
+             dz_out, (dgates_out && gate_ovr >= 0) ? gate_ovr : -1, B, H, 4 * H, (long)H, nullptr, 0, 0, 0, 0, 0.f};
   return launch_step_bwd(p, stream);
 }
 
@@ -1004,7 +1034,7 @@ extern "C" int blm_lstm_search_step_bwd(const float* dz8_t, const float* w8_t, c
   if (H % 16 != 0 || !al16(dz8_t) || !al16(w8_t))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_search_step_bwd: needs H % 16 == 0 and 16-byte aligned dz8_t / w8_t");
   LstmBwdP p{dz8_t, w8_t, dy_prev, dc_next, c_prev, c, acts8, dz8_out, dc_prev, nullptr, nullptr, probs, partial, nullptr, 8,
-             B, H, 8 * H, (long)H};
+             B, H, 8 * H, (long)H, nullptr, 0, 0, 0, 0, 0.f};
   return launch_step_bwd(p, stream);
 }
 
@@ -1014,7 +1044,20 @@ extern "C" int blm_lstm_step_dh_ld(const float* dz, const float* w_t, float* dh_
   if (H % 16 != 0 || G % 64 != 0 || G == 0 || !al16(dz) || !al16(w_t))
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_dh: needs H % 16 == 0, G % 64 == 0 and 16-byte aligned dz / w_t");
   LstmBwdP p{dz, w_t, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dh_out, nullptr, nullptr, nullptr, nullptr, -1,
-             B, H, G, (long)ldo};
+             B, H, G, (long)ldo, nullptr, 0, 0, 0, 0, 0.f};
+  return launch_step_bwd(p, stream);
+}
+
+extern "C" int blm_lstm_step_dh_act(const float* dz, const float* w_t, float* out, int64_t ldo, int B, int H, int G, int act_mode,
+                                    float* feat, int ld_f, int M, float scale, int acts, void* stream) {
+  if (!dz || !w_t || !out || !feat || B < 0 || H < 0 || G < 0 || ldo < H || (act_mode != 1 && act_mode != 2) || M < 0 || M >= H ||
+      ld_f < (act_mode == 1 ? H : M) || (acts & ~15))
+    return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_dh_act: bad arguments");
+  if ((long)B * H == 0) return BLM_OK;
+  if (H % 16 != 0 || G % 64 != 0 || G == 0 || !al16(dz) || !al16(w_t))
+    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_dh_act: needs H % 16 == 0, G % 64 == 0 and 16-byte aligned dz / w_t");
+  LstmBwdP p{dz, w_t, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out, nullptr, nullptr, nullptr, nullptr, -1,
+             B, H, G, (long)ldo, feat, act_mode, M, ld_f, acts, scale};
   return launch_step_bwd(p, stream);
 }
 
@@ -1022,47 +1065,92 @@ extern "C" int blm_lstm_step_dh(const float* dz, const float* w_t, float* dh_out
   return blm_lstm_step_dh_ld(dz, w_t, dh_out, H, B, H, G, stream);
 }
 
-// ------------------------------------------------------------------ GPNN2 gate: the time loops (host side)
-// One C call per layer and direction instead of 11 ctypes calls per time step: the launches are 3-9 us each, the Python
-// side of a ctypes call costs about as much (the sequences themselves: ops._LSTMRecurrentGPNN2 / include/bayeslm.h).
-extern "C" int blm_lstm_gpnn2_seq_fwd(const float* xw, const float* w_hh, const float* FT, int nF, const float* cwp, float* hs,
-                                      float* cs, float* z4, float* ga, float* pre, float* feat, float* sact, float* aact, int gate,
-                                      int acts, int T, int B, int H, int M, int MP, int GP, void* stream) {
-  if (!xw || !w_hh || !FT || !cwp || !hs || !cs || !z4 || !ga || !pre || !feat || !sact || !aact || gate < 0 || gate > 3 || T < 0 ||
-      nF < 1 || (nF != 1 && nF != T))
-    return blm_fail(BLM_ERR_INVALID, "blm_lstm_gpnn2_seq_fwd: bad arguments");
-  const size_t bh = (size_t)B * H, bg = 4 * bh, off = (size_t)gate * H;
+// ------------------------------------------------------------------ GPNN2 cells: the time loops (host side)
+// One C call per layer and direction: the launches are 3-9 us each and form one dependent chain (the sequences themselves:
+// include/bayeslm.h blm_gpnn2_seq, ops._LSTMRecurrentGPNN2).
+extern "C" int blm_lstm_cell_fwd(const float*, const float*, const float*, float*, float*, float*, int, int, void*);
+extern "C" int blm_lstm_cell_bwd2(const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, int,
+                                  int, void*);
+
+static int gpnn2_seq_check(const blm_gpnn2_seq* q, bool bwd, const char* who) {
+  if (!q) return blm_fail(BLM_ERR_INVALID, "%s: null descriptor", who);
+  if (q->abi_version != BLM_ABI_VERSION) return blm_fail(BLM_ERR_ABI, "%s: abi_version mismatch", who);
+  if (q->mode < 0 || q->mode > 2 || q->T < 0 || q->B < 0 || q->H <= 0 || q->M <= 0 || q->MP <= q->M || q->GP < q->MP || q->nF < 1 ||
+      (q->nF != 1 && q->nF != q->T) || (q->mode == 0 && (q->gate < 0 || q->gate > 3)))
+    return blm_fail(BLM_ERR_INVALID, "%s: bad mode / shape", who);
+  if (!bwd && (!q->xw || !q->FT || !q->cwp || !q->hs || !q->cs || !q->ga || !q->feat || !q->sact || !q->gout ||
+               (q->mode == 0 && (!q->z4 || !q->pre)) || (q->mode != 2 && !q->w_hh)))
+    return blm_fail(BLM_ERR_INVALID, "%s: null buffer", who);
+  if (bwd && (!q->Fp || !q->cwt || !q->cs || !q->ga || !q->feat || !q->dy || !q->dh || !q->dcs2 || !q->dgates || !q->df ||
+              (q->mode != 2 && (!q->w_hh_t || !q->da)) || (q->mode == 1 && !q->gout)))
+    return blm_fail(BLM_ERR_INVALID, "%s: null backward buffer", who);
+  return BLM_OK;
+}
+
+extern "C" int blm_lstm_gpnn2_seq_fwd(const blm_gpnn2_seq* q, void* stream) {
+  if (int rc = gpnn2_seq_check(q, false, "blm_lstm_gpnn2_seq_fwd")) return rc;
+  const int T = q->T, B = q->B, H = q->H, M = q->M, MP = q->MP, GP = q->GP;
+  const size_t bh = (size_t)B * H, bg = 4 * bh, bm = (size_t)B * MP, bp = (size_t)B * GP, off = (size_t)q->gate * H;
   const float scale = 1.0f / sqrtf((float)M);
   for (int t = 0; t < T; ++t) {
-    int rc = blm_lstm_step_dh(hs + t * bh, w_hh, z4 + t * bg, B, 4 * H, H, stream);
-    if (!rc) rc = blm_add_cols(xw + t * bg + off, 4 * H, z4 + t * bg + off, 4 * H, pre + t * bh, H, B, H, stream);
-    if (!rc) rc = blm_lstm_step_dh(pre + t * bh, FT + (size_t)(nF > 1 ? t : 0) * MP * H, feat + (size_t)t * B * MP, B, MP, H, stream);
-    if (!rc) rc = blm_gpnn2_actsum_fwd(feat + (size_t)t * B * MP, sact + (size_t)t * B * GP, B, M, MP, GP, scale, acts, stream);
-    if (!rc) rc = blm_lstm_step_dh(sact + (size_t)t * B * GP, cwp, aact + t * bh, B, H, GP, stream);
-    if (!rc) rc = blm_lstm_cell_ovr_fwd(xw + t * bg, z4 + t * bg, cs + t * bh, aact + t * bh, gate, hs + (t + 1) * bh, cs + (t + 1) * bh,
-                                        ga + t * bg, B, H, stream);
+    const float* FT = q->FT + (size_t)(q->nF > 1 ? t : 0) * MP * H;
+    int rc = BLM_OK;
+    if (q->mode == 0) {  // a gate's pre-activation through the GPNN2
+      rc = blm_lstm_step_dh(q->hs + t * bh, q->w_hh, q->z4 + t * bg, B, 4 * H, H, stream);
+      if (!rc) rc = blm_add_cols(q->xw + t * bg + off, 4 * H, q->z4 + t * bg + off, 4 * H, q->pre + t * bh, H, B, H, stream);
+      if (!rc) rc = blm_lstm_step_dh_act(q->pre + t * bh, FT, q->sact + t * bp, GP, B, MP, H, 1, q->feat + t * bm, MP, M, scale, q->acts, stream);
+      if (!rc) rc = blm_lstm_step_dh(q->sact + t * bp, q->cwp, q->gout + t * bh, B, H, GP, stream);
+      if (!rc) rc = blm_lstm_cell_ovr_fwd(q->xw + t * bg, q->z4 + t * bg, q->cs + t * bh, q->gout + t * bh, q->gate, q->hs + (t + 1) * bh,
+                                          q->cs + (t + 1) * bh, q->ga + t * bg, B, H, stream);
+    } else if (q->mode == 1) {  // the cell state enters through the GPNN2: gout[t] = c_in
+      rc = blm_lstm_step_dh_act(q->cs + t * bh, FT, q->sact + t * bp, GP, B, MP, H, 1, q->feat + t * bm, MP, M, scale, q->acts, stream);
+      if (!rc) rc = blm_lstm_step_dh(q->sact + t * bp, q->cwp, q->gout + t * bh, B, H, GP, stream);
+      if (!rc) rc = blm_lstm_step_fwd(q->xw + t * bg, q->w_hh, q->hs + t * bh, q->gout + t * bh, q->hs + (t + 1) * bh, q->cs + (t + 1) * bh,
+                                      q->ga + t * bg, nullptr, B, H, stream);
+    } else {  // the hidden projection of all four gates is the GPNN2 of h: gout[t] = hw (B,4H), cwp is (4H,GP)
+      rc = blm_lstm_step_dh_act(q->hs + t * bh, FT, q->sact + t * bp, GP, B, MP, H, 1, q->feat + t * bm, MP, M, scale, q->acts, stream);
+      if (!rc) rc = blm_lstm_step_dh(q->sact + t * bp, q->cwp, q->gout + t * bg, B, 4 * H, GP, stream);
+      if (!rc) rc = blm_lstm_cell_fwd(q->xw + t * bg, q->gout + t * bg, q->cs + t * bh, q->hs + (t + 1) * bh, q->cs + (t + 1) * bh,
+                                      q->ga + t * bg, B, H, stream);
+    }
     if (rc) return rc;
   }
   return BLM_OK;
 }
 
-extern "C" int blm_lstm_gpnn2_seq_bwd(const float* dy, const float* w_hh_t, const float* Fp, int nF, const float* cwt, const float* cs,
-                                      const float* ga, const float* feat, float* dh, float* dcs2, float* dgates, float* da, float* ds,
-                                      float* df, int gate, int acts, int T, int B, int H, int M, int MP, int GP, void* stream) {
-  if (!dy || !w_hh_t || !Fp || !cwt || !cs || !ga || !feat || !dh || !dcs2 || !dgates || !da || !ds || !df || gate < 0 || gate > 3 ||
-      T < 0 || nF < 1 || (nF != 1 && nF != T))
-    return blm_fail(BLM_ERR_INVALID, "blm_lstm_gpnn2_seq_bwd: bad arguments");
-  const size_t bh = (size_t)B * H, bg = 4 * bh, off = (size_t)gate * H;
+extern "C" int blm_lstm_gpnn2_seq_bwd(const blm_gpnn2_seq* q, void* stream) {
+  if (int rc = gpnn2_seq_check(q, true, "blm_lstm_gpnn2_seq_bwd")) return rc;
+  const int T = q->T, B = q->B, H = q->H, M = q->M, MP = q->MP, GP = q->GP;
+  const size_t bh = (size_t)B * H, bg = 4 * bh, bm = (size_t)B * MP, bp = (size_t)B * GP, off = (size_t)q->gate * H;
   const float scale = 1.0f / sqrtf((float)M);
   int k = 0;  // dcs2 (2,B,H): dc ping-pong, [0] holds dc_T on entry; the final dc_0 is in dcs2[T & 1]
   for (int t = T - 1; t >= 0; --t) {
-    int rc = blm_lstm_cell_ovr_bwd2(dh, dy + t * bh, dcs2 + k * bh, cs + t * bh, cs + (t + 1) * bh, ga + t * bg, gate, dgates + t * bg,
-                                    da + t * bh, dcs2 + (k ^ 1) * bh, B, H, stream);                                 // dh_t = recurrent part + dy_t
-    if (!rc) rc = blm_lstm_step_dh(da + t * bh, cwt, ds, B, GP, H, stream);                                        // d s = d a . [W | b]
-    if (!rc) rc = blm_gpnn2_actsum_bwd(ds, feat + (size_t)t * B * MP, df + (size_t)t * B * GP, B, M, MP, GP, scale, acts, stream);
-    if (!rc) rc = blm_lstm_step_dh_ld(df + (size_t)t * B * GP, Fp + (size_t)(nF > 1 ? t : 0) * H * GP, dgates + t * bg + off, 4 * H, B, H,
-                                      GP, stream);                                                                  // d pre -> gate's slot
-    if (!rc) rc = blm_lstm_step_dh(dgates + t * bg, w_hh_t, dh, B, H, 4 * H, stream);                               // dh_{t-1}
+    const float* Fp = q->Fp + (size_t)(q->nF > 1 ? t : 0) * H * GP;
+    float* dc_in = q->dcs2 + k * bh;
+    float* dc_out = q->dcs2 + (k ^ 1) * bh;
+    int rc = BLM_OK;
+    if (q->mode == 0) {
+      rc = blm_lstm_cell_ovr_bwd2(q->dh, q->dy + t * bh, dc_in, q->cs + t * bh, q->cs + (t + 1) * bh, q->ga + t * bg, q->gate,
+                                  q->dgates + t * bg, q->da + t * bh, dc_out, B, H, stream);              // dh_t = recurrent part + dy_t
+      if (!rc) rc = blm_lstm_step_dh_act(q->da + t * bh, q->cwt, q->df + t * bp, GP, B, GP, H, 2, q->feat + t * bm, MP, M, scale, q->acts,
+                                         stream);                                                       // d f = (d a . [W | b]) * actsum'(f)
+      if (!rc) rc = blm_lstm_step_dh_ld(q->df + t * bp, Fp, q->dgates + t * bg + off, 4 * H, B, H, GP, stream);  // d pre -> the gate's slot
+      if (!rc) rc = blm_lstm_step_dh(q->dgates + t * bg, q->w_hh_t, q->dh, B, H, 4 * H, stream);         // dh_{t-1}
+    } else if (q->mode == 1) {
+      // cell backward of step t with c_in as its incoming cell state: dc_out <- d c_in; then d c_{t-1} = GPNN2 backward
+      rc = blm_lstm_cell_bwd2(q->dh, q->dy + t * bh, dc_in, q->gout + t * bh, q->cs + (t + 1) * bh, q->ga + t * bg, q->dgates + t * bg,
+                              q->da + t * bh, B, H, stream);
+      if (!rc) rc = blm_lstm_step_dh_act(q->da + t * bh, q->cwt, q->df + t * bp, GP, B, GP, H, 2, q->feat + t * bm, MP, M, scale, q->acts,
+                                         stream);
+      if (!rc) rc = blm_lstm_step_dh(q->df + t * bp, Fp, dc_out, B, H, GP, stream);                      // raw d c_{t-1}
+      if (!rc) rc = blm_lstm_step_dh(q->dgates + t * bg, q->w_hh_t, q->dh, B, H, 4 * H, stream);         // dh_{t-1}
+    } else {
+      rc = blm_lstm_cell_bwd2(q->dh, q->dy + t * bh, dc_in, q->cs + t * bh, q->cs + (t + 1) * bh, q->ga + t * bg, q->dgates + t * bg, dc_out,
+                              B, H, stream);
+      if (!rc) rc = blm_lstm_step_dh_act(q->dgates + t * bg, q->cwt, q->df + t * bp, GP, B, GP, 4 * H, 2, q->feat + t * bm, MP, M, scale,
+                                         q->acts, stream);                                              // d f = (d hw . [W | b]) * actsum'(f)
+      if (!rc) rc = blm_lstm_step_dh(q->df + t * bp, Fp, q->dh, B, H, GP, stream);                       // dh_{t-1} = d f . F_t^T
+    }
     if (rc) return rc;
     k ^= 1;
   }

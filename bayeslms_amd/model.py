@@ -985,12 +985,23 @@ class GPLSTMCell(_LoopCell):
         gt, H = self.gate_type, self.hidden_size
         T = inputs.shape[0]
         gp = self.gpnn
-        if 1 <= gt <= 4 and gp.skip_act and ops.lstm_recurrent_gpnn2_supported(H, gp.n_MC_terms):
-            # the whole layer from one autograd node, six skinny launches per step (ops._LSTMRecurrentGPNN2)
-            xw = ops.linear(inputs, self.weights_ih, 2.0 * self.bias_ih)  # bias_ih enters on both sides, as in the reference
-            y, hT, cT = ops.lstm_recurrent_gpnn2(xw, hx, cx, self.weights_hh, gp.coef.weight, gp.coef.bias, gp.frequency_mean,
-                                                 gp.frequency_lgstd, gp.step_noises(T), gt - 1,
-                                                 sum(1 << GPNN._SLOT[a] for a in gp.act_set))
+        if 1 <= gt <= 6 and gp.skip_act and ops.lstm_recurrent_gpnn2_supported(H, gp.n_MC_terms):
+            # the whole layer from one autograd node, 4-6 skinny launches per step (ops._LSTMRecurrentGPNN2); bias_ih enters
+            # on both sides where the reference adds F.linear(hx, weights_hh, bias_ih) (gate types 1-5), once for type 6
+            acts = sum(1 << GPNN._SLOT[a] for a in gp.act_set)
+            xw = ops.linear(inputs, self.weights_ih, self.bias_ih if gt == 6 else 2.0 * self.bias_ih)
+            mode, gate = (0, gt - 1) if gt <= 4 else ((1, 0) if gt == 5 else (2, 0))
+            y, hT, cT = ops.lstm_recurrent_gpnn2(xw, hx, cx, None if gt == 6 else self.weights_hh, gp.coef.weight, gp.coef.bias,
+                                                 gp.frequency_mean, gp.frequency_lgstd, gp.step_noises(T), gate, acts, mode)
+            return y, (hT, cT)
+        if (gt == 7 and gp.skip_act and ops.lstm_recurrent_gpnn2_supported(self.input_size, gp.n_MC_terms)
+                and ops.lstm_recurrent_gp_supported(H, self.weights_hh)):
+            # the input projection of every step in a handful of batched launches (ops._GPNN2Steps), then the plain fused
+            # recurrence on it; bias_ih rides on the hidden side in the reference (model.py:1748)
+            acts = sum(1 << GPNN._SLOT[a] for a in gp.act_set)
+            xw = ops.gpnn2_steps(inputs, gp.coef.weight, gp.coef.bias + self.bias_ih, gp.frequency_mean, gp.frequency_lgstd,
+                                 gp.step_noises(T), acts)
+            y, hT, cT = ops.lstm_recurrent_gp(xw, hx, cx, self.weights_hh)
             return y, (hT, cT)
         xw_all = None if gt == 7 else ops.linear(inputs, self.weights_ih, self.bias_ih)
         outs = []

@@ -1542,19 +1542,17 @@ class _LSTMRecurrentGP(torch.autograd.Function):
 
 
 class _LSTMRecurrentGPNN2(torch.autograd.Function):
-    """GP-LSTM cell whose gate ``g`` (0 i, 1 f, 2 g, 3 o) is a GPNN2 of that gate's pre-activation, with FRESH frequencies
-    at every time step (GPLSTMCell gate types 1-4 with type digit 4, model.py:1698-1702, 1763-1770; GPNN2 :2061-2076):
-        z4_t  = h_{t-1} W_hh^T                                   (B,4H)   blm_lstm_step_dh
-        pre_t = xw_t[:, g] + z4_t[:, g]                          (B,H)    blm_add_cols
-        f_t   = pre_t F_t,   F_t = mean + eps_t * exp(lgstd)     (B,M)    blm_lstm_step_dh on F_t^T
-        s_t   = (f_t + sum_a a(f_t)) / sqrt(M) | 1               (B,Mp)   blm_gpnn2_actsum_fwd
-        a_t   = s_t [coef.weight | coef.bias]^T                  (B,H)    blm_lstm_step_dh
-        cell update with a_t as gate g's activation                       blm_lstm_cell_ovr_fwd
-    Six skinny launches per step from ONE autograd node (the step-wise form paid ~10 launches plus ten autograd nodes per
-    step); every product has a fixed summation order (no split-K atomics).  The T frequency matrices are sampled up front in
-    one launch (blm_gpnn2_sample_steps) with the counters the step-wise path uses, so both paths see the same noise.
-    Backward mirrors it with five launches per step; the weight gradients are batched over all steps afterwards, the
-    per-step frequency gradients pre_t^T d f_t become d mean / d lgstd in one launch (blm_gpnn2_freq_grad, eps_t regenerated)."""
+    """GP-LSTM layer whose cell holds a GPNN2 that draws FRESH frequencies at every time step (GPLSTMCell with type digit 4,
+    model.py:1698-1702, 1744-1771; GPNN2 :2061-2076), from ONE autograd node.  GPNN2_t(x) = (actsum(x F_t) | 1) [W | b]^T,
+    F_t = mean + eps_t * exp(lgstd).  ``mode``:
+      0  gate types 1-4: gate ``g``'s activation is GPNN2_t of its pre-activation  xw_t[:, g] + (h_{t-1} W_hh^T)[:, g]
+      1  gate type 5:    the cell state enters the update as GPNN2_t(c_{t-1})
+      2  gate type 6:    the hidden projection of all four gates is GPNN2_t(h_{t-1})  (w_hh unused)
+    Per step 4-6 skinny launches (products on blm_lstm_step_dh: fixed summation order, no split-K atomics, no memset)
+    instead of ~10 launches plus ten autograd nodes; the time loops run in C (blm_lstm_gpnn2_seq_fwd / _bwd).  The T
+    frequency matrices are sampled in one launch (blm_gpnn2_sample_steps) with the Philox counters the step-wise path
+    uses, so both paths see the same noise; the weight gradients are batched over all steps after the loop, the per-step
+    frequency gradients x_t^T d f_t become d mean / d lgstd in one launch (blm_gpnn2_freq_grad, eps_t regenerated)."""
 
     MP, GP = 160, 192  # feature columns padded to the products' tile rules (output % 16, contraction % 64); 150 MC terms
 
@@ -1572,21 +1570,32 @@ class _LSTMRecurrentGPNN2(torch.autograd.Function):
         return None, noises[0].rng()
 
     @staticmethod
-    def forward(ctx, xw, h0, c0, w_hh, coef_w, coef_b, fmean, flgstd, noises, g, acts):
-        xw, w_hh = _f32(xw, "xw"), _f32(w_hh, "w_hh")
+    def _desc(mode, g, acts, T, B, H, M, nF, **bufs):
+        q = L.Gpnn2Seq()
+        q.abi_version, q.mode, q.gate, q.acts = L.ABI_VERSION, mode, g, acts
+        q.T, q.B, q.H, q.M, q.MP, q.GP, q.nF = T, B, H, M, _LSTMRecurrentGPNN2.MP, _LSTMRecurrentGPNN2.GP, nF
+        for k, v in bufs.items():
+            setattr(q, k, ptr(v))
+        return q
+
+    @staticmethod
+    def forward(ctx, xw, h0, c0, w_hh, coef_w, coef_b, fmean, flgstd, noises, g, acts, mode):
+        xw = _f32(xw, "xw")
+        w_hh = _f32(w_hh, "w_hh") if mode != 2 else None
         T, B, G4 = xw.shape
         H = G4 // 4
         M = fmean.shape[1]
         MP, GP = _LSTMRecurrentGPNN2.MP, _LSTMRecurrentGPNN2.GP
-        if M >= MP or H % 64 != 0:
-            raise BayesLMError("lstm_recurrent_gpnn2: needs n_MC_terms < %d and H %% 64 == 0" % MP)
+        NO = G4 if mode == 2 else H  # outputs of the GPNN2
+        if M >= MP or H % 64 != 0 or fmean.shape[0] != H or coef_w.shape != (NO, M):
+            raise BayesLMError("lstm_recurrent_gpnn2: needs n_MC_terms < %d, H %% 64 == 0, a GPNN2(H, %d)" % (MP, NO))
         dev = xw.device
         L.require_gfx950()
         lib_, st = lib(), stream()
         new = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
         nF = T if noises is not None else 1
         # F_t^T with zero rows m >= M (the w_t operand of the feature product) and F_t padded along m (the w_t operand of
-        # d pre = d f . F_t^T), all T of them in ONE launch, with the noise of calls 0..T-1 of the step-wise path
+        # d x = d f . F_t^T), all T of them in ONE launch, with the noise of calls 0..T-1 of the step-wise path
         FT, Fp = new(nF, MP, H), new(nF, H, GP)
         eps_all, rng0 = _LSTMRecurrentGPNN2._noise(noises, dev)
         if noises is None:
@@ -1594,80 +1603,183 @@ class _LSTMRecurrentGPNN2(torch.autograd.Function):
         check(lib_.blm_gpnn2_sample_steps(ptr(_f32(fmean, "frequency_mean")), ptr(_f32(flgstd, "frequency_lgstd")), ptr(eps_all),
                                           C.byref(rng0) if rng0 is not None else None, nF, H, M, MP, GP, ptr(FT), ptr(Fp), st),
               "blm_gpnn2_sample_steps")
-        cwp = torch.zeros(H, GP, device=dev, dtype=torch.float32)      # [coef.weight | coef.bias | 0]
+        cwp = torch.zeros(NO, GP, device=dev, dtype=torch.float32)  # [coef.weight | coef.bias | 0]
         cwp[:, :M].copy_(coef_w)
         cwp[:, M].copy_(coef_b)
         hs, cs = new(T + 1, B, H), new(T + 1, B, H)
         hs[0].copy_(h0)
         cs[0].copy_(c0)
-        z4, ga = new(T, B, G4), new(T, B, G4)
-        pre, feat, sact, aact = new(T, B, H), new(T, B, MP), new(T, B, GP), new(T, B, H)
-        check(lib_.blm_lstm_gpnn2_seq_fwd(ptr(xw), ptr(w_hh), ptr(FT), nF, ptr(cwp), ptr(hs), ptr(cs), ptr(z4), ptr(ga), ptr(pre), ptr(feat),
-                                          ptr(sact), ptr(aact), g, acts, T, B, H, M, MP, GP, st), "blm_lstm_gpnn2_seq_fwd")
+        ga = new(T, B, G4)
+        z4 = new(T, B, G4) if mode == 0 else None
+        pre = new(T, B, H) if mode == 0 else None
+        feat, gout = new(T, B, MP), new(T, B, NO)
+        sact = torch.zeros(T, B, GP, device=dev, dtype=torch.float32)  # the feature product writes columns < MP; the padding stays 0
+        q = _LSTMRecurrentGPNN2._desc(mode, g, acts, T, B, H, M, nF, xw=xw, w_hh=w_hh, FT=FT, Fp=Fp, cwp=cwp, hs=hs, cs=cs, ga=ga, z4=z4,
+                                      pre=pre, feat=feat, sact=sact, gout=gout)
+        check(lib_.blm_lstm_gpnn2_seq_fwd(C.byref(q), st), "blm_lstm_gpnn2_seq_fwd")
         if _STATE_TAP is not None:
             _STATE_TAP.layers.append((hs.index_select(0, _STATE_TAP.idx), cs.index_select(0, _STATE_TAP.idx)))
-        ctx.save_for_backward(hs, cs, ga, w_hh, pre, feat, sact, Fp, cwp)
-        ctx.meta = (g, acts, M, fmean, flgstd, noises, coef_w.requires_grad, coef_b.requires_grad)
+        ctx.save_for_backward(hs, cs, ga, feat, sact, Fp, cwp, *([w_hh] if mode != 2 else []), *([pre] if mode == 0 else []),
+                              *([gout] if mode == 1 else []))
+        ctx.meta = (mode, g, acts, M, fmean, flgstd, noises, coef_w.requires_grad, coef_b.requires_grad)
         return hs[1:], hs[T], cs[T]
 
     @staticmethod
     def backward(ctx, dy, dhT, dcT):
-        hs, cs, ga, w_hh, pre, feat, sact, Fp, cwp = ctx.saved_tensors
-        g, acts, M, fmean, flgstd, noises, need_cw, need_cb = ctx.meta
+        mode, g, acts, M, fmean, flgstd, noises, need_cw, need_cb = ctx.meta
+        hs, cs, ga, feat, sact, Fp, cwp = ctx.saved_tensors[:7]
+        rest = list(ctx.saved_tensors[7:])
+        w_hh = rest.pop(0) if mode != 2 else None
+        pre = rest.pop(0) if mode == 0 else None
+        gout = rest.pop(0) if mode == 1 else None
         T, B, G4 = ga.shape
         H = G4 // 4
         MP, GP = _LSTMRecurrentGPNN2.MP, _LSTMRecurrentGPNN2.GP
+        NO = cwp.shape[0]
         dev = ga.device
         dy = _f32(dy, "dy")
         lib_, st = lib(), stream()
         new = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
         nF = Fp.shape[0]
-        w_t = new(H, G4)
-        check(lib_.blm_transpose(ptr(w_hh), ptr(w_t), G4, H, st), "blm_transpose")
-        cwt = new(GP, H)
-        check(lib_.blm_transpose(ptr(cwp), ptr(cwt), H, GP, st), "blm_transpose")
-        dgates, da, ds, df = new(T, B, G4), new(T, B, H), new(B, GP), new(T, B, GP)
+        w_t = None
+        if mode != 2:
+            w_t = new(H, G4)
+            check(lib_.blm_transpose(ptr(w_hh), ptr(w_t), G4, H, st), "blm_transpose")
+        cwt = new(GP, NO)
+        check(lib_.blm_transpose(ptr(cwp), ptr(cwt), NO, GP, st), "blm_transpose")
+        dgates, df = new(T, B, G4), new(T, B, GP)
+        da = new(T, B, H) if mode != 2 else None
         dh = torch.zeros(B, H, device=dev, dtype=torch.float32) if dhT is None else _f32(dhT, "dhT").clone()
         dcs = torch.zeros(2, B, H, device=dev, dtype=torch.float32)
         if dcT is not None:
             dcs[0].copy_(dcT)
-        scale = 1.0 / math.sqrt(M)
-        check(lib_.blm_lstm_gpnn2_seq_bwd(ptr(dy), ptr(w_t), ptr(Fp), nF, ptr(cwt), ptr(cs), ptr(ga), ptr(feat), ptr(dh), ptr(dcs),
-                                          ptr(dgates), ptr(da), ptr(ds), ptr(df), g, acts, T, B, H, M, MP, GP, st), "blm_lstm_gpnn2_seq_bwd")
+        q = _LSTMRecurrentGPNN2._desc(mode, g, acts, T, B, H, M, nF, w_hh_t=w_t, Fp=Fp, cwt=cwt, cs=cs, ga=ga, feat=feat, gout=gout, dy=dy,
+                                      dh=dh, dcs2=dcs, dgates=dgates, da=da, df=df)
+        check(lib_.blm_lstm_gpnn2_seq_bwd(C.byref(q), st), "blm_lstm_gpnn2_seq_bwd")
         k = T & 1
-        dw = torch.empty_like(w_hh)
-        gemm(L.GEMM_TN, dgates, hs, dw, G4, H, T * B, G4, H, H)  # hs[0:T] = h_{t-1}
+        dw = None
+        if mode != 2:
+            dw = torch.empty_like(w_hh)
+            gemm(L.GEMM_TN, dgates, hs, dw, G4, H, T * B, G4, H, H)  # hs[0:T] = h_{t-1}
         dcw = dcb = None
         if need_cw or need_cb:
-            dcwp = new(H, GP)
-            gemm(L.GEMM_TN, da, sact, dcwp, H, GP, T * B, H, GP, GP)  # column M of s is the constant 1: its row is d coef.bias
+            dout = dgates if mode == 2 else da  # the gradient of the GPNN2's output, all steps
+            dcwp = new(NO, GP)
+            gemm(L.GEMM_TN, dout, sact, dcwp, NO, GP, T * B, NO, GP, GP)  # column M of s is the constant 1: its row is d coef.bias
             dcw = dcwp[:, :M].contiguous() if need_cw else None
             dcb = dcwp[:, M].contiguous() if need_cb else None
         if fmean.requires_grad or flgstd.requires_grad:
-            # d F_t = pre_t^T d f_t (contraction over the B rows of ONE step: the frequencies differ per step); d mean is their
+            # d F_t = x_t^T d f_t (contraction over the B rows of ONE step: the frequencies differ per step); d mean is their
             # sum, d lgstd their eps_t-weighted sum times sigma -- one launch, eps_t regenerated from the Philox counters
+            x_in = pre if mode == 0 else (cs if mode == 1 else hs)  # rows 0..T-1: the GPNN2's inputs
             eps_all, rng0 = _LSTMRecurrentGPNN2._noise(noises, dev)
-            if noises is None:  # mean frequencies (deterministic GPNN2): d mean only
+            Tn, Bn = T, B
+            if noises is None:  # mean frequencies (deterministic GPNN2): d mean only, one contraction over all T*B rows
                 eps_all = torch.zeros(1, H, M, device=dev, dtype=torch.float32)
-                pre_s, df_s, Tn = pre.reshape(1, T * B, H), df.reshape(1, T * B, GP), 1
-            else:
-                pre_s, df_s, Tn = pre, df, T
-            check(lib_.blm_gpnn2_freq_grad(ptr(pre_s), ptr(df_s), ptr(eps_all), C.byref(rng0) if rng0 is not None else None,
+                Tn, Bn = 1, T * B
+            check(lib_.blm_gpnn2_freq_grad(ptr(x_in), ptr(df), ptr(eps_all), C.byref(rng0) if rng0 is not None else None,
                                            ptr(flgstd), ptr(_grad_buf(fmean)) if fmean.requires_grad else None,
                                            ptr(_grad_buf(flgstd)) if (flgstd.requires_grad and noises is not None) else None,
-                                           Tn, pre_s.shape[1], H, M, GP, st), "blm_gpnn2_freq_grad")
+                                           Tn, Bn, H, M, GP, st), "blm_gpnn2_freq_grad")
             _notify(fmean, flgstd)
-        return dgates, dh, dcs[k], dw, dcw, dcb, None, None, None, None, None
+        return dgates, dh, dcs[k], dw, dcw, dcb, None, None, None, None, None, None
+
+
+class _GPNN2Steps(torch.autograd.Function):
+    """out[t] = GPNN2_t(x[t]) for all T steps of a window -- a GPNN2 that is called once per time step and draws fresh
+    frequencies at every call, on inputs that do not depend on the recurrence (GPLSTMCell gate type 7 with type digit 4:
+    the input projection, model.py:1747-1748).  Only the feature product is per step (T skinny launches, independent of
+    each other); the activation sum, the coefficient product and every gradient are batched over the T*B rows."""
+
+    @staticmethod
+    def forward(ctx, x, coef_w, coef_b, fmean, flgstd, noises, acts):
+        x = _f32(x, "x")
+        T, B, E = x.shape
+        NO, M = coef_w.shape
+        MP, GP = _LSTMRecurrentGPNN2.MP, _LSTMRecurrentGPNN2.GP
+        if M >= MP or E % 64 != 0 or fmean.shape != (E, M):
+            raise BayesLMError("gpnn2_steps: needs n_MC_terms < %d, input width %% 64 == 0" % MP)
+        dev = x.device
+        L.require_gfx950()
+        lib_, st = lib(), stream()
+        new = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
+        nF = T if noises is not None else 1
+        FT, Fp = new(nF, MP, E), new(nF, E, GP)
+        eps_all, rng0 = _LSTMRecurrentGPNN2._noise(noises, dev)
+        if noises is None:
+            eps_all = torch.zeros(1, E, M, device=dev, dtype=torch.float32)
+        check(lib_.blm_gpnn2_sample_steps(ptr(_f32(fmean, "frequency_mean")), ptr(_f32(flgstd, "frequency_lgstd")), ptr(eps_all),
+                                          C.byref(rng0) if rng0 is not None else None, nF, E, M, MP, GP, ptr(FT), ptr(Fp), st),
+              "blm_gpnn2_sample_steps")
+        cwp = torch.zeros(NO, GP, device=dev, dtype=torch.float32)
+        cwp[:, :M].copy_(coef_w)
+        cwp[:, M].copy_(coef_b)
+        feat, sact = new(T, B, MP), new(T, B, GP)
+        x_p, f_p, FT_p = _P(x), _P(feat), _P(FT)
+        for t in range(T):
+            check(lib_.blm_lstm_step_dh(x_p[t], FT_p[t if nF > 1 else 0], f_p[t], B, MP, E, st), "blm_lstm_step_dh")
+        check(lib_.blm_gpnn2_actsum_fwd(ptr(feat), ptr(sact), T * B, M, MP, GP, 1.0 / math.sqrt(M), acts, st), "blm_gpnn2_actsum_fwd")
+        out = new(T, B, NO)
+        gemm(L.GEMM_NT, sact, cwp, out, T * B, NO, GP, GP, GP, NO)
+        ctx.save_for_backward(x, feat, sact, Fp, cwp)
+        ctx.meta = (acts, M, fmean, flgstd, noises, coef_w.requires_grad, coef_b.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, feat, sact, Fp, cwp = ctx.saved_tensors
+        acts, M, fmean, flgstd, noises, need_cw, need_cb = ctx.meta
+        T, B, E = x.shape
+        NO = cwp.shape[0]
+        MP, GP = _LSTMRecurrentGPNN2.MP, _LSTMRecurrentGPNN2.GP
+        dev = x.device
+        dout = _f32(dout, "dout")
+        lib_, st = lib(), stream()
+        new = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
+        nF = Fp.shape[0]
+        ds = new(T, B, GP)
+        gemm(L.GEMM_NN, dout, cwp, ds, T * B, GP, NO, NO, GP, GP)
+        df = new(T, B, GP)
+        check(lib_.blm_gpnn2_actsum_bwd(ptr(ds), ptr(feat), ptr(df), T * B, M, MP, GP, 1.0 / math.sqrt(M), acts, st), "blm_gpnn2_actsum_bwd")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = new(T, B, E)
+            df_p, dx_p, Fp_p = _P(df), _P(dx), _P(Fp)
+            for t in range(T):
+                check(lib_.blm_lstm_step_dh(df_p[t], Fp_p[t if nF > 1 else 0], dx_p[t], B, E, GP, st), "blm_lstm_step_dh")
+        dcw = dcb = None
+        if need_cw or need_cb:
+            dcwp = new(NO, GP)
+            gemm(L.GEMM_TN, dout, sact, dcwp, NO, GP, T * B, NO, GP, GP)
+            dcw = dcwp[:, :M].contiguous() if need_cw else None
+            dcb = dcwp[:, M].contiguous() if need_cb else None
+        if fmean.requires_grad or flgstd.requires_grad:
+            eps_all, rng0 = _LSTMRecurrentGPNN2._noise(noises, dev)
+            Tn, Bn = T, B
+            if noises is None:
+                eps_all = torch.zeros(1, E, M, device=dev, dtype=torch.float32)
+                Tn, Bn = 1, T * B
+            check(lib_.blm_gpnn2_freq_grad(ptr(x), ptr(df), ptr(eps_all), C.byref(rng0) if rng0 is not None else None, ptr(flgstd),
+                                           ptr(_grad_buf(fmean)) if fmean.requires_grad else None,
+                                           ptr(_grad_buf(flgstd)) if (flgstd.requires_grad and noises is not None) else None,
+                                           Tn, Bn, E, M, GP, st), "blm_gpnn2_freq_grad")
+            _notify(fmean, flgstd)
+        return dx, dcw, dcb, None, None, None, None
+
+
+def gpnn2_steps(x, coef_w, coef_b, fmean, flgstd, noises, acts):
+    """(T,B,E) -> (T,B,NO): GPNN2_t(x[t]) with the noise of calls 0..T-1 (``noises`` as for lstm_recurrent_gpnn2)."""
+    return _GPNN2Steps.apply(x, coef_w, coef_b, fmean, flgstd, noises, int(acts))
 
 
 def lstm_recurrent_gpnn2_supported(H, n_mc):
     return H % 64 == 0 and n_mc < _LSTMRecurrentGPNN2.MP
 
 
-def lstm_recurrent_gpnn2(xw, h0, c0, w_hh, coef_w, coef_b, fmean, flgstd, noises, gate, acts):
+def lstm_recurrent_gpnn2(xw, h0, c0, w_hh, coef_w, coef_b, fmean, flgstd, noises, gate, acts, mode=0):
     """-> (y (T,B,H), hT, cT).  ``noises``: list of T NoiseSpec (training) or None (mean frequencies); ``acts``: bit set of the
-    GPNN2's activations in the mixture's slot order (1 tanh, 2 sigmoid, 4 relu, 8 gelu)."""
-    return _LSTMRecurrentGPNN2.apply(xw, h0, c0, w_hh, coef_w, coef_b, fmean, flgstd, noises, int(gate), int(acts))
+    GPNN2's activations in the mixture's slot order (1 tanh, 2 sigmoid, 4 relu, 8 gelu); ``mode``: see _LSTMRecurrentGPNN2."""
+    return _LSTMRecurrentGPNN2.apply(xw, h0, c0, w_hh, coef_w, coef_b, fmean, flgstd, noises, int(gate), int(acts), int(mode))
 
 
 def lstm_recurrent_gp_supported(H, w_rec):

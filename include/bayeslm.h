@@ -507,6 +507,12 @@ int blm_lstm_search_step_bwd(const float* dz8_t, const float* w8_t, const float*
 int blm_lstm_step_dh(const float* dz, const float* w_t, float* dh_out, int B, int H, int G, void* stream);
 /* The same product written into a column window of a wider matrix: dh_out has row stride ldo >= H. */
 int blm_lstm_step_dh_ld(const float* dz, const float* w_t, float* dh_out, int64_t ldo, int B, int H, int G, void* stream);
+/* ... with the GPNN2 activation sum on the way out (feat has row stride ld_f; the product has H output columns):
+ *   act_mode 1: the product is the feature matrix f:  feat = f  and  out[:, m] = (f + sum_a a(f)) * scale for m < M,
+ *               out[:, M] = 1, 0 for M < m < H                       (blm_gpnn2_actsum_fwd fused behind the product)
+ *   act_mode 2: the product is d s:  out[:, m] = d s * (1 + sum_a a'(feat)) * scale for m < M, 0 beyond   (..._bwd) */
+int blm_lstm_step_dh_act(const float* dz, const float* w_t, float* out, int64_t ldo, int B, int H, int G, int act_mode, float* feat,
+                         int ld_f, int M, float scale, int acts, void* stream);
 
 /* GPNN2 (random-feature GP, model.py:2036-2076) between its two products: features f (rows, ld_f) -> s (rows, ld_s),
  *   s[:, m] = (f + sum_{a in acts} a(f)) * scale   for m < M   (acts: bit set in the slot order 1 tanh, 2 sigmoid, 4 relu,
@@ -530,22 +536,31 @@ int blm_gpnn2_sample_steps(const float* mean, const float* lgstd, const float* e
  *   dmean += sum_t G_t,   dlgstd += exp(lgstd) * sum_t eps_t * G_t      (either may be NULL). */
 int blm_gpnn2_freq_grad(const float* pre, const float* df, const float* eps_all, const blm_rng* rng0, const float* lgstd,
                         float* dmean, float* dlgstd, int T, int B, int H, int M, int GP, void* stream);
-/* The time loops of a GP-LSTM layer whose gate `gate` (0 i, 1 f, 2 g, 3 o) is a GPNN2 of its pre-activation with fresh
- * frequencies per step (GPLSTMCell gate types 1-4, type digit 4; model.py:1763-1770), as ONE call per direction.  Per step
- *   z4_t = h_{t-1} w_hh^T;  pre_t = xw_t[:, gate] + z4_t[:, gate];  f_t = pre_t F_t;  s_t = actsum(f_t) | 1;
- *   a_t = s_t cwp^T;  cell update with a_t as that gate's activation        (cwp (H,GP) = [coef.weight | coef.bias | 0])
- * FT (nF,MP,H) / Fp (nF,H,GP) from blm_gpnn2_sample_steps, nF = T or 1 (mean frequencies at every step).  Buffers
- * (T rows each unless noted): hs, cs (T+1,B,H) with row 0 = initial state; z4, ga (B,4H); pre, aact (B,H); feat (B,MP);
- * sact (B,GP).  Backward walks t = T-1..0: dh (B,H) holds dh_T on entry and dh_0 on exit, dcs2 (2,B,H) ping-pongs dc
- * ([0] = dc_T on entry, dc_0 ends in [T & 1]); it fills dgates (T,B,4H) (= d xw, the gate's slot holding d pre),
- * da (T,B,H), df (T,B,GP); ds (B,GP) is scratch; w_hh_t = w_hh^T (H,4H), cwt = cwp^T (GP,H).
- * Needs H % 64 == 0, MP % 16 == 0, GP % 64 == 0, M < MP <= GP (BLM_ERR_UNSUPPORTED from the products otherwise). */
-int blm_lstm_gpnn2_seq_fwd(const float* xw, const float* w_hh, const float* FT, int nF, const float* cwp, float* hs, float* cs,
-                           float* z4, float* ga, float* pre, float* feat, float* sact, float* aact, int gate, int acts, int T, int B,
-                           int H, int M, int MP, int GP, void* stream);
-int blm_lstm_gpnn2_seq_bwd(const float* dy, const float* w_hh_t, const float* Fp, int nF, const float* cwt, const float* cs,
-                           const float* ga, const float* feat, float* dh, float* dcs2, float* dgates, float* da, float* ds,
-                           float* df, int gate, int acts, int T, int B, int H, int M, int MP, int GP, void* stream);
+/* The time loops of a GP-LSTM layer with a GPNN2 that draws fresh frequencies at every step (GPLSTMCell, type digit 4;
+ * model.py:1744-1771), ONE call per direction.  GPNN2_t(x) = (actsum(x F_t) | 1) cwp^T with cwp = [coef.weight | coef.bias | 0]
+ * (rows = outputs, GP columns), FT (nF,MP,H) / Fp (nF,H,GP) from blm_gpnn2_sample_steps, nF = T or 1 (mean frequencies).
+ *   mode 0  gate types 1-4: z4_t = h_{t-1} w_hh^T; pre_t = xw_t[:, gate] + z4_t[:, gate]; gout_t = GPNN2_t(pre_t) (B,H) is
+ *           that gate's activation in the cell update (xw carries both bias_ih)
+ *   mode 1  gate type 5:    gout_t = c_in = GPNN2_t(c_{t-1}) (B,H) takes c_{t-1}'s place in the fused step (blm_lstm_step_fwd)
+ *   mode 2  gate type 6:    gout_t = GPNN2_t(h_{t-1}) (B,4H; cwp is (4H,GP)) is the hidden projection of all four gates
+ * Buffers (T rows each unless noted): hs, cs (T+1,B,H) with row 0 = initial state; ga (B,4H); feat (B,MP); sact (B,GP);
+ * mode 0 also z4 (B,4H) and pre (B,H).  Backward walks t = T-1..0: dh (B,H) holds dh_T on entry and dh_0 on exit, dcs2
+ * (2,B,H) ping-pongs dc ([0] = dc_T on entry, dc_0 ends in [T & 1]); it fills dgates (T,B,4H) (= d xw; mode 0: the gate's
+ * slot holds d pre), df (T,B,GP), da (T,B,H) (modes 0 / 1: the gradient of gout); ds is unused (the activation sum and its
+ * derivative ride in the epilogues of the feature / d s products, blm_lstm_step_dh_act; sact's padding columns >= MP must be
+ * zero on entry of the forward call); w_hh_t = w_hh^T (H,4H), cwt = cwp^T.  Needs H % 64 == 0, MP % 16 == 0, GP % 64 == 0, M < MP <= GP (BLM_ERR_UNSUPPORTED from the
+ * products otherwise). */
+typedef struct blm_gpnn2_seq {
+  uint32_t abi_version; /* BLM_ABI_VERSION */
+  int32_t mode, gate, acts;
+  int32_t T, B, H, M, MP, GP, nF;
+  const float *xw, *w_hh, *w_hh_t, *FT, *Fp, *cwp, *cwt;
+  float *hs, *cs, *ga, *z4, *pre, *feat, *sact, *gout;
+  const float* dy;
+  float *dh, *dcs2, *dgates, *da, *ds, *df;
+} blm_gpnn2_seq;
+int blm_lstm_gpnn2_seq_fwd(const blm_gpnn2_seq* q, void* stream);
+int blm_lstm_gpnn2_seq_bwd(const blm_gpnn2_seq* q, void* stream);
 
 /* torch.optim.Adam(lr, betas, eps, weight_decay) on one tensor (architect.py:33): g += wd*p;
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr * (m/(1-b1^step)) / (sqrt(v/(1-b2^step)) + eps).

@@ -64,14 +64,21 @@ def test_struct_layout_matches_the_c_compiler(built_lib, tmp_path):
                    'int main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(blm_gemm_args), offsetof(blm_gemm_args, var_b),'
                    ' offsetof(blm_gemm_args, C2), offsetof(blm_gemm_args, kl_lambda), offsetof(blm_gemm_args, drop_rng));'
                    'printf("%zu %zu %zu %zu %zu\\n", sizeof(blm_var_item), offsetof(blm_var_item, v), offsetof(blm_var_item, w_out),'
-                   ' offsetof(blm_var_item, kl_minus), offsetof(blm_var_item, dlgstd));return 0;}\n')
+                   ' offsetof(blm_var_item, kl_minus), offsetof(blm_var_item, dlgstd));'
+                   'printf("%zu %zu %zu %zu %zu\\n", sizeof(blm_gpnn2_seq), offsetof(blm_gpnn2_seq, nF), offsetof(blm_gpnn2_seq, xw),'
+                   ' offsetof(blm_gpnn2_seq, dy), offsetof(blm_gpnn2_seq, df));'
+                   'printf("%zu %zu %zu\\n", sizeof(blm_gemm_plan), offsetof(blm_gemm_plan, source), offsetof(blm_gemm_plan, model_us));'
+                   'return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     G = _lib.GemmArgs
     V = _lib.VarItem
+    Q, P = _lib.Gpnn2Seq, _lib.GemmPlan
     assert got == [ctypes.sizeof(G), G.var_b.offset, G.C2.offset, G.kl_lambda.offset, G.drop_rng.offset,
-                   ctypes.sizeof(V), V.v.offset, V.w_out.offset, V.kl_minus.offset, V.dlgstd.offset]
+                   ctypes.sizeof(V), V.v.offset, V.w_out.offset, V.kl_minus.offset, V.dlgstd.offset,
+                   ctypes.sizeof(Q), Q.nF.offset, Q.xw.offset, Q.dy.offset, Q.df.offset,
+                   ctypes.sizeof(P), P.source.offset, P.model_us.offset]
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -617,10 +617,12 @@ def test_gauss_rnn_fused_steps_match_oracle(dev, gp):
         assert grad_close(p.grad, leaf[k].grad), k
 
 
-@pytest.mark.parametrize("gp", ["34", "14", "24", "44", "340", "3434", "3464"])
+@pytest.mark.parametrize("gp", ["34", "14", "24", "44", "340", "3434", "3464", "54", "64", "540", "6454", "74", "740", "7434"])
 def test_gauss_rnn_gpnn2_fused_steps_match_oracle(dev, gp):
-    """H = 64: GP cells whose gate is a GPNN2 of its pre-activation with fresh frequencies at every time step (type digit 4,
-    model.py:1763-1770) run from one autograd node with six skinny launches per step (ops._LSTMRecurrentGPNN2).  Injected
+    """H = 64: GP cells with a GPNN2 that draws fresh frequencies at every time step (type digit 4) -- on a gate's
+    pre-activation (gate types 1-4, model.py:1763-1770), on the cell state (5) or as the hidden projection (6) -- run from one
+    autograd node with 4-6 skinny launches per step (ops._LSTMRecurrentGPNN2); the input projection (7) is batched over the
+    window (ops._GPNN2Steps) in front of the plain fused recurrence.  Injected
     per-step eps, two windows with the carried state; logits and every gradient against the CPU oracle (which the
     gauss_rnn_{34,14,...} fixtures pin to the reference); then Philox mode: same step -> same result, fused == step-wise."""
     from bayeslms_amd import model as M, ops
@@ -633,7 +635,7 @@ def test_gauss_rnn_gpnn2_fused_steps_match_oracle(dev, gp):
             if "weights" in k or "frequency_mean" in k:
                 p.mul_(3.0)
     cells = [0] if len(gp) < 3 else ([1] if len(gp) == 3 else [c for c in (0, 1) if gp[2 * c + 1] == "4"])
-    fused = [c for c in cells if 1 <= m.rnn.rnn[c].gate_type <= 4]
+    fused = [c for c in cells if 1 <= m.rnn.rnn[c].gate_type <= 7]
     assert fused and all(ops.lstm_recurrent_gpnn2_supported(H, m.rnn.rnn[c].gpnn.n_MC_terms) for c in fused)
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(6)

@@ -63,11 +63,17 @@ def main():
            ns(model="LSTM", uncertainty="Gaussian", L_gauss_pos="6360")),
           ("LSTM Variational L_v_pos 11", lambda: M.VariationalRNNModel("LSTM", V, 1024, 1024, 2, 0.2, True, "11"),
            ns(model="LSTM", uncertainty="Variational", L_v_pos="11")),
-          # the cells that still run step-wise (one GEMM + cell pair and an autograd node per time step, as the reference does)
-          ("LSTM Gaussian L_gauss_pos 53 (GPNN on the cell state: step-wise)", lambda: M.GaussRNNModel("LSTM", V, 1024, 1024, 2, 0.2, True, "53"),
+          ("LSTM Gaussian L_gauss_pos 53 (GPNN on the cell state)", lambda: M.GaussRNNModel("LSTM", V, 1024, 1024, 2, 0.2, True, "53"),
            ns(model="LSTM", uncertainty="Gaussian", L_gauss_pos="53")),
-          ("LSTM Gaussian L_gauss_pos 34 (GPNN2 cell: step-wise)", lambda: M.GaussRNNModel("LSTM", V, 1024, 1024, 2, 0.2, True, "34"),
-           ns(model="LSTM", uncertainty="Gaussian", L_gauss_pos="34"))]
+          # GPNN2 cells: fresh frequencies at every time step, 4-6 skinny launches per step from one autograd node
+          ("LSTM Gaussian L_gauss_pos 34 (GPNN2 on the cell gate)", lambda: M.GaussRNNModel("LSTM", V, 1024, 1024, 2, 0.2, True, "34"),
+           ns(model="LSTM", uncertainty="Gaussian", L_gauss_pos="34")),
+          ("LSTM Gaussian L_gauss_pos 54 (GPNN2 on the cell state)", lambda: M.GaussRNNModel("LSTM", V, 1024, 1024, 2, 0.2, True, "54"),
+           ns(model="LSTM", uncertainty="Gaussian", L_gauss_pos="54")),
+          ("LSTM Gaussian L_gauss_pos 64 (GPNN2 hidden projection)", lambda: M.GaussRNNModel("LSTM", V, 1024, 1024, 2, 0.2, True, "64"),
+           ns(model="LSTM", uncertainty="Gaussian", L_gauss_pos="64")),
+          ("LSTM Gaussian L_gauss_pos 74 (GPNN2 input projection, batched over the window)", lambda: M.GaussRNNModel("LSTM", V, 1024, 1024, 2, 0.2, True, "74"),
+           ns(model="LSTM", uncertainty="Gaussian", L_gauss_pos="74"))]
     for name, build, a in rn:
         run(name, build(), T.kl_selector(a), 35, 64, 0.5)
 
