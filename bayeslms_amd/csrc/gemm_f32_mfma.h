@@ -551,12 +551,12 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN]
 // written to the now idle staging buffer 64 rows at a time and read back row-major, so every lane
 // handles 4 consecutive columns: 16-byte loads of bias/aux, one Philox block per lane for the
 // dropout mask, 16-byte stores of C (4x fewer memory instructions than the register-layout walk).
-template <int EPI, int WTM, int WTN>
+template <int EPI, int WTM, int WTN, int WGN = 2>
 __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM][WTN], float* stage, int m0, int n0,
                                               int wm, int wn, int li, int lh) {
-  constexpr int BN = 64 * WTN, SS = BN + 4;
+  constexpr int BN = 32 * WTN * WGN, SS = BN + 4;
   constexpr int NP = WTM == 2 ? 2 : 1;
-  constexpr int TPRW = BN / 4, RPS = 256 / TPRW;
+  constexpr int TPRW = BN / 4, RPS = (128 * WGN) / TPRW;
   const int t = threadIdx.x, c4 = 4 * (t % TPRW);
   const int col = n0 + c4;
   const bool accum = p.flags & BLM_GEMM_ACCUMULATE;
@@ -661,9 +661,12 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
 // multiples of 4.  Full K tiles are then fetched by branch-free float4 loads through per-thread
 // pointers set up once (rows/cols outside the matrix are clamped, not zeroed: they only feed
 // C elements that are never stored); only a K tail tile goes through the guarded loaders.
-template <int OP, int WTM, int WTN, bool SAMP, bool FAST, int SPLIT = 0>  // SPLIT: 0 fp32 MFMA, 3 / 6 opt-in bf16 part products
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
-  constexpr int BM = 64 * WTM, BN = 64 * WTN;
+// WGN = columns of the wave grid: 2 (4 waves as 2 x 2, the tiles 11 / 12 / 21 / 22) or 4 (8 waves as 2 x 4: tile 28 = 128 x 128 run by
+// eight waves of 64 x 32 -- the per-wave shape and the two waves per SIMD of the 128 x 64 tile inside ONE barrier domain, so the
+// halves cannot drift apart along K and their shared B panel is staged once; LDS-DMA path, whole K tiles only: host-checked)
+template <int OP, int WTM, int WTN, bool SAMP, bool FAST, int SPLIT = 0, int WGN = 2>  // SPLIT: 0 fp32 MFMA, 3 / 6 opt-in bf16 part products
+__global__ __launch_bounds__(128 * WGN, WGN == 2 ? 2 : 1) void gemm_f32_kernel(const GemmP p) {
+  constexpr int BM = 64 * WTM, BN = 32 * WTN * WGN, NT = 128 * WGN;
   constexpr bool A_KMAJ = (OP != BLM_GEMM_TN), B_KMAJ = (OP == BLM_GEMM_NT);
   // k-contiguous sources are transposed on the LDS write: stride BM+2 keeps that scatter at most
   // 2-way conflicting (free for ds_write_b32) AND even, so the interleaved two-tile operand read is an
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   const int m0 = mt * BM, n0 = nt * BN;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN, li = lane & 31, lh = lane >> 5;
 #ifdef BLM_GEMM_PROF
   if (t == 0 && blockIdx.x < 8192) {
     blm_wg_life[4 * blockIdx.x] = wall_clock64();
@@ -983,7 +986,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   // wave w moves chunks 4w..4w+3 (1 KB each) of the A and of the B tile: 8 rows x 128 B of a k-contiguous
   // operand (chunk index swizzled), 2 k rows x 512 B of an m/n-contiguous one
   // NQA / NQB chunks of 1 KB per wave and tile: dim / 32 (a tile of `dim` rows x 32 k or 32 k x `dim` columns is dim/8 KB)
-  constexpr int NQA = BM / 32, NQB = BN / 32;
+  constexpr int NQA = BM / (16 * WGN), NQB = BN / (16 * WGN);  // (dim / 8 chunks) / (2 * WGN waves)
+  static_assert(NQA >= 1 && NQB >= 1, "every wave moves at least one chunk of each operand");
   uint32_t dsa[NQA], dsb[NQB];  // per-lane byte offsets from the (K-advanced) scalar base; the host takes this path below 4 GB
   if constexpr (DMA) {
     constexpr int LPA = BM / 4, LPB = BN / 4;  // lanes per k row of an m/n-contiguous tile (rows per instruction: 64 / LP)
@@ -1200,12 +1204,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   // only ever be indexed by compile-time constants or it is demoted to scratch)
   if (p.vec_epi) {  // aligned C/aux, N % 4 == 0, no atomics: 16-byte row-wise epilogue through LDS
     switch (p.epi) {
-      case BLM_EPI_NONE: epilogue_rows<BLM_EPI_NONE, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
-      case BLM_EPI_BIAS: epilogue_rows<BLM_EPI_BIAS, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
-      case BLM_EPI_BIAS_GELU: epilogue_rows<BLM_EPI_BIAS_GELU, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
-      case BLM_EPI_MUL_DGELU: epilogue_rows<BLM_EPI_MUL_DGELU, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
-      case BLM_EPI_GP_MIX: epilogue_rows<BLM_EPI_GP_MIX, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
-      case BLM_EPI_MUL_DGP_MIX: epilogue_rows<BLM_EPI_MUL_DGP_MIX, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
+      case BLM_EPI_NONE: epilogue_rows<BLM_EPI_NONE, WTM, WTN, WGN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
+      case BLM_EPI_BIAS: epilogue_rows<BLM_EPI_BIAS, WTM, WTN, WGN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
+      case BLM_EPI_BIAS_GELU: epilogue_rows<BLM_EPI_BIAS_GELU, WTM, WTN, WGN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
+      case BLM_EPI_MUL_DGELU: epilogue_rows<BLM_EPI_MUL_DGELU, WTM, WTN, WGN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
+      case BLM_EPI_GP_MIX: epilogue_rows<BLM_EPI_GP_MIX, WTM, WTN, WGN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
+      case BLM_EPI_MUL_DGP_MIX: epilogue_rows<BLM_EPI_MUL_DGP_MIX, WTM, WTN, WGN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
       default: break;
     }
   }
@@ -1222,9 +1226,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
   }
 }
 
-template <int OP, int WTM, int WTN, bool SAMP, bool FAST>
+template <int OP, int WTM, int WTN, bool SAMP, bool FAST, int WGN = 2>
 static int launch_cfg(const GemmP& p, hipStream_t st) {
-  constexpr int BM = 64 * WTM, BN = 64 * WTN;
+  constexpr int BM = 64 * WTM, BN = 32 * WTN * WGN;
   constexpr bool A_KMAJ = (OP != BLM_GEMM_TN), B_KMAJ = (OP == BLM_GEMM_NT);
   constexpr bool DMAL = use_dma<OP, WTM, WTN, SAMP, FAST>();
   constexpr int KSX = DMAL ? 32 : KS, PADL = DMAL ? 0 : 4;
@@ -1252,18 +1256,18 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
     BLM_HIP(hipMemsetAsync(p.C, 0, (size_t)p.M * p.N * sizeof(float), st));
   if constexpr (DMAL) {
     if (p.split) {  // opt-in split-bf16 arithmetic: same loaders, tiles and epilogues, different matrix instruction
-      auto kern = p.split == 6 ? gemm_f32_kernel<OP, WTM, WTN, SAMP, FAST, 6> : gemm_f32_kernel<OP, WTM, WTN, SAMP, FAST, 3>;
+      auto kern = p.split == 6 ? gemm_f32_kernel<OP, WTM, WTN, SAMP, FAST, 6, WGN> : gemm_f32_kernel<OP, WTM, WTN, SAMP, FAST, 3, WGN>;
       static bool attr_done_s[2] = {false, false};
       if (!attr_done_s[p.split == 6]) {
         BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done_s[p.split == 6] = true;
       }
-      hipLaunchKernelGGL(kern, dim3((unsigned)(nb * splits)), dim3(256), lds, st, q);
+      hipLaunchKernelGGL(kern, dim3((unsigned)(nb * splits)), dim3(128 * WGN), lds, st, q);
       BLM_HIP(hipGetLastError());
       return BLM_OK;
     }
   }
-  auto kern = gemm_f32_kernel<OP, WTM, WTN, SAMP, FAST>;
+  auto kern = gemm_f32_kernel<OP, WTM, WTN, SAMP, FAST, 0, WGN>;
   static bool attr_done = false;  // per instantiation; benign race (idempotent)
   if (!attr_done) {
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1277,7 +1281,7 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   // the time it asks.  128x128 tiles (one workgroup per CU, lock step) read exactly the operands.  Measured and not kept:
   // padding the LDS request so that a one-round grid spreads evenly (no change), wave-priority turns between the
   // co-resident workgroups (-25 % of the surplus at K = 4096, more at 8192, step +0.3 %).  The bytes cost no time (1.5 TB/s).
-  hipLaunchKernelGGL(kern, dim3((unsigned)(nb * splits)), dim3(256), lds, st, q);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nb * splits)), dim3(128 * WGN), lds, st, q);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }
@@ -1286,6 +1290,9 @@ template <int OP, bool SAMP>
 int launch_op(const GemmP& p, hipStream_t st) {
   // tile and K slices: gemm_plan.hip (override > measured plan table > cost model), already legal for this call
   if (!p.fast) return launch_cfg<OP, 1, 1, SAMP, false>(p, st);  // odd shapes/alignments: guarded loaders only
+  if constexpr (!SAMP) {  // tile 28: 128 x 128 on eight waves (LDS-DMA loaders, whole K tiles: the planner offers it only then)
+    if (p.plan_tile == 28 && p.K % BK == 0 && !p.split) return launch_cfg<OP, 2, 1, SAMP, true, 4>(p, st);
+  }
   switch (p.plan_tile) {
     case 11: return launch_cfg<OP, 1, 1, SAMP, true>(p, st);
     case 12: return launch_cfg<OP, 1, 2, SAMP, true>(p, st);

@@ -40,33 +40,36 @@ int g_force_tile = -1, g_force_splits = -1;  // -1: environment not read yet
 // Operand / output streaming enters as a soft maximum (near that bound the plan still matters), split-K adds the atomic
 // read-modify-write of C once per slice and a zeroing pass when C is not accumulated into.  The constants are a
 // least-squares fit (tools/gemm_fit.py) to the stand-alone sweep of tools/gemm_tune.py --grid on one MI355X -- 2160
-// shapes x 4 tiles x up to 8 slice counts = 50,784 timings, median |log error| 4 %; the model's PICK reaches 98.5 % of
-// the best candidate's rate on average, >= 0.79 on every shape above 30 us (profiles/r03_gemm_model_fit.txt).
+// shapes x 5 tiles x up to 8 slice counts = 61,944 timings, median |log error| 4 %; the model's PICK reaches 98.5 % of
+// the best candidate's rate on average, >= 0.78 on every shape above 30 us (profiles/r03_gemm_model_fit.txt).
 struct TileModel { int tile, wtm, wtn, occ; };
-const TileModel kTiles[4] = {{11, 1, 1, 5}, {12, 1, 2, 3}, {21, 2, 1, 3}, {22, 2, 2, 2}};
+// 28 = the 128 x 128 tile on eight waves: the output tile, LDS footprint and matrix time per SIMD of tile 22 (two waves of
+// 64 x 32 per SIMD instead of one of 64 x 64), its own efficiency constants
+constexpr int kNTiles = 5;
+const TileModel kTiles[kNTiles] = {{11, 1, 1, 5}, {12, 1, 2, 3}, {21, 2, 1, 3}, {22, 2, 2, 2}, {28, 2, 2, 2}};
 struct ModelK {
-  double cyc_per_us;      // nominal matrix-pipe clock; einf absorbs the clock under load
-  double einf[3][4];      // [layout][tile]: efficiency of the MFMA issue with many co-resident workgroups
-  double a[4];            // e(o) = einf * o / (o + a)
-  double t0[4];           // fixed cost of the first round (us)
-  double t0r[4];          // ... of every further round
+  double cyc_per_us;        // nominal matrix-pipe clock; einf absorbs the clock under load
+  double einf[3][kNTiles];  // [layout][tile]: efficiency of the MFMA issue with many co-resident workgroups
+  double a[kNTiles];        // e(o) = einf * o / (o + a)
+  double t0[kNTiles];       // fixed cost of the first round (us)
+  double t0r[kNTiles];      // ... of every further round
   double launch_us;
-  double atomic_bpus;     // bytes of C per microsecond through float atomics
+  double atomic_bpus;       // bytes of C per microsecond through float atomics
   double memset_bpus, memset_us;
-  double hbm_bpus;        // streaming rate of A + B + C
-  double t0o[4];          // fixed cost per co-resident workgroup of a round (us)
+  double hbm_bpus;          // streaming rate of A + B + C
+  double t0o[kNTiles];      // fixed cost per co-resident workgroup of a round (us)
 };
 ModelK g_model = {
     2400.0,
-    {{0.9918, 1.0855, 1.0856, 1.0509}, {0.9913, 1.0854, 1.0891, 1.0538}, {0.9553, 1.0427, 1.0461, 1.0242}},
-    {0.2799, 0.3217, 0.3185, 0.1961},
-    {0.119, 0.195, 0.057, 1.587},
-    {0.000, 0.000, 0.000, 0.000},
-    3.843,
+    {{0.9594, 1.0617, 1.0602, 1.0452, 0.9315}, {0.9580, 1.0628, 1.0633, 1.0481, 0.9240}, {0.9268, 1.0219, 1.0221, 1.0193, 0.9714}},
+    {0.2471, 0.3049, 0.2937, 0.1959, 0.0224},
+    {0.540, 0.652, 0.545, 2.132, 2.989},
+    {0.000, 0.000, 0.000, 0.000, 0.000},
+    3.458,
     3.567e+06,
-    1.441e+07, 2.239,
-    4.565e+06,
-    {0.331, 1.440, 1.302, 2.817},
+    1.015e+07, 2.162,
+    4.31e+06,
+    {0.269, 1.342, 1.213, 2.697, 1.505},
 };
 
 double model_us(const PlanKey& k, const TileModel& t, int S) {
@@ -103,6 +106,7 @@ Plan model_plan(const PlanKey& k) {
   double bt = 1e30;
   for (const TileModel& t : kTiles) {
     if (!k.fast && t.tile != 11) continue;
+    if (t.tile == 28 && k.K % 32 != 0) continue;  // the eight-wave tile has no K-tail path
     for (int S = 1; S <= 16; ++S) {
       if (S > 1 && (!k.can_split || k.K / S < 128)) break;
       if (S == 5 || S == 7 || (S > 8 && S != 12 && S != 16)) continue;  // the slice counts the sweep measured
@@ -123,6 +127,9 @@ const Entry* find(const PlanKey& k) {
   return nullptr;
 }
 
+// 28 = 128 x 128 on eight waves (gemm_f32_mfma.h): needs the aligned fast path and whole K tiles, else the 4-wave 128 x 128 tile runs
+bool valid_tile(int t) { return t == 11 || t == 12 || t == 21 || t == 22 || t == 28; }
+
 void read_env() {
   if (g_force_tile >= 0) return;
   const char* e = getenv("BLM_GEMM_TILE");
@@ -141,14 +148,13 @@ void read_env() {
       e = end;
       if (*e == ',') ++e; else break;
     }
-    if (n == 8 && v[0] >= 0 && v[0] <= 2 && (v[6] == 11 || v[6] == 12 || v[6] == 21 || v[6] == 22) && v[7] >= 1 && v[7] <= 64)
+    if (n == 8 && v[0] >= 0 && v[0] <= 2 && valid_tile(v[6]) && v[7] >= 1 && v[7] <= 64)
       g_runtime.push_back(Entry{v[0], v[1], v[2], v[3], v[4], v[5] ? 1 : 0, v[6], v[7]});
     while (*e && *e != ';') ++e;
     if (*e == ';') ++e;
   }
 }
 
-bool valid_tile(int t) { return t == 11 || t == 12 || t == 21 || t == 22; }
 
 }  // namespace
 
@@ -169,6 +175,7 @@ Plan choose_plan(const PlanKey& k) {
   if (g_force_splits > 0) { p.splits = g_force_splits; p.source = 2; }
   // legality, whatever the source said
   if (!k.fast) p.tile = 11;
+  if (p.tile == 28 && k.K % 32 != 0) p.tile = 22;
   if (!k.can_split) p.splits = 1;
   if (p.splits < 1) p.splits = 1;
   while (p.splits > 1 && k.K / p.splits < 32) --p.splits;
@@ -225,7 +232,7 @@ extern "C" int blm_gemm_plan_model_us(const blm_gemm_args* a, int tile, int spli
 }
 
 extern "C" int blm_gemm_plan_override(int tile, int splits) {
-  if (tile != 0 && !valid_tile(tile)) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_override: tile must be 0, 11, 12, 21 or 22");
+  if (tile != 0 && !valid_tile(tile)) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_override: tile must be 0, 11, 12, 21, 22 or 28");
   if (splits < 0 || splits > 64) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_override: splits out of range");
   std::lock_guard<std::mutex> lk(g_mu);
   g_force_tile = tile; g_force_splits = splits;

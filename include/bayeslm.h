@@ -218,7 +218,8 @@ int blm_gemm(const blm_gemm_args* a, void* stream);
 int blm_set_gemm_mode(int mode);
 int blm_get_gemm_mode(void);
 
-/* Launch plan of a blm_gemm call: block tile (11 = 64x64, 12 = 64x128, 21 = 128x64, 22 = 128x128 rows x cols) and
+/* Launch plan of a blm_gemm call: block tile (11 = 64x64, 12 = 64x128, 21 = 128x64, 22 = 128x128 rows x cols on four waves;
+ * 28 = 128x128 on EIGHT waves: two waves per SIMD in one barrier domain, aligned operands and K % 32 == 0 only) and
  * number of K slices (> 1: partial sums meet in C through float atomics).  The reference leaves this to the vendor
  * BLAS behind F.linear (model.py:1127-1129); here it is one explicit rule for every shape (csrc/gemm_plan.hip):
  * override > plan table (exact-shape entries measured inside the benchmark / recipe steps, csrc/gemm_plans.inc,

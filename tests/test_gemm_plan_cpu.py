@@ -52,7 +52,7 @@ def test_every_plan_is_legal_and_deterministic():
                     for epi, acc in ((L.EPI_NONE, False), (L.EPI_NONE, True), (L.EPI_BIAS, False)):
                         a = args(op, m, n, k, epi, acc)
                         t, s, src, us = plan(a)
-                        assert t in (11, 12, 21, 22) and 1 <= s <= 16 and src in (0, 1) and us > 0
+                        assert t in (11, 12, 21, 22, 28) and 1 <= s <= 16 and src in (0, 1) and us > 0
                         assert plan(a)[:2] == (t, s)
                         if epi != L.EPI_NONE:
                             assert s == 1  # partial sums cannot pass through a bias epilogue
@@ -61,6 +61,8 @@ def test_every_plan_is_legal_and_deterministic():
                         fast = all(v % 4 == 0 and v >= 4 for v in ((m if op == L.GEMM_TN else k), (k if op == L.GEMM_NT else n)))
                         if not fast:
                             assert t == 11  # odd extents: only the guarded 64x64 kernel exists
+                        if t == 28:
+                            assert k % 32 == 0  # the eight-wave tile has no K-tail path
 
 
 def test_split_k_needs_a_dense_or_accumulated_c_and_aligned_operands_get_all_tiles():

@@ -9,36 +9,37 @@ import sys
 import numpy as np
 from scipy.optimize import least_squares
 
-TILES = {11: (1, 1, 5), 12: (1, 2, 3), 21: (2, 1, 3), 22: (2, 2, 2)}
-TIDX = {11: 0, 12: 1, 21: 2, 22: 3}
+TILES = {11: (1, 1, 5), 12: (1, 2, 3), 21: (2, 1, 3), 22: (2, 2, 2), 28: (2, 2, 2)}  # 28: 128x128 on eight waves
+TIDX = {11: 0, 12: 1, 21: 2, 22: 3, 28: 4}
+NTILE = 5
 
 
 def unpack(x):
     p = {}
-    p["einf"] = x[0:12].reshape(3, 4)
-    p["a"] = x[12:16]
-    p["t0"] = x[16:20]
-    p["t0r"] = x[20:24]
-    p["launch"] = x[24]
-    p["atomic"] = x[25]
-    p["memset_us"] = x[26]
-    p["memset_bpus"] = x[27]
-    p["hbm"] = x[28]
-    p["t0o"] = x[29:33]
+    n = NTILE
+    p["einf"] = x[0:3 * n].reshape(3, n)
+    o = 3 * n
+    p["a"] = x[o:o + n]
+    p["t0"] = x[o + n:o + 2 * n]
+    p["t0r"] = x[o + 2 * n:o + 3 * n]
+    o += 3 * n
+    p["launch"], p["atomic"], p["memset_us"], p["memset_bpus"], p["hbm"] = x[o:o + 5]
+    p["t0o"] = x[o + 5:o + 5 + n]
     return p
 
 
-X0 = np.concatenate([np.full(12, 0.9), np.full(4, 0.3), np.full(4, 3.0), np.full(4, 1.0), [2.0, 1.6e6, 2.0, 3.0e6, 4.0e6], np.full(4, 0.5)])
-LO = np.concatenate([np.full(12, 0.3), np.full(4, 0.0), np.full(4, 0.0), np.full(4, 0.0), [0.5, 1e5, 0.0, 5e5, 1e6], np.full(4, 0.0)])
-HI = np.concatenate([np.full(12, 1.2), np.full(4, 3.0), np.full(4, 30.0), np.full(4, 30.0), [8.0, 2e7, 20.0, 2e7, 8e6], np.full(4, 10.0)])
+N5 = NTILE
+X0 = np.concatenate([np.full(3 * N5, 0.9), np.full(N5, 0.3), np.full(N5, 3.0), np.full(N5, 1.0), [2.0, 1.6e6, 2.0, 3.0e6, 4.0e6], np.full(N5, 0.5)])
+LO = np.concatenate([np.full(3 * N5, 0.3), np.full(N5, 0.0), np.full(N5, 0.0), np.full(N5, 0.0), [0.5, 1e5, 0.0, 5e5, 1e6], np.full(N5, 0.0)])
+HI = np.concatenate([np.full(3 * N5, 1.2), np.full(N5, 3.0), np.full(N5, 30.0), np.full(N5, 30.0), [8.0, 2e7, 20.0, 2e7, 8e6], np.full(N5, 10.0)])
 CYC = 2400.0  # nominal cycles per microsecond; the efficiencies absorb the clock under load
 
 
 def model(p, op, M, N, K, acc, tile, S):
     """vectorised over numpy arrays (tile as index 0..3)"""
-    wtm = np.array([1, 1, 2, 2])[tile]
-    wtn = np.array([1, 2, 1, 2])[tile]
-    occ = np.array([5, 3, 3, 2])[tile]
+    wtm = np.array([1, 1, 2, 2, 2])[tile]
+    wtn = np.array([1, 2, 1, 2, 2])[tile]
+    occ = np.array([5, 3, 3, 2, 2])[tile]
     BM, BN = 64 * wtm, 64 * wtn
     tiles = np.ceil(M / BM) * np.ceil(N / BN)
     G = tiles * S
@@ -70,6 +71,8 @@ def main():
     for i, r in enumerate(rows):
         for lab, v in r["us"].items():
             t, s = lab.split("/")
+            if int(t) == 28 and r["K"] % 32 != 0:
+                continue
             op.append(r["op"]); M.append(r["M"]); N.append(r["N"]); K.append(r["K"]); acc.append(r["acc"])
             tile.append(TIDX[int(t)]); S.append(int(s)); us.append(v); sid.append(i)
     op, tile, sid = np.array(op), np.array(tile), np.array(sid)

@@ -27,7 +27,7 @@ from bayeslms_amd import _lib as L, engine, model as M, ops  # noqa: E402
 from bayeslms_amd.data import batchify, get_batch, synthetic_corpus  # noqa: E402
 
 OPN = ("NT", "NN", "TN")
-TILES = (11, 12, 21, 22)
+TILES = (11, 12, 21, 22, 28)  # 28 = 128x128 on eight waves (table / override only: the cost model knows the first four)
 SPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
 V33, V10 = 33000, 10000
 
@@ -259,10 +259,12 @@ def write_inc(report, args):
     report without a GPU): per key the candidate with the smallest time summed over the workloads (weighted by launches
     per step), listed only where it beats the cost model's own plan by --gain."""
     tot, model = {}, {}
+    if args.from_json:  # the stored report may predate the current cost model: ask the library (host-only call) again
+        L.check(L.lib().blm_gemm_plan_clear(0), "clear")
     for r in report:
         for row in r["rows"]:
             k = tuple(row["key"])
-            model[k] = tuple(row["model_plan"])
+            model[k] = query(*k[:4], k[4], bool(k[5]))[:2] if args.from_json else tuple(row["model_plan"])
             for lab, us in row["cands"].items():
                 t, s_ = lab.split("/")
                 tot.setdefault(k, {}).setdefault((int(t), int(s_)), [0.0, 0])
@@ -278,7 +280,7 @@ def write_inc(report, args):
         # more of its operands from the memory side (tools/traffic_probe.sh: co-resident workgroups drift apart along K and
         # fetch their shared panels again; 8192 x 512 x 4096: 370 / 273 / 218 MB on 64x64 / 128x64 / 128x128 tiles): it has
         # to pay for those bytes with at least --small-tile-gain
-        area = {11: 1, 12: 2, 21: 2, 22: 4}
+        area = {11: 1, 12: 2, 21: 2, 22: 4, 28: 4}
         need = args.small_tile_gain if area[t] < area[mp[0]] else args.gain
         if mp in c and c[mp] <= c[(t, s_)] * (1.0 + need):
             alt = {lab: v for lab, v in c.items() if area[lab[0]] >= area[mp[0]]}
@@ -288,6 +290,8 @@ def write_inc(report, args):
         lines.append("    {%d, %d, %d, %d, %d, %d, %d, %d},  // %s: %.1f us per step in situ; cost model's plan %d/%d: %s"
                      % (k[0], k[1], k[2], k[3], k[4], k[5], t, s_, OPN[k[0]], c[(t, s_)], mp[0], mp[1],
                         ("%.1f us" % c[mp]) if mp in c else "not measured"))
+    if args.from_json:
+        L.check(L.lib().blm_gemm_plan_clear(1), "clear")
     names = ",".join(r["workload"] for r in report)
     inc = ("// Plan table of the fp32 MFMA GEMM: {layout, M, N, K, epilogue, accumulate, tile, K slices}.  GENERATED by\n"
            "// tools/gemm_tune.py --write-inc from IN-SITU measurements on one MI355X (every candidate tile x slice count forced\n"

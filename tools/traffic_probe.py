@@ -24,7 +24,7 @@ def main():
         A = torch.randn(M, K, device=dev)
         B = torch.randn(N, K, device=dev)
         Cm = torch.empty(M, N, device=dev)
-        for tile in (21, 22, 12, 11):
+        for tile in (21, 22, 12, 11, 28):
             L.check(L.lib().blm_gemm_plan_override(tile, 1), "override")
             for r in range(reps):
                 flush.fill_(float(r))

@@ -68,7 +68,7 @@ def main():
         res[build] = table
         print("== build %s" % build)
         for r in table:
-            wg = {21: (8192 // 128) * (512 // 64), 22: (8192 // 128) * (512 // 128), 12: (8192 // 64) * (512 // 128), 11: (8192 // 64) * (512 // 64)}[r["tile"]]
+            wg = {21: (8192 // 128) * (512 // 64), 22: (8192 // 128) * (512 // 128), 12: (8192 // 64) * (512 // 128), 11: (8192 // 64) * (512 // 64), 28: (8192 // 128) * (512 // 128)}[r["tile"]]
             rd_alg = r["algorithmic_bytes_8xW"] - 4.0 * 8192 * 512
             sized = r.get("read_bytes_sized")
             fx2 = r.get("read_bytes_fetch_x2")
