@@ -663,7 +663,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
 // C elements that are never stored); only a K tail tile goes through the guarded loaders.
 // WGN = columns of the wave grid: 2 (4 waves as 2 x 2, the tiles 11 / 12 / 21 / 22) or 4 (8 waves as 2 x 4: tile 28 = 128 x 128 run by
 // eight waves of 64 x 32 -- the per-wave shape and the two waves per SIMD of the 128 x 64 tile inside ONE barrier domain, so the
-// halves cannot drift apart along K and their shared B panel is staged once; LDS-DMA path, whole K tiles only: host-checked)
+// halves cannot drift apart along K and their shared B panel is staged once; LDS-DMA path, whole K tiles only: host-checked).
+// Measured and not kept: 128 x 256 on eight waves of 64 x 64 (WTM = WTN = 2, WGN = 4): +2-5 % stand-alone on the 8192 x 4096 x 512
+// products, never the in-situ winner of any shape of the ten tuned workloads.
 template <int OP, int WTM, int WTN, bool SAMP, bool FAST, int SPLIT = 0, int WGN = 2>  // SPLIT: 0 fp32 MFMA, 3 / 6 opt-in bf16 part products
 __global__ __launch_bounds__(128 * WGN, WGN == 2 ? 2 : 1) void gemm_f32_kernel(const GemmP p) {
   constexpr int BM = 64 * WTM, BN = 32 * WTN * WGN, NT = 128 * WGN;

@@ -27,7 +27,7 @@ from bayeslms_amd import _lib as L, engine, model as M, ops  # noqa: E402
 from bayeslms_amd.data import batchify, get_batch, synthetic_corpus  # noqa: E402
 
 OPN = ("NT", "NN", "TN")
-TILES = (11, 12, 21, 22, 28)  # 28 = 128x128 on eight waves (table / override only: the cost model knows the first four)
+TILES = (11, 12, 21, 22, 28)  # 28 = 128x128 on eight waves
 SPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
 V33, V10 = 33000, 10000
 
