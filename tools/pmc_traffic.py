@@ -20,9 +20,11 @@ def _roofline_launch():
     a.abi_version, a.op, a.M, a.N, a.K, a.lda, a.ldb, a.ldc = L.ABI_VERSION, L.GEMM_NT, 8192, 512, 4096, 4096, 4096, 512
     pl = L.GemmPlan()
     L.check(L.lib().blm_gemm_plan_query(C.byref(a), C.byref(pl)), "blm_gemm_plan_query")
-    wtm, wtn = pl.tile // 10, pl.tile % 10
-    nwg = ((8192 + 64 * wtm - 1) // (64 * wtm)) * ((512 + 64 * wtn - 1) // (64 * wtn)) * pl.splits
-    return "void blm::gemm_f32_kernel<0, %d, %d, false, true" % (wtm, wtn), str(256 * nwg)
+    # tile code -> (WTM, WTN, wave-grid columns): 28 is the 128 x 128 tile on eight waves of 64 x 32
+    wtm, wtn, wgn = {11: (1, 1, 2), 12: (1, 2, 2), 21: (2, 1, 2), 22: (2, 2, 2), 28: (2, 1, 4)}[pl.tile]
+    bm, bn = 64 * wtm, 32 * wtn * wgn
+    nwg = ((8192 + bm - 1) // bm) * ((512 + bn - 1) // bn) * pl.splits
+    return "void blm::gemm_f32_kernel<0, %d, %d, false, true, 0, %d>" % (wtm, wtn, wgn), str(128 * wgn * nwg)
 
 
 KERNEL, GRID = os.environ.get("KERNEL"), os.environ.get("GRID")  # another instantiation (A/B of two tiles)

@@ -33,12 +33,12 @@ with open(out + "/bench_cfg3_kernel_stats_by_grid.csv", "w") as g:
     for tot, (k, grid, _), n in rows[:70]:
         g.write('"%s",%s,%d,%.1f,%.2f\n' % (k, grid, n, tot / 1e3, tot / n / 1e3))
 PY
-# the same launch forced onto 64x64 and 128x128 tiles, in situ: traffic / time trade-off of the tile choice
-for t in 11 22; do
+# the same launch forced onto the 4-wave tiles 64x64, 128x64 and 128x128, in situ: traffic / time trade-off of the tile choice
+for t in 11 21 22; do
   export BLM_GEMM_PLAN_SET="0,8192,512,4096,0,0,$t,1;0,8192,512,4096,1,0,$t,1"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_t$t -o bench -- $B --steps 4 --warmup 1 > $OUT/fetch_t$t.log 2>&1
   unset BLM_GEMM_PLAN_SET
-  if [ $t = 11 ]; then K="void blm::gemm_f32_kernel<0, 1, 1, false, true"; G=262144; else K="void blm::gemm_f32_kernel<0, 2, 2, false, true"; G=65536; fi
+  if [ $t = 11 ]; then K="void blm::gemm_f32_kernel<0, 1, 1, false, true, 0, 2>"; G=262144; elif [ $t = 21 ]; then K="void blm::gemm_f32_kernel<0, 2, 1, false, true, 0, 2>"; G=131072; else K="void blm::gemm_f32_kernel<0, 2, 2, false, true, 0, 2>"; G=65536; fi
   KERNEL="$K" GRID=$G python3 tools/pmc_traffic.py $(find $OUT/fetch_t$t -name "*counter_collection.csv" | head -1) $W $OUT/pmc_sampled_gemm_fwd_tile${t}_in_situ.json || true
 done
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +3M -delete
