@@ -422,7 +422,7 @@ __device__ __forceinline__ void epi_elem(const GemmP& p, bool accum, int row, in
   const long o = (long)row * p.ldc + col;
   float v = p.alpha * acc;
   if constexpr (EPI == BLM_EPI_BIAS) {
-    v += bias;
+    if (kl_on) v += bias;  // K slices: the first one carries the bias
   } else if constexpr (EPI == BLM_EPI_BIAS_GELU) {
     v += bias;
     float cdf, e;
@@ -458,7 +458,7 @@ __device__ __forceinline__ void epi_elem(const GemmP& p, bool accum, int row, in
       v = dW + klw * p.wg_mu[o];
     }
   }
-  if constexpr (EPI == BLM_EPI_NONE || EPI == BLM_EPI_BAYES_WGRAD) {
+  if constexpr (EPI == BLM_EPI_NONE || EPI == BLM_EPI_BIAS || EPI == BLM_EPI_BAYES_WGRAD) {
     if (p.atomic) { atomicAdd(p.C + o, v); return; }
   }
   p.C[o] = accum ? p.C[o] + v : v;
@@ -1216,7 +1216,7 @@ __global__ __launch_bounds__(128 * WGN, WGN == 2 ? 2 : 1) void gemm_f32_kernel(c
     }
   }
   switch (p.epi) {
-    case BLM_EPI_BIAS: epilogue<BLM_EPI_BIAS, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
+    case BLM_EPI_BIAS: epilogue<BLM_EPI_BIAS, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh, ks == 0); break;
     case BLM_EPI_BIAS_GELU: epilogue<BLM_EPI_BIAS_GELU, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
     case BLM_EPI_MUL_DGELU: epilogue<BLM_EPI_MUL_DGELU, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
     case BLM_EPI_GP_MIX: epilogue<BLM_EPI_GP_MIX, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
@@ -1240,7 +1240,7 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   q.gm = (p.M + BM - 1) / BM;
   q.gn = (p.N + BN - 1) / BN;
   const long nb = (long)q.gm * q.gn;
-  // K slices as planned (gemm_plan.hip: legality -- plain or Bayesian-wgrad epilogue, dense or accumulated C -- is the
+  // K slices as planned (gemm_plan.hip: legality -- plain, bias or Bayesian-wgrad epilogue, dense or accumulated C -- is the
   // planner's); partial sums meet in C through float atomics, C is zeroed first unless accumulating
   const int splits = p.plan_splits > 1 ? p.plan_splits : 1;
   q.splits = splits;

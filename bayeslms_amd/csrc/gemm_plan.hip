@@ -200,10 +200,11 @@ blm::PlanKey blm::plan_key(const blm_gemm_args* a) {
   k.op = a->op; k.M = a->M; k.N = a->N; k.K = a->K; k.epi = a->epilogue;
   k.acc = (a->flags & BLM_GEMM_ACCUMULATE) ? 1 : 0;
   const bool samp = a->var_b.lgstd != nullptr;
-  // split-K: partial sums meet in C through float atomics -- only for the plain epilogue (C zeroed first unless
-  // accumulating, which needs a dense C) and for the Bayesian wgrad epilogue, which is linear in dW (KL terms from the
-  // first slice only) but has no zeroing pass for its second output
-  k.can_split = !samp && ((a->epilogue == BLM_EPI_NONE && (k.acc || a->ldc == a->N)) || (a->epilogue == BLM_EPI_BAYES_WGRAD && k.acc));
+  // split-K: partial sums meet in C through float atomics -- only for the plain and bias epilogues (C zeroed first unless
+  // accumulating, which needs a dense C; the bias rides on the first slice) and for the Bayesian wgrad epilogue, which is
+  // linear in dW (KL terms from the first slice only) but has no zeroing pass for its second output
+  const bool lin = a->epilogue == BLM_EPI_NONE || a->epilogue == BLM_EPI_BIAS;
+  k.can_split = !samp && ((lin && (k.acc || a->ldc == a->N)) || (a->epilogue == BLM_EPI_BAYES_WGRAD && k.acc));
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const int ac = a->op == BLM_GEMM_TN ? a->M : a->K, bc = a->op == BLM_GEMM_NT ? a->K : a->N;
   k.fast = al16(a->A) && al16(a->B) && a->lda % 4 == 0 && a->ldb % 4 == 0 && ac % 4 == 0 && bc % 4 == 0 && ac >= 4 && bc >= 4;

@@ -49,13 +49,13 @@ def test_every_plan_is_legal_and_deterministic():
         for m in dims:
             for n in dims:
                 for k in (1, 32, 500, 512, 4096, 33000):
-                    for epi, acc in ((L.EPI_NONE, False), (L.EPI_NONE, True), (L.EPI_BIAS, False)):
+                    for epi, acc in ((L.EPI_NONE, False), (L.EPI_NONE, True), (L.EPI_BIAS, False), (L.EPI_BIAS_GELU, False)):
                         a = args(op, m, n, k, epi, acc)
                         t, s, src, us = plan(a)
                         assert t in (11, 12, 21, 22, 28) and 1 <= s <= 16 and src in (0, 1) and us > 0
                         assert plan(a)[:2] == (t, s)
-                        if epi != L.EPI_NONE:
-                            assert s == 1  # partial sums cannot pass through a bias epilogue
+                        if epi not in (L.EPI_NONE, L.EPI_BIAS):
+                            assert s == 1  # partial sums cannot pass through a non-linear epilogue (the bias rides on slice 0)
                         if s > 1:
                             assert k // s >= 32
                         fast = all(v % 4 == 0 and v >= 4 for v in ((m if op == L.GEMM_TN else k), (k if op == L.GEMM_NT else n)))
@@ -69,6 +69,8 @@ def test_split_k_needs_a_dense_or_accumulated_c_and_aligned_operands_get_all_til
     assert plan(args(L.GEMM_NN, 64, 4096, 8192))[1] > 1                      # skinny output, long K: slices fill the chip
     assert plan(args(L.GEMM_NN, 64, 4096, 8192, ldc=8192))[1] == 1            # a strided C cannot be zeroed in one pass ...
     assert plan(args(L.GEMM_NN, 64, 4096, 8192, ldc=8192, acc=True))[1] > 1   # ... unless it is accumulated into
+    assert plan(args(L.GEMM_NT, 64, 4096, 8192, L.EPI_BIAS))[1] > 1           # the bias epilogue is linear: slices allowed
+    assert plan(args(L.GEMM_NT, 64, 4096, 8192, L.EPI_BIAS, ldc=8192))[1] == 1
     assert plan(args(L.GEMM_NT, 8192, 4096, 4096, misaligned=True))[0] == 11
     assert plan(args(L.GEMM_NT, 8192, 4096, 4096))[0] != 11                   # a big aligned product is not run on 64x64 tiles
 

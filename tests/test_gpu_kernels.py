@@ -128,6 +128,8 @@ def test_gemm_random_shapes_all_paths(dev):
     ("NT", 8192, 512, 4096, False, True),
     ("NN", 8192, 512, 1536, True, False),     # K = 1536: unsplittable, 64x128 tiles
     ("TN", 512, 4096, 8192, True, False),
+    ("NT", 3200, 512, 4096, False, True),     # recipe-shape output projection: the bias epilogue under K slices
+    ("NT", 1600, 512, 8192, True, True),      # ... and accumulating
 ])
 def test_gemm_tile_rule_shapes(dev, op, M, N, K, acc, bias):
     """The shapes the round-2 tile / split rules single out (gemm_f32_mfma.h launch_op), against fp64 on the device."""
@@ -149,6 +151,25 @@ def test_gemm_tile_rule_shapes(dev, op, M, N, K, acc, bias):
     ops.gemm(code, A, B, C, M, N, K, A.stride(0), B.stride(0), N, accumulate=acc,
              epilogue=lib.EPI_BIAS if bias else lib.EPI_NONE, bias=bv)
     assert rel(C, want) < 1e-5
+
+
+@pytest.mark.parametrize("acc", [False, True])
+def test_gemm_bias_epilogue_forced_k_slices(dev, acc):
+    """Bias epilogue under split-K (forced through blm_gemm_plan_override): the bias is added by the first slice only."""
+    ops, lib = ops_mod(), L()
+    g = torch.Generator(device=dev).manual_seed(77)
+    M, N, K = 200, 136, 1056
+    A, B = torch.randn(M, K, device=dev, generator=g), torch.randn(N, K, device=dev, generator=g)
+    bv = torch.randn(N, device=dev, generator=g) * 10
+    for tile, splits in ((11, 4), (22, 3), (28, 2), (12, 8)):
+        C = torch.randn(M, N, device=dev, generator=g)
+        want = A.double() @ B.double().t() + bv.double() + (C.double() if acc else 0)
+        lib.check(lib.lib().blm_gemm_plan_override(tile, splits), "override")
+        try:
+            ops.gemm(lib.GEMM_NT, A, B, C, M, N, K, K, K, N, accumulate=acc, epilogue=lib.EPI_BIAS, bias=bv)
+        finally:
+            lib.check(lib.lib().blm_gemm_plan_override(0, 0), "override")
+        assert rel(C, want) < 1e-5, (tile, splits)
 
 
 def test_gemm_identity_asymmetric(dev):

@@ -2,11 +2,12 @@
 """Measures launch plans (block tile x K slices) of the fp32 MFMA GEMM on one MI355X and writes what
 csrc/gemm_plan.hip consumes.
 
-  gemm_tune.py --workloads cfg3,cfg2,...   IN SITU: every candidate plan is forced on ALL GEMMs of a workload's step
-        (blm_gemm_plan_override), each launch bracketed by HIP events; per distinct (layout, M, N, K, epilogue,
-        accumulate) key the fastest candidate wins (a key shared by several workloads: smallest summed time).  Then the
-        winners are installed (blm_gemm_plan_set) and the step is timed under three planners in the same process:
-        cost model only / the built-in table / the fresh winners.  --write-inc rewrites csrc/gemm_plans.inc.
+  gemm_tune.py --workloads cfg3,cfg2,...   IN SITU: per distinct (layout, M, N, K, epilogue, accumulate) key of a
+        workload's step, every candidate plan is installed for THAT key alone (blm_gemm_plan_set; all other launches keep
+        the library's current plan, so the candidate runs among its real neighbours), each launch bracketed by HIP events;
+        the fastest candidate wins (a key shared by several workloads: smallest summed time).  Then the winners are
+        installed together and the step is timed under three planners in the same process: cost model only / the
+        built-in table / the fresh winners.  --write-inc rewrites csrc/gemm_plans.inc.
   gemm_tune.py --grid                      STAND-ALONE sweep of a log-spaced M x N x K grid, all tiles x slice counts ->
         gpurun_out/gemm_grid.jsonl (the data the cost model's constants are fitted to, tools/gemm_fit.py) and a
         regression verdict: the planner's choice must reach >= --min-frac of the best candidate's rate on every shape.
@@ -148,28 +149,45 @@ def per_key_us(step, n):
     return {k: (tot / cnt, cnt / n) for k, (tot, cnt) in out.items()}
 
 
-def tune_workload(name, dev, reps, passes=2):
+def plan_set(k, t, s):
+    L.check(L.lib().blm_gemm_plan_set(k[0], k[1], k[2], k[3], k[4], k[5], int(t), int(s)), "blm_gemm_plan_set")
+
+
+def tune_workload(name, dev, reps, passes=2, min_share=0.003):
+    """Every candidate of ONE key at a time, all other launches on the plan the library has now: a launch's time depends
+    on its neighbours in the stream (what they left in the L2s, how their tails overlap its ramp), so a candidate forced
+    on every GEMM of the step at once -- rounds 2 and early 3 -- was measured in a context it will never run in (the
+    same 128x128 launch: 245 us among its real neighbours, 256 us with 128x128 forced on all of them)."""
     step, tokens = build(name, dev)
     override(0, 0)
+    L.check(L.lib().blm_gemm_plan_clear(1), "clear")
     for _ in range(3):
         step()
     base = per_key_us(step, reps)                       # the planner as built
     plans = {k: query(*k[:4], k[4], bool(k[5])) for k in base}
-    cand = {k: {} for k in base}
-    for t in TILES * passes:  # every candidate `passes` times, the fastest sample counts (clock / neighbour noise is one-sided)
-        for s in SPLITS:
-            override(t, s)
-            step()
-            r = per_key_us(step, reps)
-            for k, (us, _) in r.items():
-                if k not in cand:
-                    continue
-                # what actually ran: the planner clamps an illegal slice count to what the launch allows
-                eff_t, eff_s, _, _ = query(*k[:4], k[4], bool(k[5]))
-                lab = (eff_t, eff_s)
-                if lab not in cand[k] or us < cand[k][lab]:
-                    cand[k][lab] = us
-    override(0, 0)
+    total = sum(us * n for us, n in base.values())
+    cand = {k: {(plans[k][0], plans[k][1]): base[k][0]} for k in base}
+    for k in sorted(base, key=lambda k: -base[k][0] * base[k][1]):
+        if base[k][0] * base[k][1] < min_share * total:
+            continue
+        for _ in range(passes):  # the fastest sample counts (clock / neighbour noise is one-sided)
+            seen = set()
+            for t in TILES:
+                for s in SPLITS:
+                    plan_set(k, t, s)
+                    lab = query(*k[:4], k[4], bool(k[5]))[:2]  # what will run: the planner clamps to what is legal
+                    if lab in seen:
+                        continue
+                    seen.add(lab)
+                    step()
+                    us = per_key_us(step, reps)[k][0]
+                    if lab not in cand[k] or us < cand[k][lab]:
+                        cand[k][lab] = us
+        L.check(L.lib().blm_gemm_plan_clear(1), "clear")
+        b = min(cand[k], key=cand[k].get)
+        print("   %s %s %dx%dx%d epi%d%s: %d plans, built %d/%d %.1f us, best %d/%d %.1f us" % (
+            name, OPN[k[0]], k[1], k[2], k[3], k[4], " acc" if k[5] else "", len(cand[k]), plans[k][0], plans[k][1],
+            cand[k][(plans[k][0], plans[k][1])], b[0], b[1], cand[k][b]), flush=True)
     return {"name": name, "tokens": tokens, "base": base, "plans": plans, "cand": cand, "step": step}
 
 
@@ -188,10 +206,10 @@ def main():
     ap.add_argument("--gain", type=float, default=0.007, help="a table entry must beat the cost model's plan by this fraction")
     ap.add_argument("--small-tile-gain", type=float, default=0.03,
                     help="... by this fraction when it moves to a tile with more co-resident workgroups (more operand re-reads)")
-    ap.add_argument("--from-json", default="", help="re-derive the table from a stored report (no GPU)")
+    ap.add_argument("--from-json", default="", help="re-derive the table from stored report(s), comma separated: mean of the runs (no GPU)")
     args = ap.parse_args()
     if args.from_json:
-        return write_inc(json.load(open(args.from_json)), args)
+        return write_inc(merge_reports([json.load(open(f)) for f in args.from_json.split(",")]), args)
     dev = torch.device("cuda:0")
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     if args.grid:
@@ -207,12 +225,14 @@ def main():
     for r in results:
         for k, c in r["cand"].items():
             w = r["base"][k][1]
+            if len(c) < 2:  # below --min-share of this workload's GEMM time: not searched here
+                continue
             for lab, us in c.items():
                 tot.setdefault(k, {}).setdefault(lab, 0.0)
                 tot[k][lab] += w * us
     winners = {}
     for k, c in tot.items():
-        full = {lab: v for lab, v in c.items() if all(lab in r["cand"][k] for r in results if k in r["cand"])}
+        full = {lab: v for lab, v in c.items() if all(lab in r["cand"][k] for r in results if len(r["cand"].get(k, ())) > 1)}
         lab = min(full or c, key=(full or c).get)
         winners[k] = lab
     # model-only plans for the same keys (built-in table and run-time entries off)
@@ -237,6 +257,8 @@ def main():
               % (r["name"], ms_model, ms_builtin, ms_win, r["tokens"]), flush=True)
         rows = []
         for k, (us0, n) in sorted(r["base"].items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+            if k not in winners:
+                continue
             c = r["cand"][k]
             best = min(c, key=c.get)
             mp = model_plans[k]
@@ -252,6 +274,24 @@ def main():
         report.append({"workload": r["name"], "ms_model_only": ms_model, "ms_builtin_table": ms_builtin, "ms_winners": ms_win, "rows": rows})
     json.dump(report, open(args.out, "w"), indent=1)
     write_inc(report, args)
+
+
+def merge_reports(reports):
+    """Several stored reports (separate runs / boxes) as one: per workload, key and candidate the MEAN of the runs that
+    measured it -- a candidate only some runs could launch (a legality the library gained since) keeps those runs' value."""
+    by = {}
+    for rep in reports:
+        for r in rep:
+            w = by.setdefault(r["workload"], {})
+            for row in r["rows"]:
+                e = w.setdefault(tuple(row["key"]), {"n": row["launches_per_step"], "model_plan": row["model_plan"], "c": {}})
+                e["n"], e["model_plan"] = row["launches_per_step"], row["model_plan"]
+                for lab, us in row["cands"].items():
+                    if int(lab.split("/")[0]) in TILES:  # a report may hold a tile the library no longer has
+                        e["c"].setdefault(lab, []).append(us)
+    return [{"workload": w, "rows": [{"key": list(k), "launches_per_step": e["n"], "model_plan": e["model_plan"],
+                                      "cands": {lab: sum(v) / len(v) for lab, v in e["c"].items()}} for k, e in keys.items()]}
+            for w, keys in by.items()]
 
 
 def write_inc(report, args):
