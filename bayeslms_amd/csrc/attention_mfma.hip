@@ -789,13 +789,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_long_kernel(const AttnM p) {
 
 using namespace blm;
 
-static int attn_hpw() {  // BLM_ATTN_HPW=1|2: heads per workgroup of the T <= 128 kernels (A/B measurements; default 2)
+// Heads per workgroup of the T <= 128 kernels.  Two heads (8 waves, balanced causal tiles per SIMD, see the forward) as long
+// as that still leaves one workgroup per CU; below -- the recipes' batch 32 (256 heads), evaluation at batch 20 -- one head per
+// workgroup, so that the launch covers twice the CUs (recipe Transformer step 9.23 -> 9.12 ms, evaluation 2.03 -> 2.00 ms;
+// at 512 heads both forms tie).  BLM_ATTN_HPW=1|2 forces one form (A/B measurements).
+static int attn_hpw(int heads) {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("BLM_ATTN_HPW");
-    v = e ? atoi(e) : 2;
+    v = e ? atoi(e) : 0;
   }
-  return v;
+  if (v == 1 || v == 2) return v;
+  return heads / 2 >= 256 ? 2 : 1;
 }
 
 static void fill_m(AttnM& p, int T, int B, int nhead, float pdrop, const blm_rng* rng, int col_offset) {
@@ -837,7 +842,7 @@ int blm_attn_fwd_mfma(const float* q, const float* k, const float* v, int64_t ld
     BLM_HIP(hipGetLastError());
     return BLM_OK;
   }
-  if ((B * nhead) % 2 == 0 && attn_hpw() == 2) hipLaunchKernelGGL(attn_fwd_mfma_kernel<2>, dim3(B * nhead / 2), dim3(512), 2 * lds, st, p);
+  if ((B * nhead) % 2 == 0 && attn_hpw(B * nhead) == 2) hipLaunchKernelGGL(attn_fwd_mfma_kernel<2>, dim3(B * nhead / 2), dim3(512), 2 * lds, st, p);
   else hipLaunchKernelGGL(attn_fwd_mfma_kernel<1>, dim3(B * nhead), dim3(256), lds, st, p);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
@@ -890,7 +895,7 @@ int blm_attn_bwd_mfma(const float* q, const float* k, const float* v, int64_t ld
     BLM_HIP(hipGetLastError());
     return BLM_OK;
   }
-  const bool two = (B * nhead) % 2 == 0 && attn_hpw() == 2;
+  const bool two = (B * nhead) % 2 == 0 && attn_hpw(B * nhead) == 2;
   static int fuse = -1;  // BLM_ATTN_FUSE_DQ=0: dQ = dS K as a separate launch (A/B measurements)
   if (fuse < 0) { const char* e = getenv("BLM_ATTN_FUSE_DQ"); fuse = e ? atoi(e) : 1; }
   if (p.ds && fuse) {  // ONE launch: dK/dV, dS through the workspace, dQ = dS K by the same workgroup

@@ -61,11 +61,23 @@ __device__ __forceinline__ float gemm_keep(const GemmP& p, int m, int n) {
 }
 
 constexpr int BK = 32;
+#if defined(BLM_GEMM_PROF) && !defined(BLM_GEMM_LIFE)
+#define BLM_GEMM_LIFE  // the per-trip phase counters (heavy: they serialise the loop) imply the three stamps per workgroup (cheap)
+#endif
 #ifdef BLM_GEMM_PROF
 static __device__ unsigned long long blm_prof[4];  // per translation unit (debug build only)
-// life of every workgroup of the LAST launch (tools/gemm_drift_probe.py): [4*bid] = wall clock (10 ns) at entry,
-// [+1] at the end of the K loop, [+2] HW_ID (CU / SE / slot), [+3] XCC_ID
+#endif
+#ifdef BLM_GEMM_LIFE
+// life of every workgroup of the LAST launch (tools/gemm_drift_probe.py, gemm_phase_probe.py): [4*bid] = wall clock
+// (10 ns) at entry, [+1] at the end of the K loop, [+2] HW_ID (CU / SE / slot) | XCC_ID << 32, [+3] wall clock when the
+// epilogue's last instruction has been issued
 static __device__ long long blm_wg_life[4 * 8192];
+#define BLM_PROF_WG_END() do { if (threadIdx.x == 0 && blockIdx.x < 8192) blm_wg_life[4 * blockIdx.x + 3] = wall_clock64(); } while (0)
+// tools/gemm_epi_probe.py: 1 = the row-wise epilogue computes but does not store, 2 = every workgroup stores to tile (0, 0)
+// (the stores are issued but never leave the L2)
+static __device__ int blm_dbg_store;
+#else
+#define BLM_PROF_WG_END() do { } while (0)
 #endif
 // Epilogue-only switch kept from an experiment (two MFMA tiles of a wave interleaved by rows 2x+t
 // instead of stacked 32t+x; measured neutral on MI355X): the operand paths below are the stacked form.
@@ -545,12 +557,17 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN]
       }
     }
   }
+  BLM_PROF_WG_END();
 }
 
 // Row-wise epilogue through LDS: the accumulator tile (columns on lanes, rows in registers) is
 // written to the now idle staging buffer 64 rows at a time and read back row-major, so every lane
 // handles 4 consecutive columns: 16-byte loads of bias/aux, one Philox block per lane for the
 // dropout mask, 16-byte stores of C (4x fewer memory instructions than the register-layout walk).
+// (Measured and not kept: the non-temporal hint on these stores -- no change; tools/gemm_epi_probe.py on a -DBLM_GEMM_LIFE
+// build shows the stores cost nothing at all: 8192 x 4096 x 512 runs 256 us with them compiled out, 258 us as shipped.)
+__device__ __forceinline__ void store4(float* dst, const float4& v) { *reinterpret_cast<float4*>(dst) = v; }
+
 template <int EPI, int WTM, int WTN, int WGN = 2>
 __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM][WTN], float* stage, int m0, int n0,
                                               int wm, int wn, int li, int lh) {
@@ -602,7 +619,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
         } else if constexpr (EPI == BLM_EPI_GP_MIX) {  // z = acc + bias kept for backward; out = mixture(z) * keep
           const float4 kp = keep4(row);
           v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-          if (p.aux) *reinterpret_cast<float4*>(p.aux + o) = v;
+          if (p.aux) store4(p.aux + o, v);
           v.x = gp_mix(v.x, p.coef, p.N, col) * kp.x;
           v.y = gp_mix(v.y, p.coef, p.N, col + 1) * kp.y;
           v.z = gp_mix(v.z, p.coef, p.N, col + 2) * kp.z;
@@ -610,7 +627,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
         } else if constexpr (EPI == BLM_EPI_MUL_DGP_MIX) {  // a = z of the forward; C2 = grad w.r.t. the mixture value
           const float4 kp = keep4(row);
           v.x *= kp.x; v.y *= kp.y; v.z *= kp.z; v.w *= kp.w;
-          if (p.C2) *reinterpret_cast<float4*>(p.C2 + o) = v;
+          if (p.C2) store4(p.C2 + o, v);
           v.x *= dgp_mix(a.x, p.coef, p.N, col);
           v.y *= dgp_mix(a.y, p.coef, p.N, col + 1);
           v.z *= dgp_mix(a.z, p.coef, p.N, col + 2);
@@ -623,13 +640,17 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
           v.y += bias.y; gelu_parts(v.y, cdf, e); d.y = (cdf + v.y * 0.3989422804014327f * e) * kp.y; v.y = v.y * cdf * kp.y;
           v.z += bias.z; gelu_parts(v.z, cdf, e); d.z = (cdf + v.z * 0.3989422804014327f * e) * kp.z; v.z = v.z * cdf * kp.z;
           v.w += bias.w; gelu_parts(v.w, cdf, e); d.w = (cdf + v.w * 0.3989422804014327f * e) * kp.w; v.w = v.w * cdf * kp.w;
-          if (p.aux) *reinterpret_cast<float4*>(p.aux + o) = d;
+          if (p.aux) store4(p.aux + o, d);
         } else if constexpr (EPI == BLM_EPI_MUL_DGELU) {
           v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
         }
         float4* dst = reinterpret_cast<float4*>(p.C + o);
         if (accum) { const float4 old = *dst; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
-        *dst = v;
+#ifdef BLM_GEMM_LIFE
+        if (blm_dbg_store == 1) { if (v.x == 1.2345e-30f) store4(p.C + o, v); return; }
+        if (blm_dbg_store == 2) { store4(p.C + (long)(lr + 64 * pass) * p.ldc + c4, v); return; }
+#endif
+        store4(p.C + o, v);
       };
       if constexpr (EPI == BLM_EPI_MUL_DGELU || EPI == BLM_EPI_MUL_DGP_MIX) {
         // the second factor of all this pass's rows is requested in one go (a load inside the row loop
@@ -655,6 +676,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
       }
     }
   }
+  BLM_PROF_WG_END();
 }
 
 // FAST: every operand 16-B aligned with a leading dimension and contiguous extent that are
@@ -708,11 +730,11 @@ __global__ __launch_bounds__(128 * WGN, WGN == 2 ? 2 : 1) void gemm_f32_kernel(c
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WGN, wn = wave % WGN, li = lane & 31, lh = lane >> 5;
-#ifdef BLM_GEMM_PROF
+#ifdef BLM_GEMM_LIFE
   if (t == 0 && blockIdx.x < 8192) {
     blm_wg_life[4 * blockIdx.x] = wall_clock64();
-    blm_wg_life[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
-    blm_wg_life[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    blm_wg_life[4 * blockIdx.x + 2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |            // HW_REG_HW_ID
+                                      ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // HW_REG_XCC_ID
   }
 #endif
 
@@ -1170,8 +1192,10 @@ __global__ __launch_bounds__(128 * WGN, WGN == 2 ? 2 : 1) void gemm_f32_kernel(c
       __syncthreads();
     }
   }
-#ifdef BLM_GEMM_PROF
+#ifdef BLM_GEMM_LIFE
   if (t == 0 && blockIdx.x < 8192) blm_wg_life[4 * blockIdx.x + 1] = wall_clock64();
+#endif
+#ifdef BLM_GEMM_PROF
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(&blm_prof[0], pf_compute); atomicAdd(&blm_prof[1], pf_stash); atomicAdd(&blm_prof[2], pf_barrier); atomicAdd(&blm_prof[3], pf_n);
   }

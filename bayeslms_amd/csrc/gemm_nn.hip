@@ -13,3 +13,9 @@ extern "C" int blm_debug_prof_nn(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
+#ifdef BLM_GEMM_LIFE
+extern "C" int blm_debug_store_mode_nn(int mode) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(blm::blm_dbg_store), &mode, sizeof(int)); }
+extern "C" int blm_debug_wg_life_nn(long long* out, int nwg) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(blm::blm_wg_life), (size_t)4 * nwg * sizeof(long long));
+}
+#endif

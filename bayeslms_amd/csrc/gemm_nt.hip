@@ -12,6 +12,9 @@ extern "C" int blm_debug_prof_nt(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(blm::blm_prof), z, sizeof(z)); }
   return 0;
 }
+#endif
+#ifdef BLM_GEMM_LIFE
+extern "C" int blm_debug_store_mode_nt(int mode) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(blm::blm_dbg_store), &mode, sizeof(int)); }
 extern "C" int blm_debug_wg_life_nt(long long* out, int nwg) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(blm::blm_wg_life), (size_t)4 * nwg * sizeof(long long));
 }

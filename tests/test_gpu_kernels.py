@@ -452,6 +452,8 @@ def test_add_dropout_ln(dev, D):
 
 @pytest.mark.parametrize("T,B,nhead,hd", [(6, 3, 4, 4), (100, 2, 2, 32), (128, 3, 2, 64), (33, 2, 1, 16), (33, 2, 2, 64),
                                           (1, 1, 1, 64), (97, 1, 3, 64),
+                                          # 512 heads and more: two heads per workgroup (below: one, to cover more CUs)
+                                          (128, 64, 8, 64), (100, 65, 8, 64), (37, 128, 4, 64),
                                           # longer than 128: the chunked (flash-style) matrix-core kernels
                                           (129, 2, 2, 64), (200, 1, 3, 64), (256, 2, 1, 64), (301, 1, 2, 64), (515, 1, 1, 64),
                                           # any other head size / length: the untiled one-wave-per-row kernels
@@ -481,7 +483,7 @@ def test_attention_matches_oracle(dev, T, B, nhead, hd):
 
 
 @pytest.mark.parametrize("T,B,nhead,hd", [(8, 2, 2, 4), (96, 2, 2, 64), (50, 3, 1, 64), (128, 1, 2, 64), (160, 2, 1, 64),
-                                          (203, 1, 2, 64), (30, 2, 2, 100), (131, 1, 1, 32)])
+                                          (203, 1, 2, 64), (30, 2, 2, 100), (131, 1, 1, 32), (66, 64, 8, 64)])
 def test_attention_dropout_uses_philox_mask(dev, T, B, nhead, hd):
     """Probability dropout (VALU kernels for small heads, MFMA kernels for head_dim 64; T % 4 != 0
     takes the per-element Philox path)."""
@@ -509,7 +511,7 @@ def test_attention_dropout_uses_philox_mask(dev, T, B, nhead, hd):
 
 
 @pytest.mark.parametrize("T,B,nhead,p", [(128, 4, 8, 0.2), (128, 3, 1, 0.0), (97, 1, 3, 0.3), (50, 3, 2, 0.4), (33, 2, 2, 0.0),
-                                         (1, 1, 1, 0.0), (64, 2, 2, 0.1), (130, 2, 2, 0.2)])
+                                         (1, 1, 1, 0.0), (64, 2, 2, 0.1), (130, 2, 2, 0.2), (100, 64, 8, 0.2)])
 def test_attention_backward_workspace_path_equals_recomputation(dev, monkeypatch, T, B, nhead, p):
     """blm_attn_bwd_ws (dK/dV pass leaves dS in the scratch buffer, dQ = dS K by the same workgroup) against blm_attn_bwd
     (two recomputations): one or two heads per workgroup, partial tiles, T % 4 != 0, dropout on/off; T > 128 asks for no

@@ -31,7 +31,7 @@ def main():
             assert lib.blm_debug_wg_life_nt(buf, nwg) == 0
             st = [buf[4 * i] for i in range(nwg)]
             en = [buf[4 * i + 1] for i in range(nwg)]
-            cu = [(buf[4 * i + 3] & 15, (buf[4 * i + 2] >> 13) & 7, (buf[4 * i + 2] >> 12) & 1, (buf[4 * i + 2] >> 8) & 15) for i in range(nwg)]
+            cu = [((buf[4 * i + 2] >> 32) & 15, (buf[4 * i + 2] >> 13) & 7, (buf[4 * i + 2] >> 12) & 1, (buf[4 * i + 2] >> 8) & 15) for i in range(nwg)]
             t0, t1 = min(st), max(en)
             span = (t1 - t0) * 0.01
             per = defaultdict(list)
