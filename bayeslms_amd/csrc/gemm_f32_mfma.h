@@ -47,6 +47,8 @@ struct GemmP {
   int plan_tile, plan_splits;    // gemm_plan.hip: 11 / 12 / 21 / 22 and the number of K slices (>= 1)
   float* colsum_a;  // TN only: += column sums of A (= bias gradient of the layer whose wgrad this is)
   int splits, kper, atomic;  // split-K: block ks covers k in [ks*kper, (ks+1)*kper), partial sums by float atomics
+  int tail_from;             // tiles (in launch order) below this index are computed whole by one workgroup; only the rest -- the
+                             // tiles beyond the last full round of workgroup slots -- are sliced (0: every tile is sliced)
   // fused activation dropout
   int drop_on; uint32_t drop_thr; float drop_inv_keep; blm_rng drop_rng;
   int drop_B, drop_col_offset, drop_global_cols, drop_quad;
@@ -430,7 +432,7 @@ __device__ __forceinline__ void gemm_eps_quad(const GemmP& p, int base_row, int 
 // two operand values a lane needs per k-step are adjacent in LDS (one ds_read_b64) and a lane's two
 // output columns are adjacent in C.
 template <int EPI>
-__device__ __forceinline__ void epi_elem(const GemmP& p, bool accum, int row, int col, float acc, float bias, float keep, bool kl_on = true) {
+__device__ __forceinline__ void epi_elem(const GemmP& p, bool accum, int row, int col, float acc, float bias, float keep, bool kl_on = true, bool atomic = false) {
   const long o = (long)row * p.ldc + col;
   float v = p.alpha * acc;
   if constexpr (EPI == BLM_EPI_BIAS) {
@@ -465,20 +467,20 @@ __device__ __forceinline__ void epi_elem(const GemmP& p, bool accum, int row, in
       // them) are contributed by the first slice only
       const float klw = kl_on ? p.kl_lambda * p.kl_inv_n : 0.f;
       const float g2 = dW * e * sig + klw * (sig * sig - 1.0f);
-      if (p.atomic) atomicAdd(p.C2 + si, g2);
+      if (atomic) atomicAdd(p.C2 + si, g2);
       else p.C2[si] = accum ? p.C2[si] + g2 : g2;
       v = dW + klw * p.wg_mu[o];
     }
   }
   if constexpr (EPI == BLM_EPI_NONE || EPI == BLM_EPI_BIAS || EPI == BLM_EPI_BAYES_WGRAD) {
-    if (p.atomic) { atomicAdd(p.C + o, v); return; }
+    if (atomic) { atomicAdd(p.C + o, v); return; }
   }
   p.C[o] = accum ? p.C[o] + v : v;
 }
 
 template <int EPI, int WTM, int WTN>
 __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN], int m0, int n0, int wm, int wn,
-                                         int li, int lh, bool kl_on = true) {
+                                         int li, int lh, bool kl_on = true, bool atomic = false) {
   constexpr bool DROP = (EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_GP_MIX || EPI == BLM_EPI_MUL_DGP_MIX);
   constexpr bool BIAS = (EPI == BLM_EPI_BIAS || EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_GP_MIX);
   const bool accum = p.flags & BLM_GEMM_ACCUMULATE;
@@ -491,7 +493,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN]
     if constexpr (BIAS) bias[j] = col[j] < p.N ? p.bias[col[j]] : 0.f;
   }
   // plain/bias epilogues with two adjacent columns per lane store them as one 8-byte access
-  const bool pair_store = INTERLEAVE && WTN == 2 && (EPI == BLM_EPI_NONE || EPI == BLM_EPI_BIAS) && !p.atomic && (p.ldc % 2 == 0) &&
+  const bool pair_store = INTERLEAVE && WTN == 2 && (EPI == BLM_EPI_NONE || EPI == BLM_EPI_BIAS) && !atomic && (p.ldc % 2 == 0) &&
                           ((reinterpret_cast<uintptr_t>(p.C) & 7) == 0);
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
@@ -553,7 +555,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[WTM][WTN]
         }
 #pragma unroll
         for (int j = 0; j < WTN; ++j)
-          if (col[j] < p.N) epi_elem<EPI>(p, accum, row, col[j], acc[i][j][r], bias[j], keep[rr][j], kl_on);
+          if (col[j] < p.N) epi_elem<EPI>(p, accum, row, col[j], acc[i][j][r], bias[j], keep[rr][j], kl_on, atomic);
       }
     }
   }
@@ -707,7 +709,13 @@ __global__ __launch_bounds__(128 * WGN, WGN == 2 ? 2 : 1) void gemm_f32_kernel(c
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
   // contiguous run of tile ids.
-  const int nb = p.gm * p.gn, bid = blockIdx.x % nb, ks = blockIdx.x / nb;
+  // Slices: with tail_from = 0 block b computes slice b / nb of tile b % nb; otherwise the first tail_from tiles are whole
+  // (ks = 0, all of K, plain stores) and only the nb - tail_from tiles of the last, partly filled round are sliced.
+  const int nb = p.gm * p.gn;
+  const bool whole = (int)blockIdx.x < p.tail_from;
+  const int ntail = nb - p.tail_from, rtail = (int)blockIdx.x - p.tail_from;
+  const int bid = whole ? (int)blockIdx.x : p.tail_from + rtail % ntail, ks = whole ? 0 : rtail / ntail;
+  const bool atomic = p.atomic && !whole;
   const int q = nb >> 3, rem = nb & 7, xcd = bid & 7;
   const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
   // Inside the run, groups of 8 row blocks with the row block fastest: the 64 workgroups an XCD holds at a time are an
@@ -1057,7 +1065,7 @@ __global__ __launch_bounds__(128 * WGN, WGN == 2 ? 2 : 1) void gemm_f32_kernel(c
   };
 
   // K tiles [t0, t1) of this block (split-K: a slice of K); tiles below K/BK are full
-  const int kbeg = ks * p.kper, kend = min(p.K, kbeg + p.kper);
+  const int kbeg = ks * p.kper, kend = whole ? p.K : min(p.K, kbeg + p.kper);
   const int t0 = kbeg / BK, t1 = (kend + BK - 1) / BK;
   const int tfull = FAST ? min(t1, p.K / BK) : t0;  // tiles [t0, tfull) go through the fast loaders
   if constexpr (DMA) {
@@ -1228,7 +1236,7 @@ __global__ __launch_bounds__(128 * WGN, WGN == 2 ? 2 : 1) void gemm_f32_kernel(c
 
   // ---- epilogue (one straight-line, fully unrolled body per epilogue kind: the accumulator must
   // only ever be indexed by compile-time constants or it is demoted to scratch)
-  if (p.vec_epi) {  // aligned C/aux, N % 4 == 0, no atomics: 16-byte row-wise epilogue through LDS
+  if (p.vec_epi && !atomic) {  // aligned C/aux, N % 4 == 0, no atomics: 16-byte row-wise epilogue through LDS
     switch (p.epi) {
       case BLM_EPI_NONE: epilogue_rows<BLM_EPI_NONE, WTM, WTN, WGN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
       case BLM_EPI_BIAS: epilogue_rows<BLM_EPI_BIAS, WTM, WTN, WGN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
@@ -1240,16 +1248,26 @@ __global__ __launch_bounds__(128 * WGN, WGN == 2 ? 2 : 1) void gemm_f32_kernel(c
     }
   }
   switch (p.epi) {
-    case BLM_EPI_BIAS: epilogue<BLM_EPI_BIAS, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh, ks == 0); break;
+    case BLM_EPI_BIAS: epilogue<BLM_EPI_BIAS, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh, ks == 0, atomic); break;
     case BLM_EPI_BIAS_GELU: epilogue<BLM_EPI_BIAS_GELU, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
     case BLM_EPI_MUL_DGELU: epilogue<BLM_EPI_MUL_DGELU, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
     case BLM_EPI_GP_MIX: epilogue<BLM_EPI_GP_MIX, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
     case BLM_EPI_MUL_DGP_MIX: epilogue<BLM_EPI_MUL_DGP_MIX, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
     case BLM_EPI_BAYES_WGRAD:
-      if constexpr (OP == BLM_GEMM_TN) epilogue<BLM_EPI_BAYES_WGRAD, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh, ks == 0);
+      if constexpr (OP == BLM_GEMM_TN) epilogue<BLM_EPI_BAYES_WGRAD, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh, ks == 0, atomic);
       break;
-    default: epilogue<BLM_EPI_NONE, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh); break;
+    default: epilogue<BLM_EPI_NONE, WTM, WTN>(p, acc, m0, n0, wm, wn, li, lh, true, atomic); break;
   }
+}
+
+inline int gemm_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n = v;
+  }
+  return n;
 }
 
 template <int OP, int WTM, int WTN, bool SAMP, bool FAST, int WGN = 2>
@@ -1266,15 +1284,26 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   const long nb = (long)q.gm * q.gn;
   // K slices as planned (gemm_plan.hip: legality -- plain, bias or Bayesian-wgrad epilogue, dense or accumulated C -- is the
   // planner's); partial sums meet in C through float atomics, C is zeroed first unless accumulating
-  const int splits = p.plan_splits > 1 ? p.plan_splits : 1;
+  // plan_splits < -1: only the tiles beyond the last full round of workgroup slots (CUs x co-resident workgroups of this
+  // tile) are sliced, |plan_splits| ways -- a grid of 1032 tiles on 512 slots runs 1024 tiles whole and 8 x 32 slices
+  // instead of 6 x 1032 slices that all pass through atomics.  No full round: every tile is sliced (the uniform form).
+  int splits = p.plan_splits > 1 ? p.plan_splits : (p.plan_splits < -1 ? -p.plan_splits : 1);
+  q.tail_from = 0;
+  if (p.plan_splits < -1) {
+    constexpr int OCC = (WTM * WTN == 1) ? 5 : (WTM * WTN * WGN == 4 ? 3 : 2);  // LDS: 32 / 48 / 64 KB of 160 (gemm_plan.hip kTiles)
+    const long slots = (long)gemm_cu_count() * OCC;
+    q.tail_from = (int)(nb / slots * slots);
+    if (q.tail_from == nb) { q.tail_from = 0; splits = 1; }  // whole rounds only: nothing to slice
+  }
   q.splits = splits;
   q.kper = splits > 1 ? ((p.K + splits - 1) / splits + BK - 1) / BK * BK : (p.K > 0 ? p.K : 1);
   q.atomic = splits > 1;
+  const long nblocks = q.tail_from + (nb - q.tail_from) * (long)splits;
   {
     static int off = -1, row_plain = -1;  // BLM_GEMM_ROW_EPI=0: register-layout epilogue everywhere; =1: rows only for the GELU epilogues (A/B knobs; default: rows for all four)
     if (off < 0) { const char* e = getenv("BLM_GEMM_ROW_EPI"); off = (e && atoi(e) == 0) ? 1 : 0; row_plain = (e && atoi(e) == 1) ? 0 : 1; }
     const bool al = ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.aux) | reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.C2)) & 15) == 0;
-    q.vec_epi = !off && !q.atomic && al && p.N % 4 == 0 && p.ldc % 4 == 0 &&
+    q.vec_epi = !off && (!q.atomic || q.tail_from > 0) && al && p.N % 4 == 0 && p.ldc % 4 == 0 &&
                 (((p.epi == BLM_EPI_NONE || p.epi == BLM_EPI_BIAS) && row_plain) || p.epi == BLM_EPI_BIAS_GELU || p.epi == BLM_EPI_MUL_DGELU ||
                  p.epi == BLM_EPI_GP_MIX || p.epi == BLM_EPI_MUL_DGP_MIX);
   }
@@ -1288,7 +1317,7 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
         BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done_s[p.split == 6] = true;
       }
-      hipLaunchKernelGGL(kern, dim3((unsigned)(nb * splits)), dim3(128 * WGN), lds, st, q);
+      hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(128 * WGN), lds, st, q);
       BLM_HIP(hipGetLastError());
       return BLM_OK;
     }
@@ -1307,7 +1336,7 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   // the time it asks.  128x128 tiles (one workgroup per CU, lock step) read exactly the operands.  Measured and not kept:
   // padding the LDS request so that a one-round grid spreads evenly (no change), wave-priority turns between the
   // co-resident workgroups (-25 % of the surplus at K = 4096, more at 8192, step +0.3 %).  The bytes cost no time (1.5 TB/s).
-  hipLaunchKernelGGL(kern, dim3((unsigned)(nb * splits)), dim3(128 * WGN), lds, st, q);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(128 * WGN), lds, st, q);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }

@@ -21,7 +21,7 @@ struct PlanKey {
 
 struct Plan {
   int tile;    // 11 = 64x64, 12 = 64x128, 21 = 128x64, 22 = 128x128 (rows x cols of 64)
-  int splits;  // >= 1
+  int splits;  // >= 1: K slices of every tile; <= -2: only the tiles beyond the last whole round of workgroup slots are sliced, |splits| ways
   int source;  // 0 model, 1 table, 2 override
 };
 

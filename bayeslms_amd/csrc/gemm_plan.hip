@@ -29,7 +29,7 @@ const Entry kBuiltin[] = {
 std::mutex g_mu;
 std::vector<Entry> g_runtime;   // blm_gemm_plan_set
 bool g_builtin_on = true;       // blm_gemm_plan_clear switches the built-in table off as well (model only)
-int g_force_tile = -1, g_force_splits = -1;  // -1: environment not read yet
+int g_force_tile = -1, g_force_splits = 0;  // tile -1: environment not read yet
 
 // ---- cost model -------------------------------------------------------------------------------------------------
 // A workgroup is 4 waves, one per SIMD; per K tile of 32 a wave issues wtm*wtn*16 v_mfma_f32_32x32x2_f32 of 64 cycles.
@@ -72,30 +72,44 @@ ModelK g_model = {
     {0.269, 1.342, 1.213, 2.697, 1.505},
 };
 
+// S >= 1: every tile in S slices.  S <= -2: tail slicing -- the whole rounds of workgroup slots compute their tiles in one
+// piece (no atomics), only the tiles of the last, partly filled round are cut |S| ways (gemm_f32_mfma.h launch_cfg).
 double model_us(const PlanKey& k, const TileModel& t, int S) {
   const ModelK& m = g_model;
   const int ti = (int)(&t - kTiles);
   const long BM = 64 * t.wtm, BN = 64 * t.wtn;
   const long tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
-  const long G = tiles * S;
-  const long kper = (k.K + S - 1) / S;
-  const double kt = (double)((kper + 31) / 32);
-  const double tk = kt * 1024.0 * t.wtm * t.wtn / m.cyc_per_us;  // matrix issue time of one workgroup on its SIMDs
   const long slots = 256L * t.occ;
-  const long full = G / slots, rem = G - full * slots;
   auto eff = [&](double o) { return m.einf[k.op][ti] * o / (o + m.a[ti]); };
-  const double t_full = (double)t.occ * tk / eff((double)t.occ) + m.t0o[ti] * t.occ;
+  auto tk_of = [&](long kper) { return (double)((kper + 31) / 32) * 1024.0 * t.wtm * t.wtn / m.cyc_per_us; };  // matrix issue time of one workgroup on its SIMDs
+  bool tail = S < -1;
+  long full, rem;       // whole rounds, workgroups of the last round
+  double tk_full, tk_rem, sliced_bytes;
+  if (tail && tiles / slots > 0 && tiles % slots != 0) {
+    const long St = -S, rt = tiles % slots;
+    full = tiles / slots; rem = rt * St;
+    tk_full = tk_of(k.K); tk_rem = tk_of((k.K + St - 1) / St);
+    sliced_bytes = (double)St * (double)rt * BM * BN * 4.0;
+    if (rem > slots) return 1e30;  // more slices than one round holds: not a tail plan
+  } else {
+    if (tail) { S = tiles % slots == 0 ? 1 : -S; tail = false; }  // no whole round (or nothing left over): the uniform form
+    const long G = tiles * S;
+    full = G / slots; rem = G - full * slots;
+    tk_full = tk_rem = tk_of((k.K + S - 1) / S);
+    sliced_bytes = S > 1 ? (double)S * (double)k.M * k.N * 4.0 : 0.0;
+  }
+  const double t_full = (double)t.occ * tk_full / eff((double)t.occ) + m.t0o[ti] * t.occ;
   double us = m.launch_us;
   if (full > 0) us += m.t0[ti] + t_full + (double)(full - 1) * (m.t0r[ti] + t_full);
   if (rem > 0) {
     const double o = (double)((rem + 255) / 256);
-    us += (full > 0 ? m.t0r[ti] : m.t0[ti]) + o * tk / eff(o) + m.t0o[ti] * o;
+    us += (full > 0 ? m.t0r[ti] : m.t0[ti]) + o * tk_rem / eff(o) + m.t0o[ti] * o;
   }
   const double bytes = 4.0 * ((double)k.M * k.K + (double)k.N * k.K + (double)k.M * k.N * (k.acc ? 2.0 : 1.0));
   const double mem = m.launch_us + bytes / m.hbm_bpus;
   us = std::cbrt(us * us * us + mem * mem * mem);
-  if (S > 1) {
-    us += (double)S * (double)k.M * k.N * 4.0 / m.atomic_bpus;
+  if (sliced_bytes > 0.0) {
+    us += sliced_bytes / m.atomic_bpus;
     if (!k.acc) us += m.memset_us + (double)k.M * k.N * 4.0 / m.memset_bpus;
   }
   return us;
@@ -113,6 +127,19 @@ Plan model_plan(const PlanKey& k) {
       const double us = model_us(k, t, S) * (1.0 + 0.002 * S);  // among equals, the fewest slices
       if (us < bt) { bt = us; best.tile = t.tile; best.splits = S; }
     }
+    // tail slicing: only where whole rounds exist and leave a remainder.  The sweep the constants were fitted to has no tail
+    // plans, so the model proposes them only on request (BLM_GEMM_MODEL_TAIL=1); the plan table carries the measured ones.
+    static int model_tail = -1;
+    if (model_tail < 0) { const char* e = getenv("BLM_GEMM_MODEL_TAIL"); model_tail = (e && atoi(e) == 1) ? 1 : 0; }
+    if (!model_tail) continue;
+    const long BM = 64 * t.wtm, BN = 64 * t.wtn;
+    const long tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN), slots = 256L * t.occ;
+    if (k.can_split && tiles > slots && tiles % slots != 0)
+      for (int S : {2, 4, 8, 16, 32}) {
+        if (k.K / S < 128 || (tiles % slots) * S > slots) break;
+        const double us = model_us(k, t, -S) * (1.0 + 0.0002 * S);
+        if (us < bt) { bt = us; best.tile = t.tile; best.splits = -S; }
+      }
   }
   return best;
 }
@@ -148,7 +175,7 @@ void read_env() {
       e = end;
       if (*e == ',') ++e; else break;
     }
-    if (n == 8 && v[0] >= 0 && v[0] <= 2 && valid_tile(v[6]) && v[7] >= 1 && v[7] <= 64)
+    if (n == 8 && v[0] >= 0 && v[0] <= 2 && valid_tile(v[6]) && v[7] >= -64 && v[7] <= 64 && v[7] != 0 && v[7] != -1)
       g_runtime.push_back(Entry{v[0], v[1], v[2], v[3], v[4], v[5] ? 1 : 0, v[6], v[7]});
     while (*e && *e != ';') ++e;
     if (*e == ';') ++e;
@@ -160,7 +187,7 @@ void read_env() {
 
 double plan_model_us(const PlanKey& k, int tile, int splits) {
   for (const TileModel& t : kTiles)
-    if (t.tile == tile) return model_us(k, t, splits < 1 ? 1 : splits);
+    if (t.tile == tile) return model_us(k, t, (splits == 0 || splits == -1) ? 1 : splits);
   return -1.0;
 }
 
@@ -172,13 +199,22 @@ Plan choose_plan(const PlanKey& k) {
   Plan p = model_plan(k);
   if (const Entry* e = model_only ? nullptr : find(k)) { p.tile = e->tile; p.splits = e->splits; p.source = 1; }
   if (g_force_tile > 0 && valid_tile(g_force_tile)) { p.tile = g_force_tile; p.source = 2; }
-  if (g_force_splits > 0) { p.splits = g_force_splits; p.source = 2; }
-  // legality, whatever the source said
+  if (g_force_splits != 0) { p.splits = g_force_splits; p.source = 2; }
+  // legality, whatever the source said (splits <= -2: tail slicing, |splits| ways)
   if (!k.fast) p.tile = 11;
   if (p.tile == 28 && k.K % 32 != 0) p.tile = 22;
-  if (!k.can_split) p.splits = 1;
-  if (p.splits < 1) p.splits = 1;
-  while (p.splits > 1 && k.K / p.splits < 32) --p.splits;
+  if (!k.can_split || p.splits == 0 || p.splits == -1) p.splits = 1;
+  int n = p.splits < 0 ? -p.splits : p.splits;
+  while (n > 1 && k.K / n < 32) --n;
+  p.splits = n < 2 ? 1 : (p.splits < 0 ? -n : n);
+  if (p.splits < 0) {  // canonical form: a tail plan without a whole round is the uniform plan, one without a remainder is unsliced
+    for (const TileModel& t : kTiles)
+      if (t.tile == p.tile) {
+        const long tiles = ((k.M + 64L * t.wtm - 1) / (64L * t.wtm)) * ((k.N + 64L * t.wtn - 1) / (64L * t.wtn)), slots = 256L * t.occ;
+        if (tiles < slots) p.splits = -p.splits;
+        else if (tiles % slots == 0) p.splits = 1;
+      }
+  }
   return p;
 }
 
@@ -234,14 +270,14 @@ extern "C" int blm_gemm_plan_model_us(const blm_gemm_args* a, int tile, int spli
 
 extern "C" int blm_gemm_plan_override(int tile, int splits) {
   if (tile != 0 && !valid_tile(tile)) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_override: tile must be 0, 11, 12, 21, 22 or 28");
-  if (splits < 0 || splits > 64) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_override: splits out of range");
+  if (splits < -64 || splits > 64 || splits == -1) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_override: splits out of range");
   std::lock_guard<std::mutex> lk(g_mu);
   g_force_tile = tile; g_force_splits = splits;
   return BLM_OK;
 }
 
 extern "C" int blm_gemm_plan_set(int op, int M, int N, int K, int epilogue, int accumulate, int tile, int splits) {
-  if (op < BLM_GEMM_NT || op > BLM_GEMM_TN || !valid_tile(tile) || splits < 1 || splits > 64)
+  if (op < BLM_GEMM_NT || op > BLM_GEMM_TN || !valid_tile(tile) || splits < -64 || splits > 64 || splits == 0 || splits == -1)
     return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_set: bad op, tile or split count");
   std::lock_guard<std::mutex> lk(g_mu);
   g_runtime.push_back(Entry{op, M, N, K, epilogue, accumulate ? 1 : 0, tile, splits});

@@ -40,7 +40,7 @@ def _clean():
 def table_entries():
     import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bayeslms_amd", "csrc", "gemm_plans.inc")
-    return [tuple(int(v) for v in m.groups()) for m in re.finditer(r"^\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\}", open(path).read(), re.M)]
+    return [tuple(int(v) for v in m.groups()) for m in re.finditer(r"^\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (-?\d+)\}", open(path).read(), re.M)]
 
 
 def test_every_plan_is_legal_and_deterministic():
@@ -52,17 +52,34 @@ def test_every_plan_is_legal_and_deterministic():
                     for epi, acc in ((L.EPI_NONE, False), (L.EPI_NONE, True), (L.EPI_BIAS, False), (L.EPI_BIAS_GELU, False)):
                         a = args(op, m, n, k, epi, acc)
                         t, s, src, us = plan(a)
-                        assert t in (11, 12, 21, 22, 28) and 1 <= s <= 16 and src in (0, 1) and us > 0
+                        assert t in (11, 12, 21, 22, 28) and (1 <= s <= 16 or -32 <= s <= -2) and src in (0, 1) and us > 0
                         assert plan(a)[:2] == (t, s)
                         if epi not in (L.EPI_NONE, L.EPI_BIAS):
                             assert s == 1  # partial sums cannot pass through a non-linear epilogue (the bias rides on slice 0)
-                        if s > 1:
-                            assert k // s >= 32
+                        if abs(s) > 1:
+                            assert k // abs(s) >= 32
                         fast = all(v % 4 == 0 and v >= 4 for v in ((m if op == L.GEMM_TN else k), (k if op == L.GEMM_NT else n)))
                         if not fast:
                             assert t == 11  # odd extents: only the guarded 64x64 kernel exists
                         if t == 28:
                             assert k % 32 == 0  # the eight-wave tile has no K-tail path
+
+
+def test_tail_plans_are_accepted_clamped_and_modelled():
+    lib = L.lib()
+    a = args(L.GEMM_TN, 33000, 512, 8192, acc=True)
+    L.check(lib.blm_gemm_plan_set(L.GEMM_TN, 33000, 512, 8192, 0, 1, 28, -32), "set")
+    assert plan(a)[:3] == (28, -32, 1)                       # splits < 0: only the tail round is sliced
+    us = C.c_float()
+    L.check(lib.blm_gemm_plan_model_us(C.byref(a), 28, -32, C.byref(us)), "model")
+    us6 = C.c_float()
+    L.check(lib.blm_gemm_plan_model_us(C.byref(a), 28, 6, C.byref(us6)), "model")
+    assert 0 < us.value < us6.value                          # 16 MB instead of 405 MB through atomics
+    lib.blm_gemm_plan_clear(1)
+    L.check(lib.blm_gemm_plan_override(0, -8), "override")
+    assert plan(args(L.GEMM_NT, 8192, 512, 4096, L.EPI_BIAS_GELU))[1] == 1   # not splittable: tail plans are clamped too
+    assert plan(args(L.GEMM_NN, 3000, 2900, 64))[1] == -2                     # K / slices >= 32
+    assert lib.blm_gemm_plan_override(0, -1) != 0 and lib.blm_gemm_plan_set(0, 1, 1, 1, 0, 0, 11, 0) != 0
 
 
 def test_split_k_needs_a_dense_or_accumulated_c_and_aligned_operands_get_all_tiles():

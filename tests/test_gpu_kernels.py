@@ -172,6 +172,64 @@ def test_gemm_bias_epilogue_forced_k_slices(dev, acc):
         assert rel(C, want) < 1e-5, (tile, splits)
 
 
+@pytest.mark.parametrize("op", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("tile,M,N", [(22, 3000, 2900), (28, 3000, 2900), (11, 2624, 2100), (12, 2000, 5000), (21, 5000, 2000),
+                                      (22, 2048, 4096),   # 512 tiles = one whole round of the 128x128 tile: nothing to slice
+                                      (22, 700, 900)])    # no whole round: every tile is sliced (the uniform form)
+def test_gemm_tail_slicing(dev, op, tile, M, N):
+    """Plans with splits < 0: the tiles of the whole rounds are computed in one piece, only the tiles of the last, partly
+    filled round are cut along K (float atomics) -- plain, bias and accumulating epilogues, every layout."""
+    ops, lib = ops_mod(), L()
+    K = 1056
+    g = torch.Generator(device=dev).manual_seed(M + N + tile)
+    rn = lambda r, c: torch.randn(r, c, device=dev, generator=g)  # noqa: E731
+    if op == "NT":
+        A, B, code = rn(M, K), rn(N, K), lib.GEMM_NT
+        ref = A.double() @ B.double().t()
+    elif op == "NN":
+        A, B, code = rn(M, K), rn(K, N), lib.GEMM_NN
+        ref = A.double() @ B.double()
+    else:
+        A, B, code = rn(K, M), rn(K, N), lib.GEMM_TN
+        ref = A.double().t() @ B.double()
+    bv = torch.randn(N, device=dev, generator=g) * 5
+    for acc, bias, S in ((False, False, -4), (True, False, -8), (False, True, -2), (True, True, -3)):
+        C = rn(M, N)
+        want = ref + (C.double() if acc else 0) + (bv.double() if bias else 0)
+        lib.check(lib.lib().blm_gemm_plan_override(tile, S), "override")
+        try:
+            ops.gemm(code, A, B, C, M, N, K, A.stride(0), B.stride(0), N, accumulate=acc,
+                     epilogue=lib.EPI_BIAS if bias else lib.EPI_NONE, bias=bv if bias else None)
+        finally:
+            lib.check(lib.lib().blm_gemm_plan_override(0, 0), "override")
+        assert rel(C, want) < 1e-5, (acc, bias, S)
+
+
+def test_bayes_wgrad_tail_slicing(dev):
+    """The Bayesian weight-gradient epilogue (two outputs, KL terms once) under a tail plan."""
+    ops, lib = ops_mod(), L()
+    M, K, N = 1056, 2624, 2100          # dW is (N, K) = 2100 x 2624: 1353 tiles of 64 x 64 on 1280 slots
+    g = torch.Generator().manual_seed(31)
+    mu = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.1).to(dev))
+    lg = torch.nn.Parameter((torch.rand(N, K, generator=g) - 3.0).to(dev))
+    x = (torch.randn(M, K, generator=g) * 0.5).to(dev)
+    gy = (torch.randn(M, N, generator=g) * 0.1).to(dev)
+    eps = torch.randn(N, K, generator=g)
+    lam = 0.37
+    lib.check(lib.lib().blm_gemm_plan_override(11, -4), "override")
+    try:
+        for _ in range(2):
+            y = ops.bayes_linear(x, mu, lg, ops.NoiseSpec(eps=eps.to(dev)), kl_lambda=lam, fused=False)
+            (y * gy).sum().backward()
+    finally:
+        lib.check(lib.lib().blm_gemm_plan_override(0, 0), "override")
+    mu_c, lg_c = mu.detach().cpu().double().requires_grad_(True), lg.detach().cpu().double().requires_grad_(True)
+    yr = O.bayes_linear(x.cpu().double(), mu_c, lg_c, eps.double())
+    ((yr * gy.cpu().double()).sum() + lam * O.kl_mean_form(mu_c, lg_c)).backward()
+    assert rel(mu.grad, 2 * mu_c.grad.float()) < 2e-5
+    assert rel(lg.grad, 2 * lg_c.grad.float()) < 2e-5
+
+
 def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric B catches a transposed C write (cdna guide section 3)."""
     ops, lib = ops_mod(), L()

@@ -30,6 +30,7 @@ from bayeslms_amd.data import batchify, get_batch, synthetic_corpus  # noqa: E40
 OPN = ("NT", "NN", "TN")
 TILES = (11, 12, 21, 22, 28)  # 28 = 128x128 on eight waves
 SPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
+TAIL_SPLITS = (-2, -4, -8, -16, -32)  # only the tiles beyond the last whole round of workgroup slots are sliced (in-situ search only)
 V33, V10 = 33000, 10000
 
 
@@ -173,7 +174,7 @@ def tune_workload(name, dev, reps, passes=2, min_share=0.003):
         for _ in range(passes):  # the fastest sample counts (clock / neighbour noise is one-sided)
             seen = set()
             for t in TILES:
-                for s in SPLITS:
+                for s in SPLITS + TAIL_SPLITS:
                     plan_set(k, t, s)
                     lab = query(*k[:4], k[4], bool(k[5]))[:2]  # what will run: the planner clamps to what is legal
                     if lab in seen:
