@@ -858,7 +858,8 @@ def test_attention_unsupported_head_dim_is_loud(dev):
 def test_lstm_stack2_wavefront_equals_two_sequential_layers(dev, T, B, E, H, p):
     """ops.lstm_stack2 (two layers as a wavefront on two streams, layer 2 one time chunk behind, inter-layer dropout
     applied chunk by chunk with the whole tensor's mask) runs the same kernels on the same operands as two
-    ops.lstm_layer calls with ops.dropout between them: outputs and final states are bit-identical, gradients equal to summation order."""
+    ops.lstm_layer calls with ops.dropout between them: outputs, final states and gradients are equal to summation order
+    (a chunk's input product and the whole window's may run under different tile / K-slice plans)."""
     ops = ops_mod()
     ops.set_lstm_wavefront(None)
     probe = torch.empty(T, B, E, device=dev)
@@ -892,10 +893,10 @@ def test_lstm_stack2_wavefront_equals_two_sequential_layers(dev, T, B, E, H, p):
     ops.set_lstm_wavefront(None)  # back to the measured rule
     names = "y h1 c1 h2 c2 dx dh0 dc0 dw_ih1 dw_hh1 db_ih1 db_hh1 dw_ih2 dw_hh2 db_ih2 db_hh2".split()
     for u, v, n in zip(a, b, names):
-        if n.startswith("d"):  # layer 1's dy comes out of a dgrad GEMM per chunk instead of one over all T (different tile /
-            assert rel(u, v) < 2e-5, n  # split-K summation order); the batched wgrad GEMMs use float atomics
-        else:
-            assert torch.equal(u, v), n
+        # layer 1's dy comes out of a dgrad GEMM per chunk instead of one over all T (different tile / split-K summation
+        # order); the batched wgrad GEMMs use float atomics; since the bias epilogue takes K slices, so may the input products
+        # (a rounding difference in an input product is carried through the recurrence: 6e-6 on y after 35 steps x 2 layers at H = 1024)
+        assert rel(u, v) < 2e-5, n
 
 
 # ------------------------------------------------------------------ residual link
