@@ -1215,7 +1215,10 @@ def _stack_chunks(T):
     """Time chunks of the layer wavefront: layer 2 runs one chunk behind layer 1.  Small enough that the lag is a
     small part of T, large enough that the per-chunk input GEMM (M = chunk * B rows) and the host's event traffic stay
     cheap."""
-    c = min(32, max(4, (T + 7) // 8))
+    # equal chunks of at most 16 steps (measured: T 35 -> 3 x 12 beats 5-step and 16 + 16 + 3 chunks by 4-6 %; T 100 ->
+    # 13 ... 20 steps tie)
+    n = (T + 15) // 16
+    c = (T + n - 1) // n
     if _STACK_CHUNK > 0:
         c = _STACK_CHUNK
     return [(t0, min(T, t0 + c)) for t0 in range(0, T, c)]
@@ -1376,7 +1379,7 @@ def lstm_stack2_ok(x, w_hh1, w_hh2, w_ih2):
     T, B, _ = x.shape
     H = w_hh1.shape[1]
     if _STACK2_ON is None:
-        on = B <= 32 and T >= 64
+        on = B <= 32 and T >= 32
     else:
         on = _STACK2_ON
     return (on and T >= 8 and H % 32 == 0 and w_hh2.shape[1] == H and w_ih2.shape[1] == H and w_hh1.is_contiguous() and w_hh2.is_contiguous()
@@ -1388,8 +1391,9 @@ def lstm_stack2_ok(x, w_hh1, w_hh2, w_ih2):
 # side by side cost what one does.  Measured (tools/run_workload.py, same box, off / on):
 #   recipe shape (run_nnlm_ami_lstm.sh: T 100, B 32): 11.07 -> 9.96 ms per training step (289 k -> 321 k tokens/s);
 #   cfg2 (T 35, B 64: the kernels fill the chip, layer 2's per-chunk input GEMM of M = 320 rows and the one-chunk lag give the
-#   overlap back): 6.67 -> 6.75 ms;  cfg1 (T 35, B 20): 2.29 -> 2.30 ms.
-# Rule: on for B <= 32 and T >= 64; BLM_LSTM_WAVEFRONT=0|1 / set_lstm_wavefront(True | False) force it, None = rule.
+#   overlap back): 6.65 -> 6.74 ms;  cfg1 (T 35, B 20): 2.31 -> 2.21 ms with three chunks of 12 steps (2.30 with 5-step
+#   chunks, 2.31 with 16 + 16 + 3), evaluate() at T 35 / B 20 1.14 -> 1.07 ms.
+# Rule: on for B <= 32 and T >= 32; BLM_LSTM_WAVEFRONT=0|1 / set_lstm_wavefront(True | False) force it, None = rule.
 _env_wf = os.environ.get("BLM_LSTM_WAVEFRONT")
 _STACK2_ON = None if _env_wf is None else _env_wf == "1"
 

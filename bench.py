@@ -384,7 +384,7 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
         fwd = kt.get("lstm_seq_fwd T=%d" % Tl, {}).get("avg_ms")
         bwd = kt.get("lstm_seq_bwd T=%d" % Tl, {}).get("avg_ms")
         sf, sb = kt.get("lstm_stack2_fwd T=%d" % Tl, {}).get("avg_ms"), kt.get("lstm_stack2_bwd T=%d" % Tl, {}).get("avg_ms")
-        if sf is not None:  # the two layers ran as a wavefront on two streams (ops.lstm_stack2: B <= 32 and T >= 64)
+        if sf is not None:  # the two layers ran as a wavefront on two streams (ops.lstm_stack2: B <= 32 and T >= 32)
             r.update({"lstm_layers": "wavefront on two streams (ops.lstm_stack2)",
                       # whole two-layer recurrence incl. layer 2's per-chunk input GEMMs / dgrad GEMMs, per time step and LAYER
                       "lstm_step_fwd_us_effective": round(1e3 * sf / Tl / 2, 2),
