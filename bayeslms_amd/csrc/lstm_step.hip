@@ -496,9 +496,20 @@ struct LstmBwdP {
   // blm_lstm_step_dh_act: the GPNN2 activation sum (elementwise.hip gpnn2_actsum_*) applied to the product on its way out
   //   act_mode 1: the product is the feature matrix f -> act_feat[.., ld_f] = f,  dh_out = actsum(f) * scale | 1 | 0
   //   act_mode 2: the product is d s               -> dh_out = d s * actsum'(act_feat) * scale on columns < act_M, else 0
+  //   act_mode 3: the product is the activation that REPLACES gate f_gate of an LSTM cell (GPNN2 on a gate) -- the cell
+  //                forward (elementwise.hip lstm_cell_ovr_fwd_kernel) runs behind it: pre-activations f_xw + f_hw (B,4H),
+  //                f_c = c_{t-1}; writes h, c and the activated gates; dh_out still receives the product
   float* act_feat;
   int act_mode, act_M, act_ldf, acts;
   float act_scale;
+  // second output of a plain product: add_out[b][k - add_lo] = product[b][k] + add_src[b * add_ld + k] for k in [add_lo, add_lo + add_n)
+  const float* add_src;
+  long add_ld;
+  float* add_out;
+  int add_lo, add_n;
+  const float *f_xw, *f_hw, *f_c;
+  float *f_h, *f_cn, *f_ga;
+  int f_gate;
 };
 
 __device__ __forceinline__ float gpnn2_actsum_dev(float z, int acts) {
@@ -624,6 +635,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
 #pragma unroll
       for (int g = 0; g < 4; ++g) e_g[g] = p.ga[eo + (long)g * H];
     }
+  }
+  if (eok && p.act_mode == 3) {  // cell forward behind the product: its operands travel behind the first ring fetch as well
+    e_cp = p.f_c[ei];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e_g[g] = p.f_xw[eo + (long)g * H] + p.f_hw[eo + (long)g * H];
   }
   // ovr == 8: the architecture-search cell (search.hip search_cell_bwd_kernel) fused behind the product: ga / dg_out
   // have 8H-float rows [i f g o | i' f' g' o'], coef = the (4,2) mixing weights, dact_out = per-block partials of their gradient
@@ -766,6 +782,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
     dh = ek < p.act_M ? dh * gpnn2_dactsum_dev(p.act_feat[(long)eb * p.act_ldf + ek], p.acts) * p.act_scale : 0.f;
   }
   if (p.dh_out) p.dh_out[(long)eb * p.ldo + ek] = dh;
+  if (p.add_out && (unsigned)(ek - p.add_lo) < (unsigned)p.add_n)
+    p.add_out[(long)eb * p.add_n + (ek - p.add_lo)] = dh + p.add_src[(long)eb * p.add_ld + ek];
+  if (p.act_mode == 3) {  // wave-uniform
+    const float gi = p.f_gate == 0 ? dh : sigmoidf_(e_g[0]);
+    const float gf = p.f_gate == 1 ? dh : sigmoidf_(e_g[1]);
+    const float gg = p.f_gate == 2 ? dh : tanhf(e_g[2]);
+    const float go = p.f_gate == 3 ? dh : sigmoidf_(e_g[3]);
+    const float cn = gf * e_cp + gi * gg;
+    p.f_cn[ei] = cn;
+    p.f_h[ei] = go * tanhf(cn);
+    p.f_ga[eo] = gi;
+    p.f_ga[eo + H] = gf;
+    p.f_ga[eo + 2L * H] = gg;
+    p.f_ga[eo + 3L * H] = go;
+    return;
+  }
   if (p.dg_out) {  // cell backward of the step that produced h_{t-1} (elementwise.hip lstm_cell_bwd_kernel)
     if (p.ovr == 5) e_cp = gp_mix(e_z, p.coef, H, ek);  // gate type 5: the cell saw the GPNN mixture of z = c_{t-2} Wg^T + b
     const float gi = e_g[0], gf = e_g[1], gg = e_g[2], go = e_g[3];
@@ -1065,6 +1097,28 @@ extern "C" int blm_lstm_step_dh(const float* dz, const float* w_t, float* dh_out
   return blm_lstm_step_dh_ld(dz, w_t, dh_out, H, B, H, G, stream);
 }
 
+// Internal forms of the skinny product for the GPNN2 time loop below (same argument rules as blm_lstm_step_dh):
+// ... with a second output, the column window [lo, lo + n) of the product plus the same window of `add` (row stride add_ld)
+static int step_dh_add(const float* dz, const float* w_t, float* out, const float* add, long add_ld, float* add_out, int lo, int n,
+                       int B, int H, int G, void* stream) {
+  if ((long)B * H == 0) return BLM_OK;
+  if (H % 16 != 0 || G % 64 != 0 || G == 0 || !al16(dz) || !al16(w_t))
+    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_gpnn2_seq_fwd: needs H % 16 == 0, G % 64 == 0 and 16-byte aligned operands");
+  LstmBwdP p{dz, w_t, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out, nullptr, nullptr, nullptr, nullptr, -1,
+             B, H, G, (long)H, nullptr, 0, 0, 0, 0, 0.f, add, add_ld, add_out, lo, n};
+  return launch_step_bwd(p, stream);
+}
+// ... with the LSTM cell forward behind it: the product (B,H) is the activation that replaces gate `gate`
+static int step_dh_cell(const float* dz, const float* w_t, float* out, const float* xw, const float* hw, const float* c_prev, int gate,
+                        float* h, float* c, float* ga, int B, int H, int G, void* stream) {
+  if ((long)B * H == 0) return BLM_OK;
+  if (H % 16 != 0 || G % 64 != 0 || G == 0 || !al16(dz) || !al16(w_t))
+    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_gpnn2_seq_fwd: needs H % 16 == 0, G % 64 == 0 and 16-byte aligned operands");
+  LstmBwdP p{dz, w_t, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out, nullptr, nullptr, nullptr, nullptr, -1,
+             B, H, G, (long)H, nullptr, 3, 0, 0, 0, 0.f, nullptr, 0, nullptr, 0, 0, xw, hw, c_prev, h, c, ga, gate};
+  return launch_step_bwd(p, stream);
+}
+
 // ------------------------------------------------------------------ GPNN2 cells: the time loops (host side)
 // One C call per layer and direction: the launches are 3-9 us each and form one dependent chain (the sequences themselves:
 // include/bayeslm.h blm_gpnn2_seq, ops._LSTMRecurrentGPNN2).
@@ -1096,12 +1150,12 @@ extern "C" int blm_lstm_gpnn2_seq_fwd(const blm_gpnn2_seq* q, void* stream) {
     const float* FT = q->FT + (size_t)(q->nF > 1 ? t : 0) * MP * H;
     int rc = BLM_OK;
     if (q->mode == 0) {  // a gate's pre-activation through the GPNN2
-      rc = blm_lstm_step_dh(q->hs + t * bh, q->w_hh, q->z4 + t * bg, B, 4 * H, H, stream);
-      if (!rc) rc = blm_add_cols(q->xw + t * bg + off, 4 * H, q->z4 + t * bg + off, 4 * H, q->pre + t * bh, H, B, H, stream);
+      // three launches per step: h W_hh^T (all gates; the GPNN2 gate's pre-activation = its window + xw leaves as a second output),
+      // features + activation sum, coefficient product with the cell update behind it
+      rc = step_dh_add(q->hs + t * bh, q->w_hh, q->z4 + t * bg, q->xw + t * bg, 4L * H, q->pre + t * bh, (int)off, H, B, 4 * H, H, stream);
       if (!rc) rc = blm_lstm_step_dh_act(q->pre + t * bh, FT, q->sact + t * bp, GP, B, MP, H, 1, q->feat + t * bm, MP, M, scale, q->acts, stream);
-      if (!rc) rc = blm_lstm_step_dh(q->sact + t * bp, q->cwp, q->gout + t * bh, B, H, GP, stream);
-      if (!rc) rc = blm_lstm_cell_ovr_fwd(q->xw + t * bg, q->z4 + t * bg, q->cs + t * bh, q->gout + t * bh, q->gate, q->hs + (t + 1) * bh,
-                                          q->cs + (t + 1) * bh, q->ga + t * bg, B, H, stream);
+      if (!rc) rc = step_dh_cell(q->sact + t * bp, q->cwp, q->gout + t * bh, q->xw + t * bg, q->z4 + t * bg, q->cs + t * bh, q->gate,
+                                 q->hs + (t + 1) * bh, q->cs + (t + 1) * bh, q->ga + t * bg, B, H, GP, stream);
     } else if (q->mode == 1) {  // the cell state enters through the GPNN2: gout[t] = c_in
       rc = blm_lstm_step_dh_act(q->cs + t * bh, FT, q->sact + t * bp, GP, B, MP, H, 1, q->feat + t * bm, MP, M, scale, q->acts, stream);
       if (!rc) rc = blm_lstm_step_dh(q->sact + t * bp, q->cwp, q->gout + t * bh, B, H, GP, stream);
