@@ -220,14 +220,16 @@ int blm_get_gemm_mode(void);
 
 /* Launch plan of a blm_gemm call: block tile (11 = 64x64, 12 = 64x128, 21 = 128x64, 22 = 128x128 rows x cols on four waves;
  * 28 = 128x128 on EIGHT waves: two waves per SIMD in one barrier domain, aligned operands and K % 32 == 0 only) and
- * number of K slices (> 1: partial sums meet in C through float atomics).  The reference leaves this to the vendor
+ * number of K slices (> 1: partial sums meet in C through float atomics; legal for the plain, bias and Bayesian-wgrad
+ * epilogues.  splits <= -2 = TAIL slicing: the tiles of the whole rounds of workgroup slots are computed in one piece with
+ * plain stores, only the tiles of the last, partly filled round are cut |splits| ways).  The reference leaves this to the vendor
  * BLAS behind F.linear (model.py:1127-1129); here it is one explicit rule for every shape (csrc/gemm_plan.hip):
  * override > plan table (exact-shape entries measured inside the benchmark / recipe steps, csrc/gemm_plans.inc,
  * written by tools/gemm_tune.py) > cost model (workgroup-slot rounds x per-tile matrix-pipe efficiency).
  * All of this is host code: none of the functions below touches the GPU. */
 typedef struct blm_gemm_plan {
   int32_t tile;
-  int32_t splits;
+  int32_t splits;   /* >= 1: K slices of every tile; <= -2: only the tail round's tiles are sliced, |splits| ways */
   int32_t source;   /* 0 cost model, 1 plan table, 2 override */
   float model_us;   /* the cost model's estimate for this plan */
 } blm_gemm_plan;
