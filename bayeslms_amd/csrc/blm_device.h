@@ -137,9 +137,26 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // Exact-erf GELU (nn.GELU() default, model.py:1035).  erf by Abramowitz-Stegun 7.1.26
 // (|abs err| <= 1.5e-7, i.e. fp32 rounding level) sharing its exp(-z^2/2) with the Gaussian pdf
 // that the derivative needs: one v_exp + one v_rcp per element instead of a libm erff call.
+// The reciprocal is the hardware's v_rcp_f32 (1 ulp), not an IEEE division (10 instructions): the polynomial's own error is
+// 1.5e-7.  gelu_parts2 is the same arithmetic on two values with the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32:
+// one issue slot for two lanes' worth of work) -- in a GEMM epilogue every vector instruction is paid in matrix time.
+typedef float blm_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_parts2(blm_f2 z, blm_f2& cdf, blm_f2& pdf_exp) {
+  const blm_f2 x = __builtin_elementwise_abs(z) * 0.70710678118654752f;
+  const blm_f2 den = __builtin_elementwise_fma(x, (blm_f2)(0.3275911f), (blm_f2)(1.0f));
+  const blm_f2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+  const blm_f2 xx = -x * x;
+  pdf_exp = (blm_f2){__expf(xx.x), __expf(xx.y)};
+  blm_f2 poly = __builtin_elementwise_fma(t, (blm_f2)(1.061405429f), (blm_f2)(-1.453152027f));
+  poly = __builtin_elementwise_fma(t, poly, (blm_f2)(1.421413741f));
+  poly = __builtin_elementwise_fma(t, poly, (blm_f2)(-0.284496736f));
+  poly = __builtin_elementwise_fma(t, poly, (blm_f2)(0.254829592f));
+  const blm_f2 tail = (poly * t) * (0.5f * pdf_exp);
+  cdf = (blm_f2){z.x >= 0.f ? 1.0f - tail.x : tail.x, z.y >= 0.f ? 1.0f - tail.y : tail.y};
+}
 __device__ __forceinline__ void gelu_parts(float z, float& cdf, float& pdf_exp) {
   const float x = fabsf(z) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
   pdf_exp = __expf(-x * x);  // = exp(-z^2/2)
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float tail = 0.5f * poly * pdf_exp;  // = 0.5 erfc(|z|/sqrt2): no cancellation in the tails

@@ -637,11 +637,17 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
         } else if constexpr (EPI == BLM_EPI_BIAS_GELU) {
           const float4 kp = keep4(row);
           float4 d;
-          float cdf, e;
-          v.x += bias.x; gelu_parts(v.x, cdf, e); d.x = (cdf + v.x * 0.3989422804014327f * e) * kp.x; v.x = v.x * cdf * kp.x;
-          v.y += bias.y; gelu_parts(v.y, cdf, e); d.y = (cdf + v.y * 0.3989422804014327f * e) * kp.y; v.y = v.y * cdf * kp.y;
-          v.z += bias.z; gelu_parts(v.z, cdf, e); d.z = (cdf + v.z * 0.3989422804014327f * e) * kp.z; v.z = v.z * cdf * kp.z;
-          v.w += bias.w; gelu_parts(v.w, cdf, e); d.w = (cdf + v.w * 0.3989422804014327f * e) * kp.w; v.w = v.w * cdf * kp.w;
+          {  // two values per packed instruction (blm_device.h gelu_parts2)
+            const blm_f2 z0 = (blm_f2){v.x, v.y} + (blm_f2){bias.x, bias.y}, z1 = (blm_f2){v.z, v.w} + (blm_f2){bias.z, bias.w};
+            const blm_f2 k0 = {kp.x, kp.y}, k1 = {kp.z, kp.w};
+            blm_f2 c0, e0, c1, e1;
+            gelu_parts2(z0, c0, e0);
+            gelu_parts2(z1, c1, e1);
+            const blm_f2 d0 = __builtin_elementwise_fma(z0 * 0.3989422804014327f, e0, c0) * k0, y0 = (z0 * c0) * k0;
+            const blm_f2 d1 = __builtin_elementwise_fma(z1 * 0.3989422804014327f, e1, c1) * k1, y1 = (z1 * c1) * k1;
+            d = make_float4(d0.x, d0.y, d1.x, d1.y);
+            v = make_float4(y0.x, y0.y, y1.x, y1.y);
+          }
           if (p.aux) store4(p.aux + o, d);
         } else if constexpr (EPI == BLM_EPI_MUL_DGELU) {
           v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
