@@ -40,7 +40,7 @@ def main():
         if dbg:
             assert dbg.blm_debug_store_mode_nt(mode) == 0 and dbg.blm_debug_store_mode_nn(mode) == 0
             print("== store mode %d (%s)" % (mode, ("as shipped", "computed, not stored", "every workgroup stores to tile (0, 0)")[mode]))
-        run(dev, reps, (12,) if dbg else (12, 11, 22))
+        run(dev, reps, (12,) if dbg else tuple(int(t) for t in os.environ.get("EPI_TILES", "12,11,22").split(",")))
 
 
 def run(dev, reps, tiles):
