@@ -2,6 +2,9 @@
 """Randomised check of blm_gemm against fp64 over the whole launch heuristic: N shapes drawn from the ranges the tile /
 split rules branch on (tiny to 33000-wide, K from 1 to 33000, aligned and odd), all three layouts, accumulate on/off,
 bias epilogue.  usage: gemm_fuzz.py [count] [seed]
+       gemm_fuzz.py plans [count] [seed]   the same shapes, each under a RANDOM plan forced through blm_gemm_plan_override:
+                           every tile (11 / 12 / 21 / 22 / 28) x uniform slices (1 ... 16) or tail slicing (-2 ... -32) -- what the
+                           planner could ever hand to a launch, legal or clamped
        gemm_fuzz.py perf   PERFORMANCE regression check of the launch planner (csrc/gemm_plan.hip, cost model only: plan
                            table off): on a log-spaced M x N x K grid (64 ... 33000, all three layouts) every candidate tile x
                            slice count is timed and the planner's own choice must reach >= 0.6 of the best candidate's rate
@@ -22,6 +25,9 @@ def main():
         import subprocess
         sys.exit(subprocess.call([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune.py"), "--grid",
                                   "--coarse", "--min-frac", "0.6"]))
+    plans = len(sys.argv) > 1 and sys.argv[1] == "plans"
+    if plans:
+        del sys.argv[1]
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     dev = torch.device("cuda:0")
@@ -52,12 +58,18 @@ def main():
         C = rn(M, N)
         bv = torch.randn(N, device=dev, generator=g) if bias else None
         want = ref + (C.double() if acc else 0) + (bv.double() if bias else 0)
+        plan = (0, 0)
+        if plans:
+            plan = (rnd.choice([11, 12, 21, 22, 28]), rnd.choice([1, 2, 3, 4, 6, 8, 16, -2, -3, -4, -8, -16, -32]))
+            L.check(L.lib().blm_gemm_plan_override(*plan), "override")
         ops.gemm(op, A, B, C, M, N, K, A.stride(0), B.stride(0), N, accumulate=acc,
                  epilogue=L.EPI_BIAS if bias else L.EPI_NONE, bias=bv)
+        if plans:
+            L.check(L.lib().blm_gemm_plan_override(0, 0), "override")
         err = float((C.double() - want).norm() / want.norm().clamp_min(1e-30))
         worst = max(worst, err)
         if not (err < 2e-5):
-            print("FAIL", ("NT", "NN", "TN")[op], M, N, K, "acc" if acc else "", "bias" if bias else "", err)
+            print("FAIL", ("NT", "NN", "TN")[op], M, N, K, "acc" if acc else "", "bias" if bias else "", "plan %d/%d" % plan, err)
             sys.exit(1)
         del A, B, C, ref, want
     print("gemm_fuzz: %d shapes ok, worst relative error %.2e" % (n, worst))
