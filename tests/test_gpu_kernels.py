@@ -130,6 +130,8 @@ def test_gemm_random_shapes_all_paths(dev):
     ("TN", 512, 4096, 8192, True, False),
     ("NT", 3200, 512, 4096, False, True),     # recipe-shape output projection: the bias epilogue under K slices
     ("NT", 1600, 512, 8192, True, True),      # ... and accumulating
+    ("TN", 33000, 512, 8192, True, False),    # the headline's decoder weight gradient: tail slicing from the plan table (1024 whole tiles + 8 x 32 slices)
+    ("TN", 33000, 1024, 2240, True, False),   # ... cfg2's (64x64 tiles, 4 slices in the tail)
 ])
 def test_gemm_tile_rule_shapes(dev, op, M, N, K, acc, bias):
     """The shapes the round-2 tile / split rules single out (gemm_f32_mfma.h launch_op), against fp64 on the device."""
