@@ -1097,6 +1097,11 @@ class _LSTMLayer(torch.autograd.Function):
         # one launch per step (recurrent product + cell, blm_lstm_step_fwd) when the shape allows it,
         # else skinny GEMM + cell kernel
         fused_step = H % 32 == 0 and w_hh.data_ptr() % 16 == 0 and hs.data_ptr() % 16 == 0 and w_hh.is_contiguous()
+        if fused_step and not torch.is_grad_enabled() and B >= _UNFUSED_STEP_B:
+            # wide inference batches (the scorer packs hundreds of hypotheses per step): the fused step kernel re-reads W_hh
+            # once per 32 batch rows and runs at 0.57 of the matrix peak there; the tiled GEMM + cell kernel pair is faster
+            # from B ~ 200 on (n-best rescoring 64.5 k -> 70-72 k hypotheses/s; BLM_LSTM_UNFUSED_B moves the threshold)
+            fused_step = False
         if fused_step:  # the whole layer from one call: T launches issued by the library
             ev = _TIMER.bracket("lstm_seq_fwd T=%d" % T) if _TIMER is not None else None
             if ev:
@@ -1208,6 +1213,7 @@ def _side_stream():
     return _SIDE_STREAM
 
 
+_UNFUSED_STEP_B = int(os.environ.get("BLM_LSTM_UNFUSED_B", "256"))
 _STACK_CHUNK = int(os.environ.get("BLM_LSTM_WAVE_CHUNK", "0"))  # A/B knob: steps per wavefront chunk (0: the rule below)
 
 
@@ -1217,7 +1223,9 @@ def _stack_chunks(T):
     cheap."""
     # equal chunks of at most 16 steps (measured: T 35 -> 3 x 12 beats 5-step and 16 + 16 + 3 chunks by 4-6 %; T 100 ->
     # 13 ... 20 steps tie)
-    n = (T + 15) // 16
+    # ... and a B = 1 chain of thousands of steps (the scorer's carry chain) runs best on 128-step chunks: 62 k -> 66 k hypotheses/s)
+    cmax = 16 if T <= 256 else 128
+    n = (T + cmax - 1) // cmax
     c = (T + n - 1) // n
     if _STACK_CHUNK > 0:
         c = _STACK_CHUNK

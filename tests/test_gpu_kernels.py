@@ -855,6 +855,30 @@ def test_attention_unsupported_head_dim_is_loud(dev):
         ops.attention(qkv, 1)
 
 
+def test_lstm_wide_inference_batch_takes_the_gemm_path_with_the_same_result(dev):
+    """No-grad forward at B >= 256 (the scorer's packed hypotheses): recurrent product through the tiled GEMM + cell kernel
+    instead of the fused step kernel (ops._LSTMLayer) -- same states as the fused path (taken when gradients are on)."""
+    ops = ops_mod()
+    T, B, E, H = 7, 300, 48, 64
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.3).to(dev)  # noqa: E731
+    x, h0, c0 = mk(T, B, E), mk(B, H), mk(B, H)
+    w = [mk(4 * H, E), mk(4 * H, H), mk(4 * H), mk(4 * H)]
+    with torch.no_grad():
+        y0, h1, c1 = ops.lstm_layer(x, h0, c0, *w)
+    y1, h2, c2 = ops.lstm_layer(x.clone().requires_grad_(True), h0, c0, *w)
+    for a, b in ((y0, y1), (h1, h2), (c1, c2)):
+        assert rel(a, b.detach()) < 1e-5
+    xr, hr, cr = x.cpu().double(), h0.cpu().double(), c0.cpu().double()
+    wc = [t.cpu().double() for t in w]
+    for t in range(T):
+        z = xr[t] @ wc[0].t() + hr @ wc[1].t() + wc[2] + wc[3]
+        i, f, gg, o = z.chunk(4, 1)
+        cr = torch.sigmoid(f) * cr + torch.sigmoid(i) * torch.tanh(gg)
+        hr = torch.sigmoid(o) * torch.tanh(cr)
+    assert rel(h1, hr.float()) < 1e-5 and rel(c1, cr.float()) < 1e-5
+
+
 @pytest.mark.parametrize("T,B,E,H,p", [(12, 5, 24, 32, 0.0), (17, 3, 16, 64, 0.3), (35, 64, 1024, 1024, 0.0), (40, 1, 32, 64, 0.0),
                                          (100, 32, 32, 64, 0.2)])
 def test_lstm_stack2_wavefront_equals_two_sequential_layers(dev, T, B, E, H, p):
