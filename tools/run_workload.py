@@ -18,6 +18,9 @@ def main():
     step, tokens = G.build(name, dev)
     for _ in range(3):
         step()
+    if os.environ.get("NOGC"):  # A/B: the cyclic collector off / everything allocated so far frozen
+        import gc
+        gc.freeze() if os.environ["NOGC"] == "freeze" else gc.disable()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):

@@ -25,14 +25,29 @@ def main():
         model, mtype = M.BayesTransformerModel(V, 512, 8, 4096, 6, 0.2, True, "FFN").to(dev), "Transformer"
     model.eval()
     nbest, vocab, ntok = bench.synthetic_nbest(n_utt, 20, V)
-    sub = dict(list(nbest.items())[:50])
+    sub = dict(list(nbest.items())[:int(os.environ.get("WARM_UTT", "50"))])
     css.compute_scores_batched(sub, model, vocab, mtype, dev)
     torch.cuda.synchronize()
+    ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
     css.compute_scores_batched(nbest, model, vocab, mtype, dev)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats()
+    print("allocator during the timed call: device mallocs %d, device frees %d, retries %d, reserved %.2f -> %.2f GB" % (
+        ms1["num_device_alloc"] - ms0["num_device_alloc"], ms1["num_device_free"] - ms0["num_device_free"],
+        ms1["num_alloc_retries"] - ms0["num_alloc_retries"], ms0["reserved_bytes.all.current"] / 2**30, ms1["reserved_bytes.all.current"] / 2**30))
     print("%s: %d hypotheses in %.1f ms = %.1f hypotheses/s, %.0f tokens/s" % (kind, 20 * n_utt, 1e3 * el, 20 * n_utt / el, ntok / el))
+    if os.environ.get("NOGC"):
+        import gc
+        gc.disable()
+    for _ in range(int(os.environ.get("REPEAT", "0"))):
+        t0 = time.perf_counter()
+        css.compute_scores_batched(nbest, model, vocab, mtype, dev)
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        print("   again: %.1f ms = %.1f hypotheses/s (the call returned after %.1f ms)" % (1e3 * el, 20 * n_utt / el, 1e3 * host))
 
 
 if __name__ == "__main__":
