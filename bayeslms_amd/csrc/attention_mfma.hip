@@ -294,6 +294,53 @@ __global__ __launch_bounds__(256 * HPW) void attn_fwd_mfma_kernel(const AttnM p)
 #endif
 }
 
+// ------------------------------------------------------------------ forward, T <= 32 (n-best rescoring: hypotheses of 5-30 tokens)
+// One causal tile per head, so one WAVE per head: it loads its 32 K and 32 V rows (8 float4 per lane and matrix), keeps them in
+// its own 16.6 KB of LDS and runs attn_fwd_pass on query tile 0.  Four heads per workgroup, two workgroups per CU: eight heads in
+// flight per CU against two in the 128-row form above, whose other three waves per head have nothing to do at this length
+// (packed scoring batches launch thousands of heads: 16 rounds of a latency chain).
+__global__ __launch_bounds__(256) void attn_fwd_short_kernel(const AttnM p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int bhid = blockIdx.x * 4 + wave, nbh = p.B * p.nhead;
+  const int hb = min(bhid, nbh - 1);  // a surplus wave of the last workgroup repeats the last head's loads and stores nothing
+  float* Ks = sm + wave * 2 * 32 * LS;
+  float* Vs = Ks + 32 * LS;
+  const int b = hb / p.nhead, head = hb % p.nhead, off = head * HD;
+  const int T = p.T;
+  float qa[32];
+  {
+    float4 kk[8], vv[8];
+    const bool al = ((reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v) | (uintptr_t)(p.ld * 4) | (uintptr_t)(off * 4)) & 15) == 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = lane + 64 * u, row = i >> 4, c = (i & 15) << 2;
+      const long o = ((long)min(row, T - 1) * p.B + b) * p.ld + off + c;
+      if (al) { kk[u] = *reinterpret_cast<const float4*>(p.k + o); vv[u] = *reinterpret_cast<const float4*>(p.v + o); }
+      else { kk[u] = make_float4(p.k[o], p.k[o + 1], p.k[o + 2], p.k[o + 3]); vv[u] = make_float4(p.v[o], p.v[o + 1], p.v[o + 2], p.v[o + 3]); }
+    }
+    fetch_op(qa, p.q + ((long)min(li, T - 1) * p.B + b) * p.ld + off + 32 * lh);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = lane + 64 * u, row = i >> 4, c = (i & 15) << 2;
+      const float m = row < T ? 1.f : 0.f;
+      float* dk = Ks + row * LS + c;
+      float* dv = Vs + row * LS + c;
+      dk[0] = kk[u].x * m; dk[1] = kk[u].y * m; dk[2] = kk[u].z * m; dk[3] = kk[u].w * m;
+      dv[0] = vv[u].x * m; dv[1] = vv[u].y * m; dv[2] = vv[u].z * m; dv[3] = vv[u].w * m;
+    }
+  }
+  __syncthreads();
+  if (bhid >= nbh) return;
+  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
+#ifdef BLM_ATTN_PROF
+  long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  attn_fwd_pass(p, Ks, Vs, 0, qa, b, off, bh, li, lh, bhid, stamps);
+#else
+  attn_fwd_pass(p, Ks, Vs, 0, qa, b, off, bh, li, lh, bhid);
+#endif
+}
+
 // ------------------------------------------------------------------ backward: dQ (lane = query)
 __device__ __forceinline__ void attn_dq_pass(const AttnM& p, const float* Ks, const float* Vs, int qt, float (&qreg)[32],
                                              const float (&doreg)[32], float delta, int b, int off, uint64_t bh, int li, int lh,
@@ -793,6 +840,11 @@ using namespace blm;
 // as that still leaves one workgroup per CU; below -- the recipes' batch 32 (256 heads), evaluation at batch 20 -- one head per
 // workgroup, so that the launch covers twice the CUs (recipe Transformer step 9.23 -> 9.12 ms, evaluation 2.03 -> 2.00 ms;
 // at 512 heads both forms tie).  BLM_ATTN_HPW=1|2 forces one form (A/B measurements).
+static bool attn_short() {  // BLM_ATTN_SHORT=0: the 128-row forward also for T <= 32 (A/B measurements)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("BLM_ATTN_SHORT"); v = (e && atoi(e) == 0) ? 0 : 1; }
+  return v != 0;
+}
 static int attn_hpw(int heads) {
   static int v = -1;
   if (v < 0) {
@@ -839,6 +891,18 @@ int blm_attn_fwd_mfma(const float* q, const float* k, const float* v, int64_t ld
   }
   if (T > AT) {  // flash-style chunk loop, one workgroup per (batch column, head, 128-query block)
     hipLaunchKernelGGL(attn_fwd_long_kernel, dim3(B * nhead, (T + AT - 1) / AT), dim3(256), lds, st, p);
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
+  }
+  if (T <= 32 && attn_short()) {  // one wave per head (attn_fwd_short_kernel)
+    static bool once_s = false;
+    const size_t lds_s = (size_t)4 * 2 * 32 * LS * sizeof(float);
+    if (!once_s) {
+      const int rc = set_lds(attn_fwd_short_kernel, lds_s);
+      if (rc) return rc;
+      once_s = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_short_kernel, dim3((B * nhead + 3) / 4), dim3(256), lds_s, st, p);
     BLM_HIP(hipGetLastError());
     return BLM_OK;
   }

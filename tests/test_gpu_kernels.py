@@ -512,6 +512,8 @@ def test_add_dropout_ln(dev, D):
 
 @pytest.mark.parametrize("T,B,nhead,hd", [(6, 3, 4, 4), (100, 2, 2, 32), (128, 3, 2, 64), (33, 2, 1, 16), (33, 2, 2, 64),
                                           (1, 1, 1, 64), (97, 1, 3, 64),
+                                          # T <= 32: the forward runs one wave per head (attn_fwd_short_kernel)
+                                          (20, 5, 3, 64), (32, 64, 8, 64), (7, 3, 2, 64), (31, 2, 5, 64),
                                           # 512 heads and more: two heads per workgroup (below: one, to cover more CUs)
                                           (128, 64, 8, 64), (100, 65, 8, 64), (37, 128, 4, 64),
                                           # longer than 128: the chunked (flash-style) matrix-core kernels
@@ -543,7 +545,7 @@ def test_attention_matches_oracle(dev, T, B, nhead, hd):
 
 
 @pytest.mark.parametrize("T,B,nhead,hd", [(8, 2, 2, 4), (96, 2, 2, 64), (50, 3, 1, 64), (128, 1, 2, 64), (160, 2, 1, 64),
-                                          (203, 1, 2, 64), (30, 2, 2, 100), (131, 1, 1, 32), (66, 64, 8, 64)])
+                                          (203, 1, 2, 64), (30, 2, 2, 100), (131, 1, 1, 32), (66, 64, 8, 64), (30, 3, 2, 64), (16, 2, 4, 64)])
 def test_attention_dropout_uses_philox_mask(dev, T, B, nhead, hd):
     """Probability dropout (VALU kernels for small heads, MFMA kernels for head_dim 64; T % 4 != 0
     takes the per-element Philox path)."""
