@@ -501,3 +501,40 @@ def test_recipe_command_lines_parse_unchanged():
           "--interpolation_flag 0 --inter_alpha 0.8").split()
     b = S.build_parser().parse_args(sc)
     assert b.model == "Transformer" and b.T_gauss_pos == 1 and b.batched == 1 and b.mc_samples == 0 and b.inter_alpha == 0.8
+
+
+def test_wavefront_chunks_are_equal_and_cover_the_window():
+    """ops._stack_chunks (host rule of the LSTM layer wavefront): equal chunks of at most 16 steps for training windows,
+    128-step chunks for the scorer's long B = 1 chain; always a partition of [0, T)."""
+    from bayeslms_amd import ops
+    for T in (8, 31, 32, 35, 64, 100, 128, 256, 257, 1000, 8192):
+        ch = ops._stack_chunks(T)
+        assert ch[0][0] == 0 and ch[-1][1] == T and all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
+        sizes = [b - a for a, b in ch]
+        assert max(sizes) <= (16 if T <= 256 else 128)
+        assert max(sizes) - min(sizes) <= max(1, max(sizes) - (T - (len(ch) - 1) * max(sizes))) and min(sizes) >= 1
+    assert [b - a for a, b in ops._stack_chunks(35)] == [12, 12, 11]      # BASELINE configs[0] / configs[1] window
+    assert len(ops._stack_chunks(100)) == 7                                # the recipes' window: 6 x 15 + 10
+
+
+def test_batched_scorer_restores_the_garbage_collector(monkeypatch):
+    """compute_scores_batched switches the cyclic collector off for the call and puts it back -- also when the call fails."""
+    import gc
+    from bayeslms_amd import compute_sentence_scores as css
+    seen = {}
+
+    def boom(*a, **k):
+        seen["enabled_inside"] = gc.isenabled()
+        raise RuntimeError("stop")
+    monkeypatch.setattr(css, "_compute_scores_batched", boom)
+    assert gc.isenabled()
+    with pytest.raises(RuntimeError):
+        css.compute_scores_batched({}, None, {}, "LSTM", "cpu")
+    assert seen["enabled_inside"] is False and gc.isenabled()
+    gc.disable()
+    try:
+        with pytest.raises(RuntimeError):
+            css.compute_scores_batched({}, None, {}, "LSTM", "cpu")
+        assert not gc.isenabled()   # a caller that had it off keeps it off
+    finally:
+        gc.enable()
