@@ -105,6 +105,8 @@ SIGNATURES = {
     "blm_attn_bwd_ws_floats": (_i64, [_i, _i, _i, _i]),
     "blm_ce_fwd_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "blm_ce_interp_fwd": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _i, _i, _vp]),
+    "blm_linear_nll_ws_floats": (_i64, [_i, _i]),
+    "blm_linear_nll": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "blm_ce_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "blm_gp_coef_grad": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "blm_colsum": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp]),

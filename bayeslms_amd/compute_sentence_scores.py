@@ -136,6 +136,7 @@ def compute_scores(nbest, model, vocab, model_type, device, model_2=None, alpha=
     return scores
 
 
+_FUSED_NLL = os.environ.get("BLM_SCORER_FUSED_NLL", "1") != "0"  # 0: decoder logits materialised + CE kernel (A/B)
 _PACKED = os.environ.get("BLM_SCORER_PACKED", "1") != "0"  # 0: padded (T, N) activations in the Transformer stacks (A/B)
 
 
@@ -152,6 +153,12 @@ def _batch_nll(model, data, target_flat, model_type, hidden, model_2, hidden_2, 
     for m in (model, model_2):
         if m is not None:
             m.decoder.rows = None if packed else rows
+    # one model: the decoder returns the NLL itself, its (rows, V) logits are never stored (ops.linear_nll); two models
+    # interpolate LOGITS (reference :163) and keep the materialised pair + the two-input CE kernel
+    fused = (model_2 is None and _FUSED_NLL and not torch.is_grad_enabled() and hasattr(model.decoder, "nll_targets")
+             and ops.linear_nll_supported(model.decoder.weight, model.decoder.bias))
+    if fused:
+        model.decoder.nll_targets = target_flat
     try:
         with (ops.packed_tokens(rows, data.shape[0], data.shape[1]) if packed else contextlib.nullcontext()):
             if model_type == 'Transformer':
@@ -161,7 +168,9 @@ def _batch_nll(model, data, target_flat, model_type, hidden, model_2, hidden_2, 
             out2 = None
             if model_2 is not None:
                 out2 = model_2(data) if model_type == 'Transformer' else model_2(data, hidden_2)[0]
-        if model_2 is not None:
+        if fused:
+            nll = out
+        elif model_2 is not None:
             _, nll = ops.cross_entropy_interp(out.view(-1, out.shape[-1]), out2.view(-1, out2.shape[-1]), alpha, target_flat)
         else:
             _, nll = ops.cross_entropy(out.view(-1, out.shape[-1]), target_flat)
@@ -169,6 +178,8 @@ def _batch_nll(model, data, target_flat, model_type, hidden, model_2, hidden_2, 
         for m in (model, model_2):
             if m is not None:
                 m.decoder.rows = None
+        if fused:
+            model.decoder.nll_targets = None
     return nll if rows is not None else nll.view(data.shape[0], data.shape[1])
 
 

@@ -83,6 +83,7 @@ extern "C" int blm_gemm(const blm_gemm_args* a, void* stream) {
       if (a->var_c.row_lo < 0 || a->var_c.srows < 0 || a->var_c.row_lo + a->var_c.srows > a->M)
         return blm_fail(BLM_ERR_INVALID, "blm_gemm: var_c row window outside W");
       break;
+    case BLM_EPI_CE_PART: return blm_fail(BLM_ERR_INVALID, "blm_gemm: BLM_EPI_CE_PART is internal to blm_linear_nll");
     default: return blm_fail(BLM_ERR_INVALID, "blm_gemm: unknown epilogue");
   }
   const bool samp = a->var_b.lgstd != nullptr;
@@ -123,3 +124,74 @@ extern "C" int blm_gemm(const blm_gemm_args* a, void* stream) {
   }
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Inference: per-row negative log-likelihood of a linear decoder WITHOUT materialising the logits (the
+// reference's evaluate() / scorer compute decoder(x) (M x V floats) and log_softmax over it, train.py:452-455,
+// compute_sentence_scores...py:157-170).  The decoder GEMM's epilogue leaves, per (row, column tile), the maximum and the sum
+// of exp(logit - maximum), and the target's logit; this kernel folds the tiles of a row: nll = max + log(sum) - logit[target].
+namespace blm {
+__global__ __launch_bounds__(256) void ce_part_finish_kernel(const float* __restrict__ part, const float* __restrict__ tlogit,
+                                                             float* __restrict__ nll, float* __restrict__ lse_out, int M, int gn) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* p = part + (long)row * gn * 2;
+  float m = -INFINITY;
+  for (int j = lane; j < gn; j += 64) m = fmaxf(m, p[2 * j]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int j = lane; j < gn; j += 64) s += p[2 * j + 1] * __expf(p[2 * j] - m);
+  s = wave_sum(s);
+  if (lane == 0) {
+    const float lse = m + __logf(s);
+    nll[row] = lse - tlogit[row];
+    if (lse_out) lse_out[row] = lse;
+  }
+}
+}  // namespace blm
+
+extern "C" int64_t blm_linear_nll_ws_floats(int M, int N) {
+  if (M < 0 || N < 0) return 0;
+  return (int64_t)2 * M * ((N + 63) / 64) + M;  // [M][column tiles][2] partials (64-column tiles at most) + the target logits
+}
+
+extern "C" int blm_linear_nll(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const int64_t* tgt,
+                              float* nll, float* lse, float* ws, int M, int N, int K, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0) return blm_fail(BLM_ERR_INVALID, "blm_linear_nll: bad shape");
+  if (M == 0) return BLM_OK;
+  if (!x || !w || !tgt || !nll || !ws || ldx < K || ldw < K) return blm_fail(BLM_ERR_INVALID, "blm_linear_nll: bad arguments");
+  if (N % 4 != 0 || !aligned16(ws) || (bias && !aligned16(bias)))
+    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_linear_nll: needs N %% 4 == 0 and 16-byte aligned bias / workspace");
+  blm_gemm_args a{};
+  a.abi_version = BLM_ABI_VERSION;
+  a.op = BLM_GEMM_NT; a.M = M; a.N = N; a.K = K;
+  a.A = x; a.lda = (int)ldx; a.B = w; a.ldb = (int)ldw; a.C = ws; a.ldc = N;
+  a.alpha = 1.f; a.epilogue = BLM_EPI_BIAS_GELU;  // planning key of an epilogue that cannot take K slices
+  GemmP p{};
+  p.M = M; p.N = N; p.K = K;
+  p.A = x; p.lda = (int)ldx; p.B = w; p.ldb = (int)ldw; p.C = ws; p.ldc = N;
+  p.alpha = 1.f; p.epi = BLM_EPI_CE_PART;
+  p.bias = bias; p.aux = ws;
+  p.ce_tgt = reinterpret_cast<const long long*>(tgt);
+  p.ce_tlogit = ws + (int64_t)2 * M * ((N + 63) / 64);
+  p.split = blm_get_gemm_mode() == BLM_GEMM_MODE_BF16X3 ? 3 : (blm_get_gemm_mode() == BLM_GEMM_MODE_BF16X6 ? 6 : 0);
+  p.a_vec = aligned16(x) && (ldx % 4 == 0);
+  p.b_vec = aligned16(w) && (ldw % 4 == 0);
+  p.fast = p.a_vec && p.b_vec && K % 4 == 0 && K >= 4 &&
+           (long)M * ldx * 4 < (1L << 32) && (long)N * ldw * 4 < (1L << 32);
+  const PlanKey key = plan_key(&a);
+  const Plan pl = choose_plan(key);
+  p.plan_tile = (key.fast != 0) == (p.fast != 0) ? pl.tile : 11;
+  p.plan_splits = 1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rc = launch_op<BLM_GEMM_NT, false>(p, st);
+  if (rc) return rc;
+  // column tiles of the launch: 64 columns on tiles 11 / 21 (and on the guarded 64x64 kernel), 128 otherwise
+  const int tile = p.fast ? p.plan_tile : 11;
+  const int bn = (tile == 11 || tile == 21) ? 64 : 128;
+  const int gn = (N + bn - 1) / bn;
+  hipLaunchKernelGGL(ce_part_finish_kernel, dim3((M + 3) / 4), dim3(256), 0, st, ws, p.ce_tlogit, nll, lse, M, gn);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}

@@ -47,6 +47,10 @@ struct GemmP {
   int plan_tile, plan_splits;    // gemm_plan.hip: 11 / 12 / 21 / 22 and the number of K slices (>= 1)
   float* colsum_a;  // TN only: += column sums of A (= bias gradient of the layer whose wgrad this is)
   int splits, kper, atomic;  // split-K: block ks covers k in [ks*kper, (ks+1)*kper), partial sums by float atomics
+  // BLM_EPI_CE_PART (blm_linear_nll: inference, logits never stored): per (row, column tile) the maximum and the sum of
+  // exp(logit - maximum) go to aux[(row * gn + tile) * 2 + {0, 1}], the target's logit to ce_tlogit[row]
+  const long long* ce_tgt;
+  float* ce_tlogit;
   int tail_from;             // tiles (in launch order) below this index are computed whole by one workgroup; only the rest -- the
                              // tiles beyond the last full round of workgroup slots -- are sliced (0: every tile is sliced)
   // fused activation dropout
@@ -580,8 +584,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
   const int col = n0 + c4;
   const bool accum = p.flags & BLM_GEMM_ACCUMULATE;
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (EPI == BLM_EPI_BIAS || EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_GP_MIX)
-    if (col < p.N) bias = *reinterpret_cast<const float4*>(p.bias + col);
+  if constexpr (EPI == BLM_EPI_BIAS || EPI == BLM_EPI_BIAS_GELU || EPI == BLM_EPI_GP_MIX || EPI == BLM_EPI_CE_PART)
+    if (col < p.N && p.bias) bias = *reinterpret_cast<const float4*>(p.bias + col);
 #pragma unroll
   for (int pass = 0; pass < NP; ++pass) {
     __syncthreads();
@@ -597,7 +601,29 @@ __device__ __forceinline__ void epilogue_rows(const GemmP& p, f32x16 (&acc)[WTM]
           }
     }
     __syncthreads();
-    if (col < p.N) {
+    if constexpr (EPI == BLM_EPI_CE_PART) {
+      // every lane of a row takes part in the row's reductions (lanes past N carry -inf): TPRW consecutive lanes hold one row
+      const bool valid = col < p.N;  // N % 4 == 0: a lane's four columns are all inside or all outside
+      for (int lr = t / TPRW; lr < 64; lr += RPS) {
+        const int row = m0 + 64 * pass + lr;
+        if (row >= p.M) break;  // uniform over the lanes of a row
+        float4 v = *reinterpret_cast<const float4*>(stage + lr * SS + c4);
+        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        float m = valid ? fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)) : -INFINITY;
+#pragma unroll
+        for (int o = TPRW / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float sum = valid ? (__expf(v.x - m) + __expf(v.y - m)) + (__expf(v.z - m) + __expf(v.w - m)) : 0.f;
+#pragma unroll
+        for (int o = TPRW / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (t % TPRW == 0) {
+          float* d = p.aux + ((long)row * p.gn + n0 / BN) * 2;
+          d[0] = m;
+          d[1] = sum;
+        }
+        const long long tg = p.ce_tgt[row];
+        if (valid && tg >= col && tg < col + 4) p.ce_tlogit[row] = tg == col ? v.x : (tg == col + 1 ? v.y : (tg == col + 2 ? v.z : v.w));
+      }
+    } else if (col < p.N) {
       auto keep4 = [&](int row) {  // dropout keep factors of this lane's 4 consecutive columns: one Philox block
         float4 kp = make_float4(1.f, 1.f, 1.f, 1.f);
         if (p.drop_on) {
@@ -1250,6 +1276,7 @@ __global__ __launch_bounds__(128 * WGN, WGN == 2 ? 2 : 1) void gemm_f32_kernel(c
       case BLM_EPI_MUL_DGELU: epilogue_rows<BLM_EPI_MUL_DGELU, WTM, WTN, WGN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
       case BLM_EPI_GP_MIX: epilogue_rows<BLM_EPI_GP_MIX, WTM, WTN, WGN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
       case BLM_EPI_MUL_DGP_MIX: epilogue_rows<BLM_EPI_MUL_DGP_MIX, WTM, WTN, WGN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
+      case BLM_EPI_CE_PART: epilogue_rows<BLM_EPI_CE_PART, WTM, WTN, WGN>(p, acc, smem, m0, n0, wm, wn, li, lh); return;
       default: break;
     }
   }
@@ -1311,7 +1338,8 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
     const bool al = ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.aux) | reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.C2)) & 15) == 0;
     q.vec_epi = !off && (!q.atomic || q.tail_from > 0) && al && p.N % 4 == 0 && p.ldc % 4 == 0 &&
                 (((p.epi == BLM_EPI_NONE || p.epi == BLM_EPI_BIAS) && row_plain) || p.epi == BLM_EPI_BIAS_GELU || p.epi == BLM_EPI_MUL_DGELU ||
-                 p.epi == BLM_EPI_GP_MIX || p.epi == BLM_EPI_MUL_DGP_MIX);
+                 p.epi == BLM_EPI_GP_MIX || p.epi == BLM_EPI_MUL_DGP_MIX || p.epi == BLM_EPI_CE_PART);
+    if (p.epi == BLM_EPI_CE_PART && !q.vec_epi) return blm_fail(BLM_ERR_UNSUPPORTED, "blm_linear_nll: needs N % 4 == 0 and 16-byte aligned bias / workspace");
   }
   if (q.atomic && !(p.flags & BLM_GEMM_ACCUMULATE))
     BLM_HIP(hipMemsetAsync(p.C, 0, (size_t)p.M * p.N * sizeof(float), st));

@@ -10,6 +10,7 @@ three flat buffers (train.py:419-420,466 semantics, averaged over ranks).
 """
 import contextlib
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -388,16 +389,27 @@ def evaluate(model, source, seq_len, eval_batch_size=None):
     model.eval()
     total = torch.zeros((), device=source.device, dtype=torch.float64)
     hidden = model.init_hidden(source.shape[1]) if hasattr(model, "init_hidden") else None
+    # the decoder returns the per-token NLL itself when it can (ops.linear_nll: the (T*B, V) logits are never stored);
+    # BLM_EVAL_FUSED_NLL=0 keeps decoder + cross-entropy kernel
+    dec = getattr(model, "decoder", None)
+    fused = (os.environ.get("BLM_EVAL_FUSED_NLL", "1") != "0" and dec is not None and hasattr(dec, "nll_targets")
+             and ops.linear_nll_supported(dec.weight, dec.bias))
     with torch.no_grad():
-        for i in range(0, source.size(0) - 1, seq_len):
-            data, targets = get_batch(source, i, seq_len)
-            if hidden is None:
-                out = model(data)
-            else:
-                out, hidden = model(data, hidden)
-                hidden = repackage_hidden(hidden)
-            loss, _ = ops.cross_entropy(out.view(-1, out.shape[-1]), targets)
-            total += len(data) * loss.double()
+        try:
+            for i in range(0, source.size(0) - 1, seq_len):
+                data, targets = get_batch(source, i, seq_len)
+                if fused:
+                    dec.nll_targets = targets
+                if hidden is None:
+                    out = model(data)
+                else:
+                    out, hidden = model(data, hidden)
+                    hidden = repackage_hidden(hidden)
+                loss = out.mean() if fused else ops.cross_entropy(out.view(-1, out.shape[-1]), targets)[0]
+                total += len(data) * loss.double()
+        finally:
+            if fused:
+                dec.nll_targets = None
     return float(total.item()) / (len(source) - 1)
 
 

@@ -163,12 +163,19 @@ class _ProjHolder(nn.Module):
         self.in_features, self.out_features = in_f, out_f
 
     rows = None  # inference only (the n-best scorer): apply the projection to these flat rows of x, not to all of them
+    # inference only (scorer, evaluate()): with targets set, the DECODER returns the per-row NLL of its logits against them
+    # instead of the logits themselves, which are never stored (ops.linear_nll)
+    nll_targets = None
 
     def forward(self, x, link=None):
         if self.rows is not None:
             if torch.is_grad_enabled():
                 raise BayesLMError("_ProjHolder.rows is an inference-only row selection")
             x = x.reshape(-1, x.shape[-1]).index_select(0, self.rows)
+        if self.nll_targets is not None:
+            if torch.is_grad_enabled():
+                raise BayesLMError("_ProjHolder.nll_targets is an inference-only path")
+            return ops.linear_nll(x, self.weight, self.bias, self.nll_targets)
         return ops.linear(x, self.weight, self.bias, link)
 
 

@@ -958,6 +958,34 @@ def cross_entropy_interp(logits_a, logits_b, alpha, targets):
     return nll.mean(), nll
 
 
+def linear_nll_supported(weight, bias):
+    """Decoders blm_linear_nll takes: fp32 on the GPU, row-major, vocabulary a multiple of 4, 16-byte aligned bias."""
+    return (weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2 and weight.is_contiguous()
+            and weight.shape[0] % 4 == 0 and (bias is None or (bias.is_contiguous() and bias.data_ptr() % 16 == 0)))
+
+
+def linear_nll(x, weight, bias, targets):
+    """Inference only: per-row NLL of the decoder ``x @ weight.T + bias`` against ``targets`` without materialising the (M, V)
+    logits (blm_linear_nll: softmax partials per column tile in the GEMM epilogue + a folding kernel).  What
+    decoder -> log_softmax -> gather computes in train.py:452-455 / compute_sentence_scores...py:157-170.  -> (M,) NLL"""
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        raise BayesLMError("linear_nll is an inference-only path (no backward): call it under torch.no_grad()")
+    x2 = _f32(x, "x").reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    M, K = x2.shape
+    V = weight.shape[0]
+    if weight.shape[1] != K or targets.numel() != M:
+        raise ValueError("linear_nll: x (M, K), weight (V, K) and M targets expected")
+    L.require_gfx950()
+    tgt = targets.reshape(-1).contiguous()
+    nll = torch.empty(M, device=x2.device, dtype=torch.float32)
+    ws = torch.empty(int(lib().blm_linear_nll_ws_floats(M, V)), device=x2.device, dtype=torch.float32)
+    check(lib().blm_linear_nll(ptr(x2), x2.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(tgt), ptr(nll), None, ptr(ws),
+                               M, V, K, stream()), "blm_linear_nll")
+    return nll
+
+
 # ----------------------------------------------------------------------------
 # KL term  mean(mu^2 - 2 lg + exp(2 lg) [-1]) / 2  over a row window of mu
 # ----------------------------------------------------------------------------

@@ -149,7 +149,8 @@ typedef enum blm_epilogue {
   BLM_EPI_MUL_DGELU = 3,   /* C = acc * aux[m,n]   (aux as written by BIAS_GELU: GELU' and dropout in one factor) */
   BLM_EPI_BAYES_WGRAD = 4, /* TN only, C = dmu, C2 = dlgstd, see below                 */
   BLM_EPI_GP_MIX = 5,      /* z = acc + bias; aux = z; C = sum_i act_i(z) coef[i,n]     */
-  BLM_EPI_MUL_DGP_MIX = 6  /* C = acc * sum_i act_i'(aux) coef[i,n]; C2 (optional) = acc (after dropout) */
+  BLM_EPI_MUL_DGP_MIX = 6, /* C = acc * sum_i act_i'(aux) coef[i,n]; C2 (optional) = acc (after dropout) */
+  BLM_EPI_CE_PART = 7      /* internal to blm_linear_nll (blm_gemm refuses it): no C, per-tile softmax partials instead */
 } blm_epilogue;
 
 #define BLM_GEMM_ACCUMULATE 1u /* C (+= C2) accumulate into existing contents */
@@ -217,6 +218,16 @@ int blm_gemm(const blm_gemm_args* a, void* stream);
 #define BLM_GEMM_MODE_BF16X6 2
 int blm_set_gemm_mode(int mode);
 int blm_get_gemm_mode(void);
+
+/* Inference only: nll[m] = logsumexp_n(x[m,:] . w[n,:] + bias[n]) - (x[m,:] . w[tgt[m],:] + bias[tgt[m]]) without storing the
+ * M x N logits -- the decoder product's epilogue keeps one (max, sum of exp) pair per row and column tile, a second small
+ * kernel folds them (csrc/gemm_api.hip).  Replaces decoder + log_softmax + gather of train.py:452-455 (evaluate) and
+ * compute_sentence_scores_bayes_jianwei.py:157-170 (one model; two-model interpolation mixes LOGITS and keeps the
+ * materialised path, blm_ce_interp_fwd).  bias may be NULL; lse (optional) receives the log-sum-exp per row;
+ * ws: blm_linear_nll_ws_floats(M, N) floats, 16-byte aligned, owned by the caller.  N % 4 == 0. */
+int64_t blm_linear_nll_ws_floats(int M, int N);
+int blm_linear_nll(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const int64_t* tgt,
+                   float* nll, float* lse, float* ws, int M, int N, int K, void* stream);
 
 /* Launch plan of a blm_gemm call: block tile (11 = 64x64, 12 = 64x128, 21 = 128x64, 22 = 128x128 rows x cols on four waves;
  * 28 = 128x128 on EIGHT waves: two waves per SIMD in one barrier domain, aligned operands and K % 32 == 0 only) and

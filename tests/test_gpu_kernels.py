@@ -232,6 +232,34 @@ def test_bayes_wgrad_tail_slicing(dev):
     assert rel(lg.grad, 2 * lg_c.grad.float()) < 2e-5
 
 
+@pytest.mark.parametrize("M,V,K,with_bias", [(2560, 33000, 512, True), (700, 33000, 1024, True), (77, 1000, 60, True), (5, 52, 18, True),
+                                             (300, 4096, 64, False), (1, 8, 4, True), (129, 260, 33, True)])
+def test_linear_nll_equals_log_softmax_of_the_materialised_logits(dev, M, V, K, with_bias):
+    """blm_linear_nll (decoder product with softmax partials per column tile in its epilogue + a folding kernel; the logits
+    are never stored) against log_softmax + gather of the fp64 logits -- every tile, aligned and guarded loaders."""
+    ops, lib = ops_mod(), L()
+    g = torch.Generator(device=dev).manual_seed(M + V + K)
+    x = torch.randn(M, K, device=dev, generator=g)
+    w = torch.randn(V, K, device=dev, generator=g) * (4.0 / K ** 0.5)
+    b = torch.randn(V, device=dev, generator=g) if with_bias else None
+    tgt = torch.randint(0, V, (M,), device=dev, generator=g)
+    tgt[0] = V - 1                      # last column of the last (partial) tile
+    tgt[-1] = 0
+    logits = x.double() @ w.double().t() + (b.double() if with_bias else 0)
+    want = -(torch.log_softmax(logits, 1).gather(1, tgt.view(-1, 1)).squeeze(1))
+    tiles = (0,) if (K % 4 or V < 64) else (0, 11, 12, 21, 22, 28)
+    for tile in tiles:
+        lib.check(lib.lib().blm_gemm_plan_override(tile, 0), "override")
+        try:
+            with torch.no_grad():
+                got = ops.linear_nll(x, w, b, tgt)
+        finally:
+            lib.check(lib.lib().blm_gemm_plan_override(0, 0), "override")
+        assert float((got.double() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max())), tile
+    with pytest.raises(Exception, match="inference-only"):
+        ops.linear_nll(x.clone().requires_grad_(True), w, b, tgt)
+
+
 def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric B catches a transposed C write (cdna guide section 3)."""
     ops, lib = ops_mod(), L()
