@@ -24,6 +24,17 @@ def main():
     else:
         model, mtype = M.BayesTransformerModel(V, 512, 8, 4096, 6, 0.2, True, "FFN").to(dev), "Transformer"
     model.eval()
+    if os.environ.get("TIME_CHAIN"):  # wall time of the carry chain alone (synchronised: changes the total)
+        orig = css._carry_chain
+
+        def timed_chain(*a, **k):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = orig(*a, **k)
+            torch.cuda.synchronize()
+            print("   carry chain: %.1f ms" % (1e3 * (time.perf_counter() - t0)))
+            return r
+        css._carry_chain = timed_chain
     nbest, vocab, ntok = bench.synthetic_nbest(n_utt, 20, V)
     sub = dict(list(nbest.items())[:int(os.environ.get("WARM_UTT", "50"))])
     css.compute_scores_batched(sub, model, vocab, mtype, dev)
