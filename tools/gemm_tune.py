@@ -74,6 +74,14 @@ def _gauss_kl(mm):
 _gauss_kl.fusable = False
 
 
+_LAST_MODEL = [None]
+
+
+def _last_model_params():
+    """parameters of the model the last build() created (tools/soak.py checks them for non-finite values)"""
+    return [p.detach() for p in _LAST_MODEL[0].parameters()] if _LAST_MODEL[0] is not None else []
+
+
 def build(name, dev):
     """-> step() closure running ONE step of the workload."""
     torch.manual_seed(1111)
@@ -94,6 +102,7 @@ def build(name, dev):
         is_rnn, Vv, lr = True, V10, 1.0
     else:
         raise SystemExit("unknown workload " + name)
+    _LAST_MODEL[0] = m
     nwin = 8
     stream = synthetic_corpus(Vv, B * (nwin * T + 1) + 17, seed=1111)
     data = batchify(stream, B, dev)
