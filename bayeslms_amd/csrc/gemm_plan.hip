@@ -124,7 +124,15 @@ Plan model_plan(const PlanKey& k) {
     for (int S = 1; S <= 16; ++S) {
       if (S > 1 && (!k.can_split || k.K / S < 128)) break;
       if (S == 5 || S == 7 || (S > 8 && S != 12 && S != 16)) continue;  // the slice counts the sweep measured
-      const double us = model_us(k, t, S) * (1.0 + 0.002 * S);  // among equals, the fewest slices
+      double us = model_us(k, t, S) * (1.0 + 0.002 * S);  // among equals, the fewest slices
+      // K slices through the bias epilogue (legal since late round 3, not in the sweep the constants were fitted to) cost
+      // ~10 us more than the fit predicts at the small sizes where it matters (tools/gemm_bias_pick_check.py: the model alone
+      // picked 11/4 for NT 2560 x 512 x 1024 + bias, 44.8 us against 35.9 us unsliced; with this term the mean of best / chosen over 63 shapes goes
+      // 0.957 -> 0.98)
+      if (S > 1 && k.epi == BLM_EPI_BIAS) {
+        const long tl = ((k.M + 64L * t.wtm - 1) / (64L * t.wtm)) * ((k.N + 64L * t.wtn - 1) / (64L * t.wtn));
+        us += tl >= 128 ? 10.0 : 4.0;  // less where the unsliced grid leaves most of the chip empty
+      }
       if (us < bt) { bt = us; best.tile = t.tile; best.splits = S; }
     }
     // tail slicing: only where whole rounds exist and leave a remainder.  The sweep the constants were fitted to has no tail
