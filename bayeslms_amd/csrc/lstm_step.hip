@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
 // 16-byte loads, all issued before the first use, against the B rows of h; four wave reductions; lane 0 does the
 // cell.  No LDS, no barrier, 4 H / 256 floats per lane: the step is launch + one L2 round trip.
 template <int BB>
-__global__ __launch_bounds__(256) void lstm_step_fwd_gemv_kernel(const LstmStepP p) {
+__device__ __forceinline__ void lstm_step_gemv_body(const LstmStepP& p) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + wave;
   const int H = p.H, B = p.B;
@@ -462,6 +462,15 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_gemv_kernel(const LstmStepP
       }
     }
   }
+}
+template <int BB>
+__global__ __launch_bounds__(256) void lstm_step_fwd_gemv_kernel(const LstmStepP p) { lstm_step_gemv_body<BB>(p); }
+// Two independent recurrences in one launch (blockIdx.y picks the step): layer 1 at step t and layer 2 one chunk behind --
+// the scorer's B = 1 carry chain is two layers x thousands of ~5 us launches, half of it launch gap
+// (blm_lstm_seq_pair_fwd below).
+template <int BB>
+__global__ __launch_bounds__(256) void lstm_step_fwd_gemv_pair_kernel(const LstmStepP p0, const LstmStepP p1) {
+  if (blockIdx.y == 0) lstm_step_gemv_body<BB>(p0); else lstm_step_gemv_body<BB>(p1);
 }
 
 // ------------------------------------------------------------------ backward step
@@ -958,6 +967,44 @@ extern "C" int blm_lstm_seq_fwd(const float* xw, const float* w_hh, float* hs, f
                                      gates_act ? gates_act + t * bg : nullptr, noise_rows ? noise_rows + (size_t)t * H : nullptr,
                                      B, H, stream);
     if (rc) return rc;
+  }
+  return BLM_OK;
+}
+
+extern "C" int blm_lstm_seq_pair_fwd(const float* xw_a, const float* w_hh_a, float* hs_a, float* cs_a, float* ga_a, int n_a,
+                                     const float* xw_b, const float* w_hh_b, float* hs_b, float* cs_b, float* ga_b, int n_b,
+                                     int B, int H, void* stream) {
+  if (n_a < 0 || n_b < 0 || B < 1 || H < 1 || (n_a > 0 && (!xw_a || !w_hh_a || !hs_a || !cs_a)) || (n_b > 0 && (!xw_b || !w_hh_b || !hs_b || !cs_b)))
+    return blm_fail(BLM_ERR_INVALID, "blm_lstm_seq_pair_fwd: bad arguments");
+  const size_t bh = (size_t)B * H, bg = 4 * bh;
+  const bool pairable = B <= 4 && H % 4 == 0 && lstm_gemv() && (n_a == 0 || (al16(w_hh_a) && al16(hs_a))) && (n_b == 0 || (al16(w_hh_b) && al16(hs_b))) &&
+                        (bh * sizeof(float)) % 16 == 0;
+  hipStream_t s0 = (hipStream_t)stream;
+  const int n = n_a > n_b ? n_a : n_b;
+  for (int t = 0; t < n; ++t) {
+    const bool a = t < n_a, b = t < n_b;
+    if (a && b && pairable) {
+      const LstmStepP pa{xw_a + t * bg, w_hh_a, hs_a + t * bh, cs_a + t * bh, hs_a + (t + 1) * bh, cs_a + (t + 1) * bh,
+                         ga_a ? ga_a + t * bg : nullptr, nullptr, nullptr, nullptr, -1, nullptr, B, H, nullptr};
+      const LstmStepP pb{xw_b + t * bg, w_hh_b, hs_b + t * bh, cs_b + t * bh, hs_b + (t + 1) * bh, cs_b + (t + 1) * bh,
+                         ga_b ? ga_b + t * bg : nullptr, nullptr, nullptr, nullptr, -1, nullptr, B, H, nullptr};
+      const dim3 g((H + 3) / 4, 2), blk(256);
+      if (B == 1) hipLaunchKernelGGL(lstm_step_fwd_gemv_pair_kernel<1>, g, blk, 0, s0, pa, pb);
+      else if (B == 2) hipLaunchKernelGGL(lstm_step_fwd_gemv_pair_kernel<2>, g, blk, 0, s0, pa, pb);
+      else hipLaunchKernelGGL(lstm_step_fwd_gemv_pair_kernel<4>, g, blk, 0, s0, pa, pb);
+      BLM_HIP(hipGetLastError());
+      continue;
+    }
+    if (a) {
+      const int rc = blm_lstm_step_fwd(xw_a + t * bg, w_hh_a, hs_a + t * bh, cs_a + t * bh, hs_a + (t + 1) * bh, cs_a + (t + 1) * bh,
+                                       ga_a ? ga_a + t * bg : nullptr, nullptr, B, H, stream);
+      if (rc) return rc;
+    }
+    if (b) {
+      const int rc = blm_lstm_step_fwd(xw_b + t * bg, w_hh_b, hs_b + t * bh, cs_b + t * bh, hs_b + (t + 1) * bh, cs_b + (t + 1) * bh,
+                                       ga_b ? ga_b + t * bg : nullptr, nullptr, B, H, stream);
+      if (rc) return rc;
+    }
   }
   return BLM_OK;
 }

@@ -1242,6 +1242,7 @@ def _side_stream():
 
 
 _UNFUSED_STEP_B = int(os.environ.get("BLM_LSTM_UNFUSED_B", "256"))
+_PAIR_CHAIN = os.environ.get("BLM_LSTM_PAIR_CHAIN", "1") != "0"  # 0: B <= 4 stacks as a two-stream wavefront like larger batches (A/B)
 _STACK_CHUNK = int(os.environ.get("BLM_LSTM_WAVE_CHUNK", "0"))  # A/B knob: steps per wavefront chunk (0: the rule below)
 
 
@@ -1298,11 +1299,31 @@ class _LSTMStack2(torch.autograd.Function):
         tev = _TIMER.bracket("lstm_stack2_fwd T=%d" % T) if _TIMER is not None else None
         if tev:
             tev[0].record()
-        side.wait_stream(main)
         bh, bg = B * H * 4, B * G * 4  # bytes per time row
         p_xw1, p_xw2 = xw1.data_ptr(), xw2.data_ptr()
         p = {k: v.data_ptr() for k, v in (("hs1", hs1), ("cs1", cs1), ("ga1", ga1), ("hs2", hs2), ("cs2", cs2), ("ga2", ga2))}
-        for (t0, t1) in _stack_chunks(T):
+        chunks = _stack_chunks(T)
+        if B <= 4 and _PAIR_CHAIN:
+            # tiny batches (the scorer's carry chain): layer 1 over chunk c and layer 2 over chunk c - 1 from ONE stream, a step
+            # of each per launch (blm_lstm_seq_pair_fwd) -- no second stream, no events, half the launches
+            prev = None
+            for cur in chunks + [None]:
+                if prev is not None:
+                    a0, a1 = prev
+                    inp = hs1[a0 + 1:a1 + 1]
+                    if drop.on:
+                        inp = _dropout_apply(inp, drop, row0=a0, out=x2[a0:a1])
+                    gemm(L.GEMM_NT, inp, w_ih2, xw2[a0:a1], (a1 - a0) * B, G, H, H, H, G, epilogue=L.EPI_BIAS, bias=bias2)
+                t0, t1 = cur if cur is not None else (0, 0)
+                a0, a1 = prev if prev is not None else (0, 0)
+                check(lib_.blm_lstm_seq_pair_fwd(p_xw1 + t0 * bg, ptr(w_hh1), p["hs1"] + t0 * bh, p["cs1"] + t0 * bh, p["ga1"] + t0 * bg, t1 - t0,
+                                                 p_xw2 + a0 * bg, ptr(w_hh2), p["hs2"] + a0 * bh, p["cs2"] + a0 * bh, p["ga2"] + a0 * bg, a1 - a0,
+                                                 B, H, st()), "blm_lstm_seq_pair_fwd")
+                prev = cur
+            chunks = []
+        else:
+            side.wait_stream(main)
+        for (t0, t1) in chunks:
             n = t1 - t0
             check(lib_.blm_lstm_seq_fwd(p_xw1 + t0 * bg, ptr(w_hh1), p["hs1"] + t0 * bh, p["cs1"] + t0 * bh, p["ga1"] + t0 * bg,
                                         None, n, B, H, st()), "blm_lstm_seq_fwd")
@@ -1316,7 +1337,8 @@ class _LSTMStack2(torch.autograd.Function):
                 gemm(L.GEMM_NT, inp, w_ih2, xw2[t0:t1], n * B, G, H, H, H, G, epilogue=L.EPI_BIAS, bias=bias2)
                 check(lib_.blm_lstm_seq_fwd(p_xw2 + t0 * bg, ptr(w_hh2), p["hs2"] + t0 * bh, p["cs2"] + t0 * bh,
                                             p["ga2"] + t0 * bg, None, n, B, H, st()), "blm_lstm_seq_fwd")
-        main.wait_stream(side)
+        if chunks:
+            main.wait_stream(side)
         if tev:
             tev[1].record()
         if _STATE_TAP is not None:

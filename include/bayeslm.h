@@ -378,6 +378,13 @@ int blm_lstm_step_fwd(const float* xw_t, const float* w_hh, const float* h_prev,
  * status codes as blm_lstm_step_fwd (nothing is launched when the first step is unsupported). */
 int blm_lstm_seq_fwd(const float* xw, const float* w_hh, float* hs, float* cs, float* gates_act, const float* noise_rows,
                      int T, int B, int H, void* stream);
+/* Two independent recurrences side by side: step t of sequence A (n_a steps) and step t of sequence B (n_b steps) per launch for
+ * B <= 4 (the scorer's B = 1 carry chain: layer 1 over chunk c beside layer 2 over chunk c - 1 -- one launch per step pair
+ * instead of two; larger batches and the unpaired remainder run as blm_lstm_step_fwd launches).  Buffers as blm_lstm_seq_fwd,
+ * per sequence; n_a or n_b may be 0. */
+int blm_lstm_seq_pair_fwd(const float* xw_a, const float* w_hh_a, float* hs_a, float* cs_a, float* ga_a, int n_a,
+                          const float* xw_b, const float* w_hh_b, float* hs_b, float* cs_b, float* ga_b, int n_b,
+                          int B, int H, void* stream);
 
 /* Backward of one LSTM time step in a single launch:
  *   dh = dgates_t[b,4H] . w_hh[4H,H]   (w_hh passed TRANSPOSED: w_hh_t (H,4H), see blm_transpose)
