@@ -72,8 +72,8 @@ struct LstmStepP {
 // selects in front of the LDS writes and wave-uniform chunk offsets.  On gfx950 every vector instruction is paid in
 // matrix time (tools/mfma_valu_overlap.hip): the 64 v_cndmask + 16 64-bit address adds per chunk of the general form
 // were ~ 18 % on top of its 32 MFMAs.
-template <int RING, int NS = 4, bool REFILL = true, int NW = 4, bool PIPE = false, bool TAIL = true>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 1 : 2, PIPE ? 1 : 2))) void lstm_step_fwd_kernel(const LstmStepP p) {
+template <int RING, int NS, bool REFILL, int NW, bool PIPE, bool TAIL>
+__device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
   constexpr int U = 32 / NS;  // hidden units per workgroup
   // ONE staging buffer per wave (LDS runs a wave's instructions in order and the fragments are in registers before the
   // MFMAs start, so the next chunk may overwrite the tile): 70 KB per 4-wave workgroup and <= 256 VGPRs per wave, i.e. TWO
@@ -405,6 +405,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
   }
 }
 
+
+template <int RING, int NS = 4, bool REFILL = true, int NW = 4, bool PIPE = false, bool TAIL = true>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 1 : 2, PIPE ? 1 : 2))) void lstm_step_fwd_kernel(const LstmStepP p) {
+  lstm_step_fwd_body<RING, NS, REFILL, NW, PIPE, TAIL>(p);
+}
+// One step of TWO independent recurrences per launch (blockIdx.z picks the one): at B <= 32 a step is 128 workgroups, half the
+// chip, so layer 1's step over chunk c and layer 2's over chunk c - 1 fill it together -- what the two-stream wavefront
+// (ops.lstm_stack2) overlaps with events and a second queue, from one queue and with half the launches.
+template <int RING, int NS = 4, bool REFILL = true, int NW = 4, bool PIPE = false, bool TAIL = true>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 1 : 2, PIPE ? 1 : 2))) void lstm_step_fwd_pair_kernel(const LstmStepP p0, const LstmStepP p1) {
+  lstm_step_fwd_body<RING, NS, REFILL, NW, PIPE, TAIL>(blockIdx.z ? p1 : p0);
+}
 
 // ------------------------------------------------------------------ forward step, tiny batches (B <= 4)
 // The n-best scorer walks its carry chain as ONE long B = 1 sequence (compute_sentence_scores.py, reference :271-274):
@@ -980,14 +992,32 @@ extern "C" int blm_lstm_seq_pair_fwd(const float* xw_a, const float* w_hh_a, flo
   const bool pairable = B <= 4 && H % 4 == 0 && lstm_gemv() && (n_a == 0 || (al16(w_hh_a) && al16(hs_a))) && (n_b == 0 || (al16(w_hh_b) && al16(hs_b))) &&
                         (bh * sizeof(float)) % 16 == 0;
   hipStream_t s0 = (hipStream_t)stream;
+  // larger batches: the pair form of the fused step kernel where blm_lstm_step_fwd would launch its pipelined whole-chunk variant
+  const size_t lds4 = (size_t)4 * WAVE_LDS * sizeof(float);
+  const int nchunk = (H / 8 + 31) / 32;
+  const bool pair_mfma = !pairable && H % 256 == 0 && nchunk % 2 == 0 && nchunk >= 4 && lstm_pipe() && !lstm_tail() && lstm_waves() != 8 && n_a > 0 && n_b > 0 &&
+                         al16(w_hh_a) && al16(w_hh_b) && al16(hs_a) && al16(hs_b) && (bh * sizeof(float)) % 16 == 0 &&
+                         16.0 * H * H < 4294967296.0 && 4.0 * B * H < 4294967296.0 && !(B <= 4 && lstm_gemv());
+  if (pair_mfma) {
+    static bool once = false;
+    if (!once) {
+      BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_pair_kernel<2, 4, true, 4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+      once = true;
+    }
+  }
   const int n = n_a > n_b ? n_a : n_b;
   for (int t = 0; t < n; ++t) {
     const bool a = t < n_a, b = t < n_b;
-    if (a && b && pairable) {
+    if (a && b && (pairable || pair_mfma)) {
       const LstmStepP pa{xw_a + t * bg, w_hh_a, hs_a + t * bh, cs_a + t * bh, hs_a + (t + 1) * bh, cs_a + (t + 1) * bh,
                          ga_a ? ga_a + t * bg : nullptr, nullptr, nullptr, nullptr, -1, nullptr, B, H, nullptr};
       const LstmStepP pb{xw_b + t * bg, w_hh_b, hs_b + t * bh, cs_b + t * bh, hs_b + (t + 1) * bh, cs_b + (t + 1) * bh,
                          ga_b ? ga_b + t * bg : nullptr, nullptr, nullptr, nullptr, -1, nullptr, B, H, nullptr};
+      if (!pairable) {  // the matrix-core step kernel, software-pipelined whole-chunk form (what blm_lstm_step_fwd picks for these shapes)
+        hipLaunchKernelGGL((lstm_step_fwd_pair_kernel<2, 4, true, 4, true, false>), dim3(H / 8, (B + 31) / 32, 2), dim3(256), lds4, s0, pa, pb);
+        BLM_HIP(hipGetLastError());
+        continue;
+      }
       const dim3 g((H + 3) / 4, 2), blk(256);
       if (B == 1) hipLaunchKernelGGL(lstm_step_fwd_gemv_pair_kernel<1>, g, blk, 0, s0, pa, pb);
       else if (B == 2) hipLaunchKernelGGL(lstm_step_fwd_gemv_pair_kernel<2>, g, blk, 0, s0, pa, pb);

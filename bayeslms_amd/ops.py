@@ -1242,6 +1242,10 @@ def _side_stream():
 
 
 _UNFUSED_STEP_B = int(os.environ.get("BLM_LSTM_UNFUSED_B", "256"))
+# 1: the B <= 32 forward wavefront as paired launches from one stream (lstm_step_fwd_pair_kernel) instead of two streams.  Measured
+# and not the default: recipe LSTM 10.02 against 9.95 ms, configs[0] equal, evaluate() at T 100 +1 % -- both layers' W_hh (2 x 16.8 MB)
+# stream through the same L2s either way, the pair is bound by that, not by the launches
+_PAIR_STEPS = os.environ.get("BLM_LSTM_PAIR_STEPS", "0") == "1"
 _PAIR_CHAIN = os.environ.get("BLM_LSTM_PAIR_CHAIN", "1") != "0"  # 0: B <= 4 stacks as a two-stream wavefront like larger batches (A/B)
 _STACK_CHUNK = int(os.environ.get("BLM_LSTM_WAVE_CHUNK", "0"))  # A/B knob: steps per wavefront chunk (0: the rule below)
 
@@ -1303,7 +1307,7 @@ class _LSTMStack2(torch.autograd.Function):
         p_xw1, p_xw2 = xw1.data_ptr(), xw2.data_ptr()
         p = {k: v.data_ptr() for k, v in (("hs1", hs1), ("cs1", cs1), ("ga1", ga1), ("hs2", hs2), ("cs2", cs2), ("ga2", ga2))}
         chunks = _stack_chunks(T)
-        if B <= 4 and _PAIR_CHAIN:
+        if (B <= 4 and _PAIR_CHAIN) or (B <= 32 and _PAIR_STEPS):
             # tiny batches (the scorer's carry chain): layer 1 over chunk c and layer 2 over chunk c - 1 from ONE stream, a step
             # of each per launch (blm_lstm_seq_pair_fwd) -- no second stream, no events, half the launches
             prev = None
