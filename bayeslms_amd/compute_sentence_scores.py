@@ -14,6 +14,8 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
+from ._lib import BayesLMError
+
 
 def load_nbest(path):
     """uttid-n hyp...  -> {uttid: [hyp, ...]} in file order (reference :20-51; an empty
@@ -272,7 +274,19 @@ def _compute_scores_batched(nbest, model, vocab, model_type, device, model_2, al
     hidden = model.init_hidden(1) if is_rnn else None
     hidden_2 = model_2.init_hidden(1) if (model_2 is not None and is_rnn) else None
     S = max(1, int(mc_samples))
+    raised = []
     if mc_samples > 0:
+        from .model import variational_sites
+        sites = variational_sites(model)
+        if not sites:
+            # e.g. --uncertainty none, Gaussian type 0, Variational '00', VTransformer (whose noise branch cannot run,
+            # model.py:2800): S passes would be S identical mean-weight passes at S times the cost
+            raise BayesLMError("--mc-samples %d: %s has no variational tensor to sample (mean-weight scoring is "
+                               "--mc-samples 0)" % (mc_samples, type(model).__name__))
+        for m in sites:  # optional sampling flags (GPNN.sample, model.py:1799: False unless somebody raises it)
+            if getattr(m, "sample", True) is False:
+                m.sample = True
+                raised.append(m)
         model.train()
         model.noise_state.dropout_off = True
         model.set_seed(seed)
@@ -341,6 +355,19 @@ def _compute_scores_batched(nbest, model, vocab, model_type, device, model_2, al
                 o += len(hyps)
         pending.clear()
 
+    try:
+        _score_all(nbest, model, model_2, vocab, device, is_rnn, hidden, hidden_2, batch_tokens, score_group, flush)
+    finally:
+        if mc_samples > 0:
+            model.noise_state.dropout_off = False
+            model.eval()
+            for m in raised:
+                m.sample = False
+    return scores
+
+
+def _score_all(nbest, model, model_2, vocab, device, is_rnn, hidden, hidden_2, batch_tokens, score_group, flush):
+    """The batching loop of compute_scores_batched: the carry chain of an LSTM first, then cross-utterance batches."""
     with torch.no_grad():
         items = list(nbest.items())
         carries, carries_2 = None, None
@@ -373,10 +400,6 @@ def _compute_scores_batched(nbest, model, vocab, model_type, device, model_2, al
         if group:
             score_group(group, g_h if is_rnn else None, g_h2 if (is_rnn and model_2 is not None) else None)
         flush()
-    if mc_samples > 0:
-        model.noise_state.dropout_off = False
-        model.eval()
-    return scores
 
 
 def write_scores(scores, path):

@@ -24,7 +24,7 @@ from . import ops
 from ._lib import BayesLMError
 from .ops import Drop, NoiseSpec
 
-__all__ = ["NoiseState", "PositionalEncoding", "MultiheadAttention", "BayesMultiheadAttention", "BayesLinear",
+__all__ = ["NoiseState", "variational_sites", "PositionalEncoding", "MultiheadAttention", "BayesMultiheadAttention", "BayesLinear",
            "StandardTransformerEncoderLayer", "BayesTransformerEncoderLayer", "BayesTransformerModel",
            "TransformerModel", "GPNN", "GaussTransformerEncoderLayer", "GaussTransformerModel", "RNNModel", "BayesRNNModel", "Bayes2LSTM", "repackage_hidden",
            "VTransformerEncoderLayer", "VTransformerModel", "GPLSTMCell", "GPLSTM", "GaussRNNModel", "VNN", "VLSTMCell",
@@ -81,6 +81,13 @@ def bind_state(model, state):
     return state
 
 
+def variational_sites(model):
+    """The modules of ``model`` that draw noise in a training-mode forward (variational weights, GP coefficients, random
+    frequencies, VNN noise rows) -- GPNNs counted as they are once their ``sample`` flag is raised.  An empty list means
+    that Monte-Carlo weight sampling has nothing to sample (the scorer refuses ``--mc-samples`` then)."""
+    return [m for m in model.modules() if callable(getattr(m, "draws_noise", None)) and m.draws_noise()]
+
+
 def repackage_hidden(h):
     """Detach hidden states from their history (train.py:291-295)."""
     if isinstance(h, torch.Tensor):
@@ -134,6 +141,9 @@ class BayesLinear(_Site):
         s = 1.0 / math.sqrt(self.out_features + 1)  # model.py:1070-1073
         self.weight_mean.data.uniform_(-s, s)
         self.weight_lgstd.data.uniform_(2 * np.log(s), np.log(s))
+
+    def draws_noise(self):
+        return bool(self.sample)
 
     def noise(self):
         if not (self.training and self.sample):
@@ -346,6 +356,9 @@ class BayesTransformerModel(_LMHead):
     def embed_kl_divergence(self):
         return ops.kl_mean(self.embed_mean, self.embed_lgstd)
 
+    def draws_noise(self):
+        return self.bayes_embed
+
     def forward(self, src, has_mask=True):
         if not has_mask:
             raise BayesLMError("has_mask=False: the fused attention kernel is causal only")
@@ -373,9 +386,15 @@ class BayesTransformerModel(_LMHead):
 class GPNN(_Site):
     """Parameters of the reference's GPNN (model.py:1780-1906): an affine map followed by a learnt
     mixture of activations, sum_i act_i(z) * coef[i].  ``gpnn_type``: 0 deterministic, 1 Bayesian
-    coefficients, 2 Bayesian weights, 3 both -- which only decides which ``*_lgstd`` tensors exist
-    and enter the KL (with the '-1', model.py:1816-1826): ``self.sample`` is False and no reference
-    entry point ever sets it (model.py:1799), so the forward uses the mean tensors."""
+    coefficients, 2 Bayesian weights, 3 both -- which decides which ``*_lgstd`` tensors exist, enter
+    the KL (with the '-1', model.py:1816-1826) and are sampled.  ``self.sample`` is False by default and
+    train.py never raises it (model.py:1799), so under the reference's training entry point the forward
+    uses the mean tensors; with ``sample`` raised a TRAINING forward uses coef / weights / bias =
+    mean + exp(lgstd) * eps (model.py:1871-1883), ONE draw per forward of the enclosing layer / cell
+    (``sample_parameters()`` at model.py:2280-2281 and :1721-1723).  eps comes from the Philox streams
+    (seed, this module's tensor ids 0 = coef, 1 = weights, 2 = bias, step), or from ``eps_override``
+    (dict with any of "coef" / "weights" / "bias": parity tests against the reference's own draw)."""
+    eps_override = None
 
     def __init__(self, input_size, output_size, act_set=('sigmoid', 'tanh', 'relu'), gpnn_type=0):
         super().__init__()
@@ -394,18 +413,46 @@ class GPNN(_Site):
 
     _SLOT = {"tanh": 0, "sigmoid": 1, "relu": 2, "gelu": 3}
 
-    def coef4(self):
-        """coef_mean rows placed in the kernels' fixed slot order (tanh, sigmoid, relu, gelu)."""
+    def coef4(self, coef=None):
+        """coefficient rows (default: coef_mean) placed in the kernels' fixed slot order (tanh, sigmoid, relu, gelu)."""
+        coef = self.coef_mean if coef is None else coef
         rows = [None] * 4
         for i, a in enumerate(self.act_set):
-            rows[self._SLOT[a]] = self.coef_mean[i]
-        zero = torch.zeros_like(self.coef_mean[0])
+            rows[self._SLOT[a]] = coef[i]
+        zero = torch.zeros_like(coef[0])
         return torch.stack([r if r is not None else zero for r in rows])
+
+    def draws_noise(self):
+        return self.gpnn_type in (1, 2, 3)
+
+    def sampling(self):
+        """Does a forward in the current mode draw anything?  (model.py:1872,1878-1879)"""
+        return bool(self.training and self.sample and self.gpnn_type in (1, 2, 3))
+
+    def sampled(self):
+        """-> (weights, bias, coef) of this forward: the mean tensors, or -- training with ``sample`` raised -- every
+        tensor that has an lgstd as mean + exp(lgstd) * eps.  All draws of the module in ONE launch per direction
+        (ops.variational_group: the samples forward, d mean / d lgstd backward)."""
+        if not self.sampling():
+            return self.weights_mean, self.bias_mean, self.coef_mean
+        e = self.eps_override or {}
+        names = (["coef"] if self.gpnn_type in (1, 3) else []) + (["weights", "bias"] if self.gpnn_type in (2, 3) else [])
+        ids = {"coef": 0, "weights": 1, "bias": 2}
+        specs = [(getattr(self, n + "_mean"), getattr(self, n + "_lgstd"), self._noise(ids[n], e.get(n)), 0, 0.0, 0.0)
+                 for n in names]
+        ws, _ = ops.variational_group(specs)
+        got = dict(zip(names, ws))
+        return got.get("weights", self.weights_mean), got.get("bias", self.bias_mean), got.get("coef", self.coef_mean)
+
+    def sample_parameters(self):
+        """The reference redraws its eps buffers here (model.py:1855-1861); eps is a Philox stream keyed by
+        (seed, tensor id, step) in this engine, so there is nothing to store."""
 
     def forward(self, inp, hx=None):
         """Generic (unfused) form used by the LSTM cells: sum_i act_i(W [inp|hx] + b) coef[i]."""
         x = inp if hx is None else torch.cat([inp, hx], -1)
-        return ops.gp_mix(ops.linear(x, self.weights_mean, self.bias_mean), self.coef4())
+        w, b, coef = self.sampled()
+        return ops.gp_mix(ops.linear(x, w, b), self.coef4(coef))
 
     def kl_divergence(self, prior=None):
         if prior is not None:
@@ -465,6 +512,9 @@ class GPNN2(_Site):
         mix = ops.gp_mix(z, ones)
         a = (z + mix) if self.skip_act else mix
         return self.coef(a * (1.0 / math.sqrt(self.n_MC_terms)))
+
+    def draws_noise(self):
+        return not self.deterministic
 
     def step_noises(self, T):
         """The noise of calls 0..T-1 of one forward exactly as ``forward(x, call)`` would draw it (None: mean frequencies)."""
@@ -526,9 +576,9 @@ class GaussTransformerEncoderLayer(_Site):
         if self.gauss_pos == 4:  # GPNN2: 150 random features, then its own Linear to dim_feedforward
             f = self.linear2(ops.dropout(g(x), self._drop(self.p, 0)))
             lk2 = None
-        else:
-            f = ops.ffn_gp(x, g.weights_mean, g.bias_mean, g.coef_mean, self.linear2.weight, self.linear2.bias,
-                           self._drop(self.p, 0), lk2)
+        else:  # model.py:2280-2283: one draw of the GPNN's tensors per forward when its sample flag is raised
+            wg, bg, coef = g.sampled()
+            f = ops.ffn_gp(x, wg, bg, coef, self.linear2.weight, self.linear2.bias, self._drop(self.p, 0), lk2)
         return ops.add_dropout_ln(x, f, self.norm2.weight, self.norm2.bias, self.norm2.eps, self._drop(self.p, 2), lk2)
 
 
@@ -721,6 +771,9 @@ class Bayes2LSTM(_Site):
         self._kl_cache = None     # (KL of the last training forward, noise step, parameter versions): see _weights
 
     _ORDER = ("weight_hh", "weight_ih", "bias_hh", "bias_ih")
+
+    def draws_noise(self):
+        return 1 <= self.position <= 4  # position 5 has lgstd tensors that are never sampled (model.py:716)
 
     def _weights(self):
         """The 8 tensors _VF.lstm gets (model.py:705-732), sampled on the gate rows in train mode."""
@@ -942,43 +995,54 @@ class GPLSTMCell(_LoopCell):
         gt = self.gate_type
         if self.gpnn_type == 4 and gt > 0:
             return self._forward_gpnn2(inputs, hx, cx)
-        if 1 <= gt <= 4 and ops.lstm_recurrent_gp_supported(self.hidden_size, self.weights_hh):
+        if not 1 <= gt <= 7:  # no GPNN is built for other gate types (model.py:1686-1697): a plain cell
+            y, hT, cT = ops.lstm_layer(inputs, hx, cx, self.weights_ih, self.weights_hh, self.bias_ih, self.bias_ih)
+            return y, (hT, cT)
+        # ONE draw of the GPNN's tensors for all steps of this call when its sample flag is raised (model.py:1721-1723)
+        Wg, bg, cf = self.gpnn.sampled()
+        c4 = self.gpnn.coef4(cf)
+        fused = ops.lstm_recurrent_gp_supported(self.hidden_size, self.weights_hh)
+        if 1 <= gt <= 4 and fused:
             # GPNN on one gate: the whole layer on the fused step kernels.  The GPNN's affine map over
             # [inp|h] splits into an input part (batched over T with the other gates' input GEMM) and a
             # hidden part that takes that gate's row block of the recurrent weight; the mixture is the
             # gate's activation inside the step kernel.  bias_ih enters twice, as in the reference.
             g, E, H = gt - 1, self.input_size, self.hidden_size
-            Wg = self.gpnn.weights_mean
             xw_std = ops.linear(inputs, self.weights_ih, 2.0 * self.bias_ih)
-            xw_gp = ops.linear(inputs, Wg[:, :E], self.gpnn.bias_mean)
+            xw_gp = ops.linear(inputs, Wg[:, :E], bg)
             xw = torch.cat([xw_std[..., :g * H], xw_gp, xw_std[..., (g + 1) * H:]], -1)
             w_rec = torch.cat([self.weights_hh[:g * H], Wg[:, E:], self.weights_hh[(g + 1) * H:]], 0)
-            y, hT, cT = ops.lstm_recurrent_gp(xw, hx, cx, w_rec, self.gpnn.coef4(), g)
+            y, hT, cT = ops.lstm_recurrent_gp(xw, hx, cx, w_rec, c4, g)
             return y, (hT, cT)
-        if gt in (6, 7) and ops.lstm_recurrent_gp_supported(self.hidden_size, self.weights_hh):
+        if gt in (6, 7) and fused:
             if gt == 6:  # the hidden projection of all four gates is the GPNN of h (no bias_ih on that side)
                 xw = ops.linear(inputs, self.weights_ih, self.bias_ih)
-                y, hT, cT = ops.lstm_recurrent_gp(xw, hx, cx, self.gpnn.weights_mean, self.gpnn.coef4(), 4, self.gpnn.bias_mean)
+                y, hT, cT = ops.lstm_recurrent_gp(xw, hx, cx, Wg, c4, 4, bg)
             else:        # the input projection is the GPNN of the inputs; the hidden side carries bias_ih
-                xw = self.gpnn(inputs) + self.bias_ih
+                xw = ops.gp_mix(ops.linear(inputs, Wg, bg), c4) + self.bias_ih
                 y, hT, cT = ops.lstm_recurrent_gp(xw, hx, cx, self.weights_hh)
             return y, (hT, cT)
-        if gt == 5 and self.hidden_size % 64 == 0 and ops.lstm_recurrent_gp_supported(self.hidden_size, self.weights_hh):
+        if gt == 5 and self.hidden_size % 64 == 0 and self.input_size == self.hidden_size and fused:
             # the cell state enters every step through the GPNN (model.py:1759-1760): a second recurrent product
-            # c_{t-1} Wg^T per step, launched in front of the fused step kernel, which applies bias + mixture
+            # c_{t-1} Wg^T per step, launched in front of the fused step kernel, which applies bias + mixture.  The
+            # GPNN is built on input_size inputs but fed the H-wide cell state (model.py:1694,1760): any other shape
+            # falls through to the step-wise loop below, which raises the reference's shape error.
             xw = ops.linear(inputs, self.weights_ih, 2.0 * self.bias_ih)  # bias_ih enters on both sides, as in the reference
-            y, hT, cT = ops.lstm_recurrent_gp(xw, hx, cx, self.weights_hh, self.gpnn.coef4(), 5, self.gpnn.bias_mean,
-                                              self.gpnn.weights_mean)
+            y, hT, cT = ops.lstm_recurrent_gp(xw, hx, cx, self.weights_hh, c4, 5, bg, Wg)
             return y, (hT, cT)
+
+        def gp(v):
+            return ops.gp_mix(ops.linear(v, Wg, bg), c4)
+
         # input-side projection of all steps in one GEMM (the reference does it per step)
-        xw_all = self.gpnn(inputs) if gt == 7 else ops.linear(inputs, self.weights_ih, self.bias_ih)
+        xw_all = gp(inputs) if gt == 7 else ops.linear(inputs, self.weights_ih, self.bias_ih)
         outs = []
         for t in range(T):
-            hw = self.gpnn(hx) if gt == 6 else ops.linear(hx, self.weights_hh, self.bias_ih)
+            hw = gp(hx) if gt == 6 else ops.linear(hx, self.weights_hh, self.bias_ih)
             if gt == 5:
-                cx = self.gpnn(cx)
+                cx = gp(cx)
             if 1 <= gt <= 4:
-                hx, cx = ops.lstm_cell(xw_all[t], hw, cx, self.gpnn(inputs[t], hx), gt - 1)
+                hx, cx = ops.lstm_cell(xw_all[t], hw, cx, gp(torch.cat([inputs[t], hx], -1)), gt - 1)
             else:
                 hx, cx = ops.lstm_cell(xw_all[t], hw, cx)
             outs.append(hx)
@@ -1131,6 +1195,9 @@ class VLSTMCell(_LoopCell):
         self.vnn = VNN(input_size)
         self._params(input_size, hidden_size)
         self.eps_override = None  # (T, H) injected noise for parity tests
+
+    def draws_noise(self):
+        return self.vnn_type == 1 and bool(self.vnn.sample)
 
     def forward(self, inputs, hid=None):
         if inputs.dim() == 2:

@@ -119,27 +119,8 @@ class BayesTransModel(_LMHead):
 # Transformer: GELU | GPNN feed-forward search
 # ----------------------------------------------------------------------------
 class _SampledGPNN(GPNN):
-    """GPNN whose ``sample`` flag is live (train_search_bayes.py:236-237 sets it for the network step):
-    weights, bias and coefficients are mean + exp(lgstd) * eps in train mode when ``sample`` is set
-    (model.py:1872-1883).  ``eps_override``: dict coef/weights/bias (parity tests)."""
-    eps_override = None
-
-    def sampled(self):
-        """-> (weights, bias, coef) as used by this forward."""
-        if not (self.training and self.sample) or self.gpnn_type == 0:
-            return self.weights_mean, self.bias_mean, self.coef_mean
-        e = self.eps_override or {}
-        w, b, c = self.weights_mean, self.bias_mean, self.coef_mean
-        if self.gpnn_type in (1, 3):
-            c = ops.sampled(self.coef_mean, self.coef_lgstd, self._noise(0, e.get("coef")))
-        if self.gpnn_type in (2, 3):
-            w = ops.sampled(self.weights_mean, self.weights_lgstd, self._noise(1, e.get("weights")))
-            b = ops.sampled(self.bias_mean, self.bias_lgstd, self._noise(2, e.get("bias")))
-        return w, b, c
-
-    def sample_parameters(self):
-        """The reference redraws its eps buffers here (model.py:1855-1861); eps is a Philox stream keyed by
-        (seed, site, step) in this engine, so there is nothing to store."""
+    """The super-net's GPNN: ``sample`` is raised by train_search_bayes.py:236-237 for the network step.  The
+    sampled forward itself (model.py:1872-1883) lives in the base class (``GPNN.sampled``)."""
 
 
 class GaussTransSearchEncoderLayer(_Site):
@@ -297,7 +278,10 @@ class Bayes(_Site):
         return kl
 
     def sample_parameters(self):
-        """See _SampledGPNN.sample_parameters: nothing to store."""
+        """See GPNN.sample_parameters: nothing to store."""
+
+    def draws_noise(self):
+        return True  # once ``sample`` is raised
 
     def sampled(self):
         if not (self.training and self.sample):

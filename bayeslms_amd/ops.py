@@ -331,6 +331,10 @@ class _Linear(torch.autograd.Function):
 
 def linear(x, w, b=None, link=None):
     w = _f32(w, "weight")
+    if w.dim() != 2 or x.shape[-1] != w.shape[1] or (b is not None and b.numel() != w.shape[0]):
+        # the kernels take M = numel / K on trust: a mismatch would read past a buffer instead of raising like F.linear
+        raise BayesLMError("linear: input (..., %d) against weight %s%s" % (x.shape[-1], tuple(w.shape),
+                                                                            "" if b is None else " and bias %s" % (tuple(b.shape),)))
     return _Linear.apply(x, w, b, link)
 
 
@@ -631,16 +635,24 @@ class _FFNGP(torch.autograd.Function):
         dhk = torch.empty(M, F_, device=x.device, dtype=torch.float32) if coef.requires_grad else None
         gemm(L.GEMM_NN, dy, w2, dz, M, F_, N2, N2, F_, F_, epilogue=L.EPI_MUL_DGP_MIX, aux=z, coef=coef, C2=dhk,
              drop=drop, drop_B=B)
+        # wg / bg / coef are the leaf mean tensors, or -- GPNN.sample raised -- sampled (non-leaf) ones whose gradients go
+        # back to the sampling node (ops.variational_group: d mean, d lgstd = dW eps sigma in one launch)
+        dwg = dbg = dcoef = None
         if coef.requires_grad:
-            check(lib().blm_gp_coef_grad(ptr(dhk), ptr(z), ptr(_grad_buf(coef)), M, F_, stream()), "blm_gp_coef_grad")
+            buf, acc, dcoef = _wgrad_target(coef)
+            if not acc:
+                buf.zero_()
+            check(lib().blm_gp_coef_grad(ptr(dhk), ptr(z), ptr(buf), M, F_, stream()), "blm_gp_coef_grad")
         if w2.requires_grad:
             gemm(L.GEMM_TN, dy, h, _grad_buf(w2), N2, F_, M, N2, F_, F_, accumulate=True)
         if b2.requires_grad:
             _colsum_into(dy, M, N2, _grad_buf(b2))
         if wg.requires_grad:
-            gemm(L.GEMM_TN, dz, x, _grad_buf(wg), F_, D, M, F_, D, D, accumulate=True)
+            buf, acc, dwg = _wgrad_target(wg)
+            gemm(L.GEMM_TN, dz, x, buf, F_, D, M, F_, D, D, accumulate=acc)
         if bg.requires_grad:
-            _colsum_into(dz, M, F_, _grad_buf(bg))
+            buf, acc, dbg = _wgrad_target(bg)
+            _colsum_into(dz, M, F_, buf, accumulate=acc)
         _notify(coef, w2, b2, wg, bg)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -651,7 +663,7 @@ class _FFNGP(torch.autograd.Function):
             else:
                 dx = torch.empty_like(x)
                 gemm(L.GEMM_NN, dz, wg, dx, M, D, F_, F_, D, D)
-        return (dx,) + (None,) * 7
+        return dx, dwg, dbg, dcoef, None, None, None, None
 
 
 def ffn_gp(x, wg, bg, coef, w2, b2, drop=NO_DROP, link=None):
@@ -1492,6 +1504,10 @@ class _LSTMRecurrentGP(torch.autograd.Function):
         w_cell = _f32(w_cell, "w_cell") if ovr == 5 else None
         T, B, G = xw.shape
         H = G // 4
+        if tuple(w_rec.shape) != (G, H) or (ovr == 5 and tuple(w_cell.shape) != (H, H)):
+            # the step kernels take these as (4H, H) / (H, H) operands on trust
+            raise BayesLMError("lstm_recurrent_gp: w_rec %s / w_cell %s do not fit xw (T, B, %d)"
+                               % (tuple(w_rec.shape), None if w_cell is None else tuple(w_cell.shape), G))
         dev = xw.device
         L.require_gfx950()
         hs = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)

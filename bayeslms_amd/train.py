@@ -54,6 +54,9 @@ def build_parser():
     p.add_argument('--prior2_path', default='steps/pytorchnn/prior/transformer2/', type=str)
     # new, optional
     p.add_argument('--fused-sampling', type=int, default=0, help='1: eps generated inside the GEMM tile loader')
+    p.add_argument('--gp-sample', type=int, default=0,
+                   help='new, optional: 1 raises GPNN.sample (reference model.py:1799 leaves it False and train.py never sets '
+                        'it): the GP coefficients / weights of --uncertainty Gaussian are re-sampled every training step')
     p.add_argument('--gemm-mode', type=str, default='f32', choices=['f32', 'bf16x6', 'bf16x3'],
                    help='new, optional: opt-in split-bf16 arithmetic of the GEMM family (DESIGN.md section 7); default fp32 MFMA')
     p.add_argument('--dist-backend', type=str, default='nccl',
@@ -200,6 +203,8 @@ def main(argv=None, history=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     is_main = rank == 0
+    if world > 1:  # before the first torch.cuda call: the HSA runtime reads its environment when it is initialised
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     def say(*a):
         if is_main:
@@ -214,7 +219,6 @@ def main(argv=None, history=None):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
         else:
@@ -249,6 +253,13 @@ def main(argv=None, history=None):
         model.load_state_dict(own)
     model = model.to(device)
     model.set_fused_sampling(bool(args.fused_sampling))
+    if args.gp_sample:
+        from .model import GPNN
+        gps = [m for m in model.modules() if isinstance(m, GPNN) and m.draws_noise()]
+        if not gps:
+            raise SystemExit("--gp-sample 1: this model has no GPNN with Bayesian coefficients or weights")
+        for m in gps:
+            m.sample = True
     total_params = sum(x.data.nelement() for x in model.parameters())
     say('Args: {}'.format(args))
     say('Model total parameters: {}'.format(total_params))

@@ -136,9 +136,8 @@ def encoder_layer(x, sd, pre, nhead, mask, eps=None, drop_p=0.0):
     dr = (lambda t: F.dropout(t, drop_p, True)) if drop_p > 0.0 else (lambda t: t)  # model.py:1041-1045 sites
     a = mha(x, sd, pre + "self_attn.", nhead, mask, att_eps, drop_p)
     x = F.layer_norm(x + dr(a), (d,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])
-    if pre + "gpnn.weights_mean" in sd:
-        z = F.linear(x, sd[pre + "gpnn.weights_mean"], sd[pre + "gpnn.bias_mean"])
-        h = gp_mixture(z, sd[pre + "gpnn.coef_mean"], ["tanh", "sigmoid", "relu", "gelu"])
+    if pre + "gpnn.weights_mean" in sd:  # eps: None, or the dict of gpnn_params (GPNN.sample raised, model.py:1871-1883)
+        h = gpnn(x, sd, pre + "gpnn.", ["tanh", "sigmoid", "relu", "gelu"], eps)
     elif pre + "gpnn.frequency_mean" in sd:  # gauss_pos 4: GPNN2 random features (model.py:2036-2076)
         h = gpnn2(x, sd, pre + "gpnn.", eps, gelu=True)
     else:
@@ -345,10 +344,23 @@ def transformer_train_loss(src, targets, sd, nhead, bayes_pos, eps, kl_scale, dr
 # ----------------------------------------------------------------------------
 # GP / Variational LSTMs (Python time loops in the reference)
 # ----------------------------------------------------------------------------
-def gpnn(x, sd, pre, acts):
-    """GPNN.forward with sample=False (model.py:1863-1902)."""
-    z = F.linear(x, sd[pre + "weights_mean"], sd[pre + "bias_mean"])
-    return gp_mixture(z, sd[pre + "coef_mean"], acts)
+def gpnn_params(sd, pre, eps=None):
+    """(weights, bias, coef) of one GPNN forward (model.py:1871-1883).  ``eps`` None: the mean tensors (eval mode, or
+    ``sample`` False as under train.py); a dict with any of "coef" / "weights" / "bias": training with ``sample`` raised --
+    each tensor that HAS an lgstd (gpnn_type 1: coef; 2: weights + bias; 3: all) is mean + exp(lgstd) * eps."""
+    out = []
+    for name in ("weights", "bias", "coef"):
+        t = sd[pre + name + "_mean"]
+        if eps is not None and pre + name + "_lgstd" in sd:
+            t = t + torch.exp(sd[pre + name + "_lgstd"]) * eps[name]
+        out.append(t)
+    return out
+
+
+def gpnn(x, sd, pre, acts, eps=None):
+    """GPNN.forward (model.py:1863-1902); ``eps``: see gpnn_params."""
+    w, b, coef = gpnn_params(sd, pre, eps)
+    return gp_mixture(F.linear(x, w, b), coef, acts)
 
 
 def _gp_acts(gate_type):
@@ -360,15 +372,16 @@ def gp_lstm_cell(x, h, c, sd, pre, gate_type, eps=None):
     (GPNN, keys gpnn.weights_mean ...): gate 1-4 is a GPNN of [inp|h]; 5: c = GPNN(c) first; 6/7: the
     hidden/input projection is a GPNN.  gpnn_type 4 (GPNN2, keys gpnn.frequency_mean ...): gate 1-4 is
     GPNN2 of that gate's PRE-ACTIVATION, 5: c = GPNN2(c), 6/7 as above with GPNN2; every call draws new
-    frequencies in train mode: ``eps`` = list of T tensors (input_dim, n_MC) or None (eval)."""
+    frequencies in train mode: ``eps`` = list of T tensors (input_dim, n_MC) or None (eval).  For a GPNN cell ``eps`` may be
+    the dict of gpnn_params: GPNN.sample raised, ONE draw for all steps of this call (model.py:1721-1723)."""
     acts = _gp_acts(gate_type)
     w_ih, b_ih, w_hh = sd[pre + "weights_ih"], sd[pre + "bias_ih"], sd[pre + "weights_hh"]
     two = pre + "gpnn.frequency_mean" in sd
     outs = []
     for t in range(x.shape[0]):
         inp = x[t]
-        e = None if eps is None else eps[t]
-        gp_of = (lambda v: gpnn2(v, sd, pre + "gpnn.", e)) if two else (lambda v: gpnn(v, sd, pre + "gpnn.", acts))
+        e = None if (eps is None or not two) else eps[t]
+        gp_of = (lambda v: gpnn2(v, sd, pre + "gpnn.", e)) if two else (lambda v: gpnn(v, sd, pre + "gpnn.", acts, eps))
         if gate_type == 6:
             gates = F.linear(inp, w_ih, b_ih) + gp_of(h)
         elif gate_type == 7:
@@ -409,7 +422,8 @@ def _nn_lstm(x, h0, c0, sd, pre):
 
 def gauss_rnn_lm(x, hidden, sd, gauss_pos, eps=None):
     """GaussRNNModel.forward, dropout off (model.py:1355-1360 -> GPLSTM.forward :1638-1671).
-    ``eps`` = {cell index: [T tensors]} for GPNN2 cells in train mode."""
+    ``eps`` = {cell index: [T tensors]} for GPNN2 cells in train mode, {cell index: dict of gpnn_params} for GPNN cells
+    whose ``sample`` flag is raised."""
     y = F.embedding(x, sd["encoder.weight"])
     h0, c0 = hidden
     g = gauss_pos
@@ -502,38 +516,76 @@ def mc_sentence_score(nll_samples):
 
 
 def mc_scores(nbest, vocab, sd, family, S, seed, tensor_ids, nhead=4, pos=3, get_input_and_target=None):
-    """Oracle of compute_scores_batched(mc_samples=S).  ``family``: "tlm_ffn" (eps of layer-0 linear2) or "lstm_bayes"
-    (the 8 tensors in LSTM_EPS_ORDER).  ``tensor_ids``: Philox tensor id of each variational tensor (the engine's
-    module numbering, host-side information); sample s uses philox.normal(n, seed, STREAM_WEIGHT + id, step = s).
+    """Oracle of compute_scores_batched(mc_samples=S).  ``family`` / ``pos`` / ``tensor_ids`` (Philox tensor ids = the
+    engine's module numbering, host-side information):
+      "tlm_ffn"     eps of layer-0 linear2                                    ids [linear2]
+      "lstm_bayes"  the 8 tensors in LSTM_EPS_ORDER, pos = --L_bayes_pos      ids of the 8 tensors
+      "tlm_gauss"   layer-0 GPNN with its sample flag raised: coef / weights / bias = ids[0] + 0 / 1 / 2 (a GPNN2 layer:
+                    the one frequency draw of a forward, id ids[0], Philox step s * 1024)
+      "lstm_gauss"  GP-LSTM cells (GPNN types 1-3), pos = --L_gauss_pos       ids {cell: id of its GPNN}
+      "lstm_var"    VNN noise rows eps_t ~ N(0, 0.1), pos = --L_v_pos         ids {cell: id of its VNN}; row t of a
+                    hypothesis is elements [t H, (t+1) H) of the stream, whatever the padded batch length
+    Sample s uses philox.normal(n, seed, STREAM_WEIGHT + id, step = s): ONE model per sample for the whole list.
     LSTM: the state carried between utterances is the mean-weight state after the first hypothesis (:271-274).
     -> [(key-n, score)]"""
     from . import philox as P
-    is_rnn = family == "lstm_bayes"
+
+    def draw(like, tid, smp):
+        return torch.from_numpy(P.normal(like.numel(), seed, P.STREAM_WEIGHT + tid, smp)).view_as(like)
+
+    def gp_eps(pre, tid, smp):
+        return {n: draw(sd[pre + n + "_lgstd"], tid + k, smp) for k, n in enumerate(("coef", "weights", "bias"))
+                if pre + n + "_lgstd" in sd}
+
+    is_rnn = family.startswith("lstm")
     eps = []
     for smp in range(S):
-        if is_rnn:
-            eps.append([torch.from_numpy(P.normal(sd["rnn." + k].numel(), seed, P.STREAM_WEIGHT + tid, smp)).view_as(sd["rnn." + k])
-                        for k, tid in zip(LSTM_EPS_ORDER, tensor_ids)])
+        if family == "lstm_bayes":
+            eps.append([draw(sd["rnn." + k], tid, smp) for k, tid in zip(LSTM_EPS_ORDER, tensor_ids)])
+        elif family == "tlm_ffn":
+            eps.append(draw(sd["transformerlayers.0.linear2.weight_lgstd"], tensor_ids[0], smp))
+        elif family == "tlm_gauss":
+            pre = "transformerlayers.0.gpnn."
+            if pre + "frequency_mean" in sd:
+                eps.append(draw(sd[pre + "frequency_lgstd"], tensor_ids[0], smp * 1024))
+            else:
+                eps.append(gp_eps(pre, tensor_ids[0], smp))
+        elif family == "lstm_gauss":
+            eps.append({c: gp_eps("rnn.rnn.%d.gpnn." % c, tid, smp) for c, tid in tensor_ids.items()})
+        elif family == "lstm_var":
+            eps.append(None)  # drawn per hypothesis length below
         else:
-            w = sd["transformerlayers.0.linear2.weight_lgstd"]
-            eps.append(torch.from_numpy(P.normal(w.numel(), seed, P.STREAM_WEIGHT + tensor_ids[0], smp)).view_as(w))
+            raise ValueError(family)
+    key0 = {"lstm_bayes": "rnn.weight_hh_mean_1", "lstm_gauss": "encoder.weight", "lstm_var": "encoder.weight"}
+
+    def forward(xs, hid, smp):
+        """logits of one hypothesis under sample ``smp`` (None: mean weights) -> (logits, hidden)"""
+        e = None if smp is None else eps[smp]
+        if family == "lstm_bayes":
+            return bayes_rnn_lm(xs, hid, sd, pos, e)
+        if family == "lstm_gauss":
+            return gauss_rnn_lm(xs, hid, sd, pos, e)
+        if family == "lstm_var":
+            rows = None
+            if smp is not None:
+                T = xs.shape[0]
+                rows = {c: torch.from_numpy(P.normal(T * H, seed, P.STREAM_WEIGHT + tid, smp)).view(T, H) * 0.1
+                        for c, tid in tensor_ids.items()}
+            logits, hidden, _ = variational_rnn_lm(xs, hid, sd, pos, rows)
+            return logits, hidden
+        return transformer_lm(xs, sd, nhead, e), None
+
     out = []
-    H = sd["rnn.weight_hh_mean_1"].shape[1] if is_rnn else 0
+    H = sd[key0[family]].shape[1] if is_rnn else 0
     hid = (torch.zeros(2, 1, H), torch.zeros(2, 1, H)) if is_rnn else None
     for key, hyps in nbest.items():
         first = None
         for n, hyp in enumerate(hyps, 1):
             x, t = get_input_and_target(hyp, vocab)
             xs, ts = torch.tensor(x).view(-1, 1), torch.tensor(t)
-            nlls = []
-            for smp in range(S):
-                if is_rnn:
-                    logits, _ = bayes_rnn_lm(xs, hid, sd, pos, eps[smp])
-                else:
-                    logits = transformer_lm(xs, sd, nhead, eps[smp])
-                nlls.append(float(sentence_score(logits, ts)))
+            nlls = [float(sentence_score(forward(xs, hid, smp)[0], ts)) for smp in range(S)]
             if is_rnn and first is None:
-                _, first = bayes_rnn_lm(xs, hid, sd, pos, None)
+                first = forward(xs, hid, None)[1]
             out.append(("%s-%d" % (key, n), mc_sentence_score(nlls)))
         if is_rnn:
             hid = first

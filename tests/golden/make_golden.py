@@ -686,6 +686,79 @@ def f5_gauss_rnn_gpnn2():
              mle=npy(mle), logits_eval_0=npy(e1), logits_eval_1=npy(e2), h_eval=npy(hid[0]), c_eval=npy(hid[1]),
              cells=np.array(cells, dtype=np.int64), **kw, **pack_sd(m), **grads(m))
 
+def _gp_sample_eps(g):
+    """The eps buffers the GPNN's last forward used (model.py:1855-1861: sample_parameters() overwrites them at the
+    start of every forward of the enclosing layer / cell, so after the forward they ARE that forward's draw)."""
+    out = {}
+    for name in ("coef", "weights", "bias"):
+        if hasattr(g, name + "_lgstd"):
+            out[name] = npy(getattr(g, name + "_sample"))
+    return out
+
+
+def f4_gauss_transformer_sample(gp):
+    """GPNN with ``sample`` raised (model.py:1863-1884): coef / weights / bias = mean + exp(lgstd) * eps in train mode.
+    No reference entry point sets the flag; the fixture pins the branch itself (sample False AND True)."""
+    V, d, h, ff, L, T, B = 50, 16, 4, 32, 2, 6, 3
+    torch.manual_seed(123 + gp)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref.GaussTransformerModel(V, d, h, ff, L, 0.0, True, gp)
+    src = torch.randint(0, V, (T, B))
+    tgt = torch.randint(0, V, (T * B,))
+    g = m.transformerlayers[0].gpnn
+    g.sample = True
+    m.train()
+    logits = m(src)
+    eps = {"eps_" + k: v for k, v in _gp_sample_eps(g).items()}
+    mle = torch.nn.functional.cross_entropy(logits.view(-1, V), tgt)
+    kl = g.kl_divergence()
+    (mle + kl * 0.05).backward()
+    m.eval()
+    with torch.no_grad():
+        logits_eval = m(src)
+    save("gauss_tlm_%d_sample" % gp, src=npy(src), tgt=npy(tgt), nhead=np.int64(h), kl_scale=np.float32(0.05),
+         logits_train=npy(logits), logits_eval=npy(logits_eval), mle=npy(mle), kl=npy(kl), **eps,
+         **pack_sd(m), **grads(m))
+
+
+def f5_gauss_rnn_sample():
+    """GP-LSTM cells with GPNN.sample raised: GPLSTMCell.forward redraws the eps buffers ONCE per call (model.py:1721-1723),
+    so all T steps of a window share one draw and the second window gets a fresh one."""
+    V, H, T, B = 40, 12, 5, 3
+    for gp in ("33", "31", "32", "13", "23", "43", "53", "63", "73", "330", "3333"):
+        torch.manual_seed(151 + len(gp) + int(gp[0]) + 7 * int(gp[1]))
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = ref.GaussRNNModel("LSTM", V, H, H, 2, 0.0, True, gp)
+        x1, x2 = torch.randint(0, V, (T, B)), torch.randint(0, V, (T, B))
+        tgt = torch.randint(0, V, (T * B,))
+        cells = [c for c in (0, 1) if hasattr(m.rnn.rnn[c], "gpnn")]
+        for c in cells:
+            m.rnn.rnn[c].gpnn.sample = True
+        m.train()
+        hid = m.init_hidden(B)
+        kw, outs = {}, []
+        for w, x in enumerate((x1, x2)):
+            hid = tuple(h.detach() for h in hid)
+            l, hid = m(x, hid)
+            outs.append(l)
+            for c in cells:
+                for k, v in _gp_sample_eps(m.rnn.rnn[c].gpnn).items():
+                    kw["eps_%d_%d_%s" % (w, c, k)] = v
+        mle = torch.nn.functional.cross_entropy(outs[1].view(-1, V), tgt)
+        kl = sum(m.rnn.rnn[c].gpnn.kl_divergence() for c in cells)  # train.py:366-376
+        if not torch.is_tensor(kl):
+            kl = torch.tensor(float(kl))
+        (mle + kl * 0.07).backward()
+        m.eval()
+        with torch.no_grad():
+            hid = m.init_hidden(B)
+            e1, hid = m(x1, hid)
+            e2, hid = m(x2, hid)
+        save("gauss_rnn_%s_sample" % gp, x1=npy(x1), x2=npy(x2), tgt=npy(tgt), kl_scale=np.float32(0.07),
+             logits_train_0=npy(outs[0]), logits_train_1=npy(outs[1]), mle=npy(mle), kl=npy(kl), logits_eval_0=npy(e1),
+             logits_eval_1=npy(e2), h_eval=npy(hid[0]), c_eval=npy(hid[1]), cells=np.array(cells, dtype=np.int64), **kw,
+             **pack_sd(m), **grads(m))
+
 
 # ---------------------------------------------------------------- F9 architecture search (SURVEY 8(f)3)
 def _load_search():
@@ -898,6 +971,11 @@ if __name__ == "__main__":
         f9_search_models()
         f9_search_loop()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "gp_sample":
+        for gp in (1, 2, 3):
+            f4_gauss_transformer_sample(gp)
+        f5_gauss_rnn_sample()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "vt11":
         f5_vtransformer_11()
         sys.exit(0)
@@ -938,5 +1016,8 @@ if __name__ == "__main__":
     f9_search_models()
     f9_search_loop()
     f9_search_bayes_tlm()
+    for gp in (1, 2, 3):
+        f4_gauss_transformer_sample(gp)
+    f5_gauss_rnn_sample()
     f6_train_trajectory()
     f5_vtransformer_11()

@@ -247,6 +247,54 @@ def test_gauss_transformer_golden(dev, gp):
         assert grad_close(p.grad, grad[k]), k
 
 
+def _gp_eps(g, prefix, dev):
+    return {k[len(prefix):]: v.to(dev) for k, v in g.items() if k.startswith(prefix) and k[len(prefix):] in ("coef", "weights", "bias")}
+
+
+@pytest.mark.parametrize("gp", [1, 2, 3])
+def test_gauss_transformer_sample_branch_golden(dev, gp):
+    """GPNN.sample raised (reference model.py:1863-1884, redrawn per forward at :2280-2281): the reference's own eps
+    buffers injected; logits, KL, every gradient incl. the reparameterisation gradients of the lgstd tensors."""
+    from bayeslms_amd import model as M, ops
+    g, sd, grad = load_golden("gauss_tlm_%d_sample" % gp)
+    V, d = sd["encoder.weight"].shape
+    ff = sd["transformerlayers.0.linear1.weight"].shape[0]
+    m = M.GaussTransformerModel(V, d, int(g["nhead"]), ff, 2, 0.0, True, gp).to(dev)
+    with torch.no_grad():
+        load_sd(m, sd)
+    src, tgt = g["src"].to(dev), g["tgt"].to(dev)
+    gpnn = m.transformerlayers[0].gpnn
+    gpnn.sample = True
+    gpnn.eps_override = _gp_eps(g, "eps_", dev)
+    m.eval()
+    with torch.no_grad():  # eval mode never samples, flag or not
+        assert rel(m(src), g["logits_eval"]) < TOL
+    m.train()
+    logits = m(src)
+    assert rel(logits, g["logits_train"]) < TOL
+    mle, _ = ops.cross_entropy(logits.view(-1, V), tgt)
+    kl = gpnn.kl_divergence()
+    assert abs(float(kl) - float(g["kl"])) < TOL * abs(float(g["kl"])) + 1e-7
+    (mle + kl * float(g["kl_scale"])).backward()
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or k not in grad:
+            continue
+        assert p.grad is not None, k
+        assert grad_close(p.grad, grad[k]), k
+    # Philox mode: same (seed, step) -> same draw; another step -> another; sample off -> the mean forward
+    gpnn.eps_override = None
+    m.set_seed(3)
+    m.set_step(5)
+    with torch.no_grad():
+        a, b = m(src), m(src)
+        m.set_step(6)
+        c = m(src)
+        gpnn.sample = False
+        e = m(src)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert rel(e, g["logits_eval"]) < TOL and rel(a, g["logits_eval"]) > 1e-4
+
+
 def test_gauss_transformer_gpnn2_golden(dev):
     """--T_gauss_pos 4 (GPNN2 random-feature layer) vs the reference: eval logits, train logits with the
     recovered frequency draw injected, and every gradient."""
@@ -400,6 +448,94 @@ def test_mc_sample_scoring_matches_oracle(dev, tag):
         assert abs(a - b) <= 1e-3 * max(1.0, abs(b))
 
 
+def _scorer_nbest(g):
+    import collections
+    vocab = {w: i for i, w in enumerate(g["words"])}
+    nbest = collections.OrderedDict()
+    for line in str(g["nbest_txt"]).splitlines():
+        parts = line.strip().split(' ', 1)
+        key, hyp = (parts[0], parts[1]) if len(parts) == 2 else (line.strip(), ' ')
+        nbest.setdefault(key.rsplit('-', 1)[0], []).append(hyp)
+    return vocab, nbest
+
+
+@pytest.mark.parametrize("fam,pos", [("tlm_gauss", 3), ("tlm_gauss", 1), ("tlm_gauss", 2), ("tlm_gauss", 4),
+                                     ("lstm_gauss", "33"), ("lstm_gauss", "31"), ("lstm_gauss", "6360"), ("lstm_gauss", "530"),
+                                     ("lstm_var", "11"), ("lstm_var", "01")])
+def test_mc_sample_scoring_gp_and_variational_families(dev, fam, pos):
+    """BASELINE.json configs[4] literally: GP Transformer (--T_gauss_pos 3) / GP-LSTM / Variational LSTM n-best scoring
+    with 8 Monte-Carlo samples.  The scorer raises GPNN.sample for the call (the reference never does, model.py:1799), sample
+    s draws coef / weights / bias (GPNN2: the frequencies; VNN: the noise rows) from Philox step s; S = 8 against the
+    CPU oracle to 1e-3, independent of the batch packing; S differs from the mean-weight scores; sigma -> 0 gives them back."""
+    from bayeslms_amd import compute_sentence_scores as S, model as M
+    from oracle import bayes_oracle as O
+    g, _, _ = load_golden("scorer_tlm_ffn")
+    vocab, nbest = _scorer_nbest(g)
+    V = len(vocab)
+    torch.manual_seed(31)
+    if fam == "tlm_gauss":
+        m = M.GaussTransformerModel(V, 16, 4, 32, 2, 0.5, True, pos)
+        mtype, ids = "Transformer", [m.transformerlayers[0].gpnn._site_base]
+    elif fam == "lstm_gauss":
+        m = M.GaussRNNModel("LSTM", V, 12, 12, 2, 0.5, True, pos)
+        mtype = "LSTM"
+        ids = {c: cell.gpnn._site_base for c, cell in enumerate(m.rnn.rnn) if hasattr(cell, "gpnn")}
+    else:
+        m = M.VariationalRNNModel("LSTM", V, 12, 12, 2, 0.5, True, pos)
+        mtype = "LSTM"
+        ids = {c: cell.vnn._site_base for c, cell in enumerate(m.rnn.rnn) if cell.vnn_type == 1}
+    with torch.no_grad():  # sigma large enough for the samples to matter at these tiny sizes
+        for k, p in m.named_parameters():
+            if "lgstd" in k:
+                p.add_(1.0)
+    m = m.to(dev)
+    osd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    if mtype == "Transformer":
+        osd["pos_encoder.pe"] = O.positional_table(5000, 16)
+    seed, NS = 977, 8
+    want = O.mc_scores(nbest, vocab, osd, fam, NS, seed, ids, pos=pos, get_input_and_target=S.get_input_and_target)
+    for batch_tokens in (8192, 16):
+        got = S.compute_scores_batched(nbest, m, vocab, mtype, dev, mc_samples=NS, seed=seed, batch_tokens=batch_tokens)
+        flat = [("%s-%d" % (k, n), v) for k, hv in got.items() for n, (_, v) in enumerate(hv, 1)]
+        assert [k for k, _ in flat] == [k for k, _ in want]
+        for (k, a), (_, b) in zip(flat, want):
+            assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (batch_tokens, k, a, b)
+    assert not m.training and all(not getattr(mod, "sample", False) for mod in m.modules() if isinstance(mod, M.GPNN))
+    mean = S.compute_scores_batched(nbest, m, vocab, mtype, dev)
+    mflat = [v for hv in mean.values() for _, v in hv]
+    assert any(abs(a - b) > 1e-4 for (_, a), b in zip(flat, mflat))
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if "lgstd" in k:
+                p.fill_(-50.0)
+    got = S.compute_scores_batched(nbest, m, vocab, mtype, dev, mc_samples=2, seed=seed)
+    for a, b in zip([v for hv in got.values() for _, v in hv], mflat):
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(b))
+
+
+@pytest.mark.parametrize("kind", ["plain_tlm", "gauss0", "vt11", "plain_lstm", "var00", "bayes5"])
+def test_mc_samples_refused_when_nothing_is_sampled(dev, kind):
+    """--mc-samples S on a model without a variational tensor used to run S identical mean-weight passes:
+    it raises now -- incl. BASELINE configs[4]'s literal `--T_v_pos 11` (zero layers, nothing to sample)."""
+    from bayeslms_amd import compute_sentence_scores as S, model as M
+    from bayeslms_amd._lib import BayesLMError
+    g, _, _ = load_golden("scorer_tlm_ffn")
+    vocab, nbest = _scorer_nbest(g)
+    V = len(vocab)
+    m, mtype = {
+        "plain_tlm": lambda: (M.TransformerModel(V, 16, 4, 32, 2, 0.5, "gelu", True), "Transformer"),
+        "gauss0": lambda: (M.GaussTransformerModel(V, 16, 4, 32, 2, 0.5, True, 0), "Transformer"),
+        "vt11": lambda: (M.VTransformerModel(V, 16, 4, 32, 2, 0.5, True, 11), "Transformer"),
+        "plain_lstm": lambda: (M.RNNModel("LSTM", V, 12, 12, 2, 0.5, True), "LSTM"),
+        "var00": lambda: (M.VariationalRNNModel("LSTM", V, 12, 12, 2, 0.5, True, "00"), "LSTM"),
+        "bayes5": lambda: (M.BayesRNNModel("LSTM", V, 12, 12, 2, 0.5, True, 5), "LSTM"),
+    }[kind]()
+    m = m.to(dev)
+    with pytest.raises(BayesLMError, match="no variational tensor"):
+        S.compute_scores_batched(nbest, m, vocab, mtype, dev, mc_samples=8)
+    assert S.compute_scores_batched(nbest, m, vocab, mtype, dev)  # mean-weight scoring is unaffected
+
+
 @pytest.mark.parametrize("tag", ["tlm_ffn_interp", "lstm_bayes3_interp"])
 def test_scorer_cli_interpolation_matches_reference(dev, tag, tmp_path):
     """--interpolation_flag 1: two models, logits mixed inside the CE kernel (blm_ce_interp_fwd); scores of
@@ -514,6 +650,120 @@ def test_gauss_rnn_golden(dev, gp):
             continue  # bias_hh is never used by the GP cells (reference quirk): no gradient on either side
         assert p.grad is not None, k
         assert grad_close(p.grad, grad[k]), k
+
+
+@pytest.mark.parametrize("gp", ["33", "31", "32", "13", "23", "43", "53", "63", "73", "330", "3333"])
+def test_gauss_rnn_sample_branch_golden(dev, gp):
+    """GP-LSTM cells with GPNN.sample raised vs the reference: one draw per cell and window (model.py:1721-1723), the
+    reference's own eps buffers injected; both windows' logits, KL, every gradient."""
+    from bayeslms_amd import model as M, ops
+    g, sd, grad = load_golden("gauss_rnn_%s_sample" % gp)
+    V, H = sd["encoder.weight"].shape
+    m = M.GaussRNNModel("LSTM", V, H, H, 2, 0.0, True, gp).to(dev)
+    with torch.no_grad():
+        load_sd(m, sd)
+    x1, x2, tgt = g["x1"].to(dev), g["x2"].to(dev), g["tgt"].to(dev)
+    B = x1.shape[1]
+    cells = [int(c) for c in g["cells"]]
+    for c in cells:
+        m.rnn.rnn[c].gpnn.sample = True
+    m.eval()
+    with torch.no_grad():
+        hid = m.init_hidden(B)
+        e1, hid = m(x1, hid)
+        e2, hid = m(x2, hid)
+    assert rel(e1, g["logits_eval_0"]) < TOL and rel(e2, g["logits_eval_1"]) < TOL
+    m.train()
+    hid = m.init_hidden(B)
+    outs = []
+    for w, x in enumerate((x1, x2)):
+        for c in cells:
+            m.rnn.rnn[c].gpnn.eps_override = _gp_eps(g, "eps_%d_%d_" % (w, c), dev)
+        logits, hid = m(x, M.repackage_hidden(hid))
+        outs.append(logits.detach().clone())
+    assert rel(outs[0], g["logits_train_0"]) < TOL and rel(outs[1], g["logits_train_1"]) < TOL
+    mle, _ = ops.cross_entropy(logits.view(-1, V), tgt)
+    kl = sum(m.rnn.rnn[c].gpnn.kl_divergence() for c in cells)
+    assert abs(float(kl) - float(g["kl"])) < TOL * abs(float(g["kl"])) + 1e-7
+    (mle + kl * float(g["kl_scale"])).backward()
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or k not in grad:
+            continue
+        assert p.grad is not None, k
+        assert grad_close(p.grad, grad[k]), k
+
+
+@pytest.mark.parametrize("gp", ["33", "13", "23", "43", "330", "3343", "31", "32", "63", "6360", "73", "53", "52", "5363"])
+def test_gauss_rnn_sample_branch_fused_steps_match_oracle(dev, gp):
+    """H = 64 (the fused step kernels) with GPNN.sample raised: injected eps per cell and window, logits of both windows,
+    KL and every gradient against the CPU oracle (pinned to the reference by the *_sample fixtures); then Philox mode."""
+    from bayeslms_amd import model as M, ops
+    from oracle import bayes_oracle as O
+    torch.manual_seed(13)
+    V, H, T, B = 30, 64, 5, 4
+    m = M.GaussRNNModel("LSTM", V, H, H, 2, 0.0, True, gp).to(dev)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if "coef_mean" in k:
+                p.uniform_(-1.0, 1.0)
+            elif "weights" in k or "weight_hh" in k:
+                p.mul_(3.0)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(5)
+    x1, x2 = torch.randint(0, V, (T, B), generator=gen), torch.randint(0, V, (T, B), generator=gen)
+    tgt = torch.randint(0, V, (T * B,), generator=gen)
+    cells = [0] if len(gp) < 3 else ([1] if len(gp) == 3 else [0, 1])
+    eps = []
+    for w in (0, 1):
+        eps.append({c: {n: torch.randn(getattr(m.rnn.rnn[c].gpnn, n + "_mean").shape, generator=gen)
+                        for n in ("coef", "weights", "bias") if hasattr(m.rnn.rnn[c].gpnn, n + "_lgstd")} for c in cells})
+    for c in cells:
+        m.rnn.rnn[c].gpnn.sample = True
+    m.train()
+    hid = m.init_hidden(B)
+    keep = []
+    for w, x in enumerate((x1, x2)):
+        for c in cells:
+            m.rnn.rnn[c].gpnn.eps_override = {n: e.to(dev) for n, e in eps[w][c].items()}
+        logits, hid = m(x.to(dev), M.repackage_hidden(hid))
+        keep.append(logits.detach().clone())
+    mle, _ = ops.cross_entropy(logits.view(-1, V), tgt.to(dev))
+    kl = sum(m.rnn.rnn[c].gpnn.kl_divergence() for c in cells)
+    (mle + 0.2 * kl).backward()
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    zeros = (torch.zeros(2, B, H), torch.zeros(2, B, H))
+    r1, hr = O.gauss_rnn_lm(x1, zeros, leaf, gp, eps[0])
+    r2, hr = O.gauss_rnn_lm(x2, tuple(h.detach() for h in hr), leaf, gp, eps[1])
+    assert rel(keep[0], r1) < TOL and rel(keep[1], r2) < TOL
+    klr = O.kl_gauss_rnn(leaf, gp)
+    (O.cross_entropy_mean(r2.view(-1, V), tgt) + 0.2 * klr).backward()
+    for k, p in m.named_parameters():
+        if k == "decoder.weight" or leaf[k].grad is None:
+            continue
+        assert p.grad is not None, k
+        assert grad_close(p.grad, leaf[k].grad), k
+    for c in cells:
+        m.rnn.rnn[c].gpnn.eps_override = None
+    m.set_seed(3)
+    m.set_step(5)
+    with torch.no_grad():
+        a, _ = m(x1.to(dev), m.init_hidden(B))
+        b, _ = m(x1.to(dev), m.init_hidden(B))
+        m.set_step(6)
+        c2, _ = m(x1.to(dev), m.init_hidden(B))
+    assert torch.equal(a, b) and not torch.equal(a, c2)
+
+
+def test_gp_lstm_cell_state_gpnn_needs_square_input(dev):
+    """Gate type 5 feeds the H-wide cell state to a GPNN built on input_size inputs (model.py:1694,1760): with
+    emsize != nhid the reference raises a shape error; so does this engine, on the fused and the step-wise path."""
+    from bayeslms_amd import model as M
+    from bayeslms_amd._lib import BayesLMError
+    cell = M.GPLSTMCell(64, 128, gate_type=5, gpnn_type=3).to(dev)
+    M.bind_state(cell, M.NoiseState())
+    with pytest.raises(BayesLMError):
+        cell(torch.randn(3, 2, 64, device=dev))
 
 
 @pytest.mark.parametrize("gp", ["34", "14", "64", "74", "54", "340", "3464"])

@@ -95,6 +95,40 @@ def test_gauss_transformer_matches_reference(gp):
     torch.testing.assert_close(kl, g["kl"], **TOL)
 
 
+def _gp_eps(g, prefix="eps_"):
+    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix) and k[len(prefix):] in ("coef", "weights", "bias")}
+
+
+@pytest.mark.parametrize("gp", [1, 2, 3])
+def test_gauss_transformer_sample_branch_matches_reference(gp):
+    """GPNN.sample raised (model.py:1863-1884): coef / weights / bias = mean + exp(lgstd) * eps with the eps buffers
+    the reference's forward drew; logits, KL and every parameter gradient (the lgstd tensors get both the
+    reparameterisation and the KL gradient)."""
+    g, sd, grad = load_golden("gauss_tlm_%d_sample" % gp)
+    nhead = int(g["nhead"])
+    V = sd["encoder.weight"].shape[0]
+    eps = _gp_eps(g)
+    assert sorted(eps) == {1: ["coef"], 2: ["bias", "weights"], 3: ["bias", "coef", "weights"]}[gp]
+    torch.testing.assert_close(O.transformer_lm(g["src"], sd, nhead, None), g["logits_eval"], **TOL)
+    assert (g["logits_train"] - g["logits_eval"]).abs().max() > 1e-3  # the branch really fired
+    leaf = {k: v.clone().requires_grad_(v.dtype.is_floating_point and k != "pos_encoder.pe") for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    logits = O.transformer_lm(g["src"], leaf, nhead, eps)
+    torch.testing.assert_close(logits, g["logits_train"], **TOL)
+    pre = "transformerlayers.0.gpnn."
+    kl = torch.zeros(())
+    if gp in (1, 3):
+        kl = kl + O.kl_mean_form_minus1(leaf[pre + "coef_mean"], leaf[pre + "coef_lgstd"])
+    if gp in (2, 3):
+        kl = kl + O.kl_mean_form_minus1(leaf[pre + "weights_mean"], leaf[pre + "weights_lgstd"])
+        kl = kl + O.kl_mean_form_minus1(leaf[pre + "bias_mean"], leaf[pre + "bias_lgstd"])
+    torch.testing.assert_close(kl, g["kl"], **TOL)
+    (O.cross_entropy_mean(logits.view(-1, V), g["tgt"]) + kl * float(g["kl_scale"])).backward()
+    for k, gv in grad.items():
+        if k != "decoder.weight":
+            torch.testing.assert_close(leaf[k].grad, gv, rtol=2e-4, atol=2e-6, msg=lambda m, k=k: k + ": " + m)
+
+
 def test_gauss_transformer_gpnn2_matches_reference():
     """--T_gauss_pos 4: GPNN2 random features in layer 0 (model.py:2036-2076); train mode samples the
     frequencies with the recovered draw; gradients of every parameter against the reference's."""
@@ -333,6 +367,38 @@ def test_gauss_rnn_matches_reference(gp):
     kl = O.kl_gauss_rnn(leaf, gp)
     torch.testing.assert_close(kl, g["kl"], **TOL)
     (mle + kl * float(g["kl_scale"])).backward()
+    for k, gv in grad.items():
+        if k != "decoder.weight":
+            torch.testing.assert_close(leaf[k].grad, gv, rtol=2e-4, atol=2e-6, msg=lambda m, k=k: k + ": " + m)
+
+
+GAUSS_RNN_SAMPLE = ["33", "31", "32", "13", "23", "43", "53", "63", "73", "330", "3333"]
+
+
+def _gp_cell_eps(g, w):
+    return {int(c): _gp_eps(g, "eps_%d_%d_" % (w, int(c))) for c in g["cells"]}
+
+
+@pytest.mark.parametrize("gp", GAUSS_RNN_SAMPLE)
+def test_gauss_rnn_sample_branch_matches_reference(gp):
+    """GP-LSTM cells with GPNN.sample raised: one draw per cell and window shared by all its steps (model.py:1721-1723)."""
+    g, sd, grad = load_golden("gauss_rnn_%s_sample" % gp)
+    B, H = g["x1"].shape[1], sd["encoder.weight"].shape[1]
+    zeros = (torch.zeros(2, B, H), torch.zeros(2, B, H))
+    e1, hid = O.gauss_rnn_lm(g["x1"], zeros, sd, gp)
+    e2, hid = O.gauss_rnn_lm(g["x2"], hid, sd, gp)
+    torch.testing.assert_close(e1, g["logits_eval_0"], **TOL)
+    torch.testing.assert_close(e2, g["logits_eval_1"], **TOL)
+    assert (g["logits_train_0"] - g["logits_eval_0"]).abs().max() > 1e-4  # the branch fired
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    l1, hid = O.gauss_rnn_lm(g["x1"], zeros, leaf, gp, _gp_cell_eps(g, 0))
+    l2, hid = O.gauss_rnn_lm(g["x2"], tuple(h.detach() for h in hid), leaf, gp, _gp_cell_eps(g, 1))
+    torch.testing.assert_close(l1, g["logits_train_0"], **TOL)
+    torch.testing.assert_close(l2, g["logits_train_1"], **TOL)
+    kl = O.kl_gauss_rnn(leaf, gp)
+    torch.testing.assert_close(kl, g["kl"], **TOL)
+    (O.cross_entropy_mean(l2, g["tgt"]) + kl * float(g["kl_scale"])).backward()
     for k, gv in grad.items():
         if k != "decoder.weight":
             torch.testing.assert_close(leaf[k].grad, gv, rtol=2e-4, atol=2e-6, msg=lambda m, k=k: k + ": " + m)
