@@ -90,6 +90,11 @@ SIGNATURES = {
     "blm_gemm_plan_override": (_i, [_i, _i]),
     "blm_gemm_plan_set": (_i, [_i] * 8),
     "blm_gemm_plan_clear": (_i, [_i]),
+    "blm_gemm_plan_set_cus": (_i, [_i]),
+    "blm_gemm_plan_get_cus": (_i, []),
+    "blm_gemm_plan_comm_window": (_i, [_f]),
+    "blm_gemm_plan_comm_window_left": (_f, []),
+    "blm_gemm_plan_set_comm": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "blm_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _f, _f, _rngp, _i, _i, _vp]),
     "blm_embed_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _f, _f, _rngp, _i, _i, _vp]),
     "blm_add_pe_dropout": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
@@ -107,6 +112,9 @@ SIGNATURES = {
     "blm_ce_interp_fwd": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _i, _i, _vp]),
     "blm_linear_nll_ws_floats": (_i64, [_i, _i]),
     "blm_linear_nll": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "blm_linear_nll2_wcat_floats": (_i64, [_i, _i, _i]),
+    "blm_linear_nll2_ws_floats": (_i64, [_i, _i, _i, _i]),
+    "blm_linear_nll2": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _vp, _i64, _vp, _i64, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "blm_ce_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "blm_gp_coef_grad": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "blm_colsum": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp]),

@@ -142,6 +142,20 @@ _FUSED_NLL = os.environ.get("BLM_SCORER_FUSED_NLL", "1") != "0"  # 0: decoder lo
 _PACKED = os.environ.get("BLM_SCORER_PACKED", "1") != "0"  # 0: padded (T, N) activations in the Transformer stacks (A/B)
 
 
+_INTERP = {}  # (id(model), id(model_2), alpha) -> ops.InterpDecoder of the scoring run in progress
+
+
+def _interp_decoder(model, model_2, alpha):
+    from . import ops
+    key = (id(model), id(model_2), float(alpha))
+    dec = _INTERP.get(key)
+    d1, d2 = model.decoder, model_2.decoder
+    if dec is None or dec.w1.data_ptr() != d1.weight.data_ptr() or dec.w2.data_ptr() != d2.weight.data_ptr():
+        _INTERP.clear()  # one pair at a time: the packed [W1 | W2] is V x (K1 + K2) floats
+        dec = _INTERP[key] = ops.InterpDecoder(d1.weight, d1.bias, d2.weight, d2.bias, alpha)
+    return dec
+
+
 def _batch_nll(model, data, target_flat, model_type, hidden, model_2, hidden_2, alpha, rows=None):
     """Per-token NLL of a padded batch of hypotheses (all columns start from the same state): (T, N), or -- with
     ``rows`` (flat indices t*N + n of the real tokens) -- one value per selected row, the decoder being applied to those
@@ -159,8 +173,16 @@ def _batch_nll(model, data, target_flat, model_type, hidden, model_2, hidden_2, 
     # interpolate LOGITS (reference :163) and keep the materialised pair + the two-input CE kernel
     fused = (model_2 is None and _FUSED_NLL and not torch.is_grad_enabled() and hasattr(model.decoder, "nll_targets")
              and ops.linear_nll_supported(model.decoder.weight, model.decoder.bias))
+    # two models: the reference interpolates LOGITS (:163); alpha (x1 W1^T + b1) + (1 - alpha) (x2 W2^T + b2) is one product
+    # over packed operands, so one decoder + cross-entropy launch takes both and no logits are stored (ops.linear_nll_interp)
+    fused2 = (model_2 is not None and _FUSED_NLL and not torch.is_grad_enabled()
+              and all(hasattr(m.decoder, "return_input") for m in (model, model_2))
+              and ops.linear_nll_interp_supported(model.decoder.weight, model.decoder.bias, model_2.decoder.weight,
+                                                  model_2.decoder.bias))
     if fused:
         model.decoder.nll_targets = target_flat
+    if fused2:
+        model.decoder.return_input = model_2.decoder.return_input = True
     try:
         with (ops.packed_tokens(rows, data.shape[0], data.shape[1]) if packed else contextlib.nullcontext()):
             if model_type == 'Transformer':
@@ -172,6 +194,8 @@ def _batch_nll(model, data, target_flat, model_type, hidden, model_2, hidden_2, 
                 out2 = model_2(data) if model_type == 'Transformer' else model_2(data, hidden_2)[0]
         if fused:
             nll = out
+        elif fused2:
+            nll = ops.linear_nll_interp(out, out2, _interp_decoder(model, model_2, alpha), target_flat)
         elif model_2 is not None:
             _, nll = ops.cross_entropy_interp(out.view(-1, out.shape[-1]), out2.view(-1, out2.shape[-1]), alpha, target_flat)
         else:
@@ -182,6 +206,8 @@ def _batch_nll(model, data, target_flat, model_type, hidden, model_2, hidden_2, 
                 m.decoder.rows = None
         if fused:
             model.decoder.nll_targets = None
+        if fused2:
+            model.decoder.return_input = model_2.decoder.return_input = False
     return nll if rows is not None else nll.view(data.shape[0], data.shape[1])
 
 
@@ -358,6 +384,7 @@ def _compute_scores_batched(nbest, model, vocab, model_type, device, model_2, al
     try:
         _score_all(nbest, model, model_2, vocab, device, is_rnn, hidden, hidden_2, batch_tokens, score_group, flush)
     finally:
+        _INTERP.clear()  # the packed [W1 | W2] belongs to this scoring run
         if mc_samples > 0:
             model.noise_state.dropout_off = False
             model.eval()

@@ -109,7 +109,7 @@ extern "C" int blm_gemm(const blm_gemm_args* a, void* stream) {
     const PlanKey key = plan_key(a);
     if ((key.fast != 0) != (p.fast != 0)) return blm_fail(BLM_ERR_INVALID, "blm_gemm: planner and launcher disagree on the fast path");
     const Plan pl = choose_plan(key);
-    p.plan_tile = pl.tile; p.plan_splits = pl.splits;
+    p.plan_tile = pl.tile; p.plan_splits = pl.splits; p.plan_cus = pl.cus;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (p.colsum_a && !p.fast) {  // odd shapes: the guarded-loader kernel does not fuse it
@@ -184,7 +184,11 @@ extern "C" int blm_linear_nll(const float* x, int64_t ldx, const float* w, int64
   const Plan pl = choose_plan(key);
   p.plan_tile = (key.fast != 0) == (p.fast != 0) ? pl.tile : 11;
   p.plan_splits = 1;
+  p.plan_cus = pl.cus;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // the target's logit is written by the one lane whose column window holds it: a target outside [0, N) (a padding id, -1)
+  // would leave its slot uninitialised -- every slot starts as NaN, so such a row's NLL is NaN, not garbage
+  BLM_HIP(hipMemsetAsync(p.ce_tlogit, 0xFF, (size_t)M * sizeof(float), st));
   const int rc = launch_op<BLM_GEMM_NT, false>(p, st);
   if (rc) return rc;
   // column tiles of the launch: 64 columns on tiles 11 / 21 (and on the guarded 64x64 kernel), 128 otherwise
@@ -194,4 +198,75 @@ extern "C" int blm_linear_nll(const float* x, int64_t ldx, const float* w, int64
   hipLaunchKernelGGL(ce_part_finish_kernel, dim3((M + 3) / 4), dim3(256), 0, st, ws, p.ce_tlogit, nll, lse, M, gn);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-model scoring (compute_sentence_scores_bayes_jianwei.py:157-168): the reference interpolates the LOGITS of two language
+// models, alpha * (x1 W1^T + b1) + (1 - alpha) * (x2 W2^T + b2), then takes log_softmax -- two (M x V) matrices written, mixed
+// and read back.  The mixture is ONE product: [alpha x1 | (1 - alpha) x2] . [W1 | W2]^T + (alpha b1 + (1 - alpha) b2), so the
+// decoder + cross-entropy launch of blm_linear_nll takes it with K = K1 + K2 and the logits of neither model are ever stored.
+// The operands are packed into caller-owned workspace: the activations per call (M x (K1 + K2), small beside the product's
+// 2 M V (K1 + K2) flops), the weights and the bias only when asked (pack_w: the first call of a scoring run).
+namespace blm {
+// dst[r] = [sa * a[r] | sb * b[r]] for r < rows, zeros for rows <= r < rows_out (vocabulary padding)
+__global__ __launch_bounds__(256) void pack2_kernel(float* __restrict__ dst, long ldd, const float* __restrict__ a, long lda, int ka,
+                                                    float sa, const float* __restrict__ b, long ldb, int kb, float sb, long rows,
+                                                    long rows_out) {
+  const long kq = (long)(ka + kb) / 4, n = rows_out * kq;  // float4 columns: ka and kb are multiples of 4
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / kq;
+    const int c = (int)(i - r * kq) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) {
+      if (c < ka) { v = *reinterpret_cast<const float4*>(a + r * lda + c); v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa; }
+      else { v = *reinterpret_cast<const float4*>(b + r * ldb + (c - ka)); v.x *= sb; v.y *= sb; v.z *= sb; v.w *= sb; }
+    }
+    *reinterpret_cast<float4*>(dst + r * ldd + c) = v;
+  }
+}
+// mixed bias; the padding columns get -inf: exp(-inf - max) = 0, they never reach the soft-max sum
+__global__ __launch_bounds__(256) void bias_mix_kernel(float* __restrict__ dst, const float* __restrict__ b1, float s1,
+                                                       const float* __restrict__ b2, float s2, int n, int n_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (b1 ? s1 * b1[i] : 0.f) + (b2 ? s2 * b2[i] : 0.f);
+  else if (i < n_out) dst[i] = -INFINITY;
+}
+}  // namespace blm
+
+extern "C" int64_t blm_linear_nll2_wcat_floats(int N, int K1, int K2) {
+  if (N < 0 || K1 < 0 || K2 < 0) return 0;
+  const int64_t Np = ((int64_t)N + 3) / 4 * 4;  // vocabulary padded to the vectorised epilogue's multiple of 4
+  return Np * (K1 + K2) + Np;                  // [W1 | W2] and the mixed bias
+}
+
+extern "C" int64_t blm_linear_nll2_ws_floats(int M, int N, int K1, int K2) {
+  if (M < 0 || N < 0 || K1 < 0 || K2 < 0) return 0;
+  return (int64_t)M * (K1 + K2) + blm_linear_nll_ws_floats(M, (N + 3) / 4 * 4);  // packed activations, then blm_linear_nll's own workspace
+}
+
+extern "C" int blm_linear_nll2(const float* x1, int64_t ldx1, const float* w1, int64_t ldw1, const float* b1, int K1,
+                               const float* x2, int64_t ldx2, const float* w2, int64_t ldw2, const float* b2, int K2, float alpha,
+                               const int64_t* tgt, float* nll, float* lse, float* wcat, int pack_w, float* ws, int M, int N,
+                               void* stream) {
+  if (M < 0 || N <= 0 || K1 <= 0 || K2 <= 0) return blm_fail(BLM_ERR_INVALID, "blm_linear_nll2: bad shape");
+  if (M == 0) return BLM_OK;
+  if (!x1 || !x2 || !w1 || !w2 || !tgt || !nll || !wcat || !ws || ldx1 < K1 || ldx2 < K2 || ldw1 < K1 || ldw2 < K2)
+    return blm_fail(BLM_ERR_INVALID, "blm_linear_nll2: bad arguments");
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (K1 % 4 || K2 % 4 || ldx1 % 4 || ldx2 % 4 || ldw1 % 4 || ldw2 % 4 || !al(x1) || !al(x2) || !al(w1) || !al(w2) || !al(wcat) || !al(ws))
+    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_linear_nll2: needs K1, K2 and the row strides to be multiples of 4 and 16-byte aligned operands");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int K = K1 + K2, Np = (N + 3) / 4 * 4;
+  float* bias = wcat + (int64_t)Np * K;
+  auto blocks = [](long n) { long b = (n + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); };
+  if (pack_w) {
+    hipLaunchKernelGGL(pack2_kernel, dim3(blocks((long)Np * K / 4)), dim3(256), 0, st, wcat, (long)K, w1, (long)ldw1, K1, 1.f, w2, (long)ldw2,
+                       K2, 1.f, (long)N, (long)Np);
+    hipLaunchKernelGGL(bias_mix_kernel, dim3((Np + 255) / 256), dim3(256), 0, st, bias, b1, alpha, b2, 1.f - alpha, N, Np);
+  }
+  hipLaunchKernelGGL(pack2_kernel, dim3(blocks((long)M * K / 4)), dim3(256), 0, st, ws, (long)K, x1, (long)ldx1, K1, alpha, x2, (long)ldx2, K2,
+                     1.f - alpha, (long)M, (long)M);
+  BLM_HIP(hipGetLastError());
+  return blm_linear_nll(ws, K, wcat, K, bias, tgt, nll, lse, ws + (int64_t)M * K, M, Np, K, stream);
 }

@@ -45,6 +45,7 @@ struct GemmP {
   int gm, gn;
   int eps_quad;                  // Bayesian wgrad: eps drawn once per 4 columns and shared inside the quad (N % 4 == 0, Philox mode)
   int plan_tile, plan_splits;    // gemm_plan.hip: 11 / 12 / 21 / 22 and the number of K slices (>= 1)
+  int plan_cus;                  // compute units the plan counts its rounds of workgroup slots with (0: the device's)
   float* colsum_a;  // TN only: += column sums of A (= bias gradient of the layer whose wgrad this is)
   int splits, kper, atomic;  // split-K: block ks covers k in [ks*kper, (ks+1)*kper), partial sums by float atomics
   // BLM_EPI_CE_PART (blm_linear_nll: inference, logits never stored): per (row, column tile) the maximum and the sum of
@@ -1324,7 +1325,7 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   q.tail_from = 0;
   if (p.plan_splits < -1) {
     constexpr int OCC = (WTM * WTN == 1) ? 5 : (WTM * WTN * WGN == 4 ? 3 : 2);  // LDS: 32 / 48 / 64 KB of 160 (gemm_plan.hip kTiles)
-    const long slots = (long)gemm_cu_count() * OCC;
+    const long slots = (long)(p.plan_cus > 0 ? p.plan_cus : gemm_cu_count()) * OCC;
     q.tail_from = (int)(nb / slots * slots);
     if (q.tail_from == nb) { q.tail_from = 0; splits = 1; }  // whole rounds only: nothing to slice
   }

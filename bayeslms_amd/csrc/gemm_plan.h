@@ -22,11 +22,17 @@ struct PlanKey {
 struct Plan {
   int tile;    // 11 = 64x64, 12 = 64x128, 21 = 128x64, 22 = 128x128 (rows x cols of 64)
   int splits;  // >= 1: K slices of every tile; <= -2: only the tiles beyond the last whole round of workgroup slots are sliced, |splits| ways
-  int source;  // 0 model, 1 table, 2 override
+  int source;  // 0 model, 1 table, 2 override, 3 the table of plans measured beside a collective (comm window open)
+  int cus;     // compute units the plan was made for (plan_cus() at the time): tail slicing counts its rounds with it
+  float us;    // the cost model's estimate of this plan (what a launch takes off an open comm window)
 };
 
 Plan choose_plan(const PlanKey& k);
 double plan_model_us(const PlanKey& k, int tile, int splits);  // the model's time estimate (microseconds)
 PlanKey plan_key(const blm_gemm_args* a);  // the ONE place that derives the planning key of a call
+// Compute units the planner fills: the chip's 256 unless blm_gemm_plan_set_cus narrowed it (data-parallel training: the
+// collective's channel workgroups hold CUs while backward GEMMs run beside them, engine.GradReducer).
+int plan_cus();
+constexpr int kChipCUs = 256;
 
 }  // namespace blm

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "blm_host.h"
@@ -26,10 +27,45 @@ const Entry kBuiltin[] = {
 #include "gemm_plans.inc"
     {-1, 0, 0, 0, 0, 0, 0, 0}};
 
+// Plans for launches that run BESIDE a collective's channel workgroups (blm_gemm_plan_comm_window): measured stand-alone
+// next to a resident stand-in with RCCL's channel-kernel footprint (tools/gemm_tune_comm.py writes gemm_plans_comm.inc).
+// Listed: shapes whose whole-chip plan loses more than 5 % to another plan there; every other launch keeps its plan.
+const Entry kComm[] = {
+#include "gemm_plans_comm.inc"
+    {-1, 0, 0, 0, 0, 0, 0, 0}};
+
 std::mutex g_mu;
 std::vector<Entry> g_runtime;   // blm_gemm_plan_set
 bool g_builtin_on = true;       // blm_gemm_plan_clear switches the built-in table off as well (model only)
 int g_force_tile = -1, g_force_splits = 0;  // tile -1: environment not read yet
+// Compute units the plans may count on (blm_gemm_plan_set_cus).  Every plan-table entry was measured with the whole chip to
+// itself -- the roofline launch is exactly ONE round of 256 one-per-CU workgroups -- so the table applies at kChipCUs only;
+// with fewer CUs (a collective's channel workgroups resident beside the GEMMs) the cost model plans for that many.
+int g_cus = kChipCUs;
+// Modelled GEMM time (us) that is still expected to run beside gradient buckets in flight (blm_gemm_plan_comm_window): the
+// host enqueues far ahead of the device, so "while a bucket is in flight" is kept in DEVICE time -- every bucket adds its
+// expected time on the links, every planned launch takes its own modelled time off.
+double g_window_us = 0.0;
+std::vector<Entry> g_comm_runtime;  // blm_gemm_plan_set_comm
+bool g_comm_builtin_on = true;
+
+// choose_plan runs in front of EVERY blm_gemm launch (incl. the per-time-step products of the step-wise recurrent paths):
+// the plan of a key is computed once and kept until something that can change it happens (set / clear / override / set_cus).
+struct KeyHash {
+  size_t operator()(const PlanKey& k) const {
+    size_t h = 1469598103934665603ull;
+    for (int v : {k.op, k.M, k.N, k.K, k.epi, k.acc, k.can_split, k.fast}) { h ^= (size_t)(unsigned)v; h *= 1099511628211ull; }
+    return h;
+  }
+};
+struct KeyEq {
+  bool operator()(const PlanKey& a, const PlanKey& b) const {
+    return a.op == b.op && a.M == b.M && a.N == b.N && a.K == b.K && a.epi == b.epi && a.acc == b.acc && a.can_split == b.can_split &&
+           a.fast == b.fast;
+  }
+};
+// [cus, or -1 inside a comm window][key]: both switches toggle several times per training step
+std::unordered_map<int, std::unordered_map<PlanKey, Plan, KeyHash, KeyEq>> g_memo;
 
 // ---- cost model -------------------------------------------------------------------------------------------------
 // A workgroup is 4 waves, one per SIMD; per K tile of 32 a wave issues wtm*wtn*16 v_mfma_f32_32x32x2_f32 of 64 cycles.
@@ -79,7 +115,7 @@ double model_us(const PlanKey& k, const TileModel& t, int S) {
   const int ti = (int)(&t - kTiles);
   const long BM = 64 * t.wtm, BN = 64 * t.wtn;
   const long tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN);
-  const long slots = 256L * t.occ;
+  const long slots = (long)g_cus * t.occ;
   auto eff = [&](double o) { return m.einf[k.op][ti] * o / (o + m.a[ti]); };
   auto tk_of = [&](long kper) { return (double)((kper + 31) / 32) * 1024.0 * t.wtm * t.wtn / m.cyc_per_us; };  // matrix issue time of one workgroup on its SIMDs
   bool tail = S < -1;
@@ -102,7 +138,7 @@ double model_us(const PlanKey& k, const TileModel& t, int S) {
   double us = m.launch_us;
   if (full > 0) us += m.t0[ti] + t_full + (double)(full - 1) * (m.t0r[ti] + t_full);
   if (rem > 0) {
-    const double o = (double)((rem + 255) / 256);
+    const double o = (double)((rem + g_cus - 1) / g_cus);
     us += (full > 0 ? m.t0r[ti] : m.t0[ti]) + o * tk_rem / eff(o) + m.t0o[ti] * o;
   }
   const double bytes = 4.0 * ((double)k.M * k.K + (double)k.N * k.K + (double)k.M * k.N * (k.acc ? 2.0 : 1.0));
@@ -141,7 +177,7 @@ Plan model_plan(const PlanKey& k) {
     if (model_tail < 0) { const char* e = getenv("BLM_GEMM_MODEL_TAIL"); model_tail = (e && atoi(e) == 1) ? 1 : 0; }
     if (!model_tail) continue;
     const long BM = 64 * t.wtm, BN = 64 * t.wtn;
-    const long tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN), slots = 256L * t.occ;
+    const long tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN), slots = (long)g_cus * t.occ;
     if (k.can_split && tiles > slots && tiles % slots != 0)
       for (int S : {2, 4, 8, 16, 32}) {
         if (k.K / S < 128 || (tiles % slots) * S > slots) break;
@@ -158,6 +194,15 @@ const Entry* find(const PlanKey& k) {
     if (it->op == k.op && it->M == k.M && it->N == k.N && it->K == k.K && it->epi == k.epi && it->acc == k.acc) return &*it;
   if (g_builtin_on)
     for (const Entry* e = kBuiltin; e->op >= 0; ++e)
+      if (e->op == k.op && e->M == k.M && e->N == k.N && e->K == k.K && e->epi == k.epi && e->acc == k.acc) return e;
+  return nullptr;
+}
+
+const Entry* find_comm(const PlanKey& k) {
+  for (auto it = g_comm_runtime.rbegin(); it != g_comm_runtime.rend(); ++it)
+    if (it->op == k.op && it->M == k.M && it->N == k.N && it->K == k.K && it->epi == k.epi && it->acc == k.acc) return &*it;
+  if (g_comm_builtin_on)
+    for (const Entry* e = kComm; e->op >= 0; ++e)
       if (e->op == k.op && e->M == k.M && e->N == k.N && e->K == k.K && e->epi == k.epi && e->acc == k.acc) return e;
   return nullptr;
 }
@@ -199,13 +244,32 @@ double plan_model_us(const PlanKey& k, int tile, int splits) {
   return -1.0;
 }
 
+int plan_cus() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_cus;
+}
+
 Plan choose_plan(const PlanKey& k) {
   std::lock_guard<std::mutex> lk(g_mu);
   read_env();
   static int model_only = -1;  // BLM_GEMM_PLAN=model: the cost model alone (plan table off), for A/B runs
   if (model_only < 0) { const char* e = getenv("BLM_GEMM_PLAN"); model_only = (e && !strcmp(e, "model")) ? 1 : 0; }
-  Plan p = model_plan(k);
-  if (const Entry* e = model_only ? nullptr : find(k)) { p.tile = e->tile; p.splits = e->splits; p.source = 1; }
+  const bool under_comm = g_window_us > 0.0 && g_cus == kChipCUs;
+  auto& memo = g_memo[under_comm ? -1 : g_cus];
+  auto hit = memo.find(k);
+  if (hit != memo.end()) {
+    if (under_comm) g_window_us -= hit->second.us;
+    return hit->second;
+  }
+  Plan p{11, 1, 0, g_cus, 0.f};
+  // table entries were measured on the whole chip: they apply there only
+  const Entry* e = (model_only || g_cus != kChipCUs) ? nullptr : find(k);
+  if (e) { p.tile = e->tile; p.splits = e->splits; p.source = 1; }
+  else { p = model_plan(k); p.cus = g_cus; }
+  // beside a collective: the plan measured there, where one exists (everything else keeps its whole-chip plan -- in situ the
+  // cost model's plans for a narrowed chip lose to the measured table whenever no channel workgroup is resident)
+  if (under_comm)
+    if (const Entry* c = find_comm(k)) { p.tile = c->tile; p.splits = c->splits; p.source = 3; }
   if (g_force_tile > 0 && valid_tile(g_force_tile)) { p.tile = g_force_tile; p.source = 2; }
   if (g_force_splits != 0) { p.splits = g_force_splits; p.source = 2; }
   // legality, whatever the source said (splits <= -2: tail slicing, |splits| ways)
@@ -218,11 +282,16 @@ Plan choose_plan(const PlanKey& k) {
   if (p.splits < 0) {  // canonical form: a tail plan without a whole round is the uniform plan, one without a remainder is unsliced
     for (const TileModel& t : kTiles)
       if (t.tile == p.tile) {
-        const long tiles = ((k.M + 64L * t.wtm - 1) / (64L * t.wtm)) * ((k.N + 64L * t.wtn - 1) / (64L * t.wtn)), slots = 256L * t.occ;
+        const long tiles = ((k.M + 64L * t.wtm - 1) / (64L * t.wtm)) * ((k.N + 64L * t.wtn - 1) / (64L * t.wtn)), slots = (long)g_cus * t.occ;
         if (tiles < slots) p.splits = -p.splits;
         else if (tiles % slots == 0) p.splits = 1;
       }
   }
+  for (const TileModel& t : kTiles)
+    if (t.tile == p.tile) p.us = (float)model_us(k, t, p.splits);
+  if (memo.size() > 4096) memo.clear();  // step-wise paths with ever-changing shapes: bounded
+  memo.emplace(k, p);
+  if (under_comm) g_window_us -= p.us;
   return p;
 }
 
@@ -281,6 +350,7 @@ extern "C" int blm_gemm_plan_override(int tile, int splits) {
   if (splits < -64 || splits > 64 || splits == -1) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_override: splits out of range");
   std::lock_guard<std::mutex> lk(g_mu);
   g_force_tile = tile; g_force_splits = splits;
+  g_memo.clear();
   return BLM_OK;
 }
 
@@ -289,12 +359,47 @@ extern "C" int blm_gemm_plan_set(int op, int M, int N, int K, int epilogue, int 
     return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_set: bad op, tile or split count");
   std::lock_guard<std::mutex> lk(g_mu);
   g_runtime.push_back(Entry{op, M, N, K, epilogue, accumulate ? 1 : 0, tile, splits});
+  g_memo.clear();
   return BLM_OK;
 }
 
 extern "C" int blm_gemm_plan_clear(int keep_builtin) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_runtime.clear();
-  g_builtin_on = keep_builtin != 0;
+  g_comm_runtime.clear();
+  g_builtin_on = g_comm_builtin_on = keep_builtin != 0;
+  g_memo.clear();
+  return BLM_OK;
+}
+
+extern "C" int blm_gemm_plan_set_cus(int cus) {
+  if (cus != 0 && (cus < 8 || cus > kChipCUs)) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_set_cus: 0 (the whole chip) or 8..%d", kChipCUs);
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int n = cus == 0 ? kChipCUs : cus;
+  g_cus = n;
+  return BLM_OK;
+}
+
+extern "C" int blm_gemm_plan_get_cus(void) { return plan_cus(); }
+
+extern "C" int blm_gemm_plan_comm_window(float us) {
+  if (!(us >= 0.f) || us > 1e7f) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_comm_window: 0 (close) or a time in microseconds");
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (us == 0.f) g_window_us = 0.0;
+  else g_window_us = (g_window_us > 0.0 ? g_window_us : 0.0) + us;
+  return BLM_OK;
+}
+
+extern "C" float blm_gemm_plan_comm_window_left(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_window_us > 0.0 ? (float)g_window_us : 0.f;
+}
+
+extern "C" int blm_gemm_plan_set_comm(int op, int M, int N, int K, int epilogue, int accumulate, int tile, int splits) {
+  if (op < BLM_GEMM_NT || op > BLM_GEMM_TN || !valid_tile(tile) || splits < -64 || splits > 64 || splits == 0 || splits == -1)
+    return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_set_comm: bad op, tile or split count");
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_comm_runtime.push_back(Entry{op, M, N, K, epilogue, accumulate ? 1 : 0, tile, splits});
+  g_memo.clear();
   return BLM_OK;
 }

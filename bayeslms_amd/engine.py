@@ -18,6 +18,32 @@ import torch.distributed as dist
 from . import ops
 
 
+RCCL_CHANNELS_DEFAULT = 16
+
+
+def pin_rccl_channels(n=None):
+    """Call BEFORE dist.init_process_group("nccl").  Pins RCCL's channel count (one 256-thread workgroup per channel and
+    collective, each holding a CU's registers beside the backward GEMMs) with NCCL_MIN_NCHANNELS / NCCL_MAX_NCHANNELS unless
+    the user has set them: ``n`` or BLM_RCCL_CHANNELS or 16.  Why 16 (profiles/r04_comm_occupancy_rehearsal.txt): the
+    cfg3 gradient is 202 MB per 20 ms step -- 18 GB/s of bus bandwidth would hide it under backward -- and in the one-GPU
+    rehearsal a 16-workgroup stand-in at 150-300 GB/s costs the step 1.1 ms (5 %), 8 workgroups cannot stream a bucket
+    fast enough (2.3 ms, most of it exposed) and 32 cost 0.7-1.9 ms.  0 leaves RCCL's own choice.
+    -> the settings in force (recorded in bench.py's ``comm``)."""
+    n = int(os.environ.get("BLM_RCCL_CHANNELS", RCCL_CHANNELS_DEFAULT if n is None else n))
+    if n > 0:
+        os.environ.setdefault("NCCL_MIN_NCHANNELS", str(n))
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
+    return {k: os.environ.get(k) for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS")}
+
+
+def rccl_channels():
+    """The channel count RCCL was pinned to (0: unknown / RCCL's own choice -- the planner then keeps the whole chip)."""
+    try:
+        return max(0, int(os.environ.get("NCCL_MAX_NCHANNELS", "0")))
+    except ValueError:
+        return 0
+
+
 class FlatBuffers:
     """Re-homes every distinct parameter of ``model`` into one contiguous buffer and gives each a
     ``.grad`` view into a second one.  Tied tensors (decoder.weight is encoder.weight) appear once."""
@@ -64,13 +90,28 @@ class GradReducer:
     "nccl" = RCCL.
     """
 
-    def __init__(self, flat, bucket_bytes=32 << 20, group=None, expected=None, overlap=True):
+    def __init__(self, flat, bucket_bytes=32 << 20, group=None, expected=None, overlap=True, comm_cus=0, collective=None,
+                 comm_plan="window", comm_gbps=None):
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuda = flat.flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.cuda else None
         self.overlap = overlap
+        # CU contention (DESIGN 6): RCCL runs one channel workgroup per channel (gfx950: 256 threads, ~280 registers per
+        # lane, 19.7 KB LDS -- a CU that hosts one cannot also host an eight-wave GEMM workgroup, and a launch that is
+        # exactly one round of 256 one-per-CU workgroups spills a second round: 1.74x, tools/comm_occupancy_rehearsal.py).
+        # comm_plan "window" (default when comm_cus > 0): every bucket opens / extends the planner's comm window by its
+        # expected time on the links (bytes / comm_gbps); the GEMMs enqueued behind it take the plans measured beside a
+        # resident channel stand-in (csrc/gemm_plans_comm.inc) until their modelled time has used the window up.
+        # "narrow": the planner counts on 256 - comm_cus CUs from the first bucket of a step until finish() (measured:
+        # loses 1.5-10 % in situ -- buckets are in flight for a tenth of backward; kept for A/B).  "off": nothing.
+        self.comm_cus = int(comm_cus) if self.cuda else 0
+        self.comm_plan = comm_plan if self.comm_cus > 0 else "off"
+        self.comm_gbps = float(os.environ.get("BLM_COMM_GBPS", "100") if comm_gbps is None else comm_gbps)
+        self._narrowed = False
+        # rehearsal (tools/comm_occupancy_rehearsal.py): fn(view, comm_stream) stands in for dist.all_reduce, world 1
+        self.collective = collective
         self.late = None  # LateRows, set by the Trainer
         self.no_dense = set()  # buckets whose only tensor gets ALL of its gradient through LateRows (untied encoder)
         self.measure = False  # record (backward end, communication end) event pairs on the compute stream
@@ -154,7 +195,7 @@ class GradReducer:
         if self.launched[b]:
             return
         self.launched[b] = True
-        if self.world == 1:
+        if self.world == 1 and self.collective is None:
             return
         if b in self.no_dense and self.late is not None and self.late.used:
             return  # nothing dense was written: the compact exchange carries the whole gradient of this tensor
@@ -167,6 +208,15 @@ class GradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
+            if self.comm_plan == "window":
+                ops.gemm_comm_window(view.numel() * view.element_size() / (self.comm_gbps * 1e3))
+                self._narrowed = True
+            elif self.comm_plan == "narrow" and not self._narrowed:
+                ops.set_gemm_cus(max(8, ops.get_gemm_cus() - self.comm_cus))
+                self._narrowed = True
+            if self.collective is not None:
+                self.collective(view, self.comm_stream)
+                return
             with torch.cuda.stream(self.comm_stream):
                 self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -193,8 +243,14 @@ class GradReducer:
             self._launch(b)
         for h in self.handles:
             h.wait()
-        if self.cuda and self.world > 1:
+        if self.cuda and (self.world > 1 or self.collective is not None):
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self._narrowed:  # whatever is enqueued from here on starts after the last bucket has landed
+            if self.comm_plan == "window":
+                ops.gemm_comm_window(0)
+            else:
+                ops.set_gemm_cus(0)
+            self._narrowed = False
         if ev0 is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record(torch.cuda.current_stream())
@@ -313,17 +369,23 @@ class Trainer:
     + clip + SGD, as train.py:315-420 does, for any of the model families."""
 
     def __init__(self, model, lr, clip, momentum=0.9, kl_scale=0.0, seed=1111, rank=0, world=1, global_batch=None,
-                 bucket_bytes=32 << 20, fused_kl=True, weight_decay=0.0, overlap=True, late_rows=True):
+                 bucket_bytes=32 << 20, fused_kl=True, weight_decay=0.0, overlap=True, late_rows=True, comm_cus=None,
+                 collective=None, comm_plan=None, comm_gbps=None):
         self.model = model
         self.lr, self.clip, self.momentum = lr, clip, momentum
         self.weight_decay = weight_decay  # torch.optim.SGD(weight_decay=...) of train_search_bayes.py:391-392
         self.kl_scale = kl_scale
         self.rank, self.world = rank, world
         self.flat = FlatBuffers(model)
-        self.reducer = GradReducer(self.flat, bucket_bytes, overlap=overlap)
-        ops.set_grad_ready_hook(self.reducer.mark_ready if world > 1 else None)
+        if comm_cus is None:  # RCCL: one channel workgroup per channel (pin_rccl_channels); gloo moves bytes on the host
+            comm_cus = rccl_channels() if (world > 1 and dist.is_initialized() and dist.get_backend() == "nccl") else 0
+        self.reducer = GradReducer(self.flat, bucket_bytes, overlap=overlap, comm_cus=comm_cus if overlap else 0,
+                                   collective=collective, comm_plan=comm_plan or os.environ.get("BLM_COMM_PLAN", "window"),
+                                   comm_gbps=comm_gbps)
+        hooked = world > 1 or collective is not None
+        ops.set_grad_ready_hook(self.reducer.mark_ready if hooked else None)
         ops.set_embed_grad_sink(None)
-        if world > 1:
+        if hooked:
             self.reducer.hook_autograd()
             enc = getattr(getattr(model, "encoder", None), "weight", None)
             if late_rows and enc is not None and any(enc is p for p in self.flat.params) and dist.is_initialized():

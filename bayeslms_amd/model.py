@@ -176,12 +176,19 @@ class _ProjHolder(nn.Module):
     # inference only (scorer, evaluate()): with targets set, the DECODER returns the per-row NLL of its logits against them
     # instead of the logits themselves, which are never stored (ops.linear_nll)
     nll_targets = None
+    # inference only (two-model scoring): the DECODER hands back its input rows instead of logits -- the interpolated decoder +
+    # cross-entropy launch (ops.linear_nll_interp) takes both models' rows at once
+    return_input = False
 
     def forward(self, x, link=None):
         if self.rows is not None:
             if torch.is_grad_enabled():
                 raise BayesLMError("_ProjHolder.rows is an inference-only row selection")
             x = x.reshape(-1, x.shape[-1]).index_select(0, self.rows)
+        if self.return_input:
+            if torch.is_grad_enabled():
+                raise BayesLMError("_ProjHolder.return_input is an inference-only path")
+            return x
         if self.nll_targets is not None:
             if torch.is_grad_enabled():
                 raise BayesLMError("_ProjHolder.nll_targets is an inference-only path")

@@ -224,6 +224,24 @@ def set_gemm_mode(mode):
     check(lib().blm_set_gemm_mode(code), "blm_set_gemm_mode")
 
 
+def set_gemm_cus(n):
+    """Compute units the GEMM planner may count on (0: the whole chip).  engine.GradReducer narrows it while gradient buckets
+    are in flight: the collective's channel workgroups hold CUs beside the backward GEMMs (include/bayeslm.h
+    blm_gemm_plan_set_cus).  Host-side state of the planner: it affects launches enqueued AFTER the call."""
+    check(lib().blm_gemm_plan_set_cus(int(n)), "blm_gemm_plan_set_cus")
+
+
+def get_gemm_cus():
+    return int(lib().blm_gemm_plan_get_cus())
+
+
+def gemm_comm_window(us):
+    """A gradient bucket expected to spend ``us`` microseconds on the links has been launched (0: the exchange is over): the
+    GEMMs planned while the window is open run beside the collective's channel workgroups and take the plans measured
+    there (include/bayeslm.h blm_gemm_plan_comm_window)."""
+    check(lib().blm_gemm_plan_comm_window(float(us)), "blm_gemm_plan_comm_window")
+
+
 def get_gemm_mode():
     return ("f32", "bf16x3", "bf16x6")[int(lib().blm_get_gemm_mode())]
 
@@ -995,6 +1013,55 @@ def linear_nll(x, weight, bias, targets):
     ws = torch.empty(int(lib().blm_linear_nll_ws_floats(M, V)), device=x2.device, dtype=torch.float32)
     check(lib().blm_linear_nll(ptr(x2), x2.stride(0), ptr(weight), weight.stride(0), ptr(bias), ptr(tgt), ptr(nll), None, ptr(ws),
                                M, V, K, stream()), "blm_linear_nll")
+    return nll
+
+
+class InterpDecoder:
+    """The packed operands of a two-model scoring run (blm_linear_nll2): [W1 | W2] and alpha b1 + (1 - alpha) b2 are
+    built by the first call and kept for the following ones (same weights, same alpha: one scoring run)."""
+
+    def __init__(self, w1, b1, w2, b2, alpha):
+        self.w1, self.b1, self.w2, self.b2, self.alpha = _f32(w1, "w1"), b1, _f32(w2, "w2"), b2, float(alpha)
+        if self.w1.shape[0] != self.w2.shape[0]:
+            raise BayesLMError("interpolated decoders need one vocabulary: %d and %d rows" % (self.w1.shape[0], self.w2.shape[0]))
+        V, K1, K2 = self.w1.shape[0], self.w1.shape[1], self.w2.shape[1]
+        self.wcat = torch.empty(int(lib().blm_linear_nll2_wcat_floats(V, K1, K2)), device=self.w1.device, dtype=torch.float32)
+        self.packed = False
+
+
+def linear_nll_interp_supported(w1, b1, w2, b2):
+    """fp32 row-major decoders over ONE vocabulary (any size: the packed copy is padded) with feature counts that are multiples of 4."""
+    ok = lambda w, b: (w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous() and w.shape[1] % 4 == 0  # noqa: E731
+                       and w.data_ptr() % 16 == 0 and (b is None or (b.is_contiguous() and b.numel() == w.shape[0])))
+    return ok(w1, b1) and ok(w2, b2) and w1.shape[0] == w2.shape[0]
+
+
+def linear_nll_interp(x1, x2, dec, targets):
+    """Inference only: per-row NLL of the INTERPOLATED logits alpha (x1 W1^T + b1) + (1 - alpha) (x2 W2^T + b2)
+    (compute_sentence_scores_bayes_jianwei.py:157-168) from ONE decoder + cross-entropy launch over the packed operands
+    [alpha x1 | (1 - alpha) x2] . [W1 | W2]^T: neither model's (M, V) logits are stored.  ``dec``: InterpDecoder.  -> (M,) NLL"""
+    if torch.is_grad_enabled() and (x1.requires_grad or x2.requires_grad):
+        raise BayesLMError("linear_nll_interp is an inference-only path (no backward): call it under torch.no_grad()")
+    a = _f32(x1, "x1").reshape(-1, x1.shape[-1])
+    b = _f32(x2, "x2").reshape(-1, x2.shape[-1])
+    a = a if a.stride(-1) == 1 else a.contiguous()
+    b = b if b.stride(-1) == 1 else b.contiguous()
+    M, K1 = a.shape
+    K2 = b.shape[1]
+    V = dec.w1.shape[0]
+    if b.shape[0] != M or dec.w1.shape[1] != K1 or dec.w2.shape[1] != K2 or targets.numel() != M:
+        raise ValueError("linear_nll_interp: x1 (M, K1), x2 (M, K2), decoders (V, K1) / (V, K2) and M targets expected")
+    L.require_gfx950()
+    tgt = dev_tensor(targets.reshape(-1), "targets", torch.int64)
+    nll = torch.empty(M, device=a.device, dtype=torch.float32)
+    if M == 0:
+        return nll
+    ws = torch.empty(int(lib().blm_linear_nll2_ws_floats(M, V, K1, K2)), device=a.device, dtype=torch.float32)
+    check(lib().blm_linear_nll2(ptr(a), a.stride(0), ptr(dec.w1), dec.w1.stride(0), ptr(dec.b1), K1,
+                                ptr(b), b.stride(0), ptr(dec.w2), dec.w2.stride(0), ptr(dec.b2), K2, dec.alpha,
+                                ptr(tgt), ptr(nll), None, ptr(dec.wcat), 0 if dec.packed else 1, ptr(ws), M, V, stream()),
+          "blm_linear_nll2")
+    dec.packed = True
     return nll
 
 

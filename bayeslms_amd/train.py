@@ -220,6 +220,8 @@ def main(argv=None, history=None):
     device = torch.device("cuda", local)
     if world > 1:
         if args.dist_backend == "nccl":
+            from .engine import pin_rccl_channels
+            say("RCCL channels:", pin_rccl_channels())  # before RCCL reads its environment (engine.pin_rccl_channels)
             dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
         else:
             dist.init_process_group(args.dist_backend)

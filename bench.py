@@ -449,7 +449,25 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
     r["config"] = ("n-best rescoring with the configs[1] LSTM: %s, mean weights, hidden state carried across utterances "
                    "(compute_sentence_scores --batched)" % wl)
     res.append(r)
-    del m
+    # --interpolation_flag 1 (run_nnlm_ami_tm.sh:30-31,133-134; scorer :157-168): two LSTMs, logits interpolated 0.8 / 0.2 --
+    # both decoders + the cross entropy in ONE launch over packed operands (blm_linear_nll2), no logits stored
+    torch.manual_seed(2222)
+    m2 = M.RNNModel("LSTM", V, 1024, 1024, 2, DROPOUT, True).to(dev)
+
+    def hyp_rate2(model, model_2, mtype, fl):
+        css.compute_scores_batched(sub, model, vocab, mtype, dev, model_2, 0.8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        css.compute_scores_batched(nbest, model, vocab, mtype, dev, model_2, 0.8)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return {"value": round(n_utt * n_hyp / el, 1), "unit": "hypotheses/s", "tokens_per_s": round(ntok / el, 1),
+                "step_roofline": _frac(fl, ntok / el)}
+    r = hyp_rate2(m, m2, "LSTM", 2 * lstm_flops_per_token(V, train=False))
+    r["config"] = ("--interpolation_flag 1: %s, the configs[1] Bayesian LSTM interpolated with a standard 2x1024 LSTM "
+                   "(--inter_alpha 0.8), both decoders + cross entropy in one launch (blm_linear_nll2), state carried" % wl)
+    res.append(r)
+    del m, m2
     torch.cuda.empty_cache()
     # --- the reference recipe's own Transformer shape (run_nnlm_ami_tm.sh:22,98-99: --seq_len 100 --batch-size 32)
     torch.manual_seed(1111)
@@ -469,6 +487,13 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
     r["config"] = ("configs[4] n-best rescoring, Bayesian Transformer-FFN, %s, 8 Monte-Carlo weight samples "
                    "(score = -log mean_s exp(-NLL_s), oracle-checked)" % wl)
     res.append(r)
+    torch.manual_seed(2222)
+    m2 = M.TransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, "gelu", True).to(dev)
+    r = hyp_rate2(m, m2, "Transformer", 2 * tlm_flops_per_token(8, train=False))
+    r["config"] = ("--interpolation_flag 1 (run_nnlm_ami_tm.sh:30-31,133-134): %s, Bayesian Transformer-FFN interpolated with a "
+                   "standard Transformer (--inter_alpha 0.8), both decoders + cross entropy in one launch (blm_linear_nll2)" % wl)
+    res.append(r)
+    del m2
     del m
     torch.cuda.empty_cache()
     # --- configs[4] training leg: GP Transformer (--uncertainty Gaussian --T_gauss_pos 3), cfg3 shape
@@ -482,6 +507,19 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
     r = hyp_rate(m, "Transformer", 0, tlm_flops_per_token(8, train=False))
     r["config"] = ("configs[4] n-best rescoring, GP Transformer, %s, mean weights (the reference's inference: GPNN.sample is "
                    "never raised)" % wl)
+    res.append(r)
+    r = hyp_rate(m, "Transformer", 8, tlm_flops_per_token(8, train=False))
+    r["config"] = ("BASELINE.json configs[4] inference leg as written: GP Transformer (--T_gauss_pos 3), %s, 8 Monte-Carlo weight "
+                   "samples -- GPNN.sample raised for the call, coef / weights / bias re-drawn per sample (reference "
+                   "model.py:1871-1883), score = -log mean_s exp(-NLL_s), oracle-checked" % wl)
+    res.append(r)
+    for g in m.modules():  # the same training leg with the GP layer's tensors re-sampled every step (train --gp-sample 1)
+        if isinstance(g, M.GPNN):
+            g.sample = True
+    r, _ = _train_leg(m, TR.kl_selector(ns(uncertainty="Gaussian", T_gauss_pos=3)), T, B_PER_GPU, LR, steps, args.warmup, dev,
+                      engine, ops, flops_per_token=tlm_flops_per_token(T))
+    r["config"] = ("configs[4] training leg with GPNN.sample raised (--gp-sample 1; the reference's train.py leaves it False): "
+                   "GP Transformer LM --T_gauss_pos 3, coef / weights / bias = mean + exp(lgstd) eps every step, seq_len 128, batch 64")
     res.append(r)
     del m
     torch.cuda.empty_cache()
@@ -569,8 +607,11 @@ def main():
     local = local % max(ndev, 1)  # rehearsal of several ranks on one GPU (gloo); one GPU per rank otherwise
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rccl_env = None
     if world > 1:
         if args.backend == "nccl":
+            from bayeslms_amd.engine import pin_rccl_channels
+            rccl_env = pin_rccl_channels()  # before RCCL reads its environment: channel workgroups hold CUs beside the GEMMs
             dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
         else:
             dist.init_process_group(args.backend)
@@ -684,6 +725,9 @@ def main():
                 # the bucket that becomes ready last (layer 0's first parameters): the all-reduce nothing can hide
                 "last_bucket_mb": round((tr.reducer.buckets[-1][1] - tr.reducer.buckets[-1][0]) * 4 / 1e6, 2),
                 "grad_bytes": int(tr.flat.total * 4),
+                # RCCL channel count as pinned before init_process_group (engine.pin_rccl_channels) and the CUs the GEMM
+                # planner leaves to the channel workgroups while buckets are in flight
+                "rccl_env": rccl_env, "gemm_cus_under_comm": 256 - tr.reducer.comm_cus,
                 "late_rows": tr.reducer.late is not None,
                 "late_rows_last_step": None if tr.reducer.late is None else int(tr.reducer.late.U)},
         }

@@ -222,12 +222,24 @@ int blm_get_gemm_mode(void);
 /* Inference only: nll[m] = logsumexp_n(x[m,:] . w[n,:] + bias[n]) - (x[m,:] . w[tgt[m],:] + bias[tgt[m]]) without storing the
  * M x N logits -- the decoder product's epilogue keeps one (max, sum of exp) pair per row and column tile, a second small
  * kernel folds them (csrc/gemm_api.hip).  Replaces decoder + log_softmax + gather of train.py:452-455 (evaluate) and
- * compute_sentence_scores_bayes_jianwei.py:157-170 (one model; two-model interpolation mixes LOGITS and keeps the
- * materialised path, blm_ce_interp_fwd).  bias may be NULL; lse (optional) receives the log-sum-exp per row;
+ * compute_sentence_scores_bayes_jianwei.py:157-170 (one model; two models: blm_linear_nll2 below).  bias may be NULL; lse
+ * (optional) receives the log-sum-exp per row; a target outside [0, N) gives NaN for its row;
  * ws: blm_linear_nll_ws_floats(M, N) floats, 16-byte aligned, owned by the caller.  N % 4 == 0. */
 int64_t blm_linear_nll_ws_floats(int M, int N);
 int blm_linear_nll(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const int64_t* tgt,
                    float* nll, float* lse, float* ws, int M, int N, int K, void* stream);
+/* Two-model scoring, reference compute_sentence_scores_bayes_jianwei.py:157-168: per-row NLL of the INTERPOLATED logits
+ * alpha * (x1 w1^T + b1) + (1 - alpha) * (x2 w2^T + b2) against tgt, as ONE decoder + cross-entropy launch over the packed
+ * operands [alpha x1 | (1 - alpha) x2] (M x (K1 + K2)) and [w1 | w2] (N x (K1 + K2)): neither model's (M x N) logits are stored.
+ * wcat: blm_linear_nll2_wcat_floats(N, K1, K2) floats, caller-owned; pack_w != 0 (re)builds [w1 | w2] and the mixed bias in it
+ * (the first call of a scoring run; later calls with the same weights and alpha pass 0).  ws: blm_linear_nll2_ws_floats floats
+ * per call.  K1, K2 and all row strides multiples of 4, operands 16-byte aligned; any N (the packed vocabulary is padded to a
+ * multiple of 4 with zero rows whose bias is -inf); b1 / b2 may be NULL.  A target outside [0, N) gives NaN for its row. */
+int64_t blm_linear_nll2_wcat_floats(int N, int K1, int K2);
+int64_t blm_linear_nll2_ws_floats(int M, int N, int K1, int K2);
+int blm_linear_nll2(const float* x1, int64_t ldx1, const float* w1, int64_t ldw1, const float* b1, int K1,
+                    const float* x2, int64_t ldx2, const float* w2, int64_t ldw2, const float* b2, int K2, float alpha,
+                    const int64_t* tgt, float* nll, float* lse, float* wcat, int pack_w, float* ws, int M, int N, void* stream);
 
 /* Launch plan of a blm_gemm call: block tile (11 = 64x64, 12 = 64x128, 21 = 128x64, 22 = 128x128 rows x cols on four waves;
  * 28 = 128x128 on EIGHT waves: two waves per SIMD in one barrier domain, aligned operands and K % 32 == 0 only) and
@@ -241,7 +253,7 @@ int blm_linear_nll(const float* x, int64_t ldx, const float* w, int64_t ldw, con
 typedef struct blm_gemm_plan {
   int32_t tile;
   int32_t splits;   /* >= 1: K slices of every tile; <= -2: only the tail round's tiles are sliced, |splits| ways */
-  int32_t source;   /* 0 cost model, 1 plan table, 2 override */
+  int32_t source;   /* 0 cost model, 1 plan table, 2 override, 3 plan measured beside a collective (comm window open) */
   float model_us;   /* the cost model's estimate for this plan */
 } blm_gemm_plan;
 /* The plan blm_gemm would use for `a` (pointers are only inspected for alignment). */
@@ -255,6 +267,22 @@ int blm_gemm_plan_override(int tile, int splits);
  * keep_builtin == 0, switches the built-in table off as well (cost model only). */
 int blm_gemm_plan_set(int op, int M, int N, int K, int epilogue, int accumulate, int tile, int splits);
 int blm_gemm_plan_clear(int keep_builtin);
+/* Compute units the planner may count on: 0 = the whole chip (256, the default), or 8..256.  Data-parallel training narrows it
+ * while gradient buckets are in flight: RCCL's channel workgroups (256 threads, ~280 registers per lane, 19.7 KB LDS each on
+ * gfx950) hold CUs beside the backward GEMMs, and a plan that is exactly ONE round of 256 one-per-CU workgroups would spill a
+ * second round.  The plan table (measured on the whole chip) applies at 256 only; below it the cost model plans for `cus`.
+ * No reference counterpart (single GPU, run_nnlm_ami_tm.sh:44).  blm_gemm_plan_get_cus returns the current value. */
+int blm_gemm_plan_set_cus(int cus);
+int blm_gemm_plan_get_cus(void);
+/* "A gradient bucket is in flight": adds `us` microseconds (the bucket's expected time on the links) to the comm window; every
+ * blm_gemm planned while the window is open takes its own modelled time off it, so the window is kept in DEVICE time although
+ * the host enqueues far ahead.  Inside the window a launch uses the plan measured beside a resident collective stand-in where
+ * the table has one (csrc/gemm_plans_comm.inc, tools/gemm_tune_comm.py; blm_gemm_plan_query reports source 3), its usual plan
+ * otherwise.  us = 0 closes the window (engine.GradReducer.finish).  blm_gemm_plan_set_comm adds a run-time entry to that
+ * table (blm_gemm_plan_clear drops the run-time entries of both tables). */
+int blm_gemm_plan_comm_window(float us);
+float blm_gemm_plan_comm_window_left(void);
+int blm_gemm_plan_set_comm(int op, int M, int N, int K, int epilogue, int accumulate, int tile, int splits);
 
 /* --------------------------------------------------------------------------
  * Surrounding Transformer / LSTM ops (HBM-bound unless stated)

@@ -137,3 +137,63 @@ def test_cost_model_shape():
     assert plan(args(L.GEMM_TN, 512, 512, 8192, acc=True))[1] >= 8            # o_net weight gradient: 16 / 64 tiles need K slices
     assert plan(args(L.GEMM_NN, 2240, 1024, 33000))[1] >= 4                   # decoder input gradient at M = 2240
     lib.blm_gemm_plan_clear(1)
+
+
+def test_planner_counts_on_the_compute_units_it_is_given():
+    """blm_gemm_plan_set_cus(n): data-parallel training narrows the planner while gradient buckets are in flight (RCCL's
+    channel workgroups hold CUs beside the backward GEMMs).  The roofline launch -- NT 8192 x 512 x 4096 -- is exactly ONE
+    round of 256 one-per-CU eight-wave workgroups on the whole chip (table entry); with 8 CUs taken that plan would spill a
+    second round of 8 workgroups, so the planner must leave it: table off, cost model on 248 CUs, no one-per-CU tile."""
+    lib = L.lib()
+    a = args(L.GEMM_NT, 8192, 512, 4096)
+    assert lib.blm_gemm_plan_get_cus() == 256
+    t256, s256, src256, us256 = plan(a)
+    assert (t256, src256) == (28, 1)
+    try:
+        for cus in (248, 240, 224, 192):
+            L.check(lib.blm_gemm_plan_set_cus(cus), "set_cus")
+            assert lib.blm_gemm_plan_get_cus() == cus
+            t, s, src, us = plan(a)
+            assert src == 0, "the plan table was measured on the whole chip"
+            assert t != 28 or s > 1, "one workgroup per CU on every CU of the whole chip does not fit a narrowed one"
+            # the model prices the whole-chip plan on the narrowed chip as the two rounds it would be, and finds a plan whose
+            # cost stays near the lost share of the chip (equal workgroups quantise: 512 on 248 CUs means 3 on some)
+            us28 = C.c_float()
+            L.check(lib.blm_gemm_plan_model_us(C.byref(a), 28, 1, C.byref(us28)), "model_us")
+            assert us28.value > 1.3 * us, (cus, us28.value, us)
+            assert us < us256 * (256.0 / cus) * 1.2, (cus, us, us256)
+        L.check(lib.blm_gemm_plan_set_cus(0), "set_cus")
+        assert lib.blm_gemm_plan_get_cus() == 256 and plan(a)[:3] == (t256, s256, src256)
+        assert lib.blm_gemm_plan_set_cus(7) != 0 and lib.blm_gemm_plan_set_cus(257) != 0
+        assert lib.blm_gemm_plan_get_cus() == 256
+    finally:
+        lib.blm_gemm_plan_set_cus(0)
+
+
+def test_tail_sliced_plans_count_their_rounds_with_the_narrowed_chip():
+    """A tail plan slices only the tiles beyond the last WHOLE round of workgroup slots; the number of slots follows the CUs
+    the plan was made for (Plan.cus travels to the launcher), so every plan stays legal on a narrowed chip."""
+    lib = L.lib()
+    try:
+        for cus in (256, 248, 200):
+            L.check(lib.blm_gemm_plan_set_cus(cus), "set_cus")
+            for (op, m, n, k, epi, acc, tile, splits) in table_entries():
+                t, s, src, us = plan(args(op, m, n, k, epi, bool(acc)))
+                assert t in (11, 12, 21, 22, 28) and (1 <= s <= 16 or -32 <= s <= -2) and us > 0
+                assert src == (1 if cus == 256 else 0)
+    finally:
+        lib.blm_gemm_plan_set_cus(0)
+
+
+def test_plans_are_memoised_per_cu_count_and_invalidated_by_table_changes():
+    lib = L.lib()
+    a = args(L.GEMM_NT, 1234, 520, 768)
+    base = plan(a)[:2]
+    L.check(lib.blm_gemm_plan_set(L.GEMM_NT, 1234, 520, 768, L.EPI_NONE, 0, 11, 2), "set")
+    assert plan(a)[:3] == (11, 2, 1)  # a cached model plan must not survive a new table entry
+    lib.blm_gemm_plan_clear(1)
+    assert plan(a)[:2] == base
+    L.check(lib.blm_gemm_plan_override(12, 0), "override")
+    assert plan(a)[0] == 12
+    lib.blm_gemm_plan_override(0, 0)
+    assert plan(a)[:2] == base

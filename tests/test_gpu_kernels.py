@@ -260,6 +260,53 @@ def test_linear_nll_equals_log_softmax_of_the_materialised_logits(dev, M, V, K, 
         ops.linear_nll(x.clone().requires_grad_(True), w, b, tgt)
 
 
+@pytest.mark.parametrize("M,V,K1,K2,alpha", [(2560, 33000, 1024, 512, 0.8), (300, 33000, 512, 512, 0.5), (77, 1000, 12, 16, 0.8),
+                                             (5, 52, 12, 16, 0.3), (129, 260, 64, 32, 1.0), (64, 4096, 32, 64, 0.0), (40, 30, 16, 12, 0.7),
+                                             (200, 33001, 32, 64, 0.6)])
+def test_linear_nll_interp_equals_log_softmax_of_the_interpolated_logits(dev, M, V, K1, K2, alpha):
+    """blm_linear_nll2 (reference scorer :157-168): alpha (x1 W1^T + b1) + (1 - alpha) (x2 W2^T + b2) as ONE decoder +
+    cross-entropy launch over the packed operands, against log_softmax + gather of the fp64 interpolated logits and against the
+    materialised two-matrix kernel (blm_ce_interp_fwd); the packed weights are reused by a second call."""
+    ops = ops_mod()
+    g = torch.Generator(device=dev).manual_seed(M + V + K1)
+    x1, x2 = torch.randn(M, K1, device=dev, generator=g), torch.randn(M, K2, device=dev, generator=g)
+    w1 = torch.randn(V, K1, device=dev, generator=g) * (4.0 / K1 ** 0.5)
+    w2 = torch.randn(V, K2, device=dev, generator=g) * (4.0 / K2 ** 0.5)
+    b1, b2 = torch.randn(V, device=dev, generator=g), torch.randn(V, device=dev, generator=g)
+    tgt = torch.randint(0, V, (M,), device=dev, generator=g)
+    tgt[0], tgt[-1] = V - 1, 0
+    l1 = x1.double() @ w1.double().t() + b1.double()
+    l2 = x2.double() @ w2.double().t() + b2.double()
+    want = -(torch.log_softmax(alpha * l1 + (1 - alpha) * l2, 1).gather(1, tgt.view(-1, 1)).squeeze(1))
+    assert ops.linear_nll_interp_supported(w1, b1, w2, b2)
+    dec = ops.InterpDecoder(w1, b1, w2, b2, alpha)
+    with torch.no_grad():
+        got = ops.linear_nll_interp(x1, x2, dec, tgt)
+        assert dec.packed
+        again = ops.linear_nll_interp(x1, x2, dec, tgt)  # [W1 | W2] and the mixed bias are reused
+        _, mat = ops.cross_entropy_interp(ops.linear(x1, w1, b1), ops.linear(x2, w2, b2), alpha, tgt)
+    tol = 2e-5 * max(1.0, float(want.abs().max()))
+    assert float((got.double() - want).abs().max()) < tol
+    assert torch.equal(got, again)
+    assert float((mat.double() - want).abs().max()) < tol
+    with pytest.raises(Exception, match="inference-only"):
+        ops.linear_nll_interp(x1.clone().requires_grad_(True), x2, dec, tgt)
+
+
+def test_linear_nll_out_of_range_target_is_nan_not_garbage(dev):
+    """A target outside [0, V) (a padding id, -1) used to leave its logit slot uninitialised: the row's NLL is NaN."""
+    ops = ops_mod()
+    g = torch.Generator(device=dev).manual_seed(7)
+    x, w = torch.randn(9, 16, device=dev, generator=g), torch.randn(64, 16, device=dev, generator=g)
+    tgt = torch.randint(0, 64, (9,), device=dev, generator=g)
+    tgt[2], tgt[5] = -1, 64
+    with torch.no_grad():
+        torch.full((1 << 16,), 3.25, device=dev)  # whatever the allocator hands out next is not zeros
+        nll = ops.linear_nll(x, w, None, tgt)
+    bad = torch.isnan(nll).cpu()
+    assert bad.tolist() == [i in (2, 5) for i in range(9)]
+
+
 def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric B catches a transposed C write (cdna guide section 3)."""
     ops, lib = ops_mod(), L()

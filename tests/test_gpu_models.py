@@ -537,9 +537,10 @@ def test_mc_samples_refused_when_nothing_is_sampled(dev, kind):
 
 
 @pytest.mark.parametrize("tag", ["tlm_ffn_interp", "lstm_bayes3_interp"])
-def test_scorer_cli_interpolation_matches_reference(dev, tag, tmp_path):
-    """--interpolation_flag 1: two models, logits mixed inside the CE kernel (blm_ce_interp_fwd); scores of
-    the reference's compute_scores on the same two checkpoints."""
+def test_scorer_cli_interpolation_matches_reference(dev, tag, tmp_path, monkeypatch):
+    """--interpolation_flag 1: two models; the batched scorer takes both decoders in ONE launch over packed operands
+    (blm_linear_nll2, no logits stored), the per-hypothesis loop mixes the materialised logits inside the CE kernel
+    (blm_ce_interp_fwd); scores of the reference's compute_scores on the same two checkpoints."""
     import os
     from bayeslms_amd import compute_sentence_scores as S
     from oracle import bayes_oracle as O
@@ -556,12 +557,20 @@ def test_scorer_cli_interpolation_matches_reference(dev, tag, tmp_path):
             os.path.join(d, "words.txt"), "--model-path", os.path.join(d, "model.pt"), "--inter_path",
             os.path.join(d, "model2.pt")] + [str(a) for a in g["argv"]]
     want = [ln.split() for ln in str(g["scores_txt"]).splitlines()]
+    from bayeslms_amd import ops
+    calls = {"fused": 0, "materialised": 0}
+    real_f, real_m = ops.linear_nll_interp, ops.cross_entropy_interp
+    monkeypatch.setattr(ops, "linear_nll_interp", lambda *a, **k: (calls.__setitem__("fused", calls["fused"] + 1), real_f(*a, **k))[1])
+    monkeypatch.setattr(ops, "cross_entropy_interp", lambda *a, **k: (calls.__setitem__("materialised", calls["materialised"] + 1), real_m(*a, **k))[1])
     for batched in ("1", "0"):
         S.main(argv + ["--batched", batched])
         got = [ln.split() for ln in open(os.path.join(d, "out.txt")).read().splitlines()]
         assert [a[0] for a in got] == [b[0] for b in want]
         for a, b in zip(got, want):
             assert abs(float(a[1]) - float(b[1])) <= 1e-3 * max(1.0, abs(float(b[1]))), (batched, a, b)
+        if batched == "1":  # the batched scorer: ONE decoder + cross-entropy launch per batch, no logits of either model
+            assert calls["fused"] > 0 and calls["materialised"] == 0, calls
+    assert calls["materialised"] > 0  # --batched 0 = the reference's per-hypothesis loop keeps the two-matrix kernel
 
 
 @pytest.mark.parametrize("margs", [

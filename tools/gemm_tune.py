@@ -32,6 +32,7 @@ TILES = (11, 12, 21, 22, 28)  # 28 = 128x128 on eight waves
 SPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
 TAIL_SPLITS = (-2, -4, -8, -16, -32)  # only the tiles beyond the last whole round of workgroup slots are sliced (in-situ search only)
 V33, V10 = 33000, 10000
+TRAINER_KW = {}  # tools/gemm_tune_comm.py: collective= stand-in for RCCL's channel workgroups beside the backward GEMMs
 
 
 def override(tile, splits):
@@ -121,7 +122,7 @@ def build(name, dev):
                     out = m(d)
                 ops.cross_entropy(out.view(-1, out.shape[-1]), t)
         return step, T * B
-    tr = engine.Trainer(m, lr=lr, clip=1.0, kl_scale=float(T) / data.size(0), seed=1111)
+    tr = engine.Trainer(m, lr=lr, clip=1.0, kl_scale=float(T) / data.size(0), seed=1111, **TRAINER_KW)
 
     def step():
         d, t = get_batch(data, (st["i"] % nwin) * T, T)
