@@ -317,6 +317,41 @@ def cli_leg(dev, args, headline_ms):
             "valid_loss": round(hist["valid_loss"][-1], 4)}
 
 
+def level1_leg(dev, args, headline_ms):
+    """INTEGRATION.md level 1 priced: the headline model under the REFERENCE's loop shape (train.py:306-438) -- only `import model`
+    swapped: torch's nn.CrossEntropyLoss on the (8192 x 33000) logits, optimizer.zero_grad() (gradients to None: the in-place
+    weight-gradient kernels re-create their zeroed buffers every step), model...kl_divergence() added to the loss and
+    back-propagated by autograd, torch.nn.utils.clip_grad_norm_, torch.optim.SGD(momentum 0.9) -- beside engine.Trainer."""
+    import torch.nn as nn
+    from bayeslms_amd import model as M
+    from bayeslms_amd.data import batchify, get_batch, synthetic_corpus
+    torch.manual_seed(1111)
+    m = M.BayesTransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, True, "FFN").to(dev)
+    Bc, steps, warm = B_PER_GPU, max(args.steps, 10), max(args.warmup, 5)
+    train = batchify(synthetic_corpus(V, Bc * ((steps + warm) * T + 1) + 17, seed=1111), Bc, dev)
+    crit = nn.CrossEntropyLoss()
+    opt = torch.optim.SGD(m.parameters(), lr=LR, momentum=0.9, weight_decay=0)
+    m.train()
+    for i in range(steps + warm):
+        if i == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        data, tgt = get_batch(train, i * T, T)
+        m.set_step(i)  # new noise / dropout streams per step (the one line a maintainer adds; without it every step reuses step 0's)
+        opt.zero_grad()
+        out = m(data)
+        loss = crit(out.view(-1, V), tgt) + m.transformerlayers[0].linear2.kl_divergence() / len(train) * T
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), CLIP)
+        opt.step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    return {"config": "INTEGRATION.md level 1: `from bayeslms_amd.model import *` under the reference's own loop (torch CrossEntropyLoss, "
+                      "zero_grad(), clip_grad_norm_, optim.SGD), headline configuration",
+            "value": round(T * Bc / ms * 1e3, 1), "unit": "tokens/s", "ms_per_step": round(ms, 3), "loss_finite": bool(torch.isfinite(loss)),
+            "vs_engine_trainer_step": round(ms / headline_ms, 4), "step_roofline": _frac(tlm_flops_per_token(T), T * Bc / ms * 1e3)}
+
+
 def search_leg(kind, dev, steps=8, warm=3):
     """Architecture-search window (Architect.step on a validation window + network step) at the
     reference's full sizes, under this run's clock (tools/bench_search.py is the stand-alone form)."""
@@ -524,7 +559,8 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
     del m
     torch.cuda.empty_cache()
     # --- the CLI itself, and the architecture search
-    for name, fn in (("cli", lambda: cli_leg(dev, args, headline_ms)), ("search_tlm", lambda: search_leg("tlm", dev)),
+    for name, fn in (("cli", lambda: cli_leg(dev, args, headline_ms)), ("level1", lambda: level1_leg(dev, args, headline_ms)),
+                     ("search_tlm", lambda: search_leg("tlm", dev)),
                      ("search_lstm", lambda: search_leg("lstm", dev))):
         try:
             res.append(fn())

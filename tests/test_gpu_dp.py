@@ -55,24 +55,27 @@ def _kl(model):
 _kl.fusable = True
 
 
-def _run(rank, world, port, ret, family="tlm_ffn"):
+def _run(rank, world, port, ret, family="tlm_ffn", T=12):
     import torch.distributed as dist
-    from bayeslms_amd import data as D, engine
+    from bayeslms_amd import data as D, engine, ops
     from bayeslms_amd.model import repackage_hidden
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    stream = torch.randint(0, 150, (8 * 61,), generator=torch.Generator().manual_seed(1))
+    stream = torch.randint(0, 150, (8 * (4 * T + 13),), generator=torch.Generator().manual_seed(1))
     train = D.batchify(stream, 8, dev, rank, world)
     m, kl_fn, is_rnn = _build(dev, family)
+    stack2 = []
+    real_stack2 = ops.lstm_stack2
+    ops.lstm_stack2 = lambda *a, **k: (stack2.append(1), real_stack2(*a, **k))[1]
     tr = engine.Trainer(m, lr=0.2, clip=0.5, kl_scale=0.01, seed=1111, rank=rank, world=world, bucket_bytes=8192)
     if world > 1:
         assert tr.reducer.late is not None and len(tr.reducer.buckets) > 2
     losses = []
     hidden = m.init_hidden(train.shape[1]) if is_rnn else None
     for i in range(4):
-        data, tgt = D.get_batch(train, i * 12, 12)
+        data, tgt = D.get_batch(train, i * T, T)
         loss, kl, hidden = tr.step(data, tgt, hidden=hidden, kl_fn=kl_fn)
         if hidden is not None:
             hidden = repackage_hidden(hidden)
@@ -83,6 +86,7 @@ def _run(rank, world, port, ret, family="tlm_ffn"):
         assert not silent, silent
         assert tr.reducer.late.U > 0
     ret[(world, rank)] = (losses, tr.flat.flat_param.detach().cpu().clone())
+    ret[("stack2", world, rank)] = len(stack2)
     if world > 1:
         dist.destroy_process_group()
 
@@ -104,9 +108,29 @@ def test_two_ranks_equal_one_rank_on_the_global_batch(family):
     assert err < 1e-4, err
 
 
-def _spawn(world, ret, family="tlm_ffn"):
+def _spawn(world, ret, family="tlm_ffn", T=12):
     port = _free_port()
-    mp.spawn(_run, args=(world, port, ret, family), nprocs=world, join=True)
+    mp.spawn(_run, args=(world, port, ret, family, T), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("family", ["rnn_none", "rnn_bayes3"])
+def test_two_ranks_equal_one_rank_with_the_layer_wavefront(family):
+    """What a data-parallel LSTM run at the recipes' shape executes: <= 32 columns per rank and T >= 32 put
+    the two layers on the two-stream wavefront (ops.lstm_stack2) while the reducer's hooks, its communication stream and
+    the bucket overlap (8 KB buckets) are active -- two ranks == one rank on the global batch, replicas bit-identical."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        _spawn(1, ret, family, 36)
+        _spawn(2, ret, family, 36)
+        l1, p1 = ret[(1, 0)]
+        l2a, p2a = ret[(2, 0)]
+        l2b, p2b = ret[(2, 1)]
+        assert ret[("stack2", 1, 0)] == 4 and ret[("stack2", 2, 0)] == 4 and ret[("stack2", 2, 1)] == 4  # every step took it
+    assert torch.equal(p2a, p2b)
+    for a, b, c in zip(l1, l2a, l2b):
+        assert abs(a - 0.5 * (b + c)) < 2e-4 * abs(a)
+    err = float((p1 - p2a).abs().max() / p1.abs().max())
+    assert err < 1e-4, err
 
 
 def _rccl_one_rank(port, ret):

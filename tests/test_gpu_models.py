@@ -1165,6 +1165,55 @@ def test_cfg2_full_size_matches_oracle_on_a_column_subset(dev):
     assert rel(hid[0][:, :C], hr[0]) < 1e-4 and rel(hid[1][:, :C], hr[1]) < 1e-4
 
 
+def test_cfg1_full_size_matches_oracle(dev):
+    """BASELINE configs[0] at its real size (RNNModel 2x1024, V 10000, T 35, B 20): at this shape the product runs the two
+    layers as a wavefront on two streams (ops.lstm_stack2: B <= 32 and T >= 32), which at production width was only ever
+    compared with the sequential path.  Against the CPU oracle: eval logits + carried state over two windows on the first 3
+    columns, and -- dropout off -- the training loss and EVERY parameter gradient of the full 20-column batch."""
+    from bayeslms_amd import model as M, ops
+    from oracle import bayes_oracle as O
+    torch.manual_seed(1111)
+    V, H, T, B, C = 10000, 1024, 35, 20, 3
+    m = M.RNNModel("LSTM", V, H, H, 2, 0.0, True).to(dev)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(12)
+    x1, x2 = torch.randint(0, V, (T, B), generator=g), torch.randint(0, V, (T, B), generator=g)
+    tgt = torch.randint(0, V, (T * B,), generator=g)
+    calls = []
+    real = ops.lstm_stack2
+    ops.lstm_stack2 = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        m.eval()
+        with torch.no_grad():
+            hid = m.init_hidden(B)
+            l1, hid = m(x1.to(dev), hid)
+            l2, hid = m(x2.to(dev), hid)
+            z = (torch.zeros(2, C, H), torch.zeros(2, C, H))
+            r1, hr = O.rnn_lm(x1[:, :C], z, sd)
+            r2, hr = O.rnn_lm(x2[:, :C], hr, sd)
+        assert len(calls) == 2, "the wavefront path must be the one under test at this shape"
+        assert rel(l1[:, :C], r1) < 1e-4 and rel(l2[:, :C], r2) < 1e-4
+        assert rel(hid[0][:, :C], hr[0]) < 1e-4 and rel(hid[1][:, :C], hr[1]) < 1e-4
+        m.train()
+        h0 = tuple(h.detach() for h in hid)
+        logits, _ = m(x2.to(dev), h0)
+        assert len(calls) == 3
+        loss, _ = ops.cross_entropy(logits.view(-1, V), tgt.to(dev))
+        loss.backward()
+    finally:
+        ops.lstm_stack2 = real
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    rl, _ = O.rnn_lm(x2, tuple(h.cpu() for h in h0), leaf)
+    rloss = O.cross_entropy_mean(rl.view(-1, V), tgt)
+    assert abs(float(loss) - float(rloss)) < 1e-4 * abs(float(rloss))
+    rloss.backward()
+    for k, p in m.named_parameters():
+        if k == "decoder.weight":
+            continue
+        assert grad_close(p.grad, leaf[k].grad), k
+
+
 def test_cfg3_full_model_backward_matches_oracle(dev):
     """The cfg3 model at its real width/depth/vocabulary (B = 8 columns, T = 128 keep the CPU side at a few
     seconds): train-mode loss with the sampled FFN weight (eps injected, dropout off) plus the KL term,
