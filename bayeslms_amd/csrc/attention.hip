@@ -407,10 +407,8 @@ int blm_attn_bwd_mfma(const float* q, const float* k, const float* v, int64_t ld
                       const float* lse, float* dq, float* dk, float* dv, int64_t ldd, int T, int B, int nhead,
                       float pdrop, const blm_rng* rng, int col_offset, float* ws, hipStream_t st);
 int64_t blm_attn_bwd_mfma_ws_floats(int T, int B, int nhead);
-static bool use_mfma(int head_dim) {
-  static int off = -1;
-  if (off < 0) { const char* e = getenv("BLM_ATTN_VALU"); off = (e && atoi(e)) ? 1 : 0; }
-  return head_dim == 64 && !off;
+static bool use_mfma(int head_dim) {  // option "attn_valu" = 1: the vector-ALU kernels at head_dim 64 too (cross-check of the MFMA ones)
+  return head_dim == 64 && !blm::option(blm::OPT_ATTN_VALU);
 }
 
 #define DISPATCH_HD(KERN, LDS)                                                                                   \

@@ -452,27 +452,6 @@ __device__ __forceinline__ void dq_from_ds(const AttnM& p, const float* Ks, cons
   if (q < p.T) store_t(p.dq + ((long)q * p.B + b) * p.ldd + off, dqt, lh, p.scale);
 }
 
-template <int HPW>
-__global__ __launch_bounds__(256 * HPW) void attn_bwd_dq_ds_kernel(const AttnM p) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int hsel = threadIdx.x >> 8, tid = threadIdx.x & 255;
-  const int bhid = blockIdx.x * HPW + hsel;
-  float* Ks = sm + hsel * AT * LS;
-  const int b = bhid / p.nhead, head = bhid % p.nhead, off = head * HD;
-  const int T = p.T, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  const int ntile = (T + 31) >> 5;
-  const int qt = hsel ? wave : 3 - wave;
-  float4 dsr[4][4];
-  {
-    float4 kk[8];
-    fetch_rows<256>(kk, p.k, p.ld, T, p.B, b, off, tid);
-    load_ds_rows(p, dsr, bhid, qt, ntile, li, lh);
-    put_rows<256>(Ks, kk, T, 1.f, tid);
-  }
-  __syncthreads();
-  if (qt < ntile) dq_from_ds(p, Ks, dsr, qt, b, off, li, lh);
-}
-
 // ------------------------------------------------------------------ backward: dK, dV (lane = key)
 __device__ __forceinline__ void attn_dkv_pass(const AttnM& p, const float* Qs, const float* Os, const float* lse_s,
                                               const float* del_s, int kt, int ntile, const float (&kreg)[32],
@@ -839,18 +818,10 @@ using namespace blm;
 // Heads per workgroup of the T <= 128 kernels.  Two heads (8 waves, balanced causal tiles per SIMD, see the forward) as long
 // as that still leaves one workgroup per CU; below -- the recipes' batch 32 (256 heads), evaluation at batch 20 -- one head per
 // workgroup, so that the launch covers twice the CUs (recipe Transformer step 9.23 -> 9.12 ms, evaluation 2.03 -> 2.00 ms;
-// at 512 heads both forms tie).  BLM_ATTN_HPW=1|2 forces one form (A/B measurements).
-static bool attn_short() {  // BLM_ATTN_SHORT=0: the 128-row forward also for T <= 32 (A/B measurements)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("BLM_ATTN_SHORT"); v = (e && atoi(e) == 0) ? 0 : 1; }
-  return v != 0;
-}
+// at 512 heads both forms tie).  Option "attn_hpw" = 1 | 2 forces one form (blm_set_option; both are parity-tested).
+static bool attn_short() { return blm::option(blm::OPT_ATTN_SHORT) != 0; }  // "attn_short" = 0: the 128-row forward also for T <= 32
 static int attn_hpw(int heads) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("BLM_ATTN_HPW");
-    v = e ? atoi(e) : 0;
-  }
+  const int v = blm::option(blm::OPT_ATTN_HPW);  // "attn_hpw" = 1 | 2 forces one form
   if (v == 1 || v == 2) return v;
   return heads / 2 >= 256 ? 2 : 1;
 }
@@ -941,10 +912,6 @@ int blm_attn_bwd_mfma(const float* q, const float* k, const float* v, int64_t ld
     if (rc) return rc;
     rc = set_lds(attn_bwd_dkv_long_kernel, lds2);
     if (rc) return rc;
-    rc = set_lds(attn_bwd_dq_ds_kernel<1>, lds1 / 2);
-    if (rc) return rc;
-    rc = set_lds(attn_bwd_dq_ds_kernel<2>, lds1);
-    if (rc) return rc;
     rc = set_lds(attn_bwd_dkv_mfma_kernel<1, true>, lds2);
     if (rc) return rc;
     rc = set_lds(attn_bwd_dkv_mfma_kernel<2, true>, 2 * lds2);
@@ -960,20 +927,9 @@ int blm_attn_bwd_mfma(const float* q, const float* k, const float* v, int64_t ld
     return BLM_OK;
   }
   const bool two = (B * nhead) % 2 == 0 && attn_hpw(B * nhead) == 2;
-  static int fuse = -1;  // BLM_ATTN_FUSE_DQ=0: dQ = dS K as a separate launch (A/B measurements)
-  if (fuse < 0) { const char* e = getenv("BLM_ATTN_FUSE_DQ"); fuse = e ? atoi(e) : 1; }
-  if (p.ds && fuse) {  // ONE launch: dK/dV, dS through the workspace, dQ = dS K by the same workgroup
+  if (p.ds) {  // ONE launch: dK/dV, dS through the workspace, dQ = dS K by the same workgroup
     if (two) hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<2, true>), dim3(B * nhead / 2), dim3(512), 2 * lds2, st, p);
     else hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<1, true>), dim3(B * nhead), dim3(256), lds2, st, p);
-    BLM_HIP(hipGetLastError());
-    return BLM_OK;
-  }
-  if (p.ds) {  // dK/dV first (it leaves dS in the workspace), then dQ = dS K
-    if (two) hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<2>, dim3(B * nhead / 2), dim3(512), 2 * lds2, st, p);
-    else hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<1>, dim3(B * nhead), dim3(256), lds2, st, p);
-    BLM_HIP(hipGetLastError());
-    if (two) hipLaunchKernelGGL(attn_bwd_dq_ds_kernel<2>, dim3(B * nhead / 2), dim3(512), lds1, st, p);
-    else hipLaunchKernelGGL(attn_bwd_dq_ds_kernel<1>, dim3(B * nhead), dim3(256), lds1 / 2, st, p);
     BLM_HIP(hipGetLastError());
     return BLM_OK;
   }

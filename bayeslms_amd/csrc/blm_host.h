@@ -11,3 +11,11 @@ int blm_fail(int status, const char* fmt, ...);
     hipError_t e_ = (expr);                                                                  \
     if (e_ != hipSuccess) return blm_fail(BLM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
+
+// Kernel-selection options (blm_set_option / blm_get_option, include/bayeslm.h): every switch that picks between two BUILT
+// forms of a kernel lives here -- one registry, settable at run time (so the GPU tests run both forms in one process), each
+// initialised from its BLM_* environment variable on first use.  INTEGRATION.md lists them with the test that covers each.
+namespace blm {
+enum Opt { OPT_ATTN_HPW = 0, OPT_ATTN_SHORT, OPT_ATTN_VALU, OPT_LSTM_GEMV, OPT_LSTM_PIPE, OPT_LSTM_TAIL, OPT_COUNT };
+int option(Opt o);
+}  // namespace blm

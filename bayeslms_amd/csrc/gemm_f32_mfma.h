@@ -1334,11 +1334,10 @@ static int launch_cfg(const GemmP& p, hipStream_t st) {
   q.atomic = splits > 1;
   const long nblocks = q.tail_from + (nb - q.tail_from) * (long)splits;
   {
-    static int off = -1, row_plain = -1;  // BLM_GEMM_ROW_EPI=0: register-layout epilogue everywhere; =1: rows only for the GELU epilogues (A/B knobs; default: rows for all four)
-    if (off < 0) { const char* e = getenv("BLM_GEMM_ROW_EPI"); off = (e && atoi(e) == 0) ? 1 : 0; row_plain = (e && atoi(e) == 1) ? 0 : 1; }
+    // row-wise epilogue through LDS for aligned, unsliced launches; the register-layout epilogue for atomics and odd alignments
     const bool al = ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.aux) | reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.C2)) & 15) == 0;
-    q.vec_epi = !off && (!q.atomic || q.tail_from > 0) && al && p.N % 4 == 0 && p.ldc % 4 == 0 &&
-                (((p.epi == BLM_EPI_NONE || p.epi == BLM_EPI_BIAS) && row_plain) || p.epi == BLM_EPI_BIAS_GELU || p.epi == BLM_EPI_MUL_DGELU ||
+    q.vec_epi = (!q.atomic || q.tail_from > 0) && al && p.N % 4 == 0 && p.ldc % 4 == 0 &&
+                (p.epi == BLM_EPI_NONE || p.epi == BLM_EPI_BIAS || p.epi == BLM_EPI_BIAS_GELU || p.epi == BLM_EPI_MUL_DGELU ||
                  p.epi == BLM_EPI_GP_MIX || p.epi == BLM_EPI_MUL_DGP_MIX || p.epi == BLM_EPI_CE_PART);
     if (p.epi == BLM_EPI_CE_PART && !q.vec_epi) return blm_fail(BLM_ERR_UNSUPPORTED, "blm_linear_nll: needs N % 4 == 0 and 16-byte aligned bias / workspace");
   }

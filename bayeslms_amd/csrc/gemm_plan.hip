@@ -171,19 +171,8 @@ Plan model_plan(const PlanKey& k) {
       }
       if (us < bt) { bt = us; best.tile = t.tile; best.splits = S; }
     }
-    // tail slicing: only where whole rounds exist and leave a remainder.  The sweep the constants were fitted to has no tail
-    // plans, so the model proposes them only on request (BLM_GEMM_MODEL_TAIL=1); the plan table carries the measured ones.
-    static int model_tail = -1;
-    if (model_tail < 0) { const char* e = getenv("BLM_GEMM_MODEL_TAIL"); model_tail = (e && atoi(e) == 1) ? 1 : 0; }
-    if (!model_tail) continue;
-    const long BM = 64 * t.wtm, BN = 64 * t.wtn;
-    const long tiles = ((k.M + BM - 1) / BM) * ((k.N + BN - 1) / BN), slots = (long)g_cus * t.occ;
-    if (k.can_split && tiles > slots && tiles % slots != 0)
-      for (int S : {2, 4, 8, 16, 32}) {
-        if (k.K / S < 128 || (tiles % slots) * S > slots) break;
-        const double us = model_us(k, t, -S) * (1.0 + 0.0002 * S);
-        if (us < bt) { bt = us; best.tile = t.tile; best.splits = -S; }
-      }
+    // (tail-sliced plans -- only the tiles beyond the last whole round are cut -- are scored by model_us but not proposed here:
+    // the sweep the constants were fitted to has none; the plan table carries the measured ones)
   }
   return best;
 }
@@ -252,8 +241,6 @@ int plan_cus() {
 Plan choose_plan(const PlanKey& k) {
   std::lock_guard<std::mutex> lk(g_mu);
   read_env();
-  static int model_only = -1;  // BLM_GEMM_PLAN=model: the cost model alone (plan table off), for A/B runs
-  if (model_only < 0) { const char* e = getenv("BLM_GEMM_PLAN"); model_only = (e && !strcmp(e, "model")) ? 1 : 0; }
   const bool under_comm = g_window_us > 0.0 && g_cus == kChipCUs;
   auto& memo = g_memo[under_comm ? -1 : g_cus];
   auto hit = memo.find(k);
@@ -263,7 +250,7 @@ Plan choose_plan(const PlanKey& k) {
   }
   Plan p{11, 1, 0, g_cus, 0.f};
   // table entries were measured on the whole chip: they apply there only
-  const Entry* e = (model_only || g_cus != kChipCUs) ? nullptr : find(k);
+  const Entry* e = g_cus != kChipCUs ? nullptr : find(k);  // blm_gemm_plan_clear(0) switches the table off (cost model only)
   if (e) { p.tile = e->tile; p.splits = e->splits; p.source = 1; }
   else { p = model_plan(k); p.cus = g_cus; }
   // beside a collective: the plan measured there, where one exists (everything else keeps its whole-chip plan -- in situ the

@@ -410,13 +410,6 @@ template <int RING, int NS = 4, bool REFILL = true, int NW = 4, bool PIPE = fals
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 1 : 2, PIPE ? 1 : 2))) void lstm_step_fwd_kernel(const LstmStepP p) {
   lstm_step_fwd_body<RING, NS, REFILL, NW, PIPE, TAIL>(p);
 }
-// One step of TWO independent recurrences per launch (blockIdx.z picks the one): at B <= 32 a step is 128 workgroups, half the
-// chip, so layer 1's step over chunk c and layer 2's over chunk c - 1 fill it together -- what the two-stream wavefront
-// (ops.lstm_stack2) overlaps with events and a second queue, from one queue and with half the launches.
-template <int RING, int NS = 4, bool REFILL = true, int NW = 4, bool PIPE = false, bool TAIL = true>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 1 : 2, PIPE ? 1 : 2))) void lstm_step_fwd_pair_kernel(const LstmStepP p0, const LstmStepP p1) {
-  lstm_step_fwd_body<RING, NS, REFILL, NW, PIPE, TAIL>(blockIdx.z ? p1 : p0);
-}
 
 // ------------------------------------------------------------------ forward step, tiny batches (B <= 4)
 // The n-best scorer walks its carry chain as ONE long B = 1 sequence (compute_sentence_scores.py, reference :271-274):
@@ -872,41 +865,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 using namespace blm;
 
-static int lstm_gemv() {  // BLM_LSTM_GEMV=0 disables the tiny-batch step kernel (A/B measurements)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("BLM_LSTM_GEMV");
-    v = e ? atoi(e) : 1;
-  }
-  return v;
-}
-
-static int lstm_pipe() {  // BLM_LSTM_PIPE=0|1: software-pipelined K loop of the step kernels (A/B measurements)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("BLM_LSTM_PIPE");
-    v = e ? atoi(e) : 1;
-  }
-  return v;
-}
-
-static int lstm_tail() {  // BLM_LSTM_TAIL=1: always the general (K tail) form of the pipelined kernels (A/B measurements, tests)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("BLM_LSTM_TAIL");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-
-static int lstm_waves() {  // BLM_LSTM_WAVES=4|8 (A/B measurements)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("BLM_LSTM_WAVES");
-    v = e ? atoi(e) : 4;
-  }
-  return v;
-}
+// options "lstm_gemv" / "lstm_pipe" / "lstm_tail" (blm_set_option): the tiny-batch step kernel, the software-pipelined K loop
+// and the general (K tail) form of the pipelined kernels -- each form is built and parity-tested
+static int lstm_gemv() { return blm::option(blm::OPT_LSTM_GEMV); }
+static int lstm_pipe() { return blm::option(blm::OPT_LSTM_PIPE); }
+static int lstm_tail() { return blm::option(blm::OPT_LSTM_TAIL); }
 
 extern "C" int blm_lstm_step_fwd_gp(const float*, const float*, const float*, const float*, float*, float*, float*, const float*, int,
                                     const float*, const float*, float*, int, int, void*);
@@ -939,7 +902,7 @@ extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const 
     BLM_HIP(hipGetLastError());
     return BLM_OK;
   }
-  const size_t lds4 = (size_t)4 * WAVE_LDS * sizeof(float), lds8 = 2 * lds4;
+  const size_t lds4 = (size_t)4 * WAVE_LDS * sizeof(float);
   static bool once = false;
   if (!once) {
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
@@ -947,20 +910,12 @@ extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const 
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, true, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, true, 4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<1, 4, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
     once = true;
   }
   const int nchunk = (H / 8 + 31) / 32;  // 32-k chunks per lane half of a wave's K quarter
   const dim3 grid(H / 8, (B + 31) / 32), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (H % 64 == 0 && lstm_waves() == 8) {  // two waves per SIMD, K in eighths; one workgroup per CU
-    const int nc8 = (H / 16 + 31) / 32;
-    if (nc8 == 2) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, false, 8>), grid, dim3(512), lds8, st, p);
-    else if (nc8 % 2 == 0) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, true, 8>), grid, dim3(512), lds8, st, p);
-    else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 4, true, 8>), grid, dim3(512), lds8, st, p);
-  } else if (nchunk % 2 == 0 && nchunk >= 4 && lstm_pipe()) {
+  if (nchunk % 2 == 0 && nchunk >= 4 && lstm_pipe()) {
     if (H % 256 == 0 && !lstm_tail()) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, true, 4, true, false>), grid, block, lds4, st, p);  // whole chunks only
     else hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, true, 4, true>), grid, block, lds4, st, p);
   } else if (nchunk == 2) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4, false>), grid, block, lds4, st, p);
@@ -992,32 +947,14 @@ extern "C" int blm_lstm_seq_pair_fwd(const float* xw_a, const float* w_hh_a, flo
   const bool pairable = B <= 4 && H % 4 == 0 && lstm_gemv() && (n_a == 0 || (al16(w_hh_a) && al16(hs_a))) && (n_b == 0 || (al16(w_hh_b) && al16(hs_b))) &&
                         (bh * sizeof(float)) % 16 == 0;
   hipStream_t s0 = (hipStream_t)stream;
-  // larger batches: the pair form of the fused step kernel where blm_lstm_step_fwd would launch its pipelined whole-chunk variant
-  const size_t lds4 = (size_t)4 * WAVE_LDS * sizeof(float);
-  const int nchunk = (H / 8 + 31) / 32;
-  const bool pair_mfma = !pairable && H % 256 == 0 && nchunk % 2 == 0 && nchunk >= 4 && lstm_pipe() && !lstm_tail() && lstm_waves() != 8 && n_a > 0 && n_b > 0 &&
-                         al16(w_hh_a) && al16(w_hh_b) && al16(hs_a) && al16(hs_b) && (bh * sizeof(float)) % 16 == 0 &&
-                         16.0 * H * H < 4294967296.0 && 4.0 * B * H < 4294967296.0 && !(B <= 4 && lstm_gemv());
-  if (pair_mfma) {
-    static bool once = false;
-    if (!once) {
-      BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_pair_kernel<2, 4, true, 4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
-      once = true;
-    }
-  }
   const int n = n_a > n_b ? n_a : n_b;
   for (int t = 0; t < n; ++t) {
     const bool a = t < n_a, b = t < n_b;
-    if (a && b && (pairable || pair_mfma)) {
+    if (a && b && pairable) {
       const LstmStepP pa{xw_a + t * bg, w_hh_a, hs_a + t * bh, cs_a + t * bh, hs_a + (t + 1) * bh, cs_a + (t + 1) * bh,
                          ga_a ? ga_a + t * bg : nullptr, nullptr, nullptr, nullptr, -1, nullptr, B, H, nullptr};
       const LstmStepP pb{xw_b + t * bg, w_hh_b, hs_b + t * bh, cs_b + t * bh, hs_b + (t + 1) * bh, cs_b + (t + 1) * bh,
                          ga_b ? ga_b + t * bg : nullptr, nullptr, nullptr, nullptr, -1, nullptr, B, H, nullptr};
-      if (!pairable) {  // the matrix-core step kernel, software-pipelined whole-chunk form (what blm_lstm_step_fwd picks for these shapes)
-        hipLaunchKernelGGL((lstm_step_fwd_pair_kernel<2, 4, true, 4, true, false>), dim3(H / 8, (B + 31) / 32, 2), dim3(256), lds4, s0, pa, pb);
-        BLM_HIP(hipGetLastError());
-        continue;
-      }
       const dim3 g((H + 3) / 4, 2), blk(256);
       if (B == 1) hipLaunchKernelGGL(lstm_step_fwd_gemv_pair_kernel<1>, g, blk, 0, s0, pa, pb);
       else if (B == 2) hipLaunchKernelGGL(lstm_step_fwd_gemv_pair_kernel<2>, g, blk, 0, s0, pa, pb);
@@ -1077,25 +1014,19 @@ extern "C" int blm_transpose(const float* in, float* out, int rows, int cols, vo
 static int launch_step_bwd(const LstmBwdP& p, void* stream) {
   if (4.0 * p.H * p.G >= 4294967296.0 || 4.0 * p.B * p.G >= 4294967296.0)  // the kernels address both operands with 32-bit byte offsets
     return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_bwd: operands of 4 GB and more are not supported by the fused step");
-  const size_t lds4 = (size_t)4 * BWAVE_LDS * sizeof(float), lds8 = 2 * lds4;
+  const size_t lds4 = (size_t)4 * BWAVE_LDS * sizeof(float);
   static bool once = false;
   if (!once) {
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((lstm_step_bwd_kernel<2, true, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
     BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((lstm_step_bwd_kernel<2, true, 4, true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((lstm_step_bwd_kernel<2, true, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((lstm_step_bwd_kernel<1, true, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
     once = true;
   }
   const int nchunk = (p.G / 16 + 31) / 32;  // 32-k chunks per lane quarter of a wave's contraction run
   const dim3 grid(p.H / 16, (p.B + 15) / 16), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (p.G % 128 == 0 && p.ovr != 8 && lstm_waves() == 8) {
-    const int nc8 = (p.G / 32 + 31) / 32;
-    if (nc8 % 2 == 0) hipLaunchKernelGGL((lstm_step_bwd_kernel<2, true, 8>), grid, dim3(512), lds8, st, p);
-    else hipLaunchKernelGGL((lstm_step_bwd_kernel<1, true, 8>), grid, dim3(512), lds8, st, p);
-  } else if (nchunk % 2 == 0 && nchunk >= 4 && lstm_pipe()) {
+  if (nchunk % 2 == 0 && nchunk >= 4 && lstm_pipe()) {
     if (p.G % 512 == 0 && !lstm_tail()) hipLaunchKernelGGL((lstm_step_bwd_kernel<2, true, 4, true, false>), grid, block, lds4, st, p);  // whole chunks only
     else hipLaunchKernelGGL((lstm_step_bwd_kernel<2, true, 4, true>), grid, block, lds4, st, p);
   }

@@ -91,7 +91,7 @@ class GradReducer:
     """
 
     def __init__(self, flat, bucket_bytes=32 << 20, group=None, expected=None, overlap=True, comm_cus=0, collective=None,
-                 comm_plan="window", comm_gbps=None):
+                 comm_plan=None, comm_gbps=None):
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -107,6 +107,9 @@ class GradReducer:
         # "narrow": the planner counts on 256 - comm_cus CUs from the first bucket of a step until finish() (measured:
         # loses 1.5-10 % in situ -- buckets are in flight for a tenth of backward; kept for A/B).  "off": nothing.
         self.comm_cus = int(comm_cus) if self.cuda else 0
+        comm_plan = comm_plan or os.environ.get("BLM_COMM_PLAN", "window")
+        if comm_plan not in ("window", "narrow", "off"):
+            raise ValueError("comm_plan / BLM_COMM_PLAN must be window, narrow or off, not %r" % (comm_plan,))
         self.comm_plan = comm_plan if self.comm_cus > 0 else "off"
         self.comm_gbps = float(os.environ.get("BLM_COMM_GBPS", "100") if comm_gbps is None else comm_gbps)
         self._narrowed = False
@@ -380,8 +383,7 @@ class Trainer:
         if comm_cus is None:  # RCCL: one channel workgroup per channel (pin_rccl_channels); gloo moves bytes on the host
             comm_cus = rccl_channels() if (world > 1 and dist.is_initialized() and dist.get_backend() == "nccl") else 0
         self.reducer = GradReducer(self.flat, bucket_bytes, overlap=overlap, comm_cus=comm_cus if overlap else 0,
-                                   collective=collective, comm_plan=comm_plan or os.environ.get("BLM_COMM_PLAN", "window"),
-                                   comm_gbps=comm_gbps)
+                                   collective=collective, comm_plan=comm_plan, comm_gbps=comm_gbps)
         hooked = world > 1 or collective is not None
         ops.set_grad_ready_hook(self.reducer.mark_ready if hooked else None)
         ops.set_embed_grad_sink(None)

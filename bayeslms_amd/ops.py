@@ -224,6 +224,19 @@ def set_gemm_mode(mode):
     check(lib().blm_set_gemm_mode(code), "blm_set_gemm_mode")
 
 
+def set_option(name, value):
+    """Kernel-selection options of the library (include/bayeslm.h blm_set_option): "attn_hpw", "attn_short", "attn_valu",
+    "lstm_gemv", "lstm_pipe", "lstm_tail".  Each picks between two BUILT and parity-tested forms of a kernel; the defaults are
+    the measured winners (INTEGRATION.md lists them with their tests and BLM_* environment variables)."""
+    check(lib().blm_set_option(name.encode(), int(value)), "blm_set_option")
+
+
+def get_option(name):
+    v = C.c_int(0)
+    check(lib().blm_get_option(name.encode(), C.byref(v)), "blm_get_option")
+    return int(v.value)
+
+
 def set_gemm_cus(n):
     """Compute units the GEMM planner may count on (0: the whole chip).  engine.GradReducer narrows it while gradient buckets
     are in flight: the collective's channel workgroups hold CUs beside the backward GEMMs (include/bayeslm.h
@@ -1207,7 +1220,7 @@ class _LSTMLayer(torch.autograd.Function):
         if fused_step and not torch.is_grad_enabled() and B >= _UNFUSED_STEP_B:
             # wide inference batches (the scorer packs hundreds of hypotheses per step): the fused step kernel re-reads W_hh
             # once per 32 batch rows and runs at 0.57 of the matrix peak there; the tiled GEMM + cell kernel pair is faster
-            # from B ~ 200 on (n-best rescoring 64.5 k -> 70-72 k hypotheses/s; BLM_LSTM_UNFUSED_B moves the threshold)
+            # from B ~ 200 on (n-best rescoring 64.5 k -> 70-72 k hypotheses/s)
             fused_step = False
         if fused_step:  # the whole layer from one call: T launches issued by the library
             ev = _TIMER.bracket("lstm_seq_fwd T=%d" % T) if _TIMER is not None else None
@@ -1320,13 +1333,9 @@ def _side_stream():
     return _SIDE_STREAM
 
 
-_UNFUSED_STEP_B = int(os.environ.get("BLM_LSTM_UNFUSED_B", "256"))
-# 1: the B <= 32 forward wavefront as paired launches from one stream (lstm_step_fwd_pair_kernel) instead of two streams.  Measured
-# and not the default: recipe LSTM 10.02 against 9.95 ms, configs[0] equal, evaluate() at T 100 +1 % -- both layers' W_hh (2 x 16.8 MB)
-# stream through the same L2s either way, the pair is bound by that, not by the launches
-_PAIR_STEPS = os.environ.get("BLM_LSTM_PAIR_STEPS", "0") == "1"
-_PAIR_CHAIN = os.environ.get("BLM_LSTM_PAIR_CHAIN", "1") != "0"  # 0: B <= 4 stacks as a two-stream wavefront like larger batches (A/B)
-_STACK_CHUNK = int(os.environ.get("BLM_LSTM_WAVE_CHUNK", "0"))  # A/B knob: steps per wavefront chunk (0: the rule below)
+# no-grad forwards at B >= 256 (the scorer's packed batches) take the tiled GEMM + cell kernel: the fused step kernel re-reads
+# W_hh once per 32 batch rows (measured: n-best rescoring 64.5 k -> 70-72 k hypotheses/s with the threshold at ~200-256)
+_UNFUSED_STEP_B = 256
 
 
 def _stack_chunks(T):
@@ -1339,8 +1348,6 @@ def _stack_chunks(T):
     cmax = 16 if T <= 256 else 128
     n = (T + cmax - 1) // cmax
     c = (T + n - 1) // n
-    if _STACK_CHUNK > 0:
-        c = _STACK_CHUNK
     return [(t0, min(T, t0 + c)) for t0 in range(0, T, c)]
 
 
@@ -1386,7 +1393,7 @@ class _LSTMStack2(torch.autograd.Function):
         p_xw1, p_xw2 = xw1.data_ptr(), xw2.data_ptr()
         p = {k: v.data_ptr() for k, v in (("hs1", hs1), ("cs1", cs1), ("ga1", ga1), ("hs2", hs2), ("cs2", cs2), ("ga2", ga2))}
         chunks = _stack_chunks(T)
-        if (B <= 4 and _PAIR_CHAIN) or (B <= 32 and _PAIR_STEPS):
+        if B <= 4:
             # tiny batches (the scorer's carry chain): layer 1 over chunk c and layer 2 over chunk c - 1 from ONE stream, a step
             # of each per launch (blm_lstm_seq_pair_fwd) -- no second stream, no events, half the launches
             prev = None

@@ -241,6 +241,18 @@ int blm_linear_nll2(const float* x1, int64_t ldx1, const float* w1, int64_t ldw1
                     const float* x2, int64_t ldx2, const float* w2, int64_t ldw2, const float* b2, int K2, float alpha,
                     const int64_t* tgt, float* nll, float* lse, float* wcat, int pack_w, float* ws, int M, int N, void* stream);
 
+/* Kernel-selection options: switches that pick between two BUILT forms of a kernel (each form is parity-tested; the defaults are
+ * the measured winners).  Settable at run time; each is initialised from its environment variable on first use.
+ *   "attn_hpw"   (BLM_ATTN_HPW,   0) heads per workgroup of the T <= 128 attention kernels: 0 = by head count, 1, 2
+ *   "attn_short" (BLM_ATTN_SHORT, 1) one-wave-per-head attention forward for T <= 32 (0: the 128-row forward there too)
+ *   "attn_valu"  (BLM_ATTN_VALU,  0) 1: the vector-ALU attention kernels also at head_dim 64
+ *   "lstm_gemv"  (BLM_LSTM_GEMV,  1) one-wave-per-unit LSTM step kernel for B <= 4 (0: the matrix-core step kernel)
+ *   "lstm_pipe"  (BLM_LSTM_PIPE,  1) software-pipelined K loop of the LSTM step kernels
+ *   "lstm_tail"  (BLM_LSTM_TAIL,  0) 1: the general (K tail) form of the pipelined LSTM step kernels also for whole chunks
+ * No reference counterpart (the reference leaves kernel selection to the vendor libraries behind torch). */
+int blm_set_option(const char* name, int value);
+int blm_get_option(const char* name, int* value);
+
 /* Launch plan of a blm_gemm call: block tile (11 = 64x64, 12 = 64x128, 21 = 128x64, 22 = 128x128 rows x cols on four waves;
  * 28 = 128x128 on EIGHT waves: two waves per SIMD in one barrier domain, aligned operands and K % 32 == 0 only) and
  * number of K slices (> 1: partial sums meet in C through float atomics; legal for the plain, bias and Bayesian-wgrad

@@ -197,3 +197,35 @@ def test_plans_are_memoised_per_cu_count_and_invalidated_by_table_changes():
     assert plan(a)[0] == 12
     lib.blm_gemm_plan_override(0, 0)
     assert plan(a)[:2] == base
+
+
+def test_comm_window_is_kept_in_modelled_device_time():
+    """blm_gemm_plan_comm_window(us): every plan made while the window is open takes its modelled time off it; inside the
+    window a shape listed in the comm table (csrc/gemm_plans_comm.inc or blm_gemm_plan_set_comm) takes that plan (source 3),
+    every other shape keeps its whole-chip plan; 0 closes the window."""
+    lib = L.lib()
+    a = args(L.GEMM_TN, 4096, 512, 8192, acc=True)   # FFN linear1 weight gradient: in the built-in comm table
+    b = args(L.GEMM_NT, 8192, 512, 4096)             # the roofline launch: not in it
+    whole_a, whole_b = plan(a), plan(b)
+    assert whole_a[2] == 1 and whole_b[:3] == (28, 1, 1)
+    assert lib.blm_gemm_plan_comm_window_left() == 0.0
+    L.check(lib.blm_gemm_plan_comm_window(C.c_float(1000.0)), "window")
+    try:
+        left0 = lib.blm_gemm_plan_comm_window_left()
+        under_a = plan(a)
+        left1 = lib.blm_gemm_plan_comm_window_left()
+        assert under_a[2] == 3 and under_a[:2] != whole_a[:2] and under_a[0] != 28
+        assert abs((left0 - left1) - under_a[3]) < 1e-2 * under_a[3]
+        assert plan(b)[:3] == whole_b[:3]                       # no comm entry: the whole-chip plan, and its time comes off
+        assert lib.blm_gemm_plan_comm_window_left() < left1
+        L.check(lib.blm_gemm_plan_set_comm(L.GEMM_NT, 8192, 512, 4096, L.EPI_NONE, 0, 11, 4), "set_comm")
+        assert plan(b)[:3] == (11, 4, 3)
+        for _ in range(64):                                     # the window runs out by itself
+            plan(b)
+        assert lib.blm_gemm_plan_comm_window_left() == 0.0 and plan(b)[:3] == whole_b[:3]
+        L.check(lib.blm_gemm_plan_comm_window(C.c_float(500.0)), "window")
+        L.check(lib.blm_gemm_plan_comm_window(C.c_float(0.0)), "window")
+        assert lib.blm_gemm_plan_comm_window_left() == 0.0 and plan(a)[:3] == whole_a[:3]
+    finally:
+        lib.blm_gemm_plan_comm_window(C.c_float(0.0))
+        lib.blm_gemm_plan_clear(1)

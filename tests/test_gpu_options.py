@@ -1,0 +1,185 @@
+"""GPU: every kernel-selection switch that survives (include/bayeslm.h blm_set_option, the scorer / evaluate switches) runs its
+NON-default form against the default one and against the CPU oracle -- an untested non-default kernel is product surface, not
+documentation.  INTEGRATION.md lists the switches with these tests."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture
+def option():
+    """set(name, value) for the duration of a test; every option goes back to what it was."""
+    from bayeslms_amd import ops
+    saved = {}
+
+    def setter(name, value):
+        saved.setdefault(name, ops.get_option(name))
+        ops.set_option(name, value)
+    yield setter
+    for k, v in saved.items():
+        ops.set_option(k, v)
+
+
+def _attn(dev, T, B, nhead, hd, p):
+    from bayeslms_amd import ops
+    from oracle import bayes_oracle as O
+    d = nhead * hd
+    g = torch.Generator().manual_seed(T * 3 + B)
+    qkv = torch.randn(T, B, 3 * d, generator=g)
+    go = torch.randn(T, B, d, generator=g)
+    drop = ops.Drop(p, 77, 5, 2, 0, B) if p > 0 else ops.NO_DROP
+    x = qkv.to(dev).requires_grad_(True)
+    out = ops.attention(x, nhead, drop)
+    out.backward(go.to(dev))
+    ref = None
+    if p == 0:
+        qr = qkv.clone().requires_grad_(True)
+        q, k, v = qr.chunk(3, dim=-1)
+        r = O.attention_core(q, k, v, nhead, O.causal_mask(T))
+        r.backward(go)
+        ref = (r.detach(), qr.grad)
+    return out.detach(), x.grad, ref
+
+
+@pytest.mark.parametrize("T,B,nhead,p", [(128, 8, 8, 0.0), (128, 8, 8, 0.2), (97, 2, 3, 0.0), (64, 64, 8, 0.2)])
+def test_attention_heads_per_workgroup_forms_agree(dev, option, T, B, nhead, p):
+    """"attn_hpw" 1 / 2: one head per 4-wave workgroup against two heads per 8-wave workgroup (the default picks by head
+    count), forward and the one-launch backward, with the oracle at dropout 0 and the same Philox masks otherwise."""
+    res = {}
+    for v in (1, 2):
+        option("attn_hpw", v)
+        res[v] = _attn(dev, T, B, nhead, 64, p)
+    assert rel(res[1][0], res[2][0]) < 2e-6 and rel(res[1][1], res[2][1]) < 5e-6
+    if p == 0:
+        for v in (1, 2):
+            assert rel(res[v][0], res[v][2][0]) < 1e-5 and rel(res[v][1], res[v][2][1]) < 2e-5
+
+
+@pytest.mark.parametrize("T,B,nhead,p", [(32, 16, 8, 0.0), (20, 40, 8, 0.0), (7, 3, 2, 0.0), (30, 64, 8, 0.3)])
+def test_attention_short_forward_equals_the_general_one(dev, option, T, B, nhead, p):
+    """"attn_short" 0: the 128-row forward also for T <= 32, where the default runs one wave per head (inference: no grad)."""
+    from bayeslms_amd import ops
+    from oracle import bayes_oracle as O
+    d = nhead * 64
+    qkv = torch.randn(T, B, 3 * d, generator=torch.Generator().manual_seed(T)).to(dev)
+    drop = ops.Drop(p, 5, 1, 0, 0, B) if p > 0 else ops.NO_DROP
+    outs = {}
+    with torch.no_grad():
+        for v in (1, 0):
+            option("attn_short", v)
+            outs[v] = ops.attention(qkv, nhead, drop)
+    assert rel(outs[1], outs[0]) < 2e-6
+    if p == 0:
+        q, k, v = qkv.cpu().chunk(3, dim=-1)
+        assert rel(outs[0], O.attention_core(q, k, v, nhead, O.causal_mask(T))) < 1e-5
+
+
+@pytest.mark.parametrize("T,B,nhead", [(128, 2, 4), (50, 3, 2), (160, 1, 2)])
+def test_attention_vector_alu_kernels_at_head_dim_64(dev, option, T, B, nhead):
+    """"attn_valu" 1: the untiled vector-ALU kernels (the path of every other head size) at head_dim 64 against the MFMA kernels
+    and the oracle."""
+    res = {}
+    for v in (0, 1):
+        option("attn_valu", v)
+        res[v] = _attn(dev, T, B, nhead, 64, 0.0)
+    assert rel(res[1][0], res[0][0]) < 1e-5 and rel(res[1][1], res[0][1]) < 2e-5
+    assert rel(res[1][0], res[1][2][0]) < 1e-5 and rel(res[1][1], res[1][2][1]) < 2e-5
+
+
+def _lstm(dev, T, B, H, grad):
+    from bayeslms_amd import ops
+    g = torch.Generator().manual_seed(H + B)
+    s = 1.0 / H ** 0.5
+    x = torch.randn(T, B, H, generator=g)
+    w_ih, w_hh = (torch.rand(4 * H, H, generator=g) * 2 - 1) * s, (torch.rand(4 * H, H, generator=g) * 2 - 1) * s
+    b_ih, b_hh = (torch.rand(4 * H, generator=g) * 2 - 1) * s, (torch.rand(4 * H, generator=g) * 2 - 1) * s
+    h0, c0 = torch.randn(B, H, generator=g) * 0.1, torch.randn(B, H, generator=g) * 0.1
+    t = [v.to(dev) for v in (x, h0, c0, w_ih, w_hh, b_ih, b_hh)]
+    if not grad:
+        with torch.no_grad():
+            return ops.lstm_layer(*t), (x, h0, c0, w_ih, w_hh, b_ih, b_hh)
+    t = [v.requires_grad_(True) for v in t]
+    y, hT, cT = ops.lstm_layer(*t)
+    (y.sum() * 0.3 + hT.sum() + cT.sum() * 0.5).backward()
+    return (y.detach(), hT.detach(), cT.detach(), t[0].grad, t[3].grad, t[4].grad), (x, h0, c0, w_ih, w_hh, b_ih, b_hh)
+
+
+@pytest.mark.parametrize("B,H", [(1, 1024), (2, 256), (4, 64)])
+def test_lstm_tiny_batch_kernel_equals_the_matrix_core_step(dev, option, B, H):
+    """"lstm_gemv" 0: B <= 4 on the matrix-core step kernel instead of the one-wave-per-unit form (the scorer's carry chain)."""
+    from oracle import bayes_oracle as O
+    res = {}
+    for v in (1, 0):
+        option("lstm_gemv", v)
+        res[v], cpu = _lstm(dev, 9, B, H, False)
+    for a, b in zip(res[1], res[0]):
+        assert rel(a, b) < 5e-6
+    y, h, c = O.lstm_layer(*cpu)
+    assert rel(res[0][0], y) < 1e-5 and rel(res[0][2], c) < 1e-5
+
+
+@pytest.mark.parametrize("opt,val", [("lstm_pipe", 0), ("lstm_tail", 1)])
+@pytest.mark.parametrize("B,H", [(64, 1024), (20, 512)])
+def test_lstm_step_kernel_forms_agree(dev, option, opt, val, B, H):
+    """"lstm_pipe" 0 (the K loop without software pipelining) and "lstm_tail" 1 (the general K-tail form of the pipelined loop)
+    against the default form: forward, carried state and the input / weight gradients of a whole layer."""
+    base, _ = _lstm(dev, 6, B, H, True)
+    option(opt, val)
+    other, _ = _lstm(dev, 6, B, H, True)
+    for a, b in zip(other, base):
+        assert rel(a, b) < 5e-6
+
+
+def test_options_are_validated(dev):
+    from bayeslms_amd import ops
+    from bayeslms_amd._lib import BayesLMError
+    with pytest.raises(BayesLMError, match="unknown option"):
+        ops.set_option("no_such_switch", 1)
+    with pytest.raises(BayesLMError, match="takes 0..2"):
+        ops.set_option("attn_hpw", 3)
+    assert ops.get_option("lstm_pipe") == 1 and ops.get_option("attn_valu") == 0
+
+
+def test_scorer_and_evaluate_fused_nll_switches(dev, monkeypatch):
+    """BLM_SCORER_FUSED_NLL=0 / BLM_EVAL_FUSED_NLL=0: decoder logits materialised + cross-entropy kernel (two models: two logit
+    matrices + blm_ce_interp_fwd) against the default (blm_linear_nll / blm_linear_nll2: no logits stored)."""
+    import collections
+    from bayeslms_amd import compute_sentence_scores as S, engine, model as M
+    torch.manual_seed(4)
+    V = 64
+    vocab = {"w%d" % i: i for i in range(V)}
+    vocab["<s>"] = 0
+    g = torch.Generator().manual_seed(2)
+    nbest = collections.OrderedDict()
+    for u in range(6):
+        nbest["utt%d" % u] = [" ".join("w%d" % int(t) for t in torch.randint(1, V, (int(torch.randint(1, 9, (1,), generator=g)),), generator=g))
+                              for _ in range(4)]
+    m1 = M.BayesTransformerModel(V, 32, 4, 64, 2, 0.1, True, "FFN").to(dev)
+    m2 = M.TransformerModel(V, 16, 4, 32, 2, 0.1, "gelu", True).to(dev)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(S, "_FUSED_NLL", fused)
+        one = S.compute_scores_batched(nbest, m1, vocab, "Transformer", dev)
+        two = S.compute_scores_batched(nbest, m1, vocab, "Transformer", dev, m2, 0.7)
+        res[fused] = ([v for hv in one.values() for _, v in hv], [v for hv in two.values() for _, v in hv])
+    for a, b in zip(res[True][0] + res[True][1], res[False][0] + res[False][1]):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(b))
+    assert any(abs(a - b) > 1e-3 for a, b in zip(res[True][0], res[True][1]))  # the second model matters
+    data = torch.randint(0, V, (90, 5), generator=g).to(dev)
+    monkeypatch.setenv("BLM_EVAL_FUSED_NLL", "1")
+    a = engine.evaluate(m1, data, 16)
+    monkeypatch.setenv("BLM_EVAL_FUSED_NLL", "0")
+    b = engine.evaluate(m1, data, 16)
+    assert abs(a - b) <= 1e-5 * abs(b)

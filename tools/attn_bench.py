@@ -1,6 +1,6 @@
 """Times the causal attention kernels through the C ABI at the cfg3 shape (T 128, B 64, 8 heads x 64), with and without
 dropout, back-to-back launches: forward, backward without workspace (two recomputations of the probabilities) and with
-the dS workspace (blm_attn_bwd_ws: one launch; BLM_ATTN_FUSE_DQ=0 = dK/dV launch + dQ launch)."""
+the dS workspace (blm_attn_bwd_ws: one launch)."""
 import ctypes
 import os
 import sys
