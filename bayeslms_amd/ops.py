@@ -1718,7 +1718,9 @@ class _LSTMRecurrentGPNN2(torch.autograd.Function):
         consecutive steps GPNN2.step_noises hands out."""
         if noises is None:
             return None, None
-        if noises[0].eps is not None:
+        if any(n.eps is not None for n in noises):
+            if any(n.eps is None for n in noises):  # a per-call eps_override list with holes
+                raise BayesLMError("lstm_recurrent_gpnn2: the per-step noise is either injected for EVERY step or drawn from Philox for every step")
             return torch.stack([_f32(n.eps, "eps") for n in noises]).contiguous(), None
         for t, n in enumerate(noises):
             if n.eps is not None or n.seed != noises[0].seed or n.tensor_id != noises[0].tensor_id or n.step != ((noises[0].step + t) & 0xFFFFFFFF):
@@ -1824,7 +1826,8 @@ class _LSTMRecurrentGPNN2(torch.autograd.Function):
             gemm(L.GEMM_TN, dout, sact, dcwp, NO, GP, T * B, NO, GP, GP)  # column M of s is the constant 1: its row is d coef.bias
             dcw = dcwp[:, :M].contiguous() if need_cw else None
             dcb = dcwp[:, M].contiguous() if need_cb else None
-        if fmean.requires_grad or flgstd.requires_grad:
+        # (mean frequencies -- eval mode or a deterministic GPNN2 -- give the lgstd no gradient: with the mean frozen there is nothing to do)
+        if fmean.requires_grad or (flgstd.requires_grad and noises is not None):
             # d F_t = x_t^T d f_t (contraction over the B rows of ONE step: the frequencies differ per step); d mean is their
             # sum, d lgstd their eps_t-weighted sum times sigma -- one launch, eps_t regenerated from the Philox counters
             x_in = pre if mode == 0 else (cs if mode == 1 else hs)  # rows 0..T-1: the GPNN2's inputs
@@ -1909,7 +1912,7 @@ class _GPNN2Steps(torch.autograd.Function):
             gemm(L.GEMM_TN, dout, sact, dcwp, NO, GP, T * B, NO, GP, GP)
             dcw = dcwp[:, :M].contiguous() if need_cw else None
             dcb = dcwp[:, M].contiguous() if need_cb else None
-        if fmean.requires_grad or flgstd.requires_grad:
+        if fmean.requires_grad or (flgstd.requires_grad and noises is not None):
             eps_all, rng0 = _LSTMRecurrentGPNN2._noise(noises, dev)
             Tn, Bn = T, B
             if noises is None:

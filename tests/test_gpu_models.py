@@ -944,6 +944,31 @@ def test_gauss_rnn_gpnn2_fused_steps_match_oracle(dev, gp):
     assert torch.equal(a, b) and not torch.equal(a, d)
 
 
+def test_gpnn2_cells_with_frozen_means_and_mixed_noise_lists(dev):
+    """(i) a GPNN2 cell whose frequency_mean is frozen while frequency_lgstd still wants a gradient, run with mean
+    frequencies (eval-mode graph): nothing flows to the frequencies and backward must not ask the library for two NULL outputs;
+    (ii) a per-call eps_override list with holes is refused with a message instead of failing inside the tensor guard."""
+    from bayeslms_amd import model as M, ops
+    from bayeslms_amd._lib import BayesLMError
+    torch.manual_seed(2)
+    V, H, T, B = 30, 64, 4, 3
+    for gp in ("34", "74"):
+        m = M.GaussRNNModel("LSTM", V, H, H, 2, 0.0, True, gp).to(dev)
+        gpnn = m.rnn.rnn[0].gpnn
+        gpnn.frequency_mean.requires_grad_(False)
+        x = torch.randint(0, V, (T, B), device=dev)
+        tgt = torch.randint(0, V, (T * B,), device=dev)
+        m.eval()  # mean frequencies, autograd on
+        logits, _ = m(x, m.init_hidden(B))
+        ops.cross_entropy(logits.view(-1, V), tgt)[0].backward()
+        assert gpnn.frequency_lgstd.grad is None or float(gpnn.frequency_lgstd.grad.abs().max()) == 0.0
+        assert m.rnn.rnn[0].weights_ih.grad is not None
+        m.train()
+        gpnn.eps_override = [torch.randn(gpnn.input_dim, gpnn.n_MC_terms, device=dev) if t != 2 else None for t in range(T)]
+        with pytest.raises(BayesLMError, match="EVERY step"):
+            m(x, m.init_hidden(B))
+
+
 @pytest.mark.parametrize("vp", ["00", "01", "10", "11"])
 def test_variational_rnn_golden(dev, vp):
     from bayeslms_amd import model as M, ops
