@@ -139,10 +139,13 @@ def _rccl_one_rank(port, ret):
     arithmetic (the collective over a 1-rank group is the identity, so the result must equal the
     plain run with gradients halved by grad_scale)."""
     import torch.distributed as dist
-    from bayeslms_amd import data as D, engine
+    from bayeslms_amd import _lib, data as D, engine
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
+    for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS"):
+        os.environ.pop(k, None)
+    pinned = engine.pin_rccl_channels()  # as bench.py / train.py do before RCCL reads its environment
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
     try:
         x = torch.arange(1024, device=dev, dtype=torch.float32)
@@ -161,12 +164,17 @@ def _rccl_one_rank(port, ret):
         m, _, _ = _build(dev)
         tr = engine.Trainer(m, lr=0.2, clip=0.5, kl_scale=0.01, seed=1111, rank=0, world=2, bucket_bytes=8192)
         tr.reducer.world = 2  # grad-ready hooks on, bucketed collectives issued over RCCL (1-rank group: identity)
+        # the pinned channel count reaches the reducer: the GEMM planner's comm window opens with the buckets and is closed
+        # again when the step is over
+        comm_ok = (pinned["NCCL_MAX_NCHANNELS"] == str(engine.RCCL_CHANNELS_DEFAULT) and tr.reducer.comm_cus == engine.RCCL_CHANNELS_DEFAULT
+                   and tr.reducer.comm_plan == "window")
         losses = []
         for i in range(3):
             data, tgt = D.get_batch(train, i * 12, 12)
             loss, _, _ = tr.step(data, tgt, kl_fn=_kl)
             losses.append(float(loss))
-        ret["rccl"] = (ok_identity, losses, bool(torch.isfinite(tr.flat.flat_param).all()))
+            comm_ok = comm_ok and float(_lib.lib().blm_gemm_plan_comm_window_left()) == 0.0
+        ret["rccl"] = (ok_identity and comm_ok, losses, bool(torch.isfinite(tr.flat.flat_param).all()))
     finally:
         dist.destroy_process_group()
 

@@ -962,7 +962,7 @@ def test_gpnn2_cells_with_frozen_means_and_mixed_noise_lists(dev):
         logits, _ = m(x, m.init_hidden(B))
         ops.cross_entropy(logits.view(-1, V), tgt)[0].backward()
         assert gpnn.frequency_lgstd.grad is None or float(gpnn.frequency_lgstd.grad.abs().max()) == 0.0
-        assert m.rnn.rnn[0].weights_ih.grad is not None
+        assert m.rnn.rnn[0].weights_hh.grad is not None and gpnn.coef.weight.grad is not None
         m.train()
         gpnn.eps_override = [torch.randn(gpnn.input_dim, gpnn.n_MC_terms, device=dev) if t != 2 else None for t in range(T)]
         with pytest.raises(BayesLMError, match="EVERY step"):
