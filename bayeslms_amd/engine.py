@@ -446,13 +446,21 @@ class Trainer:
         return loss.detach(), (kl.detach() if kl is not None else None), hidden
 
 
-def evaluate(model, source, seq_len, eval_batch_size=None):
-    """Eval-mode loss per token exactly as train.py:441-458 sums it."""
+def evaluate(model, source, seq_len, eval_batch_size=None, rank=0, world=1, group=None):
+    """Eval-mode loss per token exactly as train.py:441-458 sums it.  Data parallel (``world`` > 1): the columns of the
+    evaluation batch are independent streams (batchify, train.py:167-179; an LSTM's carried state is per column), so rank r
+    evaluates columns [r C / W, (r + 1) C / W) and the token-weighted sums meet in one 8-byte all-reduce -- the reference's
+    single process walks the whole stream, and with W ranks doing that each the validation pass would be the part of an epoch
+    that does not scale (it is ~1 % of a one-GPU epoch of the AMI recipe, ~10 % of an 8-GPU one).  Every rank returns the
+    same value up to the all-reduce (callers that branch on it take rank 0's: train.ValidationSchedule)."""
     from .data import get_batch
     from .model import repackage_hidden
     model.eval()
+    cols = source.shape[1]
+    lo, hi = (rank * cols) // world, ((rank + 1) * cols) // world
+    mine = source if world == 1 else source[:, lo:hi].contiguous()
     total = torch.zeros((), device=source.device, dtype=torch.float64)
-    hidden = model.init_hidden(source.shape[1]) if hasattr(model, "init_hidden") else None
+    hidden = model.init_hidden(mine.shape[1]) if (hasattr(model, "init_hidden") and hi > lo) else None
     # the decoder returns the per-token NLL itself when it can (ops.linear_nll: the (T*B, V) logits are never stored);
     # BLM_EVAL_FUSED_NLL=0 keeps decoder + cross-entropy kernel
     dec = getattr(model, "decoder", None)
@@ -461,7 +469,9 @@ def evaluate(model, source, seq_len, eval_batch_size=None):
     with torch.no_grad():
         try:
             for i in range(0, source.size(0) - 1, seq_len):
-                data, targets = get_batch(source, i, seq_len)
+                if hi <= lo:
+                    break  # more ranks than columns: nothing of this stream is mine
+                data, targets = get_batch(mine, i, seq_len)
                 if fused:
                     dec.nll_targets = targets
                 if hidden is None:
@@ -474,6 +484,12 @@ def evaluate(model, source, seq_len, eval_batch_size=None):
         finally:
             if fused:
                 dec.nll_targets = None
+    if world > 1:  # sum_r (columns of r) * (its per-window means, summed) / all columns = the whole batch's per-window means, summed
+        total = total * float(hi - lo) / float(cols)
+        on_dev = dist.get_backend(group) == "nccl"
+        t = total.reshape(1) if on_dev else total.reshape(1).cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        total = t[0]
     return float(total.item()) / (len(source) - 1)
 
 

@@ -305,7 +305,7 @@ def main(argv=None, history=None):
         for epoch in range(1, args.epochs + 1):
             t0 = time.time()
             train_epoch(epoch, sched.lr)
-            val_loss, improved, stop = sched.update(engine.evaluate(model, val_data, args.seq_len))
+            val_loss, improved, stop = sched.update(engine.evaluate(model, val_data, args.seq_len, rank=rank, world=world))
             say('-' * 89)
             say('| end of epoch {:3d} | time: {:5.2f}s | valid loss {:5.2f} | valid ppl {:8.2f}'.format(
                 epoch, time.time() - t0, val_loss, math.exp(val_loss)))
@@ -341,7 +341,7 @@ def main(argv=None, history=None):
             for k, v in sd.items():
                 own[k].copy_(v)
     _print_coef_mean(args, model, say)
-    test_loss = sched.agree(engine.evaluate(model, test_data, args.seq_len))
+    test_loss = sched.agree(engine.evaluate(model, test_data, args.seq_len, rank=rank, world=world))
     history["test_loss"] = test_loss
     say('=' * 89)
     say('| End of training | test loss {:5.2f} | test ppl {:8.2f}'.format(test_loss, math.exp(test_loss)))

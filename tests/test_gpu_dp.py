@@ -133,6 +133,37 @@ def test_two_ranks_equal_one_rank_with_the_layer_wavefront(family):
     assert err < 1e-4, err
 
 
+def _run_eval(rank, world, port, ret, family):
+    import torch.distributed as dist
+    from bayeslms_amd import data as D, engine
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    m, _, _ = _build(dev, family)
+    stream = torch.randint(0, 150, (5 * 83 + 3,), generator=torch.Generator().manual_seed(9))
+    valid = D.batchify(stream, 5, dev)  # 5 columns: an uneven split over 2 or 3 ranks, and more ranks than columns at 7
+    ret[(world, rank)] = engine.evaluate(m, valid, 12, rank=rank, world=world)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("family", ["tlm_ffn", "rnn_bayes3"])
+def test_sharded_evaluation_equals_the_single_process_pass(family):
+    """engine.evaluate(rank, world): rank r evaluates its share of the evaluation batch's columns (independent streams; the
+    LSTM's carried state is per column) and one 8-byte all-reduce joins the token-weighted sums -- the loss train.py:441-458
+    computes, on every rank, for 2, 3 and (more ranks than columns) 6 ranks."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_run_eval, args=(1, _free_port(), ret, family), nprocs=1, join=True)
+        one = ret[(1, 0)]
+        for world in (2, 3, 6):
+            mp.spawn(_run_eval, args=(world, _free_port(), ret, family), nprocs=world, join=True)
+            vals = [ret[(world, r)] for r in range(world)]
+            assert all(v == vals[0] for v in vals), vals
+            assert abs(vals[0] - one) <= 2e-6 * abs(one), (world, vals[0], one)
+
+
 def _rccl_one_rank(port, ret):
     """RCCL itself (backend "nccl"), one rank: process-group init with device_id as bench.py does it,
     the reducer's side-stream async all-reduce pattern, barrier, and a Trainer step in 'world 2'
