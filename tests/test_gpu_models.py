@@ -1167,6 +1167,36 @@ def test_cfg3_full_size_matches_oracle_on_a_column_subset(dev):
     assert torch.equal(a, b) and not torch.equal(a, c)
 
 
+def test_cfg5_gp_transformer_full_size_sampled_matches_oracle_on_a_column_subset(dev):
+    """BASELINE configs[4]'s model at its real size (GP Transformer --T_gauss_pos 3: 6L d512 ff4096 h8 V33000, T128 B64) with
+    GPNN.sample raised: the sampled coef / weights / bias (eps injected, dropout off) through the production tiles -- the GP-mixture
+    epilogue at M = 8192 -- against the CPU oracle on the first 3 columns; and the mean-weight forward."""
+    from bayeslms_amd import model as M
+    from oracle import bayes_oracle as O
+    torch.manual_seed(1111)
+    V, T, B, C = 33000, 128, 64, 3
+    m = M.GaussTransformerModel(V, 512, 8, 4096, 6, 0.2, True, 3).to(dev)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(19)
+    src = torch.randint(0, V, (T, B), generator=g)
+    gp = m.transformerlayers[0].gpnn
+    eps = {"coef": torch.randn(4, 4096, generator=g), "weights": torch.randn(4096, 512, generator=g), "bias": torch.randn(4096, generator=g)}
+    m.eval()
+    with torch.no_grad():
+        e = m(src.to(dev))[:, :C].cpu()
+        ref = O.transformer_lm(src[:, :C], sd, 8, None)
+    assert rel(e, ref) < 1e-4
+    m.train()
+    m.noise_state.dropout_off = True
+    gp.sample = True
+    gp.eps_override = {k: v.to(dev) for k, v in eps.items()}
+    with torch.no_grad():
+        t = m(src.to(dev))[:, :C].cpu()
+        ref_t = O.transformer_lm(src[:, :C], sd, 8, eps)
+    assert rel(t, ref_t) < 1e-4
+    assert rel(t, ref) > 1e-4  # the draw is really in
+
+
 def test_cfg2_full_size_matches_oracle_on_a_column_subset(dev):
     """BASELINE configs[1] at its real size (2x1024 LSTM, V33000, T35 B64): fused step kernels and the
     decoder GEMMs at M = 2240; first 3 columns against the CPU oracle, eval mode, with a carried state."""
