@@ -86,10 +86,12 @@ def _last_model_params():
 def build(name, dev):
     """-> step() closure running ONE step of the workload."""
     torch.manual_seed(1111)
-    if name in ("cfg3", "recipe_tlm", "gauss", "eval_tlm", "eval_tlm100"):
-        T, B = {"cfg3": (128, 64), "recipe_tlm": (100, 32), "gauss": (128, 64), "eval_tlm": (128, 20), "eval_tlm100": (100, 20)}[name]
-        if name == "gauss":
+    if name in ("cfg3", "recipe_tlm", "gauss", "gauss_sample", "eval_tlm", "eval_tlm100"):
+        T, B = {"cfg3": (128, 64), "recipe_tlm": (100, 32), "gauss": (128, 64), "gauss_sample": (128, 64), "eval_tlm": (128, 20),
+                "eval_tlm100": (100, 20)}[name]
+        if name.startswith("gauss"):
             m, kl = M.GaussTransformerModel(V33, 512, 8, 4096, 6, 0.2, True, 3).to(dev), _gauss_kl
+            m.transformerlayers[0].gpnn.sample = name == "gauss_sample"  # train --gp-sample 1: the GP layer re-sampled every step
         else:
             m, kl = M.BayesTransformerModel(V33, 512, 8, 4096, 6, 0.2, True, "FFN").to(dev), _ffn_kl
         is_rnn, Vv, lr = False, V33, 0.1
