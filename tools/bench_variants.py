@@ -51,6 +51,15 @@ def main():
            ns(uncertainty="Bayesian", T_bayes_pos="EMB")),
           ("Transformer Gaussian T_gauss_pos 3 (cfg5)", lambda: M.GaussTransformerModel(V, 512, 8, 4096, 6, 0.2, True, 3),
            ns(uncertainty="Gaussian", T_gauss_pos=3))]
+    def sampled(build):  # round 4: GPNN.sample raised (train --gp-sample 1): the GP tensors re-sampled every step
+        def f():
+            m = build()
+            for g in m.modules():
+                if isinstance(g, M.GPNN):
+                    g.sample = True
+            return m
+        return f
+    tf.append(("Transformer Gaussian T_gauss_pos 3, GPNN.sample raised", sampled(tf[-1][1]), tf[-1][2]))
     if len(sys.argv) < 2 or sys.argv[1] != "lstm":
         for name, build, a in tf:
             run(name, build(), T.kl_selector(a), 128, 64, 0.1)
@@ -74,6 +83,9 @@ def main():
            ns(model="LSTM", uncertainty="Gaussian", L_gauss_pos="64")),
           ("LSTM Gaussian L_gauss_pos 74 (GPNN2 input projection, batched over the window)", lambda: M.GaussRNNModel("LSTM", V, 1024, 1024, 2, 0.2, True, "74"),
            ns(model="LSTM", uncertainty="Gaussian", L_gauss_pos="74"))]
+    for name in ("LSTM Gaussian L_gauss_pos 33", "LSTM Gaussian L_gauss_pos 6360 (README example)", "LSTM Gaussian L_gauss_pos 53 (GPNN on the cell state)"):
+        _, build, a = next(r for r in rn if r[0] == name)
+        rn.append((name + ", GPNN.sample raised", sampled(build), a))
     for name, build, a in rn:
         run(name, build(), T.kl_selector(a), 35, 64, 0.5)
 
