@@ -9,7 +9,6 @@ train.py (tests/golden/train_traj_*.npz) with the bars of the CLI test: same LR-
 interval loss and final checkpoint 1e-3."""
 import io
 import math
-import os
 
 import numpy as np
 import pytest

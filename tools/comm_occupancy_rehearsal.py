@@ -148,7 +148,6 @@ def step_runs(dev, ks, rates, steps, warm, out):
                                     comm_gbps=gbps)
                 tr.reducer.measure = True
                 kl_fn = Bn._kl_fn
-                ev = []
                 for i in range(warm + steps):
                     data, tgt = get_batch(train, i * T, T)
                     if i == warm:
