@@ -21,104 +21,104 @@ from test_train_traj_oracle import load_traj, write_corpus
 pytestmark = pytest.mark.gpu
 
 
-def reference_shaped_run(args, data_dir, init, device):
-    """train.py:167-185, 193-223, 239-258, 299-519 with `model` = the shim module.  Everything that
-    is not the model is torch's own: criterion, zero_grad, clip_grad_norm_, optim.SGD, state_dict save / load."""
+def reference_shaped_run(cfg, data_dir, init, device):
+    """What a maintainer's unchanged training script does around the shim module -- the steps of the
+    reference's train.py:167-185 (column layout), :193-223 (constructors), :239-258 (partial state-dict load), :299-519 (windows,
+    loss, clipping, SGD with momentum, evaluation, best checkpoint / LR halving / fresh optimizer / reload), written here in this
+    file's own words.  Everything that is not the model is torch's own API: nn.CrossEntropyLoss on the logits, zero_grad()
+    (gradients become None), clip_grad_norm_, optim.SGD, state_dict round trips through torch.save / torch.load."""
     import types
     shim = types.ModuleType("model")
     exec("from bayeslms_amd.model import *", shim.__dict__)  # the two-line shim, verbatim
-    from bayeslms_amd import data as refdata  # data.py of the reference: Corpus / Dictionary, same file formats
-    model = shim
+    from bayeslms_amd import data as corpus_io  # same file formats as the reference's data.py
 
-    corpus = refdata.Corpus(data_dir)
+    text = corpus_io.Corpus(data_dir)
+    vocab = len(text.dictionary)
 
-    def batchify(data, bsz):  # train.py:167-179
-        nbatch = data.size(0) // bsz
-        data = data.narrow(0, 0, nbatch * bsz)
-        return data.view(bsz, -1).t().contiguous().to(device)
+    def columns(ids, width):  # the stream cut into `width` contiguous columns
+        rows = ids.size(0) // width
+        return ids[: rows * width].view(width, rows).t().contiguous().to(device)
 
-    eval_batch_size = 20
-    train_data = batchify(corpus.train, args.batch_size)
-    val_data = batchify(corpus.valid, eval_batch_size)
-    test_data = batchify(corpus.test, eval_batch_size)
-    ntokens = len(corpus.dictionary)
-    if args.model == 'Transformer':  # train.py:193-199 (--uncertainty none)
-        net = model.TransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, args.dropout, "gelu", args.tied).to(device)
+    EVAL_COLS = 20
+    streams = {"train": columns(text.train, cfg.batch_size), "valid": columns(text.valid, EVAL_COLS), "test": columns(text.test, EVAL_COLS)}
+    recurrent = cfg.model != 'Transformer'
+    if recurrent:
+        net = shim.RNNModel(cfg.model, vocab, cfg.emsize, cfg.nhid, cfg.nlayers, cfg.dropout, cfg.tied).to(device)
     else:
-        net = model.RNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, args.dropout, args.tied).to(device)
-    criterion = nn.CrossEntropyLoss()
-    model_dict = net.state_dict()  # --prior True, train.py:239-258
-    model_dict.update({k: v for k, v in init.items() if k in model_dict})
-    net.load_state_dict(model_dict)
+        net = shim.TransformerModel(vocab, cfg.emsize, cfg.nhead, cfg.nhid, cfg.nlayers, cfg.dropout, "gelu", cfg.tied).to(device)
+    weights = net.state_dict()
+    weights.update({name: t for name, t in init.items() if name in weights})  # --prior True: keys filtered by name
+    net.load_state_dict(weights)
+    xent = nn.CrossEntropyLoss()
 
-    def repackage_hidden(h):
-        return h.detach() if isinstance(h, torch.Tensor) else tuple(repackage_hidden(v) for v in h)
+    def detach(state):
+        return state.detach() if torch.is_tensor(state) else tuple(detach(s) for s in state)
 
-    def get_batch(source, i):
-        seq_len = min(args.seq_len, len(source) - 1 - i)
-        return source[i:i + seq_len], source[i + 1:i + 1 + seq_len].view(-1)
+    def windows(stream):
+        last = stream.size(0) - 1
+        for start in range(0, last, cfg.seq_len):
+            n = min(cfg.seq_len, last - start)
+            yield stream[start:start + n], stream[start + 1:start + 1 + n].reshape(-1)
 
     hist = {"interval_loss": [], "valid_loss": [], "halved_epochs": []}
 
-    def train(optimizer):
+    def one_epoch(opt):
         net.train()
-        total_loss = 0.
-        hidden = net.init_hidden(args.batch_size) if args.model != 'Transformer' else None
-        for batch, i in enumerate(range(0, train_data.size(0) - 1, args.seq_len)):
-            data, targets = get_batch(train_data, i)
-            optimizer.zero_grad()
-            if args.model == 'Transformer':
-                output = net(data)
+        state = net.init_hidden(cfg.batch_size) if recurrent else None
+        running = 0.0
+        for k, (x, y) in enumerate(windows(streams["train"])):
+            opt.zero_grad()
+            if recurrent:
+                logits, state = net(x, detach(state))
             else:
-                hidden = repackage_hidden(hidden)
-                output, hidden = net(data, hidden)
-            loss = criterion(output.view(-1, ntokens), targets)  # --uncertainty none: kl_loss = 0
-            loss.backward()
-            torch.nn.utils.clip_grad_norm_(net.parameters(), args.clip)
-            optimizer.step()
-            total_loss += loss.item()
-            if batch % args.log_interval == 0 and batch > 0:
-                hist["interval_loss"].append(total_loss / args.log_interval)
-                total_loss = 0.
+                logits = net(x)
+            nll = xent(logits.view(-1, vocab), y)  # --uncertainty none: no KL term
+            nll.backward()
+            torch.nn.utils.clip_grad_norm_(net.parameters(), cfg.clip)
+            opt.step()
+            running += nll.item()
+            if k > 0 and k % cfg.log_interval == 0:
+                hist["interval_loss"].append(running / cfg.log_interval)
+                running = 0.0
 
-    def evaluate(source):
+    def held_out_loss(stream):
         net.eval()
-        total_loss = 0.
-        hidden = net.init_hidden(eval_batch_size) if args.model != 'Transformer' else None
+        state = net.init_hidden(EVAL_COLS) if recurrent else None
+        acc = 0.0
         with torch.no_grad():
-            for i in range(0, source.size(0) - 1, args.seq_len):
-                data, targets = get_batch(source, i)
-                if args.model == 'Transformer':
-                    output = net(data)
+            for x, y in windows(stream):
+                if recurrent:
+                    logits, state = net(x, state)
+                    state = detach(state)
                 else:
-                    output, hidden = net(data, hidden)
-                    hidden = repackage_hidden(hidden)
-                total_loss += len(data) * criterion(output.view(-1, ntokens), targets).item()
-        return total_loss / (len(source) - 1)
+                    logits = net(x)
+                acc += len(x) * xent(logits.view(-1, vocab), y).item()
+        return acc / (stream.size(0) - 1)
 
-    lr, best_val_loss, counter = args.lr, None, 0
-    optimizer = optim.SGD(net.parameters(), lr=args.lr, momentum=0.9, weight_decay=0)
-    saved = io.BytesIO()
-    for epoch in range(1, args.epochs + 1):
-        train(optimizer)
-        val_loss = evaluate(val_data)
-        hist["valid_loss"].append(val_loss)
-        if not best_val_loss or val_loss < best_val_loss:
-            saved = io.BytesIO()
-            torch.save(net.state_dict(), saved)
-            best_val_loss = val_loss
+    def fresh_sgd(rate):
+        return optim.SGD(net.parameters(), lr=rate, momentum=0.9, weight_decay=0)
+
+    rate, best, halvings = cfg.lr, None, 0
+    opt = fresh_sgd(rate)
+    kept = io.BytesIO()
+    for epoch in range(1, cfg.epochs + 1):
+        one_epoch(opt)
+        v = held_out_loss(streams["valid"])
+        hist["valid_loss"].append(v)
+        if best is None or v < best:  # (the reference's `not best` treats 0.0 like None; a loss never is)
+            best, kept = v, io.BytesIO()
+            torch.save(net.state_dict(), kept)
         else:
-            lr /= 2.
-            optimizer = optim.SGD(net.parameters(), lr=lr, momentum=0.9, weight_decay=0)
-            saved.seek(0)
-            net.load_state_dict(torch.load(saved, map_location=lambda storage, loc: storage))
-            counter += 1
+            rate, halvings = rate / 2.0, halvings + 1
+            opt = fresh_sgd(rate)  # momentum buffers gone
+            kept.seek(0)
+            net.load_state_dict(torch.load(kept, map_location="cpu"))
             hist["halved_epochs"].append(epoch)
-        if counter == 8:
+        if halvings == 8:
             break
-    saved.seek(0)
-    net.load_state_dict(torch.load(saved, map_location=lambda storage, loc: storage))
-    hist["test_loss"] = evaluate(test_data)
+    kept.seek(0)
+    net.load_state_dict(torch.load(kept, map_location="cpu"))
+    hist["test_loss"] = held_out_loss(streams["test"])
     hist["final"] = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     assert math.isfinite(hist["test_loss"])
     return hist
