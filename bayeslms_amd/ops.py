@@ -1241,6 +1241,7 @@ class _LSTMLayer(torch.autograd.Function):
         if _STATE_TAP is not None:
             _STATE_TAP.layers.append((hs.index_select(0, _STATE_TAP.idx), cs.index_select(0, _STATE_TAP.idx)))
         ctx.save_for_backward(x, hs, cs, ga, w_ih, w_hh)
+        ctx.w_refs = (w_ih, w_hh)  # the parameter objects themselves (their .grad is the accumulation target)
         ctx.has_noise = noise_rows is not None
         return hs[1:], hs[T], cs[T]
 
@@ -1308,12 +1309,22 @@ class _LSTMLayer(torch.autograd.Function):
                 _colsum_into(tot[t], B, H, d_noise[t], accumulate=False)
         dx = torch.empty_like(x)
         gemm(L.GEMM_NN, dgates, w_ih, dx, T * B, E, G, G, E, E)
-        dw_ih = torch.empty_like(w_ih)
+        # leaf weights (nn.LSTM-style parameters) accumulate straight into .grad like every other wgrad of the engine -- returned
+        # to autograd they cost an AccumulateGrad add over 16.8 MB each at H = 1024 (~10 us per weight and step); sampled
+        # (non-leaf) weights of Bayes2LSTM get a fresh gradient tensor for their sampling node
+        w_ih_p, w_hh_p = ctx.w_refs
         db = torch.zeros(G, device=dev, dtype=torch.float32)
-        # the bias gradient = column sums of dgates, taken from the A tiles this weight-gradient GEMM stages anyway
-        gemm(L.GEMM_TN, dgates, x, dw_ih, G, E, T * B, G, E, E, colsum_a=db)
-        dw_hh = torch.empty_like(w_hh)
-        gemm(L.GEMM_TN, dgates, hs, dw_hh, G, H, T * B, G, H, H)  # hs[0:T] = h_{t-1}
+        dw_ih = dw_hh = None
+        if ctx.needs_input_grad[3]:
+            buf_ih, acc_ih, dw_ih = _wgrad_target(w_ih_p)
+            # the bias gradient = column sums of dgates, taken from the A tiles this weight-gradient GEMM stages anyway
+            gemm(L.GEMM_TN, dgates, x, buf_ih, G, E, T * B, G, E, E, accumulate=acc_ih, colsum_a=db)
+        else:
+            _colsum_into(dgates, T * B, G, db, accumulate=False)
+        if ctx.needs_input_grad[4]:
+            buf_hh, acc_hh, dw_hh = _wgrad_target(w_hh_p)
+            gemm(L.GEMM_TN, dgates, hs, buf_hh, G, H, T * B, G, H, H, accumulate=acc_hh)  # hs[0:T] = h_{t-1}
+        _notify(w_ih_p, w_hh_p)
         return dx, dh, dc, dw_ih, dw_hh, db, db, d_noise
 
 
@@ -1435,6 +1446,7 @@ class _LSTMStack2(torch.autograd.Function):
             _STATE_TAP.layers.append((hs1.index_select(0, _STATE_TAP.idx), cs1.index_select(0, _STATE_TAP.idx)))
             _STATE_TAP.layers.append((hs2.index_select(0, _STATE_TAP.idx), cs2.index_select(0, _STATE_TAP.idx)))
         ctx.save_for_backward(x, hs1, cs1, ga1, hs2, cs2, ga2, x2, w_ih1, w_hh1, w_ih2, w_hh2)
+        ctx.w_refs = (w_ih1, w_hh1, w_ih2, w_hh2)
         ctx.drop = drop
         return hs2[1:], hs1[T], cs1[T], hs2[T], cs2[T]
 
@@ -1510,11 +1522,17 @@ class _LSTMStack2(torch.autograd.Function):
         inp2 = x2 if drop.on else hs1[1:]
         dx = torch.empty_like(x)
         gemm(L.GEMM_NN, dg1, w_ih1, dx, T * B, E, G, G, E, E)
-        dw_ih1, dw_hh1, dw_ih2, dw_hh2 = torch.empty_like(w_ih1), torch.empty_like(w_hh1), torch.empty_like(w_ih2), torch.empty_like(w_hh2)
-        gemm(L.GEMM_TN, dg1, x, dw_ih1, G, E, T * B, G, E, E)
-        gemm(L.GEMM_TN, dg1, hs1, dw_hh1, G, H, T * B, G, H, H)  # hs[0:T] = h_{t-1}
-        gemm(L.GEMM_TN, dg2, inp2, dw_ih2, G, H, T * B, G, H, H)
-        gemm(L.GEMM_TN, dg2, hs2, dw_hh2, G, H, T * B, G, H, H)
+        # leaf weights accumulate straight into .grad (see _LSTMLayer.backward); sampled ones get fresh tensors
+        outs = []
+        for w_p, A, Bm, kdim in ((ctx.w_refs[0], dg1, x, E), (ctx.w_refs[1], dg1, hs1, H), (ctx.w_refs[2], dg2, inp2, H), (ctx.w_refs[3], dg2, hs2, H)):
+            if not w_p.requires_grad:
+                outs.append(None)
+                continue
+            buf, acc, ret = _wgrad_target(w_p)
+            gemm(L.GEMM_TN, A, Bm, buf, G, kdim, T * B, G, kdim, kdim, accumulate=acc)  # hs[0:T] = h_{t-1}
+            outs.append(ret)
+        _notify(*ctx.w_refs)
+        dw_ih1, dw_hh1, dw_ih2, dw_hh2 = outs
         db1, db2 = new(G), new(G)
         _colsum_into(dg1, T * B, G, db1, accumulate=False)
         _colsum_into(dg2, T * B, G, db2, accumulate=False)

@@ -141,8 +141,8 @@ def _run_eval(rank, world, port, ret, family):
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     m, _, _ = _build(dev, family)
-    stream = torch.randint(0, 150, (5 * 83 + 3,), generator=torch.Generator().manual_seed(9))
-    valid = D.batchify(stream, 5, dev)  # 5 columns: an uneven split over 2 or 3 ranks, and more ranks than columns at 7
+    stream = torch.randint(0, 150, (4 * 83 + 3,), generator=torch.Generator().manual_seed(9))
+    valid = D.batchify(stream, 4, dev)  # 4 columns: an uneven split over 3 ranks, and more ranks than columns at 5
     ret[(world, rank)] = engine.evaluate(m, valid, 12, rank=rank, world=world)
     if world > 1:
         dist.destroy_process_group()
@@ -152,12 +152,13 @@ def _run_eval(rank, world, port, ret, family):
 def test_sharded_evaluation_equals_the_single_process_pass(family):
     """engine.evaluate(rank, world): rank r evaluates its share of the evaluation batch's columns (independent streams; the
     LSTM's carried state is per column) and one 8-byte all-reduce joins the token-weighted sums -- the loss train.py:441-458
-    computes, on every rank, for 2, 3 and (more ranks than columns) 6 ranks."""
+    computes, on every rank, for 2, 3 and (more ranks than columns) 5 ranks.  (The GPU box allows 6 processes on the card at
+    once and the test runner itself is one of them: 5 ranks at most.)"""
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_run_eval, args=(1, _free_port(), ret, family), nprocs=1, join=True)
         one = ret[(1, 0)]
-        for world in (2, 3, 6):
+        for world in (2, 3, 5):
             mp.spawn(_run_eval, args=(world, _free_port(), ret, family), nprocs=world, join=True)
             vals = [ret[(world, r)] for r in range(world)]
             assert all(v == vals[0] for v in vals), vals
