@@ -90,6 +90,8 @@ SIGNATURES = {
     "blm_gemm_plan_override": (_i, [_i, _i]),
     "blm_gemm_plan_set": (_i, [_i] * 8),
     "blm_gemm_plan_clear": (_i, [_i]),
+    "blm_mfma_probe_ws_floats": (_i64, []),
+    "blm_mfma_probe": (_i, [_vp, _i, C.POINTER(C.c_double), _vp]),
     "blm_set_option": (_i, [C.c_char_p, _i]),
     "blm_get_option": (_i, [C.c_char_p, C.POINTER(C.c_int)]),
     "blm_gemm_plan_set_cus": (_i, [_i]),

@@ -79,3 +79,35 @@ extern "C" int blm_get_option(const char* name, int* value) {
     if (!strcmp(e.name, name)) { opt_init(e); *value = e.value; return BLM_OK; }
   return blm_fail(BLM_ERR_INVALID, "blm_get_option: unknown option '%s'", name);
 }
+
+
+// ---- what THIS chip sustains: a bare v_mfma_f32_32x32x2_f32 loop, no memory traffic --------------------------------
+// bench.py times it (HIP events) right after the headline run: boxes of the pool hold different clocks under matrix load (round 4:
+// 134.8 TFLOP/s = 2.05 GHz on one, 143-147 TFLOP/s = 2.2-2.3 GHz on the others), and the step follows the clock.  512 workgroups of
+// 4 waves = two waves per SIMD on every CU, four independent accumulator chains per wave, `iters` x 4 MFMAs per wave.
+namespace {
+using probe_f32x16 = __attribute__((ext_vector_type(16))) float;
+__global__ __launch_bounds__(256) void mfma_probe_kernel(float* out, int iters, float seed) {
+  probe_f32x16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+  const float x = seed + threadIdx.x * 1e-3f, y = seed * 0.5f + threadIdx.x * 2e-3f;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+}  // namespace
+
+extern "C" int64_t blm_mfma_probe_ws_floats(void) { return 512 * 256; }
+
+extern "C" int blm_mfma_probe(float* ws, int iters, double* flops, void* stream) {
+  if (!ws || iters < 1 || iters > (1 << 22)) return blm_fail(BLM_ERR_INVALID, "blm_mfma_probe: bad arguments");
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(512), dim3(256), 0, static_cast<hipStream_t>(stream), ws, iters, 0.37f);
+  BLM_HIP(hipGetLastError());
+  if (flops) *flops = 512.0 * 4.0 * (double)iters * 4.0 * 4096.0;  // workgroups x waves x iterations x MFMAs x 2*32*32*2 flops
+  return BLM_OK;
+}

@@ -746,6 +746,28 @@ def main():
         valid = batchify(synthetic_corpus(V, 20 * (4 * T + 1), seed=2222), 20, dev)
         eval_ppl = math.exp(min(engine.evaluate(model, valid, T), 50.0))
 
+    chip = None
+    if rank == 0:
+        # what THIS chip sustains under matrix load: a bare fp32 MFMA loop (no memory traffic, two waves per SIMD on every CU) timed
+        # with HIP events right after the run -- the boxes of the pool differ by up to 10 % here (round 4: 134.8 against 143-147
+        # TFLOP/s), and the step follows the clock.  Outside the timed region; context for `roofline` / `step_roofline`, never part of them
+        try:
+            import ctypes as C
+            from bayeslms_amd import _lib as L
+            ws = torch.empty(int(L.lib().blm_mfma_probe_ws_floats()), device=dev)
+            fl = C.c_double(0.0)
+            L.check(L.lib().blm_mfma_probe(ws.data_ptr(), 2000, C.byref(fl), L.stream()), "blm_mfma_probe")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            L.check(L.lib().blm_mfma_probe(ws.data_ptr(), 20000, C.byref(fl), L.stream()), "blm_mfma_probe")
+            e1.record()
+            torch.cuda.synchronize()
+            tf = fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+            chip = {"bare_mfma_tflops": round(tf, 1), "implied_clock_ghz": round(tf * 1e12 / (256 * 4 * 64.0) / 1e9, 2),
+                    "note": "v_mfma_f32_32x32x2_f32 loop without memory traffic on this box, right after the timed steps (blm_mfma_probe): "
+                            "the datasheet peak assumes 2.4 GHz"}
+        except Exception as e:  # noqa: BLE001
+            chip = {"error": repr(e)}
     if rank == 0:
         tokens = args.steps * T * Bc * world
         kt = timer.summary()
@@ -767,6 +789,8 @@ def main():
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes": 4 * (M_ * K_ + N_ * K_ + M_ * N_),
                     "avg_launch_ms": round(ms, 4), "launches": kt["sampled_gemm_fwd"]["n"]}
+            if chip and chip.get("bare_mfma_tflops"):
+                roof["frac_of_this_chips_bare_mfma_rate"] = round(ach / chip["bare_mfma_tflops"], 4)
         out = {
             "metric": "train_tokens_per_sec", "value": round(tokens / elapsed, 1), "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -778,6 +802,7 @@ def main():
                        "global_batch": Bc * world, "seq_len": T, "parallelism": "dp%d" % world,
                        "fused_sampling": bool(model.noise_state.fused)},
             "roofline": roof,
+            "chip": chip,
             # whole step against the same peak: SURVEY 8(d) model FLOPs, 3 x (L(2d3d + 4Td + 2d^2 + 4d ff) + 2dV) per token
             "step_roofline": {"bound": "mfma", "model_flops_per_token": STEP_FLOPS_PER_TOKEN,
                               "achieved": round(STEP_FLOPS_PER_TOKEN * tokens / world / elapsed / 1e12, 2),

@@ -250,6 +250,11 @@ int blm_linear_nll2(const float* x1, int64_t ldx1, const float* w1, int64_t ldw1
  *   "lstm_pipe"  (BLM_LSTM_PIPE,  1) software-pipelined K loop of the LSTM step kernels
  *   "lstm_tail"  (BLM_LSTM_TAIL,  0) 1: the general (K tail) form of the pipelined LSTM step kernels also for whole chunks
  * No reference counterpart (the reference leaves kernel selection to the vendor libraries behind torch). */
+/* Diagnostic, no reference counterpart: a bare v_mfma_f32_32x32x2_f32 loop (two waves per SIMD on every CU, no memory traffic),
+ * `iters` x 4 MFMAs per wave; *flops receives the work of the launch.  The caller times it (bench.py: "chip.bare_mfma_tflops") --
+ * what THIS chip sustains under matrix load, which differs between boxes by up to 10 %.  ws: blm_mfma_probe_ws_floats() floats. */
+int64_t blm_mfma_probe_ws_floats(void);
+int blm_mfma_probe(float* ws, int iters, double* flops, void* stream);
 int blm_set_option(const char* name, int value);
 int blm_get_option(const char* name, int* value);
 
