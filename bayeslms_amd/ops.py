@@ -66,6 +66,12 @@ class NoiseSpec:
 def _variational(lgstd, noise, row_lo, srows):
     v = L.Variational()
     v.lgstd = ptr(lgstd)
+    if noise is not None and noise.eps is not None:
+        e = noise.eps
+        # an injected eps is read by the kernels with lgstd's extent on trust: a wrong shape would read past it
+        if not (torch.is_tensor(e) and e.is_cuda and e.dtype == torch.float32 and e.is_contiguous() and e.numel() == lgstd.numel()):
+            raise BayesLMError("injected eps must be a contiguous fp32 GPU tensor with lgstd's %d elements, got %s"
+                               % (lgstd.numel(), (tuple(e.shape), e.dtype, e.device) if torch.is_tensor(e) else type(e)))
     v.eps = ptr(noise.eps) if (noise is not None and noise.eps is not None) else None
     v.row_lo = int(row_lo)
     v.srows = int(srows)

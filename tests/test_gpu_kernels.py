@@ -307,6 +307,17 @@ def test_linear_nll_out_of_range_target_is_nan_not_garbage(dev):
     assert bad.tolist() == [i in (2, 5) for i in range(9)]
 
 
+def test_injected_eps_of_the_wrong_extent_is_refused(dev):
+    """The kernels read an injected eps with lgstd's extent on trust; a mis-shaped, non-contiguous or CPU eps raises on the host."""
+    ops, lib = ops_mod(), L()
+    mu, lg = torch.zeros(8, 12, device=dev), torch.zeros(8, 12, device=dev)
+    ok = ops.sample_weight(mu, lg, ops.NoiseSpec(eps=torch.ones(8, 12, device=dev)))
+    assert torch.equal(ok, torch.ones(8, 12, device=dev))
+    for bad in (torch.ones(8, 11, device=dev), torch.ones(12, 8, device=dev).t(), torch.ones(8, 12), torch.ones(8, 12, device=dev).double()):
+        with pytest.raises(lib.BayesLMError, match="injected eps"):
+            ops.sample_weight(mu, lg, ops.NoiseSpec(eps=bad))
+
+
 def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric B catches a transposed C write (cdna guide section 3)."""
     ops, lib = ops_mod(), L()
