@@ -293,21 +293,36 @@ def _tiny_corpus(dtmp, nwords=30, seed=5, sizes=(("train", 260), ("valid", 40), 
     return words, texts
 
 
-def f7_scorer():
+SCORER_CASES = (
+    ("lstm_bayes3", ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Bayesian",
+                     "--L_bayes_pos", "3"],
+     lambda V: ref.BayesRNNModel("LSTM", V, 12, 12, 2, 0.5, True, 3)),
+    ("tlm_ffn", ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                 "--uncertainty", "Bayesian", "--T_bayes_pos", "FFN"],
+     lambda V: ref.BayesTransformerModel(V, 16, 4, 32, 2, 0.5, True, "FFN")),
+)
+# round 4: the Gaussian / Variational branches of the reference scorer (:391-447; GaussRNNModel is built UNTIED there, :428-429)
+SCORER_CASES_GP = (
+    ("tlm_gauss3", ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                    "--uncertainty", "Gaussian", "--T_gauss_pos", "3"],
+     lambda V: ref.GaussTransformerModel(V, 16, 4, 32, 2, 0.5, True, 3)),
+    ("lstm_gauss33", ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Gaussian",
+                      "--L_gauss_pos", "33"],
+     lambda V: ref.GaussRNNModel("LSTM", V, 12, 12, 2, 0.5, False, "33")),
+    ("lstm_var11", ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Variational",
+                    "--L_v_pos", "11"],
+     lambda V: ref.VariationalRNNModel("LSTM", V, 12, 12, 2, 0.5, True, "11")),
+)
+
+
+def f7_scorer(cases=None):
     """Drives the reference scorer's main() on CPU (its hard-coded .cuda() calls are patched to
     identity in this process) and keeps its output file as the vector."""
     import importlib
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self
     scorer = importlib.import_module("compute_sentence_scores_bayes_jianwei")
-    for tag, margs, build in (
-        ("lstm_bayes3", ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Bayesian",
-                         "--L_bayes_pos", "3"],
-         lambda V: ref.BayesRNNModel("LSTM", V, 12, 12, 2, 0.5, True, 3)),
-        ("tlm_ffn", ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
-                     "--uncertainty", "Bayesian", "--T_bayes_pos", "FFN"],
-         lambda V: ref.BayesTransformerModel(V, 16, 4, 32, 2, 0.5, True, "FFN")),
-    ):
+    for tag, margs, build in (cases or SCORER_CASES):
         with tempfile.TemporaryDirectory() as dtmp:
             words, _ = _tiny_corpus(dtmp)
             rng = np.random.RandomState(11)
@@ -971,6 +986,9 @@ if __name__ == "__main__":
         f9_search_models()
         f9_search_loop()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "scorer_gp":
+        f7_scorer(SCORER_CASES_GP)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gp_sample":
         for gp in (1, 2, 3):
             f4_gauss_transformer_sample(gp)
@@ -1019,5 +1037,6 @@ if __name__ == "__main__":
     for gp in (1, 2, 3):
         f4_gauss_transformer_sample(gp)
     f5_gauss_rnn_sample()
+    f7_scorer(SCORER_CASES_GP)
     f6_train_trajectory()
     f5_vtransformer_11()

@@ -364,7 +364,7 @@ def test_evaluate_reference_checkpoint(dev, tag, tmp_path):
         assert abs(got - float(g[split + "_loss"])) < 1e-4 * float(g[split + "_loss"]), (split, got)
 
 
-@pytest.mark.parametrize("tag", ["tlm_ffn", "lstm_bayes3"])
+@pytest.mark.parametrize("tag", ["tlm_ffn", "lstm_bayes3", "tlm_gauss3", "lstm_gauss33", "lstm_var11"])
 def test_scorer_cli_matches_reference_output(dev, tag, tmp_path):
     """Same n-best file, vocabulary and model.pt as the reference scorer run -> same score file."""
     import os
@@ -510,6 +510,37 @@ def test_mc_sample_scoring_gp_and_variational_families(dev, fam, pos):
                 p.fill_(-50.0)
     got = S.compute_scores_batched(nbest, m, vocab, mtype, dev, mc_samples=2, seed=seed)
     for a, b in zip([v for hv in got.values() for _, v in hv], mflat):
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(b))
+
+
+@pytest.mark.parametrize("tag", ["tlm_gauss3", "lstm_gauss33", "lstm_var11"])
+def test_mc_scoring_with_vanishing_sigma_reproduces_the_reference_scorer_file(dev, tag):
+    """The reference scorer's own files for its Gaussian / Variational branches (fixtures scorer_tlm_gauss3, scorer_lstm_gauss33,
+    scorer_lstm_var11): with sigma -> 0 the Monte-Carlo scorer (sample flags raised, noise on) gives them back; with the
+    checkpoint's own sigma the samples move the scores."""
+    from bayeslms_amd import compute_sentence_scores as S, model as M
+    g, sd, _ = load_golden("scorer_" + tag)
+    vocab, nbest = _scorer_nbest(g)
+    V = len(vocab)
+    m, mtype = {"tlm_gauss3": lambda: (M.GaussTransformerModel(V, 16, 4, 32, 2, 0.5, True, 3), "Transformer"),
+                "lstm_gauss33": lambda: (M.GaussRNNModel("LSTM", V, 12, 12, 2, 0.5, False, "33"), "LSTM"),
+                "lstm_var11": lambda: (M.VariationalRNNModel("LSTM", V, 12, 12, 2, 0.5, True, "11"), "LSTM")}[tag]()
+    own = m.state_dict()
+    own.update({k: v for k, v in sd.items() if k in own and tuple(v.shape) == tuple(own[k].shape)})
+    m.load_state_dict(own)
+    m = m.to(dev)
+    ref = [float(ln.split()[1]) for ln in str(g["scores_txt"]).splitlines()]
+    mean = [v for hv in S.compute_scores_batched(nbest, m, vocab, mtype, dev).values() for _, v in hv]
+    for a, b in zip(mean, ref):
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(b))
+    mc = [v for hv in S.compute_scores_batched(nbest, m, vocab, mtype, dev, mc_samples=4, seed=5).values() for _, v in hv]
+    assert any(abs(a - b) > 1e-4 for a, b in zip(mc, ref))
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if "lgstd" in k:
+                p.fill_(-50.0)
+    mc0 = [v for hv in S.compute_scores_batched(nbest, m, vocab, mtype, dev, mc_samples=2, seed=5).values() for _, v in hv]
+    for a, b in zip(mc0, ref):
         assert abs(a - b) <= 1e-3 * max(1.0, abs(b))
 
 
