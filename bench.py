@@ -733,10 +733,18 @@ def main():
     ops.set_kernel_timer(None)
     tr.reducer.measure = False
     comm_exposed = tr.reducer.comm_exposed_ms()
+    replicas_identical = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # outside the timed region: are the replicas still in lock step?  Every rank applied the same all-reduced gradient with the
+        # same clip + SGD arithmetic, so the parameter buffers must be bit-identical: two checksums per rank, gathered and compared
+        fp = tr.flat.flat_param
+        mine = torch.stack([fp.double().sum(), fp.double().abs().sum()]).to(dev)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        replicas_identical = all(bool(torch.equal(e, every[0])) for e in every)
     final_loss = float(loss)
     # eval PPL (the other half of BASELINE.json's metric): mean-weight forward on held-out synthetic
     # text exactly as train.py:441-458 (eval batch 20), outside the timed region
@@ -823,7 +831,9 @@ def main():
                 "grad_bytes": int(tr.flat.total * 4),
                 # RCCL channel count as pinned before init_process_group (engine.pin_rccl_channels) and the CUs the GEMM
                 # planner leaves to the channel workgroups while buckets are in flight
-                "rccl_env": rccl_env, "gemm_cus_under_comm": 256 - tr.reducer.comm_cus,
+                "rccl_env": rccl_env, "gemm_cus_under_comm": 256 - tr.reducer.comm_cus, "comm_plan": tr.reducer.comm_plan,
+                # parameter checksums of all ranks after the last step, gathered and compared (outside the timed region)
+                "replicas_identical": replicas_identical,
                 "late_rows": tr.reducer.late is not None,
                 "late_rows_last_step": None if tr.reducer.late is None else int(tr.reducer.late.U)},
         }

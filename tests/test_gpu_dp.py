@@ -245,3 +245,4 @@ def test_bench_gpus2_self_launch_rehearsal_on_one_device():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0
     assert out["comm_exposed_ms"] is not None and out["comm"]["late_rows"] and out["comm"]["late_rows_last_step"] > 0
+    assert out["comm"]["replicas_identical"] is True  # parameter checksums of both ranks, gathered after the last step
