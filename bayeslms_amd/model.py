@@ -179,6 +179,7 @@ class _ProjHolder(nn.Module):
     # inference only (two-model scoring): the DECODER hands back its input rows instead of logits -- the interpolated decoder +
     # cross-entropy launch (ops.linear_nll_interp) takes both models' rows at once
     return_input = False
+    is_decoder = False  # set by _LMHead._init_io for the vocabulary projection
 
     def forward(self, x, link=None):
         if self.rows is not None:
@@ -193,7 +194,8 @@ class _ProjHolder(nn.Module):
             if torch.is_grad_enabled():
                 raise BayesLMError("_ProjHolder.nll_targets is an inference-only path")
             return ops.linear_nll(x, self.weight, self.bias, self.nll_targets)
-        return ops.linear(x, self.weight, self.bias, link)
+        out = ops.linear(x, self.weight, self.bias, link)
+        return ops.as_logits(out) if self.is_decoder else out  # grad mode: F.cross_entropy on it runs the engine's kernels (ops.Logits)
 
 
 def _need_causal(attn_mask):
@@ -311,6 +313,7 @@ class _LMHead(_Site):
     def _init_io(self, ntoken, ninp, nout, tie_weights):
         self.encoder = nn.Embedding(ntoken, ninp)
         self.decoder = _ProjHolder(nout, ntoken)
+        self.decoder.is_decoder = True
         if tie_weights:
             self.decoder.weight = self.encoder.weight
         nn.init.uniform_(self.encoder.weight, -0.1, 0.1)  # model.py:1264-1268 / :211-215

@@ -950,7 +950,7 @@ class _CrossEntropy(torch.autograd.Function):
     gradient kernel with the real upstream scalar.  Either way the logits buffer is consumed."""
 
     @staticmethod
-    def forward(ctx, logits, targets, unit_grad):
+    def forward(ctx, logits, targets, unit_grad, keep=False):
         logits = _f32(logits, "logits")
         targets = dev_tensor(targets, "targets", torch.int64)
         V = logits.shape[-1]
@@ -967,20 +967,23 @@ class _CrossEntropy(torch.autograd.Function):
                                    ptr(logits) if fuse else None, 1.0 / M, M, V, stream()), "blm_ce_fwd_bwd")
         if fuse:  # the buffer now holds the gradient: any other autograd consumer of the logits must fail, not read it
             torch.autograd.graph.increment_version(logits)
-        ctx.meta = (logits, targets, lse, fuse, M, V)
+        ctx.meta = (logits, targets, lse, fuse, M, V, keep)
         ctx.mark_non_differentiable(nll)
         return loss / M, nll
 
     @staticmethod
     def backward(ctx, g, _g_nll):
-        logits, targets, lse, fuse, M, V = ctx.meta
+        logits, targets, lse, fuse, M, V, keep = ctx.meta
         if fuse:
-            return logits, None, None
+            return logits, None, None, None
         g = _f32(g.reshape(1), "g")
-        check(lib().blm_ce_bwd(ptr(logits), V, ptr(targets), ptr(lse), ptr(g), 1.0 / M, ptr(logits), M, V, stream()),
+        # keep: the caller's logits stay what they are (a user loop may still read them after backward): the gradient gets its own buffer
+        out = torch.empty_like(logits) if keep else logits
+        check(lib().blm_ce_bwd(ptr(logits), V, ptr(targets), ptr(lse), ptr(g), 1.0 / M, ptr(out), M, V, stream()),
               "blm_ce_bwd")
-        torch.autograd.graph.increment_version(logits)
-        return logits, None, None
+        if not keep:
+            torch.autograd.graph.increment_version(logits)
+        return out, None, None, None
 
 
 def cross_entropy(logits, targets, unit_grad=False):
@@ -989,7 +992,50 @@ def cross_entropy(logits, targets, unit_grad=False):
     read anything else you need from the logits BEFORE calling this).  ``unit_grad=True`` is the trainers' contract
     only: the loss enters the objective with coefficient exactly 1 (train.py:412) and the upstream gradient is not
     looked at."""
+    if type(logits) is not torch.Tensor:
+        logits = logits.as_subclass(torch.Tensor)  # model outputs are `Logits` in grad mode (below); the op wants the plain tensor
     return _CrossEntropy.apply(logits, targets, unit_grad)
+
+
+class Logits(torch.Tensor):
+    """What a language model's decoder returns in grad mode: a plain fp32 tensor to every consumer, except that
+    ``torch.nn.functional.cross_entropy`` on it (the reference loop's ``criterion(output.view(-1, ntokens), targets)``,
+    train.py:332 with ``nn.CrossEntropyLoss()``) runs the engine's one-pass cross-entropy kernels instead of torch's
+    log-softmax + NLL chain over the (M, V) logits -- an unchanged reference training script gets them by importing the shim
+    (INTEGRATION.md level 1).  Non-destructive here: the logits keep their values, the gradient gets its own buffer.  Only the
+    default loss takes the short cut (mean reduction, no class weights, no label smoothing, ignore_index at its default with no
+    negative targets expected in LM data); anything else falls through to torch.  ``view`` / ``reshape`` / ``contiguous`` /
+    ``flatten`` keep the type (so the reshaped logits still reach the loss as ``Logits``); every other operation returns plain
+    tensors."""
+
+    _KEEP = None  # filled below: the shape-only ops that preserve the type
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.nn.functional.cross_entropy:
+            inp = args[0] if len(args) > 0 else kwargs.get("input")
+            tgt = args[1] if len(args) > 1 else kwargs.get("target")
+            plain = (kwargs.get("weight") is None and kwargs.get("reduction", "mean") == "mean" and kwargs.get("label_smoothing", 0.0) == 0.0
+                     and kwargs.get("ignore_index", -100) == -100 and kwargs.get("size_average") is None and kwargs.get("reduce") is None
+                     and len(args) <= 2 and torch.is_tensor(inp) and torch.is_tensor(tgt) and inp.dim() == 2 and tgt.dim() == 1
+                     and inp.is_cuda and inp.dtype == torch.float32 and tgt.dtype == torch.int64 and tgt.numel() == inp.shape[0])
+            if plain:
+                with torch._C.DisableTorchFunctionSubclass():
+                    return _CrossEntropy.apply(inp.as_subclass(torch.Tensor), tgt, False, True)[0]
+        if func in cls._KEEP:
+            return super().__torch_function__(func, types, args, kwargs)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
+Logits._KEEP = frozenset([torch.Tensor.view, torch.Tensor.reshape, torch.Tensor.contiguous, torch.Tensor.flatten, torch.flatten,
+                          torch.reshape, torch.Tensor.view_as, torch.Tensor.reshape_as])
+
+
+def as_logits(t):
+    """Decoder output of a language model in grad mode (see Logits)."""
+    return t.as_subclass(Logits) if (torch.is_grad_enabled() and type(t) is torch.Tensor) else t
 
 
 def cross_entropy_interp(logits_a, logits_b, alpha, targets):

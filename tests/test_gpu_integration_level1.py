@@ -165,3 +165,42 @@ def test_zero_grad_set_to_none_keeps_no_stale_gradient(tmp_path):
     for k in grads[0]:  # (float atomics in the LayerNorm / split-K reductions: equal to rounding, not bit for bit)
         a, b = grads[0][k], grads[1][k]
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-9, k
+
+
+def test_torch_cross_entropy_on_model_logits_runs_the_engine_kernels(monkeypatch):
+    """The unchanged reference loop calls nn.CrossEntropyLoss on `output.view(-1, ntokens)`.  In grad mode the decoder returns
+    ops.Logits, on which F.cross_entropy takes the engine's one-pass kernels (non-destructively): same loss and gradient as torch's
+    own chain on a plain copy, the logits keep their values after backward, and non-default losses fall through to torch."""
+    from bayeslms_amd import model as M, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    V = 60
+    m = M.TransformerModel(V, 32, 4, 64, 2, 0.0, "gelu", True).to(dev)
+    x = torch.randint(0, V, (12, 5), device=dev)
+    t = torch.randint(0, V, (60,), device=dev)
+    calls = []
+    real = ops._CrossEntropy.apply
+    monkeypatch.setattr(ops._CrossEntropy, "apply", staticmethod(lambda *a: (calls.append(a[2:]), real(*a))[1]))
+    m.train()
+    out = m(x)
+    assert type(out) is ops.Logits and type(out.view(-1, V)) is ops.Logits and type(out * 2.0) is torch.Tensor
+    before = out.detach().clone()
+    loss = nn.CrossEntropyLoss()(out.view(-1, V), t)
+    assert calls == [(False, True)] and type(loss) is torch.Tensor
+    loss.backward()
+    assert torch.equal(out.detach().as_subclass(torch.Tensor), before)  # the user's logits are untouched
+    g_engine = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    plain = m(x).as_subclass(torch.Tensor)
+    ref = torch.nn.functional.cross_entropy(plain.view(-1, V), t)  # torch's own log-softmax + NLL chain
+    assert len(calls) == 1 and abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+    ref.backward()
+    for k, p in m.named_parameters():
+        assert float((p.grad - g_engine[k]).abs().max()) <= 2e-5 * float(g_engine[k].abs().max()) + 1e-9, k
+    # anything but the default loss is torch's business
+    nn.CrossEntropyLoss(reduction="sum")(m(x).view(-1, V), t)
+    nn.CrossEntropyLoss(label_smoothing=0.1)(m(x).view(-1, V), t)
+    assert len(calls) == 1
+    m.eval()
+    with torch.no_grad():
+        assert type(m(x)) is torch.Tensor
