@@ -354,7 +354,8 @@ def cli_leg(dev, args, headline_ms):
 
 def level1_leg(dev, args, headline_ms):
     """INTEGRATION.md level 1 priced: the headline model under the REFERENCE's loop shape (train.py:306-438) -- only `import model`
-    swapped: torch's nn.CrossEntropyLoss on the (8192 x 33000) logits, optimizer.zero_grad() (gradients to None: the in-place
+    swapped: nn.CrossEntropyLoss() on the (8192 x 33000) logits (ops.Logits: the engine's kernels, non-destructively),
+    optimizer.zero_grad() (gradients to None: the in-place
     weight-gradient kernels re-create their zeroed buffers every step), model...kl_divergence() added to the loss and
     back-propagated by autograd, torch.nn.utils.clip_grad_norm_, torch.optim.SGD(momentum 0.9) -- beside engine.Trainer."""
     import torch.nn as nn
@@ -381,8 +382,9 @@ def level1_leg(dev, args, headline_ms):
         opt.step()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
-    return {"config": "INTEGRATION.md level 1: `from bayeslms_amd.model import *` under the reference's own loop (torch CrossEntropyLoss, "
-                      "zero_grad(), clip_grad_norm_, optim.SGD), headline configuration",
+    return {"config": "INTEGRATION.md level 1: `from bayeslms_amd.model import *` under the reference's own loop (nn.CrossEntropyLoss() -- on the "
+                      "models' ops.Logits output it runs the engine's cross-entropy kernels --, zero_grad(), clip_grad_norm_, optim.SGD), "
+                      "headline configuration",
             "value": round(T * Bc / ms * 1e3, 1), "unit": "tokens/s", "ms_per_step": round(ms, 3), "loss_finite": bool(torch.isfinite(loss)),
             "vs_engine_trainer_step": round(ms / headline_ms, 4), "step_roofline": _frac(tlm_flops_per_token(T), T * Bc / ms * 1e3)}
 
