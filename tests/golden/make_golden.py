@@ -353,7 +353,30 @@ def f7_scorer(cases=None):
                  argv=np.array(margs), **pack_sd(m))
 
 
-def f7_scorer_interp():
+INTERP_CASES = (
+    ("lstm_bayes3_interp", ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty",
+                            "Bayesian", "--L_bayes_pos", "3"],
+     lambda V: ref.BayesRNNModel("LSTM", V, 12, 12, 2, 0.5, True, 3),
+     lambda V: ref.BayesRNNModel("LSTM", V, 12, 12, 2, 0.5, False, 0)),
+    ("tlm_ffn_interp", ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                        "--uncertainty", "Bayesian", "--T_bayes_pos", "FFN"],
+     lambda V: ref.BayesTransformerModel(V, 16, 4, 32, 2, 0.5, True, "FFN"),
+     lambda V: ref.BayesTransformerModel(V, 16, 4, 32, 2, 0.5, True, "none")),
+)
+# round 4: the Gaussian branch of the reference scorer with --interpolation_flag 1 (:391-398, :426-436)
+INTERP_CASES_GP = (
+    ("tlm_gauss3_interp", ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                           "--uncertainty", "Gaussian", "--T_gauss_pos", "3"],
+     lambda V: ref.GaussTransformerModel(V, 16, 4, 32, 2, 0.5, True, 3),
+     lambda V: ref.BayesTransformerModel(V, 16, 4, 32, 2, 0.5, True, "none")),
+    ("lstm_gauss33_interp", ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty",
+                             "Gaussian", "--L_gauss_pos", "33"],
+     lambda V: ref.GaussRNNModel("LSTM", V, 12, 12, 2, 0.5, False, "33"),
+     lambda V: ref.BayesRNNModel("LSTM", V, 12, 12, 2, 0.5, False, 0)),
+)
+
+
+def f7_scorer_interp(cases=None):
     """Reference scorer with interpolation: logits of the Bayesian model and of a second, standard
     model (built as the reference builds it, :385-436) mixed with alpha = 0.7 before the log-softmax
     (:157-168).  The second state dict travels under the sd2/ prefix."""
@@ -361,16 +384,7 @@ def f7_scorer_interp():
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self
     scorer = importlib.import_module("compute_sentence_scores_bayes_jianwei")
-    for tag, margs, build, build2 in (
-        ("lstm_bayes3_interp", ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty",
-                                "Bayesian", "--L_bayes_pos", "3"],
-         lambda V: ref.BayesRNNModel("LSTM", V, 12, 12, 2, 0.5, True, 3),
-         lambda V: ref.BayesRNNModel("LSTM", V, 12, 12, 2, 0.5, False, 0)),
-        ("tlm_ffn_interp", ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
-                            "--uncertainty", "Bayesian", "--T_bayes_pos", "FFN"],
-         lambda V: ref.BayesTransformerModel(V, 16, 4, 32, 2, 0.5, True, "FFN"),
-         lambda V: ref.BayesTransformerModel(V, 16, 4, 32, 2, 0.5, True, "none")),
-    ):
+    for tag, margs, build, build2 in (cases or INTERP_CASES):
         with tempfile.TemporaryDirectory() as dtmp:
             words, _ = _tiny_corpus(dtmp)
             rng = np.random.RandomState(12)
@@ -988,6 +1002,7 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "scorer_gp":
         f7_scorer(SCORER_CASES_GP)
+        f7_scorer_interp(INTERP_CASES_GP)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gp_sample":
         for gp in (1, 2, 3):
@@ -1038,5 +1053,6 @@ if __name__ == "__main__":
         f4_gauss_transformer_sample(gp)
     f5_gauss_rnn_sample()
     f7_scorer(SCORER_CASES_GP)
+    f7_scorer_interp(INTERP_CASES_GP)
     f6_train_trajectory()
     f5_vtransformer_11()

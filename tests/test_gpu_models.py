@@ -567,7 +567,7 @@ def test_mc_samples_refused_when_nothing_is_sampled(dev, kind):
     assert S.compute_scores_batched(nbest, m, vocab, mtype, dev)  # mean-weight scoring is unaffected
 
 
-@pytest.mark.parametrize("tag", ["tlm_ffn_interp", "lstm_bayes3_interp"])
+@pytest.mark.parametrize("tag", ["tlm_ffn_interp", "lstm_bayes3_interp", "tlm_gauss3_interp", "lstm_gauss33_interp"])
 def test_scorer_cli_interpolation_matches_reference(dev, tag, tmp_path, monkeypatch):
     """--interpolation_flag 1: two models; the batched scorer takes both decoders in ONE launch over packed operands
     (blm_linear_nll2, no logits stored), the per-hypothesis loop mixes the materialised logits inside the CE kernel

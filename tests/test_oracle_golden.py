@@ -279,7 +279,7 @@ def test_scorer_scores_of_reference(tag):
         assert abs(a - b) <= 2e-4 * max(1.0, abs(b))
 
 
-@pytest.mark.parametrize("tag", ["tlm_ffn_interp", "lstm_bayes3_interp"])
+@pytest.mark.parametrize("tag", ["tlm_ffn_interp", "lstm_bayes3_interp", "tlm_gauss3_interp", "lstm_gauss33_interp"])
 def test_scorer_interpolation_of_reference(tag):
     """Two-model scoring by the reference's compute_scores (:157-168): the LOGITS are mixed with
     alpha = 0.7 before the log-softmax; the second LSTM carries its own hidden state."""
@@ -290,9 +290,13 @@ def test_scorer_interpolation_of_reference(tag):
     vocab = {w: i for i, w in enumerate(g["words"])}
     want = [(ln.split()[0], float(ln.split()[1])) for ln in str(g["scores_txt"]).splitlines()]
     is_rnn = tag.startswith("lstm")
-    H = sd["rnn.weight_hh_mean_1"].shape[1] if is_rnn else 0
+    H = sd["encoder.weight"].shape[1] if is_rnn else 0
     hid = (torch.zeros(2, 1, H), torch.zeros(2, 1, H)) if is_rnn else None
     hid2 = (torch.zeros(2, 1, H), torch.zeros(2, 1, H)) if is_rnn else None
+    for d_ in (sd, sd2):
+        if "pos_encoder.pe" in d_:
+            d_["pos_encoder.pe"] = O.positional_table(5000, d_["encoder.weight"].shape[1])
+    first_model = (lambda xs, h: O.gauss_rnn_lm(xs, h, sd, "33")) if "gauss" in tag else (lambda xs, h: O.bayes_rnn_lm(xs, h, sd, 3, None))
     nbest = collections.OrderedDict()
     for line in str(g["nbest_txt"]).splitlines():
         parts = line.strip().split(' ', 1)
@@ -305,7 +309,7 @@ def test_scorer_interpolation_of_reference(tag):
             x, t = S.get_input_and_target(hyp, vocab)
             xs, ts = torch.tensor(x).view(-1, 1), torch.tensor(t)
             if is_rnn:
-                o1, h1 = O.bayes_rnn_lm(xs, hid, sd, 3, None)
+                o1, h1 = first_model(xs, hid)
                 o2, h2 = O.bayes_rnn_lm(xs, hid2, sd2, 0, None)
                 first, first2 = (h1, h2) if first is None else (first, first2)
             else:
