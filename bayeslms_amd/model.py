@@ -42,6 +42,10 @@ class NoiseState:
         self.global_cols = 0
         self.fused = False
         self.dropout_off = False  # Monte-Carlo weight sampling at inference: noise on, dropout off
+        # Nobody manages the step (a reference-shaped training loop around the shim, INTEGRATION.md level 1): every training-mode
+        # forward in grad mode moves on to the next step's noise / dropout streams, as torch's generator would.  The first explicit
+        # set_step() -- engine.Trainer, the Monte-Carlo scorer, tests -- takes the counter over.
+        self.auto_step = True
 
 
 class _Site(nn.Module):
@@ -70,6 +74,12 @@ class _Site(nn.Module):
         return NoiseSpec(None, st.seed, self._site_base + k, st.step)
 
 
+def _advance_step(module, _inputs, _output):
+    st = module._st()
+    if st.auto_step and module.training and torch.is_grad_enabled():
+        st.step = (st.step + 1) & 0xFFFFFFFF
+
+
 def bind_state(model, state):
     """Give every sub-module the model's NoiseState and a unique id range (16 ids per module)."""
     for idx, m in enumerate(model.modules()):
@@ -78,6 +88,8 @@ def bind_state(model, state):
             m._site_base = 16 * idx
     if 16 * (idx + 1) >= (1 << 28):  # ids live in the low 28 bits of the Philox stream word (_lib.STREAM_*)
         raise BayesLMError("model has too many modules for the noise-stream id field")
+    if isinstance(model, _Site):  # the root: see NoiseState.auto_step
+        model.register_forward_hook(_advance_step)
     return state
 
 
@@ -323,6 +335,7 @@ class _LMHead(_Site):
     # training-loop controls (new; the reference draws from torch's global generator instead)
     def set_step(self, step):
         self.noise_state.step = int(step)
+        self.noise_state.auto_step = False  # the caller manages the step from here on
 
     def set_seed(self, seed):
         self.noise_state.seed = int(seed)

@@ -373,7 +373,6 @@ def level1_leg(dev, args, headline_ms):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         data, tgt = get_batch(train, i * T, T)
-        m.set_step(i)  # new noise / dropout streams per step (the one line a maintainer adds; without it every step reuses step 0's)
         opt.zero_grad()
         out = m(data)
         loss = crit(out.view(-1, V), tgt) + m.transformerlayers[0].linear2.kl_divergence() / len(train) * T

@@ -204,3 +204,26 @@ def test_torch_cross_entropy_on_model_logits_runs_the_engine_kernels(monkeypatch
     m.eval()
     with torch.no_grad():
         assert type(m(x)) is torch.Tensor
+
+
+def test_unmanaged_training_forwards_draw_fresh_noise():
+    """A reference-shaped loop never calls set_step: every training-mode forward in grad mode moves on to the next step's noise and
+    dropout streams by itself (NoiseState.auto_step), eval / no_grad forwards do not, and the first explicit set_step takes over."""
+    from bayeslms_amd import model as M
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    m = M.BayesTransformerModel(50, 32, 4, 64, 2, 0.3, True, "FFN").to(dev)
+    x = torch.randint(0, 50, (9, 4), device=dev)
+    m.train()
+    a, b = m(x).detach().clone(), m(x).detach().clone()
+    assert m.noise_state.step == 2 and not torch.equal(a, b)  # new eps and new masks
+    with torch.no_grad():
+        c, d = m(x), m(x)
+    assert m.noise_state.step == 2 and torch.equal(c, d)      # no_grad: the Monte-Carlo scorer's kind of call manages its own step
+    m.eval()
+    m(x)
+    assert m.noise_state.step == 2
+    m.train()
+    m.set_step(7)
+    e, f = m(x).detach().clone(), m(x).detach().clone()
+    assert m.noise_state.step == 7 and torch.equal(e, f)      # managed: the same step gives the same draw
