@@ -502,7 +502,23 @@ def build_parser():
     p.add_argument('--interp-lmonly', type=str, default='')
     p.add_argument('--interp-nnweight', type=float, default=0.8)
     p.add_argument('--interp-out', type=str, default='')
+    p.add_argument('--job', type=int, default=0, help='the rescoring script\'s JOB index (1-based, `$cmd JOB=1:$nj`): job j '
+                   'scores on GPU (j - 1) mod the number of visible GPUs, so the nj independent jobs of stage 6 spread over '
+                   'a node (replicas, no exchange); 0: the GPU of LOCAL_RANK (default 0)')
     return p
+
+
+def job_device_index(job, n_devices, local_rank=0):
+    """GPU of one stage-6 job (lmrescore_nbest_pytorchnn_cuda.sh:199-203 starts nj of them, each over its own
+    archives.JOB): the jobs share nothing, so they are laid round-robin over the visible GPUs."""
+    if job < 0:
+        raise SystemExit("--job is the rescoring script's 1-based JOB index (0: use LOCAL_RANK)")
+    if n_devices < 1:
+        raise SystemExit("bayeslms_amd scoring needs an MI355X: there is no CPU path")
+    idx = (job - 1) % n_devices if job > 0 else int(local_rank)
+    if not 0 <= idx < n_devices:
+        raise SystemExit("LOCAL_RANK %d but %d GPU(s) visible" % (idx, n_devices))
+    return idx
 
 
 def main(argv=None):
@@ -511,7 +527,7 @@ def main(argv=None):
         assert os.path.exists(pth), "%s path does not exists." % what
     if not torch.cuda.is_available():
         raise SystemExit("bayeslms_amd scoring needs an MI355X: there is no CPU path")
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    device = torch.device("cuda", job_device_index(args.job, torch.cuda.device_count(), os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(device)  # one process per GPU: kernels go to the current device's stream
     if args.gemm_mode != 'f32':
         from . import ops

@@ -626,3 +626,16 @@ def test_every_environment_switch_is_documented_and_tested():
     from bayeslms_amd import engine
     red = engine.GradReducer(engine.FlatBuffers(torch.nn.Linear(3, 2)), comm_cus=16)
     assert red.comm_cus == 0 and red.comm_plan == "off"  # host tensors: no CUs to contend for
+
+
+def test_scorer_jobs_are_laid_round_robin_over_the_visible_gpus():
+    """lmrescore_nbest_pytorchnn_cuda.sh:199 starts nj jobs that share nothing: --job JOB puts job j on GPU (j-1) mod N."""
+    from bayeslms_amd.compute_sentence_scores import build_parser, job_device_index
+    assert [job_device_index(j, 8) for j in range(1, 11)] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1]
+    assert [job_device_index(j, 1) for j in (1, 2, 5)] == [0, 0, 0]
+    assert job_device_index(0, 8, "3") == 3 and job_device_index(0, 1) == 0   # default: LOCAL_RANK
+    for bad in ((0, 2, "2"), (-1, 2, 0), (1, 0, 0)):
+        with pytest.raises(SystemExit):
+            job_device_index(*bad)
+    base = ["--nbest-list", "a", "--outfile", "b", "--vocabulary", "c", "--model-path", "d"]
+    assert build_parser().parse_args(base).job == 0 and build_parser().parse_args(base + ["--job", "4"]).job == 4
