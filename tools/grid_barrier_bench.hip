@@ -11,6 +11,10 @@
 //   xcd    : per-XCD counter -> XCD leader adds to a top counter -> per-XCD generation word
 //   +xchg  : barrier plus (1) and (3)
 //   launch : the same exchange as ONE LAUNCH PER STEP (what lstm_step.hip pays today): kernel boundary + gather
+//   flags  : (round 4) NO barrier: every producer raises a word of its own after its slice has drained (sc1), a consumer wave
+//            polls all 256 words with ONE dwordx4 sc1 load per lane, and the slices are then read THROUGH the L2 (plain loads)
+//            -- legal without an invalidate because every step writes a fresh region that no XCD has read before (as the
+//            real kernel's y[t] rows would be); 32 workgroups of an XCD then share one fetch of each line
 // Every spin is bounded (a timeout word is set and the kernel drains), grid = 256 <= one workgroup per CU.
 //
 //   hipcc --offload-arch=gfx950 -O3 -o tools/grid_barrier_bench tools/grid_barrier_bench.hip && tools/grid_barrier_bench
@@ -42,6 +46,7 @@ struct Sync {            // every polled word on a 128-byte line of its own
   unsigned xcd_gen[8][32];
   unsigned census[8][32];
   unsigned timeout[32];
+  unsigned ready[NWG];   // mode 4/5: ready[p] = number of steps producer p has published
 };
 
 __device__ __forceinline__ unsigned ld_relaxed(unsigned* p) {
@@ -110,6 +115,45 @@ __device__ __forceinline__ void publish(float* hx, int wg, unsigned step, float 
 }
 
 // (3) gather 128 KB = the slices of the 128 workgroups of this workgroup's batch half: 8192 x 16 B, 32 per thread
+template <int AUX>
+__device__ __forceinline__ float gather_aux(const float* hx, int wg) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hx), 0, NWG * SLICE_FLOATS * 4, 0x00020000);
+  const int half = wg & 1;
+  float acc = 0.f;
+#pragma unroll 4
+  for (int i = 0; i < 32; i += 8) {
+    v4u v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int chunk = (i + j) * TPB + threadIdx.x;
+      const int src_wg = (chunk >> 6) * 2 + half;
+      v[j] = __builtin_amdgcn_raw_buffer_load_b128(r, (src_wg * SLICE_FLOATS + (chunk & 63) * 4) * 4, 0, AUX);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += __uint_as_float(v[j].x) + __uint_as_float(v[j].w);
+  }
+  return acc;
+}
+
+// mode 4/5: wave 0 waits until every producer has published step `want` (one 1 KB sc1 load per poll), bounded
+__device__ bool wait_all_ready(Sync* s, unsigned want) {
+  __shared__ int ok3;
+  if (threadIdx.x < 64) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(s->ready, 0, NWG * 4, 0x00020000);
+    bool good = false;
+    for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+      const v4u f = __builtin_amdgcn_raw_buffer_load_b128(r, threadIdx.x * 16, 0, 16);
+      const bool mine = (int)(f.x - want) >= 0 && (int)(f.y - want) >= 0 && (int)(f.z - want) >= 0 && (int)(f.w - want) >= 0;
+      if (__all(mine)) { good = true; break; }
+      if ((spins & 1023u) == 1023u && ld_relaxed(&s->timeout[0])) break;
+    }
+    if (!good && threadIdx.x == 0) __hip_atomic_store(&s->timeout[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) ok3 = good;
+  }
+  __syncthreads();
+  return ok3;
+}
+
 __device__ __forceinline__ float gather(const float* hx, int wg) {
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hx), 0, NWG * SLICE_FLOATS * 4, 0x00020000);
   const int half = wg & 1;
@@ -130,7 +174,7 @@ __device__ __forceinline__ float gather(const float* hx, int wg) {
 }
 
 // mode: 0 flat, 1 xcd, 2 flat + exchange, 3 xcd + exchange
-__global__ __launch_bounds__(TPB) void persistent_kernel(Sync* s, float* hx0, float* hx1, float* out, int steps, int mode) {
+__global__ __launch_bounds__(TPB) void persistent_kernel(Sync* s, float* hx0, float* hx1, float* out, int steps, int mode, float seed) {
   extern __shared__ __attribute__((aligned(16))) char lds[];  // 128 KB requested: one workgroup per CU, as the real kernel
   __shared__ unsigned sh[2];
   const int wg = blockIdx.x;
@@ -152,9 +196,23 @@ __global__ __launch_bounds__(TPB) void persistent_kernel(Sync* s, float* hx0, fl
   const unsigned n_x = sh[0], n_xcd = sh[1];
   float acc = 0.f;
   reinterpret_cast<float*>(lds)[threadIdx.x] = 0.f;
+  if (mode >= 4) {  // hx0 = steps fresh regions of NWG slices each
+    for (int t = 0; t < steps; ++t) {
+      float* hw = hx0 + (size_t)t * NWG * SLICE_FLOATS;
+      if (mode == 5) publish(hw, wg, (unsigned)t, seed);
+      if (threadIdx.x < 64) {  // the publishing wave: slice drained, then its word
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) __hip_atomic_store(&s->ready[wg], (unsigned)t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (!wait_all_ready(s, (unsigned)t + 1)) break;
+      if (mode == 5) acc += gather_aux<0>(hw, wg);
+    }
+    out[wg * TPB + threadIdx.x] = acc;
+    return;
+  }
   for (int t = 0; t < steps; ++t) {
     float* hw = (t & 1) ? hx1 : hx0;  // double-buffered exchange area: step t writes one, reads it back after the barrier
-    if (mode >= 2) publish(hw, wg, (unsigned)t, 1.0f);
+    if (mode >= 2) publish(hw, wg, (unsigned)t, seed);
     const bool ok = (mode & 1) ? barrier_xcd(s, (unsigned)t + 1, x, n_x, n_xcd) : barrier_flat(s, (unsigned)t + 2);
     if (!ok) break;
     if (mode >= 2) acc += gather(hw, wg);
@@ -179,7 +237,7 @@ static float run_persistent(Sync* s, float* hx0, float* hx1, float* out, int ste
   for (int rep = 0; rep < 5; ++rep) {
     CHECK(hipMemsetAsync(s, 0, sizeof(Sync), st));
     CHECK(hipEventRecord(a, st));
-    hipLaunchKernelGGL(persistent_kernel, dim3(NWG), dim3(TPB), lds, st, s, hx0, hx1, out, steps, mode);
+    hipLaunchKernelGGL(persistent_kernel, dim3(NWG), dim3(TPB), lds, st, s, hx0, hx1, out, steps, mode, 1.0f + rep);  // another value per repeat: a line kept from the last one would show
     CHECK(hipEventRecord(b, st));
     CHECK(hipStreamSynchronize(st));
     float ms;
@@ -218,17 +276,21 @@ int main() {
     fprintf(stderr, "grid of %d would not be co-resident\n", NWG);
     return 3;
   }
-  const char* names[4] = {"barrier flat", "barrier xcd", "barrier flat + publish 1 KB + gather 128 KB",
-                          "barrier xcd  + publish 1 KB + gather 128 KB"};
+  const char* names[6] = {"barrier flat", "barrier xcd", "barrier flat + publish 1 KB + gather 128 KB",
+                          "barrier xcd  + publish 1 KB + gather 128 KB", "ready words only (256 words, one 1 KB poll)",
+                          "ready words + publish 1 KB + gather 128 KB through the L2 (fresh region per step)"};
   const int S1 = 64, S2 = 1088;
+  float* fresh;
+  CHECK(hipMalloc(&fresh, (size_t)(S2 + 8) * NWG * SLICE_FLOATS * 4));
   printf("{\"tool\": \"grid_barrier_bench\", \"workgroups\": %d, \"results_us_per_step\": {", NWG);
-  for (int mode = 0; mode < 4; ++mode) {
+  for (int mode = 0; mode < 6; ++mode) {
+    if (mode >= 4) hx0 = fresh;
     run_persistent(s, hx0, hx1, out, 8, mode, st, lds);  // warm
     const float t1 = run_persistent(s, hx0, hx1, out, S1, mode, st, lds);
-    if (mode >= 2) {  // every word of every step's hand-off must be the value published in THAT step (no stale line)
+    if (mode >= 2 && mode != 4) {  // every word of every step's hand-off must be the value published in THAT step (no stale line)
       std::vector<float> h(NWG * TPB);
       CHECK(hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost));
-      const float want = 64.f * (S1 * (S1 + 1) / 2);
+      const float want = 64.f * (S1 * 5.f + S1 * (S1 - 1) / 2);  // last repeat: seed 5
       for (size_t i = 0; i < h.size(); ++i)
         if (h[i] != want) {
           fprintf(stderr, "STALE hand-off in mode %d: out[%zu] = %.1f, want %.1f\n", mode, i, h[i], want);
