@@ -128,6 +128,7 @@ SIGNATURES = {
     "blm_lstm_step_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "blm_lstm_step_bwd": (_i, [_vp] * 10 + [_i, _i, _vp]),
     "blm_lstm_seq_fwd": (_i, [_vp] * 6 + [_i, _i, _i, _vp]),
+    "blm_lstm_seq_bwd": (_i, [_vp] * 7 + [_i, _vp, _i, _i, _i, _i, _i, _vp]),
     "blm_lstm_seq_pair_fwd": (_i, [_vp] * 5 + [_i] + [_vp] * 5 + [_i, _i, _i, _vp]),
     "blm_lstm_step_fwd_gp": (_i, [_vp] * 8 + [_i, _vp, _vp, _vp, _i, _i, _vp]),
     "blm_lstm_step_bwd_gp": (_i, [_vp] * 10 + [_i, _vp, _vp, _vp, _vp, _i, _i, _vp]),

@@ -1060,6 +1060,32 @@ extern "C" int blm_lstm_step_bwd_gp(const float* dgates_t, const float* w_hh_t, 
   return launch_step_bwd(p, stream);
 }
 
+// The backward steps t_hi-1 .. t_lo of one layer from ONE call (the counterpart of blm_lstm_seq_fwd: with two recurrences in flight on
+// two streams a step lasts ~5 us of device time per launch, less than a ctypes call costs).  Step T-1 is the plain cell backward
+// (dh = dh_T), every earlier one the fused step.  dc_pair (2,B,H): slot k holds dc of the step above on entry; the slots alternate.
+extern "C" int blm_lstm_cell_bwd2(const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, int,
+                                  int, void*);
+extern "C" int blm_lstm_seq_bwd(const float* dh_T, const float* dy, const float* cs, const float* gates_act, const float* w_hh_t,
+                                float* dgates, float* dc_pair, int k, float* dh_rows, int T, int t_hi, int t_lo, int B, int H,
+                                void* stream) {
+  if (!dy || !cs || !gates_act || !w_hh_t || !dgates || !dc_pair || (k != 0 && k != 1) || T < 0 || t_lo < 0 || t_hi > T || t_lo > t_hi ||
+      B < 0 || H < 0 || (t_hi == T && t_hi > t_lo && !dh_T))
+    return blm_fail(BLM_ERR_INVALID, "blm_lstm_seq_bwd: bad arguments");
+  const size_t bh = (size_t)B * H, bg = 4 * bh;
+  for (int t = t_hi - 1; t >= t_lo; --t) {
+    float* dc_in = dc_pair + (size_t)k * bh;
+    float* dc_out = dc_pair + (size_t)(k ^ 1) * bh;
+    const int rc = t == T - 1
+                       ? blm_lstm_cell_bwd2(dh_T, dy + t * bh, dc_in, cs + t * bh, cs + (t + 1) * bh, gates_act + t * bg, dgates + t * bg,
+                                            dc_out, B, H, stream)
+                       : blm_lstm_step_bwd(dgates + (t + 1) * bg, w_hh_t, dy + t * bh, dc_in, cs + t * bh, cs + (t + 1) * bh,
+                                           gates_act + t * bg, dgates + t * bg, dc_out, dh_rows ? dh_rows + t * bh : nullptr, B, H, stream);
+    if (rc) return rc;
+    k ^= 1;
+  }
+  return BLM_OK;
+}
+
 extern "C" int64_t blm_lstm_search_step_partials(int B, int H) {
   if (B < 0 || H < 0) return 0;
   return 8 * (int64_t)(H / 16) * ((B + 15) / 16);

@@ -1326,16 +1326,10 @@ class _LSTMLayer(torch.autograd.Function):
             ev = _TIMER.bracket("lstm_seq_bwd T=%d" % T) if _TIMER is not None else None
             if ev:
                 ev[0].record()
-            check(lib().blm_lstm_cell_bwd2(ptr(dh), ptr(dy[T - 1]), ptr(dcs[0]), ptr(cs[T - 1]), ptr(cs[T]), ptr(ga[T - 1]),
-                                           ptr(dgates[T - 1]), ptr(dcs[1]), B, H, st), "blm_lstm_cell_bwd2")
-            k = 1
-            dg_p, dy_p, cs_p, ga_p, dcs_p, wt_p = _P(dgates), _P(dy), _P(cs), _P(ga), _P(dcs), ptr(w_t)
-            dhr_p = _P(dhr) if noise else None
-            step_bwd = lib().blm_lstm_step_bwd
-            for t in range(T - 1, 0, -1):
-                check(step_bwd(dg_p[t], wt_p, dy_p[t - 1], dcs_p[k], cs_p[t - 1], cs_p[t], ga_p[t - 1], dg_p[t - 1], dcs_p[k ^ 1],
-                               dhr_p[t - 1] if noise else None, B, H, st), "blm_lstm_step_bwd")
-                k ^= 1
+            # the whole chain from one call (step T-1: the plain cell backward; every earlier step one fused launch)
+            check(lib().blm_lstm_seq_bwd(ptr(dh), ptr(dy), ptr(cs), ptr(ga), ptr(w_t), ptr(dgates), ptr(dcs), 0,
+                                         ptr(dhr) if noise else None, T, T, 0, B, H, st), "blm_lstm_seq_bwd")
+            k = T & 1
             dh = torch.empty(B, H, device=dev, dtype=torch.float32)
             check(lib().blm_lstm_step_bwd(ptr(dgates[0]), ptr(w_t), None, None, None, None, None, None, None, ptr(dh),
                                           B, H, st), "blm_lstm_step_bwd")
@@ -1386,14 +1380,15 @@ def lstm_layer(x, h0, c0, w_ih, w_hh, b_ih, b_hh, noise_rows=None):
     return _LSTMLayer.apply(x, h0, c0, w_ih, w_hh, b_ih, b_hh, noise_rows)
 
 
-_SIDE_STREAM = None
+_SIDE_STREAMS = {}
 
 
-def _side_stream():
-    global _SIDE_STREAM
-    if _SIDE_STREAM is None:
-        _SIDE_STREAM = torch.cuda.Stream()
-    return _SIDE_STREAM
+def _side_stream(i=0):
+    """Side stream i of the layer wavefront (0: the other layer's recurrence, 1: the per-chunk GEMMs between the layers)."""
+    st_ = _SIDE_STREAMS.get(i)
+    if st_ is None:
+        st_ = _SIDE_STREAMS[i] = torch.cuda.Stream()
+    return st_
 
 
 # no-grad forwards at B >= 256 (the scorer's packed batches) take the tiled GEMM + cell kernel: the fused step kernel re-reads
@@ -1403,12 +1398,13 @@ _UNFUSED_STEP_B = 256
 
 def _stack_chunks(T):
     """Time chunks of the layer wavefront: layer 2 runs one chunk behind layer 1.  Small enough that the lag is a
-    small part of T, large enough that the per-chunk input GEMM (M = chunk * B rows) and the host's event traffic stay
-    cheap."""
-    # equal chunks of at most 16 steps (measured: T 35 -> 3 x 12 beats 5-step and 16 + 16 + 3 chunks by 4-6 %; T 100 ->
-    # 13 ... 20 steps tie)
-    # ... and a B = 1 chain of thousands of steps (the scorer's carry chain) runs best on 128-step chunks: 62 k -> 66 k hypotheses/s)
-    cmax = 16 if T <= 256 else 128
+    small part of T, large enough that the host's per-chunk work (two library calls, one GEMM, two events) stays cheap."""
+    # T 35 (BASELINE configs[0]: a 2.2 ms step of which the host needs 1.6-1.9 ms to issue): 3 x 12; smaller chunks win 2 % when the
+    # host keeps up and lose 10-25 % when it does not (round 4, tools/wf_probe.py).  T 100 (the LSTM recipe: 10 ms step, 5 ms of
+    # host): 13 chunks of 8 beat 7 of 15 by 1.2-1.5 % now that the per-chunk GEMMs run on a stream of their own (9.80-9.86 against
+    # 9.94-10.02 ms, four runs each).  A B = 1 chain of thousands of steps (the scorer's carry chain) runs best on 128-step
+    # chunks (62 k -> 66 k hypotheses/s).
+    cmax = 16 if T < 64 else (8 if T <= 256 else 128)
     n = (T + cmax - 1) // cmax
     c = (T + n - 1) // n
     return [(t0, min(T, t0 + c)) for t0 in range(0, T, c)]
@@ -1420,9 +1416,12 @@ class _LSTMStack2(torch.autograd.Function):
     store latency chain, and two of them fit a CU (70 KB LDS, <= 256 VGPRs each): the steps of layer 2 over time chunk c
     run on a side stream WHILE layer 1 walks chunk c + 1 on the main stream (a step PAIR takes 15.4 us forward /
     17.4 us backward against 21.7 / 26.5 us back to back; tools/lstm_step_bench.py).  Per chunk: layer 1's steps, event,
-    [inter-layer dropout of that chunk, RNNModel only], layer 2's input GEMM over the chunk's rows, layer 2's steps.
-    Backward mirrors it (layer 2's chain leads on the side stream, layer 1 follows a chunk behind behind the dgrad
-    GEMM of the chunk); the weight-gradient GEMMs stay batched over all T at the end.  Same kernels and the same
+    [inter-layer dropout of that chunk, RNNModel only] and layer 2's input GEMM over the chunk's rows on a THIRD stream (so
+    that layer 2's recurrence only ever waits for the first of these GEMMs), layer 2's steps.  Layer 1's next chunk is
+    issued before the host turns to layer 2's previous one.  Backward mirrors it (layer 2's chain leads on the side stream,
+    the dgrad GEMM of the chunk on the stream between, layer 1 follows a chunk behind); both chains are issued by the library
+    (blm_lstm_seq_fwd / blm_lstm_seq_bwd: ~3.3 us of host time per launch against ~5 us of device time per launch when
+    two recurrences are in flight); the weight-gradient GEMMs stay batched over all T at the end.  Same kernels and the same
     arithmetic per step as two ops.lstm_layer calls: results are bit-identical to them."""
 
     @staticmethod
@@ -1475,21 +1474,42 @@ class _LSTMStack2(torch.autograd.Function):
                 prev = cur
             chunks = []
         else:
+            between = _side_stream(1)
             side.wait_stream(main)
-        for (t0, t1) in chunks:
-            n = t1 - t0
+            between.wait_stream(main)
+        def layer1(t0, t1):
             check(lib_.blm_lstm_seq_fwd(p_xw1 + t0 * bg, ptr(w_hh1), p["hs1"] + t0 * bh, p["cs1"] + t0 * bh, p["ga1"] + t0 * bg,
-                                        None, n, B, H, st()), "blm_lstm_seq_fwd")
+                                        None, t1 - t0, B, H, st()), "blm_lstm_seq_fwd")
             ev = torch.cuda.Event()
             ev.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
+            return ev
+
+        def layer2(t0, t1, ev):
+            n = t1 - t0
+            # layer 2's input rows of this chunk on a stream of their own: layer 2's recurrence (one chunk behind) never waits
+            # for a GEMM except in front of its first chunk
+            with torch.cuda.stream(between):
+                between.wait_event(ev)
                 inp = hs1[t0 + 1:t1 + 1]
                 if drop.on:
                     inp = _dropout_apply(inp, drop, row0=t0, out=x2[t0:t1])
                 gemm(L.GEMM_NT, inp, w_ih2, xw2[t0:t1], n * B, G, H, H, H, G, epilogue=L.EPI_BIAS, bias=bias2)
+                ev2 = torch.cuda.Event()
+                ev2.record(between)
+            with torch.cuda.stream(side):
+                side.wait_event(ev2)
                 check(lib_.blm_lstm_seq_fwd(p_xw2 + t0 * bg, ptr(w_hh2), p["hs2"] + t0 * bh, p["cs2"] + t0 * bh,
                                             p["ga2"] + t0 * bg, None, n, B, H, st()), "blm_lstm_seq_fwd")
+        # issue order: layer 1's NEXT chunk goes to its stream before the host turns to layer 2's previous one, so the leading
+        # recurrence never waits for the host
+        pend = None
+        for (t0, t1) in chunks:
+            ev = layer1(t0, t1)
+            if pend is not None:
+                layer2(*pend)
+            pend = (t0, t1, ev)
+        if pend is not None:
+            layer2(*pend)
         if chunks:
             main.wait_stream(side)
         if tev:
@@ -1531,35 +1551,34 @@ class _LSTMStack2(torch.autograd.Function):
         bh, bg = B * H * 4, B * G * 4
 
         def chain(s, dyp, cs, ga, t_hi, t_lo):
-            """dgates[t] for t = t_hi-1 .. t_lo (descending) of one layer: the first launch of the whole chain is the plain
-            cell backward of step T-1, every other one the fused step (dh_t = dgates[t+1] . W_hh, then the cell of step t)."""
-            dg, dcs, w_t = s["dg"].data_ptr(), s["dcs"].data_ptr(), s["w_t"].data_ptr()
-            pcs, pga = cs.data_ptr(), ga.data_ptr()
-            for t in range(t_hi - 1, t_lo - 1, -1):
-                k = s["k"]
-                if t == T - 1:
-                    check(lib_.blm_lstm_cell_bwd2(ptr(s["dh"]), dyp + t * bh, dcs + k * bh, pcs + t * bh, pcs + (t + 1) * bh,
-                                                  pga + t * bg, dg + t * bg, dcs + (k ^ 1) * bh, B, H, st()), "blm_lstm_cell_bwd2")
-                else:
-                    check(lib_.blm_lstm_step_bwd(dg + (t + 1) * bg, w_t, dyp + t * bh, dcs + k * bh, pcs + t * bh, pcs + (t + 1) * bh,
-                                                 pga + t * bg, dg + t * bg, dcs + (k ^ 1) * bh, None, B, H, st()), "blm_lstm_step_bwd")
-                s["k"] = k ^ 1
-        main, side = torch.cuda.current_stream(), _side_stream()
+            """dgates[t] for t = t_hi-1 .. t_lo (descending) of one layer from one call: the first launch of the whole chain is the
+            plain cell backward of step T-1, every other one the fused step (dh_t = dgates[t+1] . W_hh, then the cell of step t)."""
+            check(lib_.blm_lstm_seq_bwd(ptr(s["dh"]), dyp, ptr(cs), ptr(ga), ptr(s["w_t"]), ptr(s["dg"]), ptr(s["dcs"]), s["k"], None,
+                                        T, t_hi, t_lo, B, H, st()), "blm_lstm_seq_bwd")
+            s["k"] ^= (t_hi - t_lo) & 1
+        main, side, between = torch.cuda.current_stream(), _side_stream(), _side_stream(1)
         dh01, dh02 = new(B, H), new(B, H)  # allocated on the main stream's pool, like everything else both streams touch
         tev = _TIMER.bracket("lstm_stack2_bwd T=%d" % T) if _TIMER is not None else None
         if tev:
             tev[0].record()
         side.wait_stream(main)
+        between.wait_stream(main)
         for (t0, t1) in reversed(_stack_chunks(T)):
             with torch.cuda.stream(side):
                 chain(s2, dy.data_ptr(), cs2, ga2, t1, t0)
                 ev = torch.cuda.Event()
                 ev.record(side)
-            main.wait_event(ev)
             n = t1 - t0
-            gemm(L.GEMM_NN, s2["dg"][t0:t1], w_ih2, dy1[t0:t1], n * B, H, G, G, H, H)
-            if drop.on:
-                _dropout_apply(dy1[t0:t1], drop, row0=t0, out=dy1[t0:t1])
+            # layer 1's incoming gradient rows of this chunk on the stream between the layers: layer 1's chain (one chunk behind)
+            # only ever waits for the first of these GEMMs
+            with torch.cuda.stream(between):
+                between.wait_event(ev)
+                gemm(L.GEMM_NN, s2["dg"][t0:t1], w_ih2, dy1[t0:t1], n * B, H, G, G, H, H)
+                if drop.on:
+                    _dropout_apply(dy1[t0:t1], drop, row0=t0, out=dy1[t0:t1])
+                ev2 = torch.cuda.Event()
+                ev2.record(between)
+            main.wait_event(ev2)
             chain(s1, dy1.data_ptr(), cs1, ga1, t1, t0)
         # gradient w.r.t. the initial states: dh_{-1} = dgates[0] . W_hh
         for s, strm, d in ((s2, side, dh02), (s1, main, dh01)):

@@ -440,6 +440,16 @@ int blm_lstm_seq_pair_fwd(const float* xw_a, const float* w_hh_a, float* hs_a, f
 int blm_lstm_step_bwd(const float* dgates_t, const float* w_hh_t, const float* dy_prev, const float* dc_next,
                       const float* c_prev, const float* c, const float* gates_act, float* dgates_out, float* dc_prev,
                       float* dh_out, int B, int H, void* stream);
+/* The backward steps t_hi-1 .. t_lo (descending) of one layer from ONE call -- blm_lstm_seq_fwd's counterpart: step T-1 is
+ * the plain cell backward (blm_lstm_cell_bwd2 with dh = dh_T, dh2 = dy[T-1]), every earlier step t one blm_lstm_step_bwd
+ * launch (dh = dgates[t+1] . w_hh, then the cell of step t).  dy (T,B,H); cs (T+1,B,H) as blm_lstm_seq_fwd leaves them;
+ * gates_act, dgates (T,B,4H); dc_pair (2,B,H): slot k holds the dc arriving from above on entry, the slots alternate per
+ * step, so the caller's next k is k ^ ((t_hi - t_lo) & 1); dh_rows (T,B,H) or NULL: row t receives the product of step t's
+ * launch (what h_t gets from step t+1).  dh_T is read only when t_hi == T.  A chain may be walked in several calls
+ * (t_hi of one = t_lo of the one before): the layer wavefront does, chunk by chunk. */
+int blm_lstm_seq_bwd(const float* dh_T, const float* dy, const float* cs, const float* gates_act, const float* w_hh_t,
+                     float* dgates, float* dc_pair, int k, float* dh_rows, int T, int t_hi, int t_lo, int B, int H,
+                     void* stream);
 /* The same two step kernels for the GP-LSTM cell with a GPNN on one gate (GPLSTMCell gate types 1-4,
  * model.py:1754-1771): gate `gate_ovr` (0 i, 1 f, 2 g, 3 o; -1 = plain LSTM) takes the activation
  * mixture sum_i act_i(z) coef4[i] of its pre-activation z instead of its sigmoid/tanh.  The caller

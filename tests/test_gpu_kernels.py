@@ -830,6 +830,48 @@ def test_lstm_step_bwd_full_size_matches_composition(dev):
     assert torch.equal(dh2, outs[0][2])
 
 
+@pytest.mark.parametrize("T,B,H", [(7, 20, 64), (5, 3, 1024)])
+def test_lstm_seq_bwd_is_the_per_step_chain(dev, T, B, H):
+    """blm_lstm_seq_bwd (all backward steps of a layer from one call; two chunked calls as the layer wavefront issues them) ==
+    blm_lstm_cell_bwd2 for step T-1 + one blm_lstm_step_bwd per earlier step, bit for bit, incl. the per-step dh rows."""
+    lib = L().lib()
+    from bayeslms_amd._lib import ptr, stream
+    g = torch.Generator(device=dev).manual_seed(T * 100 + B)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
+    w_t = (rn(H, 4 * H) * 0.05).contiguous()
+    dy, dh_T, cs = rn(T, B, H) * 0.1, rn(B, H) * 0.1, rn(T + 1, B, H)
+    ga = torch.sigmoid(rn(T, B, 4 * H))
+    ga[:, :, 2 * H:3 * H] = torch.tanh(rn(T, B, H))
+    dc0 = rn(B, H) * 0.1
+    # per-step reference chain
+    dg_r, dcs_r, dhr_r = torch.zeros(T, B, 4 * H, device=dev), torch.zeros(2, B, H, device=dev), torch.zeros(T, B, H, device=dev)
+    dcs_r[0].copy_(dc0)
+    k = 0
+    for t in range(T - 1, -1, -1):
+        if t == T - 1:
+            rc = lib.blm_lstm_cell_bwd2(ptr(dh_T), ptr(dy[t]), ptr(dcs_r[k]), ptr(cs[t]), ptr(cs[t + 1]), ptr(ga[t]), ptr(dg_r[t]),
+                                        ptr(dcs_r[k ^ 1]), B, H, stream())
+        else:
+            rc = lib.blm_lstm_step_bwd(ptr(dg_r[t + 1]), ptr(w_t), ptr(dy[t]), ptr(dcs_r[k]), ptr(cs[t]), ptr(cs[t + 1]), ptr(ga[t]),
+                                       ptr(dg_r[t]), ptr(dcs_r[k ^ 1]), ptr(dhr_r[t]), B, H, stream())
+        assert rc == 0
+        k ^= 1
+    for cuts in ([T, 0], [T, T // 2, 0], [T, T - 1, 1, 0]):
+        dg, dcs, dhr = torch.zeros(T, B, 4 * H, device=dev), torch.zeros(2, B, H, device=dev), torch.zeros(T, B, H, device=dev)
+        dcs[0].copy_(dc0)
+        kk = 0
+        for hi, lo in zip(cuts[:-1], cuts[1:]):
+            assert lib.blm_lstm_seq_bwd(ptr(dh_T), ptr(dy), ptr(cs), ptr(ga), ptr(w_t), ptr(dg), ptr(dcs), kk, ptr(dhr), T, hi, lo,
+                                        B, H, stream()) == 0
+            kk ^= (hi - lo) & 1
+        torch.cuda.synchronize()
+        assert kk == k and torch.equal(dg, dg_r) and torch.equal(dcs[kk], dcs_r[k]) and torch.equal(dhr, dhr_r), cuts
+    # argument checks: a chunk outside [0, T], a missing dh_T for the top chunk
+    assert lib.blm_lstm_seq_bwd(ptr(dh_T), ptr(dy), ptr(cs), ptr(ga), ptr(w_t), ptr(dg), ptr(dcs), 0, None, T, T + 1, 0, B, H, stream()) != 0
+    assert lib.blm_lstm_seq_bwd(None, ptr(dy), ptr(cs), ptr(ga), ptr(w_t), ptr(dg), ptr(dcs), 0, None, T, T, 0, B, H, stream()) != 0
+    assert lib.blm_lstm_seq_bwd(None, ptr(dy), ptr(cs), ptr(ga), ptr(w_t), ptr(dg), ptr(dcs), 0, None, T, T - 1, 0, B, H, stream()) == 0
+
+
 @pytest.mark.parametrize("M,V", [(7, 50), (33, 33000), (5, 1001)])
 def test_ce_interp_matches_torch(dev, M, V):
     """two-model scoring: NLL of alpha*a + (1-alpha)*b (reference scorer :157-168), odd V = scalar tail"""
