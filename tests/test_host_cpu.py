@@ -504,17 +504,17 @@ def test_recipe_command_lines_parse_unchanged():
 
 
 def test_wavefront_chunks_are_equal_and_cover_the_window():
-    """ops._stack_chunks (host rule of the LSTM layer wavefront): equal chunks of at most 16 steps for training windows,
-    128-step chunks for the scorer's long B = 1 chain; always a partition of [0, T)."""
+    """ops._stack_chunks (host rule of the LSTM layer wavefront): equal chunks of at most 16 steps for short training windows
+    (T < 64), at most 8 for longer ones, 128-step chunks for the scorer's long B = 1 chain; always a partition of [0, T)."""
     from bayeslms_amd import ops
     for T in (8, 31, 32, 35, 64, 100, 128, 256, 257, 1000, 8192):
         ch = ops._stack_chunks(T)
         assert ch[0][0] == 0 and ch[-1][1] == T and all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
         sizes = [b - a for a, b in ch]
-        assert max(sizes) <= (16 if T <= 256 else 128)
+        assert max(sizes) <= (16 if T < 64 else (8 if T <= 256 else 128))
         assert max(sizes) - min(sizes) <= max(1, max(sizes) - (T - (len(ch) - 1) * max(sizes))) and min(sizes) >= 1
     assert [b - a for a, b in ops._stack_chunks(35)] == [12, 12, 11]      # BASELINE configs[0] / configs[1] window
-    assert len(ops._stack_chunks(100)) == 7                                # the recipes' window: 6 x 15 + 10
+    assert [b - a for a, b in ops._stack_chunks(100)] == [8] * 12 + [4]    # the recipes' window
 
 
 def test_batched_scorer_restores_the_garbage_collector(monkeypatch):
