@@ -1474,9 +1474,14 @@ class _LSTMStack2(torch.autograd.Function):
                 prev = cur
             chunks = []
         else:
-            between = _side_stream(1)
+            # many chunks (T >= 64): the per-chunk GEMMs get a stream of their own; few (T 35: three chunks, a step the host can
+            # barely issue in time): they stay in front of layer 2's steps on the side stream, two events per chunk fewer
+            three = len(chunks) > 4
+            between = _side_stream(1) if three else side
             side.wait_stream(main)
-            between.wait_stream(main)
+            if three:
+                between.wait_stream(main)
+
         def layer1(t0, t1):
             check(lib_.blm_lstm_seq_fwd(p_xw1 + t0 * bg, ptr(w_hh1), p["hs1"] + t0 * bh, p["cs1"] + t0 * bh, p["ga1"] + t0 * bg,
                                         None, t1 - t0, B, H, st()), "blm_lstm_seq_fwd")
@@ -1494,17 +1499,22 @@ class _LSTMStack2(torch.autograd.Function):
                 if drop.on:
                     inp = _dropout_apply(inp, drop, row0=t0, out=x2[t0:t1])
                 gemm(L.GEMM_NT, inp, w_ih2, xw2[t0:t1], n * B, G, H, H, H, G, epilogue=L.EPI_BIAS, bias=bias2)
-                ev2 = torch.cuda.Event()
-                ev2.record(between)
+                if three:
+                    ev2 = torch.cuda.Event()
+                    ev2.record(between)
             with torch.cuda.stream(side):
-                side.wait_event(ev2)
+                if three:
+                    side.wait_event(ev2)
                 check(lib_.blm_lstm_seq_fwd(p_xw2 + t0 * bg, ptr(w_hh2), p["hs2"] + t0 * bh, p["cs2"] + t0 * bh,
                                             p["ga2"] + t0 * bg, None, n, B, H, st()), "blm_lstm_seq_fwd")
-        # issue order: layer 1's NEXT chunk goes to its stream before the host turns to layer 2's previous one, so the leading
-        # recurrence never waits for the host
+        # issue order with three streams: layer 1's NEXT chunk goes to its stream before the host turns to layer 2's previous one,
+        # so the leading recurrence never waits for the host
         pend = None
         for (t0, t1) in chunks:
             ev = layer1(t0, t1)
+            if not three:
+                layer2(t0, t1, ev)
+                continue
             if pend is not None:
                 layer2(*pend)
             pend = (t0, t1, ev)
@@ -1561,24 +1571,31 @@ class _LSTMStack2(torch.autograd.Function):
         tev = _TIMER.bracket("lstm_stack2_bwd T=%d" % T) if _TIMER is not None else None
         if tev:
             tev[0].record()
+        chunks = _stack_chunks(T)
+        three = len(chunks) > 4  # as in forward
+        if not three:
+            between = main
         side.wait_stream(main)
-        between.wait_stream(main)
-        for (t0, t1) in reversed(_stack_chunks(T)):
+        if three:
+            between.wait_stream(main)
+        for (t0, t1) in reversed(chunks):
             with torch.cuda.stream(side):
                 chain(s2, dy.data_ptr(), cs2, ga2, t1, t0)
                 ev = torch.cuda.Event()
                 ev.record(side)
             n = t1 - t0
-            # layer 1's incoming gradient rows of this chunk on the stream between the layers: layer 1's chain (one chunk behind)
-            # only ever waits for the first of these GEMMs
+            # layer 1's incoming gradient rows of this chunk: on the stream between the layers when there are many chunks (layer 1's
+            # chain, one chunk behind, then only ever waits for the first of these GEMMs), else in front of layer 1's steps
             with torch.cuda.stream(between):
                 between.wait_event(ev)
                 gemm(L.GEMM_NN, s2["dg"][t0:t1], w_ih2, dy1[t0:t1], n * B, H, G, G, H, H)
                 if drop.on:
                     _dropout_apply(dy1[t0:t1], drop, row0=t0, out=dy1[t0:t1])
-                ev2 = torch.cuda.Event()
-                ev2.record(between)
-            main.wait_event(ev2)
+                if three:
+                    ev2 = torch.cuda.Event()
+                    ev2.record(between)
+            if three:
+                main.wait_event(ev2)
             chain(s1, dy1.data_ptr(), cs1, ga1, t1, t0)
         # gradient w.r.t. the initial states: dh_{-1} = dgates[0] . W_hh
         for s, strm, d in ((s2, side, dh02), (s1, main, dh01)):
