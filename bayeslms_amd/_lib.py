@@ -122,6 +122,8 @@ SIGNATURES = {
     "blm_ce_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "blm_gp_coef_grad": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "blm_colsum": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp]),
+    "blm_colsum2": (_i, [_vp, _i64, _vp, _vp, _i, _i, _i, _vp]),
+    "blm_init_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "blm_sqnorm_ws_floats": (_i64, [_i]),
     "blm_sqnorm_multi": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "blm_clip_sgd_multi": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _i, _f, _vp]),

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, 
 // ------------------------------------------------------------------ column sums (bias gradients)
 // block = 32 column-quads x 8 row lanes; grid.y row chunks; partials combined with float atomics.
 __global__ __launch_bounds__(TPB) void colsum_kernel(const float* __restrict__ x, long ld, float* __restrict__ out, int M,
-                                                     int N) {
+                                                     int N, float* __restrict__ out2 = nullptr) {
   __shared__ float4 sm[8][32];
   const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int col = (blockIdx.x * 32 + cq) * 4;
@@ -493,6 +493,12 @@ __global__ __launch_bounds__(TPB) void colsum_kernel(const float* __restrict__ x
     if (col + 1 < N) atomicAdd(out + col + 1, a.y);
     if (col + 2 < N) atomicAdd(out + col + 2, a.z);
     if (col + 3 < N) atomicAdd(out + col + 3, a.w);
+    if (out2) {  // the same sums into a second vector (an LSTM layer's b_ih and b_hh receive the same gradient)
+      atomicAdd(out2 + col, a.x);
+      if (col + 1 < N) atomicAdd(out2 + col + 1, a.y);
+      if (col + 2 < N) atomicAdd(out2 + col + 2, a.z);
+      if (col + 3 < N) atomicAdd(out2 + col + 3, a.w);
+    }
   }
 }
 
@@ -941,14 +947,75 @@ extern "C" int blm_gp_coef_grad(const float* g, const float* z, float* dcoef, in
   return BLM_OK;
 }
 
-extern "C" int blm_colsum(const float* x, int64_t ld, float* out, int M, int N, int accumulate, void* stream) {
-  if (!x || !out || M < 0 || N < 0 || ld < N) return blm_fail(BLM_ERR_INVALID, "blm_colsum: bad arguments");
+extern "C" int blm_colsum2(const float* x, int64_t ld, float* out, float* out2, int M, int N, int accumulate, void* stream) {
+  if (!x || !out || M < 0 || N < 0 || ld < N || out == out2) return blm_fail(BLM_ERR_INVALID, "blm_colsum: bad arguments");
   if (N == 0) return BLM_OK;
-  if (!accumulate) BLM_HIP(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), ST));
+  if (!accumulate) {
+    BLM_HIP(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), ST));
+    if (out2) BLM_HIP(hipMemsetAsync(out2, 0, (size_t)N * sizeof(float), ST));
+  }
   if (M == 0) return BLM_OK;
   int gy = (M + 255) / 256;
   if (gy > 64) gy = 64;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 127) / 128, gy), dim3(TPB), 0, ST, x, (long)ld, out, M, N);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 127) / 128, gy), dim3(TPB), 0, ST, x, (long)ld, out, M, N, out2);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+extern "C" int blm_colsum(const float* x, int64_t ld, float* out, int M, int N, int accumulate, void* stream) {
+  return blm_colsum2(x, ld, out, nullptr, M, N, accumulate, stream);
+}
+
+// Up to 8 small vectors initialised by ONE launch: dst_i = (src_i or 0) + (src2_i or 0).  The set-up of a recurrent layer is a
+// handful of (B,H)- and (4H)-sized copies, zero fills and bias sums -- 5 us each as launches of their own.
+struct InitMulti {
+  float* dst[8];
+  const float* src[8];
+  const float* src2[8];
+  long n[8];
+};
+__global__ __launch_bounds__(TPB) void init_multi_kernel(const InitMulti p) {
+  const int i = blockIdx.y;
+  float* __restrict__ d = p.dst[i];
+  const float* __restrict__ a = p.src[i];
+  const float* __restrict__ b = p.src2[i];
+  const long n = p.n[i];
+  const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+  const long stride = (long)gridDim.x * TPB;
+  if (vec) {
+    for (long j = (long)blockIdx.x * TPB + threadIdx.x; j < (n >> 2); j += stride) {
+      float4 v = a ? reinterpret_cast<const float4*>(a)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b) {
+        const float4 w = reinterpret_cast<const float4*>(b)[j];
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
+      reinterpret_cast<float4*>(d)[j] = v;
+    }
+  } else {
+    for (long j = (long)blockIdx.x * TPB + threadIdx.x; j < n; j += stride) d[j] = (a ? a[j] : 0.f) + (b ? b[j] : 0.f);
+  }
+}
+
+extern "C" int blm_init_multi(int count, float* const* dst, const float* const* src, const float* const* src2, const int64_t* n,
+                              void* stream) {
+  if (count < 0 || count > 8 || (count > 0 && (!dst || !n))) return blm_fail(BLM_ERR_INVALID, "blm_init_multi: bad arguments (at most 8 vectors)");
+  InitMulti p{};
+  long most = 0;
+  int m = 0;
+  for (int i = 0; i < count; ++i) {
+    if (n[i] < 0 || (n[i] > 0 && !dst[i])) return blm_fail(BLM_ERR_INVALID, "blm_init_multi: bad arguments");
+    if (n[i] == 0) continue;
+    p.dst[m] = dst[i];
+    p.src[m] = src ? src[i] : nullptr;
+    p.src2[m] = src2 ? src2[i] : nullptr;
+    p.n[m] = (long)n[i];
+    most = n[i] > most ? (long)n[i] : most;
+    ++m;
+  }
+  if (m == 0) return BLM_OK;
+  long gx = (most / 4 + TPB - 1) / TPB;
+  gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+  hipLaunchKernelGGL(init_multi_kernel, dim3((unsigned)gx, m), dim3(TPB), 0, ST, p);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }

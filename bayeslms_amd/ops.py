@@ -123,6 +123,34 @@ def _notify(*params):
                 _GRAD_HOOK(p)
 
 
+_VP8, _I64x8 = C.c_void_p * 8, C.c_int64 * 8
+
+
+def _init_multi(items):
+    """``items``: (dst, src | None, src2 | None) triples of equally sized vectors -- dst = (src or 0) + (src2 or 0) -- set by
+    one launch per eight (blm_init_multi): the initial states into row 0 of the state histories, b_ih + b_hh, zeroed gradient
+    carries of a recurrent layer.  dst must be contiguous fp32 views on the GPU; sources of another layout / type are converted."""
+    L.require_gfx950()
+    for k in range(0, len(items), 8):
+        part = items[k:k + 8]
+        d, a, b, n = _VP8(), _VP8(), _VP8(), _I64x8()
+        keep = []
+        for i, (dst, s1, s2) in enumerate(part):
+            if not (dst.is_cuda and dst.dtype == torch.float32 and dst.is_contiguous()):
+                raise BayesLMError("_init_multi: destinations are contiguous fp32 GPU tensors")
+            d[i], n[i] = dst.data_ptr(), dst.numel()
+            for arr, src in ((a, s1), (b, s2)):
+                if src is None:
+                    arr[i] = None
+                    continue
+                src = _f32(src, "src")
+                if src.numel() != dst.numel():
+                    raise BayesLMError("_init_multi: %d elements into %d" % (src.numel(), dst.numel()))
+                keep.append(src)
+                arr[i] = src.data_ptr()
+        check(lib().blm_init_multi(len(part), d, a, b, n, stream()), "blm_init_multi")
+
+
 def _wgrad_target(w):
     """-> (buffer, accumulate, value_to_return): leaf parameters accumulate in place into .grad and
     autograd gets None; a non-leaf weight (e.g. a sampled tensor) gets a fresh gradient tensor."""
@@ -1243,6 +1271,35 @@ class state_tap:
         return False
 
 
+def _bias_pair_grads(b_refs, dbs, needs):
+    """b_ih and b_hh of an LSTM layer receive the same gradient ``db`` (one per layer in ``dbs``; ``b_refs`` the (b_ih, b_hh)
+    parameters layer by layer).  Leaf biases take it in place -- ONE launch for all of them (blm_init_multi: grad = grad + db) --
+    and autograd gets None; anything else gets db itself.  -> the values to return, in b_refs' order."""
+    items, out, told = [], [], []
+    for i, b in enumerate(b_refs):
+        db = dbs[i // 2]
+        if not needs[i]:
+            out.append(None)
+        elif b.is_leaf and b.is_contiguous() and b.dtype == torch.float32:
+            g = _grad_buf(b)
+            items.append((g, g, db))
+            told.append(b)
+            out.append(None)
+        else:
+            out.append(db)
+    # a cell that passes ONE parameter as both biases (VLSTMCell / GPLSTMCell add bias_ih twice, model.py:2519, :1750-1752) gets
+    # db twice: the two updates of one buffer must not share a launch
+    while items:
+        seen, now, later = set(), [], []
+        for it in items:
+            (later if it[0].data_ptr() in seen else now).append(it)
+            seen.add(it[0].data_ptr())
+        _init_multi(now)
+        items = later
+    _notify(*told)
+    return out
+
+
 class _LSTMLayer(torch.autograd.Function):
     """One layer over T steps.  Input GEMM batched over T (M = T*B), recurrent GEMM + fused cell per
     step.  Weights arrive already sampled (W = mu + noise on the gate rows)."""
@@ -1256,14 +1313,12 @@ class _LSTMLayer(torch.autograd.Function):
         H = w_hh.shape[1]
         G = 4 * H
         dev = x.device
-        bias = b_ih.clone()
-        check(lib().blm_axpy(ptr(b_hh), ptr(bias), G, 1.0, stream()), "blm_axpy")
-        xw = torch.empty(T, B, G, device=dev, dtype=torch.float32)
-        gemm(L.GEMM_NT, x, w_ih, xw, T * B, G, E, E, E, G, epilogue=L.EPI_BIAS, bias=bias)
+        bias = torch.empty(G, device=dev, dtype=torch.float32)
         hs = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
         cs = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
-        hs[0].copy_(h0)
-        cs[0].copy_(c0)
+        _init_multi([(bias, b_ih, b_hh), (hs[0], h0, None), (cs[0], c0, None)])  # one launch: b_ih + b_hh, the initial state
+        xw = torch.empty(T, B, G, device=dev, dtype=torch.float32)
+        gemm(L.GEMM_NT, x, w_ih, xw, T * B, G, E, E, E, G, epilogue=L.EPI_BIAS, bias=bias)
         ga = torch.empty(T, B, G, device=dev, dtype=torch.float32)
         st = stream()
         # one launch per step (recurrent product + cell, blm_lstm_step_fwd) when the shape allows it,
@@ -1294,6 +1349,7 @@ class _LSTMLayer(torch.autograd.Function):
             _STATE_TAP.layers.append((hs.index_select(0, _STATE_TAP.idx), cs.index_select(0, _STATE_TAP.idx)))
         ctx.save_for_backward(x, hs, cs, ga, w_ih, w_hh)
         ctx.w_refs = (w_ih, w_hh)  # the parameter objects themselves (their .grad is the accumulation target)
+        ctx.b_refs = (b_ih, b_hh)
         ctx.has_noise = noise_rows is not None
         return hs[1:], hs[T], cs[T]
 
@@ -1306,11 +1362,11 @@ class _LSTMLayer(torch.autograd.Function):
         dev = x.device
         dy = _f32(dy, "dy")
         dgates = torch.empty(T, B, G, device=dev, dtype=torch.float32)
-        dh = torch.zeros(B, H, device=dev, dtype=torch.float32) if dhT is None else _f32(dhT, "dhT").clone()
-        dc = torch.zeros(B, H, device=dev, dtype=torch.float32) if dcT is None else _f32(dcT, "dcT").clone()
         st = stream()
+        dh = torch.empty(B, H, device=dev, dtype=torch.float32)
         dcs = torch.empty(2, B, H, device=dev, dtype=torch.float32)  # ping-pong dc buffers
-        dcs[0].copy_(dc)
+        db = torch.empty(G, device=dev, dtype=torch.float32)
+        _init_multi([(dh, dhT, None), (dcs[0], dcT, None), (db, None, None)])  # one launch: incoming state gradients (or zeros), db = 0
         fused_step = (H % 32 == 0 and w_hh.is_contiguous() and w_hh.data_ptr() % 16 == 0 and dgates.data_ptr() % 16 == 0)
         noise = getattr(ctx, "has_noise", False)
         # dhr[t] = gradient reaching h_t from step t+1 (dhr[T-1] = dhT); kept for every step only when the
@@ -1359,7 +1415,6 @@ class _LSTMLayer(torch.autograd.Function):
         # to autograd they cost an AccumulateGrad add over 16.8 MB each at H = 1024 (~10 us per weight and step); sampled
         # (non-leaf) weights of Bayes2LSTM get a fresh gradient tensor for their sampling node
         w_ih_p, w_hh_p = ctx.w_refs
-        db = torch.zeros(G, device=dev, dtype=torch.float32)
         dw_ih = dw_hh = None
         if ctx.needs_input_grad[3]:
             buf_ih, acc_ih, dw_ih = _wgrad_target(w_ih_p)
@@ -1371,7 +1426,8 @@ class _LSTMLayer(torch.autograd.Function):
             buf_hh, acc_hh, dw_hh = _wgrad_target(w_hh_p)
             gemm(L.GEMM_TN, dgates, hs, buf_hh, G, H, T * B, G, H, H, accumulate=acc_hh)  # hs[0:T] = h_{t-1}
         _notify(w_ih_p, w_hh_p)
-        return dx, dh, dc, dw_ih, dw_hh, db, db, d_noise
+        db_ih, db_hh = _bias_pair_grads(ctx.b_refs, [db], ctx.needs_input_grad[5:7])
+        return dx, dh, dc, dw_ih, dw_hh, db_ih, db_hh, d_noise
 
 
 def lstm_layer(x, h0, c0, w_ih, w_hh, b_ih, b_hh, noise_rows=None):
@@ -1433,20 +1489,17 @@ class _LSTMStack2(torch.autograd.Function):
         dev = x.device
         st = stream
         lib_ = lib()
-        bias1, bias2 = b_ih1.clone(), b_ih2.clone()
-        check(lib_.blm_axpy(ptr(b_hh1), ptr(bias1), G, 1.0, st()), "blm_axpy")
-        check(lib_.blm_axpy(ptr(b_hh2), ptr(bias2), G, 1.0, st()), "blm_axpy")
-        xw1 = torch.empty(T, B, G, device=dev, dtype=torch.float32)
-        gemm(L.GEMM_NT, x, w_ih1, xw1, T * B, G, E, E, E, G, epilogue=L.EPI_BIAS, bias=bias1)
         new = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
+        bias1, bias2 = new(G), new(G)
         hs1, cs1, ga1 = new(T + 1, B, H), new(T + 1, B, H), new(T, B, G)
         hs2, cs2, ga2 = new(T + 1, B, H), new(T + 1, B, H), new(T, B, G)
+        # one launch: both layers' b_ih + b_hh and the four initial states into row 0 of the state histories
+        _init_multi([(bias1, b_ih1, b_hh1), (bias2, b_ih2, b_hh2), (hs1[0], h0a, None), (cs1[0], c0a, None), (hs2[0], h0b, None),
+                     (cs2[0], c0b, None)])
+        xw1 = new(T, B, G)
+        gemm(L.GEMM_NT, x, w_ih1, xw1, T * B, G, E, E, E, G, epilogue=L.EPI_BIAS, bias=bias1)
         xw2 = new(T, B, G)
         x2 = new(T, B, H) if drop.on else None  # layer 2's input = drop(h1) (nn.LSTM's inter-layer dropout)
-        hs1[0].copy_(h0a)
-        cs1[0].copy_(c0a)
-        hs2[0].copy_(h0b)
-        cs2[0].copy_(c0b)
         main, side = torch.cuda.current_stream(), _side_stream()
         tev = _TIMER.bracket("lstm_stack2_fwd T=%d" % T) if _TIMER is not None else None
         if tev:
@@ -1529,6 +1582,7 @@ class _LSTMStack2(torch.autograd.Function):
             _STATE_TAP.layers.append((hs2.index_select(0, _STATE_TAP.idx), cs2.index_select(0, _STATE_TAP.idx)))
         ctx.save_for_backward(x, hs1, cs1, ga1, hs2, cs2, ga2, x2, w_ih1, w_hh1, w_ih2, w_hh2)
         ctx.w_refs = (w_ih1, w_hh1, w_ih2, w_hh2)
+        ctx.b_refs = (b_ih1, b_hh1, b_ih2, b_hh2)
         ctx.drop = drop
         return hs2[1:], hs1[T], cs1[T], hs2[T], cs2[T]
 
@@ -1544,20 +1598,18 @@ class _LSTMStack2(torch.autograd.Function):
         st = stream
         dy = _f32(dy, "dy")
         new = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
-        zeros = lambda *sh: torch.zeros(*sh, device=dev, dtype=torch.float32)  # noqa: E731
 
-        def state(dhT, dcT, w_hh):
-            dh = zeros(B, H) if dhT is None else _f32(dhT, "dhT").clone()
-            dcs = new(2, B, H)
-            if dcT is None:
-                dcs[0].zero_()
-            else:
-                dcs[0].copy_(_f32(dcT, "dcT"))
+        def state(w_hh):
             w_t = new(H, G)
             check(lib_.blm_transpose(ptr(w_hh), ptr(w_t), G, H, st()), "blm_transpose")
-            return {"dh": dh, "dcs": dcs, "k": 0, "w_t": w_t, "dg": new(T, B, G)}
-        s1, s2 = state(dh1T, dc1T, w_hh1), state(dh2T, dc2T, w_hh2)
+            return {"dh": new(B, H), "dcs": new(2, B, H), "k": 0, "w_t": w_t, "dg": new(T, B, G)}
+        s1, s2 = state(w_hh1), state(w_hh2)
         dy1 = new(T, B, H)  # gradient reaching layer 1's outputs = layer 2's input gradient
+        db1, db2 = new(G), new(G)
+        # one launch: the incoming state gradients (or zeros) of both layers, zeroed bias gradients, and dy1 = 0 -- its chunks are
+        # written by K-sliced products that would each need a memset of their own otherwise
+        _init_multi([(s1["dh"], dh1T, None), (s1["dcs"][0], dc1T, None), (s2["dh"], dh2T, None), (s2["dcs"][0], dc2T, None),
+                     (db1, None, None), (db2, None, None), (dy1, None, None)])
         bh, bg = B * H * 4, B * G * 4
 
         def chain(s, dyp, cs, ga, t_hi, t_lo):
@@ -1588,7 +1640,7 @@ class _LSTMStack2(torch.autograd.Function):
             # chain, one chunk behind, then only ever waits for the first of these GEMMs), else in front of layer 1's steps
             with torch.cuda.stream(between):
                 between.wait_event(ev)
-                gemm(L.GEMM_NN, s2["dg"][t0:t1], w_ih2, dy1[t0:t1], n * B, H, G, G, H, H)
+                gemm(L.GEMM_NN, s2["dg"][t0:t1], w_ih2, dy1[t0:t1], n * B, H, G, G, H, H, accumulate=True)  # into the zeroed rows
                 if drop.on:
                     _dropout_apply(dy1[t0:t1], drop, row0=t0, out=dy1[t0:t1])
                 if three:
@@ -1612,19 +1664,25 @@ class _LSTMStack2(torch.autograd.Function):
         gemm(L.GEMM_NN, dg1, w_ih1, dx, T * B, E, G, G, E, E)
         # leaf weights accumulate straight into .grad (see _LSTMLayer.backward); sampled ones get fresh tensors
         outs = []
-        for w_p, A, Bm, kdim in ((ctx.w_refs[0], dg1, x, E), (ctx.w_refs[1], dg1, hs1, H), (ctx.w_refs[2], dg2, inp2, H), (ctx.w_refs[3], dg2, hs2, H)):
+        summed = [False, False]  # the bias gradient = column sums of dgates: taken from the A tiles a weight-gradient GEMM stages anyway
+        for j, (w_p, A, Bm, kdim) in enumerate(((ctx.w_refs[0], dg1, x, E), (ctx.w_refs[1], dg1, hs1, H), (ctx.w_refs[2], dg2, inp2, H),
+                                                (ctx.w_refs[3], dg2, hs2, H))):
             if not w_p.requires_grad:
                 outs.append(None)
                 continue
             buf, acc, ret = _wgrad_target(w_p)
-            gemm(L.GEMM_TN, A, Bm, buf, G, kdim, T * B, G, kdim, kdim, accumulate=acc)  # hs[0:T] = h_{t-1}
+            cs_a = None
+            if not summed[j // 2]:
+                cs_a, summed[j // 2] = (db1, db2)[j // 2], True
+            gemm(L.GEMM_TN, A, Bm, buf, G, kdim, T * B, G, kdim, kdim, accumulate=acc, colsum_a=cs_a)  # hs[0:T] = h_{t-1}
             outs.append(ret)
         _notify(*ctx.w_refs)
         dw_ih1, dw_hh1, dw_ih2, dw_hh2 = outs
-        db1, db2 = new(G), new(G)
-        _colsum_into(dg1, T * B, G, db1, accumulate=False)
-        _colsum_into(dg2, T * B, G, db2, accumulate=False)
-        return dx, dh01, dc01, dh02, dc02, dw_ih1, dw_hh1, db1, db1, dw_ih2, dw_hh2, db2, db2, None
+        for done, dgl, dbl in ((summed[0], dg1, db1), (summed[1], dg2, db2)):
+            if not done:
+                _colsum_into(dgl, T * B, G, dbl, accumulate=True)
+        db_ih1, db_hh1, db_ih2, db_hh2 = _bias_pair_grads(ctx.b_refs, [db1, db2], [ctx.needs_input_grad[i] for i in (7, 8, 11, 12)])
+        return dx, dh01, dc01, dh02, dc02, dw_ih1, dw_hh1, db_ih1, db_hh1, dw_ih2, dw_hh2, db_ih2, db_hh2, None
 
 
 def lstm_stack2_ok(x, w_hh1, w_hh2, w_ih2):

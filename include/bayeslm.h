@@ -391,6 +391,14 @@ int blm_gp_coef_grad(const float* g, const float* z, float* dcoef, int M, int N,
 
 /* out[n] (+)= sum_m x[m,n]   (bias gradients). */
 int blm_colsum(const float* x, int64_t ld, float* out, int M, int N, int accumulate, void* stream);
+/* ... and the same sums into a second vector out2 (NULL: none) from the same pass: nn.LSTM's b_ih and b_hh receive the same
+ * gradient (model.py:35 / _VF.lstm :812). */
+int blm_colsum2(const float* x, int64_t ld, float* out, float* out2, int M, int N, int accumulate, void* stream);
+/* Up to 8 small vectors set by ONE launch: dst[i][0..n[i]) = (src[i] ? src[i][j] : 0) + (src2[i] ? src2[i][j] : 0); src / src2
+ * may be NULL altogether.  dst, src, src2, n are HOST arrays (copied into the launch).  The set-up of a recurrent layer -- initial
+ * states into row 0 of the state histories, b_ih + b_hh, zeroed gradient carries -- is 8-12 launches of ~5 us without it. */
+int blm_init_multi(int count, float* const* dst, const float* const* src, const float* const* src2, const int64_t* n,
+                   void* stream);
 
 /* Global-norm clip + SGD momentum over a list of tensors (train.py:419-420,466):
  *   norm = sqrt(sum_i |g_i|^2); c = min(1, clip/(norm+1e-6));

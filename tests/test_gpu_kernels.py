@@ -830,6 +830,55 @@ def test_lstm_step_bwd_full_size_matches_composition(dev):
     assert torch.equal(dh2, outs[0][2])
 
 
+def test_init_multi_and_colsum2(dev):
+    """blm_init_multi: dst = (src or 0) + (src2 or 0) for up to eight vectors per launch (vector and scalar paths, more than eight
+    split by the host, in-place sums, one buffer twice = two launches); blm_colsum2: the same column sums into two vectors."""
+    ops = ops_mod()
+    lib = L().lib()
+    from bayeslms_amd._lib import BayesLMError, ptr, stream
+    g = torch.Generator(device=dev).manual_seed(3)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
+    sizes = [4096, 20 * 1024, 7, 1, 33, 4 * 1024, 12, 64, 5, 2048, 3]
+    srcs = [rn(n) for n in sizes]
+    src2 = [rn(n) if i % 3 == 0 else None for i, n in enumerate(sizes)]
+    dsts = [torch.full((n,), 9.0, device=dev) for n in sizes]
+    items = []
+    for i, n in enumerate(sizes):
+        items.append((dsts[i], None if i % 4 == 1 else srcs[i], src2[i]))
+    ops._init_multi(items)
+    for i, n in enumerate(sizes):
+        want = (torch.zeros(n, device=dev) if i % 4 == 1 else srcs[i]) + (src2[i] if src2[i] is not None else 0)
+        assert torch.equal(dsts[i], want), i
+    # a non-contiguous source is converted, an unaligned view takes the scalar path
+    base = rn(10, 6)
+    d = torch.empty(10, device=dev)
+    big = torch.empty(4097, device=dev)
+    ops._init_multi([(d, base[:, 2], None), (big[1:], srcs[0], None)])
+    assert torch.equal(d, base[:, 2]) and torch.equal(big[1:], srcs[0])
+    with pytest.raises(BayesLMError):
+        ops._init_multi([(d, srcs[0], None)])
+    # in place (grad += db), and the same buffer twice through ops._bias_pair_grads: two launches, both applied
+    b = torch.nn.Parameter(rn(64))
+    b.grad = rn(64)
+    g0, db = b.grad.clone(), rn(64)
+    assert ops._bias_pair_grads((b, b), [db], [True, True]) == [None, None]
+    assert torch.allclose(b.grad, g0 + 2 * db, rtol=0, atol=1e-6)
+    nb = b * 2.0  # a non-leaf bias (a sampled one) gets db itself
+    out = ops._bias_pair_grads((b, nb), [db], [False, True])
+    assert out[0] is None and out[1] is db
+    # nine destinations and a NULL in the middle through the C entry point's own checks
+    assert lib.blm_init_multi(9, None, None, None, None, stream()) != 0
+    # colsum2
+    x = rn(300, 130)
+    o1, o2 = torch.full((130,), 5.0, device=dev), torch.full((130,), 7.0, device=dev)
+    assert lib.blm_colsum2(ptr(x), 130, ptr(o1), ptr(o2), 300, 130, 0, stream()) == 0
+    ref = x.double().sum(0).float()
+    assert rel(o1, ref) < 1e-5 and rel(o2, ref) < 1e-5
+    assert lib.blm_colsum2(ptr(x), 130, ptr(o1), ptr(o2), 300, 130, 1, stream()) == 0
+    assert rel(o1, 2 * ref) < 1e-5 and rel(o2, 2 * ref) < 1e-5
+    assert lib.blm_colsum2(ptr(x), 130, ptr(o1), ptr(o1), 300, 130, 1, stream()) != 0  # the same vector twice is refused
+
+
 @pytest.mark.parametrize("T,B,H", [(7, 20, 64), (5, 3, 1024)])
 def test_lstm_seq_bwd_is_the_per_step_chain(dev, T, B, H):
     """blm_lstm_seq_bwd (all backward steps of a layer from one call; two chunked calls as the layer wavefront issues them) ==
