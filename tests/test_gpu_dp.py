@@ -113,15 +113,16 @@ def _spawn(world, ret, family="tlm_ffn", T=12):
     mp.spawn(_run, args=(world, port, ret, family, T), nprocs=world, join=True)
 
 
-@pytest.mark.parametrize("family", ["rnn_none", "rnn_bayes3"])
-def test_two_ranks_equal_one_rank_with_the_layer_wavefront(family):
+@pytest.mark.parametrize("family,T", [("rnn_none", 36), ("rnn_bayes3", 36), ("rnn_none", 72)])
+def test_two_ranks_equal_one_rank_with_the_layer_wavefront(family, T):
     """What a data-parallel LSTM run at the recipes' shape executes: <= 32 columns per rank and T >= 32 put
     the two layers on the two-stream wavefront (ops.lstm_stack2) while the reducer's hooks, its communication stream and
-    the bucket overlap (8 KB buckets) are active -- two ranks == one rank on the global batch, replicas bit-identical."""
+    the bucket overlap (8 KB buckets) are active -- two ranks == one rank on the global batch, replicas bit-identical.
+    T 72: nine chunks, i.e. the per-chunk GEMMs on their third stream (the recipes' T 100 takes that form)."""
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        _spawn(1, ret, family, 36)
-        _spawn(2, ret, family, 36)
+        _spawn(1, ret, family, T)
+        _spawn(2, ret, family, T)
         l1, p1 = ret[(1, 0)]
         l2a, p2a = ret[(2, 0)]
         l2b, p2b = ret[(2, 1)]
