@@ -1351,6 +1351,7 @@ class _LSTMLayer(torch.autograd.Function):
         ctx.w_refs = (w_ih, w_hh)  # the parameter objects themselves (their .grad is the accumulation target)
         ctx.b_refs = (b_ih, b_hh)
         ctx.has_noise = noise_rows is not None
+        ctx.set_materialize_grads(False)  # the final states usually feed nothing: their gradients arrive as None, not as zero fills
         return hs[1:], hs[T], cs[T]
 
     @staticmethod
@@ -1360,7 +1361,7 @@ class _LSTMLayer(torch.autograd.Function):
         H = w_hh.shape[1]
         G = 4 * H
         dev = x.device
-        dy = _f32(dy, "dy")
+        dy = torch.zeros(T, B, H, device=dev, dtype=torch.float32) if dy is None else _f32(dy, "dy")
         dgates = torch.empty(T, B, G, device=dev, dtype=torch.float32)
         st = stream()
         dh = torch.empty(B, H, device=dev, dtype=torch.float32)
@@ -1584,6 +1585,7 @@ class _LSTMStack2(torch.autograd.Function):
         ctx.w_refs = (w_ih1, w_hh1, w_ih2, w_hh2)
         ctx.b_refs = (b_ih1, b_hh1, b_ih2, b_hh2)
         ctx.drop = drop
+        ctx.set_materialize_grads(False)  # the final states usually feed nothing: their gradients arrive as None, not as zero fills
         return hs2[1:], hs1[T], cs1[T], hs2[T], cs2[T]
 
     @staticmethod
@@ -1596,7 +1598,7 @@ class _LSTMStack2(torch.autograd.Function):
         dev = x.device
         lib_ = lib()
         st = stream
-        dy = _f32(dy, "dy")
+        dy = torch.zeros(T, B, H, device=dev, dtype=torch.float32) if dy is None else _f32(dy, "dy")
         new = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
 
         def state(w_hh):
