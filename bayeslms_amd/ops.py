@@ -997,11 +997,14 @@ class _CrossEntropy(torch.autograd.Function):
             torch.autograd.graph.increment_version(logits)
         ctx.meta = (logits, targets, lse, fuse, M, V, keep)
         ctx.mark_non_differentiable(nll)
+        ctx.set_materialize_grads(False)  # no zero fill for the per-token NLL's (non-existent) gradient
         return loss / M, nll
 
     @staticmethod
     def backward(ctx, g, _g_nll):
         logits, targets, lse, fuse, M, V, keep = ctx.meta
+        if g is None:
+            return None, None, None, None
         if fuse:
             return logits, None, None, None
         g = _f32(g.reshape(1), "g")
