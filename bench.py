@@ -205,23 +205,28 @@ def _train_leg(model, kl_fn, seq, Bc, lr, steps, warm, dev, engine, ops, timed_t
     """tokens/s of engine.Trainer steps on a synthetic AMI-shaped stream (same step as the headline)."""
     from bayeslms_amd.data import batchify, get_batch, synthetic_corpus
     from bayeslms_amd.model import repackage_hidden
-    stream = synthetic_corpus(vocab, Bc * ((steps + warm) * seq + 1) + 17, seed=1111)
+    tagged = 5 if timed_tags else 0  # the event brackets of the recurrences are taken over extra steps AFTER the timed region
+    stream = synthetic_corpus(vocab, Bc * ((steps + warm + tagged) * seq + 1) + 17, seed=1111)
     train = batchify(stream, Bc, dev)
     tr = engine.Trainer(model, lr=lr, clip=CLIP, kl_scale=float(seq) / train.size(0), seed=1111)
     is_rnn = hasattr(model, "init_hidden")
     hidden = model.init_hidden(Bc) if is_rnn else None
     timer = ops.KernelTimer() if timed_tags else None
-    for i in range(warm + steps):
+    for i in range(warm + steps + tagged):
         if i == warm:
             torch.cuda.synchronize()
-            ops.set_kernel_timer(timer)
             t0 = time.perf_counter()
+        if i == warm + steps:
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            ops.set_kernel_timer(timer)
         data, tgt = get_batch(train, i * seq, seq)
         if is_rnn:
             hidden = repackage_hidden(hidden)
         loss, _, hidden = tr.step(data, tgt, hidden=hidden, kl_fn=kl_fn)
     torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    if not tagged:
+        el = time.perf_counter() - t0
     ops.set_kernel_timer(None)
     out = {"value": round(steps * seq * Bc / el, 1), "unit": "tokens/s", "ms_per_step": round(1e3 * el / steps, 3),
            "steps": steps, "warmup": warm, "final_loss": round(float(loss), 4)}
@@ -455,6 +460,7 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
         fwd = kt.get("lstm_seq_fwd T=%d" % Tl, {}).get("avg_ms")
         bwd = kt.get("lstm_seq_bwd T=%d" % Tl, {}).get("avg_ms")
         sf, sb = kt.get("lstm_stack2_fwd T=%d" % Tl, {}).get("avg_ms"), kt.get("lstm_stack2_bwd T=%d" % Tl, {}).get("avg_ms")
+        r["lstm_step_times_from"] = "event brackets over 5 extra steps after the timed region (inside it they cost the host-bound legs 4-8 %)"
         if sf is not None:  # the two layers ran as a wavefront on two streams (ops.lstm_stack2: B <= 32 and T >= 32)
             r.update({"lstm_layers": "wavefront on two streams (ops.lstm_stack2)",
                       # whole two-layer recurrence incl. layer 2's per-chunk input GEMMs / dgrad GEMMs, per time step and LAYER
