@@ -222,9 +222,10 @@ class ResidualLink:
 # per-kernel timing with HIP events on the launch stream (bench.py's live roofline numbers)
 # ----------------------------------------------------------------------------
 class KernelTimer:
-    def __init__(self, all_gemms=False):
+    def __init__(self, all_gemms=False, only=None):
         self.records = []
         self.all_gemms = all_gemms  # also bracket untagged GEMMs, keyed by layout/shape/epilogue
+        self.only = None if only is None else frozenset(only)  # bracket these tags only (a bracket costs the step ~8 us)
 
     def bracket(self, tag):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -296,7 +297,7 @@ def get_gemm_mode():
 def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, *, alpha=1.0, accumulate=False, epilogue=L.EPI_NONE, bias=None,
          aux=None, coef=None, var_b=None, C2=None, wg_mu=None, var_c=None, kl_lambda=0.0, kl_inv_n=0.0,
          drop=None, drop_B=0, tag=None, colsum_a=None):
-    if _TIMER is not None and (tag is not None or _TIMER.all_gemms):
+    if _TIMER is not None and (tag is not None or _TIMER.all_gemms) and (_TIMER.only is None or tag in _TIMER.only):
         if _TIMER.all_gemms:
             tag = f"{('NT', 'NN', 'TN')[op]} {M}x{N}x{K} epi{epilogue}{' acc' if accumulate else ''} [{tag or '-'}]"
         ev0, ev1 = _TIMER.bracket(tag)

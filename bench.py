@@ -714,16 +714,21 @@ def main():
         return mm.transformerlayers[0].linear2.kl_divergence()
     kl_fn.fusable = True
 
-    timer = ops.KernelTimer()
+    # HIP-event brackets cost the step they sit in (~8 us each: tools/timer_cost.py, 9 per step = 0.33 %): inside the timed region
+    # only the roofline launch is bracketed (the contract's live measurement); the other tagged launches of `kernels_ms` are
+    # bracketed over the last warm-up steps
+    side_tags = min(3, args.warmup)
+    timer = ops.KernelTimer(only={"sampled_gemm_fwd"}) if side_tags else ops.KernelTimer()
+    timer_all = ops.KernelTimer()
 
     def one(i, timed):
         data, targets = get_batch(train, i * T, T)
-        ops.set_kernel_timer(timer if timed else None)
+        ops.set_kernel_timer(timed)
         loss, kl, _ = tr.step(data, targets, kl_fn=kl_fn)
         return loss
 
     for i in range(args.warmup):
-        loss = one(i, False)
+        loss = one(i, timer_all if i >= args.warmup - side_tags else None)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -731,7 +736,7 @@ def main():
     tr.reducer.measure = world > 1  # event pair per step: last backward kernel -> end of the gradient exchange
     t0 = time.perf_counter()
     for i in range(args.warmup, steps_total):
-        loss = one(i, True)
+        loss = one(i, timer)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -785,7 +790,8 @@ def main():
             chip = {"error": repr(e)}
     if rank == 0:
         tokens = args.steps * T * Bc * world
-        kt = timer.summary()
+        kt = timer.summary()  # the timed region: the roofline launch
+        kt_all = timer_all.summary() if side_tags else kt  # every tagged launch, from the last warm-up steps
         M_, N_, K_ = T * Bc, D_MODEL, D_FF
         flops = 2.0 * M_ * N_ * K_  # 2*M*N*K per forward launch
         roof = None
@@ -823,7 +829,9 @@ def main():
                               "achieved": round(STEP_FLOPS_PER_TOKEN * tokens / world / elapsed / 1e12, 2),
                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
                               "frac": round(STEP_FLOPS_PER_TOKEN * tokens / world / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
-            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kt.items()},
+            "kernels_ms": {**{k: round(v["avg_ms"], 4) for k, v in kt_all.items()}, **{k: round(v["avg_ms"], 4) for k, v in kt.items()}},
+            "kernels_ms_from": ("sampled_gemm_fwd: HIP events inside the timed region; the others: the last %d warm-up steps" % side_tags)
+                               if side_tags else "HIP events inside the timed region",
             "final_loss": round(final_loss, 4), "eval_ppl": round(eval_ppl, 2),
             # rank 0, per step: time the compute stream waited between its last backward kernel and the end of the
             # gradient exchange (bucketed all-reduce + the compact embedding-row exchange); null at N = 1
