@@ -29,7 +29,7 @@ from bayeslms_amd.data import batchify, get_batch, synthetic_corpus  # noqa: E40
 
 OPN = ("NT", "NN", "TN")
 TILES = (11, 12, 21, 22, 28)  # 28 = 128x128 on eight waves
-SPLITS = (1, 2, 3, 4, 6, 8, 12, 16)
+SPLITS = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20)
 TAIL_SPLITS = (-2, -4, -8, -16, -32)  # only the tiles beyond the last whole round of workgroup slots are sliced (in-situ search only)
 V33, V10 = 33000, 10000
 TRAINER_KW = {}  # tools/gemm_tune_comm.py: collective= stand-in for RCCL's channel workgroups beside the backward GEMMs
