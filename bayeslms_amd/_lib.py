@@ -108,6 +108,7 @@ SIGNATURES = {
     "blm_ln_bwd_ws_floats": (_i64, [_i, _i]),
     "blm_add_dropout_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
     "blm_attn_fwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
+    "blm_attn_fwd_rows": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp]),
     "blm_attn_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _rngp, _i, _i, _vp]),
     "blm_attn_bwd_ws": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _rngp, _i, _i, _vp,
                             _i64, _vp]),

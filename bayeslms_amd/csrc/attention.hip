@@ -444,6 +444,18 @@ extern "C" int blm_attn_fwd(const float* q, const float* k, const float* v, int6
   return BLM_OK;
 }
 
+int blm_attn_fwd_rows_mfma(const float* q, const float* k, const float* v, int64_t ld, float* out, const int* rowmap, int T, int B,
+                           int nhead, hipStream_t st);
+
+extern "C" int blm_attn_fwd_rows(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, const int32_t* rowmap,
+                                 int T, int B, int nhead, int head_dim, void* stream) {
+  if (!q || !k || !v || !out || !rowmap || T < 0 || B < 0 || nhead <= 0) return blm_fail(BLM_ERR_INVALID, "blm_attn_fwd_rows: bad arguments");
+  if (ld_qkv < (int64_t)nhead * head_dim) return blm_fail(BLM_ERR_INVALID, "blm_attn_fwd_rows: ld_qkv too small");
+  if ((long)T * B == 0) return BLM_OK;
+  if (!use_mfma(head_dim)) return blm_fail(BLM_ERR_UNSUPPORTED, "blm_attn_fwd_rows: head_dim 64 only");
+  return blm_attn_fwd_rows_mfma(q, k, v, ld_qkv, out, rowmap, T, B, nhead, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int64_t blm_attn_bwd_ws_floats(int T, int B, int nhead, int head_dim) {
   if (T <= 0 || B <= 0 || nhead <= 0 || !use_mfma(head_dim)) return 0;
   return blm_attn_bwd_mfma_ws_floats(T, B, nhead);

@@ -48,6 +48,9 @@ struct AttnM {
   float inv_keep;
   int col_offset;
   int drop;
+  // optional (T * B): packed row of the token at padded position t * B + b, or -1 for padding -- q / k / v / out are then (R, ld)
+  // matrices of the REAL tokens only (the n-best scorer's layout, ops.packed_tokens); T <= 32 forward only
+  const int* rowmap;
 #ifdef BLM_ATTN_PROF
   long long* prof;  // tools/attn_prof.hip only: 8 wall-clock stamps (10 ns) per wave
 #endif
@@ -241,7 +244,9 @@ __device__ __forceinline__ void attn_fwd_pass(const AttnM& p, const float* Ks, c
   }
   ATTN_STAMP(stamps, 5);
   if (qok) {
-    store_t(p.out + ((long)q * p.B + b) * ((long)p.nhead * HD) + off, ot, lh, 1.f);
+    long orow = (long)q * p.B + b;
+    if (p.rowmap) orow = p.rowmap[orow];  // packed rows: a padding query has no row to write
+    if (orow >= 0) store_t(p.out + orow * ((long)p.nhead * HD) + off, ot, lh, 1.f);
     if (p.lse && lh == 0) p.lse[(long)bhid * T + q] = m + __logf(l);
   }
   ATTN_STAMP(stamps, 6);
@@ -312,18 +317,30 @@ __global__ __launch_bounds__(256) void attn_fwd_short_kernel(const AttnM p) {
   {
     float4 kk[8], vv[8];
     const bool al = ((reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v) | (uintptr_t)(p.ld * 4) | (uintptr_t)(off * 4)) & 15) == 0;
+    bool real[8];
+    auto rowof = [&](int row, bool& ok) -> long {  // row of the operand matrices that holds (row, b); ok = false: zero row
+      long r = (long)min(row, T - 1) * p.B + b;
+      ok = row < T;
+      if (p.rowmap) {
+        const int pr = p.rowmap[r];
+        ok = ok && pr >= 0;
+        r = pr >= 0 ? pr : 0;
+      }
+      return r;
+    };
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = lane + 64 * u, row = i >> 4, c = (i & 15) << 2;
-      const long o = ((long)min(row, T - 1) * p.B + b) * p.ld + off + c;
+      const long o = rowof(row, real[u]) * p.ld + off + c;
       if (al) { kk[u] = *reinterpret_cast<const float4*>(p.k + o); vv[u] = *reinterpret_cast<const float4*>(p.v + o); }
       else { kk[u] = make_float4(p.k[o], p.k[o + 1], p.k[o + 2], p.k[o + 3]); vv[u] = make_float4(p.v[o], p.v[o + 1], p.v[o + 2], p.v[o + 3]); }
     }
-    fetch_op(qa, p.q + ((long)min(li, T - 1) * p.B + b) * p.ld + off + 32 * lh);
+    bool qreal;
+    fetch_op(qa, p.q + rowof(li, qreal) * p.ld + off + 32 * lh);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = lane + 64 * u, row = i >> 4, c = (i & 15) << 2;
-      const float m = row < T ? 1.f : 0.f;
+      const float m = real[u] ? 1.f : 0.f;
       float* dk = Ks + row * LS + c;
       float* dv = Vs + row * LS + c;
       dk[0] = kk[u].x * m; dk[1] = kk[u].y * m; dk[2] = kk[u].z * m; dk[3] = kk[u].w * m;
@@ -879,6 +896,27 @@ int blm_attn_fwd_mfma(const float* q, const float* k, const float* v, int64_t ld
   }
   if ((B * nhead) % 2 == 0 && attn_hpw(B * nhead) == 2) hipLaunchKernelGGL(attn_fwd_mfma_kernel<2>, dim3(B * nhead / 2), dim3(512), 2 * lds, st, p);
   else hipLaunchKernelGGL(attn_fwd_mfma_kernel<1>, dim3(B * nhead), dim3(256), lds, st, p);
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+// Forward on PACKED rows (inference, T <= 32, head_dim 64): q / k / v (R, ld) and out (R, nhead * 64) hold the real tokens of a padded
+// (T, B) batch only, rowmap (T * B) maps a padded position to its row or -1.  BLM_ERR_UNSUPPORTED: the caller scatters / gathers
+// around blm_attn_fwd instead.
+int blm_attn_fwd_rows_mfma(const float* q, const float* k, const float* v, int64_t ld, float* out, const int* rowmap, int T, int B,
+                           int nhead, hipStream_t st) {
+  if (T > 32 || !attn_short()) return blm_fail(BLM_ERR_UNSUPPORTED, "blm_attn_fwd_rows: packed rows need T <= 32 and the one-wave-per-head form");
+  AttnM p{};
+  fill_m(p, T, B, nhead, 0.f, nullptr, 0);
+  p.q = q; p.k = k; p.v = v; p.ld = ld; p.out = out; p.lse = nullptr; p.rowmap = rowmap;
+  static bool once_s = false;
+  const size_t lds_s = (size_t)4 * 2 * 32 * LS * sizeof(float);
+  if (!once_s) {
+    const int rc = set_lds(attn_fwd_short_kernel, lds_s);
+    if (rc) return rc;
+    once_s = true;
+  }
+  hipLaunchKernelGGL(attn_fwd_short_kernel, dim3((B * nhead + 3) / 4), dim3(256), lds_s, st, p);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }

@@ -239,7 +239,7 @@ class MultiheadAttention(_Site):
         qkv = self.qkv_net(query, _link)  # _link: ops.ResidualLink of the enclosing post-LN block (new, optional)
         pk = ops.packing()  # scorer: compact real-token rows everywhere but inside the attention core
         if pk is not None:
-            a = pk.pack(ops.attention(pk.unpack(qkv), self.num_heads, self._drop(self.dropout)))
+            a = pk.attention(qkv, None, None, self.num_heads)  # inference: no dropout
         else:
             a = ops.attention(qkv, self.num_heads, self._drop(self.dropout))
         return self.o_net(a), None
@@ -270,7 +270,7 @@ class BayesMultiheadAttention(_Site):
         q, k, v = self.q_net(query), self.k_net(key), self.v_net(value)
         pk = ops.packing()
         if pk is not None:
-            a = pk.pack(ops.attention_qkv(pk.unpack(q), pk.unpack(k), pk.unpack(v), self.num_heads, self._drop(self.dropout)))
+            a = pk.attention(q, k, v, self.num_heads)  # inference: no dropout
         else:
             a = ops.attention_qkv(q, k, v, self.num_heads, self._drop(self.dropout))
         return self.o_net(a), None
@@ -713,7 +713,7 @@ class _TorchMHAParams(_Site):
         qkv = ops.linear(query, self.in_proj_weight, self.in_proj_bias)
         pk = ops.packing()
         if pk is not None:
-            return self.out_proj(pk.pack(ops.attention(pk.unpack(qkv), self.num_heads, self._drop(self.dropout)))), None
+            return self.out_proj(pk.attention(qkv, None, None, self.num_heads)), None  # inference: no dropout
         return self.out_proj(ops.attention(qkv, self.num_heads, self._drop(self.dropout))), None
 
 

@@ -1226,6 +1226,8 @@ class packed_tokens:
 
     def __init__(self, sel, T, N):
         self.sel, self.T, self.N = sel, int(T), int(N)
+        self._rowmap = None
+        self._rows_ok = True  # the packed-row attention kernel takes this batch (decided by the library at the first call)
 
     def __enter__(self):
         if torch.is_grad_enabled():
@@ -1248,6 +1250,41 @@ class packed_tokens:
         out = xc.new_zeros(self.T * self.N, xc.shape[-1])
         out.index_copy_(0, self.sel, xc.reshape(-1, xc.shape[-1]))
         return out.view(self.T, self.N, -1)
+
+    def rowmap(self):
+        """(T * N,) int32: the packed row of the token at padded position t * N + n, -1 for padding (built once per batch)."""
+        if self._rowmap is None:
+            m = torch.full((self.T * self.N,), -1, device=self.sel.device, dtype=torch.int32)
+            m[self.sel] = torch.arange(self.sel.numel(), device=self.sel.device, dtype=torch.int32)
+            self._rowmap = m
+        return self._rowmap
+
+    def attention(self, q, k, v, nhead):
+        """The attention core of a packed batch: q / k / v (R, 1, d) (or q = the fused (R, 1, 3d) projection, k = v = None) ->
+        (R, 1, d).  Short batches (T <= 32, head_dim 64: what n-best hypotheses are) run on the packed rows themselves
+        (blm_attn_fwd_rows: the kernel finds a token's row through rowmap); anything else is scattered into the padded layout,
+        run through the ordinary kernels and gathered back -- a zero fill, an index_copy and a gather per layer."""
+        if self._rows_ok:
+            if k is None:
+                qkv = _f32(q, "qkv")
+                d = qkv.shape[-1] // 3
+                qq, kk, vv, ld = qkv, qkv[..., d:], qkv[..., 2 * d:], 3 * d
+            else:
+                qq, kk, vv = _f32(q, "q"), _f32(k, "k"), _f32(v, "v")
+                d = ld = qq.shape[-1]
+            R = qq.numel() // qq.shape[-1]
+            out = torch.empty(R, 1, d, device=qq.device, dtype=torch.float32)
+            L.require_gfx950()
+            rc = lib().blm_attn_fwd_rows(qq.data_ptr(), kk.data_ptr(), vv.data_ptr(), ld, ptr(out), ptr(self.rowmap()), self.T, self.N,
+                                         nhead, d // nhead, stream())
+            if rc == 0:
+                return out
+            if rc != L.ERR_UNSUPPORTED:
+                check(rc, "blm_attn_fwd_rows")
+            self._rows_ok = False
+        if k is None:
+            return self.pack(attention(self.unpack(q), nhead))
+        return self.pack(attention_qkv(self.unpack(q), self.unpack(k), self.unpack(v), nhead))
 
 
 def packing():

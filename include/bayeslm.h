@@ -356,6 +356,13 @@ int blm_attn_fwd(const float* q, const float* k, const float* v, int64_t ld_qkv,
 int blm_attn_bwd(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out, const float* dout,
                  const float* lse, float* dq, float* dk, float* dv, int64_t ld_dqkv, int T, int B, int nhead,
                  int head_dim, float p, const blm_rng* rng, int col_offset, int global_cols, void* stream);
+/* Inference on PACKED rows (the n-best scorer keeps only the real tokens of a padded (T, B) batch of hypotheses through the whole
+ * Transformer stack): q / k / v are (R, ld_qkv) and out (R, nhead * head_dim) matrices of the R real tokens, rowmap (T * B) int32
+ * gives the row of the token at padded position t * B + b or -1 for padding (the real tokens of a column are a prefix of it).
+ * Same arithmetic as blm_attn_fwd without dropout; nothing is scattered to or gathered from a padded buffer.  head_dim 64 and
+ * T <= 32 (one wave per head); anything else returns BLM_ERR_UNSUPPORTED and the caller scatters / gathers around blm_attn_fwd. */
+int blm_attn_fwd_rows(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, const int32_t* rowmap, int T,
+                      int B, int nhead, int head_dim, void* stream);
 /* The same backward with a caller-owned scratch buffer of blm_attn_bwd_ws_floats() floats (0: this shape has no use
  * for one): the dK/dV kernel leaves dS (B*nhead, T, T) there and dQ = dS K is one small product instead of a second
  * recomputation of the probabilities and their dropout masks.  ws == NULL is blm_attn_bwd.  Same results. */

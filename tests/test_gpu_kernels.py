@@ -830,6 +830,36 @@ def test_lstm_step_bwd_full_size_matches_composition(dev):
     assert torch.equal(dh2, outs[0][2])
 
 
+@pytest.mark.parametrize("T,N,nhead,fused", [(17, 9, 8, True), (32, 5, 4, False), (1, 3, 8, True), (40, 4, 8, True)])
+def test_attention_on_packed_rows_equals_scatter_attend_gather(dev, T, N, nhead, fused):
+    """ops.packed_tokens.attention: the attention core on the REAL tokens' rows of a padded (T, N) batch of hypotheses
+    (blm_attn_fwd_rows: the kernel finds a token's row through rowmap) == scatter into the padded layout, ordinary attention,
+    gather -- bit for bit (same kernel, same operands); T > 32 takes that fallback by itself."""
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(T * 7 + N)
+    d = nhead * 64
+    lens = torch.randint(1, T + 1, (N,), generator=g)
+    lens[0] = T
+    sel = torch.tensor([t * N + n for n in range(N) for t in range(int(lens[n]))], dtype=torch.int64)
+    sel = sel[torch.randperm(sel.numel(), generator=g)].to(dev)  # the caller's row order is arbitrary
+    R = sel.numel()
+    with torch.no_grad():
+        if fused:
+            qkv = (torch.randn(R, 1, 3 * d, generator=g) * 0.5).to(dev)
+            args = (qkv, None, None)
+        else:
+            args = tuple((torch.randn(R, 1, d, generator=g) * 0.5).to(dev) for _ in range(3))
+        with ops.packed_tokens(sel, T, N) as pk:
+            got = pk.attention(*args, nhead)
+            took_rows = pk._rows_ok
+            if fused:
+                want = pk.pack(ops.attention(pk.unpack(args[0]), nhead))
+            else:
+                want = pk.pack(ops.attention_qkv(pk.unpack(args[0]), pk.unpack(args[1]), pk.unpack(args[2]), nhead))
+    assert took_rows == (T <= 32)
+    assert got.shape == (R, 1, d) and torch.equal(got, want)
+
+
 def test_init_multi_and_colsum2(dev):
     """blm_init_multi: dst = (src or 0) + (src2 or 0) for up to eight vectors per launch (vector and scalar paths, more than eight
     split by the host, in-place sums, one buffer twice = two launches); blm_colsum2: the same column sums into two vectors."""
