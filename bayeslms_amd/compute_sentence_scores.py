@@ -245,11 +245,11 @@ def _carry_chain(model, stream_ids, offs, hidden, max_tokens=8192):
                 emb = ops.embed(seg, model.encoder.weight, None, 1.0, ops.NO_DROP)
                 last = model.rnn(emb, hidden)[1]
             if len(tap.layers) == nlayers:
-                hb = torch.stack([h for h, _ in tap.layers])  # (L, n_utt, 1, H)
-                cb = torch.stack([c for _, c in tap.layers])
+                hb = torch.stack([h for h, _ in tap.layers], 1)  # (n_utt, L, 1, H): an utterance's (L, 1, H) state is a contiguous
+                cb = torch.stack([c for _, c in tap.layers], 1)  # view of it, not a copy per utterance (two launches each before)
                 carries.append(hidden)
                 for k in range(v - u - 1):
-                    carries.append((hb[:, k].contiguous(), cb[:, k].contiguous()))
+                    carries.append((hb[k], cb[k]))
                 hidden = last
                 u = v
                 continue
