@@ -26,9 +26,10 @@ def main():
     from collections import OrderedDict
     css.compute_scores_batched(OrderedDict(list(nbest.items())[:150]), m, vocab, mtype, dev)
     torch.cuda.synchronize()
+    bt = int(os.environ.get("BATCH_TOKENS", "0")) or None  # padded tokens per batch (None: the scorer's default)
     for _ in range(reps):
         t0 = time.perf_counter()
-        css.compute_scores_batched(nbest, m, vocab, mtype, dev)
+        css.compute_scores_batched(nbest, m, vocab, mtype, dev, batch_tokens=bt)
         host = time.perf_counter() - t0
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
