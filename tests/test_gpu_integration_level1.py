@@ -42,10 +42,9 @@ def reference_shaped_run(cfg, data_dir, init, device):
     EVAL_COLS = 20
     streams = {"train": columns(text.train, cfg.batch_size), "valid": columns(text.valid, EVAL_COLS), "test": columns(text.test, EVAL_COLS)}
     recurrent = cfg.model != 'Transformer'
-    if recurrent:
-        net = shim.RNNModel(cfg.model, vocab, cfg.emsize, cfg.nhid, cfg.nlayers, cfg.dropout, cfg.tied).to(device)
-    else:
-        net = shim.TransformerModel(vocab, cfg.emsize, cfg.nhead, cfg.nhid, cfg.nlayers, cfg.dropout, "gelu", cfg.tied).to(device)
+    net = build_through_shim(shim, cfg, vocab).to(device)
+    extra_term = penalty_of(cfg)  # None, or net -> the divergence term this flag combination adds to the criterion
+    per_window = float(cfg.seq_len) / float(streams["train"].size(0))  # ... / len(train_data) * seq_len
     weights = net.state_dict()
     weights.update({name: t for name, t in init.items() if name in weights})  # --prior True: keys filtered by name
     net.load_state_dict(weights)
@@ -72,7 +71,9 @@ def reference_shaped_run(cfg, data_dir, init, device):
                 logits, state = net(x, detach(state))
             else:
                 logits = net(x)
-            nll = xent(logits.view(-1, vocab), y)  # --uncertainty none: no KL term
+            nll = xent(logits.view(-1, vocab), y)
+            if extra_term is not None:  # a torch scalar with a grad_fn: autograd carries it into the .grad tensors
+                nll = nll + extra_term(net) * per_window
             nll.backward()
             torch.nn.utils.clip_grad_norm_(net.parameters(), cfg.clip)
             opt.step()
@@ -124,7 +125,58 @@ def reference_shaped_run(cfg, data_dir, init, device):
     return hist
 
 
-@pytest.mark.parametrize("tag", ["tlm_none", "lstm_none"])
+def build_through_shim(shim, cfg, vocab):
+    """The constructor a maintainer's script reaches for each --model / --uncertainty pair (reference train.py:193-223), called
+    positionally as the reference calls it."""
+    kind = cfg.uncertainty
+    if cfg.model == 'Transformer':
+        head = (vocab, cfg.emsize, cfg.nhead, cfg.nhid, cfg.nlayers, cfg.dropout)
+        if kind == 'none':
+            return shim.TransformerModel(*head, "gelu", cfg.tied)
+        table = {'Bayesian': (shim.BayesTransformerModel, cfg.T_bayes_pos), 'Gaussian': (shim.GaussTransformerModel, cfg.T_gauss_pos),
+                 'Variational': (shim.VTransformerModel, cfg.T_v_pos)}
+    else:
+        head = (cfg.model, vocab, cfg.emsize, cfg.nhid, cfg.nlayers, cfg.dropout)
+        if kind == 'none':
+            return shim.RNNModel(*head, cfg.tied)
+        table = {'Bayesian': (shim.BayesRNNModel, cfg.L_bayes_pos), 'Gaussian': (shim.GaussRNNModel, cfg.L_gauss_pos),
+                 'Variational': (shim.VariationalRNNModel, cfg.L_v_pos)}
+    ctor, where = table[kind]
+    return ctor(*head, cfg.tied, where)
+
+
+def penalty_of(cfg):
+    """Which modules' kl_divergence() the reference's training loop adds for a flag combination (train.py:334-399), restated as a
+    table: (model, uncertainty) -> the list of module paths, summed.  An empty list means the loss is the criterion alone."""
+    paths = []
+    if cfg.uncertainty == 'Bayesian' and cfg.model == 'LSTM':
+        if cfg.L_bayes_pos in (1, 2, 3, 4, 5):
+            paths = ["rnn"]
+    elif cfg.uncertainty == 'Bayesian':
+        paths = {'FFN': ["transformerlayers.0.linear2"], 'MHA': ["transformerlayers.0.self_attn.o_net"]}.get(cfg.T_bayes_pos, [])
+        if cfg.T_bayes_pos == 'EMB':
+            return lambda net: net.embed_kl_divergence()
+    elif cfg.uncertainty == 'Gaussian' and cfg.model == 'Transformer':
+        if cfg.T_gauss_pos in (1, 2, 3):
+            paths = ["transformerlayers.0.gpnn"]
+    elif cfg.uncertainty == 'Gaussian':
+        digits = cfg.L_gauss_pos  # first digit: where in the cell, second: which tensors are random; 2 / 3 / 4 digits: which cells
+        if int(digits[0]) > 0 and int(digits[1]) in (1, 2, 3):
+            cells = {2: [0], 3: [1]}.get(len(digits), [0, 1])
+            paths = ["rnn.rnn.%d.gpnn" % c for c in cells]
+    elif cfg.uncertainty == 'Variational' and cfg.model == 'LSTM':
+        paths = ["rnn.rnn.%d.vnn" % c for c in (0, 1) if cfg.L_v_pos[c] == '1']
+    elif cfg.uncertainty == 'Variational':
+        paths = ["transformerlayers.%d" % i for i in {1: [0], 2: [1], 3: [0, 1]}.get(int(cfg.T_v_pos), [])]
+    if not paths:
+        return None
+    return lambda net: sum(net.get_submodule(p).kl_divergence() for p in paths)
+
+
+TRAJECTORIES = ["tlm_none", "lstm_none", "lstm_bayes5", "tlm_gauss3", "lstm_gauss33", "lstm_var00"]
+
+
+@pytest.mark.parametrize("tag", TRAJECTORIES)
 def test_shim_under_the_reference_loop_reproduces_train_py(tag, tmp_path):
     import argparse
     z, a, init, snaps = load_traj(tag)
@@ -133,7 +185,10 @@ def test_shim_under_the_reference_loop_reproduces_train_py(tag, tmp_path):
     args = argparse.Namespace(model=a["model"], emsize=int(a["emsize"]), nhid=int(a["nhid"]), nlayers=int(a["nlayers"]),
                               nhead=int(a.get("nhead", 2)), dropout=float(a["dropout"]), tied=bool(a.get("tied", False)),
                               batch_size=int(a["batch_size"]), seq_len=int(a["seq_len"]), clip=float(a["clip"]), lr=float(a["lr"]),
-                              epochs=int(a["epochs"]), log_interval=int(a["log_interval"]))
+                              epochs=int(a["epochs"]), log_interval=int(a["log_interval"]), uncertainty=a["uncertainty"],
+                              T_bayes_pos=a.get("T_bayes_pos", "none"), L_bayes_pos=int(a.get("L_bayes_pos", 0)),
+                              L_gauss_pos=a.get("L_gauss_pos", "00"), L_v_pos=a.get("L_v_pos", "11"),
+                              T_gauss_pos=int(a.get("T_gauss_pos", 3)), T_v_pos=int(a.get("T_v_pos", 0)))
     hist = reference_shaped_run(args, d, init, torch.device("cuda:0"))
     assert list(hist["halved_epochs"]) == list(z["halved_epochs"]), (hist["valid_loss"], list(z["valid_loss"]))
     assert np.allclose(hist["valid_loss"], z["valid_loss"], rtol=1e-4), (hist["valid_loss"], list(z["valid_loss"]))
