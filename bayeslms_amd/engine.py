@@ -9,8 +9,11 @@ remaining backward GEMMs; then one fused global-norm clip + SGD-momentum kernel 
 three flat buffers (train.py:419-420,466 semantics, averaged over ranks).
 """
 import contextlib
+import datetime
 import math
 import os
+import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -34,6 +37,92 @@ def pin_rccl_channels(n=None):
         os.environ.setdefault("NCCL_MIN_NCHANNELS", str(n))
         os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
     return {k: os.environ.get(k) for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS")}
+
+
+DIST_TIMEOUT_S = 180.0
+_T0 = time.time()
+_STAGE = {"last": "process start"}
+
+
+def heartbeat(stage, rank=None):
+    """One line on stderr per stage of a multi-rank run (``[blm rank R +S.Ss] stage``) and the stage remembered for
+    ``last_stage()``: a run that stops -- a rendezvous nobody joins, a collective one rank never enters -- says where.
+    bench.py's launcher parent parses these lines; they never go to stdout (the one JSON line lives there)."""
+    if rank is None:
+        rank = int(os.environ.get("RANK", "0"))
+    _STAGE["last"] = stage
+    sys.stderr.write("[blm rank %d +%.1fs] %s\n" % (rank, time.time() - _T0, stage))
+    sys.stderr.flush()
+
+
+def last_stage():
+    return _STAGE["last"]
+
+
+def dist_timeout_s(timeout_s=None):
+    return float(os.environ.get("BLM_DIST_TIMEOUT_S", DIST_TIMEOUT_S if timeout_s is None else timeout_s))
+
+
+def init_distributed(backend, device=None, timeout_s=None, **kw):
+    """dist.init_process_group with a BOUNDED rendezvous and collective timeout (``timeout_s`` or BLM_DIST_TIMEOUT_S or
+    180 s, not torch's 10 / 30 minutes: a rank that never arrives ends the job inside the timeout -- the store raises, and the
+    RCCL watchdog aborts the process when a collective outlives it), RCCL's channel count pinned first
+    (pin_rccl_channels), and two heartbeats: ``rendezvous ok`` when the group exists, ``first all-reduce ok`` after an
+    8-byte all-reduce whose result is checked (the first real contact of the ranks' communicators -- on RCCL the ring /
+    tree set-up over xGMI happens here).  -> the RCCL channel settings in force (None for another backend).
+    The reference has no counterpart: one process, one device (train.py:136)."""
+    timeout = datetime.timedelta(seconds=dist_timeout_s(timeout_s))
+    rccl_env = None
+    if backend == "nccl":
+        rccl_env = pin_rccl_channels()  # before RCCL reads its environment
+        if os.environ.get("NCCL_MAX_NCHANNELS"):
+            sys.stderr.write("[blm] RCCL channels pinned: %s (BLM_RCCL_CHANNELS=0 leaves RCCL's own choice)\n" % (rccl_env,))
+        dist.init_process_group("nccl", device_id=device, timeout=timeout, **kw)  # nccl == RCCL on ROCm
+    else:
+        dist.init_process_group(backend, timeout=timeout, **kw)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    heartbeat("rendezvous ok (world %d, backend %s, timeout %.0f s)" % (world, backend, timeout.total_seconds()), rank)
+    on_dev = backend == "nccl"
+    t = torch.ones(1, dtype=torch.float64, device=device if on_dev else "cpu")
+    dist.all_reduce(t)
+    if float(t.item()) != float(world):
+        raise RuntimeError("first all-reduce returned %r on rank %d, world %d" % (float(t.item()), rank, world))
+    heartbeat("first all-reduce ok", rank)
+    return rccl_env
+
+
+def allreduce_busbw(nbytes, reps=5, device=None, group=None):
+    """Stand-alone all-reduce of ``nbytes`` (fp32 sum), ``reps`` timed repetitions after one warm-up, nothing else on the
+    device: what the links give the gradient exchange when it does not share the chip with backward.
+    busbw = 2 (N-1)/N x bytes / time (the ring's per-link traffic, RCCL-tests' convention).  Collective: every rank calls."""
+    world = dist.get_world_size(group)
+    n = max(1, int(nbytes) // 4)
+    cuda = device is not None and torch.device(device).type == "cuda"
+    x = torch.zeros(n, dtype=torch.float32, device=device if cuda else "cpu")
+    dist.all_reduce(x, group=group)
+    if cuda:
+        torch.cuda.synchronize()
+    dist.barrier(group)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(x, group=group)
+    if cuda:
+        torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / reps
+    t = torch.tensor([el], dtype=torch.float64, device=device if (cuda and dist.get_backend(group) == "nccl") else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    el = float(t.item())
+    alg = n * 4 / el / 1e9
+    return {"mb": round(n * 4 / 1e6, 2), "reps": reps, "ms": round(1e3 * el, 4), "algbw_gbps": round(alg, 2),
+            "busbw_gbps": round(alg * 2.0 * (world - 1) / max(world, 1), 2)}
+
+
+def rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def rccl_channels():
@@ -119,6 +208,11 @@ class GradReducer:
         self.no_dense = set()  # buckets whose only tensor gets ALL of its gradient through LateRows (untied encoder)
         self.measure = False  # record (backward end, communication end) event pairs on the compute stream
         self.exposed_events = []
+        # diagnostics, one step at a time (bench.py's comm block): every collective of the step bracketed on the communication
+        # stream -> bucket_report().  The bracket makes the communication stream wait for each collective in turn, so it is
+        # never on inside a timed region
+        self.measure_buckets = False
+        self.bucket_events, self.bucket_marks = [], []
         # buckets = contiguous runs of parameters, built from the END of the buffer (backward order).  Two refinements
         # for what is exposed at the end of backward:
         #  * a tensor of a bucket's size or more travels ALONE (the tied encoder / decoder weight, 67.6 MB at cfg3: with
@@ -208,7 +302,7 @@ class GradReducer:
     def _all_reduce(self, view):
         self.reduced_elems += view.numel()
         if self.cuda:
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.measure_buckets)
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
             if self.comm_plan == "window":
@@ -221,8 +315,21 @@ class GradReducer:
                 self.collective(view, self.comm_stream)
                 return
             with torch.cuda.stream(self.comm_stream):
+                if self.measure_buckets:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm_stream)
+                    h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    h.wait()  # the communication stream (not the host, on RCCL) waits for this collective
+                    e1.record(self.comm_stream)
+                    self.bucket_events.append((view.numel() * view.element_size(), ev, e0, e1))
+                    return
                 self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
+            if self.measure_buckets:
+                t0 = time.perf_counter()
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                self.bucket_marks.append((view.numel() * view.element_size(), t0, time.perf_counter()))
+                return
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
@@ -239,9 +346,11 @@ class GradReducer:
                 if b is not None and self.expected[k] == 0 and len(self.buckets[b][2]) == 1:
                     self.no_dense.add(b)
         ev0 = None
-        if self.measure and self.cuda:
+        if (self.measure or self.measure_buckets) and self.cuda:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record(torch.cuda.current_stream())
+            self.bwd_end_event = ev0
+        self.bwd_end_mark = time.perf_counter()
         for b in range(len(self.buckets)):
             self._launch(b)
         for h in self.handles:
@@ -254,13 +363,36 @@ class GradReducer:
             else:
                 ops.set_gemm_cus(0)
             self._narrowed = False
-        if ev0 is not None:
+        if ev0 is not None and self.measure:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record(torch.cuda.current_stream())
             self.exposed_events.append((ev0, ev1))
         if self.late is not None:
             self.late.apply()
         self.reset()
+
+    def bucket_report(self):
+        """After ONE step taken with ``measure_buckets`` raised: one entry per collective of that step, in launch order --
+        its size, launch -> done on the communication stream (ms), and where it sat relative to the end of backward
+        (``ready_before_bwd_end_ms``: how long before the last backward kernel the bucket's gradients were complete;
+        ``done_after_bwd_end_ms`` > 0: that much of it was exposed).  Synchronises; clears the record."""
+        out = []
+        if self.cuda:
+            torch.cuda.synchronize()
+            end = getattr(self, "bwd_end_event", None)
+            for nbytes, ready, e0, e1 in self.bucket_events:
+                r = {"mb": round(nbytes / 1e6, 2), "ms": round(e0.elapsed_time(e1), 4)}
+                if end is not None:
+                    r["ready_before_bwd_end_ms"] = round(ready.elapsed_time(end), 4)
+                    r["done_after_bwd_end_ms"] = round(end.elapsed_time(e1), 4)
+                out.append(r)
+        else:
+            for nbytes, t0, t1 in self.bucket_marks:
+                out.append({"mb": round(nbytes / 1e6, 4), "ms": round(1e3 * (t1 - t0), 4),
+                            "ready_before_bwd_end_ms": round(1e3 * (self.bwd_end_mark - t0), 4),
+                            "done_after_bwd_end_ms": round(1e3 * (t1 - self.bwd_end_mark), 4)})
+        self.bucket_events, self.bucket_marks = [], []
+        return out
 
     def comm_exposed_ms(self):
         """Average time per step the compute stream sat between the last backward kernel and the end of the

@@ -62,6 +62,9 @@ def build_parser():
     p.add_argument('--dist-backend', type=str, default='nccl',
                    help='new, optional (under torchrun): torch.distributed backend; nccl = RCCL over xGMI, one GPU per rank; '
                         'gloo lets several ranks rehearse on one GPU')
+    p.add_argument('--dist-timeout-s', type=float, default=None,
+                   help='new, optional (under torchrun): rendezvous and collective timeout in seconds (default 180, BLM_DIST_TIMEOUT_S): '
+                        'a rank that never arrives, or a collective one rank never enters, ends the job instead of hanging it')
     p.add_argument('--dp-overlap', type=int, default=1,
                    help='new, optional: 1 = bucket all-reduces start while backward is still running, 0 = all after backward')
     p.add_argument('--dp-late-rows', type=int, default=1,
@@ -219,12 +222,12 @@ def main(argv=None, history=None):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        if args.dist_backend == "nccl":
-            from .engine import pin_rccl_channels
-            say("RCCL channels:", pin_rccl_channels())  # before RCCL reads its environment (engine.pin_rccl_channels)
-            dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
-        else:
-            dist.init_process_group(args.dist_backend)
+        # bounded rendezvous / collective timeout (--dist-timeout-s, BLM_DIST_TIMEOUT_S, 180 s), RCCL's channel count pinned before
+        # RCCL reads its environment, `rendezvous ok` / `first all-reduce ok` heartbeats on stderr (engine.init_distributed)
+        from .engine import init_distributed
+        rccl_env = init_distributed(args.dist_backend, device if args.dist_backend == "nccl" else None, args.dist_timeout_s)
+        if rccl_env is not None:
+            say("RCCL channels:", rccl_env)
 
     from . import data as D, engine, ops
     from .model import repackage_hidden
@@ -305,6 +308,8 @@ def main(argv=None, history=None):
         for epoch in range(1, args.epochs + 1):
             t0 = time.time()
             train_epoch(epoch, sched.lr)
+            if world > 1:
+                engine.heartbeat("epoch %d trained" % epoch, rank)
             val_loss, improved, stop = sched.update(engine.evaluate(model, val_data, args.seq_len, rank=rank, world=world))
             say('-' * 89)
             say('| end of epoch {:3d} | time: {:5.2f}s | valid loss {:5.2f} | valid ppl {:8.2f}'.format(

@@ -60,18 +60,51 @@ def parse():
                     "rehearsing several ranks on one GPU)")
     ap.add_argument("--dp-overlap", type=int, default=1, help="N > 1: 0 = every bucket all-reduced after backward")
     ap.add_argument("--dp-late-rows", type=int, default=1, help="N > 1: 0 = the tied encoder gradient travels dense")
+    ap.add_argument("--deadline-s", type=float, default=None,
+                    help="N > 1: overall wall-clock bound of the run (default 420; 0 = none).  Every rank arms a timer that prints "
+                         "ONE error JSON line (rank 0) and exits 124 when it fires; the self-launching parent enforces the same bound "
+                         "+ 15 s from outside (it terminates the child process group) for ranks that cannot run their own timer")
+    ap.add_argument("--dist-timeout-s", type=float, default=None,
+                    help="N > 1: rendezvous / collective timeout handed to init_process_group (default 180, BLM_DIST_TIMEOUT_S)")
+    ap.add_argument("--comm-ab-steps", type=int, default=5,
+                    help="N > 1: steps of each A/B leg after the timed region (overlap off, comm-window plans off); 0 skips them")
+    ap.add_argument("--rehearse-hang", type=str, default="",
+                    help="test knob of --rehearse-launch: RANK:STAGE[:gil] (RANK `*` = every rank) -- that rank stops for ever when it reaches STAGE "
+                         "(rendezvous | warmup | timed); `gil` holds the interpreter lock so that its own deadline timer cannot run")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launch plumbing only (spawn, rendezvous, barrier, max-over-ranks, one JSON line from rank 0) "
                          "with NO GPU work: what the CPU-side test of `--gpus N` self-launch runs")
     return ap.parse_args()
 
 
+ERROR_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "error", "last_stage")
+
+
+def error_line(n_gpus, error, last_stage, **extra):
+    """The ONE JSON line of a run that did not finish: same head as the normal line, value null."""
+    return json.dumps({"metric": "train_tokens_per_sec", "value": None, "unit": "tokens/s", "n_gpus": n_gpus, "error": error,
+                       "last_stage": last_stage, **extra})
+
+
+def deadline_of(args):
+    if args.deadline_s is not None:
+        return max(0.0, args.deadline_s)
+    return 420.0 if args.gpus > 1 else 0.0
+
+
 def self_launch(args):
-    """`python bench.py --gpus N` from ONE process: run the N ranks as a child `torch.distributed.run` and relay its
-    output and exit code.  This process has not made (and never makes) a GPU call -- a process that has initialised
-    HIP must not be replaced or forked into ranks."""
+    """`python bench.py --gpus N` from ONE process: run the N ranks as a child `torch.distributed.run` (its own process
+    group / session) and relay its output and exit code.  This process has not made (and never makes) a GPU call -- a
+    process that has initialised HIP must not be replaced or forked into ranks.  It is also the run's outer bound: the
+    ranks' stderr heartbeats (`[blm rank R +S.Ss] stage`) are relayed and remembered, and when the child has neither ended
+    nor printed its line `--deadline-s` + 15 s after the start, its process group is terminated (SIGTERM, 10 s later
+    SIGKILL), ONE JSON line {"metric", "value": null, "error", "last_stage"} goes to stdout and the exit code is 124.  A child
+    that ends non-zero without a line gets the same line with its exit code."""
+    import re
+    import signal
     import socket
     import subprocess
+    import threading
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -81,29 +114,246 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    for line in proc.stdout:  # the ranks' stdout: rank 0's JSON line (anything else is passed through as well)
-        sys.stdout.write(line)
-        sys.stdout.flush()
-    return proc.wait()
+    t_start = time.time()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    stages, json_lines = {}, []
+    beat = re.compile(r"^\[blm rank (\d+) \+([0-9.]+)s\] (.*)$")
+
+    def pump_out():
+        for line in proc.stdout:  # the ranks' stdout: rank 0's JSON line (anything else is passed through as well)
+            if line.startswith("{"):
+                json_lines.append(line)
+            sys.stdout.write(line)
+            sys.stdout.flush()
+
+    def pump_err():
+        for line in proc.stderr:
+            m = beat.match(line.rstrip("\n"))
+            if m:
+                stages[int(m.group(1))] = m.group(3)
+            sys.stderr.write(line)
+            sys.stderr.flush()
+    threads = [threading.Thread(target=pump_out, daemon=True), threading.Thread(target=pump_err, daemon=True)]
+    for t in threads:
+        t.start()
+    limit = deadline_of(args)
+    try:
+        rc = proc.wait(timeout=(limit + 15.0) if limit > 0 else None)
+    except subprocess.TimeoutExpired:
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
+            try:
+                os.killpg(proc.pid, sig)  # the child's own group (start_new_session): the agent and every rank, nothing else
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        for t in threads:
+            t.join(timeout=5.0)
+        if not json_lines:
+            print(error_line(args.gpus, "deadline: no result %.0f s after the launch (--deadline-s %.0f + 15 s); the child process "
+                                        "group was terminated by the launcher" % (time.time() - t_start, limit),
+                             {"rank %d" % r: s_ for r, s_ in sorted(stages.items())} or "no heartbeat seen"), flush=True)
+        return 124
+    for t in threads:
+        t.join(timeout=5.0)
+    if rc != 0 and not json_lines:
+        print(error_line(args.gpus, "the ranks ended with exit code %d and no result line" % rc,
+                         {"rank %d" % r: s_ for r, s_ in sorted(stages.items())} or "no heartbeat seen"), flush=True)
+    return rc
+
+
+def arm_deadline(args, rank, world):
+    """In-rank half of the bound: a timer thread that, `--deadline-s` after the start, writes where this rank was, prints the
+    ONE error JSON line on rank 0 and leaves the process with 124 (os._exit: the main thread may be inside a collective that
+    will never return; nothing is exec'ed or replaced).  torchrun then ends the other ranks.  -> the timer (cancel it)."""
+    import threading
+    limit = deadline_of(args)
+    if limit <= 0 or world <= 1:
+        return None
+    from bayeslms_amd import engine
+
+    def fire():
+        stage = engine.last_stage()
+        sys.stderr.write("[blm rank %d] DEADLINE %.0f s: still after stage %r -- giving up\n" % (rank, limit, stage))
+        sys.stderr.flush()
+        if rank == 0:
+            print(error_line(world, "deadline: %.0f s (--deadline-s) passed on rank 0" % limit, stage), flush=True)
+        os._exit(124)
+    t = threading.Timer(limit, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def _timed_steps(step_fn, n, first, dev, world):
+    """n steps bracketed like the headline's timed region -> ms per step, max over ranks."""
+    cuda = dev is not None and dev.type == "cuda"
+    if cuda:
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(n):
+        step_fn(first + i)
+    if cuda:
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev if (cuda and dist.get_backend() == "nccl") else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return round(1e3 * el / max(n, 1), 4)
+
+
+def comm_diagnostics(red, step_fn, first, n_ab, dev, world):
+    """After the timed region, so that ONE multi-GPU line explains its own scaling (every rank calls; same order everywhere):
+      * `buckets_last_step`: one more step with every collective bracketed on the communication stream
+        (GradReducer.bucket_report: size, launch -> done, position relative to the end of backward);
+      * `step_ms_as_configured` / `step_ms_no_overlap` / `step_ms_no_comm_window`: n_ab steps each, same barrier + max-over-ranks
+        bracket -- all buckets after backward (what the overlap buys), and the GEMM planner's comm-window plans off (what
+        leaving CUs to the channel workgroups buys or costs)."""
+    rep = {}
+    red.measure_buckets = True
+    try:
+        step_fn(first)
+        rep["buckets_last_step"] = red.bucket_report()
+    finally:
+        red.measure_buckets = False
+    first += 1
+    if n_ab > 0:
+        rep["ab_steps"] = n_ab
+        rep["step_ms_as_configured"] = _timed_steps(step_fn, n_ab, first, dev, world)
+        first += n_ab
+        if red.overlap:
+            red.overlap = False
+            try:
+                rep["step_ms_no_overlap"] = _timed_steps(step_fn, n_ab, first, dev, world)
+            finally:
+                red.overlap = True
+            first += n_ab
+        else:
+            rep["step_ms_no_overlap"] = None
+        if red.comm_plan != "off":
+            keep, red.comm_plan = red.comm_plan, "off"
+            try:
+                rep["step_ms_no_comm_window"] = _timed_steps(step_fn, n_ab, first, dev, world)
+            finally:
+                red.comm_plan = keep
+        else:
+            rep["step_ms_no_comm_window"] = None
+    return rep
+
+
+def comm_block(args, engine, red, flat, rccl_env, busbw, diag, replicas_identical):
+    """The `comm` object of a multi-rank line (rank 0 assembles it; the collective parts were measured on every rank)."""
+    return {
+        "backend": args.backend, "world_seen": dist.get_world_size(), "rccl_version": engine.rccl_version() if args.backend == "nccl" else None,
+        "dist_timeout_s": engine.dist_timeout_s(args.dist_timeout_s),
+        "overlap": bool(args.dp_overlap), "buckets": len(red.buckets),
+        # sizes in backward (launch) order: full 32 MB runs, big tensors alone, quarter-size tail buckets
+        "bucket_mb": [round((e - s) * 4 / 1e6, 2) for s, e, _ in red.buckets],
+        "exchanged_mb_last_step": round(red.last_reduced_elems * 4 / 1e6, 2),
+        # the bucket that becomes ready last (layer 0's first parameters): the all-reduce nothing can hide
+        "last_bucket_mb": round((red.buckets[-1][1] - red.buckets[-1][0]) * 4 / 1e6, 2),
+        "grad_bytes": int(flat.total * 4),
+        # stand-alone all-reduces before training, nothing else on the device (engine.allreduce_busbw): the whole gradient and one bucket
+        "allreduce_busbw_gbps": None if not busbw else busbw[0]["busbw_gbps"], "allreduce_standalone": busbw,
+        # RCCL channel count as pinned before init_process_group (engine.pin_rccl_channels) and the CUs the GEMM
+        # planner leaves to the channel workgroups while buckets are in flight (DESIGN 6)
+        "rccl_env": rccl_env, "gemm_cus_under_comm": 256 - red.comm_cus, "comm_plan": red.comm_plan,
+        # parameter checksums of all ranks after the last step, gathered and compared (outside the timed region)
+        "replicas_identical": replicas_identical,
+        "late_rows": red.late is not None,
+        "late_rows_last_step": None if red.late is None else int(red.late.U),
+        **(diag or {}),
+    }
+
+
+def _maybe_hang(args, rank, stage):
+    """--rehearse-hang RANK:STAGE[:gil] (tests of the deadline paths): this rank never gets past `stage`."""
+    if not args.rehearse_hang:
+        return
+    part = args.rehearse_hang.split(":")
+    if (part[0] != "*" and int(part[0]) != rank) or part[1] != stage:
+        return
+    if len(part) > 2 and part[2] == "gil":
+        import ctypes
+        ctypes.PyDLL(None).sleep(10 ** 6)  # a C call that keeps the interpreter lock: this rank's own timer thread cannot run
+    while True:
+        time.sleep(3600)
+
+
+class _HostStandIn:
+    """--rehearse-launch: what stands where engine.Trainer stands in the real run, on CPU tensors -- a small torch network whose
+    parameters live in engine.FlatBuffers, gradients exchanged by the real engine.GradReducer (autograd hooks, buckets,
+    LateRows for the tied embedding) over gloo, plain SGD.  No kernels of the library are involved and nothing is measured
+    for the record; it exists so that every line of the multi-rank protocol runs where there is no GPU."""
+
+    def __init__(self, engine, rank, world, overlap):
+        import torch.nn as nn
+        torch.manual_seed(1111)
+        self.Vs, d = 96, 16
+        self.net = nn.ModuleDict({"encoder": nn.Embedding(self.Vs, d), "l1": nn.Linear(d, 64), "l2": nn.Linear(64, d)})
+        self.flat = engine.FlatBuffers(self.net)
+        self.reducer = engine.GradReducer(self.flat, bucket_bytes=2048, overlap=overlap)
+        self.reducer.hook_autograd()
+        self.rank, self.world = rank, world
+
+    def step(self, i):
+        g = torch.Generator().manual_seed(1000 * i + self.rank)
+        ids = torch.randint(0, self.Vs, (12, 3), generator=g)
+        tgt = torch.randint(0, self.Vs, (36,), generator=g)
+        self.flat.zero_grad()
+        h = self.net["l2"](torch.tanh(self.net["l1"](self.net["encoder"](ids))))
+        loss = torch.nn.functional.cross_entropy(h.view(-1, h.shape[-1]) @ self.net["encoder"].weight.t(), tgt)
+        loss.backward()
+        self.reducer.finish()
+        with torch.no_grad():
+            self.flat.flat_param.add_(self.flat.flat_grad, alpha=-0.1 / self.world)
+        return loss.detach()
 
 
 def rehearse_launch(args, world, rank):
-    """No GPU: every step of the multi-rank protocol around the timed region, on CPU tensors."""
-    dist.init_process_group("gloo" if args.backend == "nccl" else args.backend)
-    dist.barrier()
-    t0 = time.perf_counter()
-    x = torch.ones(1 << 16)
-    for _ in range(args.steps):
-        dist.all_reduce(x)
-    dist.barrier()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    """No GPU: every step of the multi-rank protocol around (and after) the timed region, on CPU tensors over gloo -- the bounded
+    rendezvous, the heartbeats, the deadline timer, the stand-alone all-reduce, warm-up, the barrier-bracketed timed steps with
+    max over ranks, the replica check, the comm diagnostics (per-bucket times, A/B legs) and the one JSON line from rank 0."""
+    from bayeslms_amd import engine
+    timer = arm_deadline(args, rank, world)
+    _maybe_hang(args, rank, "rendezvous")
+    backend = "gloo" if args.backend == "nccl" else args.backend
+    engine.init_distributed(backend, None, args.dist_timeout_s)
+    tr = _HostStandIn(engine, rank, world, bool(args.dp_overlap))
+    busbw = [engine.allreduce_busbw(tr.flat.total * 4, 3), engine.allreduce_busbw(1 << 16, 3)]
+    engine.heartbeat("stand-alone all-reduce ok", rank)
+    _maybe_hang(args, rank, "warmup")
+    for i in range(args.warmup):
+        tr.step(i)
+    engine.heartbeat("warm-up ok (%d steps)" % args.warmup, rank)
+    _maybe_hang(args, rank, "timed")
+    ms = _timed_steps(tr.step, args.steps, args.warmup, None, world)
+    engine.heartbeat("timed region ok (%d steps)" % args.steps, rank)
+    fp = tr.flat.flat_param
+    mine = torch.stack([fp.double().sum(), fp.double().abs().sum()])
+    every = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    identical = all(bool(torch.equal(e, every[0])) for e in every)
+    diag = comm_diagnostics(tr.reducer, tr.step, args.warmup + args.steps, args.comm_ab_steps, None, world)
+    engine.heartbeat("comm diagnostics ok", rank)
     if rank == 0:
+        args.backend = backend
         print(json.dumps({"metric": "train_tokens_per_sec", "value": None, "unit": "tokens/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * float(t) / max(args.steps, 1), 3),
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+                          "comm": comm_block(args, engine, tr.reducer, tr.flat, None, busbw, diag, identical),
                           "rehearsal": "launch plumbing only, no GPU work: NOT a measurement"}), flush=True)
+        engine.heartbeat("line printed", rank)
     dist.barrier()
+    if timer is not None:
+        timer.cancel()
     dist.destroy_process_group()
 
 
@@ -695,14 +945,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rccl_env = None
+    from bayeslms_amd import engine as _eng
+    timer_dl = arm_deadline(args, rank, world)
     if world > 1:
-        if args.backend == "nccl":
-            from bayeslms_amd.engine import pin_rccl_channels
-            rccl_env = pin_rccl_channels()  # before RCCL reads its environment: channel workgroups hold CUs beside the GEMMs
-            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
-        else:
-            dist.init_process_group(args.backend)
-
+        # bounded rendezvous + collective timeout, RCCL channels pinned before RCCL reads its environment (channel workgroups
+        # hold CUs beside the GEMMs), heartbeats `rendezvous ok` / `first all-reduce ok` on stderr (engine.init_distributed)
+        rccl_env = _eng.init_distributed(args.backend, dev if args.backend == "nccl" else None, args.dist_timeout_s)
     from bayeslms_amd import engine, model as M, ops
     from bayeslms_amd.data import batchify, get_batch, synthetic_corpus
 
@@ -736,10 +984,19 @@ def main():
         loss, kl, _ = tr.step(data, targets, kl_fn=kl_fn)
         return loss
 
+    busbw = None
+    if world > 1:
+        _eng.heartbeat("model built (%d parameters, %d buckets)" % (tr.flat.total, len(tr.reducer.buckets)), rank)
+        # stand-alone all-reduces before training: the whole gradient and one 32 MB bucket (gloo rehearsals: 8 MB, the host moves it)
+        cap = None if args.backend == "nccl" else (8 << 20)
+        busbw = [_eng.allreduce_busbw(min(tr.flat.total * 4, cap or (1 << 62)), 5, dev),
+                 _eng.allreduce_busbw(min(32 << 20, cap or (1 << 62)), 5, dev)]
+        _eng.heartbeat("stand-alone all-reduce ok (%.1f MB: busbw %.1f GB/s)" % (busbw[0]["mb"], busbw[0]["busbw_gbps"]), rank)
     for i in range(args.warmup):
         loss = one(i, timer_all if i >= args.warmup - side_tags else None)
     torch.cuda.synchronize()
     if world > 1:
+        _eng.heartbeat("warm-up ok (%d steps)" % args.warmup, rank)
         dist.barrier()
     torch.cuda.synchronize()
     tr.reducer.measure = world > 1  # event pair per step: last backward kernel -> end of the gradient exchange
@@ -755,7 +1012,9 @@ def main():
     tr.reducer.measure = False
     comm_exposed = tr.reducer.comm_exposed_ms()
     replicas_identical = None
+    diag = None
     if world > 1:
+        _eng.heartbeat("timed region ok (%d steps)" % args.steps, rank)
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -767,6 +1026,14 @@ def main():
         dist.all_gather(every, mine)
         replicas_identical = all(bool(torch.equal(e, every[0])) for e in every)
     final_loss = float(loss)
+    if world > 1:
+        # outside the timed region, every rank: per-bucket brackets of one more step, then the A/B legs (overlap off; comm-window
+        # plans off), the windows of the stream re-used
+        try:
+            diag = comm_diagnostics(tr.reducer, lambda i: one(i % steps_total, None), steps_total, args.comm_ab_steps, dev, world)
+            _eng.heartbeat("comm diagnostics ok", rank)
+        except Exception as e:  # noqa: BLE001 -- a diagnostic must never cost the headline line (a stuck collective ends in the deadline)
+            diag = {"diagnostics_error": repr(e)}
     # eval PPL (the other half of BASELINE.json's metric): mean-weight forward on held-out synthetic
     # text exactly as train.py:441-458 (eval batch 20), outside the timed region
     eval_ppl = None
@@ -845,21 +1112,7 @@ def main():
             # rank 0, per step: time the compute stream waited between its last backward kernel and the end of the
             # gradient exchange (bucketed all-reduce + the compact embedding-row exchange); null at N = 1
             "comm_exposed_ms": None if comm_exposed is None else round(comm_exposed, 4),
-            "comm": None if world == 1 else {
-                "backend": args.backend, "overlap": bool(args.dp_overlap), "buckets": len(tr.reducer.buckets),
-                # sizes in backward (launch) order: full 32 MB runs, big tensors alone, quarter-size tail buckets
-                "bucket_mb": [round((e - s) * 4 / 1e6, 2) for s, e, _ in tr.reducer.buckets],
-                "exchanged_mb_last_step": round(tr.reducer.last_reduced_elems * 4 / 1e6, 2),
-                # the bucket that becomes ready last (layer 0's first parameters): the all-reduce nothing can hide
-                "last_bucket_mb": round((tr.reducer.buckets[-1][1] - tr.reducer.buckets[-1][0]) * 4 / 1e6, 2),
-                "grad_bytes": int(tr.flat.total * 4),
-                # RCCL channel count as pinned before init_process_group (engine.pin_rccl_channels) and the CUs the GEMM
-                # planner leaves to the channel workgroups while buckets are in flight
-                "rccl_env": rccl_env, "gemm_cus_under_comm": 256 - tr.reducer.comm_cus, "comm_plan": tr.reducer.comm_plan,
-                # parameter checksums of all ranks after the last step, gathered and compared (outside the timed region)
-                "replicas_identical": replicas_identical,
-                "late_rows": tr.reducer.late is not None,
-                "late_rows_last_step": None if tr.reducer.late is None else int(tr.reducer.late.U)},
+            "comm": None if world == 1 else comm_block(args, engine, tr.reducer, tr.flat, rccl_env, busbw, diag, replicas_identical),
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -886,8 +1139,12 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["extra_configs"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
+        if world > 1:
+            _eng.heartbeat("line printed", rank)
     if world > 1:
         dist.barrier()  # rank 0 is still evaluating / printing: nobody tears the communicator down under it
+        if timer_dl is not None:
+            timer_dl.cancel()
         dist.destroy_process_group()
 
 

@@ -178,9 +178,11 @@ def _rccl_one_rank(port, ret):
     torch.cuda.set_device(0)
     for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS"):
         os.environ.pop(k, None)
-    pinned = engine.pin_rccl_channels()  # as bench.py / train.py do before RCCL reads its environment
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    # as bench.py / train.py do it: channels pinned before RCCL reads its environment, bounded timeout, checked first all-reduce
+    pinned = engine.init_distributed("nccl", dev, 120, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     try:
+        bw = engine.allreduce_busbw(8 << 20, 3, dev)  # the stand-alone all-reduce of bench.py's comm block, on RCCL
+        assert bw["mb"] == 8.39 and bw["ms"] > 0 and bw["busbw_gbps"] == 0.0 and engine.rccl_version()  # (N-1)/N = 0 at one rank
         x = torch.arange(1024, device=dev, dtype=torch.float32)
         side = torch.cuda.Stream()
         ev = torch.cuda.Event()
@@ -207,6 +209,14 @@ def _rccl_one_rank(port, ret):
             loss, _, _ = tr.step(data, tgt, kl_fn=_kl)
             losses.append(float(loss))
             comm_ok = comm_ok and float(_lib.lib().blm_gemm_plan_comm_window_left()) == 0.0
+        # per-bucket brackets on the communication stream around RCCL's own asynchronous work objects (bench.py's comm block)
+        tr.reducer.measure_buckets = True
+        data, tgt = D.get_batch(train, 36, 12)
+        loss, _, _ = tr.step(data, tgt, kl_fn=_kl)
+        rep = tr.reducer.bucket_report()
+        tr.reducer.measure_buckets = False
+        comm_ok = comm_ok and len(rep) >= len(tr.reducer.buckets) and all(r["ms"] > 0 and "done_after_bwd_end_ms" in r for r in rep)
+        losses.append(float(loss))
         ret["rccl"] = (ok_identity and comm_ok, losses, bool(torch.isfinite(tr.flat.flat_param).all()))
     finally:
         dist.destroy_process_group()
@@ -247,3 +257,10 @@ def test_bench_gpus2_self_launch_rehearsal_on_one_device():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0
     assert out["comm_exposed_ms"] is not None and out["comm"]["late_rows"] and out["comm"]["late_rows_last_step"] > 0
     assert out["comm"]["replicas_identical"] is True  # parameter checksums of both ranks, gathered after the last step
+    c = out["comm"]  # the line explains its own scaling
+    assert c["world_seen"] == 2 and c["allreduce_busbw_gbps"] > 0 and c["dist_timeout_s"] == 180.0
+    assert len(c["buckets_last_step"]) >= c["buckets"] and all(b["ms"] > 0 for b in c["buckets_last_step"])
+    assert c["ab_steps"] == 5 and c["step_ms_as_configured"] > 0 and c["step_ms_no_overlap"] > 0 and "step_ms_no_comm_window" in c
+    for stage in ("rendezvous ok", "first all-reduce ok", "model built", "stand-alone all-reduce ok", "warm-up ok", "timed region ok",
+                  "comm diagnostics ok", "line printed"):
+        assert stage in r.stderr, stage

@@ -1,6 +1,7 @@
 """CPU: host-side logic -- data layout vs the reference's own outputs, state_dict contract,
 data-parallel column sharding and the gradient reducer under gloo (world_size 2)."""
 import os
+import time
 import socket
 import tempfile
 
@@ -263,28 +264,100 @@ def test_grad_reducer_never_infers_readiness():
     red.unhook()
 
 
-def test_bench_self_launches_its_ranks_from_one_process():
-    """VERDICT r1 / ADVICE: `python bench.py --gpus N` must start its own ranks (a torch.distributed.run child, before
-    any GPU call) instead of exiting.  CPU side: the launch plumbing only (--rehearse-launch: no GPU work)."""
-    import json
+def _bench(argv, env_extra=None, timeout=300):
     import subprocess
     import sys
     env = dict(os.environ)
-    env.pop("WORLD_SIZE", None)
-    env.pop("RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
-                        "--warmup", "1", "--rehearse-launch"], capture_output=True, text=True, timeout=600, env=env,
-                       cwd="/tmp")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout,
+                       env=env, cwd="/tmp")
+    return r, time.time() - t0
+
+
+def test_bench_self_launches_its_ranks_from_one_process():
+    """VERDICT r1 / ADVICE: `python bench.py --gpus N` must start its own ranks (a torch.distributed.run child, before
+    any GPU call) instead of exiting.  CPU side: the launch plumbing only (--rehearse-launch: no GPU work).
+    VERDICT r4 #1: the rehearsal walks every stage of the real multi-rank run (bounded rendezvous, heartbeats, stand-alone
+    all-reduce, timed region, replica check, per-bucket brackets, A/B legs) and fills every field of the `comm` block."""
+    import json
+    r, _ = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--rehearse-launch"])
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] is None
+    c = out["comm"]
+    assert c["world_seen"] == 2 and c["backend"] == "gloo" and c["dist_timeout_s"] == 180.0 and c["replicas_identical"] is True
+    assert "rccl_version" in c and c["allreduce_busbw_gbps"] > 0 and len(c["allreduce_standalone"]) == 2
+    assert c["allreduce_standalone"][0]["mb"] == round(c["grad_bytes"] / 1e6, 2)
+    b = c["buckets_last_step"]  # one entry per collective of one step, launch order = backward order
+    assert len(b) == c["buckets"] >= 3 and all(x["ms"] > 0 and "ready_before_bwd_end_ms" in x and "done_after_bwd_end_ms" in x for x in b)
+    assert abs(sum(x["mb"] for x in b) - c["grad_bytes"] / 1e6) < 1e-3
+    assert c["ab_steps"] == 5 and c["step_ms_as_configured"] > 0 and c["step_ms_no_overlap"] > 0
+    assert "step_ms_no_comm_window" in c  # null here: host tensors have no CUs to plan around (comm_plan "off")
+    for stage in ("rendezvous ok (world 2, backend gloo, timeout 180 s)", "first all-reduce ok", "stand-alone all-reduce ok",
+                  "warm-up ok (1 steps)", "timed region ok (2 steps)", "comm diagnostics ok"):
+        for rank in (0, 1):
+            assert any(ln.startswith("[blm rank %d +" % rank) and ln.endswith("] " + stage) for ln in r.stderr.splitlines()), (rank, stage)
+    assert "[blm rank 0 +" in r.stderr and "line printed" in r.stderr
+    # --dp-overlap 0: the A/B leg is reported as null, not re-measured under another name
+    r, _ = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "1", "--rehearse-launch", "--dp-overlap", "0",
+                   "--comm-ab-steps", "2", "--dist-timeout-s", "60"])
+    c = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["comm"]
+    assert c["step_ms_no_overlap"] is None and c["ab_steps"] == 2 and c["dist_timeout_s"] == 60.0 and c["overlap"] is False
     # a WORLD_SIZE / --gpus mismatch is an error, not a silently different run
-    env["WORLD_SIZE"] = "3"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
-                       timeout=600, env=env, cwd="/tmp")
+    r, _ = _bench(["--gpus", "2"], {"WORLD_SIZE": "3"})
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("hang,who_reports", [("1:warmup", "rank"), ("0:timed:gil", "launcher_rc"), ("*:rendezvous:gil", "launcher_kill")])
+def test_bench_multi_rank_run_cannot_hang_silently(hang, who_reports):
+    """a stuck rank ends the run INSIDE the deadline with a non-zero exit code and exactly one JSON line
+    {"metric", "value": null, "error", "last_stage"}.  Three ways to be stuck:
+      * a rank that stops in Python: every rank's own deadline timer fires, rank 0 prints the line, exit 124;
+      * rank 0 stuck in a call that holds the interpreter lock (its timer cannot run): another rank's timer ends the job, the
+        launcher parent sees a non-zero child without a line and prints it, with every rank's last heartbeat;
+      * every rank stuck that way before the rendezvous: the launcher parent terminates the child's process group at
+        deadline + 15 s and prints the line."""
+    import json
+    r, took = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--rehearse-launch", "--deadline-s", "4",
+                      "--rehearse-hang", hang], timeout=120)
+    assert r.returncode != 0 and took < 60.0, (r.returncode, took)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["value"] is None and out["metric"] == "train_tokens_per_sec" and out["n_gpus"] == 2 and out["error"]
+    if who_reports == "rank":
+        assert out["last_stage"] == "stand-alone all-reduce ok" and "passed on rank 0" in out["error"]
+        assert "DEADLINE 4 s" in r.stderr
+    elif who_reports == "launcher_rc":
+        assert out["last_stage"] == {"rank 0": "warm-up ok (1 steps)", "rank 1": "warm-up ok (1 steps)"}
+        assert "no result line" in out["error"]
+    else:
+        assert r.returncode == 124 and out["last_stage"] == "no heartbeat seen" and "terminated by the launcher" in out["error"]
+        assert 15.0 <= took
+
+
+def test_init_distributed_is_bounded_and_checks_its_first_all_reduce(monkeypatch):
+    """engine.init_distributed hands init_process_group a timeout (BLM_DIST_TIMEOUT_S / argument / 180 s) instead of torch's
+    10-30 minutes: a rank whose peers never come raises inside it."""
+    from bayeslms_amd import engine
+    monkeypatch.delenv("BLM_DIST_TIMEOUT_S", raising=False)
+    assert engine.dist_timeout_s() == 180.0 and engine.dist_timeout_s(25) == 25.0
+    monkeypatch.setenv("BLM_DIST_TIMEOUT_S", "3")
+    assert engine.dist_timeout_s(25) == 3.0
+    rc, out, err = _py("import os, time\n"
+                       "os.environ.update(RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='%d')\n"
+                       "from bayeslms_amd import engine\n"
+                       "t0 = time.time()\n"
+                       "try:\n"
+                       "    engine.init_distributed('gloo')\n"
+                       "except Exception as e:\n"
+                       "    print('RAISED', type(e).__name__, round(time.time() - t0))\n" % _free_port(), {"BLM_DIST_TIMEOUT_S": "3"})
+    assert "RAISED" in out and int(out.split()[-1]) < 30, (rc, out, err[-1500:])
 
 
 def test_stage7_score_interpolation_matches_awk(tmp_path):
