@@ -86,6 +86,7 @@ SIGNATURES = {
     "blm_set_gemm_mode": (_i, [_i]),
     "blm_get_gemm_mode": (_i, []),
     "blm_gemm_plan_query": (_i, [C.POINTER(GemmArgs), C.POINTER(GemmPlan)]),
+    "blm_gemm_plan_launch": (_i, [C.POINTER(GemmArgs), C.POINTER(GemmPlan)]),
     "blm_gemm_plan_model_us": (_i, [C.POINTER(GemmArgs), _i, _i, C.POINTER(C.c_float)]),
     "blm_gemm_plan_override": (_i, [_i, _i]),
     "blm_gemm_plan_set": (_i, [_i] * 8),

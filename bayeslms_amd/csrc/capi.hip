@@ -43,6 +43,10 @@ OptEntry g_opts[blm::OPT_COUNT] = {
     {"lstm_gemv", "BLM_LSTM_GEMV", 1, 0, 1, 1, false},    // 1: one-wave-per-unit step kernel for B <= 4; 0: the matrix-core step kernel there too
     {"lstm_pipe", "BLM_LSTM_PIPE", 1, 0, 1, 1, false},    // 1: software-pipelined K loop of the step kernels where a lane walks >= 4 chunks
     {"lstm_tail", "BLM_LSTM_TAIL", 0, 0, 1, 0, false},    // 1: the general (K tail) form of the pipelined step kernels also for whole chunks
+    // 1: every reduction in a fixed order -- no K slices in the GEMM family (no float atomics into C), column sums / GP coefficient
+    // gradients in one row chunk, KL sums through block partials added by one block, the embedding gradient by one wave per
+    // vocabulary row in position order: two runs from one seed give bit-identical parameters (tests/test_gpu_deterministic.py)
+    {"deterministic", "BLM_DETERMINISTIC", 0, 0, 1, 0, false},
 };
 std::mutex g_opt_mu;
 void opt_init(OptEntry& e) {

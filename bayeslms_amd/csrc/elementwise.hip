@@ -55,6 +55,67 @@ __global__ __launch_bounds__(TPB) void embed_bwd_kernel(const int64_t* __restric
   for (int j = lane; j < D; j += 64) atomicAdd(g + j, d[j] * scale * keep1(dk, t, b, j));
 }
 
+// Deterministic form of the embedding gradient (blm_set_option("deterministic", 1)): ONE wave owns a vocabulary row, walks the
+// window's token ids in position order (staged in LDS as 32-bit ids, `chunk` at a time) and adds the matching rows of dy in
+// registers -- every output row has one writer and a fixed order of additions; no atomics.  Most waves find no match and only
+// scan: n / 64 LDS reads + ballots per row and 512-column slab.
+constexpr int EMB_DET_CHUNK = 8192;
+__global__ __launch_bounds__(TPB) void embed_bwd_det_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dy,
+                                                            float* __restrict__ denc, int T, int B, int D, long vocab,
+                                                            float scale, DropKey dk) {
+  __shared__ int sid[EMB_DET_CHUNK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long n = (long)T * B;
+  const bool single = n <= EMB_DET_CHUNK;  // the whole window fits: staged once
+  const long per_round = (long)gridDim.x * (TPB / 64);
+  auto stage = [&](long base) {
+    const long m = min((long)EMB_DET_CHUNK, n - base);
+    for (long i = threadIdx.x; i < m; i += TPB) {
+      const long id = ids[base + i];
+      sid[i] = (id >= 0 && id < vocab) ? (int)id : -1;
+    }
+  };
+  if (single) { stage(0); __syncthreads(); }
+  for (long v0 = 0; v0 < vocab; v0 += per_round) {       // block-uniform trip count: every wave reaches every barrier
+    const long v = v0 + (long)blockIdx.x * (TPB / 64) + wave;
+    for (int d0 = 0; d0 < D; d0 += 512) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      bool hit = false;
+      for (long base = 0; base < n; base += EMB_DET_CHUNK) {
+        if (!single) { __syncthreads(); stage(base); __syncthreads(); }
+        const int m = (int)min((long)EMB_DET_CHUNK, n - base);
+        if (v < vocab) {
+          for (int i = 0; i < m; i += 64) {
+            const int id = (i + lane < m) ? sid[i + lane] : -1;
+            unsigned long long match = __ballot(id == (int)v);
+            while (match) {
+              const int j = __ffsll((long long)match) - 1;
+              match &= match - 1;
+              const long row = base + i + j;
+              const int t = (int)(row / B), b = (int)(row % B);
+              const float* d = dy + row * D;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const int c = d0 + k * 64 + lane;
+                if (c < D) acc[k] += d[c] * scale * keep1(dk, t, b, c);
+              }
+              hit = true;
+            }
+          }
+        }
+      }
+      if (hit) {
+        float* g = denc + v * D;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int c = d0 + k * 64 + lane;
+          if (c < D) g[c] += acc[k];
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ dropout
 __global__ __launch_bounds__(TPB) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long rows,
                                                       DropKey dk) {
@@ -240,10 +301,11 @@ __global__ __launch_bounds__(TPB) void add_drop_ln_bwd_generic(const float* __re
                                                                const float* __restrict__ rstd_i, float* __restrict__ dx,
                                                                float* __restrict__ dy, float* __restrict__ ws, long M,
                                                                DropKey dk) {
-  // one wave per block-row walk; partial dgamma/dbeta accumulated straight into ws[block] (zeroed by launcher)
+  // one wave per block-row walk; partial dgamma/dbeta accumulated straight into this WAVE's pair of ws rows (zeroed by the
+  // launcher): a lane owns its columns there, so no atomics and a fixed order of additions (the finish kernel adds the rows)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, D = dk.D;
-  float* wg = ws + ((long)blockIdx.x * 2 + 0) * D;
-  float* wb = ws + ((long)blockIdx.x * 2 + 1) * D;
+  float* wg = ws + (((long)blockIdx.x * 4 + wave) * 2 + 0) * D;
+  float* wb = ws + (((long)blockIdx.x * 4 + wave) * 2 + 1) * D;
   for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
     const int t = (int)(row / dk.B), b = (int)(row % dk.B);
     const float mean = mean_i[row], rstd = rstd_i[row];
@@ -252,8 +314,8 @@ __global__ __launch_bounds__(TPB) void add_drop_ln_bwd_generic(const float* __re
       const float d = dout[row * D + j], xh = (s[row * D + j] - mean) * rstd, dxh = d * gamma[j];
       s1 += dxh;
       s2 += dxh * xh;
-      atomicAdd(wg + j, d * xh);
-      atomicAdd(wb + j, d);
+      wg[j] += d * xh;
+      wb[j] += d;
     }
     const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
     for (int j = lane; j < D; j += 64) {
@@ -331,6 +393,7 @@ __global__ __launch_bounds__(TPB) void ce_kernel(const float* __restrict__ logit
     if (lse_out) lse_out[row] = lse;
   }
   if (dlogits) {
+    if (!valid) gscale = 0.f;  // a row without a target in [0, V) (torch's ignore_index = -100, padding ids) has no loss and no gradient
     float* d = dlogits + row * ld;
     for (int j = threadIdx.x * 4; j < V4; j += TPB * 4) {
       float4 v = *reinterpret_cast<const float4*>(x + j);
@@ -386,6 +449,7 @@ __global__ __launch_bounds__(1024) void ce_row_kernel(const float* __restrict__ 
     if (lse_out) lse_out[row] = lse;
   }
   if (dlogits) {
+    if (!valid) gscale = 0.f;  // no target in [0, V): no loss, no gradient (see ce_kernel)
     float* d = dlogits + row * ld;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -445,9 +509,9 @@ __global__ __launch_bounds__(TPB) void ce_bwd_kernel(const float* __restrict__ l
   const long row = blockIdx.x;
   const float* x = logits + row * ld;
   float* d = dlogits + row * ld;
-  const float lse = lse_in[row], gs = g_dev[0] * scale;
   const long t = tgt[row];
   const bool valid = t >= 0 && t < V;
+  const float lse = lse_in[row], gs = valid ? g_dev[0] * scale : 0.f;  // no target in [0, V): no gradient
   for (int j = threadIdx.x; j < V; j += TPB) d[j] = (__expf(x[j] - lse) - ((valid && j == t) ? 1.f : 0.f)) * gs;
 }
 
@@ -795,6 +859,14 @@ extern "C" int blm_embed_bwd(const int64_t* ids, const float* dy, float* denc, i
   if (p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_embed_bwd: dropout needs rng");
   if ((long)T * B == 0) return BLM_OK;
   const long rows = (long)T * B;
+  if (blm::option(blm::OPT_DETERMINISTIC)) {  // one wave per vocabulary row, additions in position order
+    long g = (vocab + 3) / 4;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(embed_bwd_det_kernel, dim3((unsigned)g), dim3(TPB), 0, ST, ids, dy, denc, T, B, D, (long)vocab, scale,
+                       make_key(p, rng, B, D, col_offset, global_cols));
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
+  }
   hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(TPB), 0, ST, ids, dy, denc, T, B, D,
                      (long)vocab, scale, make_key(p, rng, B, D, col_offset, global_cols));
   BLM_HIP(hipGetLastError());
@@ -887,9 +959,11 @@ extern "C" int blm_add_dropout_ln_bwd(const float* dout, const float* s, const f
   else if (al && D == 512) LN_BWD(2);
   else if (al && D == 1024) LN_BWD(4);
   else if (al && D == 2048) LN_BWD(8);
-  else {
-    BLM_HIP(hipMemsetAsync(ws, 0, (size_t)2 * nblk * D * sizeof(float), ST));
+  else {  // four partial rows per workgroup (one per wave): a quarter of the blocks fills the same workspace
+    nblk = (nblk + 3) / 4;
+    BLM_HIP(hipMemsetAsync(ws, 0, (size_t)2 * 4 * nblk * D * sizeof(float), ST));
     hipLaunchKernelGGL(add_drop_ln_bwd_generic, dim3(nblk), dim3(TPB), 0, ST, dout, s, gamma, mean, rstd, dx, dy, ws, M, dk);
+    nblk *= 4;
   }
 #undef LN_BWD
   BLM_HIP(hipGetLastError());
@@ -942,6 +1016,7 @@ extern "C" int blm_gp_coef_grad(const float* g, const float* z, float* dcoef, in
   if (M == 0 || N == 0) return BLM_OK;
   int gy = (M + 127) / 128;
   if (gy > 64) gy = 64;
+  if (blm::option(blm::OPT_DETERMINISTIC)) gy = 1;  // one row chunk: each sum has one writer, rows added in a fixed order
   hipLaunchKernelGGL(gp_coef_grad_kernel, dim3((N + 63) / 64, gy), dim3(TPB), 0, ST, g, z, dcoef, M, N);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
@@ -957,6 +1032,7 @@ extern "C" int blm_colsum2(const float* x, int64_t ld, float* out, float* out2, 
   if (M == 0) return BLM_OK;
   int gy = (M + 255) / 256;
   if (gy > 64) gy = 64;
+  if (blm::option(blm::OPT_DETERMINISTIC)) gy = 1;  // one row chunk: each sum has one writer, rows added in a fixed order
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 127) / 128, gy), dim3(TPB), 0, ST, x, (long)ld, out, M, N, out2);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
@@ -976,9 +1052,11 @@ struct InitMulti {
 };
 __global__ __launch_bounds__(TPB) void init_multi_kernel(const InitMulti p) {
   const int i = blockIdx.y;
-  float* __restrict__ d = p.dst[i];
-  const float* __restrict__ a = p.src[i];
-  const float* __restrict__ b = p.src2[i];
+  // no __restrict__: dst may BE src or src2 (in-place accumulation, ops._bias_pair_grads: grad = grad + db); every element is read
+  // by the lane that writes it, before it writes it
+  float* d = p.dst[i];
+  const float* a = p.src[i];
+  const float* b = p.src2[i];
   const long n = p.n[i];
   const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
   const long stride = (long)gridDim.x * TPB;

@@ -27,7 +27,8 @@ struct Plan {
   float us;    // the cost model's estimate of this plan (what a launch takes off an open comm window)
 };
 
-Plan choose_plan(const PlanKey& k);
+// consume: the plan's modelled time is taken off an open comm window (launches: blm_gemm, blm_linear_nll*); a query passes false
+Plan choose_plan(const PlanKey& k, bool consume = true);
 double plan_model_us(const PlanKey& k, int tile, int splits);  // the model's time estimate (microseconds)
 PlanKey plan_key(const blm_gemm_args* a);  // the ONE place that derives the planning key of a call
 // Compute units the planner fills: the chip's 256 unless blm_gemm_plan_set_cus narrowed it (data-parallel training: the

@@ -238,14 +238,14 @@ int plan_cus() {
   return g_cus;
 }
 
-Plan choose_plan(const PlanKey& k) {
+Plan choose_plan(const PlanKey& k, bool consume) {
   std::lock_guard<std::mutex> lk(g_mu);
   read_env();
   const bool under_comm = g_window_us > 0.0 && g_cus == kChipCUs;
   auto& memo = g_memo[under_comm ? -1 : g_cus];
   auto hit = memo.find(k);
   if (hit != memo.end()) {
-    if (under_comm) g_window_us -= hit->second.us;
+    if (under_comm && consume) g_window_us -= hit->second.us;
     return hit->second;
   }
   Plan p{11, 1, 0, g_cus, 0.f};
@@ -278,7 +278,7 @@ Plan choose_plan(const PlanKey& k) {
     if (t.tile == p.tile) p.us = (float)model_us(k, t, p.splits);
   if (memo.size() > 4096) memo.clear();  // step-wise paths with ever-changing shapes: bounded
   memo.emplace(k, p);
-  if (under_comm) g_window_us -= p.us;
+  if (under_comm && consume) g_window_us -= p.us;
   return p;
 }
 
@@ -305,6 +305,9 @@ blm::PlanKey blm::plan_key(const blm_gemm_args* a) {
   // linear in dW (KL terms from the first slice only) but has no zeroing pass for its second output
   const bool lin = a->epilogue == BLM_EPI_NONE || a->epilogue == BLM_EPI_BIAS;
   k.can_split = !samp && ((lin && (k.acc || a->ldc == a->N)) || (a->epilogue == BLM_EPI_BAYES_WGRAD && k.acc));
+  // deterministic mode (blm_set_option("deterministic", 1)): partial sums never meet through float atomics -- every plan, whatever
+  // its source (table, override, model), is legalised to one K slice, tail slicing included (choose_plan: !can_split -> splits = 1)
+  if (option(OPT_DETERMINISTIC)) k.can_split = 0;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const int ac = a->op == BLM_GEMM_TN ? a->M : a->K, bc = a->op == BLM_GEMM_NT ? a->K : a->N;
   k.fast = al16(a->A) && al16(a->B) && a->lda % 4 == 0 && a->ldb % 4 == 0 && ac % 4 == 0 && bc % 4 == 0 && ac >= 4 && bc >= 4;
@@ -317,7 +320,17 @@ extern "C" int blm_gemm_plan_query(const blm_gemm_args* a, blm_gemm_plan* out) {
   PlanKey k;
   if (int rc = key_of(a, &k)) return rc;
   if (!out) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_query: null out");
-  const Plan p = choose_plan(k);
+  const Plan p = choose_plan(k, /*consume=*/false);  // a query is not a launch: an open comm window keeps its time
+  out->tile = p.tile; out->splits = p.splits; out->source = p.source;
+  out->model_us = (float)plan_model_us(k, p.tile, p.splits);
+  return BLM_OK;
+}
+
+extern "C" int blm_gemm_plan_launch(const blm_gemm_args* a, blm_gemm_plan* out) {
+  PlanKey k;
+  if (int rc = key_of(a, &k)) return rc;
+  if (!out) return blm_fail(BLM_ERR_INVALID, "blm_gemm_plan_launch: null out");
+  const Plan p = choose_plan(k, /*consume=*/true);
   out->tile = p.tile; out->splits = p.splits; out->source = p.source;
   out->model_us = (float)plan_model_us(k, p.tile, p.splits);
   return BLM_OK;

@@ -11,10 +11,30 @@ namespace blm {
 
 constexpr int TPB = 256;
 
+// Deterministic mode (blm_set_option("deterministic", 1)): the KL block sums do not meet in a float atomic; every block leaves
+// its (scaled) partial here and ONE block adds them in index order (kl_finish_kernel).  A fixed array in the code object's
+// data segment -- the C ABI hands these entry points no workspace -- used in stream order: the mode assumes that the library's
+// KL reductions of a process are issued on one stream at a time (they are: the forward's own stream).
+constexpr int KL_DET_SLOTS = 4096;
+__device__ float g_kl_partial[KL_DET_SLOTS];
+
+__global__ __launch_bounds__(TPB) void kl_finish_kernel(int n, float* __restrict__ out) {
+  __shared__ float red[TPB / 64];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += TPB) a += g_kl_partial[i];
+  const float t = block_sum<TPB / 64>(a, red);
+  if (threadIdx.x == 0) out[0] += t;
+}
+
+__device__ __forceinline__ void kl_commit(float t, float* out, bool det, int slot) {
+  if (det) g_kl_partial[slot] = t;
+  else if (t != 0.f) atomicAdd(out, t);
+}
+
 // rows x cols, cols % 4 == 0, all pointers 16-B aligned.
 __global__ __launch_bounds__(TPB) void sample_weight_vec4(const float* __restrict__ mu, long rows, long cols,
                                                           blm_variational v, float* __restrict__ w,
-                                                          float* kl_out, float kl_scale) {
+                                                          float* kl_out, float kl_scale, bool det) {
   __shared__ float red[TPB / 64];
   const long c4n = cols >> 2, total = rows * c4n;
   float klp = 0.f;
@@ -40,14 +60,14 @@ __global__ __launch_bounds__(TPB) void sample_weight_vec4(const float* __restric
   }
   if (kl_out) {
     const float t = block_sum<TPB / 64>(klp, red);
-    if (threadIdx.x == 0 && t != 0.f) atomicAdd(kl_out, t * kl_scale);
+    if (threadIdx.x == 0) kl_commit(t * kl_scale, kl_out, det, blockIdx.x);
   }
 }
 
 // Any shape / alignment (bias vectors, tiny test layers).
 __global__ __launch_bounds__(TPB) void sample_weight_scalar(const float* __restrict__ mu, long rows, long cols,
                                                             blm_variational v, float* __restrict__ w,
-                                                            float* kl_out, float kl_scale) {
+                                                            float* kl_out, float kl_scale, bool det) {
   __shared__ float red[TPB / 64];
   const long total = rows * cols;
   float klp = 0.f;
@@ -74,7 +94,7 @@ __global__ __launch_bounds__(TPB) void sample_weight_scalar(const float* __restr
   }
   if (kl_out) {
     const float t = block_sum<TPB / 64>(klp, red);
-    if (threadIdx.x == 0 && t != 0.f) atomicAdd(kl_out, t * kl_scale);
+    if (threadIdx.x == 0) kl_commit(t * kl_scale, kl_out, det, blockIdx.x);
   }
 }
 
@@ -114,7 +134,7 @@ __global__ __launch_bounds__(TPB) void philox_normal_kernel(float* out, long n, 
 }
 
 __global__ __launch_bounds__(TPB) void kl_fwd_kernel(const float* __restrict__ mu, long ld, const float* __restrict__ lg,
-                                                     long rows, long cols, float minus, float scale, float* out) {
+                                                     long rows, long cols, float minus, float scale, float* out, bool det) {
   __shared__ float red[TPB / 64];
   const long total = rows * cols;
   float acc = 0.f;
@@ -124,14 +144,14 @@ __global__ __launch_bounds__(TPB) void kl_fwd_kernel(const float* __restrict__ m
     acc += m * m - 2.f * l + s * s - minus;
   }
   const float t = block_sum<TPB / 64>(acc, red);
-  if (threadIdx.x == 0) atomicAdd(out, t * scale);
+  if (threadIdx.x == 0) { if (det) g_kl_partial[blockIdx.x] = t * scale; else atomicAdd(out, t * scale); }
 }
 
 // Contiguous case (ld == cols: the whole tensor, or a window of full rows): no index arithmetic, 16-byte loads, four
 // independent load pairs in flight per thread (the scalar kernel above spends its time in 64-bit divisions and one
 // dependent load per iteration: 16.8 MB took 24-32 us = 6-9 % of the HBM rate).
 __global__ __launch_bounds__(TPB) void kl_fwd_flat4_kernel(const float4* __restrict__ mu, const float4* __restrict__ lg, long n4,
-                                                           float minus, float scale, float* out) {
+                                                           float minus, float scale, float* out, bool det) {
   __shared__ float red[TPB / 64];
   float acc = 0.f;
   const long stride = (long)gridDim.x * TPB;
@@ -154,7 +174,7 @@ __global__ __launch_bounds__(TPB) void kl_fwd_flat4_kernel(const float4* __restr
     }
   }
   const float t = block_sum<TPB / 64>(acc, red);
-  if (threadIdx.x == 0) atomicAdd(out, t * scale);
+  if (threadIdx.x == 0) { if (det) g_kl_partial[blockIdx.x] = t * scale; else atomicAdd(out, t * scale); }
 }
 
 __global__ __launch_bounds__(TPB) void kl_bwd_kernel(const float* __restrict__ mu, long ld, const float* __restrict__ lg,
@@ -176,6 +196,7 @@ struct VarGroupP {
   int vec[BLM_VAR_GROUP_MAX];  // float4 path: cols % 4 == 0 and every pointer of the item 16-byte aligned
   float* kl_out;
   const float* g;
+  int det;  // forward: KL block sums into g_kl_partial[y * gridDim.x + x] (items without a KL term leave 0)
 };
 
 __device__ __forceinline__ float eps_at(const blm_variational& v, unsigned idx) {
@@ -233,8 +254,10 @@ __global__ __launch_bounds__(TPB) void var_group_fwd_kernel(const VarGroupP p) {
   }
   if (kl_on) {  // block-uniform
     const float t = block_sum<TPB / 64>(klp, red);
-    if (threadIdx.x == 0 && t != 0.f)
-      atomicAdd(p.kl_out, t * (0.5f * it.kl_weight / ((float)v.srows * (float)cols)));
+    if (threadIdx.x == 0)
+      kl_commit(t * (0.5f * it.kl_weight / ((float)v.srows * (float)cols)), p.kl_out, p.det != 0, blockIdx.y * gridDim.x + blockIdx.x);
+  } else if (p.det && p.kl_out && threadIdx.x == 0) {
+    g_kl_partial[blockIdx.y * gridDim.x + blockIdx.x] = 0.f;
   }
 }
 
@@ -334,13 +357,17 @@ extern "C" int blm_sample_weight(const float* mu, int64_t rows, int64_t cols, co
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool vec = (cols % 4 == 0) && al16(mu) && (!w_out || al16(w_out)) && (!v->lgstd || al16(v->lgstd)) &&
                    (!v->eps || al16(v->eps));
+  const bool det = kl_out && blm::option(blm::OPT_DETERMINISTIC);
+  const int g = grid_for(vec ? rows * cols / 4 : rows * cols);  // <= 2048 <= KL_DET_SLOTS
   if (vec)
-    hipLaunchKernelGGL(sample_weight_vec4, dim3(grid_for(rows * cols / 4)), dim3(TPB), 0, st, mu, (long)rows,
-                       (long)cols, *v, w_out, kl_out, kl_scale);
+    hipLaunchKernelGGL(sample_weight_vec4, dim3(g), dim3(TPB), 0, st, mu, (long)rows, (long)cols, *v, w_out, kl_out, kl_scale, det);
   else
-    hipLaunchKernelGGL(sample_weight_scalar, dim3(grid_for(rows * cols)), dim3(TPB), 0, st, mu, (long)rows, (long)cols,
-                       *v, w_out, kl_out, kl_scale);
+    hipLaunchKernelGGL(sample_weight_scalar, dim3(g), dim3(TPB), 0, st, mu, (long)rows, (long)cols, *v, w_out, kl_out, kl_scale, det);
   BLM_HIP(hipGetLastError());
+  if (det) {
+    hipLaunchKernelGGL(kl_finish_kernel, dim3(1), dim3(TPB), 0, st, g, kl_out);
+    BLM_HIP(hipGetLastError());
+  }
   return BLM_OK;
 }
 
@@ -382,8 +409,14 @@ extern "C" int blm_variational_group_fwd(const blm_var_item* items, int32_t n, f
   // every KL block ends in one float atomic on the same word (they serialise in L2): <= 256 blocks per item
   long gx = (most + 4 * TPB - 1) / (4 * TPB);
   gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+  p.det = (any_kl && blm::option(blm::OPT_DETERMINISTIC)) ? 1 : 0;
+  if (p.det) while (gx * n > KL_DET_SLOTS) gx = (gx + 1) / 2;  // n <= BLM_VAR_GROUP_MAX: gx stays >= 1
   hipLaunchKernelGGL(var_group_fwd_kernel, dim3((unsigned)gx, (unsigned)n), dim3(TPB), 0, st, p);
   BLM_HIP(hipGetLastError());
+  if (p.det) {
+    hipLaunchKernelGGL(kl_finish_kernel, dim3(1), dim3(TPB), 0, st, (int)(gx * n), kl_out);
+    BLM_HIP(hipGetLastError());
+  }
   return BLM_OK;
 }
 
@@ -395,6 +428,7 @@ extern "C" int blm_variational_group_bwd(const blm_var_item* items, int32_t n, c
   if (n == 0) return BLM_OK;
   p.kl_out = nullptr;
   p.g = kl_grad;
+  p.det = 0;
   long gx = (most + 4 * TPB - 1) / (4 * TPB);
   gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
   hipLaunchKernelGGL(var_group_bwd_kernel, dim3((unsigned)gx, (unsigned)n), dim3(TPB), 0, static_cast<hipStream_t>(stream), p);
@@ -535,18 +569,24 @@ extern "C" int blm_kl_mean_fwd(const float* mu, int64_t ld_mu, const float* lgst
   // every block ends in ONE float atomic on the same address: 256 blocks (one per CU) instead of 2048 cut the
   // launch from 32 to a few microseconds (the atomics serialise in L2)
   const int kl_grid = grid_for(rows * cols) < 256 ? grid_for(rows * cols) : 256;
+  const bool det = blm::option(blm::OPT_DETERMINISTIC) != 0;  // block partials + one fixed-order finishing block instead of atomics
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int blocks;
   if (ld_mu == cols && (rows * cols) % 4 == 0 && al16(mu) && al16(lgstd)) {
     const long n4 = rows * cols / 4;
-    const int g4 = grid_for(n4 / 4 + 1) < 512 ? grid_for(n4 / 4 + 1) : 512;
-    hipLaunchKernelGGL(kl_fwd_flat4_kernel, dim3(g4), dim3(TPB), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float4*>(mu), reinterpret_cast<const float4*>(lgstd), n4,
-                       minus_one ? 1.0f : 0.0f, scale, out);
-    BLM_HIP(hipGetLastError());
-    return BLM_OK;
+    blocks = grid_for(n4 / 4 + 1) < 512 ? grid_for(n4 / 4 + 1) : 512;
+    hipLaunchKernelGGL(kl_fwd_flat4_kernel, dim3(blocks), dim3(TPB), 0, st, reinterpret_cast<const float4*>(mu),
+                       reinterpret_cast<const float4*>(lgstd), n4, minus_one ? 1.0f : 0.0f, scale, out, det);
+  } else {
+    blocks = kl_grid;
+    hipLaunchKernelGGL(kl_fwd_kernel, dim3(blocks), dim3(TPB), 0, st, mu, (long)ld_mu, lgstd, (long)rows, (long)cols,
+                       minus_one ? 1.0f : 0.0f, scale, out, det);
   }
-  hipLaunchKernelGGL(kl_fwd_kernel, dim3(kl_grid), dim3(TPB), 0, static_cast<hipStream_t>(stream), mu,
-                     (long)ld_mu, lgstd, (long)rows, (long)cols, minus_one ? 1.0f : 0.0f, scale, out);
   BLM_HIP(hipGetLastError());
+  if (det) {
+    hipLaunchKernelGGL(kl_finish_kernel, dim3(1), dim3(TPB), 0, st, blocks, out);
+    BLM_HIP(hipGetLastError());
+  }
   return BLM_OK;
 }
 

@@ -261,7 +261,7 @@ def set_gemm_mode(mode):
 
 def set_option(name, value):
     """Kernel-selection options of the library (include/bayeslm.h blm_set_option): "attn_hpw", "attn_short", "attn_valu",
-    "lstm_gemv", "lstm_pipe", "lstm_tail".  Each picks between two BUILT and parity-tested forms of a kernel; the defaults are
+    "lstm_gemv", "lstm_pipe", "lstm_tail", "deterministic" (see set_deterministic).  Each of the others picks between two BUILT and parity-tested forms of a kernel; the defaults are
     the measured winners (INTEGRATION.md lists them with their tests and BLM_* environment variables)."""
     check(lib().blm_set_option(name.encode(), int(value)), "blm_set_option")
 
@@ -270,6 +270,21 @@ def get_option(name):
     v = C.c_int(0)
     check(lib().blm_get_option(name.encode(), C.byref(v)), "blm_get_option")
     return int(v.value)
+
+
+def set_deterministic(on=True):
+    """Deterministic mode (blm_set_option("deterministic", 1) / BLM_DETERMINISTIC=1): every reduction of the library
+    in a fixed order -- one K slice per GEMM tile (no float atomics into C), bias / GP-coefficient column sums in one row chunk,
+    KL sums through block partials added by one block, the embedding gradient by one wave per vocabulary row in position order
+    -- and, on this side, the two-layer LSTM stack on one stream (no layer wavefront).  Two runs from one seed then give
+    bit-identical losses and parameters (tests/test_gpu_deterministic.py), also two data-parallel runs of the same world
+    size; a run at another world size sums the batch columns in another order and is equal to rounding only.  Costs a few
+    per cent of the step (bench.py extra_configs `deterministic`).  Process-wide."""
+    set_option("deterministic", 1 if on else 0)
+
+
+def is_deterministic():
+    return get_option("deterministic") == 1
 
 
 def set_gemm_cus(n):
@@ -976,7 +991,11 @@ class _CrossEntropy(torch.autograd.Function):
     """unit_grad=True (the trainer's case, loss = CE + KL with coefficient 1, train.py:412): the
     forward pass over the logits also overwrites them in place with d(mean NLL)/d(logits), and
     backward returns that buffer untouched.  unit_grad=False: forward keeps lse, backward runs the
-    gradient kernel with the real upstream scalar.  Either way the logits buffer is consumed."""
+    gradient kernel with the real upstream scalar.  Either way the logits buffer is consumed -- unless
+    ``keep`` (the `Logits` short cut of an unchanged torch loop): the logits stay the caller's, are saved through
+    autograd (an in-place edit between the loss and backward() raises, as torch's own loss would), the gradient gets
+    its own buffer, and the mean is torch's: over the rows whose target is not ignore_index (-100), which get neither
+    loss nor gradient (the kernels give any row without a target in [0, V) a zero NLL and a zero gradient row)."""
 
     @staticmethod
     def forward(ctx, logits, targets, unit_grad, keep=False):
@@ -989,26 +1008,35 @@ class _CrossEntropy(torch.autograd.Function):
         nll = torch.empty(M, device=logits.device, dtype=torch.float32)
         loss = torch.zeros((), device=logits.device, dtype=torch.float32)
         grad_mode = ctx.needs_input_grad[0]  # forward itself runs with grad mode off
-        fuse = grad_mode and unit_grad
-        lse = torch.empty(M, device=logits.device, dtype=torch.float32) if (grad_mode and not unit_grad) else None
+        fuse = grad_mode and unit_grad and not keep
+        lse = torch.empty(M, device=logits.device, dtype=torch.float32) if (grad_mode and not fuse) else None
         L.require_gfx950()
         check(lib().blm_ce_fwd_bwd(ptr(logits), V, ptr(targets), ptr(nll), ptr(lse), ptr(loss),
                                    ptr(logits) if fuse else None, 1.0 / M, M, V, stream()), "blm_ce_fwd_bwd")
         if fuse:  # the buffer now holds the gradient: any other autograd consumer of the logits must fail, not read it
             torch.autograd.graph.increment_version(logits)
-        ctx.meta = (logits, targets, lse, fuse, M, V, keep)
+        inv_count = None
+        if keep:  # torch's mean: over the targets that are not ignore_index (device-side count, no host synchronisation)
+            inv_count = 1.0 / (targets != -100).sum().clamp_(min=1).to(torch.float32)
+            ctx.save_for_backward(logits)  # version-checked at backward
+            ctx.meta = (None, targets, lse, fuse, M, V, keep, inv_count)
+        else:
+            ctx.meta = (logits, targets, lse, fuse, M, V, keep, None)
         ctx.mark_non_differentiable(nll)
         ctx.set_materialize_grads(False)  # no zero fill for the per-token NLL's (non-existent) gradient
-        return loss / M, nll
+        return (loss * inv_count if keep else loss / M), nll
 
     @staticmethod
     def backward(ctx, g, _g_nll):
-        logits, targets, lse, fuse, M, V, keep = ctx.meta
+        logits, targets, lse, fuse, M, V, keep, inv_count = ctx.meta
         if g is None:
             return None, None, None, None
         if fuse:
             return logits, None, None, None
         g = _f32(g.reshape(1), "g")
+        if keep:
+            (logits,) = ctx.saved_tensors
+            g = g * (inv_count * M)  # the kernel scales by 1 / M
         # keep: the caller's logits stay what they are (a user loop may still read them after backward): the gradient gets its own buffer
         out = torch.empty_like(logits) if keep else logits
         check(lib().blm_ce_bwd(ptr(logits), V, ptr(targets), ptr(lse), ptr(g), 1.0 / M, ptr(out), M, V, stream()),
@@ -1035,8 +1063,9 @@ class Logits(torch.Tensor):
     train.py:332 with ``nn.CrossEntropyLoss()``) runs the engine's one-pass cross-entropy kernels instead of torch's
     log-softmax + NLL chain over the (M, V) logits -- an unchanged reference training script gets them by importing the shim
     (INTEGRATION.md level 1).  Non-destructive here: the logits keep their values, the gradient gets its own buffer.  Only the
-    default loss takes the short cut (mean reduction, no class weights, no label smoothing, ignore_index at its default with no
-    negative targets expected in LM data); anything else falls through to torch.  ``view`` / ``reshape`` / ``contiguous`` /
+    default loss takes the short cut (mean reduction, no class weights, no label smoothing, ignore_index at its default -100, which is
+    honoured as torch honours it: such rows get no loss and no gradient, the mean is over the others); anything else falls through to
+    torch.  ``view`` / ``reshape`` / ``contiguous`` /
     ``flatten`` keep the type (so the reshaped logits still reach the loss as ``Logits``); every other operation returns plain
     tensors."""
 
@@ -1520,7 +1549,9 @@ class _LSTMStack2(torch.autograd.Function):
     the dgrad GEMM of the chunk on the stream between, layer 1 follows a chunk behind); both chains are issued by the library
     (blm_lstm_seq_fwd / blm_lstm_seq_bwd: ~3.3 us of host time per launch against ~5 us of device time per launch when
     two recurrences are in flight); the weight-gradient GEMMs stay batched over all T at the end.  Same kernels and the same
-    arithmetic per step as two ops.lstm_layer calls: results are bit-identical to them."""
+    arithmetic per step as two ops.lstm_layer calls: the forward is bit-identical to them; the backward is equal up to
+    summation order (the per-chunk dgrad GEMMs accumulate into a pre-zeroed dy1, with K slices through float atomics where the
+    planner picks them -- 1e-6 run to run; deterministic mode, ops.set_deterministic, takes the one-stream path instead)."""
 
     @staticmethod
     def forward(ctx, x, h0a, c0a, h0b, c0b, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, drop):
@@ -1733,6 +1764,8 @@ def lstm_stack2_ok(x, w_hh1, w_hh2, w_ih2):
     and, unless it was switched on or off explicitly, the shapes it PAYS for (see below)."""
     T, B, _ = x.shape
     H = w_hh1.shape[1]
+    if is_deterministic():
+        return False  # one stream: the per-chunk dgrad GEMMs of the wavefront accumulate into dy1 from two streams' launches
     if _STACK2_ON is None:
         on = B <= 32 and T >= 32
     else:

@@ -273,8 +273,13 @@ typedef struct blm_gemm_plan {
   int32_t source;   /* 0 cost model, 1 plan table, 2 override, 3 plan measured beside a collective (comm window open) */
   float model_us;   /* the cost model's estimate for this plan */
 } blm_gemm_plan;
-/* The plan blm_gemm would use for `a` (pointers are only inspected for alignment). */
+/* The plan blm_gemm would use for `a` now (pointers are only inspected for alignment).  A query is not a launch: an open comm
+ * window (below) keeps its time. */
 int blm_gemm_plan_query(const blm_gemm_args* a, blm_gemm_plan* out);
+/* The planning step of a launch on its own: the same plan, AND its modelled time is taken off an open comm window, exactly as
+ * blm_gemm / blm_linear_nll do in front of their launch.  For callers that account for matrix work they issue outside the
+ * library, and for the host-side tests of the window (tests/test_gemm_plan_cpu.py). */
+int blm_gemm_plan_launch(const blm_gemm_args* a, blm_gemm_plan* out);
 /* The cost model's estimate (microseconds) of `a` under a given tile / slice count. */
 int blm_gemm_plan_model_us(const blm_gemm_args* a, int tile, int splits, float* us);
 /* Tuning tools: force a tile and / or a slice count for every call of this process (0 = no override; also read once
@@ -295,7 +300,7 @@ int blm_gemm_plan_get_cus(void);
  * blm_gemm planned while the window is open takes its own modelled time off it, so the window is kept in DEVICE time although
  * the host enqueues far ahead.  Inside the window a launch uses the plan measured beside a resident collective stand-in where
  * the table has one (csrc/gemm_plans_comm.inc, tools/gemm_tune_comm.py; blm_gemm_plan_query reports source 3), its usual plan
- * otherwise.  us = 0 closes the window (engine.GradReducer.finish).  blm_gemm_plan_set_comm adds a run-time entry to that
+ * otherwise.  us = 0 closes the window (engine.GradReducer.finish).  Only launches (and blm_gemm_plan_launch) debit the window.  blm_gemm_plan_set_comm adds a run-time entry to that
  * table (blm_gemm_plan_clear drops the run-time entries of both tables). */
 int blm_gemm_plan_comm_window(float us);
 float blm_gemm_plan_comm_window_left(void);

@@ -27,6 +27,13 @@ def plan(a):
     return out.tile, out.splits, out.source, out.model_us
 
 
+def launch_plan(a):
+    """The planning step of a launch (blm_gemm does the same in front of its kernel): takes its time off an open comm window."""
+    out = L.GemmPlan()
+    L.check(L.lib().blm_gemm_plan_launch(C.byref(a), C.byref(out)), "blm_gemm_plan_launch")
+    return out.tile, out.splits, out.source, out.model_us
+
+
 @pytest.fixture(autouse=True)
 def _clean():
     lib = L.lib()
@@ -212,16 +219,18 @@ def test_comm_window_is_kept_in_modelled_device_time():
     L.check(lib.blm_gemm_plan_comm_window(C.c_float(1000.0)), "window")
     try:
         left0 = lib.blm_gemm_plan_comm_window_left()
-        under_a = plan(a)
+        assert plan(a)[2] == 3 and plan(b)[:3] == whole_b[:3]
+        assert lib.blm_gemm_plan_comm_window_left() == left0    # a query is not a launch -- the window keeps its time
+        under_a = launch_plan(a)
         left1 = lib.blm_gemm_plan_comm_window_left()
         assert under_a[2] == 3 and under_a[:2] != whole_a[:2] and under_a[0] != 28
         assert abs((left0 - left1) - under_a[3]) < 1e-2 * under_a[3]
-        assert plan(b)[:3] == whole_b[:3]                       # no comm entry: the whole-chip plan, and its time comes off
+        assert launch_plan(b)[:3] == whole_b[:3]                # no comm entry: the whole-chip plan, and its time comes off
         assert lib.blm_gemm_plan_comm_window_left() < left1
         L.check(lib.blm_gemm_plan_set_comm(L.GEMM_NT, 8192, 512, 4096, L.EPI_NONE, 0, 11, 4), "set_comm")
         assert plan(b)[:3] == (11, 4, 3)
         for _ in range(64):                                     # the window runs out by itself
-            plan(b)
+            launch_plan(b)
         assert lib.blm_gemm_plan_comm_window_left() == 0.0 and plan(b)[:3] == whole_b[:3]
         L.check(lib.blm_gemm_plan_comm_window(C.c_float(500.0)), "window")
         L.check(lib.blm_gemm_plan_comm_window(C.c_float(0.0)), "window")
@@ -229,3 +238,27 @@ def test_comm_window_is_kept_in_modelled_device_time():
     finally:
         lib.blm_gemm_plan_comm_window(C.c_float(0.0))
         lib.blm_gemm_plan_clear(1)
+
+
+def test_deterministic_mode_legalises_every_plan_to_one_k_slice():
+    """blm_set_option("deterministic", 1): partial sums never meet through float atomics -- table plans (K-sliced and tail-sliced),
+    overrides, run-time entries and the cost model's picks all come back with splits == 1; switching it off restores them
+    (the memo is keyed by can_split, nothing has to be cleared)."""
+    lib = L.lib()
+    sliced = [e for e in table_entries() if e[7] != 1]
+    assert sliced, "the built-in table has K-sliced and tail-sliced plans"
+    shapes = [args(e[0], e[1], e[2], e[3], e[4], bool(e[5])) for e in sliced]
+    shapes.append(args(L.GEMM_TN, 1024, 1024, 70000, acc=True))  # the cost model slices this one
+    before = [plan(a) for a in shapes]
+    assert any(abs(b[1]) > 1 for b in before)
+    L.check(lib.blm_set_option(b"deterministic", 1), "set_option")
+    try:
+        assert all(plan(a)[1] == 1 for a in shapes)
+        L.check(lib.blm_gemm_plan_override(0, 8), "override")
+        assert all(plan(a)[1] == 1 for a in shapes)
+        L.check(lib.blm_gemm_plan_override(0, 0), "override")
+        L.check(lib.blm_gemm_plan_set(L.GEMM_NT, 320, 4096, 1024, L.EPI_NONE, 0, 11, -4), "set")
+        assert plan(args(L.GEMM_NT, 320, 4096, 1024))[1] == 1
+    finally:
+        L.check(lib.blm_set_option(b"deterministic", 0), "set_option")
+    assert [plan(a)[:2] for a in shapes] == [b[:2] for b in before]
