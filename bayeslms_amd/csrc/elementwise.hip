@@ -875,7 +875,7 @@ extern "C" int blm_embed_bwd(const int64_t* ids, const float* dy, float* denc, i
 
 extern "C" int blm_dropout(const float* x, float* y, int rows, int B, int D, float p, const blm_rng* rng, int col_offset,
                            int global_cols, void* stream) {
-  if (!x || !y || rows < 0 || B < 0 || D < 0) return blm_fail(BLM_ERR_INVALID, "blm_dropout: bad arguments");
+  if (!x || !y || !blm::extents_ok({rows, B, D})) return blm_fail(BLM_ERR_INVALID, "blm_dropout: bad arguments");
   if (p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_dropout: dropout needs rng");
   const long n = (long)rows * B * D;
   if (n == 0) return BLM_OK;
@@ -887,7 +887,7 @@ extern "C" int blm_dropout(const float* x, float* y, int rows, int B, int D, flo
 
 extern "C" int blm_dropout_rows(const float* x, float* y, int rows, int row0, int B, int D, float p, const blm_rng* rng,
                                 int col_offset, int global_cols, void* stream) {
-  if (!x || !y || rows < 0 || row0 < 0 || B < 0 || D < 0) return blm_fail(BLM_ERR_INVALID, "blm_dropout_rows: bad arguments");
+  if (!x || !y || row0 < 0 || !blm::extents_ok({rows, B, D}) || !blm::extents_ok({row0, B, D})) return blm_fail(BLM_ERR_INVALID, "blm_dropout_rows: bad arguments");
   if (p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_dropout_rows: dropout needs rng");
   const long n = (long)rows * B * D;
   if (n == 0) return BLM_OK;
@@ -900,7 +900,7 @@ extern "C" int blm_dropout_rows(const float* x, float* y, int rows, int row0, in
 
 extern "C" int blm_add_pe_dropout(const float* x, const float* pe, float* out, int T, int B, int D, float p,
                                   const blm_rng* rng, int col_offset, int global_cols, void* stream) {
-  if (!x || !pe || !out || T < 0 || B < 0 || D < 0) return blm_fail(BLM_ERR_INVALID, "blm_add_pe_dropout: bad arguments");
+  if (!x || !pe || !out || !blm::extents_ok({T, B, D})) return blm_fail(BLM_ERR_INVALID, "blm_add_pe_dropout: bad arguments");
   if (p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_add_pe_dropout: dropout needs rng");
   const long n = (long)T * B * D;
   if (n == 0) return BLM_OK;
@@ -1012,7 +1012,7 @@ extern "C" int blm_ce_interp_fwd(const float* logits_a, const float* logits_b, i
 }
 
 extern "C" int blm_gp_coef_grad(const float* g, const float* z, float* dcoef, int M, int N, void* stream) {
-  if (!g || !z || !dcoef || M < 0 || N < 0) return blm_fail(BLM_ERR_INVALID, "blm_gp_coef_grad: bad arguments");
+  if (!g || !z || !dcoef || !blm::extents_ok({M, N})) return blm_fail(BLM_ERR_INVALID, "blm_gp_coef_grad: bad arguments");
   if (M == 0 || N == 0) return BLM_OK;
   int gy = (M + 127) / 128;
   if (gy > 64) gy = 64;
@@ -1023,7 +1023,7 @@ extern "C" int blm_gp_coef_grad(const float* g, const float* z, float* dcoef, in
 }
 
 extern "C" int blm_colsum2(const float* x, int64_t ld, float* out, float* out2, int M, int N, int accumulate, void* stream) {
-  if (!x || !out || M < 0 || N < 0 || ld < N || out == out2) return blm_fail(BLM_ERR_INVALID, "blm_colsum: bad arguments");
+  if (!x || !out || !blm::extents_ok({M, N}) || ld < N || !blm::extents_ok({M, ld}) || out == out2) return blm_fail(BLM_ERR_INVALID, "blm_colsum: bad arguments");
   if (N == 0) return BLM_OK;
   if (!accumulate) {
     BLM_HIP(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), ST));
@@ -1235,7 +1235,8 @@ extern "C" int blm_gpnn2_actsum_bwd(const float* ds, const float* f, float* df, 
 
 extern "C" int blm_add_cols(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int64_t rows, int cols,
                             void* stream) {
-  if (!a || !b || !out || rows < 0 || cols < 0 || lda < cols || ldb < cols || ldo < cols)
+  if (!a || !b || !out || !blm::extents_ok({rows, cols}) || lda < cols || ldb < cols || ldo < cols || !blm::extents_ok({rows, lda}) ||
+      !blm::extents_ok({rows, ldb}) || !blm::extents_ok({rows, ldo}))
     return blm_fail(BLM_ERR_INVALID, "blm_add_cols: bad arguments");
   if (rows * (long)cols == 0) return BLM_OK;
   hipLaunchKernelGGL(add_cols_kernel, dim3(grid_for(rows * (long)cols)), dim3(TPB), 0, ST, a, (long)lda, b, (long)ldb, out, (long)ldo,

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void ce_part_finish_kernel(const float* __rest
 }  // namespace blm
 
 extern "C" int64_t blm_linear_nll_ws_floats(int M, int N) {
-  if (M < 0 || N < 0) return 0;
+  if (!blm::extents_ok({M, N})) return 0;
   return (int64_t)2 * M * ((N + 63) / 64) + M;  // [M][column tiles][2] partials (64-column tiles at most) + the target logits
 }
 
@@ -235,13 +235,13 @@ __global__ __launch_bounds__(256) void bias_mix_kernel(float* __restrict__ dst, 
 }  // namespace blm
 
 extern "C" int64_t blm_linear_nll2_wcat_floats(int N, int K1, int K2) {
-  if (N < 0 || K1 < 0 || K2 < 0) return 0;
+  if (!blm::extents_ok({N, K1}) || !blm::extents_ok({N, K2})) return 0;
   const int64_t Np = ((int64_t)N + 3) / 4 * 4;  // vocabulary padded to the vectorised epilogue's multiple of 4
   return Np * (K1 + K2) + Np;                  // [W1 | W2] and the mixed bias
 }
 
 extern "C" int64_t blm_linear_nll2_ws_floats(int M, int N, int K1, int K2) {
-  if (M < 0 || N < 0 || K1 < 0 || K2 < 0) return 0;
+  if (!blm::extents_ok({M, N}) || !blm::extents_ok({M, K1}) || !blm::extents_ok({M, K2})) return 0;
   return (int64_t)M * (K1 + K2) + blm_linear_nll_ws_floats(M, (N + 3) / 4 * 4);  // packed activations, then blm_linear_nll's own workspace
 }
 

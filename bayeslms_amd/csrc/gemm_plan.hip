@@ -228,6 +228,7 @@ void read_env() {
 }  // namespace
 
 double plan_model_us(const PlanKey& k, int tile, int splits) {
+  std::lock_guard<std::mutex> lk(g_mu);  // model_us reads g_cus (found by the ThreadSanitizer build: a query beside blm_gemm_plan_set_cus)
   for (const TileModel& t : kTiles)
     if (t.tile == tile) return model_us(k, t, (splits == 0 || splits == -1) ? 1 : splits);
   return -1.0;

@@ -927,7 +927,8 @@ extern "C" int blm_lstm_step_fwd_gp(const float* xw_t, const float* w_hh, const 
 
 extern "C" int blm_lstm_seq_fwd(const float* xw, const float* w_hh, float* hs, float* cs, float* gates_act,
                                 const float* noise_rows, int T, int B, int H, void* stream) {
-  if (T < 0) return blm_fail(BLM_ERR_INVALID, "blm_lstm_seq_fwd: bad arguments");
+  if (!blm::extents_ok({T, B, H, 4}) || (T > 0 && (!xw || !w_hh || !hs || !cs)))
+    return blm_fail(BLM_ERR_INVALID, "blm_lstm_seq_fwd: bad arguments");
   const size_t bh = (size_t)B * H, bg = 4 * bh;
   for (int t = 0; t < T; ++t) {
     const int rc = blm_lstm_step_fwd(xw + t * bg, w_hh, hs + t * bh, cs + t * bh, hs + (t + 1) * bh, cs + (t + 1) * bh,
@@ -941,7 +942,7 @@ extern "C" int blm_lstm_seq_fwd(const float* xw, const float* w_hh, float* hs, f
 extern "C" int blm_lstm_seq_pair_fwd(const float* xw_a, const float* w_hh_a, float* hs_a, float* cs_a, float* ga_a, int n_a,
                                      const float* xw_b, const float* w_hh_b, float* hs_b, float* cs_b, float* ga_b, int n_b,
                                      int B, int H, void* stream) {
-  if (n_a < 0 || n_b < 0 || B < 1 || H < 1 || (n_a > 0 && (!xw_a || !w_hh_a || !hs_a || !cs_a)) || (n_b > 0 && (!xw_b || !w_hh_b || !hs_b || !cs_b)))
+  if (!blm::extents_ok({n_a, B, H, 4}) || !blm::extents_ok({n_b, B, H, 4}) || B < 1 || H < 1 || (n_a > 0 && (!xw_a || !w_hh_a || !hs_a || !cs_a)) || (n_b > 0 && (!xw_b || !w_hh_b || !hs_b || !cs_b)))
     return blm_fail(BLM_ERR_INVALID, "blm_lstm_seq_pair_fwd: bad arguments");
   const size_t bh = (size_t)B * H, bg = 4 * bh;
   const bool pairable = B <= 4 && H % 4 == 0 && lstm_gemv() && (n_a == 0 || (al16(w_hh_a) && al16(hs_a))) && (n_b == 0 || (al16(w_hh_b) && al16(hs_b))) &&
@@ -1004,7 +1005,7 @@ extern "C" int blm_lstm_search_step_fwd(const float* xw8_t, const float* w8_hh, 
 }
 
 extern "C" int blm_transpose(const float* in, float* out, int rows, int cols, void* stream) {
-  if (!in || !out || rows < 0 || cols < 0) return blm_fail(BLM_ERR_INVALID, "blm_transpose: bad arguments");
+  if (!in || !out || !blm::extents_ok({rows, cols})) return blm_fail(BLM_ERR_INVALID, "blm_transpose: bad arguments");
   if ((long)rows * cols == 0) return BLM_OK;
   hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols);
   BLM_HIP(hipGetLastError());
@@ -1087,7 +1088,7 @@ extern "C" int blm_lstm_seq_bwd(const float* dh_T, const float* dy, const float*
 }
 
 extern "C" int64_t blm_lstm_search_step_partials(int B, int H) {
-  if (B < 0 || H < 0) return 0;
+  if (!blm::extents_ok({B, H})) return 0;
   return 8 * (int64_t)(H / 16) * ((B + 15) / 16);
 }
 

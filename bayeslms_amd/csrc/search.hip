@@ -218,13 +218,13 @@ using namespace blm;
 static int mix_grid(long rows, int B, int N) { return grid_for(((N & 3) == 0 ? (rows * B * N) >> 2 : rows * B * N)); }
 
 extern "C" int64_t blm_mix2_partials(int rows, int B, int N) {
-  if (rows < 0 || B < 0 || N < 0) return 0;
+  if (!blm::extents_ok({rows, B, N})) return 0;
   return 2 * (int64_t)mix_grid(rows, B, N);
 }
 
 extern "C" int blm_mix2_fwd(const float* a, const float* b, const float* probs, float* out, int rows, int B, int N,
                             float drop_p, const blm_rng* rng, int col_offset, int global_cols, void* stream) {
-  if (!a || !b || !probs || !out || rows < 0 || B < 0 || N < 0) return blm_fail(BLM_ERR_INVALID, "blm_mix2_fwd: bad arguments");
+  if (!a || !b || !probs || !out || !blm::extents_ok({rows, B, N})) return blm_fail(BLM_ERR_INVALID, "blm_mix2_fwd: bad arguments");
   if (drop_p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_mix2_fwd: dropout needs rng");
   if ((long)rows * B * N == 0) return BLM_OK;
   hipLaunchKernelGGL(mix2_fwd_kernel, dim3(mix_grid(rows, B, N)), dim3(TPB), 0, ST, a, b, probs, out, (long)rows,
@@ -236,7 +236,7 @@ extern "C" int blm_mix2_fwd(const float* a, const float* b, const float* probs, 
 extern "C" int blm_mix2_bwd(const float* dout, const float* a, const float* b, const float* probs, const float* mul_a,
                             float* da, float* db, float* partial, int rows, int B, int N, float drop_p, const blm_rng* rng,
                             int col_offset, int global_cols, void* stream) {
-  if (!dout || !a || !b || !probs || !partial || rows < 0 || B < 0 || N < 0)
+  if (!dout || !a || !b || !probs || !partial || !blm::extents_ok({rows, B, N}))
     return blm_fail(BLM_ERR_INVALID, "blm_mix2_bwd: bad arguments");
   if (drop_p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_mix2_bwd: dropout needs rng");
   hipLaunchKernelGGL(mix2_bwd_kernel<false>, dim3(mix_grid(rows, B, N)), dim3(TPB), 0, ST, dout, a, b, probs, mul_a, da, db,
@@ -248,7 +248,7 @@ extern "C" int blm_mix2_bwd(const float* dout, const float* a, const float* b, c
 extern "C" int blm_mix2_gp_bwd(const float* dout, const float* a, const float* b, const float* probs, const float* mul_a,
                                const float* z_b, const float* coef, float* da, float* dz_b, float* dhk, float* partial, int rows,
                                int B, int N, float drop_p, const blm_rng* rng, int col_offset, int global_cols, void* stream) {
-  if (!dout || !a || !b || !probs || !z_b || !coef || !partial || rows < 0 || B < 0 || N < 0)
+  if (!dout || !a || !b || !probs || !z_b || !coef || !partial || !blm::extents_ok({rows, B, N}))
     return blm_fail(BLM_ERR_INVALID, "blm_mix2_gp_bwd: bad arguments");
   if (drop_p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_mix2_gp_bwd: dropout needs rng");
   hipLaunchKernelGGL(mix2_bwd_kernel<true>, dim3(mix_grid(rows, B, N)), dim3(TPB), 0, ST, dout, a, b, probs, mul_a, da, dz_b,

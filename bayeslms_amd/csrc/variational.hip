@@ -347,10 +347,10 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 extern "C" int blm_sample_weight(const float* mu, int64_t rows, int64_t cols, const blm_variational* v, float* w_out,
                                  float* kl_out, float kl_weight, void* stream) {
-  if (!mu || !v || rows < 0 || cols < 0) return blm_fail(BLM_ERR_INVALID, "blm_sample_weight: bad arguments");
+  if (!mu || !v || !blm::extents_ok({rows, cols})) return blm_fail(BLM_ERR_INVALID, "blm_sample_weight: bad arguments");
   if (!w_out && !kl_out) return BLM_OK;
   if (rows == 0 || cols == 0) return BLM_OK;
-  if (v->lgstd && (v->row_lo < 0 || v->srows < 0 || v->row_lo + v->srows > rows))
+  if (v->lgstd && (v->row_lo < 0 || v->srows < 0 || (int64_t)v->row_lo + v->srows > rows))
     return blm_fail(BLM_ERR_INVALID, "blm_sample_weight: noisy row window outside W");
   if (kl_out && !v->lgstd) return blm_fail(BLM_ERR_INVALID, "blm_sample_weight: KL requested without lgstd");
   const float kl_scale = v->srows > 0 ? 0.5f * kl_weight / ((float)v->srows * (float)cols) : 0.f;
@@ -438,9 +438,9 @@ extern "C" int blm_variational_group_bwd(const blm_var_item* items, int32_t n, c
 
 extern "C" int blm_sample_weight_bwd(const float* dw, int64_t rows, int64_t cols, const blm_variational* v, float* dmu,
                                      float* dlgstd, void* stream) {
-  if (!dw || !v || rows < 0 || cols < 0) return blm_fail(BLM_ERR_INVALID, "blm_sample_weight_bwd: bad arguments");
+  if (!dw || !v || !blm::extents_ok({rows, cols})) return blm_fail(BLM_ERR_INVALID, "blm_sample_weight_bwd: bad arguments");
   if (rows == 0 || cols == 0 || (!dmu && !dlgstd)) return BLM_OK;
-  if (dlgstd && (!v->lgstd || v->row_lo < 0 || v->srows < 0 || v->row_lo + v->srows > rows))
+  if (dlgstd && (!v->lgstd || v->row_lo < 0 || v->srows < 0 || (int64_t)v->row_lo + v->srows > rows))
     return blm_fail(BLM_ERR_INVALID, "blm_sample_weight_bwd: noisy row window outside W");
   hipLaunchKernelGGL(sample_weight_bwd_kernel, dim3(grid_for(rows * cols)), dim3(TPB), 0, static_cast<hipStream_t>(stream),
                      dw, (long)rows, (long)cols, *v, dmu, dlgstd);
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void gpnn2_freq_grad_kernel(const float* __res
 
 extern "C" int blm_gpnn2_sample_steps(const float* mean, const float* lgstd, const float* eps_all, const blm_rng* rng0, int T,
                                       int H, int M, int MP, int GP, float* FT, float* Fp, void* stream) {
-  if (!mean || !lgstd || (!eps_all && !rng0) || !FT || !Fp || T < 0 || H <= 0 || M <= 0 || MP < M || GP < MP)
+  if (!mean || !lgstd || (!eps_all && !rng0) || !FT || !Fp || H <= 0 || M <= 0 || MP < M || GP < MP || !blm::extents_ok({T, H, GP}))
     return blm_fail(BLM_ERR_INVALID, "blm_gpnn2_sample_steps: bad arguments");
   if (T == 0) return BLM_OK;
   blm_rng r{};
@@ -541,7 +541,8 @@ extern "C" int blm_gpnn2_sample_steps(const float* mean, const float* lgstd, con
 extern "C" int blm_gpnn2_freq_grad(const float* pre, const float* df, const float* eps_all, const blm_rng* rng0,
                                    const float* lgstd, float* dmean, float* dlgstd, int T, int B, int H, int M, int GP,
                                    void* stream) {
-  if (!pre || !df || (!eps_all && !rng0) || !lgstd || (!dmean && !dlgstd) || T < 0 || B < 0 || H <= 0 || M <= 0 || GP < M)
+  if (!pre || !df || (!eps_all && !rng0) || !lgstd || (!dmean && !dlgstd) || H <= 0 || M <= 0 || GP < M || !blm::extents_ok({T, B, H}) ||
+      !blm::extents_ok({T, B, GP}))
     return blm_fail(BLM_ERR_INVALID, "blm_gpnn2_freq_grad: bad arguments");
   if (T == 0 || B == 0) return BLM_OK;
   blm_rng r{};
@@ -563,7 +564,7 @@ extern "C" int blm_philox_normal(float* out, int64_t n, const blm_rng* rng, void
 
 extern "C" int blm_kl_mean_fwd(const float* mu, int64_t ld_mu, const float* lgstd, int64_t rows, int64_t cols,
                                int minus_one, float weight, float* out, void* stream) {
-  if (!mu || !lgstd || !out || rows <= 0 || cols <= 0 || ld_mu < cols)
+  if (!mu || !lgstd || !out || rows <= 0 || cols <= 0 || ld_mu < cols || !blm::extents_ok({rows, cols}) || !blm::extents_ok({rows, ld_mu}))
     return blm_fail(BLM_ERR_INVALID, "blm_kl_mean_fwd: bad arguments");
   const float scale = 0.5f * weight / ((float)rows * (float)cols);
   // every block ends in ONE float atomic on the same address: 256 blocks (one per CU) instead of 2048 cut the
@@ -593,7 +594,8 @@ extern "C" int blm_kl_mean_fwd(const float* mu, int64_t ld_mu, const float* lgst
 extern "C" int blm_kl_mean_bwd(const float* mu, int64_t ld_mu, const float* lgstd, int64_t rows, int64_t cols,
                                const float* g_dev, float weight, float* dmu, int64_t ld_dmu, float* dlgstd,
                                void* stream) {
-  if (!mu || !lgstd || !g_dev || !dmu || !dlgstd || rows <= 0 || cols <= 0 || ld_mu < cols || ld_dmu < cols)
+  if (!mu || !lgstd || !g_dev || !dmu || !dlgstd || rows <= 0 || cols <= 0 || ld_mu < cols || ld_dmu < cols || !blm::extents_ok({rows, cols}) ||
+      !blm::extents_ok({rows, ld_mu}) || !blm::extents_ok({rows, ld_dmu}))
     return blm_fail(BLM_ERR_INVALID, "blm_kl_mean_bwd: bad arguments");
   const float scale = weight / ((float)rows * (float)cols);
   hipLaunchKernelGGL(kl_bwd_kernel, dim3(grid_for(rows * cols)), dim3(TPB), 0, static_cast<hipStream_t>(stream), mu,
