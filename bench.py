@@ -357,11 +357,12 @@ def rehearse_launch(args, world, rank):
     dist.destroy_process_group()
 
 
-def cpu_baseline(cols=B_PER_GPU, steps=5, warm=2, all_cores_live=False):
+def cpu_baseline(cols=B_PER_GPU, steps=9, warm=1, all_cores_live=False):
     """The CPU oracle (the reference's algorithm restated, pinned to the reference's own outputs incl. its train.py
     trajectories) timed on this box's host cores, SURVEY 8(d) protocol: the SAME workload as `value` -- all 64 batch
     columns, T = 128, dropout 0.2 on (torch's generator, as the reference), fwd + CE + KL + bwd + clip + SGD --
-    median of `steps` steps after `warm` warm-ups.  ~25 s of CPU work."""
+    median of `steps` (9) steps after `warm` warm-up, with the spread of the nine (a shared 16-core slice: +-13 % run to run in round
+    4).  ~40 s of CPU work."""
     from bayeslms_amd import model as M
     from bayeslms_amd.data import synthetic_corpus
     from oracle import bayes_oracle as O
@@ -402,6 +403,7 @@ def cpu_baseline(cols=B_PER_GPU, steps=5, warm=2, all_cores_live=False):
         return out
     times = timed(0, total)
     med = sorted(times[warm:])[steps // 2]
+    spread = {"min": round(cols * T / max(times[warm:]), 1), "max": round(cols * T / min(times[warm:]), 1), "n": steps}
     # SURVEY 8(d) says "all host cores".  The host of a one-GPU box shows all 256 cores but its CPU share is 16: one thread per visible
     # core is oversubscription -- a step then costs ~80 s whatever the batch (94 tokens/s on the full batch, measured in round 4:
     # profiles/r04_cpu_baseline_all_cores.json) -- so the default run reports that committed measurement and `--cpu-all-cores`
@@ -426,7 +428,7 @@ def cpu_baseline(cols=B_PER_GPU, steps=5, warm=2, all_cores_live=False):
                              "sample": rec["runs"][0]["sample"]}
             except Exception:  # noqa: BLE001
                 all_cores = None
-    return {"value": round(cols * T / med, 1), "unit": "tokens/s", "cores": ncores, "kind": "port",
+    return {"value": round(cols * T / med, 1), "unit": "tokens/s", "cores": ncores, "kind": "port", "spread_tokens_per_s": spread,
             "host_cores_visible": avail, "all_visible_cores": all_cores,
             "sample": "oracle/bayes_oracle.py train step (fwd+CE+KL+bwd+clip+SGD, dropout %.1f on), same model, T=%d, all "
                       "%d batch columns, median of %d steps after %d warm-ups, %d threads (the 1-GPU box's CPU share)"
@@ -446,9 +448,10 @@ def lstm_flops_per_token(V_, E=1024, H=1024, L_=2, train=True):
 
 
 def _frac(flops_per_token, tokens_per_s):
+    """Whole-step fraction of the fp32 MFMA peak (157.3 TFLOP/s) from SURVEY 8(d)'s model FLOPs per token: {"tflops", "frac"}
+    (the headline's `step_roofline` spells the same quantity out)."""
     tf = flops_per_token * tokens_per_s / 1e12
-    return {"bound": "mfma", "model_flops_per_token": int(flops_per_token), "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+    return {"tflops": round(tf, 2), "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
 
 
 def _train_leg(model, kl_fn, seq, Bc, lr, steps, warm, dev, engine, ops, timed_tags=False, vocab=V, flops_per_token=None):
@@ -600,7 +603,7 @@ def cli_leg(dev, args, headline_ms):
         with contextlib.redirect_stdout(io.StringIO()):
             TR.main(argv, history=hist)
     ms = hist["ms_per_batch"][-1]  # the second interval: batches 21-40 (the first contains lazy initialisation)
-    return {"config": "python -m bayeslms_amd.train, the headline configuration on a synthetic corpus in the reference's file "
+    return {"id": "cli", "config": "python -m bayeslms_amd.train, the headline configuration on a synthetic corpus in the reference's file "
                       "format: the CLI's own `ms/batch` log value (second log interval of 20 batches)",
             "value": round(ms, 3), "unit": "ms/batch", "tokens_per_s": round(B_PER_GPU * T / ms * 1e3, 1),
             "bench_ms_per_step": round(headline_ms, 3), "ratio_to_bench_step": round(ms / headline_ms, 4),
@@ -643,7 +646,7 @@ def level1_leg(dev, args, headline_ms):
         return 1e3 * (time.perf_counter() - t0) / steps, loss
     ms, loss = loop(True)        # the loop as the reference has it
     ms_nosync, _ = loop(False)   # the same loop without the per-step read-back (what r04 priced)
-    return {"config": "INTEGRATION.md level 1: `from bayeslms_amd.model import *` under the reference's own loop (nn.CrossEntropyLoss() -- on the "
+    return {"id": "level1", "config": "INTEGRATION.md level 1: `from bayeslms_amd.model import *` under the reference's own loop (nn.CrossEntropyLoss() -- on the "
                       "models' ops.Logits output it runs the engine's cross-entropy kernels --, zero_grad(), clip_grad_norm_, optim.SGD, "
                       "total_loss += loss.item() every step as train.py:422), headline configuration",
             "value": round(T * Bc / ms * 1e3, 1), "unit": "tokens/s", "ms_per_step": round(ms, 3), "loss_finite": bool(torch.isfinite(loss)),
@@ -696,8 +699,28 @@ def search_leg(kind, dev, steps=8, warm=3):
     dt = (time.perf_counter() - t0) / steps
     name = ("GaussTransModelSearch 6L d=512 ff=4096 V=33000, T 128, B 64" if kind == "tlm"
             else "BayesLSTMModelSearch E=H=1024 V=33000, T 35, B 64")
-    return {"config": "architecture search (train_search_bayes.py), %s: one window = Architect.step + network step" % name,
+    return {"id": "search_" + kind, "config": "architecture search (train_search_bayes.py), %s: one window = Architect.step + network step" % name,
             "value": round(Ts * B_PER_GPU / dt, 1), "unit": "tokens/s", "ms_per_window": round(1e3 * dt, 3), "windows": steps}
+
+
+def deterministic_leg(dev, args, engine, M, ops, headline_ms):
+    """The headline step in deterministic mode (ops.set_deterministic: one K slice per GEMM tile, fixed-order column sums / KL /
+    embedding gradient; tests/test_gpu_deterministic.py holds two such runs to bit-identical parameters): what it costs."""
+    from bayeslms_amd import train as TR
+    from types import SimpleNamespace
+    torch.manual_seed(1111)
+    m = M.BayesTransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, True, "FFN").to(dev)
+    kl = TR.kl_selector(SimpleNamespace(model="Transformer", uncertainty="Bayesian", T_bayes_pos="FFN", L_bayes_pos=0))
+    ops.set_deterministic(True)
+    try:
+        r, _ = _train_leg(m, kl, T, B_PER_GPU, LR, max(args.steps, 5), args.warmup, dev, engine, ops, flops_per_token=tlm_flops_per_token(T))
+    finally:
+        ops.set_deterministic(False)
+    r["id"] = "cfg2_deterministic"
+    r["config"] = ("the headline configuration in deterministic mode (BLM_DETERMINISTIC=1 / ops.set_deterministic): every reduction in a "
+                   "fixed order, two runs from one seed bit-identical; not the default")
+    r["vs_headline_step"] = round(r["ms_per_step"] / headline_ms, 4)
+    return r
 
 
 def extra_configs(dev, args, engine, M, ops, headline_ms):
@@ -736,6 +759,7 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
     m = M.RNNModel("LSTM", 10000, 1024, 1024, 2, DROPOUT, True).to(dev)
     r, kt = _train_leg(m, None, 35, 20, 1.0, 2 * steps, max(args.warmup, 20), dev, engine, ops, timed_tags=True, vocab=10000,
                        flops_per_token=lstm_flops_per_token(10000))
+    r["id"] = "cfg0_lstm_train"
     r["config"] = ("BASELINE.json configs[0]: 2-layer 1024-hidden standard LSTM LM (--uncertainty none) tied, V=10000, batch 20, "
                    "seq_len 35, dropout 0.2, clip 1.0, SGD momentum 0.9")
     lstm_steps(r, kt, 35, 20)
@@ -752,6 +776,7 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
     kl_lstm = TR.kl_selector(ns(model="LSTM", uncertainty="Bayesian", L_bayes_pos=3))
     r, kt = _train_leg(m, kl_lstm, 35, B_PER_GPU, 1.0, 2 * steps, max(args.warmup, 20), dev, engine, ops, timed_tags=True,
                        flops_per_token=lstm_flops_per_token(V))
+    r["id"] = "cfg1_bayes_lstm_train"
     r["config"] = ("BASELINE.json configs[1]: Bayesian LSTM LM (--uncertainty Bayesian --L_bayes_pos 3) 2x1024 tied, "
                    "V=33000, batch 64, seq_len 35, dropout 0.2, clip 1.0, SGD momentum 0.9")
     lstm_steps(r, kt, 35, B_PER_GPU)
@@ -759,11 +784,13 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
     # the reference recipe's own shape (run_nnlm_ami_lstm.sh:24,100: --seq_len 100 --batch-size 32)
     r, kt = _train_leg(m, kl_lstm, 100, 32, 1.0, steps, max(args.warmup, 8), dev, engine, ops, timed_tags=True,
                        flops_per_token=lstm_flops_per_token(V))
+    r["id"] = "recipe_lstm_train"
     r["config"] = ("recipe shape (run_nnlm_ami_lstm.sh: --seq_len 100 --batch-size 32): Bayesian LSTM LM --L_bayes_pos 3, 2x1024 "
                    "tied, V=33000")
     lstm_steps(r, kt, 100, 32)
     res.append(r)
     e = _eval_leg(m, 35, dev, engine, V, lstm_flops_per_token(V, train=False))
+    e["id"] = "cfg1_evaluate"
     e["config"] = "evaluate() (train.py:441-458), the configs[1] LSTM, eval batch 20, seq_len 35, mean weights"
     res.append(e)
     # LSTM 20-best rescoring (mean weights; the carried state makes it the latency-bound scorer)
@@ -782,6 +809,7 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
                 "step_roofline": _frac(fl * max(mc, 1), ntok / el)}
     wl = "%d utterances x %d-best, lengths 1 + Poisson(7) clipped to [1, 60] (SURVEY 8(d))" % (n_utt, n_hyp)
     r = hyp_rate(m, "LSTM", 0, lstm_flops_per_token(V, train=False))
+    r["id"] = "cfg1_rescore"
     r["config"] = ("n-best rescoring with the configs[1] LSTM: %s, mean weights, hidden state carried across utterances "
                    "(compute_sentence_scores --batched)" % wl)
     res.append(r)
@@ -800,6 +828,7 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
         return {"value": round(n_utt * n_hyp / el, 1), "unit": "hypotheses/s", "tokens_per_s": round(ntok / el, 1),
                 "step_roofline": _frac(fl, ntok / el)}
     r = hyp_rate2(m, m2, "LSTM", 2 * lstm_flops_per_token(V, train=False))
+    r["id"] = "cfg1_rescore_interp"
     r["config"] = ("--interpolation_flag 1: %s, the configs[1] Bayesian LSTM interpolated with a standard 2x1024 LSTM "
                    "(--inter_alpha 0.8), both decoders + cross entropy in one launch (blm_linear_nll2), state carried" % wl)
     res.append(r)
@@ -810,22 +839,27 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
     m = M.BayesTransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, True, "FFN").to(dev)
     r, _ = _train_leg(m, TR.kl_selector(ns(uncertainty="Bayesian", T_bayes_pos="FFN")), 100, 32, LR, steps, args.warmup, dev, engine,
                       ops, flops_per_token=tlm_flops_per_token(100))
+    r["id"] = "recipe_tlm_train"
     r["config"] = ("recipe shape (run_nnlm_ami_tm.sh: --seq_len 100 --batch-size 32): Bayesian Transformer LM --T_bayes_pos FFN, "
                    "6L d_model=512 d_ff=4096 V=33000")
     res.append(r)
     e = _eval_leg(m, T, dev, engine, V, tlm_flops_per_token(T, train=False))
+    e["id"] = "cfg2_evaluate"
     e["config"] = "evaluate() (train.py:441-458), the headline Transformer, eval batch 20, seq_len 128, mean weights"
     res.append(e)
     r = hyp_rate(m, "Transformer", 0, tlm_flops_per_token(8, train=False))
+    r["id"] = "cfg4_bayes_tlm_rescore"
     r["config"] = "configs[4] n-best rescoring, Bayesian Transformer-FFN, %s, mean weights" % wl
     res.append(r)
     r = hyp_rate(m, "Transformer", 8, tlm_flops_per_token(8, train=False))
+    r["id"] = "cfg4_bayes_tlm_rescore_mc8"
     r["config"] = ("configs[4] n-best rescoring, Bayesian Transformer-FFN, %s, 8 Monte-Carlo weight samples "
                    "(score = -log mean_s exp(-NLL_s), oracle-checked)" % wl)
     res.append(r)
     torch.manual_seed(2222)
     m2 = M.TransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, "gelu", True).to(dev)
     r = hyp_rate2(m, m2, "Transformer", 2 * tlm_flops_per_token(8, train=False))
+    r["id"] = "cfg2_rescore_interp"
     r["config"] = ("--interpolation_flag 1 (run_nnlm_ami_tm.sh:30-31,133-134): %s, Bayesian Transformer-FFN interpolated with a "
                    "standard Transformer (--inter_alpha 0.8), both decoders + cross entropy in one launch (blm_linear_nll2)" % wl)
     res.append(r)
@@ -837,14 +871,17 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
     m = M.GaussTransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, True, 3).to(dev)
     r, _ = _train_leg(m, TR.kl_selector(ns(uncertainty="Gaussian", T_gauss_pos=3)), T, B_PER_GPU, LR, steps, args.warmup, dev,
                       engine, ops, flops_per_token=tlm_flops_per_token(T))
+    r["id"] = "cfg4_gp_tlm_train"
     r["config"] = ("BASELINE.json configs[4] training leg on 1 GPU: GP Transformer LM (--uncertainty Gaussian --T_gauss_pos 3) 6L "
                    "d_model=512 d_ff=4096 V=33000, seq_len 128, batch 64")
     res.append(r)
     r = hyp_rate(m, "Transformer", 0, tlm_flops_per_token(8, train=False))
+    r["id"] = "cfg4_gp_tlm_rescore"
     r["config"] = ("configs[4] n-best rescoring, GP Transformer, %s, mean weights (the reference's inference: GPNN.sample is "
                    "never raised)" % wl)
     res.append(r)
     r = hyp_rate(m, "Transformer", 8, tlm_flops_per_token(8, train=False))
+    r["id"] = "cfg4_gp_tlm_rescore_mc8"
     r["config"] = ("BASELINE.json configs[4] inference leg as written: GP Transformer (--T_gauss_pos 3), %s, 8 Monte-Carlo weight "
                    "samples -- GPNN.sample raised for the call, coef / weights / bias re-drawn per sample (reference "
                    "model.py:1871-1883), score = -log mean_s exp(-NLL_s), oracle-checked" % wl)
@@ -854,19 +891,21 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
             g.sample = True
     r, _ = _train_leg(m, TR.kl_selector(ns(uncertainty="Gaussian", T_gauss_pos=3)), T, B_PER_GPU, LR, steps, args.warmup, dev,
                       engine, ops, flops_per_token=tlm_flops_per_token(T))
+    r["id"] = "cfg4_gp_tlm_train_gpsample"
     r["config"] = ("configs[4] training leg with GPNN.sample raised (--gp-sample 1; the reference's train.py leaves it False): "
                    "GP Transformer LM --T_gauss_pos 3, coef / weights / bias = mean + exp(lgstd) eps every step, seq_len 128, batch 64")
     res.append(r)
     del m
     torch.cuda.empty_cache()
     # --- the CLI itself, and the architecture search
-    for name, fn in (("cli", lambda: cli_leg(dev, args, headline_ms)), ("level1", lambda: level1_leg(dev, args, headline_ms)),
+    for name, fn in (("cfg2_deterministic", lambda: deterministic_leg(dev, args, engine, M, ops, headline_ms)),
+                     ("cli", lambda: cli_leg(dev, args, headline_ms)), ("level1", lambda: level1_leg(dev, args, headline_ms)),
                      ("search_tlm", lambda: search_leg("tlm", dev)),
                      ("search_lstm", lambda: search_leg("lstm", dev))):
         try:
             res.append(fn())
         except Exception as e:  # noqa: BLE001
-            res.append({"config": name, "error": repr(e)})
+            res.append({"id": name, "error": repr(e)})
         torch.cuda.empty_cache()
     return res
 
@@ -926,6 +965,58 @@ def _kl_fn(mm):
 
 
 _kl_fn.fusable = True
+
+
+def compact_line(out):
+    """The driver keeps the last ~8 KB of stdout: the line stays short and ends with what must survive.  Every extra_configs
+    entry keeps an `id` and its numbers; its description (`config`) and the notes go to stderr as `[bench legend] id: text`,
+    once.  `baseline_configs` -- one object per BASELINE.json configuration, the numbers this run measured for it -- is the
+    LAST key of the line."""
+    ex = out.get("extra_configs")
+    by_id = {}
+    if isinstance(ex, list):
+        for r in ex:
+            rid = r.get("id", "?")
+            by_id[rid] = r
+            for k in ("config", "lstm_step_times_from", "lstm_layers", "note"):
+                if k in r:
+                    sys.stderr.write("[bench legend] %s.%s: %s\n" % (rid, k, r.pop(k)))
+            cb = r.get("cpu_baseline")
+            if isinstance(cb, dict) and "sample" in cb:
+                sys.stderr.write("[bench legend] %s.cpu_baseline.sample: %s\n" % (rid, cb.pop("sample")))
+    for mode in (out.get("opt_in") if isinstance(out.get("opt_in"), list) else []):
+        if "note" in mode:
+            sys.stderr.write("[bench legend] opt_in.%s: %s\n" % (mode.get("gemm_mode"), mode.pop("note")))
+    chip = out.get("chip")
+    if isinstance(chip, dict) and "note" in chip:
+        sys.stderr.write("[bench legend] chip: %s\n" % chip.pop("note"))
+    sys.stderr.flush()
+
+    def pick(rid, *keys):
+        r = by_id.get(rid)
+        if not isinstance(r, dict):
+            return None
+        if "error" in r:
+            return {"error": r["error"][:120]}
+        o = {k: r[k] for k in ("value", "unit") if k in r}
+        if isinstance(r.get("step_roofline"), dict):
+            o["frac"] = r["step_roofline"].get("frac")
+        for k in keys:
+            if k in r:
+                o[k] = r[k]["value"] if (k == "cpu_baseline" and isinstance(r[k], dict) and "value" in r[k]) else r[k]
+        return o
+    n = out.get("n_gpus", 1)
+    headline = {"value": out["value"], "unit": out["unit"], "n_gpus": n, "frac": (out.get("step_roofline") or {}).get("frac"),
+                "kernel_frac": (out.get("roofline") or {}).get("frac"), "eval_ppl": out.get("eval_ppl")}
+    out["baseline_configs"] = {
+        "configs[0]": pick("cfg0_lstm_train", "cpu_baseline"),
+        "configs[1]": pick("cfg1_bayes_lstm_train"),
+        "configs[2]": headline if n == 1 else None,
+        "configs[3]": headline if n > 1 else None,  # the same model data-parallel: `--gpus N` runs (global batch 64 N)
+        "configs[4]": {"train_1gpu": pick("cfg4_gp_tlm_train"), "rescore_mean_weights": pick("cfg4_gp_tlm_rescore"),
+                       "rescore_8_mc_samples": pick("cfg4_gp_tlm_rescore_mc8")},
+    }
+    return out
 
 
 def main():
@@ -1093,9 +1184,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: Bayesian Transformer LM (--uncertainty Bayesian "
+            "config": {"workload": "BASELINE.json configs[%d]%s: Bayesian Transformer LM (--uncertainty Bayesian "
                                    "--T_bayes_pos FFN) 6L d_model=512 d_ff=4096 8 heads V=33000 tied, dropout 0.2, "
-                                   "clip 1.0, SGD momentum 0.9; fwd+CE+KL+bwd+all-reduce+clip+SGD",
+                                   "clip 1.0, SGD momentum 0.9; fwd+CE+KL+bwd+all-reduce+clip+SGD"
+                                   % ((2, "") if world == 1 else (3, " (configs[2] data-parallel over %d GPUs, 64 columns each)" % world)),
                        "global_batch": Bc * world, "seq_len": T, "parallelism": "dp%d" % world,
                        "fused_sampling": bool(model.noise_state.fused)},
             "roofline": roof,
@@ -1138,6 +1230,7 @@ def main():
                 out["extra_configs"] = extra_configs(dev, args, engine, M, ops, out["ms_per_step"])
             except Exception as e:  # noqa: BLE001
                 out["extra_configs"] = {"error": repr(e)}
+        out = compact_line(out)
         print(json.dumps(out), flush=True)
         if world > 1:
             _eng.heartbeat("line printed", rank)
