@@ -36,6 +36,6 @@ inline bool extents_ok(std::initializer_list<long> dims) {
 // forms of a kernel lives here -- one registry, settable at run time (so the GPU tests run both forms in one process), each
 // initialised from its BLM_* environment variable on first use.  INTEGRATION.md lists them with the test that covers each.
 namespace blm {
-enum Opt { OPT_ATTN_HPW = 0, OPT_ATTN_SHORT, OPT_ATTN_VALU, OPT_LSTM_GEMV, OPT_LSTM_PIPE, OPT_LSTM_TAIL, OPT_DETERMINISTIC, OPT_COUNT };
+enum Opt { OPT_ATTN_HPW = 0, OPT_ATTN_SHORT, OPT_ATTN_VALU, OPT_LSTM_GEMV, OPT_LSTM_PIPE, OPT_LSTM_TAIL, OPT_DETERMINISTIC, OPT_LSTM_MB2, OPT_COUNT };
 int option(Opt o);
 }  // namespace blm

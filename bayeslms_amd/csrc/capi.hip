@@ -47,6 +47,7 @@ OptEntry g_opts[blm::OPT_COUNT] = {
     // gradients in one row chunk, KL sums through block partials added by one block, the embedding gradient by one wave per
     // vocabulary row in position order: two runs from one seed give bit-identical parameters (tests/test_gpu_deterministic.py)
     {"deterministic", "BLM_DETERMINISTIC", 0, 0, 1, 0, false},
+    {"lstm_mb2", "BLM_LSTM_MB2", 1, 0, 1, 1, false},     // 1: the search cell's forward step takes two batch tiles per workgroup at B > 32 (W streamed once, one round)
 };
 std::mutex g_opt_mu;
 void opt_init(OptEntry& e) {

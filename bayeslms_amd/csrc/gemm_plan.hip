@@ -252,12 +252,16 @@ Plan choose_plan(const PlanKey& k, bool consume) {
   Plan p{11, 1, 0, g_cus, 0.f};
   // table entries were measured on the whole chip: they apply there only
   const Entry* e = g_cus != kChipCUs ? nullptr : find(k);  // blm_gemm_plan_clear(0) switches the table off (cost model only)
+  // a plan measured WITH K slices says nothing about the tile to run WITHOUT them (deterministic mode, or a launch whose C cannot
+  // take atomics): the cost model then picks among the unsliced candidates
+  if (e && !k.can_split && (e->splits > 1 || e->splits < -1)) e = nullptr;
   if (e) { p.tile = e->tile; p.splits = e->splits; p.source = 1; }
   else { p = model_plan(k); p.cus = g_cus; }
   // beside a collective: the plan measured there, where one exists (everything else keeps its whole-chip plan -- in situ the
   // cost model's plans for a narrowed chip lose to the measured table whenever no channel workgroup is resident)
   if (under_comm)
-    if (const Entry* c = find_comm(k)) { p.tile = c->tile; p.splits = c->splits; p.source = 3; }
+    if (const Entry* c = find_comm(k))
+      if (k.can_split || (c->splits >= -1 && c->splits <= 1)) { p.tile = c->tile; p.splits = c->splits; p.source = 3; }
   if (g_force_tile > 0 && valid_tile(g_force_tile)) { p.tile = g_force_tile; p.source = 2; }
   if (g_force_splits != 0) { p.splits = g_force_splits; p.source = 2; }
   // legality, whatever the source said (splits <= -2: tail slicing, |splits| ways)

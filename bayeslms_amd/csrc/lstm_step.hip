@@ -72,9 +72,15 @@ struct LstmStepP {
 // selects in front of the LDS writes and wave-uniform chunk offsets.  On gfx950 every vector instruction is paid in
 // matrix time (tools/mfma_valu_overlap.hip): the 64 v_cndmask + 16 64-bit address adds per chunk of the general form
 // were ~ 18 % on top of its 32 MFMAs.
-template <int RING, int NS, bool REFILL, int NW, bool PIPE, bool TAIL>
+// MB = batch tiles of 32 rows per workgroup (1 or 2).  MB = 2 (the search cell at B > 32, round 5): a workgroup multiplies its 32
+// weight rows against 64 batch rows -- two accumulator tiles per wave fed from ONE staged W tile -- so the 8H x H weight is
+// streamed once per step instead of once per batch tile, and the grid is H / 4 workgroups = one round of the chip where the
+// MB = 1 form needed two (the step is latency-bound: two rounds cost twice one round, tools/search_step_bench.py).
+template <int RING, int NS, bool REFILL, int NW, bool PIPE, bool TAIL, int MB = 1>
 __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
   constexpr int U = 32 / NS;  // hidden units per workgroup
+  constexpr int NT = 1 + MB;  // staged tiles per wave and chunk: MB tiles of h, one of W
+  static_assert(MB == 1 || (MB == 2 && !PIPE && NS == 8), "two batch tiles per workgroup: the plain K loop of the search cell only");
   // ONE staging buffer per wave (LDS runs a wave's instructions in order and the fragments are in registers before the
   // MFMAs start, so the next chunk may overwrite the tile): 70 KB per 4-wave workgroup and <= 256 VGPRs per wave, i.e. TWO
   // workgroups fit a CU -- the step kernels of two independent recurrences (the layers of a stack, run as a wavefront on
@@ -82,11 +88,11 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
   constexpr int NBUF = 1;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
-  const int j0 = blockIdx.x * U, b0 = blockIdx.y * 32;
+  const int j0 = blockIdx.x * U, b0 = blockIdx.y * 32 * MB;
   const int H = p.H, B = p.B;
   const int Kw = H / NW, Kh = Kw >> 1, kbase = wave * Kw;
   const int nchunk = (Kh + 31) >> 5;
-  float* base = sm + wave * (NBUF * 2 * TILE);
+  float* base = sm + wave * (NBUF * NT * TILE);
 #ifdef BLM_LSTM_PROF
   long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -94,7 +100,7 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
 
   const int brow = threadIdx.x / U, eu = threadIdx.x % U;
   const int eb = b0 + brow, ej = j0 + eu;
-  const bool eok = eb < B && brow < 32;
+  const bool eok = eb < B && brow < 32 * MB;
   float xg[NS], cprev = 0.f;
 
   // staging roles: one instruction moves 4 rows x 2 halves x 128 B
@@ -111,15 +117,16 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.whh), 0, (int)(4u * NS * (uint32_t)H * (uint32_t)H), 0x00020000);  // < 4 GB (host check)
 #endif
   const int kb4 = __builtin_amdgcn_readfirstlane(kbase * 4);
-  uint32_t aoff[8], woff[8];
+  uint32_t aoff[MB][8], woff[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int row = 4 * q + srow;
 #ifdef BLM_LSTM_PROF
-    aoff[q] = (uint32_t)(((long)(p.alias >= 2 ? 0 : min(b0 + row, B - 1)) * H + shalf * Kh + 4 * spart) * 4);
+    aoff[0][q] = (uint32_t)(((long)(p.alias >= 2 ? 0 : min(b0 + row, B - 1)) * H + shalf * Kh + 4 * spart) * 4);
     woff[q] = (uint32_t)((((long)(row / U) * H + (p.alias >= 1 ? 0 : j0) + (row % U)) * H + shalf * Kh + 4 * spart) * 4);
 #else
-    aoff[q] = (uint32_t)(((long)min(b0 + row, B - 1) * H + shalf * Kh + 4 * spart) * 4);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) aoff[m][q] = (uint32_t)(((long)min(b0 + 32 * m + row, B - 1) * H + shalf * Kh + 4 * spart) * 4);
     woff[q] = (uint32_t)((((long)(row / U) * H + j0 + (row % U)) * H + shalf * Kh + 4 * spart) * 4);
 #endif
   }
@@ -137,33 +144,38 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
   // to keep RING x 16 KB per wave of loads in flight while the matrix core works on a chunk.  The loop
   // body is branch free (tail lanes and the refill past the last chunk read a clamped, valid address)
   // so that the s_waitcnt in front of each put() only waits for ITS chunk.
-  float4 ra[RING][8], rw[RING][8];
-  auto fetch = [&](float4 (&a)[8], float4 (&w)[8], int c) {
+  float4 ra[RING][MB][8], rw[RING][8];
+  auto fetch = [&](float4 (&a)[MB][8], float4 (&w)[8], int c) {
     if constexpr (TAIL) {
       const int off = min(32 * min(c, nchunk - 1) + 4 * spart, Kh - 4) - 4 * spart;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        a[q] = ldg(arsrc, aoff[q] + 4u * off, kb4);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) a[m][q] = ldg(arsrc, aoff[m][q] + 4u * off, kb4);
         w[q] = ldg(wrsrc, woff[q] + 4u * off, kb4);
       }
     } else {
       const int so = kb4 + 128 * min(c, nchunk - 1);  // wave-uniform
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        a[q] = ldg(arsrc, aoff[q], so);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) a[m][q] = ldg(arsrc, aoff[m][q], so);
         w[q] = ldg(wrsrc, woff[q], so);
       }
     }
   };
-  f32x16 acc = (f32x16)(0.f);
-  // one chunk: registers -> LDS tile `buf`, refill the registers with chunk c + RING, 32 MFMA steps
-  auto chunk = [&](float4 (&a)[8], float4 (&w)[8], int buf, int c) {
+  f32x16 acc[MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) acc[m] = (f32x16)(0.f);
+  // one chunk: registers -> LDS tiles `buf` (h tile(s), then the W tile), refill the registers with chunk c + RING, 32 MFMA steps per h tile
+  auto chunk = [&](float4 (&a)[MB][8], float4 (&w)[8], int buf, int c) {
     const bool in = 32 * c + 4 * spart < Kh;  // K tail of the last chunk -> zeros
-    float* d = base + buf * 2 * TILE + soff;
+    float* d = base + buf * NT * TILE + soff;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      *reinterpret_cast<float4*>(d + 4 * q * LSTR) = fill(a[q], in);
-      *reinterpret_cast<float4*>(d + TILE + 4 * q * LSTR) = fill(w[q], in);
+#pragma unroll
+      for (int m = 0; m < MB; ++m) *reinterpret_cast<float4*>(d + m * TILE + 4 * q * LSTR) = fill(a[m][q], in);
+      *reinterpret_cast<float4*>(d + MB * TILE + 4 * q * LSTR) = fill(w[q], in);
     }
     if (c == 0) {  // the first chunk's bytes have landed (its LDS writes are issued)
       LSTM_STAMP(1);
@@ -176,20 +188,25 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
     // the writes above without a workgroup barrier; the fence only pins the compiler's order
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const float* at = base + buf * 2 * TILE + li * LSTR + lh * 32;
-    const float* wt = at + TILE;
-    float4 av[8], wv[8];
+    const float* at = base + buf * NT * TILE + li * LSTR + lh * 32;
+    const float* wt = at + MB * TILE;
+    float4 av[MB][8], wv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      av[j] = *reinterpret_cast<const float4*>(at + 4 * j);
+#pragma unroll
+      for (int m = 0; m < MB; ++m) av[m][j] = *reinterpret_cast<const float4*>(at + m * TILE + 4 * j);
       wv[j] = *reinterpret_cast<const float4*>(wt + 4 * j);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].x, wv[j].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, wv[j].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].z, wv[j].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].w, wv[j].w, acc, 0, 0, 0);
+    for (int j = 0; j < 8; ++j) {  // MB independent accumulator chains share every W fragment
+#pragma unroll
+      for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][j].x, wv[j].x, acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][j].y, wv[j].y, acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][j].z, wv[j].z, acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][j].w, wv[j].w, acc[m], 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
   };
@@ -209,7 +226,7 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
     cprev = p.ovr == 5 ? p.zsave[(long)eb * H + ej] + p.rbias[ej] : p.cprev[(long)eb * H + ej];
   }
   if constexpr (PIPE) {
-    static_assert(RING == 2 && NBUF == 1, "the pipelined loop walks chunk pairs through one staging tile");
+    static_assert(RING == 2 && NBUF == 1 && MB == 1, "the pipelined loop walks chunk pairs through one staging tile");
     float4 fa[2][8], fw[2][8];  // fragment sets: one feeds the MFMAs while the other is filled
     float* dst = base + soff;
     const float* at = base + li * LSTR + lh * 32;
@@ -227,8 +244,8 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
       const int off = TAIL ? min(offu + 4 * spart, Kh - 4) - 4 * spart : 0;
 #pragma unroll
       for (int q = q0; q < q0 + 2; ++q) {
-        if constexpr (TAIL) { a[q] = ldg(arsrc, aoff[q] + 4u * off, kb4); w[q] = ldg(wrsrc, woff[q] + 4u * off, kb4); }
-        else { a[q] = ldg(arsrc, aoff[q], kb4 + 4 * offu); w[q] = ldg(wrsrc, woff[q], kb4 + 4 * offu); }
+        if constexpr (TAIL) { a[q] = ldg(arsrc, aoff[0][q] + 4u * off, kb4); w[q] = ldg(wrsrc, woff[q] + 4u * off, kb4); }
+        else { a[q] = ldg(arsrc, aoff[0][q], kb4 + 4 * offu); w[q] = ldg(wrsrc, woff[q], kb4 + 4 * offu); }
       }
     };
     auto get2 = [&](float4 (&fa_)[8], float4 (&fw_)[8], int j0) {  // 4 ds_read_b128
@@ -239,10 +256,10 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
       }
     };
     auto mfma4 = [&](const float4& a, const float4& w) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc[0], 0, 0, 0);
     };
     // MFMAs of the fragments in (ca, cw) interleaved with the staging of chunk cn (registers a, w) into (na, nw): 32 slots
     // of ONE MFMA + ONE LDS instruction (+ one refill load), each its own scheduling region so that the order survives
@@ -255,12 +272,12 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
       const int so = TAIL ? kb4 : kb4 + 4 * offu;
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(ca[k >> 2], k & 3), comp(cw[k >> 2], k & 3), acc, 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(ca[k >> 2], k & 3), comp(cw[k >> 2], k & 3), acc[0], 0, 0, 0);
         if (k < 16) {  // ds_write_b128 of the next chunk: k even -> h tile row q, k odd -> W tile row q
           const int q = k >> 1;
           if ((k & 1) == 0) {
             *reinterpret_cast<float4*>(dst + 4 * q * LSTR) = fill(a[q], in);
-            if constexpr (REFILL) a[q] = ldg(arsrc, TAIL ? aoff[q] + 4u * off : aoff[q], so);
+            if constexpr (REFILL) a[q] = ldg(arsrc, TAIL ? aoff[0][q] + 4u * off : aoff[0][q], so);
           } else {
             *reinterpret_cast<float4*>(dst + TILE + 4 * q * LSTR) = fill(w[q], in);
             if constexpr (REFILL) w[q] = ldg(wrsrc, TAIL ? woff[q] + 4u * off : woff[q], so);
@@ -281,8 +298,8 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
     // prologue: chunk 0 staged alone
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      put2(ra[0], rw[0], 0, 2 * j);
-      if constexpr (REFILL) refill2(ra[0], rw[0], RING, 2 * j);
+      put2(ra[0][0], rw[0], 0, 2 * j);
+      if constexpr (REFILL) refill2(ra[0][0], rw[0], RING, 2 * j);
     }
     LSTM_STAMP(1);
 #ifdef BLM_LSTM_PROF
@@ -295,10 +312,10 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
     for (int cc = 0; cc + 2 < nchunk; cc += 2) {
-      comb(fa[0], fw[0], ra[1], rw[1], cc + 1, fa[1], fw[1]);
-      comb(fa[1], fw[1], ra[0], rw[0], cc + 2, fa[0], fw[0]);
+      comb(fa[0], fw[0], ra[1][0], rw[1], cc + 1, fa[1], fw[1]);
+      comb(fa[1], fw[1], ra[0][0], rw[0], cc + 2, fa[0], fw[0]);
     }
-    comb(fa[0], fw[0], ra[1], rw[1], nchunk - 1, fa[1], fw[1]);
+    comb(fa[0], fw[0], ra[1][0], rw[1], nchunk - 1, fa[1], fw[1]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) mfma4(fa[1][j], fw[1][j]);
   } else if constexpr (REFILL) {
@@ -319,12 +336,14 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
 #endif
   __syncthreads();  // every wave is done with its staging tiles: the reduction buffer overlays them
   LSTM_STAMP(3);
-  float* red = sm;  // NW x 32 x RSTR floats = 20 / 40 KB
+  float* red = sm;  // NW x 32 MB x RSTR floats = 20 / 40 KB
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-    red[(wave * 32 + row) * RSTR + li] = acc[r];
-  }
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      red[((wave * MB + m) * 32 + row) * RSTR + li] = acc[m][r];
+    }
   __syncthreads();
   LSTM_STAMP(4);
 #ifdef BLM_LSTM_PROF
@@ -344,11 +363,12 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
 #pragma unroll
     for (int g = 0; g < NS; ++g) {
       const int n = g * U + eu;
-      hw[g] = (red[(0 * 32 + brow) * RSTR + n] + red[(1 * 32 + brow) * RSTR + n]) +
-              (red[(2 * 32 + brow) * RSTR + n] + red[(3 * 32 + brow) * RSTR + n]);
+      constexpr int WS = 32 * MB;  // batch rows per wave slab of the reduction buffer (brow < WS)
+      hw[g] = (red[(0 * WS + brow) * RSTR + n] + red[(1 * WS + brow) * RSTR + n]) +
+              (red[(2 * WS + brow) * RSTR + n] + red[(3 * WS + brow) * RSTR + n]);
       if constexpr (NW == 8)
-        hw[g] += (red[(4 * 32 + brow) * RSTR + n] + red[(5 * 32 + brow) * RSTR + n]) +
-                 (red[(6 * 32 + brow) * RSTR + n] + red[(7 * 32 + brow) * RSTR + n]);
+        hw[g] += (red[(4 * WS + brow) * RSTR + n] + red[(5 * WS + brow) * RSTR + n]) +
+                 (red[(6 * WS + brow) * RSTR + n] + red[(7 * WS + brow) * RSTR + n]);
     }
     const long i = (long)eb * H + ej, o = (long)eb * NS * H + ej;
     if constexpr (NS == 8) {  // search cell: eight activations, four probs-weighted mixes (search.hip search_cell_fwd_kernel)
@@ -406,9 +426,9 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
 }
 
 
-template <int RING, int NS = 4, bool REFILL = true, int NW = 4, bool PIPE = false, bool TAIL = true>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 1 : 2, PIPE ? 1 : 2))) void lstm_step_fwd_kernel(const LstmStepP p) {
-  lstm_step_fwd_body<RING, NS, REFILL, NW, PIPE, TAIL>(p);
+template <int RING, int NS = 4, bool REFILL = true, int NW = 4, bool PIPE = false, bool TAIL = true, int MB = 1>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((PIPE || MB > 1) ? 1 : 2, (PIPE || MB > 1) ? 1 : 2))) void lstm_step_fwd_kernel(const LstmStepP p) {
+  lstm_step_fwd_body<RING, NS, REFILL, NW, PIPE, TAIL, MB>(p);
 }
 
 // ------------------------------------------------------------------ forward step, tiny batches (B <= 4)
@@ -869,6 +889,7 @@ using namespace blm;
 // and the general (K tail) form of the pipelined kernels -- each form is built and parity-tested
 static int lstm_gemv() { return blm::option(blm::OPT_LSTM_GEMV); }
 static int lstm_pipe() { return blm::option(blm::OPT_LSTM_PIPE); }
+static int lstm_mb2() { return blm::option(blm::OPT_LSTM_MB2); }
 static int lstm_tail() { return blm::option(blm::OPT_LSTM_TAIL); }
 
 extern "C" int blm_lstm_step_fwd_gp(const float*, const float*, const float*, const float*, float*, float*, float*, const float*, int,
@@ -996,6 +1017,19 @@ extern "C" int blm_lstm_search_step_fwd(const float* xw8_t, const float* w8_hh, 
   const int nchunk = (H / 8 + 31) / 32;
   const dim3 grid(H / 4, (B + 31) / 32), block(256);
   hipStream_t st = (hipStream_t)stream;
+  // B > 32: two batch tiles per workgroup -- the stacked weight streams once, H / 4 workgroups per 64 batch rows (one round of the
+  // chip at H = 1024) instead of two rounds of the one-tile form (12.2 us per round, tools/search_step_bench.py)
+  if (B > 32 && nchunk % 2 == 0 && H % 256 == 0 && lstm_mb2() && !lstm_tail()) {
+    const size_t lds3 = (size_t)4 * 3 * TILE * sizeof(float);
+    static bool once3 = false;
+    if (!once3) {
+      BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 8, true, 4, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+      once3 = true;
+    }
+    hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 8, true, 4, false, false, 2>), dim3(H / 4, (B + 63) / 64), block, lds3, st, p);
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
+  }
   if (nchunk % 2 == 0 && nchunk >= 4 && H % 256 == 0 && lstm_pipe() && !lstm_tail())  // pipelined K loop, whole chunks (see blm_lstm_step_fwd)
     hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 8, true, 4, true, false>), grid, block, lds, st, p);
   else if (nchunk % 2 == 0) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 8>), grid, block, lds, st, p);

@@ -142,6 +142,36 @@ def test_lstm_step_kernel_forms_agree(dev, option, opt, val, B, H):
         assert rel(a, b) < 5e-6
 
 
+@pytest.mark.parametrize("B,H", [(64, 256), (50, 512), (96, 256)])
+def test_search_step_two_batch_tiles_per_workgroup_equals_one(dev, option, B, H):
+    """"lstm_mb2" (default 1): at B > 32 the search cell's forward step multiplies its 32 weight rows against TWO batch tiles per
+    workgroup (the stacked 8H x H weight streams once, half the workgroups); 0 = one tile per workgroup.  Same K order per wave and
+    the same fixed cross-wave reduction: h, c and the eight activations are bit-identical, incl. a ragged last tile (B = 50) and a
+    second row of workgroups (B = 96)."""
+    from bayeslms_amd._lib import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(B + H)
+    xw = torch.randn(B, 8 * H, generator=g).to(dev)
+    w8 = (0.05 * torch.randn(8 * H, H, generator=g)).to(dev)
+    h0, c0 = torch.randn(B, H, generator=g).to(dev), torch.randn(B, H, generator=g).to(dev)
+    probs = torch.softmax(torch.randn(4, 2, generator=g), -1).contiguous().to(dev)
+    outs = []
+    for mb2 in (1, 0):
+        option("lstm_mb2", mb2)
+        h, c, a = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev), torch.zeros(B, 8 * H, device=dev)
+        check(lib().blm_lstm_search_step_fwd(ptr(xw), ptr(w8), ptr(h0), ptr(c0), ptr(probs), ptr(h), ptr(c), ptr(a), B, H, stream()))
+        outs.append((h.cpu(), c.cpu(), a.cpu()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    # and against fp64: z = xw + h0 W8^T, eight activations, four mixes, cell
+    z = xw.double().cpu() + h0.double().cpu() @ w8.double().cpu().t()
+    act = torch.cat([torch.tanh(z[:, k * H:(k + 1) * H]) if k % 4 == 2 else torch.sigmoid(z[:, k * H:(k + 1) * H]) for k in range(8)], 1)
+    pr = probs.double().cpu()
+    gate = [act[:, k * H:(k + 1) * H] * pr[k, 0] + act[:, (k + 4) * H:(k + 5) * H] * pr[k, 1] for k in range(4)]
+    cn = gate[1] * c0.double().cpu() + gate[0] * gate[2]
+    hn = gate[3] * torch.tanh(cn)
+    assert rel(outs[0][0].double(), hn) < 2e-5 and rel(outs[0][1].double(), cn) < 2e-5 and rel(outs[0][2].double(), act) < 2e-5
+
+
 def test_options_are_validated(dev):
     from bayeslms_amd import ops
     from bayeslms_amd._lib import BayesLMError
