@@ -80,7 +80,7 @@ template <int RING, int NS, bool REFILL, int NW, bool PIPE, bool TAIL, int MB = 
 __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
   constexpr int U = 32 / NS;  // hidden units per workgroup
   constexpr int NT = 1 + MB;  // staged tiles per wave and chunk: MB tiles of h, one of W
-  static_assert(MB == 1 || (MB == 2 && !PIPE && NS == 8), "two batch tiles per workgroup: the plain K loop of the search cell only");
+  static_assert(MB == 1 || (MB == 2 && NS == 8), "two batch tiles per workgroup: the search cell only (its epilogue has a thread per (batch row, unit) of 64 rows)");
   // ONE staging buffer per wave (LDS runs a wave's instructions in order and the fragments are in registers before the
   // MFMAs start, so the next chunk may overwrite the tile): 70 KB per 4-wave workgroup and <= 256 VGPRs per wave, i.e. TWO
   // workgroups fit a CU -- the step kernels of two independent recurrences (the layers of a stack, run as a wavefront on
@@ -225,7 +225,82 @@ __device__ __forceinline__ void lstm_step_fwd_body(const LstmStepP& p) {
     // c_{t-1} Wg^T (blm_lstm_step_dh, launched before this step); + bias -> z, kept for the backward pass
     cprev = p.ovr == 5 ? p.zsave[(long)eb * H + ej] + p.rbias[ej] : p.cprev[(long)eb * H + ej];
   }
-  if constexpr (PIPE) {
+  if constexpr (PIPE && MB == 2) {
+    // The pipelined loop for two batch tiles: per chunk 64 MFMAs (two independent accumulator chains sharing every W fragment)
+    // with the next chunk's 24 ds_write_b128 (+ the 24 refill loads) and 24 fragment ds_read_b128 issued between them, one LDS
+    // instruction per MFMA slot, each slot its own scheduling region (see the one-tile form below).  Whole chunks only.
+    static_assert(RING == 2 && NBUF == 1 && REFILL && !TAIL, "the pipelined two-tile loop: ring of two, whole chunks");
+    float4 fa[2][MB][8], fw[2][8];
+    float* dst = base + soff;
+    const float* at = base + li * LSTR + lh * 32;
+    auto comp = [](const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); };
+    auto comb = [&](const float4 (&ca)[MB][8], const float4 (&cw)[8], float4 (&a)[MB][8], float4 (&w)[8], int cn, float4 (&na)[MB][8],
+                    float4 (&nw)[8]) {
+      const int so = kb4 + 128 * min(cn + RING, nchunk - 1);
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(ca[m][k >> 2], k & 3), comp(cw[k >> 2], k & 3), acc[m], 0, 0, 0);
+          const int slot = k * MB + m;  // 0 .. 63
+          if (slot < 24) {         // ds_write_b128 of the next chunk: tile slot % 3 (h tile 0, h tile 1, W), row group slot / 3
+            const int t = slot % 3, q = slot / 3;
+            if (t < 2) {
+              *reinterpret_cast<float4*>(dst + t * TILE + 4 * q * LSTR) = a[t][q];
+              a[t][q] = ldg(arsrc, aoff[t][q], so);
+            } else {
+              *reinterpret_cast<float4*>(dst + 2 * TILE + 4 * q * LSTR) = w[q];
+              w[q] = ldg(wrsrc, woff[q], so);
+            }
+            if (slot == 23) {      // the tiles are complete before they are read back (compiler order; LDS is in order per wave)
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
+          } else if (slot < 48) {  // ds_read_b128 of the next chunk's fragments
+            const int r = slot - 24, t = r % 3, j = r / 3;
+            if (t < 2) na[t][j] = *reinterpret_cast<const float4*>(at + t * TILE + 4 * j);
+            else nw[j] = *reinterpret_cast<const float4*>(at + 2 * TILE + 4 * j);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+    {  // prologue: chunk 0 staged alone, its registers refilled with chunk RING
+      const int so = kb4 + 128 * min(RING, nchunk - 1);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          *reinterpret_cast<float4*>(dst + m * TILE + 4 * q * LSTR) = ra[0][m][q];
+          ra[0][m][q] = ldg(arsrc, aoff[m][q], so);
+        }
+        *reinterpret_cast<float4*>(dst + MB * TILE + 4 * q * LSTR) = rw[0][q];
+        rw[0][q] = ldg(wrsrc, woff[q], so);
+      }
+      LSTM_STAMP(1);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) fa[0][m][j] = *reinterpret_cast<const float4*>(at + m * TILE + 4 * j);
+        fw[0][j] = *reinterpret_cast<const float4*>(at + MB * TILE + 4 * j);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll 1
+    for (int cc = 0; cc + 2 < nchunk; cc += 2) {
+      comb(fa[0], fw[0], ra[1], rw[1], cc + 1, fa[1], fw[1]);
+      comb(fa[1], fw[1], ra[0], rw[0], cc + 2, fa[0], fw[0]);
+    }
+    comb(fa[0], fw[0], ra[1], rw[1], nchunk - 1, fa[1], fw[1]);
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fa[1][m][k >> 2], k & 3), comp(fw[1][k >> 2], k & 3), acc[m], 0, 0, 0);
+  } else if constexpr (PIPE) {
     static_assert(RING == 2 && NBUF == 1 && MB == 1, "the pipelined loop walks chunk pairs through one staging tile");
     float4 fa[2][8], fw[2][8];  // fragment sets: one feeds the MFMAs while the other is filled
     float* dst = base + soff;
@@ -1024,9 +1099,13 @@ extern "C" int blm_lstm_search_step_fwd(const float* xw8_t, const float* w8_hh, 
     static bool once3 = false;
     if (!once3) {
       BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 8, true, 4, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+      BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<2, 8, true, 4, true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
       once3 = true;
     }
-    hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 8, true, 4, false, false, 2>), dim3(H / 4, (B + 63) / 64), block, lds3, st, p);
+    if (nchunk >= 4 && lstm_pipe())
+      hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 8, true, 4, true, false, 2>), dim3(H / 4, (B + 63) / 64), block, lds3, st, p);
+    else
+      hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 8, true, 4, false, false, 2>), dim3(H / 4, (B + 63) / 64), block, lds3, st, p);
     BLM_HIP(hipGetLastError());
     return BLM_OK;
   }
