@@ -36,7 +36,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dens
 # forward FLOPs per token L(2d*3d + 4Td + 2d^2 + 4d*ff) + 2dV = 98.28 M, training = 3x
 STEP_FLOPS_PER_TOKEN = 3 * (NLAYERS * (2 * D_MODEL * 3 * D_MODEL + 4 * T * D_MODEL + 2 * D_MODEL * D_MODEL + 4 * D_MODEL * D_FF)
                             + 2 * D_MODEL * V)
-PMC_TRAFFIC_FILE = "r04_pmc_sampled_gemm_fwd.json"
+PMC_TRAFFIC_FILE = "r05_pmc_sampled_gemm_fwd.json"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (the opt-in split modes are priced against this one)
 
 
