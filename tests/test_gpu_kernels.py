@@ -397,6 +397,36 @@ def test_sample_weight_injected_and_philox(dev):
         assert float((W2.cpu() - ref2).abs().max()) < 1e-4
 
 
+def test_integration_md_ctypes_stub_runs_as_written(dev):
+    """INTEGRATION.md section 2 shows the binding a maintainer would add: that first code block is executed VERBATIM here (from the
+    repository root, as the snippet's relative library path assumes) and its `sample_weight` held to the numpy Philox oracle
+    and to the KL formula of BayesLinear.kl_divergence (model.py:1109-1125)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md"), encoding="utf-8").read()
+    sec = doc[doc.index("## 2. Binding the C ABI directly"):]
+    code = re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+    assert "def sample_weight(" in code and "blm_sample_weight" in code
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        exec(compile(code, "INTEGRATION.md:section2", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    g = torch.Generator().manual_seed(9)
+    mu, lg = torch.randn(24, 20, generator=g), torch.rand(24, 20, generator=g) - 2.0
+    kl = torch.zeros((), device=dev)
+    W = ns["sample_weight"](mu.to(dev), lg.to(dev), 77, 3, 9, kl_out=kl)
+    z = torch.from_numpy(P.normal(24 * 20, 77, P.STREAM_WEIGHT + 3, 9)).view_as(lg)
+    assert float((W.cpu() - (mu + torch.exp(lg) * z)).abs().max()) < 1e-4
+    assert abs(float(kl) - float(O.kl_mean_form(mu, lg))) < 1e-4 * abs(float(kl)) + 1e-6
+    # a bad call comes back as a status with a message, which is what the stub turns into its RuntimeError
+    rc = ns["lib"].blm_sample_weight(None, 1, 1, None, None, None, ns["C"].c_float(1.0), None)
+    assert rc != 0 and b"blm_sample_weight" in ns["lib"].blm_last_error()
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_bayes_linear_golden(dev, fused):
     """BayesLinear fwd/bwd/KL against the reference's own numbers (tests/golden/bayes_linear.npz)."""
