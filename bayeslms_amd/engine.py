@@ -160,6 +160,19 @@ class FlatBuffers:
         self.flat_grad.zero_()
 
 
+class _HostStagedReduce:
+    """Handle of one all-reduce on a host-staged transport (gloo with device gradients): the transport reduced a host copy;
+    wait() waits for it and writes the sums back on the communication stream with a blocking copy."""
+
+    def __init__(self, work, host, view, stream):
+        self.work, self.host, self.view, self.stream = work, host, view, stream
+
+    def wait(self):
+        self.work.wait()
+        with torch.cuda.stream(self.stream):
+            self.view.copy_(self.host)  # pageable source: returns when the bytes are on the device
+
+
 class GradReducer:
     """Bucketed asynchronous all-reduce of a flat gradient buffer.
 
@@ -213,6 +226,13 @@ class GradReducer:
         # never on inside a timed region
         self.measure_buckets = False
         self.bucket_events, self.bucket_marks = [], []
+        # BLM_DP_CHECK=1 (diagnosis, off by default): in front of every collective of the gradient exchange the ranks compare
+        # (sequence number, element count) through a small all-gather; a disagreement raises with every rank's pair instead of
+        # ending in a transport error (gloo) or a hang until the collective timeout (RCCL)
+        # collectives ordered on the device's streams (RCCL) or staged through the host with a copy back on the transport's own stream (gloo)
+        self.stream_ordered = not (dist.is_initialized() and dist.get_backend(group) != "nccl")
+        self.check = os.environ.get("BLM_DP_CHECK", "0") == "1"
+        self.seq = 0
         # buckets = contiguous runs of parameters, built from the END of the buffer (backward order).  Two refinements
         # for what is exposed at the end of backward:
         #  * a tensor of a bucket's size or more travels ALONE (the tied encoder / decoder weight, 67.6 MB at cfg3: with
@@ -299,7 +319,25 @@ class GradReducer:
         s, e, _ = self.buckets[b]
         self._all_reduce(self.flat.flat_grad[s:e])
 
-    def _all_reduce(self, view):
+    def _check_agreement(self, view, what):
+        self.seq += 1
+        if os.environ.get("BLM_DP_TRACE"):  # diagnosis: this rank's sequence of collectives, one line each, no synchronisation added
+            import threading
+            with open("%s.rank%d" % (os.environ["BLM_DP_TRACE"], dist.get_rank() if dist.is_initialized() else 0), "a") as f:
+                f.write("%d %s %d thread=%s\n" % (self.seq, what, view.numel(), threading.current_thread().name))
+        if not self.check or self.world <= 1 or self.collective is not None:
+            return
+        on_dev = self.cuda and dist.get_backend(self.group) == "nccl"
+        mine = torch.tensor([self.seq, view.numel()], dtype=torch.int64, device=view.device if on_dev else "cpu")
+        every = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(every, mine, group=self.group)
+        pairs = [tuple(int(x) for x in e.tolist()) for e in every]
+        if any(p != pairs[0] for p in pairs):
+            raise ops.BayesLMError("GradReducer (BLM_DP_CHECK): the ranks disagree on collective %s: (sequence number, elements) "
+                                   "per rank = %s" % (what, pairs))
+
+    def _all_reduce(self, view, what="bucket"):
+        self._check_agreement(view, what)
         self.reduced_elems += view.numel()
         if self.cuda:
             ev = torch.cuda.Event(enable_timing=self.measure_buckets)
@@ -313,6 +351,18 @@ class GradReducer:
                 self._narrowed = True
             if self.collective is not None:
                 self.collective(view, self.comm_stream)
+                return
+            if not self.stream_ordered:  # gloo on device tensors: staged through the host HERE (see LateRows.begin), same handles and order
+                with torch.cuda.stream(self.comm_stream):
+                    t0 = time.perf_counter()
+                    host = view.to("cpu")  # waits for the communication stream, which waits for `ev`
+                    h = _HostStagedReduce(dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group, async_op=True), host, view,
+                                          self.comm_stream)
+                if self.measure_buckets:
+                    h.wait()
+                    self.bucket_marks.append((view.numel() * view.element_size(), t0, time.perf_counter()))
+                else:
+                    self.handles.append(h)
                 return
             with torch.cuda.stream(self.comm_stream):
                 if self.measure_buckets:
@@ -377,7 +427,7 @@ class GradReducer:
         (``ready_before_bwd_end_ms``: how long before the last backward kernel the bucket's gradients were complete;
         ``done_after_bwd_end_ms`` > 0: that much of it was exposed).  Synchronises; clears the record."""
         out = []
-        if self.cuda:
+        if self.cuda and self.stream_ordered:
             torch.cuda.synchronize()
             end = getattr(self, "bwd_end_event", None)
             for nbytes, ready, e0, e1 in self.bucket_events:
@@ -456,7 +506,18 @@ class LateRows:
             ctx = contextlib.nullcontext()
         with ctx:
             mine = ids.reshape(-1).clamp(0, self.V - 1)
-            dist.all_gather_into_tensor(self.allids, mine, group=red.group)
+            red._check_agreement(mine, "all-gather of the step's token ids")
+            if self.cuda and not red.stream_ordered:
+                # a host-staged transport (gloo: the one-GPU rehearsals) is handed HOST tensors.  c10d's own staging of device
+                # tensors copies the result back on a stream of its own, and with 4 ranks sharing a GPU the numbering below read
+                # `allids` while that copy was still landing in 1 of ~30 steps -- the ranks then disagreed on U and the compact
+                # all-reduce died with a size mismatch (round 5: 4-8 of 16 `bench.py --gpus 4 --backend gloo` runs; 0 of 16 since).
+                # Neither wait() on an explicit work object nor a device-wide synchronisation behind it closed the window.
+                host = torch.empty(self.allids.numel(), dtype=torch.int64)
+                dist.all_gather_into_tensor(host, mine.cpu(), group=red.group)
+                self.allids.copy_(host)
+            else:  # RCCL: ordered on this stream by construction
+                dist.all_gather_into_tensor(self.allids, mine, group=red.group)
             self.mark.zero_()
             self.mark.index_fill_(0, self.allids, 1)
             torch.cumsum(self.mark, 0, out=self.csum)
@@ -482,7 +543,7 @@ class LateRows:
         return view, self.slots.view(ids.shape), self.U, self._done
 
     def _done(self):
-        self.red._all_reduce(self.buf[: self.U * self.D])
+        self.red._all_reduce(self.buf[: self.U * self.D], "compact embedding rows (U = %d)" % self.U)
 
     def apply(self):
         """After the exchange: flat gradient rows += compact rows."""

@@ -136,6 +136,22 @@ def self_launch(args):
     threads = [threading.Thread(target=pump_out, daemon=True), threading.Thread(target=pump_err, daemon=True)]
     for t in threads:
         t.start()
+
+    def pass_on(signum, _frame):  # a launcher that is told to stop (timeout(1), Ctrl-C, a scheduler) takes its ranks with it
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+        try:
+            proc.wait(timeout=10.0)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        os._exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, pass_on)
     limit = deadline_of(args)
     try:
         rc = proc.wait(timeout=(limit + 15.0) if limit > 0 else None)

@@ -264,3 +264,31 @@ def test_bench_gpus2_self_launch_rehearsal_on_one_device():
     for stage in ("rendezvous ok", "first all-reduce ok", "model built", "stand-alone all-reduce ok", "warm-up ok", "timed region ok",
                   "comm diagnostics ok", "line printed"):
         assert stage in r.stderr, stage
+
+
+def test_bench_four_ranks_on_one_device_agree_on_the_compact_rows():
+    """Round 5: `bench.py --gpus 4 --backend gloo` (4 ranks + launcher + torchrun agent share this box's GPU) used to die in 4-8 of
+    16 runs -- the ranks disagreed on U, the number of distinct token ids of the global batch, because c10d's own staging of device
+    tensors for gloo let engine.LateRows read the gathered ids while the copy back was still landing.  The rehearsal transport is
+    now handed host tensors (engine.LateRows.begin, engine._HostStagedReduce).  Two runs back to back: both finish, replicas
+    identical, U = the count computed here on the host from the same synthetic stream."""
+    import json
+    import subprocess
+    import sys
+    from bayeslms_amd.data import batchify, get_batch, synthetic_corpus
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    steps, warm, Bc, W, T, V = 3, 2, 16, 4, 128, 33000
+    full = batchify(synthetic_corpus(V, Bc * W * ((steps + warm) * T + 1) + 17, seed=1111), Bc * W)
+    # the last training step of the run is the first A/B leg's last step: the windows of the stream are re-used modulo steps + warm
+    want = {int(torch.unique(get_batch(full, i * T, T)[0]).numel()) for i in range(steps + warm)}
+    for _ in range(2):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(W), "--backend", "gloo", "--steps", str(steps),
+                            "--warmup", str(warm), "--batch", str(Bc), "--no-cpu-baseline", "--no-opt-in", "--no-extra", "--comm-ab-steps", "1",
+                            "--deadline-s", "240"], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        c = out["comm"]
+        assert out["n_gpus"] == 4 and c["world_seen"] == 4 and c["replicas_identical"] is True and c["late_rows_last_step"] in want, c

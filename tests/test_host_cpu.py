@@ -156,6 +156,42 @@ def _reducer_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _dp_check_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from bayeslms_amd import engine, BayesLMError
+    os.environ["BLM_DP_CHECK"] = "1"
+    os.environ["BLM_DP_TRACE"] = ret["trace"]
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 8))
+    red = engine.GradReducer(engine.FlatBuffers(net), bucket_bytes=1 << 20)
+    assert red.check
+    buf = torch.zeros(64)
+    red._all_reduce(buf[:16], "agreeing")          # same size everywhere: goes through
+    for h in red.handles:
+        h.wait()
+    red.handles = []
+    try:
+        red._all_reduce(buf[: 16 + 8 * rank], "compact embedding rows (U = %d)" % (2 + rank))   # what a disagreement on U looks like
+        ret[rank] = "no error"
+    except BayesLMError as e:
+        ret[rank] = str(e)
+    dist.destroy_process_group()
+
+
+def test_dp_check_names_the_collective_the_ranks_disagree_on():
+    """BLM_DP_CHECK=1: a collective whose element count differs between the ranks raises on EVERY rank with each rank's
+    (sequence number, elements) pair, before anything is handed to the transport."""
+    port = _free_port()
+    with mp.Manager() as mgr, tempfile.TemporaryDirectory() as d:
+        ret = mgr.dict()
+        ret["trace"] = os.path.join(d, "dp")
+        mp.spawn(_dp_check_worker, args=(2, port, ret), nprocs=2, join=True)
+        for r in (0, 1):
+            assert "disagree" in ret[r] and "[(2, 16), (2, 24)]" in ret[r] and "compact embedding rows" in ret[r], ret[r]
+            lines = open("%s.rank%d" % (ret["trace"], r)).read().splitlines()  # BLM_DP_TRACE: this rank's sequence of collectives
+            assert len(lines) == 2 and lines[0].startswith("1 agreeing 16 ") and lines[1].startswith("2 compact embedding rows (U = %d) %d " % (2 + r, 16 + 8 * r))
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_grad_reducer_gloo_world2(world):
     port = _free_port()
@@ -687,7 +723,7 @@ def test_every_environment_switch_is_documented_and_tested():
         if os.path.isfile(path) and path.endswith((".py", ".hip", ".h")):
             src = open(path, encoding="utf-8", errors="ignore").read()
             used |= set(re.findall(r'(?:getenv\(|environ\.get\(|environ\[|environ\.setdefault\()\s*["\'](BLM_[A-Z0-9_]+)', src))
-            used |= set(re.findall(r'\{"[a-z_]+", "(BLM_[A-Z0-9_]+)"', src))  # the option registry of csrc/capi.hip
+            used |= set(re.findall(r'\{"[a-z0-9_]+", "(BLM_[A-Z0-9_]+)"', src))  # the option registry of csrc/capi.hip
     doc = open(os.path.join(root, "INTEGRATION.md"), encoding="utf-8").read()
     table = doc[doc.index("## 4. Switches"):]
     listed = set(re.findall(r"^\| `(BLM_[A-Z0-9_]+)`|, `(BLM_[A-Z0-9_]+)` \(", table, re.M)) if False else set()
