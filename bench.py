@@ -197,6 +197,8 @@ def arm_deadline(args, rank, world):
         sys.stderr.flush()
         if rank == 0:
             print(error_line(world, "deadline: %.0f s (--deadline-s) passed on rank 0" % limit, stage), flush=True)
+        else:
+            time.sleep(2.0)  # rank 0's line first: the agent ends every rank as soon as one of them is gone
         os._exit(124)
     t = threading.Timer(limit, fire)
     t.daemon = True

@@ -367,7 +367,9 @@ def test_bench_multi_rank_run_cannot_hang_silently(hang, who_reports):
     out = json.loads(lines[0])
     assert out["value"] is None and out["metric"] == "train_tokens_per_sec" and out["n_gpus"] == 2 and out["error"]
     if who_reports == "rank":
-        assert out["last_stage"] == "stand-alone all-reduce ok" and "passed on rank 0" in out["error"]
+        # rank 0's own line (the other ranks leave two seconds after their timers fire); should the agent still be quicker, the
+        # launcher's line with every rank's last heartbeat says the same
+        assert out["last_stage"] in ("stand-alone all-reduce ok", {"rank 0": "stand-alone all-reduce ok", "rank 1": "stand-alone all-reduce ok"})
         assert "DEADLINE 4 s" in r.stderr
     elif who_reports == "launcher_rc":
         assert out["last_stage"] == {"rank 0": "warm-up ok (1 steps)", "rank 1": "warm-up ok (1 steps)"}
