@@ -54,6 +54,9 @@ def _build(family, dev, V):
         m = M.VTransformerModel(V, 64, 4, 128, 3, 0.2, True, 3)  # (its kl_divergence raises as the reference's crashes, model.py:2770-2779)
     elif family == "rnn_none":
         m = M.RNNModel("LSTM", V, 64, 64, 2, 0.2, True)
+    elif family == "cfg2_small":
+        m = M.BayesRNNModel("LSTM", V, 64, 64, 2, 0.2, True, 3)
+        kl = lambda mm: mm.rnn.kl_divergence()  # noqa: E731
     elif family == "rnn_gauss33":
         m = M.GaussRNNModel("LSTM", V, 64, 64, 2, 0.2, True, "33")
         kl = lambda mm: mm.rnn.rnn[0].gpnn.kl_divergence()  # noqa: E731
@@ -110,6 +113,31 @@ def test_every_family_is_bit_identical_run_to_run(family, det):
         l1, p1 = _train(family, dev, 150, 12, 8, 6, gp_sample=gp)
         l2, p2 = _train(family, dev, 150, 12, 8, 6, gp_sample=gp)
         assert l1 == l2 and torch.equal(p1, p2), (family, gp, float((p1 - p2).abs().max()))
+
+
+@pytest.mark.parametrize("T,B", [(36, 8), (72, 16)])
+def test_layer_wavefront_is_bit_identical_to_the_sequential_layers(T, B, det):
+    """A bitwise race check of the two- / three-stream layer wavefront (ops.lstm_stack2; ADVICE r4: at the default mode's 1e-6
+    atomics noise a missing stream wait cannot be told from summation order).  In deterministic mode every per-chunk product has
+    one K slice, so the wavefront FORCED on must reproduce the sequential layers bit for bit -- losses and every parameter
+    after 8 training steps of the 2 x 64 LSTM and of the Bayesian LSTM (dropout on, clip + SGD momentum).  T 36: three chunks on
+    two streams; T 72: nine chunks, the per-chunk GEMMs on their third stream."""
+    dev = torch.device("cuda:0")
+    out = {}
+    for family in ("rnn_none", "cfg2_small"):
+        for forced in (False, True):
+            det.set_lstm_wavefront(forced)
+            try:
+                calls = []
+                real = det.lstm_stack2
+                det.lstm_stack2 = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+                out[(family, forced)] = _train(family, dev, 150, T, B, 8) + (len(calls),)
+            finally:
+                det.lstm_stack2 = real
+                det.set_lstm_wavefront(None)
+        (l0, p0, n0), (l1, p1, n1) = out[(family, False)], out[(family, True)]
+        assert n0 == 0 and n1 == 8, (n0, n1)  # the sequential layers, then the wavefront in every step
+        assert l0 == l1 and torch.equal(p0, p1), (family, float((p0 - p1).abs().max()))
 
 
 def test_deterministic_mode_equals_the_default_mode_to_rounding(det):
