@@ -173,6 +173,27 @@ SIGNATURES = {
 }
 
 _lib = None
+ROCTX_RANGES = [0]  # ranges pushed so far (BLM_ROCTX=1)
+
+
+def _wrap_with_roctx(l):
+    """BLM_ROCTX=1: every C-ABI call of this binding runs inside a roctx range named after the entry point
+    (roctxRangePushA / roctxRangePop of libroctx64), so `rocprofv3 --marker-trace --kernel-trace` shows which call each kernel
+    dispatch belongs to.  Off by default: a range costs two more foreign calls per entry point."""
+    rx = C.CDLL("libroctx64.so")
+    rx.roctxRangePushA.argtypes, rx.roctxRangePushA.restype = [C.c_char_p], C.c_int
+    rx.roctxRangePop.argtypes, rx.roctxRangePop.restype = [], C.c_int
+    for name in SIGNATURES:
+        fn = getattr(l, name)
+
+        def ranged(*a, _fn=fn, _name=name.encode()):
+            rx.roctxRangePushA(_name)
+            ROCTX_RANGES[0] += 1
+            try:
+                return _fn(*a)
+            finally:
+                rx.roctxRangePop()
+        setattr(l, name, ranged)
 
 
 class BayesLMError(RuntimeError):
@@ -194,6 +215,8 @@ def lib():
             fn.argtypes = args
         if l.blm_abi_version() != ABI_VERSION:
             raise BayesLMError("libbayeslm_hip.so ABI %d != binding ABI %d" % (l.blm_abi_version(), ABI_VERSION))
+        if os.environ.get("BLM_ROCTX", "0") == "1":
+            _wrap_with_roctx(l)
         _lib = l
     return _lib
 

@@ -153,3 +153,23 @@ def test_no_kernel_uses_scratch_memory(built_lib):
     allowed = ("philox4x32_10_rolled",)  # none expected; keep the tuple for a documented exception
     bad = [b for b in bad if not any(a in b[0] for a in allowed)]
     assert not bad, bad
+
+
+def test_roctx_ranges_wrap_every_entry_point():
+    """BLM_ROCTX=1: the binding pushes / pops a roctx range (libroctx64) around every entry point; results and status codes pass
+    through unchanged (host-only calls here: no GPU)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes as C\n"
+            "from bayeslms_amd import _lib as L\n"
+            "lib = L.lib()\n"
+            "assert lib.blm_abi_version() == L.ABI_VERSION\n"
+            "a = L.GemmArgs(); a.abi_version = L.ABI_VERSION; a.op, a.M, a.N, a.K, a.lda, a.ldb, a.ldc = 0, 8192, 512, 4096, 4096, 4096, 512\n"
+            "p = L.GemmPlan()\n"
+            "assert lib.blm_gemm_plan_query(C.byref(a), C.byref(p)) == 0 and p.tile == 28\n"
+            "assert lib.blm_colsum(None, 1, None, 1, 1, 0, None) == L.ERR_INVALID and b'blm_colsum' in lib.blm_last_error()\n"
+            "print('RANGES', L.ROCTX_RANGES[0])\n")
+    env = dict(os.environ, BLM_ROCTX="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "RANGES 4" in r.stdout, (r.stdout, r.stderr[-2000:])
