@@ -178,9 +178,12 @@ ROCTX_RANGES = [0]  # ranges pushed so far (BLM_ROCTX=1)
 
 def _wrap_with_roctx(l):
     """BLM_ROCTX=1: every C-ABI call of this binding runs inside a roctx range named after the entry point
-    (roctxRangePushA / roctxRangePop of libroctx64), so `rocprofv3 --marker-trace --kernel-trace` shows which call each kernel
+    (roctxRangePushA / roctxRangePop of librocprofiler-sdk-roctx, else libroctx64), so `rocprofv3 --marker-trace --kernel-trace` shows which call each kernel
     dispatch belongs to.  Off by default: a range costs two more foreign calls per entry point."""
-    rx = C.CDLL("libroctx64.so")
+    try:  # rocprofv3 (rocprofiler-sdk) intercepts this one; the roctracer library is the fallback for older tools
+        rx = C.CDLL("librocprofiler-sdk-roctx.so")
+    except OSError:
+        rx = C.CDLL("libroctx64.so")
     rx.roctxRangePushA.argtypes, rx.roctxRangePushA.restype = [C.c_char_p], C.c_int
     rx.roctxRangePop.argtypes, rx.roctxRangePop.restype = [], C.c_int
     for name in SIGNATURES:
