@@ -859,7 +859,7 @@ extern "C" int blm_embed_bwd(const int64_t* ids, const float* dy, float* denc, i
   if (p > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "blm_embed_bwd: dropout needs rng");
   if ((long)T * B == 0) return BLM_OK;
   const long rows = (long)T * B;
-  if (blm::option(blm::OPT_DETERMINISTIC)) {  // one wave per vocabulary row, additions in position order
+  if (blm::option(blm::OPT_DETERMINISTIC) && vocab <= 0x7fffffffL) {  // one wave per vocabulary row, additions in position order (ids staged as 32-bit)
     long g = (vocab + 3) / 4;
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(embed_bwd_det_kernel, dim3((unsigned)g), dim3(TPB), 0, ST, ids, dy, denc, T, B, D, (long)vocab, scale,

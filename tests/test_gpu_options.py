@@ -142,12 +142,13 @@ def test_lstm_step_kernel_forms_agree(dev, option, opt, val, B, H):
         assert rel(a, b) < 5e-6
 
 
-@pytest.mark.parametrize("B,H", [(64, 256), (50, 512), (96, 256)])
+@pytest.mark.parametrize("B,H", [(64, 512), (50, 512), (96, 512), (64, 1024), (40, 1024)])
 def test_search_step_two_batch_tiles_per_workgroup_equals_one(dev, option, B, H):
     """"lstm_mb2" (default 1): at B > 32 the search cell's forward step multiplies its 32 weight rows against TWO batch tiles per
     workgroup (the stacked 8H x H weight streams once, half the workgroups); 0 = one tile per workgroup.  Same K order per wave and
-    the same fixed cross-wave reduction: h, c and the eight activations are bit-identical, incl. a ragged last tile (B = 50) and a
-    second row of workgroups (B = 96)."""
+    the same fixed cross-wave reduction: h, c and the eight activations are bit-identical, incl. a ragged last tile (B = 50, 40) and a
+    second row of workgroups (B = 96).  H = 512 takes the plain K loop of the two-tile form, H = 1024 its software-pipelined one
+    (H = 256 has one chunk per lane and keeps the one-tile kernel)."""
     from bayeslms_amd._lib import check, lib, ptr, stream
     g = torch.Generator().manual_seed(B + H)
     xw = torch.randn(B, 8 * H, generator=g).to(dev)
