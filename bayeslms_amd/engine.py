@@ -97,7 +97,7 @@ def allreduce_busbw(nbytes, reps=5, device=None, group=None):
     busbw = 2 (N-1)/N x bytes / time (the ring's per-link traffic, RCCL-tests' convention).  Collective: every rank calls."""
     world = dist.get_world_size(group)
     n = max(1, int(nbytes) // 4)
-    cuda = device is not None and torch.device(device).type == "cuda"
+    cuda = device is not None and torch.device(device).type == "cuda" and dist.get_backend(group) == "nccl"  # gloo: host tensors
     x = torch.zeros(n, dtype=torch.float32, device=device if cuda else "cpu")
     dist.all_reduce(x, group=group)
     if cuda:
@@ -109,7 +109,7 @@ def allreduce_busbw(nbytes, reps=5, device=None, group=None):
     if cuda:
         torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / reps
-    t = torch.tensor([el], dtype=torch.float64, device=device if (cuda and dist.get_backend(group) == "nccl") else "cpu")
+    t = torch.tensor([el], dtype=torch.float64, device=device if cuda else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     el = float(t.item())
     alg = n * 4 / el / 1e9

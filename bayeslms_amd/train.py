@@ -289,6 +289,8 @@ def main(argv=None, history=None):
             if batch % args.log_interval == 0 and batch > 0:
                 if world > 1:  # the mean over the GLOBAL batch, as the single-process log line prints it
                     total_loss = total_loss.detach().clone()
+                    if args.dist_backend != "nccl":
+                        total_loss = total_loss.cpu()  # a host-staged transport is handed host tensors (engine.LateRows.begin)
                     dist.all_reduce(total_loss)
                     total_loss = total_loss / world
                 cur = float(total_loss) / args.log_interval

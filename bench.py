@@ -1124,13 +1124,14 @@ def main():
     diag = None
     if world > 1:
         _eng.heartbeat("timed region ok (%d steps)" % args.steps, rank)
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        on_dev = args.backend == "nccl"  # a host-staged transport (gloo rehearsals) is handed host tensors (engine.LateRows.begin)
+        t = torch.tensor([elapsed], device=dev if on_dev else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # outside the timed region: are the replicas still in lock step?  Every rank applied the same all-reduced gradient with the
         # same clip + SGD arithmetic, so the parameter buffers must be bit-identical: two checksums per rank, gathered and compared
         fp = tr.flat.flat_param
-        mine = torch.stack([fp.double().sum(), fp.double().abs().sum()]).to(dev)
+        mine = torch.stack([fp.double().sum(), fp.double().abs().sum()]).to(dev if on_dev else "cpu")
         every = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         replicas_identical = all(bool(torch.equal(e, every[0])) for e in every)
