@@ -103,6 +103,45 @@ def build(name, dev):
         T, B = 35, 20
         m, kl = M.RNNModel("LSTM", V10, 1024, 1024, 2, 0.2, True).to(dev), None
         is_rnn, Vv, lr = True, V10, 1.0
+    elif name in ("search_lstm", "search_tlm"):
+        # the architecture-search windows of bench.search_leg (Architect.step on a validation window + the network step), one window per step()
+        import types
+        from bayeslms_amd import model_search_bayes as S, train_search_bayes as TS
+        from bayeslms_amd.architect import Architect
+        torch.manual_seed(11)
+        if name == "search_tlm":
+            Ts = 128
+            m = S.GaussTransModelSearch(V33, 512, 8, 4096, 6, 0.2, True).to(dev)
+            a = types.SimpleNamespace(model="Transformer", T_bayes_pos="FFN", uncertainty="none", L_bayes_pos=0)
+        else:
+            Ts = 35
+            m = S.BayesLSTMModelSearch("LSTM", V33, 1024, 1024, 2, 0.2, True).to(dev)
+            a = types.SimpleNamespace(model="LSTM", T_bayes_pos="none", uncertainty="none", L_bayes_pos=1)
+        TS.freeze_unused(a, m)
+        klf = TS.kl_selector(a)
+        arch = Architect(m, V33, types.SimpleNamespace(wdecay=5e-7, clip=1.0, arch_lr=3e-3, arch_wdecay=1e-3))
+        trs = engine.Trainer(m, lr=0.1, clip=1.0, kl_scale=Ts / 65536.0, weight_decay=TS.SGD_WEIGHT_DECAY)
+        d = torch.randint(0, V33, (Ts + 1, 64), device=dev)
+        x, y = d[:Ts], d[1:].reshape(-1)
+        sst = {"i": 0, "hidden": m.init_hidden(64) if name == "search_lstm" else None, "hv": m.init_hidden(64) if name == "search_lstm" else None}
+        _LAST_MODEL[0] = m
+
+        def sstep():
+            s_ = sst["i"]
+            sst["i"] += 1
+            m.train()
+            m.set_step(2 * s_ + 1)
+            arch.step(x, y, x, y, None, False, sst["hv"])
+            if name == "search_tlm":
+                for layer in m.transformerlayers:
+                    layer.gpnn.sample = True
+            else:
+                sst["hidden"] = M.repackage_hidden(sst["hidden"])
+            _, _, sst["hidden"] = trs.step(x, y, sst["hidden"], klf, philox_step=2 * s_)
+            if name == "search_tlm":
+                for layer in m.transformerlayers:
+                    layer.gpnn.sample = False
+        return sstep, Ts * 64
     else:
         raise SystemExit("unknown workload " + name)
     _LAST_MODEL[0] = m
