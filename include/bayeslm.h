@@ -249,6 +249,17 @@ int blm_linear_nll2(const float* x1, int64_t ldx1, const float* w1, int64_t ldw1
  *   "lstm_gemv"  (BLM_LSTM_GEMV,  1) one-wave-per-unit LSTM step kernel for B <= 4 (0: the matrix-core step kernel)
  *   "lstm_pipe"  (BLM_LSTM_PIPE,  1) software-pipelined K loop of the LSTM step kernels
  *   "lstm_tail"  (BLM_LSTM_TAIL,  0) 1: the general (K tail) form of the pipelined LSTM step kernels also for whole chunks
+ *   "lstm_mb2"   (BLM_LSTM_MB2,   1) the architecture-search cell's forward step (blm_lstm_search_step_fwd) takes two batch tiles per
+ *                                    workgroup at B > 32: the stacked 8H x H weight streams once, one round of workgroups (0: one tile)
+ * and one MODE, off by default:
+ *   "deterministic" (BLM_DETERMINISTIC, 0) 1: every reduction of the library in a fixed order -- blm_gemm / blm_linear_nll* plans are
+ *                                    legalised to ONE K slice (no float atomics into C; colsum_a then has one writer per element),
+ *                                    blm_colsum* / blm_gp_coef_grad use one row chunk, the KL sums of blm_sample_weight /
+ *                                    blm_variational_group_fwd / blm_kl_mean_fwd go through block partials added by one block (a
+ *                                    fixed array of the code object: these calls must then be issued on one stream at a time),
+ *                                    blm_embed_bwd runs one wave per vocabulary row in position order.  Same arithmetic, another
+ *                                    order of additions: results equal the default mode's to rounding and are bit-identical run to
+ *                                    run (tests/test_gpu_deterministic.py); 1.26-1.33 x the default step time.
  * No reference counterpart (the reference leaves kernel selection to the vendor libraries behind torch). */
 /* Diagnostic, no reference counterpart: a bare v_mfma_f32_32x32x2_f32 loop (two waves per SIMD on every CU, no memory traffic),
  * `iters` x 4 MFMAs per wave; *flops receives the work of the launch.  The caller times it (bench.py: "chip.bare_mfma_tflops") --
@@ -404,7 +415,10 @@ int blm_gp_coef_grad(const float* g, const float* z, float* dcoef, int M, int N,
 /* out[n] (+)= sum_m x[m,n]   (bias gradients). */
 int blm_colsum(const float* x, int64_t ld, float* out, int M, int N, int accumulate, void* stream);
 /* ... and the same sums into a second vector out2 (NULL: none) from the same pass: nn.LSTM's b_ih and b_hh receive the same
- * gradient (model.py:35 / _VF.lstm :812). */
+ * gradient (model.py:35 / _VF.lstm :812).  For callers that bind the ABI directly: the Python host of this repository takes the
+ * bias gradients out of the weight-gradient GEMM (blm_gemm_args.colsum_a) and adds them to both leaves with blm_init_multi, so
+ * nothing under bayeslms_amd/ calls this entry point (it is covered at kernel level, tests/test_gpu_kernels.py).  In
+ * deterministic mode (blm_set_option("deterministic", 1)) both column-sum entry points use one row chunk: one writer per sum. */
 int blm_colsum2(const float* x, int64_t ld, float* out, float* out2, int M, int N, int accumulate, void* stream);
 /* Up to 8 small vectors set by ONE launch: dst[i][0..n[i]) = (src[i] ? src[i][j] : 0) + (src2[i] ? src2[i][j] : 0); src / src2
  * may be NULL altogether.  dst, src, src2, n are HOST arrays (copied into the launch).  The set-up of a recurrent layer -- initial
