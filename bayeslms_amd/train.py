@@ -59,6 +59,10 @@ def build_parser():
                         'it): the GP coefficients / weights of --uncertainty Gaussian are re-sampled every training step')
     p.add_argument('--gemm-mode', type=str, default='f32', choices=['f32', 'bf16x6', 'bf16x3'],
                    help='new, optional: opt-in split-bf16 arithmetic of the GEMM family (DESIGN.md section 7); default fp32 MFMA')
+    p.add_argument('--deterministic', type=int, default=0,
+                   help='new, optional: 1 = every reduction of the engine in a fixed order (ops.set_deterministic / BLM_DETERMINISTIC=1): '
+                        'two runs from one seed give bit-identical losses and parameters, also under torchrun at the same world size; '
+                        'costs about a quarter of the step')
     p.add_argument('--dist-backend', type=str, default='nccl',
                    help='new, optional (under torchrun): torch.distributed backend; nccl = RCCL over xGMI, one GPU per rank; '
                         'gloo lets several ranks rehearse on one GPU')
@@ -233,6 +237,8 @@ def main(argv=None, history=None):
     from .model import repackage_hidden
     if args.gemm_mode != 'f32':
         ops.set_gemm_mode(args.gemm_mode)
+    if args.deterministic:
+        ops.set_deterministic(True)
 
     say('Configurations')
     for k, v in vars(args).items():

@@ -240,3 +240,32 @@ def test_two_rank_runs_are_bit_identical_to_each_other_and_equal_one_rank_to_rou
         os.environ.pop("BLM_DETERMINISTIC", None)
         ops.set_deterministic(False)
     assert float((p1 - pa).abs().max()) < 1e-4 * float(p1.abs().max())
+
+
+def test_train_cli_deterministic_flag_gives_bit_identical_checkpoints(tmp_path):
+    """`python -m bayeslms_amd.train --deterministic 1`, twice, on a reference trajectory's corpus WITH dropout (0.3, which the
+    recorded RNG-free run does not have): identical log values and a bit-identical best checkpoint."""
+    import numpy as np
+    from bayeslms_amd import ops, train as T
+    from test_train_traj_oracle import load_traj, write_corpus
+    z, args, init, _ = load_traj("lstm_bayes5")
+    d = str(tmp_path)
+    write_corpus(z, d)
+    prior = os.path.join(d, "prior")
+    os.makedirs(prior)
+    torch.save(init, os.path.join(prior, "model.pt"))
+    argv = [str(a) for a in z["argv"]]
+    argv[argv.index("--dropout") + 1] = "0.3"
+    argv[argv.index("--epochs") + 1] = "2"
+    runs = []
+    try:
+        for k in range(2):
+            save = os.path.join(d, "m%d.pt" % k)
+            hist = {}
+            T.main(argv + ["--data", d, "--save", save, "--prior_path", prior, "--cuda", "--deterministic", "1"], history=hist)
+            runs.append((hist, torch.load(save, map_location="cpu")))
+    finally:
+        ops.set_deterministic(False)
+    (h0, f0), (h1, f1) = runs
+    assert h0["interval_loss"] == h1["interval_loss"] and h0["valid_loss"] == h1["valid_loss"] and h0["test_loss"] == h1["test_loss"]
+    assert all(torch.equal(f0[k], f1[k]) for k in f0) and len(h0["interval_loss"]) > 0 and np.isfinite(h0["test_loss"])
