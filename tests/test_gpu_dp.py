@@ -108,6 +108,23 @@ def test_two_ranks_equal_one_rank_on_the_global_batch(family):
     assert err < 1e-4, err
 
 
+@pytest.mark.parametrize("family", ["tlm_ffn", "rnn_bayes3"])
+def test_four_ranks_equal_one_rank_on_the_global_batch(family):
+    """Two columns per rank: four ranks (sharing this box's GPU) reproduce the single-process run of the same global batch and
+    stay bit-identical among themselves (tools/dp4_probe.py walks all six families this way)."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        _spawn(1, ret, family)
+        _spawn(4, ret, family)
+        l1, p1 = ret[(1, 0)]
+        ps = [ret[(4, r)][1] for r in range(4)]
+        ls = [ret[(4, r)][0] for r in range(4)]
+    assert all(torch.equal(ps[0], p) for p in ps[1:])
+    for i, a in enumerate(l1):
+        assert abs(a - sum(l[i] for l in ls) / 4.0) < 2e-4 * abs(a)
+    assert float((p1 - ps[0]).abs().max() / p1.abs().max()) < 1e-4
+
+
 def _spawn(world, ret, family="tlm_ffn", T=12):
     port = _free_port()
     mp.spawn(_run, args=(world, port, ret, family, T), nprocs=world, join=True)
