@@ -66,6 +66,10 @@ def parse():
                          "+ 15 s from outside (it terminates the child process group) for ranks that cannot run their own timer")
     ap.add_argument("--dist-timeout-s", type=float, default=None,
                     help="N > 1: rendezvous / collective timeout handed to init_process_group (default 180, BLM_DIST_TIMEOUT_S)")
+    ap.add_argument("--dp-autotune", type=int, default=1,
+                    help="N > 1: 1 = after the warm-up, three steps each as configured / with the comm-window plans off / with the overlap off "
+                         "(barrier-bracketed, max over ranks: the same numbers on every rank); a setting that is more than 2 %% faster than "
+                         "the configured one is kept for the timed region and reported in comm.autotune; 0 = run as configured")
     ap.add_argument("--comm-ab-steps", type=int, default=5,
                     help="N > 1: steps of each A/B leg after the timed region (overlap off, comm-window plans off); 0 skips them")
     ap.add_argument("--rehearse-hang", type=str, default="",
@@ -267,7 +271,37 @@ def comm_diagnostics(red, step_fn, first, n_ab, dev, world):
     return rep
 
 
-def comm_block(args, engine, red, flat, rccl_env, busbw, diag, replicas_identical):
+def dp_autotune(red, step_fn, first, dev, world, n=3):
+    """The defaults of the gradient exchange (bucket overlap, the planner's comm window) were derived on ONE GPU against a stand-in of
+    RCCL's channel kernel.  Before the timed region the ranks time `n` real steps under each alternative -- same barrier + max-over-
+    ranks bracket as the timed region, so every rank sees the same three numbers and takes the same decision -- and keep whatever is
+    more than 2 % faster than the configured setting.  -> the record for comm.autotune."""
+    rec = {"steps_each": n, "ms": {}, "picked": "as_configured"}
+    rec["ms"]["as_configured"] = _timed_steps(step_fn, n, first, dev, world)
+    first += n
+    alts = []
+    if red.comm_plan != "off":
+        alts.append(("comm_plan_off", "comm_plan", "off"))
+    if red.overlap:
+        alts.append(("overlap_off", "overlap", False))
+    for name, attr, val in alts:
+        keep = getattr(red, attr)
+        setattr(red, attr, val)
+        try:
+            rec["ms"][name] = _timed_steps(step_fn, n, first, dev, world)
+        finally:
+            setattr(red, attr, keep)
+        first += n
+    best = min(rec["ms"], key=rec["ms"].get)
+    if best != "as_configured" and rec["ms"][best] < 0.98 * rec["ms"]["as_configured"]:
+        rec["picked"] = best
+        for name, attr, val in alts:
+            if name == best:
+                setattr(red, attr, val)
+    return rec
+
+
+def comm_block(args, engine, red, flat, rccl_env, busbw, diag, replicas_identical, autotune=None):
     """The `comm` object of a multi-rank line (rank 0 assembles it; the collective parts were measured on every rank)."""
     return {
         "backend": args.backend, "world_seen": dist.get_world_size(), "rccl_version": engine.rccl_version() if args.backend == "nccl" else None,
@@ -284,6 +318,8 @@ def comm_block(args, engine, red, flat, rccl_env, busbw, diag, replicas_identica
         # RCCL channel count as pinned before init_process_group (engine.pin_rccl_channels) and the CUs the GEMM
         # planner leaves to the channel workgroups while buckets are in flight
         "rccl_env": rccl_env, "gemm_cus_under_comm": 256 - red.comm_cus, "comm_plan": red.comm_plan,
+        # what the timed region ran with: the configured setting, or an alternative that was > 2 % faster in the calibration steps
+        "overlap_in_timed_region": bool(red.overlap), "autotune": autotune,
         # parameter checksums of all ranks after the last step, gathered and compared (outside the timed region)
         "replicas_identical": replicas_identical,
         "late_rows": red.late is not None,
@@ -352,6 +388,7 @@ def rehearse_launch(args, world, rank):
     for i in range(args.warmup):
         tr.step(i)
     engine.heartbeat("warm-up ok (%d steps)" % args.warmup, rank)
+    autotune = dp_autotune(tr.reducer, tr.step, args.warmup, None, world) if args.dp_autotune else None
     _maybe_hang(args, rank, "timed")
     ms = _timed_steps(tr.step, args.steps, args.warmup, None, world)
     engine.heartbeat("timed region ok (%d steps)" % args.steps, rank)
@@ -366,7 +403,7 @@ def rehearse_launch(args, world, rank):
         args.backend = backend
         print(json.dumps({"metric": "train_tokens_per_sec", "value": None, "unit": "tokens/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-                          "comm": comm_block(args, engine, tr.reducer, tr.flat, None, busbw, diag, identical),
+                          "comm": comm_block(args, engine, tr.reducer, tr.flat, None, busbw, diag, identical, autotune),
                           "rehearsal": "launch plumbing only, no GPU work: NOT a measurement"}), flush=True)
         engine.heartbeat("line printed", rank)
     dist.barrier()
@@ -1104,8 +1141,12 @@ def main():
     for i in range(args.warmup):
         loss = one(i, timer_all if i >= args.warmup - side_tags else None)
     torch.cuda.synchronize()
+    autotune = None
     if world > 1:
         _eng.heartbeat("warm-up ok (%d steps)" % args.warmup, rank)
+        if args.dp_autotune:
+            autotune = dp_autotune(tr.reducer, lambda i: one(i % steps_total, None), 0, dev, world)
+            _eng.heartbeat("autotune ok (%s: %s)" % (autotune["picked"], autotune["ms"]), rank)
         dist.barrier()
     torch.cuda.synchronize()
     tr.reducer.measure = world > 1  # event pair per step: last backward kernel -> end of the gradient exchange
@@ -1223,7 +1264,7 @@ def main():
             # rank 0, per step: time the compute stream waited between its last backward kernel and the end of the
             # gradient exchange (bucketed all-reduce + the compact embedding-row exchange); null at N = 1
             "comm_exposed_ms": None if comm_exposed is None else round(comm_exposed, 4),
-            "comm": None if world == 1 else comm_block(args, engine, tr.reducer, tr.flat, rccl_env, busbw, diag, replicas_identical),
+            "comm": None if world == 1 else comm_block(args, engine, tr.reducer, tr.flat, rccl_env, busbw, diag, replicas_identical, autotune),
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -277,7 +277,8 @@ def test_bench_gpus2_self_launch_rehearsal_on_one_device():
     c = out["comm"]  # the line explains its own scaling
     assert c["world_seen"] == 2 and c["allreduce_busbw_gbps"] > 0 and c["dist_timeout_s"] == 180.0
     assert len(c["buckets_last_step"]) >= c["buckets"] and all(b["ms"] > 0 for b in c["buckets_last_step"])
-    assert c["ab_steps"] == 5 and c["step_ms_as_configured"] > 0 and c["step_ms_no_overlap"] > 0 and "step_ms_no_comm_window" in c
+    assert c["ab_steps"] == 5 and c["step_ms_as_configured"] > 0 and "step_ms_no_overlap" in c and "step_ms_no_comm_window" in c
+    assert c["autotune"]["picked"] in c["autotune"]["ms"] and c["overlap_in_timed_region"] == (c["autotune"]["picked"] != "overlap_off")
     for stage in ("rendezvous ok", "first all-reduce ok", "model built", "stand-alone all-reduce ok", "warm-up ok", "timed region ok",
                   "comm diagnostics ok", "line printed"):
         assert stage in r.stderr, stage

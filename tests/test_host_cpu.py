@@ -319,7 +319,7 @@ def test_bench_self_launches_its_ranks_from_one_process():
     VERDICT r4 #1: the rehearsal walks every stage of the real multi-rank run (bounded rendezvous, heartbeats, stand-alone
     all-reduce, timed region, replica check, per-bucket brackets, A/B legs) and fills every field of the `comm` block."""
     import json
-    r, _ = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--rehearse-launch"])
+    r, _ = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--rehearse-launch", "--dp-autotune", "0"])
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -344,6 +344,17 @@ def test_bench_self_launches_its_ranks_from_one_process():
                    "--comm-ab-steps", "2", "--dist-timeout-s", "60"])
     c = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["comm"]
     assert c["step_ms_no_overlap"] is None and c["ab_steps"] == 2 and c["dist_timeout_s"] == 60.0 and c["overlap"] is False
+    # the calibration in front of the timed region (default on): the configured setting and its alternatives timed on every rank with
+    # the same max-over-ranks numbers; what was picked is what the timed region ran with
+    a = c["autotune"]
+    assert a["steps_each"] == 3 and set(a["ms"]) == {"as_configured"} and a["picked"] == "as_configured"  # overlap already off, no comm window on the host
+    assert c["overlap_in_timed_region"] is False
+    r, _ = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "1", "--rehearse-launch", "--comm-ab-steps", "0"])
+    c = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["comm"]
+    a = c["autotune"]
+    assert set(a["ms"]) == {"as_configured", "overlap_off"} and a["picked"] in a["ms"]
+    assert c["overlap_in_timed_region"] == (a["picked"] != "overlap_off")
+    assert a["picked"] == "as_configured" or a["ms"][a["picked"]] < 0.98 * a["ms"]["as_configured"]
     # a WORLD_SIZE / --gpus mismatch is an error, not a silently different run
     r, _ = _bench(["--gpus", "2"], {"WORLD_SIZE": "3"})
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
