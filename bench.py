@@ -986,7 +986,7 @@ def opt_in_modes(model, tr, train, get_batch, steps_total, args, ops, engine):
             ops.set_gemm_mode(mode)
             loss_m = eval_loss()
             timer = ops.KernelTimer()
-            for i in range(args.warmup):
+            for i in range(max(args.warmup, 10)):  # the first steps in a new mode load its code objects and settle the clocks (354-500 k seen with 5)
                 ops.set_kernel_timer(None)
                 d, t = get_batch(train, (i % steps_total) * T, T)
                 tr.step(d, t, kl_fn=_kl_fn)
