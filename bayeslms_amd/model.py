@@ -14,6 +14,7 @@ tensors and all dropout masks come from a counter-based Philox stream keyed by
 data-parallel ranks regenerate them with no storage.  Tensors must live on the
 GPU; there is no CPU path.
 """
+import copy
 import math
 
 import numpy as np
@@ -322,8 +323,15 @@ class BayesTransformerEncoderLayer(_PostLNLayer):
 class _LMHead(_Site):
     """Shared embedding / decoder plumbing of the language models."""
 
-    def _init_io(self, ntoken, ninp, nout, tie_weights):
+    def _make_encoder(self, ntoken, ninp):
         self.encoder = nn.Embedding(ntoken, ninp)
+
+    def _init_io(self, ntoken, ninp, nout, tie_weights):
+        """Embedding (unless the caller made it already: the RNN models create it BEFORE the recurrent module, the
+        Transformers after the layers -- the reference's orders, which fix both the state_dict key order and the order of
+        the RNG draws), vocabulary projection, then ``init_weights``."""
+        if not hasattr(self, "encoder"):
+            self._make_encoder(ntoken, ninp)
         self.decoder = _ProjHolder(nout, ntoken)
         self.decoder.is_decoder = True
         if tie_weights:
@@ -433,6 +441,14 @@ class GPNN(_Site):
         if gpnn_type in (2, 3):
             self.weights_lgstd = nn.Parameter(torch.empty(output_size, input_size).uniform_(lo, hi))
             self.bias_lgstd = nn.Parameter(torch.empty(output_size).uniform_(lo, hi))
+        # the reference constructor ends with sample_parameters() (model.py:1812, :1853-1861): N(0,1) draws nobody
+        # reads before the next one replaces them, but they advance torch's generator, so every module built after
+        # this one is initialised from a different point of the stream -- made here too, and dropped
+        if gpnn_type in (1, 3):
+            torch.zeros(len(act_set), output_size).normal_()
+        if gpnn_type in (2, 3):
+            torch.zeros(output_size, input_size).normal_()
+            torch.zeros(output_size).normal_()
 
     _SLOT = {"tanh": 0, "sigmoid": 1, "relu": 2, "gelu": 3}
 
@@ -507,9 +523,12 @@ class GPNN2(_Site):
         if bad:
             raise BayesLMError("GPNN2 activations %s are not built by this engine" % sorted(bad))
         stdv = 1.0 / math.sqrt(n_MC_terms)
-        self.frequency_mean = nn.Parameter(torch.empty(input_dim, n_MC_terms).uniform_(-stdv, stdv))
-        self.frequency_lgstd = nn.Parameter(torch.empty(input_dim, n_MC_terms).uniform_(2 * np.log(stdv), np.log(stdv)))
-        self.coef = _ProjHolder(n_MC_terms, output_dim)
+        self.frequency_mean = nn.Parameter(torch.empty(input_dim, n_MC_terms))
+        self.frequency_lgstd = nn.Parameter(torch.empty(input_dim, n_MC_terms))
+        self.coef = _ProjHolder(n_MC_terms, output_dim)  # drawn BEFORE the frequencies (model.py:2053-2059)
+        with torch.no_grad():
+            self.frequency_mean.uniform_(-stdv, stdv)
+            self.frequency_lgstd.uniform_(2 * np.log(stdv), np.log(stdv))
         self.eps_override = None  # (input_dim, n_MC_terms), the reference's layout
         self.frequency_mean_prior = self.frequency_lgstd_prior = None
 
@@ -727,7 +746,10 @@ class _TorchEncoderLayer(_PostLNLayer):
 class _TorchEncoder(nn.Module):
     def __init__(self, d_model, nhead, dim_feedforward, dropout, nlayers):
         super().__init__()
-        self.layers = nn.ModuleList(_TorchEncoderLayer(d_model, nhead, dim_feedforward, dropout) for _ in range(nlayers))
+        # nn.TransformerEncoder clones ONE constructed layer (reference model.py:134-136): every layer starts from layer
+        # 0's draw, and the generator advances by one layer only
+        first = _TorchEncoderLayer(d_model, nhead, dim_feedforward, dropout)
+        self.layers = nn.ModuleList([first] + [copy.deepcopy(first) for _ in range(nlayers - 1)] if nlayers > 0 else [])
 
 
 class TransformerModel(_LMHead):
@@ -774,22 +796,25 @@ class Bayes2LSTM(_Site):
         self.bias, self.dropout, self.position = bias, float(dropout), position
         G, H = 4 * hidden_size, hidden_size
         s = 1.0 / math.sqrt(H)
+        # Registration AND draw order follow the reference constructor (model.py:598-636 creates, :642-665 resets), so that
+        # the same torch seed gives the same initial state_dict: the lgstd tensors are born from torch.rand (draws that
+        # positions 1-4 then overwrite), the means are uniform in the order ih, hh, bias_hh, bias_ih.
         for layer in (1, 2):
-            self.register_parameter("weight_ih_mean_%d" % layer, nn.Parameter(torch.empty(G, input_size).uniform_(-s, s)))
-            self.register_parameter("weight_hh_mean_%d" % layer, nn.Parameter(torch.empty(G, H).uniform_(-s, s)))
-            self.register_parameter("bias_ih_mean_%d" % layer, nn.Parameter(torch.empty(G).uniform_(-s, s)))
-            self.register_parameter("bias_hh_mean_%d" % layer, nn.Parameter(torch.empty(G).uniform_(-s, s)))
+            for name, shape in (("weight_ih", (G, input_size)), ("weight_hh", (G, H)), ("bias_ih", (G,)), ("bias_hh", (G,))):
+                self.register_parameter("%s_mean_%d" % (name, layer), nn.Parameter(torch.empty(*shape)))
         if 1 <= position <= 5:
             R = H if position <= 4 else G
-            lo, hi = (2 * math.log(s), math.log(s))
             for layer in (1, 2):
-                def mk(*shape):
-                    t = torch.empty(*shape)
-                    return nn.Parameter(t.uniform_(lo, hi) if position <= 4 else t.uniform_(0, 1))  # model.py:625-633
-                self.register_parameter("weight_hh_lgstd_%d" % layer, mk(R, H))
-                self.register_parameter("weight_ih_lgstd_%d" % layer, mk(R, input_size))
-                self.register_parameter("bias_hh_lgstd_%d" % layer, mk(R))
-                self.register_parameter("bias_ih_lgstd_%d" % layer, mk(R))
+                for name, shape in (("weight_hh", (R, H)), ("weight_ih", (R, input_size)), ("bias_hh", (R,)), ("bias_ih", (R,))):
+                    self.register_parameter("%s_lgstd_%d" % (name, layer), nn.Parameter(torch.rand(*shape)))
+        with torch.no_grad():
+            for layer in (1, 2):
+                for name in ("weight_ih", "weight_hh", "bias_hh", "bias_ih"):
+                    getattr(self, "%s_mean_%d" % (name, layer)).uniform_(-s, s)
+            if 1 <= position <= 4:  # position 5 keeps its torch.rand values (model.py:625-633, never reset)
+                for layer in (1, 2):
+                    for name in self._ORDER:
+                        getattr(self, "%s_lgstd_%d" % (name, layer)).uniform_(2 * math.log(s), math.log(s))
         self.eps_override = None  # list of 8 tensors in the reference's draw order (model.py:668-703)
         self._kl_cache = None     # (KL of the last training forward, noise step, parameter versions): see _weights
 
@@ -898,6 +923,7 @@ class BayesRNNModel(_RNNLM):
         if tie_weights and nhid != ninp:
             raise ValueError("When using the tied flag, nhid must be equal to emsize.")
         self.rnn_type, self.nhid, self.nlayers, self.p = rnn_type, nhid, nlayers, dropout
+        self._make_encoder(ntoken, ninp)
         self.rnn = Bayes2LSTM(ninp, nhid, nlayers, position=bayes_pos, dropout=dropout)
         self._init_io(ntoken, ninp, nhid, tie_weights)
         self.noise_state = bind_state(self, NoiseState())
@@ -951,6 +977,7 @@ class RNNModel(_RNNLM):
         if tie_weights and nhid != ninp:
             raise ValueError("When using the tied flag, nhid must be equal to emsize.")
         self.rnn_type, self.nhid, self.nlayers, self.p = rnn_type, nhid, nlayers, dropout
+        self._make_encoder(ntoken, ninp)
         self.rnn = _LSTMParams(ninp, nhid, nlayers, dropout)
         self._init_io(ntoken, ninp, nhid, tie_weights)
         self.noise_state = bind_state(self, NoiseState())
@@ -1171,6 +1198,7 @@ class GaussRNNModel(_RNNLM):
         if tie_weights and nhid != ninp:
             raise ValueError("When using the tied flag, nhid must be equal to emsize.")
         self.rnn_type, self.nhid, self.nlayers, self.p = rnn_type, nhid, nlayers, dropout
+        self._make_encoder(ntoken, ninp)
         self.rnn = GPLSTM(ninp, nhid, nlayers, dropout=dropout, gpnn_type=gauss_pos)
         self._init_io(ntoken, ninp, nhid, tie_weights)
         self.noise_state = bind_state(self, NoiseState())
@@ -1266,6 +1294,7 @@ class VariationalRNNModel(_RNNLM):
         if tie_weights and nhid != ninp:
             raise ValueError("When using the tied flag, nhid must be equal to emsize.")
         self.rnn_type, self.nhid, self.nlayers, self.p = rnn_type, nhid, nlayers, dropout
+        self._make_encoder(ntoken, ninp)
         self.rnn = VariationalLSTM(ninp, nhid, nlayers, dropout=dropout, vlstm_type=v_pos)
         self._init_io(ntoken, ninp, nhid, tie_weights)
         self.noise_state = bind_state(self, NoiseState())

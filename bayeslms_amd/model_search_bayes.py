@@ -224,6 +224,7 @@ class GaussTransModelSearch(_ArchMixin, GaussTransModel):
         raise AttributeError("'BayesTransModel' object has no attribute 'arch_parameters'")
 
     def _initialize_arch_parameters(self):
+        torch.randn(self.nlayers, 1, 2)  # drawn and then replaced by zeros in the reference (:323-324): same generator state after
         self.set_arch(torch.zeros(self.nlayers, 1, 2))
 
     def _attach(self):
@@ -244,6 +245,7 @@ class BayesTransModelSearch(_ArchMixin, BayesTransModel):
         raise AttributeError("'BayesTransModel' object has no attribute 'arch_parameters'")  # :161-165
 
     def _initialize_arch_parameters(self):
+        torch.randn(self.nlayers, 1, 2)  # drawn and then replaced by zeros in the reference (:168-170): same generator state after
         self.set_arch(torch.zeros(self.nlayers, 1, 2))
 
     def _attach(self):
@@ -268,6 +270,10 @@ class Bayes(_Site):
         self.sample = False
         self.weights_lgstd = nn.Parameter(torch.empty(output_size, input_size).uniform_(lo, hi))
         self.bias_lgstd = nn.Parameter(torch.empty(output_size).uniform_(lo, hi))
+        # the reference constructor ends with sample_parameters() (:813, :832-835): two N(0,1) draws that are replaced
+        # before anything reads them, made here too so that torch's generator leaves this constructor where theirs does
+        torch.zeros(output_size, input_size).normal_()
+        torch.zeros(output_size).normal_()
         self.eps_override = None
 
     def kl_divergence(self):
@@ -364,6 +370,7 @@ class BayesLSTMModel(_RNNLM):
         if tie_weights and nhid != ninp:
             raise ValueError("When using the tied flag, nhid must be equal to emsize.")
         self.rnn_type, self.nhid, self.nlayers, self.p = rnn_type, nhid, nlayers, dropout
+        self._make_encoder(ntoken, ninp)
         self.rnn = BayesLSTMSearch(ninp, nhid, nlayers, dropout=dropout)
         self._init_io(ntoken, ninp, nhid, tie_weights)
         self.noise_state = bind_state(self, NoiseState())

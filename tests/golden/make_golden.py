@@ -988,8 +988,76 @@ def f9_search_loop():
 
 
 
+# ---------------------------------------------------------------- F10 initial state under a torch seed
+def init_state_cases():
+    """name -> (module, class, constructor arguments): every constructor train.py / train_search_bayes.py can reach
+    (train.py:186-221, train_search_bayes.py:158-163), tied and untied, every position / type string the parity
+    fixtures use."""
+    V = 50
+    cases = {}
+    for tied in (True, False):
+        cases["rnn_none_t%d" % tied] = ("model", "RNNModel", ["LSTM", V, 12, 12 if tied else 20, 2, 0.2, tied])
+        cases["tlm_none_t%d" % tied] = ("model", "TransformerModel", [V, 16, 4, 32, 3, 0.2, "gelu", tied])
+    for pos in range(6):
+        cases["rnn_bayes%d" % pos] = ("model", "BayesRNNModel", ["LSTM", V, 12, 12, 2, 0.2, True, pos])
+    cases["rnn_bayes2_untied"] = ("model", "BayesRNNModel", ["LSTM", V, 12, 12, 2, 0.2, False, 2])
+    for g in ("00", "13", "23", "33", "330", "3333", "6360", "34", "74", "53", "43", "63", "73", "14", "340", "3464", "54",
+              "64", "31", "32", "10", "20"):
+        cases["rnn_gauss%s" % g] = ("model", "GaussRNNModel", ["LSTM", V, 12, 12, 2, 0.2, True, g])
+    for v in ("00", "01", "10", "11"):
+        cases["rnn_var%s" % v] = ("model", "VariationalRNNModel", ["LSTM", V, 12, 12, 2, 0.2, True, v])
+    for b in ("none", "FFN", "MHA", "EMB"):
+        cases["tlm_bayes_%s" % b] = ("model", "BayesTransformerModel", [V, 16, 4, 32, 2, 0.2, True, b])
+    for g in range(5):
+        cases["tlm_gauss%d" % g] = ("model", "GaussTransformerModel", [V, 16, 4, 32, 3, 0.2, True, g])
+    for v in (0, 1, 2, 3, 11):
+        cases["tlm_var%d" % v] = ("model", "VTransformerModel", [V, 16, 4, 32, 4, 0.2, True, v])
+    cases["search_bayes_tlm"] = ("model_search_bayes", "BayesTransModelSearch", [V, 16, 4, 32, 3, 0.2, True])
+    cases["search_bayes_tlm_untied"] = ("model_search_bayes", "BayesTransModelSearch", [V, 16, 4, 32, 2, 0.2, False])
+    cases["search_gauss_tlm"] = ("model_search_bayes", "GaussTransModelSearch", [V, 16, 4, 32, 3, 0.2, True])
+    cases["search_bayes_lstm"] = ("model_search_bayes", "BayesLSTMModelSearch", ["LSTM", V, 12, 12, 2, 0.2, True])
+    cases["search_bayes_lstm_untied"] = ("model_search_bayes", "BayesLSTMModelSearch", ["LSTM", V, 12, 12, 2, 0.2, False])
+    return cases
+
+
+def tensor_digest(t):
+    """[shape, sha256 of the little-endian bytes, float64 sum] -- the bit-exact identity of one tensor in ~100 bytes
+    (the sum is there for the failure message: which way and how far a mismatching tensor is off)."""
+    import hashlib
+    a = np.ascontiguousarray(npy(t))
+    return [list(a.shape), hashlib.sha256(a.tobytes()).hexdigest(), float(a.astype(np.float64).sum())]
+
+
+def f10_init_state(seed=1111):
+    """The state_dict (keys in order, one digest per tensor) and the architecture logits every reference constructor
+    leaves behind under ``torch.manual_seed(seed)`` (train.py:122 seeds before it builds the model), plus the first
+    values torch's generator yields AFTER the constructor returned: a run that starts from the same seed then also
+    meets the same stream in whatever draws next.  Written as JSON: tests/golden/init_state.json."""
+    import json
+    S, _ = _load_search()
+    mods = {"model": ref, "model_search_bayes": S}
+    out = {"seed": seed, "torch": torch.__version__, "cases": {}}
+    for name, (mod, cls, args) in init_state_cases().items():
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = getattr(mods[mod], cls)(*args)
+        after = torch.rand(4, dtype=torch.float64).tolist()
+        entry = {"module": mod, "cls": cls, "args": args, "state": [[k] + tensor_digest(v) for k, v in m.state_dict().items()],
+                 "generator_after": after}
+        if hasattr(m, "arch_parameters"):
+            entry["arch"] = [tensor_digest(a) for a in m.arch_parameters()]
+        out["cases"][name] = entry
+    path = os.path.join(OUT, "init_state.json")
+    with open(path, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+        f.write("\n")
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "%d constructors" % len(out["cases"]))
+
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "init":
+        f10_init_state()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "rnnv":
         f5_gauss_variational_rnn()
         sys.exit(0)
