@@ -1051,7 +1051,9 @@ def cross_entropy(logits, targets, unit_grad=False):
     (its version counter is bumped, so another autograd use of the same tensor raises instead of reading gradients;
     read anything else you need from the logits BEFORE calling this).  ``unit_grad=True`` is the trainers' contract
     only: the loss enters the objective with coefficient exactly 1 (train.py:412) and the upstream gradient is not
-    looked at."""
+    looked at.  The mean is over ALL M rows (the trainers' targets are corpus words, train.py:299-304); a row whose target
+    is outside [0, V) contributes no loss and no gradient but still counts in M -- torch's ``ignore_index`` mean (over the
+    other rows only) is what ``F.cross_entropy`` on the models' `Logits` gives."""
     if type(logits) is not torch.Tensor:
         logits = logits.as_subclass(torch.Tensor)  # model outputs are `Logits` in grad mode (below); the op wants the plain tensor
     return _CrossEntropy.apply(logits, targets, unit_grad)
