@@ -128,3 +128,47 @@ def test_training_step_at_512_columns_equals_two_half_batches():
     assert set(gw) == set(g1) == set(g2)
     for k in gw:
         assert rel(g1[k] + g2[k], gw[k]) < 5e-4, k
+
+
+def test_longest_sequence_the_positional_table_allows():
+    """T = 5000 = PositionalEncoding's max_len (model.py:93-105): the longest input the reference's Transformers accept
+    (one more row and its ``x + self.pe[:x.size(0)]`` fails to broadcast, model.py:116).  Eval NLL and one training
+    loss + gradients (dropout 0, eps from the Philox stream) against the CPU oracle; T = 5001 raises here too."""
+    from oracle import bayes_oracle as O, philox as P
+    V, d, h, ff, nl, T, B = 60, 128, 2, 64, 2, 5000, 2
+    torch.manual_seed(1111)
+    m = M.BayesTransformerModel(V, d, h, ff, nl, 0.0, True, "FFN")
+    for mod in m.modules():  # layer 0 is built with a hard-coded dropout of 0.2 (model.py:1202)
+        if hasattr(mod, "p"):
+            mod.p = 0.0
+        if hasattr(mod, "dropout") and isinstance(mod.dropout, float):
+            mod.dropout = 0.0
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    gen = torch.Generator().manual_seed(5)
+    src = torch.randint(0, V, (T, B), generator=gen)
+    tgt = torch.randint(0, V, (T * B,), generator=gen)
+    torch.set_num_threads(16)
+    m.eval()
+    with torch.no_grad():
+        _, nll = ops.cross_entropy(m(src.to(DEV)).view(-1, V), tgt.to(DEV))
+        ref_nll = O.token_nll(O.transformer_lm(src, sd, h, None), tgt)
+    assert rel(nll.cpu(), ref_nll) < 1e-4
+    m.train()
+    m.set_seed(1111)
+    m.set_step(3)
+    lin2 = m.transformerlayers[0].linear2
+    loss, _ = ops.cross_entropy(m(src.to(DEV)).view(-1, V), tgt.to(DEV))
+    loss.backward()
+    eps = torch.from_numpy(P.normal(d * ff, 1111, P.STREAM_WEIGHT + lin2._site_base, 3)).view(d, ff)
+    leaf = {k: v.clone().requires_grad_(k.endswith(("weight_mean", "weight_lgstd", "qkv_net.weight"))) for k, v in sd.items()}
+    leaf["decoder.weight"] = leaf["encoder.weight"]
+    rl = O.cross_entropy_mean(O.transformer_lm(src, leaf, h, eps), tgt)
+    rl.backward()
+    assert abs(float(loss.detach()) - float(rl.detach())) < 1e-4 * abs(float(rl.detach()))
+    cur = dict(m.named_parameters())
+    for k in ("transformerlayers.0.linear2.weight_mean", "transformerlayers.0.linear2.weight_lgstd",
+              "transformerlayers.1.self_attn.qkv_net.weight"):
+        assert rel(cur[k].grad.cpu(), leaf[k].grad) < 1e-3, k  # attention over 5000 positions: BASELINE's bar
+    with pytest.raises(Exception):
+        m(torch.randint(0, V, (T + 1, 1), device=DEV))
