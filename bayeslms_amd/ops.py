@@ -969,6 +969,8 @@ def _dropout_apply(x, drop, row0=0, out=None):
     """``row0``: x is the block of rows [row0, row0 + rows) of a longer (T, B, D) tensor and gets THAT block's mask."""
     D = x.shape[-1]
     B = x.shape[-2] if x.dim() >= 2 else 1
+    if x.numel() == 0:
+        raise BayesLMError("dropout: empty tensor %s" % (tuple(x.shape),))
     rows = x.numel() // (B * D)
     y = torch.empty_like(x) if out is None else out
     L.require_gfx950()
@@ -1005,6 +1007,8 @@ class _CrossEntropy(torch.autograd.Function):
         M = logits.numel() // V
         if targets.numel() != M:
             raise BayesLMError("cross_entropy: %d targets for %d rows" % (targets.numel(), M))
+        if M == 0:
+            raise BayesLMError("cross_entropy: no rows (the mean over zero tokens is undefined; torch returns nan here)")
         nll = torch.empty(M, device=logits.device, dtype=torch.float32)
         loss = torch.zeros((), device=logits.device, dtype=torch.float32)
         grad_mode = ctx.needs_input_grad[0]  # forward itself runs with grad mode off

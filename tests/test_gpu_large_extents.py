@@ -172,3 +172,33 @@ def test_longest_sequence_the_positional_table_allows():
         assert rel(cur[k].grad.cpu(), leaf[k].grad) < 1e-3, k  # attention over 5000 positions: BASELINE's bar
     with pytest.raises(Exception):
         m(torch.randint(0, V, (T + 1, 1), device=DEV))
+
+
+def test_empty_inputs_end_in_empties_or_in_the_engines_own_error():
+    """The other end of the range.  The reference's flows never produce an empty batch (train.py:299-304 always cuts
+    at least one row, the scorer wraps every hypothesis in <s> ... </s>): products over zero rows return empties as
+    torch's do, everything else refuses with BayesLMError -- no launch with an empty grid, no arithmetic error."""
+    from bayeslms_amd._lib import BayesLMError
+    w, b = torch.randn(32, 16, device=DEV), torch.randn(32, device=DEV)
+    none = torch.empty(0, dtype=torch.long, device=DEV)
+    assert ops.linear(torch.empty(0, 16, device=DEV), w, b).shape == (0, 32)
+    assert ops.linear(torch.empty(0, 3, 16, device=DEV), w, b).shape == (0, 3, 32)
+    with torch.no_grad():
+        assert ops.linear_nll(torch.empty(0, 16, device=DEV), w, b, none).shape == (0,)
+    refused = {
+        "embed": lambda: ops.embed(torch.empty(0, 2, dtype=torch.long, device=DEV), torch.randn(10, 16, device=DEV)),
+        "cross_entropy": lambda: ops.cross_entropy(torch.empty(0, 32, device=DEV), none),
+        "attention": lambda: ops.attention(torch.empty(0, 2, 3 * 128, device=DEV), 2),
+        "dropout": lambda: ops.dropout(torch.empty(0, 16, device=DEV), ops.Drop(0.5, 1, 0, 0, 0, 1)),
+    }
+    tlm = M.BayesTransformerModel(50, 32, 2, 64, 2, 0.2, True, "FFN").to(DEV).eval()
+    rnn = M.RNNModel("LSTM", 50, 32, 32, 2, 0.2, True).to(DEV).eval()
+    for shape in ((0, 2), (3, 0)):
+        ids = torch.empty(*shape, dtype=torch.long, device=DEV)
+        refused["tlm %r" % (shape,)] = lambda ids=ids: tlm(ids)
+        refused["lstm %r" % (shape,)] = lambda ids=ids: rnn(ids, rnn.init_hidden(ids.shape[1]))
+    with torch.no_grad():
+        for name, fn in refused.items():
+            with pytest.raises(BayesLMError):
+                fn()
+    torch.cuda.synchronize()  # nothing was left behind on the stream
