@@ -72,9 +72,12 @@ def parse():
                          "the configured one is kept for the timed region and reported in comm.autotune; 0 = run as configured")
     ap.add_argument("--comm-ab-steps", type=int, default=5,
                     help="N > 1: steps of each A/B leg after the timed region (overlap off, comm-window plans off); 0 skips them")
+    ap.add_argument("--dp-extras-budget-s", type=float, default=120.0,
+                    help="N > 1: wall-clock budget of the extra legs after the headline (configs[4] data-parallel); when it (or the "
+                         "deadline) passes, rank 0 prints the headline line it already holds, marked, and every rank exits 0")
     ap.add_argument("--rehearse-hang", type=str, default="",
                     help="test knob of --rehearse-launch: RANK:STAGE[:gil] (RANK `*` = every rank) -- that rank stops for ever when it reaches STAGE "
-                         "(rendezvous | warmup | timed); `gil` holds the interpreter lock so that its own deadline timer cannot run")
+                         "(rendezvous | warmup | timed | extras); `gil` holds the interpreter lock so that its own deadline timer cannot run")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launch plumbing only (spawn, rendezvous, barrier, max-over-ranks, one JSON line from rank 0) "
                          "with NO GPU work: what the CPU-side test of `--gpus N` self-launch runs")
@@ -195,10 +198,21 @@ def arm_deadline(args, rank, world):
         return None
     from bayeslms_amd import engine
 
-    def fire():
+    def fire(why=None):
         stage = engine.last_stage()
-        sys.stderr.write("[blm rank %d] DEADLINE %.0f s: still after stage %r -- giving up\n" % (rank, limit, stage))
+        sys.stderr.write("[blm rank %d] DEADLINE %s: still after stage %r -- giving up\n" % (rank, why or ("%.0f s" % limit), stage))
         sys.stderr.flush()
+        if PENDING["headline_done"]:
+            # the headline was measured and assembled; what did not return is an EXTRA leg (configs[4]'s data-parallel legs):
+            # rank 0 prints the line it holds, marked, and every rank leaves with 0 -- an extra never costs the headline
+            if rank == 0 and PENDING["line"] is not None:
+                line = PENDING["line"]
+                line["extra_configs"] = {"error": "cut short by the deadline after stage %r" % stage}
+                line["baseline_configs"] = line.pop("baseline_configs", None)  # stays the last key
+                print(json.dumps(line), flush=True)
+            else:
+                time.sleep(2.0)
+            os._exit(0)
         if rank == 0:
             print(error_line(world, "deadline: %.0f s (--deadline-s) passed on rank 0" % limit, stage), flush=True)
         else:
@@ -207,7 +221,12 @@ def arm_deadline(args, rank, world):
     t = threading.Timer(limit, fire)
     t.daemon = True
     t.start()
+    PENDING["fire"] = fire
     return t
+
+
+# what the deadline prints when it falls into an extra leg of a multi-rank run (arm_deadline.fire, main)
+PENDING = {"headline_done": False, "line": None, "fire": None}
 
 
 def _timed_steps(step_fn, n, first, dev, world):
@@ -399,12 +418,24 @@ def rehearse_launch(args, world, rank):
     identical = all(bool(torch.equal(e, every[0])) for e in every)
     diag = comm_diagnostics(tr.reducer, tr.step, args.warmup + args.steps, args.comm_ab_steps, None, world)
     engine.heartbeat("comm diagnostics ok", rank)
+    out = None
     if rank == 0:
         args.backend = backend
-        print(json.dumps({"metric": "train_tokens_per_sec", "value": None, "unit": "tokens/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-                          "comm": comm_block(args, engine, tr.reducer, tr.flat, None, busbw, diag, identical, autotune),
-                          "rehearsal": "launch plumbing only, no GPU work: NOT a measurement"}), flush=True)
+        out = {"metric": "train_tokens_per_sec", "value": None, "unit": "tokens/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+               "comm": comm_block(args, engine, tr.reducer, tr.flat, None, busbw, diag, identical, autotune),
+               "rehearsal": "launch plumbing only, no GPU work: NOT a measurement", "baseline_configs": None}
+    if not args.no_extra:  # the protocol of the extra legs (main: configs[4]'s data-parallel legs) around a stand-in leg
+        def legs():
+            ms2 = _timed_steps(tr.step, 2, args.warmup, None, world)
+            return [{"id": "rehearsal_extra_leg", "ms_per_step": ms2}]
+        ex = run_dp_extras(args, engine, rank, world, out, legs)
+        if rank == 0:
+            out["extra_configs"] = ex
+    if rank == 0:
+        out["baseline_configs"] = out.pop("baseline_configs")  # stays the last key
+        PENDING["line"] = None
+        print(json.dumps(out), flush=True)
         engine.heartbeat("line printed", rank)
     dist.barrier()
     if timer is not None:
@@ -965,6 +996,128 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
     return res
 
 
+def run_dp_extras(args, engine, rank, world, out, legs):
+    """The extra legs of a multi-rank run (every rank calls `legs()`), arranged so that they can no longer cost the headline:
+    rank 0 holds the finished line (`out`), and a leg that does not return inside --dp-extras-budget-s (or the deadline) ends
+    in that line, marked `extra_configs.error`, with exit code 0 on every rank (arm_deadline.fire).  -> the legs' records."""
+    import copy
+    import threading
+    if rank == 0:
+        PENDING["line"] = compact_line(copy.deepcopy(out), legend=False) if "baseline_configs" not in out else copy.deepcopy(out)
+    PENDING["headline_done"] = True
+    engine.heartbeat("headline ok; extra legs", rank)
+    budget = (threading.Timer(args.dp_extras_budget_s, PENDING["fire"], args=("of the extra legs, %.0f s (--dp-extras-budget-s)" % args.dp_extras_budget_s,))
+              if PENDING["fire"] is not None else None)
+    if budget is not None:
+        budget.daemon = True
+        budget.start()
+    _maybe_hang(args, rank, "extras")
+    try:
+        ex = legs()
+    except Exception as e:  # noqa: BLE001
+        ex = {"error": repr(e)}
+    if budget is not None:
+        budget.cancel()
+    return ex
+
+
+def dp_extra_configs(dev, args, engine, M, ops, rank, world, main_reducer):
+    """BASELINE.json configs[4] on N GPUs -- "GP Transformer LM (--uncertainty Gaussian --T_gauss_pos 3) ..., 8xMI355X DP, n-best
+    rescoring inference path with 8 MC weight samples" -- as two legs every rank runs after the headline (same barrier +
+    max-over-ranks brackets; `value` = what all ranks processed / that time):
+      * cfg4_gp_tlm_train_dp: the GP Transformer's training step data-parallel, 64 columns per GPU, through the same
+        GradReducer / LateRows settings the headline's timed region ran with;
+      * cfg4_gp_tlm_rescore_mc8_dp: rank r rescores ITS OWN archive of 1000 utterances x 20-best with 8 Monte-Carlo weight
+        samples -- the product's placement (compute_sentence_scores --job: stage 6 starts nj independent jobs over archives.JOB,
+        lmrescore_nbest_pytorchnn_cuda.sh:199-203; replicas only, no collective on the data path).
+    A failure is recorded per leg; the legs end in the same collectives on every rank whether they failed or not."""
+    from collections import OrderedDict
+    from types import SimpleNamespace as ns
+    from bayeslms_amd import compute_sentence_scores as css
+    from bayeslms_amd import train as TR
+    from bayeslms_amd.data import batchify, get_batch, synthetic_corpus
+    on_dev = args.backend == "nccl"
+    res = []
+
+    def agree(ok, el):
+        """-> (every rank succeeded, the slowest rank's time): ONE collective, entered by every rank on every path."""
+        t = torch.tensor([0.0 if ok else 1.0, el], dtype=torch.float64, device=dev if on_dev else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0].item()) == 0.0, float(t[1].item())
+
+    # --- training leg
+    Bc, steps, warm = args.batch, args.steps, min(args.warmup, 3)
+    m = None
+    rec = {"id": "cfg4_gp_tlm_train_dp", "n_gpus": world,
+           "config": "BASELINE.json configs[4] training leg data-parallel over %d GPUs: GP Transformer LM (--uncertainty Gaussian "
+                     "--T_gauss_pos 3) 6L d_model=512 d_ff=4096 V=33000, seq_len 128, %d columns per GPU (global batch %d)"
+                     % (world, Bc, Bc * world)}
+    try:
+        stream = synthetic_corpus(V, Bc * world * ((steps + warm) * T + 1) + 17, seed=1111)
+        train = batchify(stream, Bc * world, dev, rank, world)
+        torch.manual_seed(1111)
+        m = M.GaussTransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, True, 3).to(dev)
+        tr = engine.Trainer(m, lr=LR, clip=CLIP, kl_scale=float(T) / float(train.size(0)), seed=1111, rank=rank, world=world,
+                            overlap=bool(main_reducer.overlap), late_rows=main_reducer.late is not None)
+        tr.reducer.comm_plan = main_reducer.comm_plan  # what the headline's calibration steps kept
+        kl = TR.kl_selector(ns(model="Transformer", uncertainty="Gaussian", T_bayes_pos="none", L_bayes_pos=0, T_gauss_pos=3,
+                               L_gauss_pos="00", L_v_pos="11", T_v_pos=0))
+        last = {}
+
+        def one(i):
+            data, targets = get_batch(train, i * T, T)
+            last["loss"] = tr.step(data, targets, kl_fn=kl)[0]
+        for i in range(warm):
+            one(i)
+        ms = _timed_steps(one, steps, warm, dev, world)  # barrier + synchronize on both sides, max over ranks
+        fp = tr.flat.flat_param
+        mine = torch.stack([fp.double().sum(), fp.double().abs().sum()]).to(dev if on_dev else "cpu")
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rec.update({"value": round(T * Bc * world / (ms * 1e-3), 1), "unit": "tokens/s", "ms_per_step": ms, "steps": steps, "warmup": warm,
+                    "final_loss": round(float(last["loss"]), 4),
+                    "replicas_identical": all(bool(torch.equal(e, every[0])) for e in every),
+                    "step_roofline": _frac(tlm_flops_per_token(T), T * Bc / (ms * 1e-3))})  # per GPU against one GPU's peak
+        engine.heartbeat("configs[4] training leg ok (%.3f ms per step)" % ms, rank)
+    except Exception as e:  # noqa: BLE001 -- recorded; a rank that is alone in failing ends in the extras' budget (main)
+        rec["error"] = repr(e)
+    res.append(rec)
+    # --- rescoring leg (the model of the training leg where there is one; scoring reads mean + exp(lgstd) eps per sample)
+    n_utt, n_hyp, mc = 1000, 20, 8
+    rec = {"id": "cfg4_gp_tlm_rescore_mc8_dp", "n_gpus": world,
+           "config": "BASELINE.json configs[4] inference leg on %d GPUs: every GPU rescores its own archive (%d utterances x %d-best, "
+                     "lengths 1 + Poisson(7) clipped to [1, 60]) with the GP Transformer and 8 Monte-Carlo weight samples "
+                     "(GPNN.sample raised for the call); independent jobs as in the recipe's stage 6, no collective on the data path"
+                     % (world, n_utt, n_hyp)}
+    ok, el, ntok = True, 0.0, 0
+    try:
+        if m is None:
+            torch.manual_seed(1111)
+            m = M.GaussTransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, True, 3).to(dev)
+        nbest, vocab, ntok = synthetic_nbest(n_utt, n_hyp, V, seed=7 + rank)
+        sub = OrderedDict(list(nbest.items())[:150])
+        css.compute_scores_batched(sub, m, vocab, "Transformer", dev, mc_samples=mc)  # warm-up: allocator, plans, full packed batches
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        css.compute_scores_batched(nbest, m, vocab, "Transformer", dev, mc_samples=mc)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        rec["error"] = repr(e)
+    all_ok, slowest = agree(ok, el)
+    if all_ok:
+        rec.update({"value": round(n_utt * n_hyp * world / slowest, 1), "unit": "hypotheses/s", "slowest_rank_s": round(slowest, 3),
+                    "tokens_per_s": round(ntok * world / slowest, 1),
+                    "step_roofline": _frac(tlm_flops_per_token(8, train=False) * mc, ntok / slowest)})
+        engine.heartbeat("configs[4] rescoring leg ok (%.2f s)" % slowest, rank)
+    elif "error" not in rec:
+        rec["error"] = "another rank failed in this leg"
+    res.append(rec)
+    return res
+
+
 def opt_in_modes(model, tr, train, get_batch, steps_total, args, ops, engine):
     """Separately reported, NOT part of `value`: the same step with the GEMM family's matrix instruction switched to
     the opt-in split-bf16 arithmetic (include/bayeslm.h blm_set_gemm_mode).  fp32 operands in HBM and LDS, fp32
@@ -1022,30 +1175,31 @@ def _kl_fn(mm):
 _kl_fn.fusable = True
 
 
-def compact_line(out):
+def compact_line(out, legend=True):
     """The driver keeps the last ~8 KB of stdout: the line stays short and ends with what must survive.  Every extra_configs
     entry keeps an `id` and its numbers; its description (`config`) and the notes go to stderr as `[bench legend] id: text`,
     once.  `baseline_configs` -- one object per BASELINE.json configuration, the numbers this run measured for it -- is the
     LAST key of the line."""
     ex = out.get("extra_configs")
     by_id = {}
+    err = sys.stderr if legend else open(os.devnull, "w")
     if isinstance(ex, list):
         for r in ex:
             rid = r.get("id", "?")
             by_id[rid] = r
             for k in ("config", "lstm_step_times_from", "lstm_layers", "note"):
                 if k in r:
-                    sys.stderr.write("[bench legend] %s.%s: %s\n" % (rid, k, r.pop(k)))
+                    err.write("[bench legend] %s.%s: %s\n" % (rid, k, r.pop(k)))
             cb = r.get("cpu_baseline")
             if isinstance(cb, dict) and "sample" in cb:
-                sys.stderr.write("[bench legend] %s.cpu_baseline.sample: %s\n" % (rid, cb.pop("sample")))
+                err.write("[bench legend] %s.cpu_baseline.sample: %s\n" % (rid, cb.pop("sample")))
     for mode in (out.get("opt_in") if isinstance(out.get("opt_in"), list) else []):
         if "note" in mode:
-            sys.stderr.write("[bench legend] opt_in.%s: %s\n" % (mode.get("gemm_mode"), mode.pop("note")))
+            err.write("[bench legend] opt_in.%s: %s\n" % (mode.get("gemm_mode"), mode.pop("note")))
     chip = out.get("chip")
     if isinstance(chip, dict) and "note" in chip:
-        sys.stderr.write("[bench legend] chip: %s\n" % chip.pop("note"))
-    sys.stderr.flush()
+        err.write("[bench legend] chip: %s\n" % chip.pop("note"))
+    err.flush()
 
     def pick(rid, *keys):
         r = by_id.get(rid)
@@ -1068,8 +1222,10 @@ def compact_line(out):
         "configs[1]": pick("cfg1_bayes_lstm_train"),
         "configs[2]": headline if n == 1 else None,
         "configs[3]": headline if n > 1 else None,  # the same model data-parallel: `--gpus N` runs (global batch 64 N)
-        "configs[4]": {"train_1gpu": pick("cfg4_gp_tlm_train"), "rescore_mean_weights": pick("cfg4_gp_tlm_rescore"),
-                       "rescore_8_mc_samples": pick("cfg4_gp_tlm_rescore_mc8")},
+        "configs[4]": ({"train_1gpu": pick("cfg4_gp_tlm_train"), "rescore_mean_weights": pick("cfg4_gp_tlm_rescore"),
+                        "rescore_8_mc_samples": pick("cfg4_gp_tlm_rescore_mc8")} if n == 1 else
+                       {"train_dp": pick("cfg4_gp_tlm_train_dp", "n_gpus", "replicas_identical"),
+                        "rescore_8_mc_samples_dp": pick("cfg4_gp_tlm_rescore_mc8_dp", "n_gpus")}),
     }
     return out
 
@@ -1290,7 +1446,14 @@ def main():
                 out["extra_configs"] = extra_configs(dev, args, engine, M, ops, out["ms_per_step"])
             except Exception as e:  # noqa: BLE001
                 out["extra_configs"] = {"error": repr(e)}
+    if world > 1 and not args.no_extra:  # configs[4]'s data-parallel legs, every rank
+        ex = run_dp_extras(args, _eng, rank, world, out if rank == 0 else None,
+                           lambda: dp_extra_configs(dev, args, engine, M, ops, rank, world, tr.reducer))
+        if rank == 0:
+            out["extra_configs"] = ex
+    if rank == 0:
         out = compact_line(out)
+        PENDING["line"] = None  # from here on the deadline has nothing left to print
         print(json.dumps(out), flush=True)
         if world > 1:
             _eng.heartbeat("line printed", rank)

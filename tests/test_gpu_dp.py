@@ -265,7 +265,7 @@ def test_bench_gpus2_self_launch_rehearsal_on_one_device():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
-                        "--warmup", "2", "--batch", "8", "--no-cpu-baseline", "--no-opt-in", "--no-extra"],
+                        "--warmup", "2", "--batch", "8", "--no-cpu-baseline", "--no-opt-in"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -280,8 +280,19 @@ def test_bench_gpus2_self_launch_rehearsal_on_one_device():
     assert c["ab_steps"] == 5 and c["step_ms_as_configured"] > 0 and "step_ms_no_overlap" in c and "step_ms_no_comm_window" in c
     assert c["autotune"]["picked"] in c["autotune"]["ms"] and c["overlap_in_timed_region"] == (c["autotune"]["picked"] != "overlap_off")
     for stage in ("rendezvous ok", "first all-reduce ok", "model built", "stand-alone all-reduce ok", "warm-up ok", "timed region ok",
-                  "comm diagnostics ok", "line printed"):
+                  "comm diagnostics ok", "headline ok; extra legs", "configs[4] training leg ok", "configs[4] rescoring leg ok", "line printed"):
         assert stage in r.stderr, stage
+    # BASELINE.json configs[4] on N GPUs (after the headline, every rank): the GP Transformer's training step data-parallel and
+    # every rank rescoring its own archive with 8 Monte-Carlo weight samples
+    ex = {e["id"]: e for e in out["extra_configs"]}
+    tr, sc = ex["cfg4_gp_tlm_train_dp"], ex["cfg4_gp_tlm_rescore_mc8_dp"]
+    assert "error" not in tr and tr["n_gpus"] == 2 and tr["value"] > 0 and tr["replicas_identical"] is True and tr["final_loss"] == tr["final_loss"]
+    assert abs(tr["value"] - 128 * 8 * 2 / (tr["ms_per_step"] * 1e-3)) < 1.0  # all ranks' tokens / the slowest rank's time
+    assert "error" not in sc and sc["unit"] == "hypotheses/s" and abs(sc["value"] - 2 * 1000 * 20 / sc["slowest_rank_s"]) < 0.05 * sc["value"]
+    assert list(out)[-1] == "baseline_configs"
+    b4 = out["baseline_configs"]["configs[4]"]
+    assert b4["train_dp"]["value"] == tr["value"] and b4["rescore_8_mc_samples_dp"]["value"] == sc["value"]
+    assert out["baseline_configs"]["configs[3]"]["value"] == out["value"] and out["baseline_configs"]["configs[2]"] is None
 
 
 def test_bench_four_ranks_on_one_device_agree_on_the_compact_rows():

@@ -390,6 +390,36 @@ def test_bench_multi_rank_run_cannot_hang_silently(hang, who_reports):
         assert 15.0 <= took
 
 
+@pytest.mark.parametrize("hang", ["", "1:extras", "*:extras"])
+def test_bench_extra_legs_of_a_multi_rank_run_cannot_cost_the_headline(hang):
+    """At N > 1 the line also carries configs[4]'s data-parallel legs, run by every rank AFTER the headline was measured and
+    assembled.  Rank 0 holds the finished line while they run: legs that return are added (`extra_configs`, and
+    `baseline_configs` stays the last key); a leg that does not return inside --dp-extras-budget-s ends in THAT line, marked, with
+    exit code 0 on every rank -- still exactly one JSON line, with the headline's fields and its `comm` block intact."""
+    import json
+    argv = ["--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--rehearse-launch", "--dp-autotune", "0",
+            "--comm-ab-steps", "0", "--dp-extras-budget-s", "4"]
+    r, took = _bench(argv + (["--rehearse-hang", hang] if hang else []), timeout=120)
+    assert r.returncode == 0 and took < 60.0, (r.returncode, took, r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ms_per_step"] > 0 and out["comm"]["replicas_identical"] is True
+    assert list(out)[-1] == "baseline_configs"
+    assert "headline ok; extra legs" in r.stderr
+    if not hang:
+        assert out["extra_configs"] == [{"id": "rehearsal_extra_leg", "ms_per_step": out["extra_configs"][0]["ms_per_step"]}]
+        assert "line printed" in r.stderr and "DEADLINE" not in r.stderr
+    else:
+        assert "cut short by the deadline after stage 'headline ok; extra legs'" in out["extra_configs"]["error"]
+        assert "DEADLINE" in r.stderr
+    # --no-extra: the legs are skipped altogether
+    if not hang:
+        r, _ = _bench(argv + ["--no-extra"])
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert r.returncode == 0 and "extra_configs" not in out and "headline ok; extra legs" not in r.stderr
+
+
 def test_init_distributed_is_bounded_and_checks_its_first_all_reduce(monkeypatch):
     """engine.init_distributed hands init_process_group a timeout (BLM_DIST_TIMEOUT_S / argument / 180 s) instead of torch's
     10-30 minutes: a rank whose peers never come raises inside it."""
