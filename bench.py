@@ -1200,6 +1200,8 @@ def compact_line(out, legend=True):
     if isinstance(chip, dict) and "note" in chip:
         err.write("[bench legend] chip: %s\n" % chip.pop("note"))
     err.flush()
+    if not legend:
+        err.close()
 
     def pick(rid, *keys):
         r = by_id.get(rid)
