@@ -81,10 +81,14 @@ def build_parser():
 
 
 def build_model(args, ntokens):
-    """Model dispatch of train.py:193-223."""
+    """Model dispatch of train.py:193-223.  With ``--uncertainty none`` the reference builds the model TWICE and trains the
+    second one (``model_2`` first, train.py:196-199 / :211-214): the first construction is repeated here and dropped, so that
+    the same ``--seed`` starts from the same weights (the constructors draw from torch's generator in the reference's order,
+    tests/test_init_state_cpu.py)."""
     from . import model as M
     if args.model == 'Transformer':
         if args.uncertainty == 'none':
+            M.TransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, args.dropout, "gelu", args.tied)  # model_2
             return M.TransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, args.dropout, "gelu", args.tied)
         if args.uncertainty == 'Bayesian':
             return M.BayesTransformerModel(ntokens, args.emsize, args.nhead, args.nhid, args.nlayers, args.dropout,
@@ -97,6 +101,7 @@ def build_model(args, ntokens):
                                        args.tied, args.T_v_pos)
     else:
         if args.uncertainty == 'none':
+            M.RNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, args.dropout, args.tied)  # model_2
             return M.RNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, args.dropout, args.tied)
         if args.uncertainty == 'Bayesian':
             return M.BayesRNNModel(args.model, ntokens, args.emsize, args.nhid, args.nlayers, args.dropout, args.tied,

@@ -512,8 +512,11 @@ np.savez(out, **kw)
 """
 
 
-def f6_train_trajectory():
-    """SURVEY 8(c) F6: RNG-free runs of the reference's own train.py (dropout 0, nothing sampled: --uncertainty none;
+def f6_train_trajectory(seed_only=False):
+    """``seed_only``: NO saved initial state -- train.py is started with ``--seed 1111`` alone, so the run begins from whatever
+    its own constructors draw under that seed (incl. the second construction of ``--uncertainty none``, train.py:196-199, and the
+    discarded ``sample_parameters()`` draws of the GP layers); three of the families, fixtures ``train_traj_seed_<tag>.npz``.
+    SURVEY 8(c) F6: RNG-free runs of the reference's own train.py (dropout 0, nothing sampled: --uncertainty none;
     Bayesian LSTM position 5 = KL in the loss but no draw, model.py:716; the GP families, whose GPNN.sample is never
     raised by train.py) from an initial state saved here and loaded through its --prior True path (train.py:239-258).
     Kept at full precision: the total loss of every step, the interval means / valid losses / test loss train.py
@@ -522,7 +525,7 @@ def f6_train_trajectory():
     import subprocess
     lr_l, lr_t = os.environ.get("TRAJ_LR_LSTM", "1.5"), os.environ.get("TRAJ_LR_TLM", "0.4")
     common = ["--epochs", os.environ.get("TRAJ_EPOCHS", "6"), "--batch-size", "4", "--seq_len", "7", "--dropout", "0.0", "--clip", "1.0", "--tied",
-              "--log-interval", "10", "--prior", "True"]
+              "--log-interval", "10"] + (["--seed", "1111"] if seed_only else ["--prior", "True"])
     for tag, lr, margs, build in (
         ("lstm_none", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "none"],
          lambda V: ref.RNNModel("LSTM", V, 12, 12, 2, 0.0, True)),
@@ -542,6 +545,8 @@ def f6_train_trajectory():
                         "--L_v_pos", "00"],
          lambda V: ref.VariationalRNNModel("LSTM", V, 12, 12, 2, 0.0, True, "00")),
     ):
+        if seed_only and tag not in ("lstm_none", "tlm_gauss3", "lstm_gauss33"):
+            continue
         with tempfile.TemporaryDirectory() as dtmp:
             words, texts = _tiny_corpus(dtmp)
             torch.manual_seed(61)
@@ -555,7 +560,7 @@ def f6_train_trajectory():
             open(probe, "w").write(_TRAIN_PROBE)
             out_npz = os.path.join(dtmp, "rec.npz")
             cmd = [sys.executable, probe, os.path.join(REF, "train.py"), out_npz, "--data", dtmp, "--lr", lr,
-                   "--save", os.path.join(dtmp, "model.pt"), "--prior_path", prior_dir] + common + margs
+                   "--save", os.path.join(dtmp, "model.pt")] + ([] if seed_only else ["--prior_path", prior_dir]) + common + margs
             env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=REF, OMP_NUM_THREADS="1")
             run = subprocess.run(cmd, cwd=dtmp, env=env, capture_output=True, text=True)
             assert run.returncode == 0, run.stderr[-3000:]
@@ -579,9 +584,9 @@ def f6_train_trajectory():
             margins = [abs(valid[i] - min(valid[:i])) / min(valid[:i]) for i in range(1, len(valid))]
             print(tag, "valid", [round(float(v), 4) for v in valid], "halved at", halved, "test", round(float(test), 4),
                   "min decision margin %.1e" % min(margins))
-            kw = {"init/" + k: npy(v) for k, v in init.items() if not k.endswith("pos_encoder.pe")}
+            kw = {} if seed_only else {"init/" + k: npy(v) for k, v in init.items() if not k.endswith("pos_encoder.pe")}
             kw.update({k: z[k] for k in z.files if k.startswith("snap")})
-            save("train_traj_" + tag, words=np.array(words), train_txt=np.array(texts["train"]),
+            save("train_traj_" + ("seed_" if seed_only else "") + tag, words=np.array(words), train_txt=np.array(texts["train"]),
                  valid_txt=np.array(texts["valid"]), test_txt=np.array(texts["test"]), argv=np.array(common + margs + ["--lr", lr]),
                  step_loss=z["bwd"], interval_loss=np.array(interval), valid_loss=np.array(valid), test_loss=np.float64(test),
                  kl_printed=np.array(kl_printed), sgd_lr=z["sgd_lr"], halved_epochs=np.array(halved, dtype=np.int64),
@@ -1020,6 +1025,24 @@ def init_state_cases():
     return cases
 
 
+def init_state_cli_cases():
+    """name -> (train.py's flags, the constructor calls train.py:193-223 makes for them in order, the LAST one being the
+    model it trains): ``--uncertainty none`` builds the model twice (``model_2`` first, :196-199 / :211-214)."""
+    V = 50
+    base = dict(emsize=16, nhead=4, nhid=32, nlayers=2, dropout=0.2, tied=True, T_bayes_pos="none", L_bayes_pos=0, T_gauss_pos=3,
+                L_gauss_pos="00", L_v_pos="11", T_v_pos=0)
+    tlm = ("TransformerModel", [V, 16, 4, 32, 2, 0.2, "gelu", True])
+    rnn = ("RNNModel", ["LSTM", V, 16, 16, 2, 0.2, True])
+    return {
+        "cli_tlm_none": (dict(base, model="Transformer", uncertainty="none"), [tlm, tlm]),
+        "cli_lstm_none": (dict(base, model="LSTM", uncertainty="none", nhid=16), [rnn, rnn]),
+        "cli_tlm_bayes_ffn": (dict(base, model="Transformer", uncertainty="Bayesian", T_bayes_pos="FFN"),
+                              [("BayesTransformerModel", [V, 16, 4, 32, 2, 0.2, True, "FFN"])]),
+        "cli_lstm_bayes3": (dict(base, model="LSTM", uncertainty="Bayesian", L_bayes_pos=3, nhid=16),
+                            [("BayesRNNModel", ["LSTM", V, 16, 16, 2, 0.2, True, 3])]),
+    }
+
+
 def tensor_digest(t):
     """[shape, sha256 of the little-endian bytes, float64 sum] -- the bit-exact identity of one tensor in ~100 bytes
     (the sum is there for the failure message: which way and how far a mismatching tensor is off)."""
@@ -1047,6 +1070,15 @@ def f10_init_state(seed=1111):
         if hasattr(m, "arch_parameters"):
             entry["arch"] = [tensor_digest(a) for a in m.arch_parameters()]
         out["cases"][name] = entry
+    out["ntokens"] = 50
+    for name, (flags, calls) in init_state_cli_cases().items():
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            for cls, args in calls:
+                m = getattr(ref, cls)(*args)
+        after = torch.rand(4, dtype=torch.float64).tolist()
+        out["cases"][name] = {"module": "model", "cls": calls[-1][0], "args": calls[-1][1], "cli": flags,
+                              "state": [[k] + tensor_digest(v) for k, v in m.state_dict().items()], "generator_after": after}
     path = os.path.join(OUT, "init_state.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))
@@ -1094,6 +1126,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "traj":
         f6_train_trajectory()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "traj_seed":
+        f6_train_trajectory(seed_only=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "late":
         f6_train_checkpoint()

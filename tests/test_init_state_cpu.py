@@ -9,7 +9,8 @@ model.py:1812, model_search_bayes.py:813; the ``torch.rand`` births of Bayes2LST
 and nn.TransformerEncoder's habit of cloning ONE constructed layer (model.py:134-136).
 
 Fixture: tests/golden/init_state.json, written by ``make_golden.py init`` from the reference's own constructors
-(56 of them: every family of train.py and train_search_bayes.py, tied and untied, every position / type string the
+(56 of them, plus four model builds through train.py's own dispatch, which constructs the model twice for
+``--uncertainty none``: every family of train.py and train_search_bayes.py, tied and untied, every position / type string the
 parity fixtures use): per tensor its shape, the SHA-256 of its bytes and its float64 sum.  Constructors only create
 parameters -- no kernel is launched, so this runs without a GPU."""
 import hashlib
@@ -48,7 +49,13 @@ def test_fixture_covers_every_constructor_the_entry_points_reach():
 def test_same_seed_same_initial_state_as_the_reference(name):
     case = GOLD["cases"][name]
     torch.manual_seed(GOLD["seed"])
-    m = getattr(MODS[case["module"]], case["cls"])(*case["args"])
+    if "cli" in case:  # through the CLI's dispatch: `--uncertainty none` builds the model twice and keeps the second (train.py:196-199)
+        from types import SimpleNamespace
+        from bayeslms_amd import train as TR
+        m = TR.build_model(SimpleNamespace(**case["cli"]), GOLD["ntokens"])
+        assert type(m).__name__ == case["cls"]
+    else:
+        m = getattr(MODS[case["module"]], case["cls"])(*case["args"])
     after = torch.rand(4, dtype=torch.float64).tolist()
     sd = m.state_dict()
     assert list(sd.keys()) == [row[0] for row in case["state"]], "state_dict keys or their order"

@@ -11,6 +11,9 @@ import torch
 from conftest import GOLDEN
 
 TAGS = ["lstm_none", "tlm_none", "lstm_bayes5", "tlm_gauss3", "lstm_gauss33", "lstm_var00"]
+# the same script started with `--seed 1111` ALONE (no saved initial state, make_golden.py traj_seed): the run begins from what
+# train.py's own model construction draws under that seed
+SEED_TAGS = ["seed_lstm_none", "seed_tlm_gauss3", "seed_lstm_gauss33"]
 
 
 def load_traj(tag):
@@ -42,11 +45,25 @@ def write_corpus(z, d):
             f.write(str(z[split + "_txt"]))
 
 
-@pytest.mark.parametrize("tag", TAGS)
+def cli_namespace(z):
+    """A fixture's argv as bayeslms_amd.train's parser sees it (defaults filled in)."""
+    from bayeslms_amd import train as T
+    return T.build_parser().parse_args([str(a) for a in z["argv"]])
+
+
+@pytest.mark.parametrize("tag", TAGS + SEED_TAGS)
 def test_oracle_training_loop_matches_reference_train_py(tag, tmp_path):
     from bayeslms_amd import data as D
     from oracle import bayes_oracle as O, train_oracle as TO
     z, args, init, snaps = load_traj(tag)
+    if tag.startswith("seed_"):
+        # no saved state: OUR constructors under train.py's seed, through the CLI's model dispatch (which repeats the
+        # reference's throw-away first construction for --uncertainty none), are where the reference's run started
+        from bayeslms_amd import train as T
+        assert not init and args["seed"] == "1111"
+        torch.manual_seed(int(args["seed"]))
+        init = {k: v.detach().clone() for k, v in T.build_model(cli_namespace(z), len(z["words"])).state_dict().items()
+                if not k.endswith("pos_encoder.pe")}
     write_corpus(z, str(tmp_path))
     corpus = D.Corpus(str(tmp_path))
     bsz, seq_len = int(args["batch_size"]), int(args["seq_len"])
