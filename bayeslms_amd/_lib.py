@@ -131,8 +131,6 @@ SIGNATURES = {
     "blm_clip_sgd_multi": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _i, _f, _vp]),
     "blm_lstm_step_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "blm_lstm_step_bwd": (_i, [_vp] * 10 + [_i, _i, _vp]),
-    "blm_lstm_step_bwd_ks": (_i, [_vp] * 11 + [_i, _i, _i, _vp]),
-    "blm_lstm_step_bwd_ks_ws_floats": (_i64, [_i, _i, _i]),
     "blm_lstm_seq_fwd": (_i, [_vp] * 6 + [_i, _i, _i, _vp]),
     "blm_lstm_seq_bwd": (_i, [_vp] * 7 + [_i, _vp, _i, _i, _i, _i, _i, _vp]),
     "blm_lstm_seq_pair_fwd": (_i, [_vp] * 5 + [_i] + [_vp] * 5 + [_i, _i, _i, _vp]),

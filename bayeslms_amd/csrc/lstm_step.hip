@@ -939,159 +939,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PIPE ? 
   }
 }
 
-// ------------------------------------------------------------------ backward step, contraction split over workgroups
-// The 16 x 16 form above moves (16 + 16) x G x 4 bytes of operand rows into every workgroup -- 512 KB at G = 4096 -- and that, at
-// the 66-73 GB/s a CU draws from its XCD's L2 (MI355X_MICROARCH.md, "Indexed rows"), IS its K loop: 7.8 us per 4096 of G (10.4 us
-// the LSTM step, 18.2 us the search cell's).  Here a workgroup owns a 32 x 32 tile of dh (32x32x2 MFMAs: 8 flops per operand byte
-// instead of 4) over ONE of S slices of the contraction -- (H / 32) x ceil(B / 32) x S workgroups, 256 KB each at G = 4096, S = 4.
-// The S partial tiles of a dh tile meet in a caller-owned workspace: every workgroup stores its partial tile and bumps the tile's
-// counter; the workgroup that arrives LAST adds the S partials in slice order (fixed summation order, no atomics on data), runs the
-// cell backward of the tile and re-arms the counter for the next launch.  Plain cells only (no GP gate, no activation modes).
-struct LstmBwdKsP {
-  const float *dg, *wt;                   // dgates_t (B,G), W_hh^T (H,G)
-  const float *dy, *dc_next, *cprev, *c, *ga;
-  float *dg_out, *dc_prev, *dh_out;
-  unsigned* cnt;                          // one arrival counter per dh tile, zero on entry and on exit
-  float* ws;                              // (tiles, S, 32 x 32) partial tiles
-  int B, H, G, S, sync;
-};
-
-template <bool REFILL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_step_bwd_ks_kernel(const LstmBwdKsP p) {
-  constexpr int RING = 2;
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  __shared__ unsigned arrived;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
-  const int k0 = blockIdx.x * 32, b0 = blockIdx.y * 32, slice = blockIdx.z;
-  const int H = p.H, B = p.B, S = p.S;
-  const long G = p.G;
-  const int Ks = p.G / S, Kw = Ks >> 2, Kh = Kw >> 1, nchunk = Kh >> 5;  // host: Kh % 32 == 0, nchunk even (== 2 without REFILL)
-  float* base = sm + wave * (2 * TILE);
-  const int srow = lane >> 4, shalf = (lane >> 3) & 1, spart = lane & 7;  // one instruction stages 4 rows x 2 halves x 128 B
-  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dg), 0, (int)(4u * (uint32_t)B * (uint32_t)p.G), 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, (int)(4u * (uint32_t)H * (uint32_t)p.G), 0x00020000);
-  const int kb4 = __builtin_amdgcn_readfirstlane((slice * Ks + wave * Kw) * 4);
-  uint32_t aoff[8], woff[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int row = 4 * q + srow;
-    aoff[q] = (uint32_t)(((long)min(b0 + row, B - 1) * G + shalf * Kh + 4 * spart) * 4);
-    woff[q] = (uint32_t)(((long)(k0 + row) * G + shalf * Kh + 4 * spart) * 4);
-  }
-  auto ldg = [](__amdgpu_buffer_rsrc_t r, uint32_t voff, int soff) {
-    const bu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-  };
-  const int soff = srow * LSTR + shalf * 32 + 4 * spart;
-  float4 ra[RING][8], rw[RING][8];
-  auto fetch = [&](float4 (&a)[8], float4 (&w)[8], int c) {
-    const int so = kb4 + 128 * min(c, nchunk - 1);  // wave-uniform; past the last chunk: a valid address, the data is dropped
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      a[q] = ldg(arsrc, aoff[q], so);
-      w[q] = ldg(wrsrc, woff[q], so);
-    }
-  };
-  f32x16 acc = (f32x16)(0.f);
-  auto chunk = [&](float4 (&a)[8], float4 (&w)[8], int c) {
-    float* d = base + soff;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      *reinterpret_cast<float4*>(d + 4 * q * LSTR) = a[q];
-      *reinterpret_cast<float4*>(d + TILE + 4 * q * LSTR) = w[q];
-    }
-    if constexpr (REFILL) fetch(a, w, c + RING);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // wave-private tiles, in-order LDS: see the forward kernel
-    __builtin_amdgcn_wave_barrier();
-    const float* at = base + li * LSTR + lh * 32;
-    const float* wt = at + TILE;
-    float4 av[8], wv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      av[j] = *reinterpret_cast<const float4*>(at + 4 * j);
-      wv[j] = *reinterpret_cast<const float4*>(wt + 4 * j);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].x, wv[j].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, wv[j].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].z, wv[j].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].w, wv[j].w, acc, 0, 0, 0);
-    }
-    __builtin_amdgcn_wave_barrier();
-  };
-#pragma unroll
-  for (int r = 0; r < RING; ++r) fetch(ra[r], rw[r], r);
-  if constexpr (REFILL) {
-#pragma unroll 1
-    for (int cc = 0; cc < nchunk; cc += RING) {
-#pragma unroll
-      for (int r = 0; r < RING; ++r) chunk(ra[r], rw[r], cc + r);
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < RING; ++r) chunk(ra[r], rw[r], r);
-  }
-  // the four waves' K runs -> one partial tile, element e = 32 * (batch row) + column; thread t owns e = t + 256 i
-  __syncthreads();
-  float* red = sm;  // 4 x 32 x RSTR floats, overlays the staging tiles
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-    red[(wave * 32 + row) * RSTR + li] = acc[r];
-  }
-  __syncthreads();
-  float v[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int e = threadIdx.x + 256 * i, br = e >> 5, col = e & 31;
-    v[i] = (red[(0 * 32 + br) * RSTR + col] + red[(1 * 32 + br) * RSTR + col]) + (red[(2 * 32 + br) * RSTR + col] + red[(3 * 32 + br) * RSTR + col]);
-  }
-  if (S > 1 && p.sync != 4) {  // sync 4: timing only -- no exchange, every slice runs the epilogue on its own partial
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-    float* wst = p.ws + (long)tile * S * 1024;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) __hip_atomic_store(wst + slice * 1024 + threadIdx.x + 256 * i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (p.sync == 1) __threadfence();   // this thread's partial is visible to the device before the arrival below
-    else if (p.sync == 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the device-scope (write-through) stores above have been acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0) arrived = __hip_atomic_fetch_add(p.cnt + tile, 1u, p.sync == 1 ? __ATOMIC_ACQ_REL : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (arrived != (unsigned)(S - 1)) return;  // workgroup-uniform
-    if (p.sync == 1) __threadfence();
-    if (threadIdx.x == 0) __hip_atomic_store(p.cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // everybody has arrived: re-arm
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = threadIdx.x + 256 * i;
-      float s0 = __hip_atomic_load(wst + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int k = 1; k < S; ++k) s0 += __hip_atomic_load(wst + k * 1024 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // slice order
-      v[i] = s0;
-    }
-  }
-  const long G4 = 4L * H;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int e = threadIdx.x + 256 * i, eb = b0 + (e >> 5), ek = k0 + (e & 31);
-    if (eb >= B) continue;
-    const long ei = (long)eb * H + ek, eo = (long)eb * G4 + ek;
-    const float dh = v[i];
-    if (p.dh_out) p.dh_out[ei] = dh;
-    if (p.dg_out) {  // cell backward of the step that produced h_{t-1} (the 16 x 16 kernel's, plain cell)
-      const float gi = p.ga[eo], gf = p.ga[eo + H], gg = p.ga[eo + 2L * H], go = p.ga[eo + 3L * H];
-      const float tc = tanhf(p.c[ei]);
-      const float dhv = dh + (p.dy ? p.dy[ei] : 0.f);
-      const float dc = (p.dc_next ? p.dc_next[ei] : 0.f) + dhv * go * (1.f - tc * tc);
-      const float dgi = dc * gg, dgf = dc * p.cprev[ei], dgg = dc * gi, dgo = dhv * tc;
-      p.dg_out[eo] = dgi * gi * (1.f - gi);
-      p.dg_out[eo + H] = dgf * gf * (1.f - gf);
-      p.dg_out[eo + 2L * H] = dgg * (1.f - gg * gg);
-      p.dg_out[eo + 3L * H] = dgo * go * (1.f - go);
-      p.dc_prev[ei] = dc * gf;
-    }
-  }
-}
-
 // out (cols x rows) = in (rows x cols)^T, 32x32 tiles through LDS
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
   __shared__ float t[32][33];
@@ -1299,56 +1146,6 @@ static int launch_step_bwd(const LstmBwdP& p, void* stream) {
   }
   else if (nchunk % 2 == 0) hipLaunchKernelGGL(lstm_step_bwd_kernel<2>, grid, block, lds4, st, p);
   else hipLaunchKernelGGL(lstm_step_bwd_kernel<1>, grid, block, lds4, st, p);
-  BLM_HIP(hipGetLastError());
-  return BLM_OK;
-}
-
-// K slices of the split backward step (lstm_step_bwd_ks_kernel): the fewest of 1, 2, 4, 8 that give every CU a workgroup, among
-// those whose per-wave K run is a whole, even number of 64-float chunks; 0 = this shape stays on the 16 x 16 kernel
-static int bwd_ks_slices(int B, int H, int G) {
-  if (H % 32 != 0 || B < 1) return 0;
-  const long tiles = (long)(H / 32) * ((B + 31) / 32);
-  int pick = 0;
-  for (int S = 1; S <= 8; S *= 2) {
-    if (G % (S * 256) != 0) break;
-    const int nchunk = G / S / 256;
-    if (nchunk < 2 || nchunk % 2 != 0) continue;
-    pick = S;
-    if (tiles * S >= 256) break;
-  }
-  return pick;
-}
-
-extern "C" int64_t blm_lstm_step_bwd_ks_ws_floats(int B, int H, int G) {
-  const int S = bwd_ks_slices(B, H, G);
-  if (S == 0 || !blm::extents_ok({B, H, G})) return 0;
-  const int64_t tiles = (int64_t)(H / 32) * ((B + 31) / 32);
-  return ((tiles + 3) / 4) * 4 + tiles * S * 1024;  // counters (32-bit words, zero before the first call) then the partial tiles
-}
-
-extern "C" int blm_lstm_step_bwd_ks(const float* dgates_t, const float* w_hh_t, const float* dy_prev, const float* dc_next,
-                                    const float* c_prev, const float* c, const float* gates_act, float* dgates_out, float* dc_prev,
-                                    float* dh_out, float* ws, int B, int H, int G, void* stream) {
-  if (!dgates_t || !w_hh_t || !ws || B < 0 || H < 0 || G < 0 || (!dgates_out && !dh_out) ||
-      (dgates_out && (!c_prev || !c || !gates_act || !dc_prev)) || !blm::extents_ok({B, H, G}))
-    return blm_fail(BLM_ERR_INVALID, "blm_lstm_step_bwd_ks: bad arguments");
-  if ((long)B * H == 0) return BLM_OK;
-  const int S = bwd_ks_slices(B, H, G);
-  if (S == 0 || !al16(dgates_t) || !al16(w_hh_t) || 4.0 * H * G >= 4294967296.0 || 4.0 * B * G >= 4294967296.0)
-    return blm_fail(BLM_ERR_UNSUPPORTED, "blm_lstm_step_bwd_ks: needs H % 32 == 0, G a multiple of 512, 16-byte aligned operands under 4 GB");
-  const long tiles = (long)(H / 32) * ((B + 31) / 32);
-  LstmBwdKsP p{dgates_t, w_hh_t, dy_prev, dc_next, c_prev, c, gates_act, dgates_out, dc_prev, dh_out,
-               reinterpret_cast<unsigned*>(ws), ws + ((tiles + 3) / 4) * 4, B, H, G, S, getenv("BLM_KS_SYNC") ? atoi(getenv("BLM_KS_SYNC")) : 3};
-  const size_t lds = (size_t)4 * 2 * TILE * sizeof(float);
-  static bool once = false;
-  if (!once) {
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_ks_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_ks_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    once = true;
-  }
-  const dim3 grid(H / 32, (B + 31) / 32, S), block(256);
-  if (G / S / 256 == 2) hipLaunchKernelGGL(lstm_step_bwd_ks_kernel<false>, grid, block, lds, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(lstm_step_bwd_ks_kernel<true>, grid, block, lds, (hipStream_t)stream, p);
   BLM_HIP(hipGetLastError());
   return BLM_OK;
 }
