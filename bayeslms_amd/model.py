@@ -47,6 +47,11 @@ class NoiseState:
         # forward in grad mode moves on to the next step's noise / dropout streams, as torch's generator would.  The first explicit
         # set_step() -- engine.Trainer, the Monte-Carlo scorer, tests -- takes the counter over.
         self.auto_step = True
+        # "philox" (default): eps / dropout from the counter-based streams keyed by (seed, site, step).  "torch": the variational
+        # eps of the Bayesian and Variational families is drawn from torch's CPU generator exactly as the reference draws it
+        # (``new_zeros(shape).normal_(0, std)`` per tensor, in its order) and uploaded -- a parity mode: with dropout 0 a run
+        # from the same ``--seed`` then sees the reference's own noise (train --noise-source torch); dropout stays Philox
+        self.source = "philox"
 
 
 class _Site(nn.Module):
@@ -65,14 +70,24 @@ class _Site(nn.Module):
             return ops.NO_DROP
         return Drop(float(p), st.seed, self._site_base + k, st.step, st.col_offset, st.global_cols)
 
-    def _noise(self, k=0, override=None):
-        """NoiseSpec of variational tensor k of this module, or None in eval mode (mean weights)."""
+    def _noise(self, k=0, override=None, like=None):
+        """NoiseSpec of variational tensor k of this module, or None in eval mode (mean weights).  ``like``: the log-sigma tensor
+        the draw belongs to -- under NoiseState.source "torch" the eps is drawn here, now, from torch's CPU generator the way
+        the reference draws it (model.py:1087, :671: ``lgstd.new_zeros(*lgstd.size()).normal_()``)."""
         if override is not None:
             return NoiseSpec(eps=override)
         if not self.training:
             return None
         st = self._st()
+        if st.source == "torch" and like is not None:
+            return NoiseSpec(eps=torch_eps(like.shape, like.device))
         return NoiseSpec(None, st.seed, self._site_base + k, st.step)
+
+
+def torch_eps(shape, device, std=1.0):
+    """One eps tensor from torch's CPU generator, drawn as the reference draws it on the CPU path (same call, same shape, so the
+    same values from the same generator state), then moved to the device."""
+    return torch.zeros(*shape).normal_(0, std).to(device)
 
 
 def _advance_step(module, _inputs, _output):
@@ -161,7 +176,7 @@ class BayesLinear(_Site):
     def noise(self):
         if not (self.training and self.sample):
             return None
-        return self._noise(0, self.eps_override)
+        return self._noise(0, self.eps_override, self.weight_lgstd)
 
     def kl_divergence(self, prior=None):
         if prior is not None:
@@ -170,7 +185,7 @@ class BayesLinear(_Site):
 
     def forward(self, input):
         return ops.bayes_linear(input, self.weight_mean, self.weight_lgstd, self.noise(), self.fused_kl_lambda,
-                                self._st().fused)
+                                self._st().fused and self._st().source == "philox")
 
     def extra_repr(self):
         return "in_features={}, out_features={}, bias=False".format(self.in_features, self.out_features)
@@ -354,6 +369,12 @@ class _LMHead(_Site):
     def set_fused_sampling(self, on):
         self.noise_state.fused = bool(on)
 
+    def set_noise_source(self, source):
+        """"philox" (default) | "torch": see NoiseState.source."""
+        if source not in ("philox", "torch"):
+            raise ValueError("noise source must be 'philox' or 'torch'")
+        self.noise_state.source = source
+
 
 class BayesTransformerModel(_LMHead):
     """Reference model.py:1179-1309.  Only layer 0 is Bayesian and it is built with a hard-coded
@@ -397,7 +418,7 @@ class BayesTransformerModel(_LMHead):
         scale = math.sqrt(self.ninp)
         if self.bayes_embed:
             x = ops.embed(src, self.encoder.weight, None, scale)
-            noise = self._noise(0, self.embed_eps_override) if self.training else None
+            noise = self._noise(0, self.embed_eps_override, self.embed_lgstd) if self.training else None
             W = ops.sampled(self.embed_mean, self.embed_lgstd, noise) if noise is not None else self.embed_mean
             x = ops.linear(x, W)
             x = self.pos_encoder(x)
@@ -838,7 +859,7 @@ class Bayes2LSTM(_Site):
                 lg = getattr(self, "%s_lgstd_%d" % (name, layer))
                 ov = self.eps_override[k] if self.eps_override is not None else None
                 klw = lg.numel() / cnt[name.split("_")[0]] if layer == 1 else 0.0
-                specs.append((mu, lg, self._noise(k, ov), (pos - 1) * H, klw, 0.0))
+                specs.append((mu, lg, self._noise(k, ov, lg), (pos - 1) * H, klw, 0.0))
                 keys.append((name, layer))
             ws, kl = ops.variational_group(specs)
             if torch.is_grad_enabled():
@@ -851,7 +872,7 @@ class Bayes2LSTM(_Site):
                 if 1 <= pos <= 4 and self.training:
                     lg = getattr(self, "%s_lgstd_%d" % (name, layer))
                     ov = self.eps_override[k] if self.eps_override is not None else None
-                    out[(name, layer)] = ops.sampled(mu, lg, self._noise(k, ov), (pos - 1) * H)
+                    out[(name, layer)] = ops.sampled(mu, lg, self._noise(k, ov, lg), (pos - 1) * H)
                 else:
                     out[(name, layer)] = mu
                 k += 1
@@ -1230,6 +1251,9 @@ class VNN(_Site):
     def noise_rows(self, T, eps=None):
         """(T, H) rows eps_t * exp(lgstd), eps_t ~ N(0, 0.1) from the Philox stream (or injected)."""
         H = self.input_size
+        if eps is None and self._st().source == "torch":
+            # one (1, H) draw of N(0, 0.1) per time step, as the reference's per-step call makes it (model.py:2555-2561)
+            eps = torch.cat([torch_eps((1, H), "cpu", 0.1) for _ in range(T)], 0).to(self.hidden_lgstd.device)
         if eps is None:
             st = self._st()
             eps = ops.philox_normal(T * H, st.seed, ops.L.STREAM_WEIGHT + self._site_base, st.step,

@@ -544,18 +544,31 @@ def f6_train_trajectory(seed_only=False):
         ("lstm_var00", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Variational",
                         "--L_v_pos", "00"],
          lambda V: ref.VariationalRNNModel("LSTM", V, 12, 12, 2, 0.0, True, "00")),
+        # seed_only alone -- runs WITH weight noise (dropout 0): the eps of every training step comes from torch's CPU generator,
+        # which train.py seeded and the constructors advanced (bayeslms_amd.train --noise-source torch draws the same)
+        # (--T_bayes_pos FFN / MHA cannot be followed this way: their layer 0 is built with a hard-coded dropout of 0.2,
+        #  model.py:1202,1207, whose masks also come from torch's generator)
+        ("noisy_tlm_bayes_emb", lr_t, ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                                 "--uncertainty", "Bayesian", "--T_bayes_pos", "EMB"], None),
+        ("noisy_lstm_bayes3", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Bayesian",
+                               "--L_bayes_pos", "3"], None),
+        ("noisy_lstm_var11", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Variational",
+                              "--L_v_pos", "11"], None),
     ):
-        if seed_only and tag not in ("lstm_none", "tlm_gauss3", "lstm_gauss33"):
+        if (seed_only and tag not in ("lstm_none", "tlm_gauss3", "lstm_gauss33") and build is not None) or (not seed_only and build is None):
+            continue
+        if os.environ.get("TRAJ_ONLY") and tag not in os.environ["TRAJ_ONLY"].split(","):
             continue
         with tempfile.TemporaryDirectory() as dtmp:
             words, texts = _tiny_corpus(dtmp)
-            torch.manual_seed(61)
-            with contextlib.redirect_stdout(io.StringIO()):
-                m0 = build(len(words))
             prior_dir = os.path.join(dtmp, "prior")
-            os.makedirs(prior_dir)
-            init = {k: v.detach().clone() for k, v in m0.state_dict().items()}
-            torch.save(init, os.path.join(prior_dir, "model.pt"))
+            if not seed_only:
+                torch.manual_seed(61)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    m0 = build(len(words))
+                os.makedirs(prior_dir)
+                init = {k: v.detach().clone() for k, v in m0.state_dict().items()}
+                torch.save(init, os.path.join(prior_dir, "model.pt"))
             probe = os.path.join(dtmp, "probe.py")
             open(probe, "w").write(_TRAIN_PROBE)
             out_npz = os.path.join(dtmp, "rec.npz")

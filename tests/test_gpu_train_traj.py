@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_train_traj_oracle import SEED_TAGS, TAGS, load_traj, write_corpus
+from test_train_traj_oracle import NOISY_SEED_TAGS, SEED_TAGS, TAGS, load_traj, write_corpus
 
 pytestmark = pytest.mark.gpu
 
@@ -40,12 +40,16 @@ def test_train_cli_reproduces_reference_train_py_trajectory(tag, tmp_path, capsy
         assert out.count("tensor([") == len(z["valid_loss"]) + 1  # the coef_mean print, per epoch and at the end
 
 
-@pytest.mark.parametrize("tag", SEED_TAGS)
+@pytest.mark.parametrize("tag", SEED_TAGS + NOISY_SEED_TAGS)
 def test_train_cli_from_the_seed_alone_reproduces_reference_train_py(tag, tmp_path, capsys):
     """No --prior: the reference's train.py and this CLI are both started with `--seed 1111` and nothing else in common but the
     corpus and the flags.  The constructors draw from torch's generator in the reference's order (tests/test_init_state_cpu.py)
     and the dispatch repeats its throw-away first construction for --uncertainty none, so the two runs start from the same
-    weights -- and stay together: valid / test loss 1e-4, the same LR-halving epoch, interval loss and final checkpoint 1e-3."""
+    weights -- and stay together: valid / test loss 1e-4, the same LR-halving epoch, interval loss and final checkpoint 1e-3.
+    The ``noisy`` runs sample their Bayesian / Variational weights in every training step (dropout 0): under
+    ``--noise-source torch`` the CLI draws each eps from torch's CPU generator with the reference's own calls, in its order (one per
+    Bayesian tensor and forward; eight per Bayes2LSTM forward; one (1, H) row per time step and noisy cell), so the run sees the
+    reference's noise and follows it just the same."""
     from bayeslms_amd import train as T
     z, args, init, snaps = load_traj(tag)
     assert not init and "prior" not in args and args["seed"] == "1111"
@@ -53,7 +57,8 @@ def test_train_cli_from_the_seed_alone_reproduces_reference_train_py(tag, tmp_pa
     write_corpus(z, d)
     save = os.path.join(d, "model.pt")
     hist = {}
-    T.main([str(a) for a in z["argv"]] + ["--data", d, "--save", save, "--cuda"], history=hist)
+    T.main([str(a) for a in z["argv"]] + ["--data", d, "--save", save, "--cuda"] + (["--noise-source", "torch"] if "noisy" in tag else []),
+           history=hist)
     capsys.readouterr()
     assert list(hist["halved_epochs"]) == list(z["halved_epochs"]), (hist["valid_loss"], list(z["valid_loss"]))
     assert np.allclose(hist["valid_loss"], z["valid_loss"], rtol=1e-4), (hist["valid_loss"], list(z["valid_loss"]))

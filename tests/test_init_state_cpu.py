@@ -81,3 +81,36 @@ def test_baseline_transformer_layers_start_as_copies_of_layer_0():
         assert torch.equal(a, b) and a.data_ptr() != b.data_ptr(), k
     assert len({id(p) for p in m.parameters()}) == len(list(m.parameters()))
     assert l0._site_base != l2._site_base  # each copy still has its own dropout / noise stream ids
+
+
+def test_noise_source_torch_draws_eps_as_the_reference_does():
+    """``set_noise_source("torch")`` (train --noise-source torch): the eps of a variational tensor is ONE
+    ``zeros(shape).normal_()`` from torch's CPU generator at the moment the forward asks for it -- the reference's own call
+    (model.py:1087, :671) -- so the value equals what the reference would have drawn from the same generator state; the default
+    stays the Philox stream (no eps tensor on the host).  No kernel is launched here."""
+    from bayeslms_amd import train as TR
+    torch.manual_seed(5)
+    m = M.BayesTransformerModel(50, 16, 4, 32, 2, 0.0, True, "FFN")
+    lin2 = m.transformerlayers[0].linear2
+    m.train()
+    assert m.noise_state.source == "philox" and lin2.noise().eps is None
+    with pytest.raises(ValueError):
+        m.set_noise_source("numpy")
+    m.set_noise_source("torch")
+    torch.manual_seed(9)
+    want = torch.zeros(*lin2.weight_lgstd.shape).normal_()
+    after = torch.rand(2)
+    torch.manual_seed(9)
+    got = lin2.noise().eps
+    assert torch.equal(got, want) and torch.equal(torch.rand(2), after)  # same values, generator advanced by exactly that draw
+    m.eval()
+    assert lin2.noise() is None  # mean weights: nothing drawn
+    # one (1, H) row of N(0, 0.1) per time step for the variational cells
+    v = M.VariationalRNNModel("LSTM", 50, 12, 12, 2, 0.0, True, "11")
+    v.set_noise_source("torch")
+    torch.manual_seed(3)
+    want = torch.cat([torch.zeros(1, 12).normal_(0, 0.1) for _ in range(4)], 0) * torch.exp(v.rnn.rnn[0].vnn.hidden_lgstd)
+    torch.manual_seed(3)
+    assert torch.equal(v.rnn.rnn[0].vnn.noise_rows(4), want)
+    args = TR.build_parser().parse_args(["--noise-source", "torch"])
+    assert args.noise_source == "torch" and TR.build_parser().parse_args([]).noise_source == "philox"
