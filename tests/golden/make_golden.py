@@ -479,6 +479,11 @@ def f6_train_checkpoint():
 _TRAIN_PROBE = r"""
 import math, os, runpy, sys
 import numpy as np, torch
+if os.environ.get("PROBE_ZERO_DROPOUT"):   # harness switch: every nn.Dropout of the run is built with p = 0 (no mask is drawn)
+    _dinit = torch.nn.Dropout.__init__
+    def _zdrop(self, p=0.5, inplace=False):
+        _dinit(self, 0.0, inplace)
+    torch.nn.Dropout.__init__ = _zdrop
 rec = {"exp": [], "bwd": [], "snaps": [], "sgd_lr": []}
 _exp = math.exp
 def _rexp(x):
@@ -546,8 +551,13 @@ def f6_train_trajectory(seed_only=False):
          lambda V: ref.VariationalRNNModel("LSTM", V, 12, 12, 2, 0.0, True, "00")),
         # seed_only alone -- runs WITH weight noise (dropout 0): the eps of every training step comes from torch's CPU generator,
         # which train.py seeded and the constructors advanced (bayeslms_amd.train --noise-source torch draws the same)
-        # (--T_bayes_pos FFN / MHA cannot be followed this way: their layer 0 is built with a hard-coded dropout of 0.2,
-        #  model.py:1202,1207, whose masks also come from torch's generator)
+        # --T_bayes_pos FFN / MHA: their layer 0 is built with a hard-coded dropout of 0.2 (model.py:1202,1207) whose masks come
+        # from the same generator and cannot be followed; recorded with the HARNESS building every nn.Dropout with p = 0
+        # (PROBE_ZERO_DROPOUT in the probe above; the fixture says so: zero_dropout = 1), which leaves the weight noise alone
+        ("noisy_tlm_bayes_ffn_nodrop", lr_t, ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                                        "--uncertainty", "Bayesian", "--T_bayes_pos", "FFN"], None),
+        ("noisy_tlm_bayes_mha_nodrop", lr_t, ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                                        "--uncertainty", "Bayesian", "--T_bayes_pos", "MHA"], None),
         ("noisy_tlm_bayes_emb", lr_t, ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
                                  "--uncertainty", "Bayesian", "--T_bayes_pos", "EMB"], None),
         ("noisy_lstm_bayes3", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Bayesian",
@@ -575,6 +585,8 @@ def f6_train_trajectory(seed_only=False):
             cmd = [sys.executable, probe, os.path.join(REF, "train.py"), out_npz, "--data", dtmp, "--lr", lr,
                    "--save", os.path.join(dtmp, "model.pt")] + ([] if seed_only else ["--prior_path", prior_dir]) + common + margs
             env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=REF, OMP_NUM_THREADS="1")
+            if tag.endswith("_nodrop"):
+                env["PROBE_ZERO_DROPOUT"] = "1"
             run = subprocess.run(cmd, cwd=dtmp, env=env, capture_output=True, text=True)
             assert run.returncode == 0, run.stderr[-3000:]
             log = run.stdout
@@ -593,7 +605,7 @@ def f6_train_trajectory(seed_only=False):
             nsnap = 1 + max(int(k[4:].split("/")[0]) for k in z.files if k.startswith("snap"))
             assert nsnap == len(valid) + 1 and abs(test - float(z["test_loss"])) == 0.0
             halved = [i + 1 for i in range(len(valid)) if i > 0 and not valid[i] < min(valid[:i])]
-            assert len(z["sgd_lr"]) == 1 + len(halved) and len(halved) >= 1, (valid, z["sgd_lr"])
+            assert len(z["sgd_lr"]) == 1 + len(halved) and (len(halved) >= 1 or seed_only), (valid, z["sgd_lr"])
             margins = [abs(valid[i] - min(valid[:i])) / min(valid[:i]) for i in range(1, len(valid))]
             print(tag, "valid", [round(float(v), 4) for v in valid], "halved at", halved, "test", round(float(test), 4),
                   "min decision margin %.1e" % min(margins))
@@ -603,7 +615,7 @@ def f6_train_trajectory(seed_only=False):
                  valid_txt=np.array(texts["valid"]), test_txt=np.array(texts["test"]), argv=np.array(common + margs + ["--lr", lr]),
                  step_loss=z["bwd"], interval_loss=np.array(interval), valid_loss=np.array(valid), test_loss=np.float64(test),
                  kl_printed=np.array(kl_printed), sgd_lr=z["sgd_lr"], halved_epochs=np.array(halved, dtype=np.int64),
-                 final_lr=z["final_lr"], rows=z["rows"], **kw)
+                 final_lr=z["final_lr"], rows=z["rows"], zero_dropout=np.int64(tag.endswith("_nodrop")), **kw)
 
 
 def f5_gauss_variational_rnn():

@@ -41,7 +41,7 @@ def test_train_cli_reproduces_reference_train_py_trajectory(tag, tmp_path, capsy
 
 
 @pytest.mark.parametrize("tag", SEED_TAGS + NOISY_SEED_TAGS)
-def test_train_cli_from_the_seed_alone_reproduces_reference_train_py(tag, tmp_path, capsys):
+def test_train_cli_from_the_seed_alone_reproduces_reference_train_py(tag, tmp_path, capsys, monkeypatch):
     """No --prior: the reference's train.py and this CLI are both started with `--seed 1111` and nothing else in common but the
     corpus and the flags.  The constructors draw from torch's generator in the reference's order (tests/test_init_state_cpu.py)
     and the dispatch repeats its throw-away first construction for --uncertainty none, so the two runs start from the same
@@ -53,6 +53,20 @@ def test_train_cli_from_the_seed_alone_reproduces_reference_train_py(tag, tmp_pa
     from bayeslms_amd import train as T
     z, args, init, snaps = load_traj(tag)
     assert not init and "prior" not in args and args["seed"] == "1111"
+    if int(z["zero_dropout"]) if "zero_dropout" in z.files else 0:
+        # --T_bayes_pos FFN / MHA: the reference run was recorded with the harness building every nn.Dropout with p = 0 (layer 0's
+        # hard-coded 0.2 draws masks from the same generator); the same switch here, after the model is built
+        build = T.build_model
+
+        def build_without_dropout(a, n):
+            m = build(a, n)
+            for mod in m.modules():
+                if hasattr(mod, "p"):
+                    mod.p = 0.0
+                if isinstance(getattr(mod, "dropout", None), float):
+                    mod.dropout = 0.0
+            return m
+        monkeypatch.setattr(T, "build_model", build_without_dropout)
     d = str(tmp_path)
     write_corpus(z, d)
     save = os.path.join(d, "model.pt")

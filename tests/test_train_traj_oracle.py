@@ -18,7 +18,10 @@ SEED_TAGS = ["seed_lstm_none", "seed_tlm_gauss3", "seed_lstm_gauss33"]
 # generator -- seeded by train.py, advanced by the constructors, then one ``new_zeros(shape).normal_()`` per tensor and step
 # (--T_bayes_pos FFN / MHA are out of reach: their layer 0 has a hard-coded dropout of 0.2, model.py:1202,1207 -- masks from the
 # same generator, which no fused kernel reproduces)
-NOISY_SEED_TAGS = ["seed_noisy_tlm_bayes_emb", "seed_noisy_lstm_bayes3", "seed_noisy_lstm_var11"]
+NOISY_SEED_TAGS = ["seed_noisy_tlm_bayes_emb", "seed_noisy_lstm_bayes3", "seed_noisy_lstm_var11",
+                   # the headline family and its MHA sibling, recorded with the HARNESS building every nn.Dropout of the reference run
+                   # with p = 0 (fixture field zero_dropout; make_golden.py PROBE_ZERO_DROPOUT): the weight noise alone
+                   "seed_noisy_tlm_bayes_ffn_nodrop", "seed_noisy_tlm_bayes_mha_nodrop"]
 
 
 def load_traj(tag):
@@ -63,13 +66,13 @@ def noisy_family(args):
     time step and noisy cell, cell 0's T rows before cell 1's (:2555-2561, :2503-2507)."""
     from oracle import bayes_oracle as O
     if args["model"] == "Transformer":
-        assert args["T_bayes_pos"] == "EMB"
-        nhead = int(args["nhead"])
+        pos, nhead = args["T_bayes_pos"], int(args["nhead"])
+        lg = {"EMB": "embed_lgstd", "FFN": "transformerlayers.0.linear2.weight_lgstd", "MHA": "transformerlayers.0.self_attn.o_net.weight_lgstd"}[pos]
 
         def fwd(sd, x, hidden):
-            eps = torch.zeros(*sd["embed_lgstd"].shape).normal_() if torch.is_grad_enabled() else None
+            eps = torch.zeros(*sd[lg].shape).normal_() if torch.is_grad_enabled() else None
             return O.transformer_lm(x, sd, nhead, eps), None
-        return fwd, (lambda sd: O.kl_transformer(sd, "EMB")), False
+        return fwd, (lambda sd: O.kl_transformer(sd, pos)), False
     if args["uncertainty"] == "Bayesian":
         pos = int(args["L_bayes_pos"])
 
