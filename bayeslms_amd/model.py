@@ -16,6 +16,7 @@ GPU; there is no CPU path.
 """
 import copy
 import math
+import os
 
 import numpy as np
 import torch
@@ -51,7 +52,9 @@ class NoiseState:
         # eps of the Bayesian and Variational families is drawn from torch's CPU generator exactly as the reference draws it
         # (``new_zeros(shape).normal_(0, std)`` per tensor, in its order) and uploaded -- a parity mode: with dropout 0 a run
         # from the same ``--seed`` then sees the reference's own noise (train --noise-source torch); dropout stays Philox
-        self.source = "philox"
+        self.source = os.environ.get("BLM_NOISE_SOURCE", "philox")  # an unchanged reference script selects it from outside
+        if self.source not in ("philox", "torch"):
+            raise ValueError("BLM_NOISE_SOURCE must be 'philox' or 'torch', not %r" % self.source)
 
 
 class _Site(nn.Module):

@@ -59,8 +59,8 @@ def build_parser():
                         'it): the GP coefficients / weights of --uncertainty Gaussian are re-sampled every training step')
     p.add_argument('--gemm-mode', type=str, default='f32', choices=['f32', 'bf16x6', 'bf16x3'],
                    help='new, optional: opt-in split-bf16 arithmetic of the GEMM family (DESIGN.md section 7); default fp32 MFMA')
-    p.add_argument('--noise-source', type=str, default='philox', choices=['philox', 'torch'],
-                   help='new, optional: where the variational eps of the Bayesian / Variational families comes from.  philox (default): '
+    p.add_argument('--noise-source', type=str, default=None, choices=['philox', 'torch'],
+                   help='new, optional: where the variational eps of the Bayesian / Variational families comes from (default: BLM_NOISE_SOURCE or philox).  philox: '
                         'counter-based streams keyed by (seed, tensor, step), generated on the GPU.  torch: drawn from torch\'s CPU generator '
                         'exactly as the reference draws it (same calls, same order) and uploaded -- a parity mode: with --dropout 0 a run '
                         'from the same --seed follows the reference\'s CPU run WITH its weight noise')
@@ -274,7 +274,8 @@ def main(argv=None, history=None):
         model.load_state_dict(own)
     model = model.to(device)
     model.set_fused_sampling(bool(args.fused_sampling))
-    model.set_noise_source(args.noise_source)
+    if args.noise_source is not None:
+        model.set_noise_source(args.noise_source)
     if args.gp_sample:
         from .model import GPNN
         gps = [m for m in model.modules() if isinstance(m, GPNN) and m.draws_noise()]

@@ -42,6 +42,12 @@ def reference_shaped_run(cfg, data_dir, init, device):
     EVAL_COLS = 20
     streams = {"train": columns(text.train, cfg.batch_size), "valid": columns(text.valid, EVAL_COLS), "test": columns(text.test, EVAL_COLS)}
     recurrent = cfg.model != 'Transformer'
+    if getattr(cfg, "seed", None) is not None:
+        # no saved state: the script seeds torch's generator (train.py:124) and builds -- for `--uncertainty none` TWICE, keeping
+        # the second model (train.py:196-199, :211-214)
+        torch.manual_seed(cfg.seed)
+        if cfg.uncertainty == 'none':
+            build_through_shim(shim, cfg, vocab)
     net = build_through_shim(shim, cfg, vocab).to(device)
     extra_term = penalty_of(cfg)  # None, or net -> the divergence term this flag combination adds to the criterion
     per_window = float(cfg.seq_len) / float(streams["train"].size(0))  # ... / len(train_data) * seq_len
@@ -174,12 +180,17 @@ def penalty_of(cfg):
 
 
 TRAJECTORIES = ["tlm_none", "lstm_none", "lstm_bayes5", "tlm_gauss3", "lstm_gauss33", "lstm_var00"]
+# started from `--seed 1111` alone; the `noisy` ones sample their weights every step: BLM_NOISE_SOURCE=torch in the environment of the
+# unchanged script makes the shim draw each eps from torch's generator as the reference's own modules would have
+FROM_SEED = ["seed_lstm_none", "seed_tlm_gauss3", "seed_noisy_lstm_bayes3", "seed_noisy_lstm_var11", "seed_noisy_tlm_bayes_emb"]
 
 
-@pytest.mark.parametrize("tag", TRAJECTORIES)
-def test_shim_under_the_reference_loop_reproduces_train_py(tag, tmp_path):
+@pytest.mark.parametrize("tag", TRAJECTORIES + FROM_SEED)
+def test_shim_under_the_reference_loop_reproduces_train_py(tag, tmp_path, monkeypatch):
     import argparse
     z, a, init, snaps = load_traj(tag)
+    if "noisy" in tag:
+        monkeypatch.setenv("BLM_NOISE_SOURCE", "torch")
     d = str(tmp_path)
     write_corpus(z, d)
     args = argparse.Namespace(model=a["model"], emsize=int(a["emsize"]), nhid=int(a["nhid"]), nlayers=int(a["nlayers"]),
@@ -188,7 +199,9 @@ def test_shim_under_the_reference_loop_reproduces_train_py(tag, tmp_path):
                               epochs=int(a["epochs"]), log_interval=int(a["log_interval"]), uncertainty=a["uncertainty"],
                               T_bayes_pos=a.get("T_bayes_pos", "none"), L_bayes_pos=int(a.get("L_bayes_pos", 0)),
                               L_gauss_pos=a.get("L_gauss_pos", "00"), L_v_pos=a.get("L_v_pos", "11"),
-                              T_gauss_pos=int(a.get("T_gauss_pos", 3)), T_v_pos=int(a.get("T_v_pos", 0)))
+                              T_gauss_pos=int(a.get("T_gauss_pos", 3)), T_v_pos=int(a.get("T_v_pos", 0)),
+                              seed=int(a["seed"]) if tag.startswith("seed_") else None)
+    assert bool(init) != tag.startswith("seed_")
     hist = reference_shaped_run(args, d, init, torch.device("cuda:0"))
     assert list(hist["halved_epochs"]) == list(z["halved_epochs"]), (hist["valid_loss"], list(z["valid_loss"]))
     assert np.allclose(hist["valid_loss"], z["valid_loss"], rtol=1e-4), (hist["valid_loss"], list(z["valid_loss"]))

@@ -83,12 +83,18 @@ def test_baseline_transformer_layers_start_as_copies_of_layer_0():
     assert l0._site_base != l2._site_base  # each copy still has its own dropout / noise stream ids
 
 
-def test_noise_source_torch_draws_eps_as_the_reference_does():
+def test_noise_source_torch_draws_eps_as_the_reference_does(monkeypatch):
     """``set_noise_source("torch")`` (train --noise-source torch): the eps of a variational tensor is ONE
     ``zeros(shape).normal_()`` from torch's CPU generator at the moment the forward asks for it -- the reference's own call
     (model.py:1087, :671) -- so the value equals what the reference would have drawn from the same generator state; the default
     stays the Philox stream (no eps tensor on the host).  No kernel is launched here."""
     from bayeslms_amd import train as TR
+    monkeypatch.setenv("BLM_NOISE_SOURCE", "torch")  # the switch an unchanged reference script is given from outside
+    assert M.RNNModel("LSTM", 50, 12, 12, 2, 0.0, True).noise_state.source == "torch"
+    monkeypatch.setenv("BLM_NOISE_SOURCE", "numpy")
+    with pytest.raises(ValueError):
+        M.RNNModel("LSTM", 50, 12, 12, 2, 0.0, True)
+    monkeypatch.delenv("BLM_NOISE_SOURCE")
     torch.manual_seed(5)
     m = M.BayesTransformerModel(50, 16, 4, 32, 2, 0.0, True, "FFN")
     lin2 = m.transformerlayers[0].linear2
@@ -113,4 +119,4 @@ def test_noise_source_torch_draws_eps_as_the_reference_does():
     torch.manual_seed(3)
     assert torch.equal(v.rnn.rnn[0].vnn.noise_rows(4), want)
     args = TR.build_parser().parse_args(["--noise-source", "torch"])
-    assert args.noise_source == "torch" and TR.build_parser().parse_args([]).noise_source == "philox"
+    assert args.noise_source == "torch" and TR.build_parser().parse_args([]).noise_source is None  # None: BLM_NOISE_SOURCE or philox
