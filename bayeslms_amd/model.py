@@ -50,8 +50,10 @@ class NoiseState:
         self.auto_step = True
         # "philox" (default): eps / dropout from the counter-based streams keyed by (seed, site, step).  "torch": the variational
         # eps of the Bayesian and Variational families is drawn from torch's CPU generator exactly as the reference draws it
-        # (``new_zeros(shape).normal_(0, std)`` per tensor, in its order) and uploaded -- a parity mode: with dropout 0 a run
-        # from the same ``--seed`` then sees the reference's own noise (train --noise-source torch); dropout stays Philox
+        # (``new_zeros(shape).normal_(0, std)`` per tensor, in its order) and uploaded, and the dropout masks of the LSTM language
+        # models (embedding, nn.LSTM's inter-layer, output: model.py:217-221) are the ones torch's CPU dropout draws -- a parity
+        # mode: a run from the same ``--seed`` then sees the reference's own noise (train --noise-source torch).  The
+        # Transformers' dropout sites live inside fused kernels (attention probabilities among them) and stay Philox
         self.source = os.environ.get("BLM_NOISE_SOURCE", "philox")  # an unchanged reference script selects it from outside
         if self.source not in ("philox", "torch"):
             raise ValueError("BLM_NOISE_SOURCE must be 'philox' or 'torch', not %r" % self.source)
@@ -73,6 +75,25 @@ class _Site(nn.Module):
             return ops.NO_DROP
         return Drop(float(p), st.seed, self._site_base + k, st.step, st.col_offset, st.global_cols)
 
+    def _torch_drop(self, p):
+        """Is this dropout site served by torch's generator in the current forward?  (NoiseState.source "torch", LSTM families.)"""
+        st = self._st()
+        return st.source == "torch" and self.training and p > 0.0 and not st.dropout_off
+
+    def _dropout(self, x, p, k=0):
+        """drop(x) at dropout site k of this module: the engine's kernel with the Philox mask, or -- NoiseState.source "torch" --
+        x times the mask torch's CPU dropout would have drawn here (a parity mode: the mask crosses the bus every step)."""
+        if self._torch_drop(p):
+            st = self._st()
+            return x * torch_dropout_mask(x.shape, p, x.device, st.col_offset, st.global_cols)
+        return ops.dropout(x, self._drop(p, k))
+
+    def _embed_dropout(self, ids, weight, p, k=0):
+        """drop(embedding(ids)) of the LSTM language models (model.py:217-219): one fused launch, or gather then torch's mask."""
+        if self._torch_drop(p):
+            return self._dropout(ops.embed(ids, weight, None, 1.0, ops.NO_DROP), p, k)
+        return ops.embed(ids, weight, None, 1.0, self._drop(p, k))
+
     def _noise(self, k=0, override=None, like=None):
         """NoiseSpec of variational tensor k of this module, or None in eval mode (mean weights).  ``like``: the log-sigma tensor
         the draw belongs to -- under NoiseState.source "torch" the eps is drawn here, now, from torch's CPU generator the way
@@ -91,6 +112,16 @@ def torch_eps(shape, device, std=1.0):
     """One eps tensor from torch's CPU generator, drawn as the reference draws it on the CPU path (same call, same shape, so the
     same values from the same generator state), then moved to the device."""
     return torch.zeros(*shape).normal_(0, std).to(device)
+
+
+def torch_dropout_mask(shape, p, device, col_offset=0, global_cols=0):
+    """The mask (0 or 1 / (1 - p)) torch's CPU dropout would have applied to a (T, B, D) tensor: ``torch.dropout`` on ones, i.e. the
+    same bernoulli_ of the same shape from the same generator (nn.Dropout and nn.LSTM's inter-layer dropout both end there).  Under
+    data parallelism the reference's single process would have drawn the mask of the GLOBAL batch: every rank draws that and keeps
+    its columns [col_offset, col_offset + B)."""
+    T, B, D = shape
+    full = torch.dropout(torch.ones(T, max(int(global_cols), B), D), float(p), True)
+    return full[:, col_offset:col_offset + B].contiguous().to(device)
 
 
 def _advance_step(module, _inputs, _output):
@@ -496,9 +527,20 @@ class GPNN(_Site):
         """-> (weights, bias, coef) of this forward: the mean tensors, or -- training with ``sample`` raised -- every
         tensor that has an lgstd as mean + exp(lgstd) * eps.  All draws of the module in ONE launch per direction
         (ops.variational_group: the samples forward, d mean / d lgstd backward)."""
+        drawn = None
+        if self._st().source == "torch" and self.gpnn_type in (1, 2, 3):
+            # the reference's sample_parameters() of this forward (model.py:1853-1861; called by the enclosing layer / cell in train
+            # AND eval mode, :1721-1723, :2280-2281): coef, weights, bias from torch's CPU generator -- used below when sampling,
+            # dropped otherwise, but the generator moves either way (what draws next, e.g. a dropout mask, sees the same state)
+            drawn = {}
+            if self.gpnn_type in (1, 3):
+                drawn["coef"] = torch_eps(self.coef_mean.shape, "cpu")
+            if self.gpnn_type in (2, 3):
+                drawn["weights"] = torch_eps(self.weights_mean.shape, "cpu")
+                drawn["bias"] = torch_eps(self.bias_mean.shape, "cpu")
         if not self.sampling():
             return self.weights_mean, self.bias_mean, self.coef_mean
-        e = self.eps_override or {}
+        e = self.eps_override or {k: v.to(self.weights_mean.device) for k, v in (drawn or {}).items()}
         names = (["coef"] if self.gpnn_type in (1, 3) else []) + (["weights", "bias"] if self.gpnn_type in (2, 3) else [])
         ids = {"coef": 0, "weights": 1, "bias": 2}
         specs = [(getattr(self, n + "_mean"), getattr(self, n + "_lgstd"), self._noise(ids[n], e.get(n)), 0, 0.0, 0.0)
@@ -953,9 +995,9 @@ class BayesRNNModel(_RNNLM):
         self.noise_state = bind_state(self, NoiseState())
 
     def forward(self, x, hidden):
-        emb = ops.embed(x, self.encoder.weight, None, 1.0, self._drop(self.p, 0))
+        emb = self._embed_dropout(x, self.encoder.weight, self.p, 0)
         out, hidden = self.rnn(emb, hidden)
-        out = ops.dropout(out, self._drop(self.p, 1))
+        out = self._dropout(out, self.p, 1)
         return self.decoder(out), hidden
 
 
@@ -975,7 +1017,7 @@ class _LSTMParams(_Site):
 
     def forward(self, x, hx):
         h0, c0 = hx
-        if self.nlayers == 2:
+        if self.nlayers == 2 and not self._torch_drop(self.p):  # torch's mask covers a whole layer output: the layers run one after the other
             l1 = tuple(getattr(self, "%s_l0" % n) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
             l2 = tuple(getattr(self, "%s_l1" % n) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
             if ops.lstm_stack2_ok(x, l1[1], l2[1], l2[0]):  # wavefront on two streams, inter-layer dropout per chunk
@@ -985,8 +1027,8 @@ class _LSTMParams(_Site):
         for k in range(self.nlayers):
             x, h, c = ops.lstm_layer(x, h0[k], c0[k], getattr(self, "weight_ih_l%d" % k), getattr(self, "weight_hh_l%d" % k),
                                      getattr(self, "bias_ih_l%d" % k), getattr(self, "bias_hh_l%d" % k))
-            if k + 1 < self.nlayers:
-                x = ops.dropout(x, self._drop(self.p, k))
+            if k + 1 < self.nlayers:  # nn.LSTM's inter-layer dropout: on every layer's output but the last
+                x = self._dropout(x, self.p, k)
             hs.append(h)
             cs.append(c)
         return x, (torch.stack(hs), torch.stack(cs))
@@ -1007,9 +1049,9 @@ class RNNModel(_RNNLM):
         self.noise_state = bind_state(self, NoiseState())
 
     def forward(self, x, hidden):
-        emb = ops.embed(x, self.encoder.weight, None, 1.0, self._drop(self.p, 0))
+        emb = self._embed_dropout(x, self.encoder.weight, self.p, 0)
         out, hidden = self.rnn(emb, hidden)
-        out = ops.dropout(out, self._drop(self.p, 1))
+        out = self._dropout(out, self.p, 1)
         return self.decoder(out), hidden
 
 
@@ -1228,9 +1270,9 @@ class GaussRNNModel(_RNNLM):
         self.noise_state = bind_state(self, NoiseState())
 
     def forward(self, x, hidden):
-        emb = ops.embed(x, self.encoder.weight, None, 1.0, self._drop(self.p, 0))
+        emb = self._embed_dropout(x, self.encoder.weight, self.p, 0)
         out, hidden = self.rnn(emb, hidden)
-        out = ops.dropout(out.contiguous(), self._drop(self.p, 1))
+        out = self._dropout(out.contiguous(), self.p, 1)
         return self.decoder(out), hidden
 
 
@@ -1327,7 +1369,7 @@ class VariationalRNNModel(_RNNLM):
         self.noise_state = bind_state(self, NoiseState())
 
     def forward(self, x, hidden):
-        emb = ops.embed(x, self.encoder.weight, None, 1.0, self._drop(self.p, 0))
+        emb = self._embed_dropout(x, self.encoder.weight, self.p, 0)
         out, hidden = self.rnn(emb, hidden)
-        out = ops.dropout(out.contiguous(), self._drop(self.p, 1))
+        out = self._dropout(out.contiguous(), self.p, 1)
         return self.decoder(out), hidden

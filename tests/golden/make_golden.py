@@ -564,6 +564,16 @@ def f6_train_trajectory(seed_only=False):
                                "--L_bayes_pos", "3"], None),
         ("noisy_lstm_var11", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Variational",
                               "--L_v_pos", "11"], None),
+        # ... and WITH dropout 0.2 as well (the LSTM language models: embedding, nn.LSTM's inter-layer and output dropout all draw
+        # their masks through torch's CPU dropout; a later --dropout wins over the common 0.0)
+        ("noisy_drop_lstm_none", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "none",
+                                  "--dropout", "0.2"], None),
+        ("noisy_drop_lstm_bayes3", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Bayesian",
+                                    "--L_bayes_pos", "3", "--dropout", "0.2"], None),
+        ("noisy_drop_lstm_gauss33", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Gaussian",
+                                     "--L_gauss_pos", "33", "--dropout", "0.2"], None),
+        ("noisy_drop_lstm_var11", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Variational",
+                                   "--L_v_pos", "11", "--dropout", "0.2"], None),
     ):
         if (seed_only and tag not in ("lstm_none", "tlm_gauss3", "lstm_gauss33") and build is not None) or (not seed_only and build is None):
             continue

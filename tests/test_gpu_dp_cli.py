@@ -85,9 +85,10 @@ def test_two_rank_cli_from_the_seed_alone_follows_the_references_noisy_run(tmp_p
     """Data parallel AND weight noise AND no saved state: `torchrun ... -m bayeslms_amd.train --seed 1111 --noise-source torch`
     with two ranks (every rank seeds torch's generator the same way, builds the same model and draws the same eps; each trains its
     columns of the global batch) against the reference's single-process `train.py --seed 1111` run of the Bayesian LSTM
-    (--L_bayes_pos 3, eight weight draws per forward): the same valid / test losses (1e-4), LR-halving epochs and final
-    checkpoint (1e-3) as the reference and as the single-process CLI."""
-    z, args, init, snaps = load_traj("seed_noisy_lstm_bayes3")
+    (--L_bayes_pos 3, eight weight draws per forward) WITH --dropout 0.2 (every rank draws the dropout mask of the global batch,
+    as the reference's one process would have, and keeps its columns): the same valid / test losses (1e-4), LR-halving epochs
+    and final checkpoint (1e-3) as the reference and as the single-process CLI."""
+    z, args, init, snaps = load_traj("seed_noisy_drop_lstm_bayes3")
     assert not init and int(args["batch_size"]) % 2 == 0
     d = str(tmp_path)
     write_corpus(z, d)

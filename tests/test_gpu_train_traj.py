@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_train_traj_oracle import NOISY_SEED_TAGS, SEED_TAGS, TAGS, load_traj, write_corpus
+from test_train_traj_oracle import DROP_SEED_TAGS, NOISY_SEED_TAGS, SEED_TAGS, TAGS, load_traj, write_corpus
 
 pytestmark = pytest.mark.gpu
 
@@ -40,7 +40,7 @@ def test_train_cli_reproduces_reference_train_py_trajectory(tag, tmp_path, capsy
         assert out.count("tensor([") == len(z["valid_loss"]) + 1  # the coef_mean print, per epoch and at the end
 
 
-@pytest.mark.parametrize("tag", SEED_TAGS + NOISY_SEED_TAGS)
+@pytest.mark.parametrize("tag", SEED_TAGS + NOISY_SEED_TAGS + DROP_SEED_TAGS)
 def test_train_cli_from_the_seed_alone_reproduces_reference_train_py(tag, tmp_path, capsys, monkeypatch):
     """No --prior: the reference's train.py and this CLI are both started with `--seed 1111` and nothing else in common but the
     corpus and the flags.  The constructors draw from torch's generator in the reference's order (tests/test_init_state_cpu.py)
@@ -49,7 +49,8 @@ def test_train_cli_from_the_seed_alone_reproduces_reference_train_py(tag, tmp_pa
     The ``noisy`` runs sample their Bayesian / Variational weights in every training step (dropout 0): under
     ``--noise-source torch`` the CLI draws each eps from torch's CPU generator with the reference's own calls, in its order (one per
     Bayesian tensor and forward; eight per Bayes2LSTM forward; one (1, H) row per time step and noisy cell), so the run sees the
-    reference's noise and follows it just the same."""
+    reference's noise and follows it just the same.  The ``drop`` runs add --dropout 0.2: the LSTM language models' dropout masks
+    (embedding, inter-layer, output) are then the ones torch's CPU dropout draws from that generator, too."""
     from bayeslms_amd import train as T
     z, args, init, snaps = load_traj(tag)
     assert not init and "prior" not in args and args["seed"] == "1111"

@@ -22,6 +22,10 @@ NOISY_SEED_TAGS = ["seed_noisy_tlm_bayes_emb", "seed_noisy_lstm_bayes3", "seed_n
                    # the headline family and its MHA sibling, recorded with the HARNESS building every nn.Dropout of the reference run
                    # with p = 0 (fixture field zero_dropout; make_golden.py PROBE_ZERO_DROPOUT): the weight noise alone
                    "seed_noisy_tlm_bayes_ffn_nodrop", "seed_noisy_tlm_bayes_mha_nodrop"]
+# ... and with --dropout 0.2 on top: the LSTM language models' three dropout sites (embedding, nn.LSTM's inter-layer, output) draw
+# their masks through torch's CPU dropout from the same generator; the Gaussian cell's per-forward sample_parameters() draws
+# (dropped, train.py never raises GPNN.sample) move it as well
+DROP_SEED_TAGS = ["seed_noisy_drop_lstm_none", "seed_noisy_drop_lstm_bayes3", "seed_noisy_drop_lstm_gauss33", "seed_noisy_drop_lstm_var11"]
 
 
 def load_traj(tag):
@@ -65,6 +69,9 @@ def noisy_family(args):
     Bayesian embedding projection (model.py:1243-1248), eight per Bayes2LSTM forward (:668-703), one (1, H) row of N(0, 0.1) per
     time step and noisy cell, cell 0's T rows before cell 1's (:2555-2561, :2503-2507)."""
     from oracle import bayes_oracle as O
+    if args["uncertainty"] == "none":  # the plain LSTM with its three dropout sites (masks from torch's generator, as the reference's)
+        p = float(args["dropout"])
+        return (lambda sd, x, h: O.rnn_lm_train(x, h, sd, p) if torch.is_grad_enabled() else O.rnn_lm(x, h, sd)), None, True
     if args["model"] == "Transformer":
         pos, nhead = args["T_bayes_pos"], int(args["nhead"])
         lg = {"EMB": "embed_lgstd", "FFN": "transformerlayers.0.linear2.weight_lgstd", "MHA": "transformerlayers.0.self_attn.o_net.weight_lgstd"}[pos]
@@ -92,7 +99,7 @@ def noisy_family(args):
     return fwd, (lambda sd: held["kl"]), True  # train.py:379-382: the KL of the forward that has just run
 
 
-@pytest.mark.parametrize("tag", TAGS + SEED_TAGS + NOISY_SEED_TAGS)
+@pytest.mark.parametrize("tag", TAGS + SEED_TAGS + NOISY_SEED_TAGS + DROP_SEED_TAGS[:1])
 def test_oracle_training_loop_matches_reference_train_py(tag, tmp_path):
     from bayeslms_amd import data as D
     from oracle import bayes_oracle as O, train_oracle as TO
