@@ -114,6 +114,8 @@ SIGNATURES = {
     "blm_attn_bwd_ws": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _rngp, _i, _i, _vp,
                             _i64, _vp]),
     "blm_attn_bwd_ws_floats": (_i64, [_i, _i, _i, _i]),
+    "blm_attn_fwd_keep": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "blm_attn_bwd_keep": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "blm_ce_fwd_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "blm_ce_interp_fwd": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _i, _i, _vp]),
     "blm_linear_nll_ws_floats": (_i64, [_i, _i]),

@@ -32,10 +32,12 @@ struct AttnP {
   float inv_keep;
   int col_offset;
   bool drop;
+  const float* keep;  // blm_attn_*_keep: the dropout factors themselves, (B_global * nhead, T, T) floats (0 or 1 / (1 - p)), instead of the Philox stream
 };
 
 // keep factor for probability element g (global index into (B_global*nhead, T, T))
 __device__ __forceinline__ float keep_at(const AttnP& p, uint64_t g) {
+  if (p.keep) return p.keep[g];  // wave-uniform branch
   const u32x4 u = philox_block(p.rng, g >> 2);
   const int c = (int)(g & 3);
   const uint32_t bits = c == 0 ? u.x : (c == 1 ? u.y : (c == 2 ? u.z : u.w));
@@ -420,6 +422,33 @@ static bool use_mfma(int head_dim) {  // option "attn_valu" = 1: the vector-ALU 
     default: hipLaunchKernelGGL(KERN<64>, dim3(B * nhead), dim3(ATT_T), LDS, st, p); break;                       \
   }
 
+// the vector-ALU kernels: LDS-tiled for T <= 128 and power-of-two heads, one wave per query otherwise
+static int launch_fwd_valu(const AttnP& p, int T, int B, int nhead, int head_dim, hipStream_t st) {
+  if (!tiled_ok(T, head_dim)) {  // any other head size / longer sequences: one wave per query
+    hipLaunchKernelGGL(attn_fwd_generic_kernel, dim3(T, B * nhead), dim3(64), 0, st, p, head_dim);
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
+  }
+  const size_t lds = (size_t)2 * T * head_dim * sizeof(float);
+  DISPATCH_HD(attn_fwd_kernel, lds)
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
+static int launch_bwd_valu(const AttnP& p, int T, int B, int nhead, int head_dim, hipStream_t st) {
+  if (!tiled_ok(T, head_dim)) {
+    hipLaunchKernelGGL(attn_bwd_dq_generic_kernel, dim3(T, B * nhead), dim3(64), 0, st, p, head_dim);
+    BLM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(attn_bwd_dkv_generic_kernel, dim3(T, B * nhead), dim3(64), 0, st, p, head_dim);
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
+  }
+  const size_t lds = ((size_t)2 * T * head_dim + 2 * T) * sizeof(float);
+  DISPATCH_HD(attn_bwd_kernel, lds)
+  BLM_HIP(hipGetLastError());
+  return BLM_OK;
+}
+
 extern "C" int blm_attn_fwd(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, float* lse,
                             int T, int B, int nhead, int head_dim, float pdrop, const blm_rng* rng, int col_offset,
                             int global_cols, void* stream) {
@@ -433,15 +462,25 @@ extern "C" int blm_attn_fwd(const float* q, const float* k, const float* v, int6
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (use_mfma(head_dim)) return blm_attn_fwd_mfma(q, k, v, ld_qkv, out, lse, T, B, nhead, pdrop, rng, col_offset, st);
   p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.out = out; p.lse = lse;
-  if (!tiled_ok(T, head_dim)) {  // any other head size / longer sequences: one wave per query
-    hipLaunchKernelGGL(attn_fwd_generic_kernel, dim3(T, B * nhead), dim3(64), 0, st, p, head_dim);
-    BLM_HIP(hipGetLastError());
-    return BLM_OK;
-  }
-  const size_t lds = (size_t)2 * T * head_dim * sizeof(float);
-  DISPATCH_HD(attn_fwd_kernel, lds)
-  BLM_HIP(hipGetLastError());
-  return BLM_OK;
+  return launch_fwd_valu(p, T, B, nhead, head_dim, st);
+}
+
+// The dropout factors of the probabilities handed over instead of generated: keep (global_cols * nhead, T, T), 0 or 1 / (1 - p), head
+// index (col_offset + b) * nhead + head as in the reference's (B * h, T, T) probabilities (model.py:905-914).  A parity path
+// (NoiseState.source "torch": the mask torch's CPU dropout drew); always the vector-ALU kernels.
+extern "C" int blm_attn_fwd_keep(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, float* lse, int T, int B,
+                                 int nhead, int head_dim, const float* keep, int col_offset, int global_cols, void* stream) {
+  if (!q || !k || !v || !out || !keep || col_offset < 0 || B < 0 || (long)global_cols < (long)col_offset + B)
+    return blm_fail(BLM_ERR_INVALID, "blm_attn_fwd_keep: bad arguments");
+  AttnP p{};
+  int rc = fill(p, T, B, nhead, head_dim, 0.f, nullptr, col_offset, "blm_attn_fwd_keep");
+  if (rc) return rc;
+  if (ld_qkv < (int64_t)nhead * head_dim) return blm_fail(BLM_ERR_INVALID, "blm_attn_fwd_keep: ld_qkv too small");
+  if (!blm::extents_ok({global_cols, nhead, T, T})) return blm_fail(BLM_ERR_INVALID, "blm_attn_fwd_keep: extents");
+  if ((long)T * B == 0) return BLM_OK;
+  p.drop = true; p.keep = keep;
+  p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.out = out; p.lse = lse;
+  return launch_fwd_valu(p, T, B, nhead, head_dim, static_cast<hipStream_t>(stream));
 }
 
 int blm_attn_fwd_rows_mfma(const float* q, const float* k, const float* v, int64_t ld, float* out, const int* rowmap, int T, int B,
@@ -488,15 +527,23 @@ extern "C" int blm_attn_bwd_ws(const float* q, const float* k, const float* v, i
   }
   p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.o_in = out; p.dout = dout; p.lse = const_cast<float*>(lse);
   p.dq = dq; p.dk = dk; p.dv = dv; p.ldd = ld_dqkv;
-  if (!tiled_ok(T, head_dim)) {
-    hipLaunchKernelGGL(attn_bwd_dq_generic_kernel, dim3(T, B * nhead), dim3(64), 0, st, p, head_dim);
-    BLM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(attn_bwd_dkv_generic_kernel, dim3(T, B * nhead), dim3(64), 0, st, p, head_dim);
-    BLM_HIP(hipGetLastError());
-    return BLM_OK;
-  }
-  const size_t lds = ((size_t)2 * T * head_dim + 2 * T) * sizeof(float);
-  DISPATCH_HD(attn_bwd_kernel, lds)
-  BLM_HIP(hipGetLastError());
-  return BLM_OK;
+  return launch_bwd_valu(p, T, B, nhead, head_dim, st);
+}
+
+extern "C" int blm_attn_bwd_keep(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out, const float* dout,
+                                 const float* lse, float* dq, float* dk, float* dv, int64_t ld_dqkv, int T, int B, int nhead,
+                                 int head_dim, const float* keep, int col_offset, int global_cols, void* stream) {
+  if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !keep || col_offset < 0 || B < 0 || (long)global_cols < (long)col_offset + B)
+    return blm_fail(BLM_ERR_INVALID, "blm_attn_bwd_keep: bad arguments");
+  AttnP p{};
+  int rc = fill(p, T, B, nhead, head_dim, 0.f, nullptr, col_offset, "blm_attn_bwd_keep");
+  if (rc) return rc;
+  if (ld_qkv < (int64_t)nhead * head_dim || ld_dqkv < (int64_t)nhead * head_dim)
+    return blm_fail(BLM_ERR_INVALID, "blm_attn_bwd_keep: leading dimension too small");
+  if (!blm::extents_ok({global_cols, nhead, T, T})) return blm_fail(BLM_ERR_INVALID, "blm_attn_bwd_keep: extents");
+  if ((long)T * B == 0) return BLM_OK;
+  p.drop = true; p.keep = keep;
+  p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.o_in = out; p.dout = dout; p.lse = const_cast<float*>(lse);
+  p.dq = dq; p.dk = dk; p.dv = dv; p.ldd = ld_dqkv;
+  return launch_bwd_valu(p, T, B, nhead, head_dim, static_cast<hipStream_t>(stream));
 }

@@ -48,12 +48,14 @@ class NoiseState:
         # forward in grad mode moves on to the next step's noise / dropout streams, as torch's generator would.  The first explicit
         # set_step() -- engine.Trainer, the Monte-Carlo scorer, tests -- takes the counter over.
         self.auto_step = True
-        # "philox" (default): eps / dropout from the counter-based streams keyed by (seed, site, step).  "torch": the variational
-        # eps of the Bayesian and Variational families is drawn from torch's CPU generator exactly as the reference draws it
-        # (``new_zeros(shape).normal_(0, std)`` per tensor, in its order) and uploaded, and the dropout masks of the LSTM language
-        # models (embedding, nn.LSTM's inter-layer, output: model.py:217-221) are the ones torch's CPU dropout draws -- a parity
-        # mode: a run from the same ``--seed`` then sees the reference's own noise (train --noise-source torch).  The
-        # Transformers' dropout sites live inside fused kernels (attention probabilities among them) and stay Philox
+        # "philox" (default): eps / dropout from the counter-based streams keyed by (seed, site, step), generated inside the kernels.
+        # "torch": a parity mode -- every draw the reference makes from torch's CPU generator in a training run is made here, by the
+        # same call, in the same order, and uploaded: the variational eps of the Bayesian / Variational / GP families
+        # (``new_zeros(shape).normal_(0, std)`` per tensor; the GPNN's per-forward sample_parameters() draws, used or not; GPNN2's
+        # fresh frequencies at every call) and every dropout mask (``torch.dropout`` on ones: embedding / positional encoding,
+        # nn.LSTM's inter-layer, output, attention probabilities (B * h, T, T), dropout1, feed-forward, dropout2), the blocks then
+        # run unfused with the masks multiplied in between.  A run from the same ``--seed`` then sees the reference's own noise and
+        # follows its CPU run (train --noise-source torch, BLM_NOISE_SOURCE=torch)
         self.source = os.environ.get("BLM_NOISE_SOURCE", "philox")  # an unchanged reference script selects it from outside
         if self.source not in ("philox", "torch"):
             raise ValueError("BLM_NOISE_SOURCE must be 'philox' or 'torch', not %r" % self.source)
@@ -87,6 +89,17 @@ class _Site(nn.Module):
             st = self._st()
             return x * torch_dropout_mask(x.shape, p, x.device, st.col_offset, st.global_cols)
         return ops.dropout(x, self._drop(p, k))
+
+    def _attn_drop(self, p, T, B, nhead, device):
+        """The dropout of the attention probabilities: the Philox site, or -- NoiseState.source "torch" -- the mask torch's CPU
+        dropout draws for the reference's (B * h, T, T) probability tensor (model.py:905-914), handed to the vector-ALU attention
+        kernels as it is (under data parallelism: the global batch's heads, this rank's window selected by col_offset)."""
+        if self._torch_drop(p):
+            st = self._st()
+            G = max(int(st.global_cols), B)
+            keep = torch.dropout(torch.ones(G * nhead, T, T), float(p), True).to(device)
+            return Drop(float(p), col_offset=int(st.col_offset), global_cols=G, keep=keep)
+        return self._drop(p)
 
     def _embed_dropout(self, ids, weight, p, k=0):
         """drop(embedding(ids)) of the LSTM language models (model.py:217-219): one fused launch, or gather then torch's mask."""
@@ -177,7 +190,15 @@ class PositionalEncoding(_Site):
         return self.pe.view(self.pe.shape[0], self.pe.shape[2])
 
     def forward(self, x):
+        if self._torch_drop(self.p):
+            return self._dropout(ops.add_pe(x, self.table(), ops.NO_DROP), self.p)
         return ops.add_pe(x, self.table(), self._drop(self.p))
+
+    def embed(self, src, weight, scale):
+        """drop(embedding(src) * scale + pe): one launch, or -- torch's masks -- the launch without dropout, then the mask."""
+        if self._torch_drop(self.p):
+            return self._dropout(ops.embed(src, weight, self.table(), scale, ops.NO_DROP), self.p)
+        return ops.embed(src, weight, self.table(), scale, self._drop(self.p))
 
 
 class BayesLinear(_Site):
@@ -291,7 +312,7 @@ class MultiheadAttention(_Site):
         if pk is not None:
             a = pk.attention(qkv, None, None, self.num_heads)  # inference: no dropout
         else:
-            a = ops.attention(qkv, self.num_heads, self._drop(self.dropout))
+            a = ops.attention(qkv, self.num_heads, self._attn_drop(self.dropout, qkv.shape[0], qkv.shape[1], self.num_heads, qkv.device))
         return self.o_net(a), None
 
 
@@ -322,7 +343,7 @@ class BayesMultiheadAttention(_Site):
         if pk is not None:
             a = pk.attention(q, k, v, self.num_heads)  # inference: no dropout
         else:
-            a = ops.attention_qkv(q, k, v, self.num_heads, self._drop(self.dropout))
+            a = ops.attention_qkv(q, k, v, self.num_heads, self._attn_drop(self.dropout, q.shape[0], q.shape[1], self.num_heads, q.device))
         return self.o_net(a), None
 
 
@@ -336,7 +357,27 @@ class _PostLNLayer(_Site):
         self.norm2 = nn.LayerNorm(d_model)
         self.p = dropout
 
+    def _forward_torch_masks(self, src, src_mask, inner):
+        """The block with every dropout mask drawn by torch's CPU dropout in the reference's order (NoiseState.source "torch", a
+        parity mode): attention probabilities (inside self_attn; the Bayesian o_net's eps after it), dropout1, the feed-forward's
+        inner dropout (linear2's eps after it), dropout2 (model.py:1160-1176).  Unfused: the engine's products, attention,
+        activation and add + LayerNorm kernels with the masks multiplied in between."""
+        a = self.self_attn(src, src, src, attn_mask=src_mask)[0]
+        x = ops.add_dropout_ln(src, self._dropout(a, self.p, 1), self.norm1.weight, self.norm1.bias, self.norm1.eps, ops.NO_DROP)
+        f = self.linear2(self._dropout(inner(x), self.p, 0))
+        return ops.add_dropout_ln(x, self._dropout(f, self.p, 2), self.norm2.weight, self.norm2.bias, self.norm2.eps, ops.NO_DROP)
+
+    def _gelu_linear1(self, x):
+        """GELU(linear1(x)) as its own tensor: the product, then the activation-mixture kernel with the mixture (0, 0, 0, 1) on
+        (tanh, sigmoid, relu, gelu) -- the erf form, as F.gelu."""
+        z = ops.linear(x, self.linear1.weight, self.linear1.bias)
+        coef = torch.zeros(4, z.shape[-1], device=z.device)
+        coef[3] = 1.0
+        return ops.gp_mix(z, coef)
+
     def forward(self, src, src_mask=None):
+        if self._torch_drop(self.p):
+            return self._forward_torch_masks(src, src_mask, self._gelu_linear1)
         lk1, lk2 = ops.ResidualLink(), ops.ResidualLink()  # residual + branch gradients meet inside the dgrad GEMMs
         a = self.self_attn(src, src, src, attn_mask=src_mask, _link=lk1)[0]
         x = ops.add_dropout_ln(src, a, self.norm1.weight, self.norm1.bias, self.norm1.eps, self._drop(self.p, 1), lk1)
@@ -458,8 +499,7 @@ class BayesTransformerModel(_LMHead):
             x = self.pos_encoder(x)
         else:
             # gather * sqrt(d) + positional table + dropout in one kernel (model.py:1284,1293)
-            x = ops.embed(src, self.encoder.weight, self.pos_encoder.table(), scale,
-                          self.pos_encoder._drop(self.pos_encoder.p))
+            x = self.pos_encoder.embed(src, self.encoder.weight, scale)
         if ops.packing() is not None:
             x = ops.packing().pack(x)
         for layer in self.transformerlayers:
@@ -607,6 +647,8 @@ class GPNN2(_Site):
             ov = self.eps_override
             if isinstance(ov, (list, tuple)):
                 ov = ov[call]
+            if ov is None and self._st().source == "torch":  # the reference's own draw (model.py:2064-2066), from torch's generator
+                ov = torch_eps(self.frequency_lgstd.shape, self.frequency_lgstd.device)
             if ov is not None:
                 noise = NoiseSpec(eps=ov)
             else:
@@ -633,6 +675,8 @@ class GPNN2(_Site):
             ov = self.eps_override
             if isinstance(ov, (list, tuple)):
                 ov = ov[call]
+            if ov is None and self._st().source == "torch":  # one draw per call, in call order (nothing else draws inside the time loop)
+                ov = torch_eps(self.frequency_lgstd.shape, self.frequency_lgstd.device)
             if ov is not None:
                 out.append(NoiseSpec(eps=ov))
             else:
@@ -677,6 +721,9 @@ class GaussTransformerEncoderLayer(_Site):
         self.p = dropout
 
     def forward(self, src, src_mask=None):
+        if self._torch_drop(self.p):
+            # same block, the GPNN (or GPNN2) in GELU(linear1)'s place; its sample_parameters() draws come right before it (model.py:2280-2283)
+            return _PostLNLayer._forward_torch_masks(self, src, src_mask, self.gpnn)
         lk1, lk2 = ops.ResidualLink(), ops.ResidualLink()
         a = self.self_attn(src, src, src, attn_mask=src_mask, _link=lk1)[0]
         x = ops.add_dropout_ln(src, a, self.norm1.weight, self.norm1.bias, self.norm1.eps, self._drop(self.p, 1), lk1)
@@ -716,8 +763,7 @@ class GaussTransformerModel(_LMHead):
     def forward(self, src, has_mask=True):
         if not has_mask:
             raise BayesLMError("has_mask=False: the fused attention kernel is causal only")
-        x = ops.embed(src, self.encoder.weight, self.pos_encoder.table(), math.sqrt(self.ninp),
-                      self.pos_encoder._drop(self.pos_encoder.p))
+        x = self.pos_encoder.embed(src, self.encoder.weight, math.sqrt(self.ninp))
         if ops.packing() is not None:
             x = ops.packing().pack(x)
         for layer in self.transformerlayers:
@@ -774,8 +820,7 @@ class VTransformerModel(_LMHead):
     def forward(self, src, has_mask=True):
         if not has_mask:
             raise BayesLMError("has_mask=False: the fused attention kernel is causal only")
-        x = ops.embed(src, self.encoder.weight, self.pos_encoder.table(), math.sqrt(self.ninp),
-                      self.pos_encoder._drop(self.pos_encoder.p))
+        x = self.pos_encoder.embed(src, self.encoder.weight, math.sqrt(self.ninp))
         for layer in self.transformerlayers:
             x = layer(x, src_mask=True)
         return self.decoder(x)
@@ -799,7 +844,8 @@ class _TorchMHAParams(_Site):
         pk = ops.packing()
         if pk is not None:
             return self.out_proj(pk.attention(qkv, None, None, self.num_heads)), None  # inference: no dropout
-        return self.out_proj(ops.attention(qkv, self.num_heads, self._drop(self.dropout))), None
+        return self.out_proj(ops.attention(qkv, self.num_heads, self._attn_drop(self.dropout, qkv.shape[0], qkv.shape[1], self.num_heads,
+                                                                                qkv.device))), None
 
 
 class _TorchEncoderLayer(_PostLNLayer):
@@ -839,8 +885,7 @@ class TransformerModel(_LMHead):
     def forward(self, src, has_mask=True):
         if not has_mask:
             raise BayesLMError("has_mask=False: the fused attention kernel is causal only")
-        x = ops.embed(src, self.encoder.weight, self.pos_encoder.table(), math.sqrt(self.ninp),
-                      self.pos_encoder._drop(self.pos_encoder.p))
+        x = self.pos_encoder.embed(src, self.encoder.weight, math.sqrt(self.ninp))
         if ops.packing() is not None:
             x = ops.packing().pack(x)
         for layer in self.transformerlayers.layers:

@@ -38,6 +38,7 @@ class Drop:
     step: int = 0
     col_offset: int = 0
     global_cols: int = 0
+    keep: torch.Tensor = None  # attention only (parity mode): the dropout factors of the probabilities themselves, (global_cols * nhead, T, T)
 
     @property
     def on(self):
@@ -775,9 +776,16 @@ class _Attention(torch.autograd.Function):
         lse = torch.empty(B * nhead, T, device=a.device, dtype=torch.float32)
         L.require_gfx950()
         r = drop.rng() if drop.on else None
-        check(lib().blm_attn_fwd(q.data_ptr(), kk.data_ptr(), vv.data_ptr(), ld, ptr(out), ptr(lse), T, B, nhead, hd,
-                                 float(drop.p), C.byref(r) if r is not None else None, drop.col_offset,
-                                 drop.global_cols or B, stream()), "blm_attn_fwd")
+        if drop.keep is not None:  # the mask itself (torch's CPU dropout drew it): the vector-ALU kernels read it
+            keep = _f32(drop.keep, "keep")
+            if keep.numel() != (drop.global_cols or B) * nhead * T * T or not keep.is_contiguous():
+                raise BayesLMError("attention: keep mask must be (global_cols * nhead, T, T) contiguous")
+            check(lib().blm_attn_fwd_keep(q.data_ptr(), kk.data_ptr(), vv.data_ptr(), ld, ptr(out), ptr(lse), T, B, nhead, hd,
+                                          ptr(keep), drop.col_offset, drop.global_cols or B, stream()), "blm_attn_fwd_keep")
+        else:
+            check(lib().blm_attn_fwd(q.data_ptr(), kk.data_ptr(), vv.data_ptr(), ld, ptr(out), ptr(lse), T, B, nhead, hd,
+                                     float(drop.p), C.byref(r) if r is not None else None, drop.col_offset,
+                                     drop.global_cols or B, stream()), "blm_attn_fwd")
         ctx.save_for_backward(q, kk if not packed else None, vv if not packed else None, out, lse)
         ctx.meta = (nhead, drop, packed, d)
         return out
@@ -796,6 +804,11 @@ class _Attention(torch.autograd.Function):
             q, kk, vv, ld = a, k, v, d
             dq, dk, dv = (torch.empty(T, B, d, device=a.device, dtype=torch.float32) for _ in range(3))
             ldd = d
+        if drop.keep is not None:
+            check(lib().blm_attn_bwd_keep(q.data_ptr(), kk.data_ptr(), vv.data_ptr(), ld, ptr(out), ptr(dout), ptr(lse),
+                                          dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ldd, T, B, nhead, d // nhead,
+                                          ptr(drop.keep), drop.col_offset, drop.global_cols or B, stream()), "blm_attn_bwd_keep")
+            return (dqkv, None, None, None, None) if packed else (dq, dk, dv, None, None)
         r = drop.rng() if drop.on else None
         # scratch for dS (B*nhead, T, T): the dK/dV kernel leaves it there, dQ = dS K needs no second recomputation
         nws = int(lib().blm_attn_bwd_ws_floats(T, B, nhead, d // nhead)) if _ATTN_WS else 0

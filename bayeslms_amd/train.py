@@ -60,10 +60,11 @@ def build_parser():
     p.add_argument('--gemm-mode', type=str, default='f32', choices=['f32', 'bf16x6', 'bf16x3'],
                    help='new, optional: opt-in split-bf16 arithmetic of the GEMM family (DESIGN.md section 7); default fp32 MFMA')
     p.add_argument('--noise-source', type=str, default=None, choices=['philox', 'torch'],
-                   help='new, optional: where the variational eps of the Bayesian / Variational families comes from (default: BLM_NOISE_SOURCE or philox).  philox: '
-                        'counter-based streams keyed by (seed, tensor, step), generated on the GPU.  torch: drawn from torch\'s CPU generator '
-                        'exactly as the reference draws it (same calls, same order) and uploaded -- a parity mode: with --dropout 0 a run '
-                        'from the same --seed follows the reference\'s CPU run WITH its weight noise')
+                   help='new, optional: where the noise of a training run comes from (default: BLM_NOISE_SOURCE or philox).  philox: counter-based '
+                        'streams keyed by (seed, tensor / site, step), generated inside the kernels.  torch: a parity mode -- every draw the '
+                        'reference makes from torch\'s CPU generator (variational eps, GP draws, every dropout mask) is made by the same call in '
+                        'the same order and uploaded, the blocks run unfused: a run from the same --seed follows the reference\'s CPU run, '
+                        'noise and dropout on')
     p.add_argument('--deterministic', type=int, default=0,
                    help='new, optional: 1 = every reduction of the engine in a fixed order (ops.set_deterministic / BLM_DETERMINISTIC=1): '
                         'two runs from one seed give bit-identical losses and parameters, also under torchrun at the same world size; '

@@ -387,6 +387,15 @@ int blm_attn_bwd_ws(const float* q, const float* k, const float* v, int64_t ld_q
                     const float* lse, float* dq, float* dk, float* dv, int64_t ld_dqkv, int T, int B, int nhead,
                     int head_dim, float p, const blm_rng* rng, int col_offset, int global_cols, float* ws,
                     int64_t ws_floats, void* stream);
+/* The same attention with the dropout factors of the probabilities HANDED OVER instead of generated from the Philox stream: keep is
+ * (global_cols * nhead, T, T) floats, 0 or 1 / (1 - p), indexed by the head ((col_offset + b) * nhead + head) as the reference's
+ * (B * h, T, T) probability tensor is (model.py:905-914: softmax -> nn.Dropout -> bmm).  A parity path -- the caller passes the mask
+ * torch's CPU dropout drew (NoiseState.source "torch"); always the vector-ALU kernels, any head size / length. */
+int blm_attn_fwd_keep(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, float* lse, int T, int B, int nhead,
+                      int head_dim, const float* keep, int col_offset, int global_cols, void* stream);
+int blm_attn_bwd_keep(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out, const float* dout,
+                      const float* lse, float* dq, float* dk, float* dv, int64_t ld_dqkv, int T, int B, int nhead, int head_dim,
+                      const float* keep, int col_offset, int global_cols, void* stream);
 
 /* Cross entropy over materialised logits (M, V) (train.py:233,332;
  * compute_sentence_scores_bayes_jianwei.py:168):

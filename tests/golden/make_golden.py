@@ -574,6 +574,26 @@ def f6_train_trajectory(seed_only=False):
                                      "--L_gauss_pos", "33", "--dropout", "0.2"], None),
         ("noisy_drop_lstm_var11", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Variational",
                                    "--L_v_pos", "11", "--dropout", "0.2"], None),
+        # the Transformers with --dropout 0.2: positional-encoding, attention-probability, dropout1, feed-forward and dropout2 masks
+        # (for FFN / MHA on top of layer 0's hard-coded 0.2), every one of them torch's CPU dropout
+        ("noisy_drop_tlm_none", lr_t, ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                                 "--uncertainty", "none", "--dropout", "0.2"], None),
+        ("noisy_drop_tlm_bayes_ffn", lr_t, ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                                      "--uncertainty", "Bayesian", "--T_bayes_pos", "FFN", "--dropout", "0.2"], None),
+        ("noisy_drop_tlm_bayes_mha", lr_t, ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                                      "--uncertainty", "Bayesian", "--T_bayes_pos", "MHA", "--dropout", "0.2"], None),
+        ("noisy_drop_tlm_bayes_emb", lr_t, ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                                      "--uncertainty", "Bayesian", "--T_bayes_pos", "EMB", "--dropout", "0.2"], None),
+        ("noisy_drop_tlm_gauss3", lr_t, ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                                   "--uncertainty", "Gaussian", "--T_gauss_pos", "3", "--dropout", "0.2"], None),
+        # GPNN2 (random features: fresh frequencies drawn at EVERY call in train mode, model.py:2064-2066): once per forward in the
+        # Transformer layer, once per time step inside the GP-LSTM cell
+        ("noisy_drop_tlm_gauss4", lr_t, ["--model", "Transformer", "--emsize", "16", "--nhid", "32", "--nlayers", "2", "--nhead", "4",
+                                   "--uncertainty", "Gaussian", "--T_gauss_pos", "4", "--dropout", "0.2"], None),
+        ("noisy_drop_lstm_gauss34", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Gaussian",
+                                     "--L_gauss_pos", "34", "--dropout", "0.2"], None),
+        ("noisy_drop_lstm_gauss74", lr_l, ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty", "Gaussian",
+                                     "--L_gauss_pos", "74", "--dropout", "0.2"], None),
     ):
         if (seed_only and tag not in ("lstm_none", "tlm_gauss3", "lstm_gauss33") and build is not None) or (not seed_only and build is None):
             continue

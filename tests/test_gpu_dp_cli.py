@@ -81,14 +81,16 @@ def test_torchrun_two_rank_cli_equals_one_rank_and_reference_trajectory(tag, tmp
             assert float((f2[k] - v).abs().max()) <= 1e-3 * (float(v.abs().max()) + 1e-12), (world, k)
 
 
-def test_two_rank_cli_from_the_seed_alone_follows_the_references_noisy_run(tmp_path):
+@pytest.mark.parametrize("tag", ["seed_noisy_drop_lstm_bayes3", "seed_noisy_drop_tlm_bayes_ffn"])
+def test_two_rank_cli_from_the_seed_alone_follows_the_references_noisy_run(tag, tmp_path):
     """Data parallel AND weight noise AND no saved state: `torchrun ... -m bayeslms_amd.train --seed 1111 --noise-source torch`
     with two ranks (every rank seeds torch's generator the same way, builds the same model and draws the same eps; each trains its
     columns of the global batch) against the reference's single-process `train.py --seed 1111` run of the Bayesian LSTM
     (--L_bayes_pos 3, eight weight draws per forward) WITH --dropout 0.2 (every rank draws the dropout mask of the global batch,
     as the reference's one process would have, and keeps its columns): the same valid / test losses (1e-4), LR-halving epochs
-    and final checkpoint (1e-3) as the reference and as the single-process CLI."""
-    z, args, init, snaps = load_traj("seed_noisy_drop_lstm_bayes3")
+    and final checkpoint (1e-3) as the reference and as the single-process CLI.  Second case: the headline family (Bayesian
+    Transformer-FFN) with all its dropout sites on -- the attention-probability mask of the global batch's heads included."""
+    z, args, init, snaps = load_traj(tag)
     assert not init and int(args["batch_size"]) % 2 == 0
     d = str(tmp_path)
     write_corpus(z, d)

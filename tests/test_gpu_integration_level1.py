@@ -183,7 +183,8 @@ TRAJECTORIES = ["tlm_none", "lstm_none", "lstm_bayes5", "tlm_gauss3", "lstm_gaus
 # started from `--seed 1111` alone; the `noisy` ones sample their weights every step: BLM_NOISE_SOURCE=torch in the environment of the
 # unchanged script makes the shim draw each eps from torch's generator as the reference's own modules would have
 FROM_SEED = ["seed_lstm_none", "seed_tlm_gauss3", "seed_noisy_lstm_bayes3", "seed_noisy_lstm_var11", "seed_noisy_tlm_bayes_emb",
-             "seed_noisy_drop_lstm_none", "seed_noisy_drop_lstm_bayes3", "seed_noisy_drop_lstm_gauss33"]  # the last three: --dropout 0.2 as well
+             "seed_noisy_drop_lstm_none", "seed_noisy_drop_lstm_bayes3", "seed_noisy_drop_lstm_gauss33",  # --dropout 0.2 as well
+             "seed_noisy_drop_tlm_none", "seed_noisy_drop_tlm_bayes_ffn", "seed_noisy_drop_tlm_gauss3"]
 
 
 @pytest.mark.parametrize("tag", TRAJECTORIES + FROM_SEED)

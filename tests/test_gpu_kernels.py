@@ -688,6 +688,41 @@ def test_attention_dropout_uses_philox_mask(dev, T, B, nhead, hd):
     assert rel(qd.grad, qr.grad) < 2e-5
 
 
+@pytest.mark.parametrize("T,B,nhead,hd", [(8, 2, 2, 4), (96, 2, 2, 64), (128, 1, 2, 64), (160, 2, 1, 64), (30, 2, 2, 100), (131, 1, 1, 32),
+                                          (7, 4, 4, 4)])
+@pytest.mark.parametrize("window", [False, True])
+def test_attention_with_the_dropout_mask_handed_over(dev, T, B, nhead, hd, window):
+    """blm_attn_fwd_keep / blm_attn_bwd_keep (``Drop.keep``): the dropout factors of the probabilities are an operand -- the
+    (B_global * nhead, T, T) tensor torch's CPU dropout drew for the reference's probabilities (NoiseState.source "torch") --
+    instead of the Philox stream.  LDS-tiled and one-wave-per-query vector-ALU kernels (head_dim 64 included: the matrix-core
+    kernels only know the stream); ``window``: this rank holds columns [1, 1 + B) of a global batch of B + 2."""
+    ops = ops_mod()
+    p = 0.3
+    d = nhead * hd
+    G, off = (B + 2, 1) if window else (B, 0)
+    g = torch.Generator().manual_seed(T + hd)
+    torch.manual_seed(T)
+    keep_all = torch.dropout(torch.ones(G * nhead, T, T), p, True)
+    keep = keep_all[off * nhead:(off + B) * nhead]
+    qkv = torch.randn(T, B, 3 * d, generator=g)
+    qd = qkv.to(dev).requires_grad_(True)
+    out = ops.attention(qd, nhead, ops.Drop(p, col_offset=off, global_cols=G, keep=keep_all.to(dev)))
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = qr.chunk(3, dim=-1)
+    qh = (q * hd ** -0.5).contiguous().view(T, B * nhead, hd).transpose(0, 1)
+    kh = k.contiguous().view(T, B * nhead, hd).transpose(0, 1)
+    vh = v.contiguous().view(T, B * nhead, hd).transpose(0, 1)
+    pr = torch.softmax(torch.bmm(qh, kh.transpose(1, 2)) + O.causal_mask(T), -1) * keep
+    ref = torch.bmm(pr, vh).transpose(0, 1).contiguous().view(T, B, d)
+    assert rel(out, ref) < 1e-5
+    go = torch.randn(T, B, d, generator=g)
+    out.backward(go.to(dev))
+    ref.backward(go)
+    assert rel(qd.grad, qr.grad) < 2e-5
+    with pytest.raises(Exception):  # a mask of another size is refused
+        ops.attention(qd, nhead, ops.Drop(p, col_offset=off, global_cols=G, keep=keep_all[:-1].contiguous().to(dev)))
+
+
 @pytest.mark.parametrize("T,B,nhead,p", [(128, 4, 8, 0.2), (128, 3, 1, 0.0), (97, 1, 3, 0.3), (50, 3, 2, 0.4), (33, 2, 2, 0.0),
                                          (1, 1, 1, 0.0), (64, 2, 2, 0.1), (130, 2, 2, 0.2), (100, 64, 8, 0.2)])
 def test_attention_backward_workspace_path_equals_recomputation(dev, monkeypatch, T, B, nhead, p):

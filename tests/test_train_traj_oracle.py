@@ -25,7 +25,14 @@ NOISY_SEED_TAGS = ["seed_noisy_tlm_bayes_emb", "seed_noisy_lstm_bayes3", "seed_n
 # ... and with --dropout 0.2 on top: the LSTM language models' three dropout sites (embedding, nn.LSTM's inter-layer, output) draw
 # their masks through torch's CPU dropout from the same generator; the Gaussian cell's per-forward sample_parameters() draws
 # (dropped, train.py never raises GPNN.sample) move it as well
-DROP_SEED_TAGS = ["seed_noisy_drop_lstm_none", "seed_noisy_drop_lstm_bayes3", "seed_noisy_drop_lstm_gauss33", "seed_noisy_drop_lstm_var11"]
+DROP_SEED_TAGS = ["seed_noisy_drop_lstm_none", "seed_noisy_drop_lstm_bayes3", "seed_noisy_drop_lstm_gauss33", "seed_noisy_drop_lstm_var11",
+                  # the Transformers: positional-encoding, attention-probability (B * h, T, T), dropout1, feed-forward and dropout2 masks,
+                  # layer 0's hard-coded 0.2 of --T_bayes_pos FFN / MHA included
+                  "seed_noisy_drop_tlm_none", "seed_noisy_drop_tlm_bayes_ffn", "seed_noisy_drop_tlm_bayes_mha", "seed_noisy_drop_tlm_bayes_emb",
+                  "seed_noisy_drop_tlm_gauss3",
+                  # GPNN2 random features: fresh frequencies at every call -- once per forward in the Transformer layer, once per
+                  # time step inside the GP-LSTM cell (gate 3: on the cell gate; gate 7: the input projection)
+                  "seed_noisy_drop_tlm_gauss4", "seed_noisy_drop_lstm_gauss34", "seed_noisy_drop_lstm_gauss74"]
 
 
 def load_traj(tag):
