@@ -517,6 +517,55 @@ np.savez(out, **kw)
 """
 
 
+def f6_headline_from_seed():
+    """BASELINE.json configs[2] AT ITS REAL SIZE under the reference's own train.py, the recipe's flags (Bayesian Transformer-FFN, 6
+    layers, d_model 512, d_ff 4096, 8 heads, 33,000 words, tied, dropout 0.2, clip 1.0, batch 64 x seq_len 128), started from
+    ``--seed 1111`` alone: three training steps of 8,192 tokens with weight noise and every dropout site on, then its
+    evaluate() on the valid and test text.  Kept: the corpus, the total loss of every step, valid and test loss (no parameters:
+    the model is what the seed gives).  ~50 M parameters on the CPU: a few minutes."""
+    import subprocess
+    V, B, T, steps = 33000, 64, 128, 3
+    rng = np.random.RandomState(20)
+    words = ["<s>", "<unk>"] + ["w%d" % i for i in range(V - 2)]
+
+    def text(ntok):
+        lines, left = [], ntok
+        while left > 0:
+            n = min(left, int(rng.randint(3, 30)))
+            ids = 2 + np.minimum((rng.pareto(1.1, n) * 40).astype(np.int64), V - 3)  # heavy tail over the vocabulary
+            lines.append(" ".join(words[i] for i in ids))
+            left -= n + 1  # + the <s> the tokenizer appends
+        return lines
+    texts = {"train": text(B * (steps * T + 1) + 40), "valid": text(20 * (T + 1) + 30), "test": text(20 * (T + 1) + 30)}
+    margs = ["--model", "Transformer", "--emsize", "512", "--nhid", "4096", "--nlayers", "6", "--nhead", "8", "--uncertainty", "Bayesian",
+             "--T_bayes_pos", "FFN", "--dropout", "0.2", "--clip", "1.0", "--lr", "0.1", "--batch-size", str(B), "--seq_len", str(T),
+             "--epochs", "1", "--tied", "--log-interval", "1", "--seed", "1111"]
+    with tempfile.TemporaryDirectory() as dtmp:
+        with open(os.path.join(dtmp, "words.txt"), "w") as f:
+            for i, w in enumerate(words):
+                f.write("%s %d\n" % (w, i))
+        for k, lines in texts.items():
+            with open(os.path.join(dtmp, k + ".txt"), "w") as f:
+                f.write("\n".join(lines) + "\n")
+        probe = os.path.join(dtmp, "probe.py")
+        open(probe, "w").write(_TRAIN_PROBE.replace('rec["snaps"].append(', 'os.environ.get("PROBE_NO_SNAPS") or rec["snaps"].append('))
+        out_npz = os.path.join(dtmp, "rec.npz")
+        cmd = [sys.executable, probe, os.path.join(REF, "train.py"), out_npz, "--data", dtmp, "--save", os.path.join(dtmp, "model.pt")] + margs
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=REF, OMP_NUM_THREADS="8", PROBE_NO_SNAPS="1")
+        run = subprocess.run(cmd, cwd=dtmp, env=env, capture_output=True, text=True)
+        assert run.returncode == 0, run.stderr[-3000:]
+        z = np.load(out_npz)
+        ppl = [ln for ln in run.stdout.splitlines() if " ppl " in ln]
+        assert len(ppl) == len(z["exp"]) and len(z["bwd"]) == steps, (len(ppl), len(z["exp"]), len(z["bwd"]))
+        valid = [v for ln, v in zip(ppl, z["exp"]) if "end of epoch" in ln]
+        test = [v for ln, v in zip(ppl, z["exp"]) if "End of training" in ln]
+        interval = [v for ln, v in zip(ppl, z["exp"]) if "batches" in ln]
+        print("headline from seed: step losses", [round(float(v), 5) for v in z["bwd"]], "valid", valid, "test", test)
+        save("train_headline_from_seed", words_n=np.int64(V), train_txt=np.array(texts["train"]), valid_txt=np.array(texts["valid"]),
+             test_txt=np.array(texts["test"]), argv=np.array(margs), step_loss=z["bwd"], interval_loss=np.array(interval),
+             valid_loss=np.array(valid), test_loss=np.float64(test[0]), rows=z["rows"])
+
+
 def f6_train_trajectory(seed_only=False):
     """``seed_only``: NO saved initial state -- train.py is started with ``--seed 1111`` alone, so the run begins from whatever
     its own constructors draw under that seed (incl. the second construction of ``--uncertainty none``, train.py:196-199, and the
@@ -1181,6 +1230,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "traj":
         f6_train_trajectory()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "headline_seed":
+        f6_headline_from_seed()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "traj_seed":
         f6_train_trajectory(seed_only=True)

@@ -82,3 +82,29 @@ def test_train_cli_from_the_seed_alone_reproduces_reference_train_py(tag, tmp_pa
     final = torch.load(save, map_location="cpu")
     for k, v in snaps[-1].items():
         assert float((final[k] - v).abs().max()) <= 1e-3 * (float(v.abs().max()) + 1e-12), k
+
+
+def test_headline_configuration_at_full_size_follows_the_reference_from_the_seed_alone(tmp_path, capsys):
+    """BASELINE.json configs[2] at its real size under the recipe's own flags -- Bayesian Transformer-FFN, 6 layers, d_model 512,
+    d_ff 4096, 8 heads, 33,000 words, tied, dropout 0.2, clip 1.0, batch 64 x seq_len 128 -- started with ``--seed 1111`` and nothing
+    else: three training steps of 8,192 tokens with weight noise and every dropout site on, then evaluate() on the valid and test
+    text.  The reference's own train.py did this on the CPU (tests/golden/train_headline_from_seed.npz, ``make_golden.py
+    headline_seed``); under ``--noise-source torch`` the CLI draws what the reference drew and lands on its losses: per log
+    interval, valid and test to 1e-4 (north_star: "within 1e-3 relative on fp32 for a fixed RNG seed")."""
+    from bayeslms_amd import train as T
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_headline_from_seed.npz"), allow_pickle=False)
+    d = str(tmp_path)
+    V = int(z["words_n"])
+    with open(os.path.join(d, "words.txt"), "w") as f:
+        for i, w in enumerate(["<s>", "<unk>"] + ["w%d" % i for i in range(V - 2)]):
+            f.write("%s %d\n" % (w, i))
+    for split in ("train", "valid", "test"):
+        with open(os.path.join(d, split + ".txt"), "w") as f:
+            f.write("\n".join(str(ln) for ln in z[split + "_txt"]) + "\n")
+    hist = {}
+    T.main([str(a) for a in z["argv"]] + ["--data", d, "--save", os.path.join(d, "model.pt"), "--cuda", "--noise-source", "torch"], history=hist)
+    capsys.readouterr()
+    assert len(hist["interval_loss"]) == len(z["interval_loss"]) == 2  # batches 1 (the first two steps' sum, train.py:422-436) and 2
+    assert np.allclose(hist["interval_loss"], z["interval_loss"], rtol=1e-4), (hist["interval_loss"], list(z["interval_loss"]))
+    assert np.allclose(hist["valid_loss"], z["valid_loss"], rtol=1e-4), (hist["valid_loss"], list(z["valid_loss"]))
+    assert abs(hist["test_loss"] - float(z["test_loss"])) <= 1e-4 * float(z["test_loss"])
