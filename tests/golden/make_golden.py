@@ -517,14 +517,28 @@ np.savez(out, **kw)
 """
 
 
-def f6_headline_from_seed():
-    """BASELINE.json configs[2] AT ITS REAL SIZE under the reference's own train.py, the recipe's flags (Bayesian Transformer-FFN, 6
+FULL_SIZE = {
+    # fixture name -> (V, B, T, train.py's flags): BASELINE.json configs[0] / [1] / [2] / [4] as written
+    "train_cfg0_from_seed": (10000, 20, 35, ["--model", "LSTM", "--emsize", "1024", "--nhid", "1024", "--nlayers", "2", "--uncertainty", "none",
+                                             "--dropout", "0.2", "--clip", "1.0", "--lr", "0.1"]),
+    "train_cfg1_from_seed": (33000, 64, 35, ["--model", "LSTM", "--emsize", "1024", "--nhid", "1024", "--nlayers", "2", "--uncertainty", "Bayesian",
+                                             "--L_bayes_pos", "3", "--dropout", "0.2", "--clip", "1.0", "--lr", "0.1"]),
+    "train_headline_from_seed": (33000, 64, 128, ["--model", "Transformer", "--emsize", "512", "--nhid", "4096", "--nlayers", "6", "--nhead", "8",
+                                                  "--uncertainty", "Bayesian", "--T_bayes_pos", "FFN", "--dropout", "0.2", "--clip", "1.0",
+                                                  "--lr", "0.1"]),
+    "train_cfg4_from_seed": (33000, 64, 128, ["--model", "Transformer", "--emsize", "512", "--nhid", "4096", "--nlayers", "6", "--nhead", "8",
+                                              "--uncertainty", "Gaussian", "--T_gauss_pos", "3", "--dropout", "0.2", "--clip", "1.0", "--lr", "0.1"]),
+}
+
+
+def f6_headline_from_seed(name="train_headline_from_seed"):
+    """(``name``: which of FULL_SIZE; the text below describes configs[2].)  BASELINE.json configs[2] AT ITS REAL SIZE under the reference's own train.py, the recipe's flags (Bayesian Transformer-FFN, 6
     layers, d_model 512, d_ff 4096, 8 heads, 33,000 words, tied, dropout 0.2, clip 1.0, batch 64 x seq_len 128), started from
     ``--seed 1111`` alone: three training steps of 8,192 tokens with weight noise and every dropout site on, then its
     evaluate() on the valid and test text.  Kept: the corpus, the total loss of every step, valid and test loss (no parameters:
     the model is what the seed gives).  ~50 M parameters on the CPU: a few minutes."""
     import subprocess
-    V, B, T, steps = 33000, 64, 128, 3
+    (V, B, T, flags), steps = FULL_SIZE[name], 3
     rng = np.random.RandomState(20)
     words = ["<s>", "<unk>"] + ["w%d" % i for i in range(V - 2)]
 
@@ -536,10 +550,9 @@ def f6_headline_from_seed():
             lines.append(" ".join(words[i] for i in ids))
             left -= n + 1  # + the <s> the tokenizer appends
         return lines
-    texts = {"train": text(B * (steps * T + 1) + 40), "valid": text(20 * (T + 1) + 30), "test": text(20 * (T + 1) + 30)}
-    margs = ["--model", "Transformer", "--emsize", "512", "--nhid", "4096", "--nlayers", "6", "--nhead", "8", "--uncertainty", "Bayesian",
-             "--T_bayes_pos", "FFN", "--dropout", "0.2", "--clip", "1.0", "--lr", "0.1", "--batch-size", str(B), "--seq_len", str(T),
-             "--epochs", "1", "--tied", "--log-interval", "1", "--seed", "1111"]
+    extra = 40 if B > 41 else B // 2  # rows = steps * T + 1 exactly (text() may add one token)
+    texts = {"train": text(B * (steps * T + 1) + extra), "valid": text(20 * (T + 1) + 30), "test": text(20 * (T + 1) + 30)}
+    margs = flags + ["--batch-size", str(B), "--seq_len", str(T), "--epochs", "1", "--tied", "--log-interval", "1", "--seed", "1111"]
     with tempfile.TemporaryDirectory() as dtmp:
         with open(os.path.join(dtmp, "words.txt"), "w") as f:
             for i, w in enumerate(words):
@@ -560,8 +573,8 @@ def f6_headline_from_seed():
         valid = [v for ln, v in zip(ppl, z["exp"]) if "end of epoch" in ln]
         test = [v for ln, v in zip(ppl, z["exp"]) if "End of training" in ln]
         interval = [v for ln, v in zip(ppl, z["exp"]) if "batches" in ln]
-        print("headline from seed: step losses", [round(float(v), 5) for v in z["bwd"]], "valid", valid, "test", test)
-        save("train_headline_from_seed", words_n=np.int64(V), train_txt=np.array(texts["train"]), valid_txt=np.array(texts["valid"]),
+        print(name, "step losses", [round(float(v), 5) for v in z["bwd"]], "valid", valid, "test", test)
+        save(name, words_n=np.int64(V), train_txt=np.array(texts["train"]), valid_txt=np.array(texts["valid"]),
              test_txt=np.array(texts["test"]), argv=np.array(margs), step_loss=z["bwd"], interval_loss=np.array(interval),
              valid_loss=np.array(valid), test_loss=np.float64(test[0]), rows=z["rows"])
 
@@ -1232,7 +1245,8 @@ if __name__ == "__main__":
         f6_train_trajectory()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "headline_seed":
-        f6_headline_from_seed()
+        for name in (sys.argv[2:] or list(FULL_SIZE)):
+            f6_headline_from_seed(name)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "traj_seed":
         f6_train_trajectory(seed_only=True)

@@ -84,15 +84,19 @@ def test_train_cli_from_the_seed_alone_reproduces_reference_train_py(tag, tmp_pa
         assert float((final[k] - v).abs().max()) <= 1e-3 * (float(v.abs().max()) + 1e-12), k
 
 
-def test_headline_configuration_at_full_size_follows_the_reference_from_the_seed_alone(tmp_path, capsys):
-    """BASELINE.json configs[2] at its real size under the recipe's own flags -- Bayesian Transformer-FFN, 6 layers, d_model 512,
+@pytest.mark.parametrize("name", ["train_headline_from_seed", "train_cfg0_from_seed", "train_cfg1_from_seed", "train_cfg4_from_seed"])
+def test_baseline_configurations_at_full_size_follow_the_reference_from_the_seed_alone(name, tmp_path, capsys):
+    """(``train_headline_from_seed`` is described below; the others are BASELINE.json configs[0] -- standard 2 x 1024 LSTM, 10,000
+    words, batch 20 x 35 --, configs[1] -- Bayesian LSTM gate 3, 33,000 words, batch 64 x 35 -- and configs[4]'s training leg -- GP
+    Transformer ``--T_gauss_pos 3`` at the headline shape --, each with --dropout 0.2, --clip 1.0, tied, as the recipes run them.)
+    BASELINE.json configs[2] at its real size under the recipe's own flags -- Bayesian Transformer-FFN, 6 layers, d_model 512,
     d_ff 4096, 8 heads, 33,000 words, tied, dropout 0.2, clip 1.0, batch 64 x seq_len 128 -- started with ``--seed 1111`` and nothing
     else: three training steps of 8,192 tokens with weight noise and every dropout site on, then evaluate() on the valid and test
     text.  The reference's own train.py did this on the CPU (tests/golden/train_headline_from_seed.npz, ``make_golden.py
     headline_seed``); under ``--noise-source torch`` the CLI draws what the reference drew and lands on its losses: per log
     interval, valid and test to 1e-4 (north_star: "within 1e-3 relative on fp32 for a fixed RNG seed")."""
     from bayeslms_amd import train as T
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_headline_from_seed.npz"), allow_pickle=False)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"), allow_pickle=False)
     d = str(tmp_path)
     V = int(z["words_n"])
     with open(os.path.join(d, "words.txt"), "w") as f:
