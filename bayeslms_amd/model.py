@@ -78,7 +78,7 @@ class _Site(nn.Module):
         return Drop(float(p), st.seed, self._site_base + k, st.step, st.col_offset, st.global_cols)
 
     def _torch_drop(self, p):
-        """Is this dropout site served by torch's generator in the current forward?  (NoiseState.source "torch", LSTM families.)"""
+        """Is this dropout site served by torch's generator in the current forward?  (NoiseState.source "torch", training mode.)"""
         st = self._st()
         return st.source == "torch" and self.training and p > 0.0 and not st.dropout_off
 
