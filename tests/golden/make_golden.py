@@ -353,6 +353,64 @@ def f7_scorer(cases=None):
                  argv=np.array(margs), **pack_sd(m))
 
 
+SCORER_FULL_SIZE = {
+    # fixture -> (scorer flags, reference constructor under torch.manual_seed(1111)): BASELINE.json configs[1] / [2] / [4] at their real
+    # sizes, 33,000 words; the parameters are NOT stored -- the model is what the seed gives (tests/test_init_state_cpu.py)
+    "scorer_cfg1_from_seed": (["--model", "LSTM", "--emsize", "1024", "--nhid", "1024", "--nlayers", "2", "--uncertainty", "Bayesian",
+                               "--L_bayes_pos", "3"], lambda V: ref.BayesRNNModel("LSTM", V, 1024, 1024, 2, 0.5, True, 3)),
+    "scorer_cfg2_from_seed": (["--model", "Transformer", "--emsize", "512", "--nhid", "4096", "--nlayers", "6", "--nhead", "8",
+                               "--uncertainty", "Bayesian", "--T_bayes_pos", "FFN"],
+                              lambda V: ref.BayesTransformerModel(V, 512, 8, 4096, 6, 0.5, True, "FFN")),
+    "scorer_cfg4_from_seed": (["--model", "Transformer", "--emsize", "512", "--nhid", "4096", "--nlayers", "6", "--nhead", "8",
+                               "--uncertainty", "Gaussian", "--T_gauss_pos", "3"],
+                              lambda V: ref.GaussTransformerModel(V, 512, 8, 4096, 6, 0.5, True, 3)),
+}
+
+
+def f7_scorer_full_size(names=None):
+    """The reference scorer's main() (mean weights, one hypothesis per forward, compute_sentence_scores_bayes_jianwei.py:123-173,
+    :237-274) on the BASELINE models at their real sizes: 8 utterances x 5-best over a 33,000-word vocabulary, out-of-vocabulary
+    words and an empty hypothesis among them.  Kept: the n-best text, the score file, the flags."""
+    import importlib
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    scorer = importlib.import_module("compute_sentence_scores_bayes_jianwei")
+    V = 33000
+    words = ["<s>", "<unk>"] + ["w%d" % i for i in range(V - 2)]
+    for name in (names or list(SCORER_FULL_SIZE)):
+        margs, build = SCORER_FULL_SIZE[name]
+        with tempfile.TemporaryDirectory() as dtmp:
+            with open(os.path.join(dtmp, "words.txt"), "w") as f:
+                for i, w in enumerate(words):
+                    f.write("%s %d\n" % (w, i))
+            rng = np.random.RandomState(13)
+            nb = []
+            for u in range(8):
+                for n in range(1, 6):
+                    ln = 0 if (u, n) == (3, 2) else int(rng.randint(1, 31))
+                    toks = [words[2 + min(int(rng.pareto(1.1) * 40), V - 3)] if rng.rand() > 0.1 else "zzz" for _ in range(ln)]
+                    nb.append(("utt%d-C-%d %s" % (u, n, " ".join(toks))).rstrip())
+            nbest_txt = "\n".join(nb) + "\n"
+            with open(os.path.join(dtmp, "nbest.txt"), "w") as f:
+                f.write(nbest_txt)
+            torch.manual_seed(1111)
+            with contextlib.redirect_stdout(io.StringIO()):
+                m = build(V)
+            torch.save(m.state_dict(), os.path.join(dtmp, "model.pt"))
+            old = sys.argv
+            sys.argv = ["scorer", "--nbest-list", os.path.join(dtmp, "nbest.txt"), "--outfile", os.path.join(dtmp, "out.txt"),
+                        "--vocabulary", os.path.join(dtmp, "words.txt"), "--model-path", os.path.join(dtmp, "model.pt")] + margs
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    scorer.main()
+            finally:
+                sys.argv = old
+            out_txt = open(os.path.join(dtmp, "out.txt")).read()
+            print(name, out_txt.splitlines()[:3])
+            save(name, words_n=np.int64(V), nbest_txt=np.array(nbest_txt), scores_txt=np.array(out_txt), argv=np.array(margs),
+                 seed=np.int64(1111))
+
+
 INTERP_CASES = (
     ("lstm_bayes3_interp", ["--model", "LSTM", "--emsize", "12", "--nhid", "12", "--nlayers", "2", "--uncertainty",
                             "Bayesian", "--L_bayes_pos", "3"],
@@ -1243,6 +1301,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "traj":
         f6_train_trajectory()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "scorer_full":
+        f7_scorer_full_size(sys.argv[2:])
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "headline_seed":
         for name in (sys.argv[2:] or list(FULL_SIZE)):

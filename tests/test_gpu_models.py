@@ -394,6 +394,47 @@ def test_scorer_cli_matches_reference_output(dev, tag, tmp_path):
     assert len(mc) == len(want) and all(v == v and v >= 0 for v in mc)
 
 
+@pytest.mark.parametrize("name,ctor", [
+    ("scorer_cfg1_from_seed", lambda M, V: M.BayesRNNModel("LSTM", V, 1024, 1024, 2, 0.5, True, 3)),
+    ("scorer_cfg2_from_seed", lambda M, V: M.BayesTransformerModel(V, 512, 8, 4096, 6, 0.5, True, "FFN")),
+    ("scorer_cfg4_from_seed", lambda M, V: M.GaussTransformerModel(V, 512, 8, 4096, 6, 0.5, True, 3)),
+])
+def test_scorer_cli_at_full_size_matches_the_reference_scorer(dev, name, ctor, tmp_path):
+    """BASELINE.json configs[1] / [2] / [4] at their REAL sizes (33,000 words) through the rescoring path: the reference scorer's
+    main() scored 8 utterances x 5-best (out-of-vocabulary words and an empty hypothesis among them) with the model its
+    constructor gives under torch.manual_seed(1111) -- the fixture keeps the n-best text and the score file, no parameters.  Our
+    constructor under the same seed gives the same model (tests/test_init_state_cpu.py); its state_dict goes to model.pt and the
+    scorer CLI -- padded per-utterance batches (fused decoder + NLL, packed rows) and the per-hypothesis loop -- must write the
+    reference's scores: every one within 1e-3 relative (north_star's bar for n-best rescoring scores)."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from bayeslms_amd import compute_sentence_scores as S, model as M
+    g = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    V, d = int(g["words_n"]), str(tmp_path)
+    with open(os.path.join(d, "words.txt"), "w") as f:
+        for i, w in enumerate(["<s>", "<unk>"] + ["w%d" % i for i in range(V - 2)]):
+            f.write("%s %d\n" % (w, i))
+    with open(os.path.join(d, "nbest.txt"), "w") as f:
+        f.write(str(g["nbest_txt"]))
+    torch.manual_seed(int(g["seed"]))
+    torch.save(ctor(M, V).state_dict(), os.path.join(d, "model.pt"))
+    argv = ["--nbest-list", os.path.join(d, "nbest.txt"), "--outfile", os.path.join(d, "out.txt"), "--vocabulary",
+            os.path.join(d, "words.txt"), "--model-path", os.path.join(d, "model.pt")] + [str(a) for a in g["argv"]]
+    want = [ln.split() for ln in str(g["scores_txt"]).splitlines()]
+    assert len(want) == 40
+    worst = 0.0
+    for batched in ("1", "0"):
+        S.main(argv + ["--batched", batched])
+        got = [ln.split() for ln in open(os.path.join(d, "out.txt")).read().splitlines()]
+        assert [a[0] for a in got] == [b[0] for b in want]
+        for a, b in zip(got, want):
+            err = abs(float(a[1]) - float(b[1])) / max(1.0, abs(float(b[1])))
+            worst = max(worst, err)
+            assert err <= 1e-3, (batched, a, b)
+    assert worst <= 1e-4, worst  # in fact an order of magnitude inside the bar (the file prints four decimals)
+
+
 @pytest.mark.parametrize("tag", ["tlm_ffn", "lstm_bayes3"])
 def test_mc_sample_scoring_matches_oracle(dev, tag):
     """BASELINE.json configs[4]: n-best scoring with S Monte-Carlo weight samples.  Not in the reference (it scores
