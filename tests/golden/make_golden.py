@@ -586,6 +586,14 @@ FULL_SIZE = {
                                                   "--lr", "0.1"]),
     "train_cfg4_from_seed": (33000, 64, 128, ["--model", "Transformer", "--emsize", "512", "--nhid", "4096", "--nlayers", "6", "--nhead", "8",
                                               "--uncertainty", "Gaussian", "--T_gauss_pos", "3", "--dropout", "0.2", "--clip", "1.0", "--lr", "0.1"]),
+    # the same two Bayesian configurations with the HARNESS building every nn.Dropout with p = 0 (name ends in _nodrop, fixture field
+    # zero_dropout): weight noise alone -- on our side that is the PRODUCTION path (fused feed-forward with eps handed in, matrix-core
+    # attention, fused LSTM steps), not the unfused parity blocks
+    "train_headline_nodrop_from_seed": (33000, 64, 128, ["--model", "Transformer", "--emsize", "512", "--nhid", "4096", "--nlayers", "6", "--nhead", "8",
+                                                         "--uncertainty", "Bayesian", "--T_bayes_pos", "FFN", "--dropout", "0.0", "--clip", "1.0",
+                                                         "--lr", "0.1"]),
+    "train_cfg1_nodrop_from_seed": (33000, 64, 35, ["--model", "LSTM", "--emsize", "1024", "--nhid", "1024", "--nlayers", "2", "--uncertainty", "Bayesian",
+                                                    "--L_bayes_pos", "3", "--dropout", "0.0", "--clip", "1.0", "--lr", "0.1"]),
 }
 
 
@@ -623,6 +631,8 @@ def f6_headline_from_seed(name="train_headline_from_seed"):
         out_npz = os.path.join(dtmp, "rec.npz")
         cmd = [sys.executable, probe, os.path.join(REF, "train.py"), out_npz, "--data", dtmp, "--save", os.path.join(dtmp, "model.pt")] + margs
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=REF, OMP_NUM_THREADS="8", PROBE_NO_SNAPS="1")
+        if "_nodrop" in name:
+            env["PROBE_ZERO_DROPOUT"] = "1"
         run = subprocess.run(cmd, cwd=dtmp, env=env, capture_output=True, text=True)
         assert run.returncode == 0, run.stderr[-3000:]
         z = np.load(out_npz)
@@ -634,7 +644,7 @@ def f6_headline_from_seed(name="train_headline_from_seed"):
         print(name, "step losses", [round(float(v), 5) for v in z["bwd"]], "valid", valid, "test", test)
         save(name, words_n=np.int64(V), train_txt=np.array(texts["train"]), valid_txt=np.array(texts["valid"]),
              test_txt=np.array(texts["test"]), argv=np.array(margs), step_loss=z["bwd"], interval_loss=np.array(interval),
-             valid_loss=np.array(valid), test_loss=np.float64(test[0]), rows=z["rows"])
+             valid_loss=np.array(valid), test_loss=np.float64(test[0]), rows=z["rows"], zero_dropout=np.int64("_nodrop" in name))
 
 
 def f6_train_trajectory(seed_only=False):

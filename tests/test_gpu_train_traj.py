@@ -84,8 +84,9 @@ def test_train_cli_from_the_seed_alone_reproduces_reference_train_py(tag, tmp_pa
         assert float((final[k] - v).abs().max()) <= 1e-3 * (float(v.abs().max()) + 1e-12), k
 
 
-@pytest.mark.parametrize("name", ["train_headline_from_seed", "train_cfg0_from_seed", "train_cfg1_from_seed", "train_cfg4_from_seed"])
-def test_baseline_configurations_at_full_size_follow_the_reference_from_the_seed_alone(name, tmp_path, capsys):
+@pytest.mark.parametrize("name", ["train_headline_from_seed", "train_cfg0_from_seed", "train_cfg1_from_seed", "train_cfg4_from_seed",
+                                  "train_headline_nodrop_from_seed", "train_cfg1_nodrop_from_seed"])
+def test_baseline_configurations_at_full_size_follow_the_reference_from_the_seed_alone(name, tmp_path, capsys, monkeypatch):
     """(``train_headline_from_seed`` is described below; the others are BASELINE.json configs[0] -- standard 2 x 1024 LSTM, 10,000
     words, batch 20 x 35 --, configs[1] -- Bayesian LSTM gate 3, 33,000 words, batch 64 x 35 -- and configs[4]'s training leg -- GP
     Transformer ``--T_gauss_pos 3`` at the headline shape --, each with --dropout 0.2, --clip 1.0, tied, as the recipes run them.)
@@ -105,6 +106,21 @@ def test_baseline_configurations_at_full_size_follow_the_reference_from_the_seed
     for split in ("train", "valid", "test"):
         with open(os.path.join(d, split + ".txt"), "w") as f:
             f.write("\n".join(str(ln) for ln in z[split + "_txt"]) + "\n")
+    if int(z["zero_dropout"]) if "zero_dropout" in z.files else 0:
+        # the ``_nodrop`` pair: the reference run was recorded with the harness building every nn.Dropout with p = 0; the same switch
+        # here.  With no mask to hand over the blocks stay FUSED: this is the production training path (sampled feed-forward with
+        # the eps handed in, matrix-core attention, fused LSTM steps) at real size against the reference's own run
+        build = T.build_model
+
+        def build_without_dropout(a, n):
+            m = build(a, n)
+            for mod in m.modules():
+                if hasattr(mod, "p"):
+                    mod.p = 0.0
+                if isinstance(getattr(mod, "dropout", None), float):
+                    mod.dropout = 0.0
+            return m
+        monkeypatch.setattr(T, "build_model", build_without_dropout)
     hist = {}
     T.main([str(a) for a in z["argv"]] + ["--data", d, "--save", os.path.join(d, "model.pt"), "--cuda", "--noise-source", "torch"], history=hist)
     capsys.readouterr()
