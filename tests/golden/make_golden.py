@@ -10,6 +10,13 @@ reference classes on tiny seeded inputs and stores inputs + state_dict +
 outputs as .npz (data only; no reference source is copied).  eps recovery
 follows SURVEY.md Appendix D: re-seed, replay the same ``zeros().normal_()``
 draws the layer makes, re-seed again, run the layer.
+
+Recipes (first argument; none = the layer / model / scorer fixtures of round 1): rnnv, search, search_btlm, scorer_gp,
+gp_sample, vt11, rnn_gpnn2, pos5, gpnn2, interp, late, traj (six train.py trajectories from a saved initial state),
+init (initial state_dict digests of 60 model builds under one seed), traj_seed (train.py runs started from --seed 1111 alone:
+nothing sampled / weight noise / weight noise and dropout; TRAJ_ONLY=tag,tag limits the list), headline_seed [names]
+(BASELINE configurations at full size from the seed alone, three steps + evaluate), scorer_full [names] (the reference scorer on
+the full-size models the seed gives).
 """
 import contextlib
 import io
