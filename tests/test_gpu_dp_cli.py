@@ -106,3 +106,26 @@ def test_two_rank_cli_from_the_seed_alone_follows_the_references_noisy_run(tag, 
         assert abs(hist["test_loss"] - float(z["test_loss"])) <= 1e-4 * float(z["test_loss"]), world
         for k, v in snaps[-1].items():
             assert float((final[k] - v).abs().max()) <= 1e-3 * (float(v.abs().max()) + 1e-12), (world, k)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_at_the_headline_size_follow_the_references_single_process_run(world, tmp_path):
+    """BASELINE.json configs[3] in small: the headline configuration at its REAL size (Bayesian Transformer-FFN 6L d512 ff4096, 33,000
+    words, dropout 0.2, global batch 64 x 128), data-parallel over two ranks of 32 (four of 16) columns each, started with `--seed 1111
+    --noise-source torch` -- against the reference's SINGLE-process train.py run from the same seed
+    (tests/golden/train_headline_from_seed.npz): every rank draws the global batch's eps and masks and keeps its columns / heads,
+    gradients meet in the bucketed all-reduce and the compact embedding-row exchange; interval, valid and test losses 1e-4."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "train_headline_from_seed.npz"), allow_pickle=False)
+    d = str(tmp_path)
+    V = int(z["words_n"])
+    with open(os.path.join(d, "words.txt"), "w") as f:
+        for i, w in enumerate(["<s>", "<unk>"] + ["w%d" % i for i in range(V - 2)]):
+            f.write("%s %d\n" % (w, i))
+    for split in ("train", "valid", "test"):
+        with open(os.path.join(d, split + ".txt"), "w") as f:
+            f.write("\n".join(str(ln) for ln in z[split + "_txt"]) + "\n")
+    hist, _ = _cli(world, [str(a) for a in z["argv"]] + ["--data", d, "--cuda", "--noise-source", "torch", "--save", os.path.join(d, "m.pt")],
+                   os.path.join(d, "hist.json"), ("--dist-backend", "gloo"))
+    assert np.allclose(hist["interval_loss"], z["interval_loss"], rtol=1e-4), (hist["interval_loss"], list(z["interval_loss"]))
+    assert np.allclose(hist["valid_loss"], z["valid_loss"], rtol=1e-4), (hist["valid_loss"], list(z["valid_loss"]))
+    assert abs(hist["test_loss"] - float(z["test_loss"])) <= 1e-4 * float(z["test_loss"])
