@@ -81,6 +81,22 @@ def test_struct_layout_matches_the_c_compiler(built_lib, tmp_path):
                    ctypes.sizeof(P), P.source.offset, P.model_us.offset]
 
 
+def test_c_host_example_builds_against_the_header_and_fails_cleanly_without_a_gpu(built_lib, tmp_path):
+    """examples/c_host/bayes_linear_step.c: plain C (gcc -Wall -Werror), include/bayeslm.h, the library and the HIP runtime --
+    no Python, no torch.  It links against nothing else, and on a machine without a GPU its first library call comes back as
+    a status with a message (exit code 3), not as a crash.  tests/test_gpu_kernels.py runs it on the GPU."""
+    import torch
+    from conftest import build_c_host
+    exe = build_c_host(tmp_path)
+    needed = subprocess.check_output(["readelf", "-d", exe], text=True)
+    libs = set(re.findall(r"Shared library: \[([^\]]+)\]", needed))
+    assert "libbayeslm_hip.so" in libs and not any("torch" in x or "python" in x or "c10" in x for x in libs), libs
+    if torch.cuda.is_available():
+        return
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "status -3" in r.stderr, (r.returncode, r.stdout, r.stderr)
+
+
 def test_product_path_has_no_cpu_fallback():
     import torch
     from bayeslms_amd import ops, BayesLMError

@@ -427,6 +427,20 @@ def test_integration_md_ctypes_stub_runs_as_written(dev):
     assert rc != 0 and b"blm_sample_weight" in ns["lib"].blm_last_error()
 
 
+@pytest.mark.parametrize("sizes", [(), (250, 100, 75), (1024, 512, 4096), (64, 4096, 512)])
+def test_c_host_without_python_or_torch_runs_a_bayes_linear_step(dev, tmp_path, sizes):
+    """The drop-in boundary is the C ABI, not the Python package: examples/c_host/bayes_linear_step.c (plain C + the HIP runtime,
+    built by gcc) runs one BayesLinear training step (model.py:1083-1129 and its autograd) through blm_sample_weight /
+    blm_gemm NT, NN, TN + BLM_EPI_BAYES_WGRAD and holds y, dx, dmu, dlgstd and the KL to a double-precision loop over the
+    same Philox noise (1e-4), at the default size, an odd one and the headline layer's two shapes."""
+    import subprocess
+    from conftest import build_c_host
+    exe = build_c_host(tmp_path)
+    r = subprocess.run([exe] + [str(v) for v in sizes], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK (worst relative difference" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "gfx950" in r.stdout and "returns -2" in r.stdout
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_bayes_linear_golden(dev, fused):
     """BayesLinear fwd/bwd/KL against the reference's own numbers (tests/golden/bayes_linear.npz)."""
