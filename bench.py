@@ -1155,9 +1155,21 @@ def opt_in_modes(model, tr, train, get_batch, steps_total, args, ops, engine):
             kt = timer.summary()
             ms = kt.get("sampled_gemm_fwd", {}).get("avg_ms")
             nprod = 6 if mode == "bf16x6" else 3
+            # the split modes draw ~70 W more than fp32 and their step has been seen at 16.5 and at 28.7 ms on different boxes
+            # (the fp32 step within 1 % on both): ten more steps, each bracketed on its own, say whether THIS box holds the rate
+            each = []
+            for i in range(10):
+                d, t = get_batch(train, ((args.warmup + args.steps + i) % steps_total) * T, T)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                tr.step(d, t, kl_fn=_kl_fn)
+                torch.cuda.synchronize()
+                each.append(1e3 * (time.perf_counter() - t1))
+            each.sort()
             res.append({
                 "gemm_mode": mode, "value": round(args.steps * T * data.shape[1] / el, 1), "unit": "tokens/s",
                 "ms_per_step": round(1e3 * el / args.steps, 3),
+                "step_ms_min_median_max": [round(each[0], 2), round(each[len(each) // 2], 2), round(each[-1], 2)],
                 "eval_loss_rel_diff_vs_f32": abs(loss_m - ref) / abs(ref),
                 "sampled_gemm_fwd_ms": None if ms is None else round(ms, 4),
                 "sampled_gemm_fwd_fp32_equiv_tflops": None if ms is None else round(2.0 * T * data.shape[1] * D_MODEL * D_FF / (ms * 1e-3) / 1e12, 1),
