@@ -13,6 +13,7 @@ import ctypes as C
 import math
 import os
 import threading
+import weakref
 from dataclasses import dataclass
 
 import torch
@@ -80,10 +81,65 @@ def _variational(lgstd, noise, row_lo, srows):
     return v
 
 
+class _GradSlab:
+    """Where ``param.grad`` comes from when it is None -- the state ``zero_grad()`` (set_to_none, torch's default and what the
+    reference's loop leaves behind, train.py:401) puts every parameter in at the start of every step.  A zeros_like per
+    parameter is one fill launch each: 78 launches of ~5 us per step of the headline model under the reference's own loop
+    (INTEGRATION level 1; 1.9 % of the step, rocprofv3 of tools/level1_probe.py).  Instead: the parameters seen in one step
+    get a 256-byte aligned slot each, and from the next step on the first request of a step allocates ONE zeroed slab for
+    all of them (one fill) and every request is a view into it.  A parameter asking again for a slot the current slab has
+    already handed out means a new step has begun: new slab.  Dead parameters (weak references) leave the layout when a
+    slab is built.  The data-parallel trainer never comes here: its gradients are views of engine.FlatBuffers."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.on = True
+        self.dev = {}
+
+    def take(self, param):
+        if not (self.on and param.is_cuda and param.dtype == torch.float32):
+            return torch.zeros_like(param, memory_format=torch.contiguous_format)
+        key = id(param)
+        with self.lock:
+            st = self.dev.setdefault(param.device, {"slots": {}, "total": 0, "buf": None, "claimed": set()})
+            slot = st["slots"].get(key)
+            if slot is not None and (slot[0]() is not param or slot[2] != param.numel()):
+                slot = None  # the id belongs to another tensor now
+            if slot is None:  # first sight: plain zeros now, a slot from the next step on
+                n = param.numel()
+                st["slots"][key] = (weakref.ref(param), st["total"], n)
+                st["total"] += (n + 63) // 64 * 64
+                st["buf"] = None  # the slab in use does not know the new layout
+                return torch.zeros_like(param, memory_format=torch.contiguous_format)
+            if st["buf"] is None or key in st["claimed"]:
+                off = 0
+                live = {}
+                for k, (ref, _, n) in st["slots"].items():
+                    if ref() is not None:
+                        live[k] = (ref, off, n)
+                        off += (n + 63) // 64 * 64
+                st["slots"], st["total"] = live, off
+                st["buf"] = torch.zeros(off, device=param.device, dtype=torch.float32)
+                st["claimed"] = set()
+                slot = live[key]
+            st["claimed"].add(key)
+            return st["buf"][slot[1]:slot[1] + slot[2]].view(param.shape)
+
+
+_GRAD_SLAB = _GradSlab()
+
+
+def set_grad_slab(on):
+    """False: every missing ``param.grad`` is its own zeros_like again (tests compare the two)."""
+    _GRAD_SLAB.on = bool(on)
+    with _GRAD_SLAB.lock:
+        _GRAD_SLAB.dev.clear()
+
+
 def _grad_buf(param):
-    """param.grad (allocated zeroed on first use): wgrad kernels accumulate into it."""
+    """param.grad (zeroed when it does not exist yet: a view of the step's gradient slab): wgrad kernels accumulate into it."""
     if param.grad is None:
-        param.grad = torch.zeros_like(param, memory_format=torch.contiguous_format)
+        param.grad = _GRAD_SLAB.take(param)
     return param.grad
 
 

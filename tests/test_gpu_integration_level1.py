@@ -297,3 +297,59 @@ def test_unmanaged_training_forwards_draw_fresh_noise():
     m.set_step(7)
     e, f = m(x).detach().clone(), m(x).detach().clone()
     assert m.noise_state.step == 7 and torch.equal(e, f)      # managed: the same step gives the same draw
+
+
+@pytest.mark.parametrize("family", ["tlm_ffn", "lstm_bayes3"])
+def test_missing_gradients_come_from_one_zeroed_slab_per_step(family):
+    """`zero_grad()` (set_to_none) leaves every `.grad` None, and the in-place weight-gradient kernels then need zeroed targets: from
+    the second step on they are views of ONE slab per step (ops._GradSlab: one fill instead of one per parameter -- 78 launches per
+    step of the headline model).  Same losses and parameters as with a zeros_like per parameter, under torch's own clip + SGD with
+    momentum; a fresh slab every step; a parameter that joins late or is dropped does not disturb the others."""
+    from bayeslms_amd import model as M, ops
+    dev = torch.device("cuda:0")
+    V = 70
+
+    def run(slab):
+        ops.set_grad_slab(slab)
+        torch.manual_seed(11)
+        if family == "tlm_ffn":
+            m = M.BayesTransformerModel(V, 32, 4, 64, 2, 0.1, True, "FFN").to(dev)
+        else:
+            m = M.BayesRNNModel("LSTM", V, 32, 32, 2, 0.1, True, 3).to(dev)
+        g = torch.Generator().manual_seed(3)
+        opt = torch.optim.SGD(m.parameters(), lr=0.5, momentum=0.9)
+        losses, slabs = [], []
+        hidden = m.init_hidden(6) if family != "tlm_ffn" else None
+        for step in range(4):
+            x = torch.randint(0, V, (10, 6), generator=g).to(dev)
+            t = torch.randint(0, V, (60,), generator=g).to(dev)
+            m.train()
+            m.set_step(step)
+            m.zero_grad()
+            assert all(p.grad is None for p in m.parameters())
+            if hidden is None:
+                out = m(x)
+            else:
+                out, _ = m(x, tuple(h.detach() for h in hidden))
+            loss = nn.CrossEntropyLoss()(out.view(-1, V), t)
+            loss.backward()
+            stores = {p.grad.untyped_storage().data_ptr() for p in m.parameters() if p.grad is not None}
+            slabs.append(stores)
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 0.25)
+            opt.step()
+            losses.append(float(loss))
+        return losses, slabs, {k: v.detach().clone() for k, v in m.state_dict().items()}
+    try:
+        l_on, s_on, p_on = run(True)
+        l_off, s_off, p_off = run(False)
+    finally:
+        ops.set_grad_slab(True)
+    n_par = len(p_on)
+    assert len(s_on[0]) > 3 and len(s_off[1]) > 3            # first sight / slab off: a buffer per parameter
+    # steps 1..3: the gradients written by the engine's kernels live in one storage (autograd-accumulated ones, if any, in their own)
+    for k in (1, 2, 3):
+        assert 2 * len(s_on[k]) <= len(s_off[k]), (k, len(s_on[k]), len(s_off[k]), n_par)
+    for a, b in zip(l_on, l_off):
+        assert abs(a - b) <= 1e-6 * abs(b), (l_on, l_off)
+    for k in p_on:
+        assert float((p_on[k] - p_off[k]).abs().max()) <= 1e-5 * float(p_off[k].abs().max()) + 1e-8, k
