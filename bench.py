@@ -983,6 +983,21 @@ def extra_configs(dev, args, engine, M, ops, headline_ms):
     res.append(r)
     del m
     torch.cuda.empty_cache()
+    # --- configs[4] names "Variational (--T_v_pos 11)" beside the GP Transformer.  The reference's VTransformerModel builds NO encoder
+    # layer for that value (model.py:2808-2897; 2 and 3 build nlayers - 1, 1 crashes in kl_divergence): embedding -> decoder, no KL
+    # term, nothing to sample.  That model's training step, as the reference's flags give it:
+    torch.manual_seed(1111)
+    m = M.VTransformerModel(V, D_MODEL, NHEAD, D_FF, NLAYERS, DROPOUT, True, 11).to(dev)
+    r, _ = _train_leg(m, TR.kl_selector(ns(uncertainty="Variational", T_v_pos=11)), T, B_PER_GPU, LR, steps, args.warmup, dev,
+                      engine, ops, flops_per_token=tlm_flops_per_token(T, L_=0))
+    r["id"] = "cfg4_var_tlm_v11_train"
+    r["config"] = ("BASELINE.json configs[4], its Variational half: --uncertainty Variational --T_v_pos 11 builds a VTransformerModel "
+                   "WITHOUT encoder layers in the reference (model.py:2808-2897, quirk kept and pinned by fixture vtransformer_11): "
+                   "embedding + positional encoding + tied decoder, V=33000, seq_len 128, batch 64; no KL term (train.py:387-396), "
+                   "nothing to sample (--mc-samples refuses it)")
+    res.append(r)
+    del m
+    torch.cuda.empty_cache()
     # --- the CLI itself, and the architecture search
     for name, fn in (("cfg2_deterministic", lambda: deterministic_leg(dev, args, engine, M, ops, headline_ms)),
                      ("cli", lambda: cli_leg(dev, args, headline_ms)), ("level1", lambda: level1_leg(dev, args, headline_ms)),
@@ -1237,7 +1252,8 @@ def compact_line(out, legend=True):
         "configs[2]": headline if n == 1 else None,
         "configs[3]": headline if n > 1 else None,  # the same model data-parallel: `--gpus N` runs (global batch 64 N)
         "configs[4]": ({"train_1gpu": pick("cfg4_gp_tlm_train"), "rescore_mean_weights": pick("cfg4_gp_tlm_rescore"),
-                        "rescore_8_mc_samples": pick("cfg4_gp_tlm_rescore_mc8")} if n == 1 else
+                        "rescore_8_mc_samples": pick("cfg4_gp_tlm_rescore_mc8"),
+                        "variational_T_v_pos_11_train": pick("cfg4_var_tlm_v11_train")} if n == 1 else
                        {"train_dp": pick("cfg4_gp_tlm_train_dp", "n_gpus", "replicas_identical"),
                         "rescore_8_mc_samples_dp": pick("cfg4_gp_tlm_rescore_mc8_dp", "n_gpus")}),
     }
