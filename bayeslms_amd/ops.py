@@ -96,8 +96,12 @@ class _GradSlab:
         self.on = True
         self.dev = {}
 
+    @staticmethod
+    def eligible(param):
+        return param.is_cuda and param.dtype == torch.float32
+
     def take(self, param):
-        if not (self.on and param.is_cuda and param.dtype == torch.float32):
+        if not (self.on and self.eligible(param)):
             return torch.zeros_like(param, memory_format=torch.contiguous_format)
         key = id(param)
         with self.lock:

@@ -791,3 +791,44 @@ def test_scorer_jobs_are_laid_round_robin_over_the_visible_gpus():
             job_device_index(*bad)
     base = ["--nbest-list", "a", "--outfile", "b", "--vocabulary", "c", "--model-path", "d"]
     assert build_parser().parse_args(base).job == 0 and build_parser().parse_args(base + ["--job", "4"]).job == 4
+
+
+def test_gradient_slab_bookkeeping(monkeypatch):
+    """ops._GradSlab (where a missing `.grad` comes from under the reference's zero_grad() loop) on host tensors: first sight = plain
+    zeros, later steps = views of one zeroed slab per step at 256-byte aligned offsets; a second request for a slot means a new step
+    and a new slab; parameters that died leave the layout; a parameter whose id is reused with another size is re-registered."""
+    import gc
+    import torch
+    from bayeslms_amd import ops
+    slab = ops._GradSlab()
+    monkeypatch.setattr(slab, "eligible", lambda p: p.dtype == torch.float32)
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 64, 130, 1)]
+    first = [slab.take(p) for p in ps]
+    assert all(float(g.abs().sum()) == 0.0 and g.shape == p.shape for g, p in zip(first, ps))
+    assert len({g.untyped_storage().data_ptr() for g in first}) == 4                    # first sight: a buffer each
+    step2 = [slab.take(p) for p in ps]
+    base = step2[0].untyped_storage().data_ptr()
+    assert all(g.untyped_storage().data_ptr() == base for g in step2)                  # one slab
+    offs = [g.data_ptr() - base for g in step2]
+    assert offs == [0, 256, 512, 512 + 192 * 4] and all(float(g.abs().sum()) == 0.0 for g in step2)
+    for g in step2:
+        g.add_(1.0)                                                                     # a step's gradients
+    step3 = [slab.take(p) for p in ps]                                                  # same slots asked again: next step
+    assert step3[0].untyped_storage().data_ptr() != base and all(float(g.abs().sum()) == 0.0 for g in step3)
+    assert all(float(g.sum()) == g.numel() for g in step2)                              # the previous step's views keep their values
+    # a late joiner gets plain zeros now and a slot afterwards; the slab in use is abandoned (its layout is stale)
+    late = torch.nn.Parameter(torch.randn(7, 3))
+    g_late = slab.take(late)
+    assert g_late.shape == (7, 3) and g_late.untyped_storage().data_ptr() != step3[0].untyped_storage().data_ptr()
+    step4 = [slab.take(p) for p in ps + [late]]
+    assert len({g.untyped_storage().data_ptr() for g in step4}) == 1 and step4[-1].shape == (7, 3)
+    # dead parameters leave the layout
+    total_before = slab.dev[ps[0].device]["total"]
+    del ps[2], first, step2, step3, step4
+    gc.collect()
+    step5 = [slab.take(p) for p in ps + [late]]
+    assert slab.dev[late.device]["total"] < total_before and len(slab.dev[late.device]["slots"]) == 4
+    assert len({g.untyped_storage().data_ptr() for g in step5}) == 1
+    # switched off: plain zeros
+    slab.on = False
+    assert slab.take(ps[0]).untyped_storage().data_ptr() != step5[0].untyped_storage().data_ptr()
