@@ -192,7 +192,7 @@ def test_dp_check_names_the_collective_the_ranks_disagree_on():
             assert len(lines) == 2 and lines[0].startswith("1 agreeing 16 ") and lines[1].startswith("2 compact embedding rows (U = %d) %d " % (2 + r, 16 + 8 * r))
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])  # 8: the world size of BASELINE configs[3], never run on hardware here
 def test_grad_reducer_gloo_world2(world):
     port = _free_port()
     with mp.Manager() as mgr:
@@ -253,7 +253,7 @@ def _late_rows_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_late_rows_gloo_world2(world):
     port = _free_port()
     with mp.Manager() as mgr:
@@ -311,6 +311,35 @@ def _bench(argv, env_extra=None, timeout=300):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout,
                        env=env, cwd="/tmp")
     return r, time.time() - t0
+
+
+def test_bench_under_the_drivers_own_launch_command_with_eight_ranks():
+    """The driver does not use `bench.py`'s own launcher: it runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W`.  That command, verbatim, with N = 8 -- the
+    world size of BASELINE configs[3], which has never met hardware here -- as a rehearsal on the host (gloo, --rehearse-launch: every
+    stage of the multi-rank run, no GPU work): ONE JSON line from rank 0, all eight ranks through every heartbeat, replicas equal."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--rehearse-launch"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 2 and out["warmup"] == 1 and out["value"] is None and "NOT a measurement" in out["rehearsal"]
+    c = out["comm"]
+    assert c["world_seen"] == 8 and c["replicas_identical"] is True and c["autotune"]["picked"] in c["autotune"]["ms"]
+    assert list(out)[-1] == "baseline_configs" and out["extra_configs"][0]["id"] == "rehearsal_extra_leg"  # the post-headline legs ran too
+    err = r.stderr.splitlines()
+    for rank in range(8):
+        for stage in ("rendezvous ok (world 8, backend gloo, timeout 180 s)", "first all-reduce ok", "timed region ok (2 steps)"):
+            assert any(ln.startswith("[blm rank %d +" % rank) and ln.endswith("] " + stage) for ln in err), (rank, stage)
 
 
 def test_bench_self_launches_its_ranks_from_one_process():
