@@ -659,9 +659,30 @@ def evaluate(model, source, seq_len, eval_batch_size=None, rank=0, world=1, grou
     dec = getattr(model, "decoder", None)
     fused = (os.environ.get("BLM_EVAL_FUSED_NLL", "1") != "0" and dec is not None and hasattr(dec, "nll_targets")
              and ops.linear_nll_supported(dec.weight, dec.bias))
+    # A model without carried state (the Transformers) sees every window on its own: G full windows are evaluated as ONE batch of
+    # G x columns independent columns (same positions, same causal mask per column) -- the reference's eval batch of 10-20 columns
+    # gives the matrix cores 1280-2560 rows per product, G of them ~16384 (headline model, 12 windows of 20 x 128: 1.085 M tokens/s
+    # window by window, 1.178 M in threes, 1.197 M in sixes, tools/eval_windows_probe.py).  total = sum over windows of len * mean is unchanged up
+    # to the order of the additions.  BLM_EVAL_WINDOWS=1 walks the windows one by one as train.py:441-458 does.
+    n_full = max(0, (source.size(0) - 1) // seq_len)  # windows of exactly seq_len rows; the ragged last one goes alone
+    n_win = 1
+    if hidden is None and hi > lo and not hasattr(model, "init_hidden"):
+        n_win = int(os.environ.get("BLM_EVAL_WINDOWS", "0")) or max(1, min(n_full, 16384 // max(1, seq_len * (hi - lo))))
     with torch.no_grad():
         try:
-            for i in range(0, source.size(0) - 1, seq_len):
+            i, left = 0, n_full
+            while n_win > 1 and left > 1 and hi > lo:
+                g = min(n_win, left)
+                starts = range(i, i + g * seq_len, seq_len)
+                data = torch.cat([mine[k:k + seq_len] for k in starts], 1)
+                targets = torch.cat([mine[k + 1:k + 1 + seq_len] for k in starts], 1).reshape(-1)
+                if fused:
+                    dec.nll_targets = targets
+                out = model(data)
+                loss = out.mean() if fused else ops.cross_entropy(out.view(-1, out.shape[-1]), targets)[0]
+                total += (g * seq_len) * loss.double()  # equally sized windows: sum_k len * mean_k = G len * mean of all
+                i, left = i + g * seq_len, left - g
+            for i in range(i, source.size(0) - 1, seq_len):
                 if hi <= lo:
                     break  # more ranks than columns: nothing of this stream is mine
                 data, targets = get_batch(mine, i, seq_len)

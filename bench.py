@@ -578,7 +578,7 @@ def _eval_leg(model, seq, dev, engine, vocab, flops_per_token, windows=12):
     """engine.evaluate (train.py:441-458: eval batch 20, mean weights) on held-out synthetic text: tokens/s."""
     from bayeslms_amd.data import batchify, synthetic_corpus
     valid = batchify(synthetic_corpus(vocab, 20 * (windows * seq + 1), seed=2222), 20, dev)
-    engine.evaluate(model, valid[: 2 * seq + 1], seq)
+    engine.evaluate(model, valid, seq)  # warm-up on the pass itself: a stateless model's windows run in groups, whose products have the group's row count
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss = engine.evaluate(model, valid, seq)

@@ -214,3 +214,47 @@ def test_scorer_and_evaluate_fused_nll_switches(dev, monkeypatch):
     monkeypatch.setenv("BLM_EVAL_FUSED_NLL", "0")
     b = engine.evaluate(m1, data, 16)
     assert abs(a - b) <= 1e-5 * abs(b)
+
+
+def test_evaluate_batches_the_windows_of_a_stateless_model(dev, monkeypatch):
+    """evaluate() (train.py:441-458) walks the stream window by window; a Transformer carries nothing from one window to the next, so
+    G full windows run as ONE batch of G x columns columns (BLM_EVAL_WINDOWS=G; default: as many as fill ~16384 rows; 1: one by one, the
+    reference's walk).  Same loss to rounding for every G, fused and unfused decoder, with a ragged last window and with fewer
+    windows than G; an LSTM (carried state) is never batched."""
+    from bayeslms_amd import engine, model as M
+    torch.manual_seed(6)
+    V = 64
+    g = torch.Generator().manual_seed(8)
+    m = M.BayesTransformerModel(V, 32, 4, 64, 2, 0.1, True, "FFN").to(dev)
+    calls = []
+    real = m.forward
+    m.forward = lambda x, *a, **k: (calls.append(tuple(x.shape)), real(x, *a, **k))[1]
+    for rows in (90, 97, 17, 12):  # 5 full windows + ragged, 6 full exactly (96 + 1), one full + ragged, no full window
+        data = torch.randint(0, V, (rows, 5), generator=g).to(dev)
+        for fused in ("1", "0"):
+            monkeypatch.setenv("BLM_EVAL_FUSED_NLL", fused)
+            monkeypatch.setenv("BLM_EVAL_WINDOWS", "1")
+            del calls[:]
+            ref = engine.evaluate(m, data, 16)
+            assert all(c[1] == 5 for c in calls) and len(calls) == -(-(rows - 1) // 16)
+            for G in ("0", "2", "3", "64"):
+                monkeypatch.setenv("BLM_EVAL_WINDOWS", G)
+                del calls[:]
+                got = engine.evaluate(m, data, 16)
+                assert abs(got - ref) <= 2e-6 * abs(ref), (rows, fused, G, got, ref)
+                if G == "0" and rows >= 33:
+                    assert calls[0][1] == 5 * ((rows - 1) // 16)      # every full window in one batch at this size
+                if G == "3" and rows == 97:
+                    assert [c[1] for c in calls] == [15, 15]
+                if G == "64" and rows == 90:
+                    assert [c[1] for c in calls] == [25, 5]           # five full windows at once, the ragged one alone
+                if G == "2" and rows == 90:
+                    assert [c[1] for c in calls] == [10, 10, 5, 5]    # 2 + 2 + the fifth full window + the ragged one
+    monkeypatch.delenv("BLM_EVAL_WINDOWS")
+    monkeypatch.setenv("BLM_EVAL_FUSED_NLL", "1")
+    lstm = M.RNNModel("LSTM", V, 32, 32, 2, 0.1, True).to(dev)
+    seen = []
+    real2 = lstm.forward
+    lstm.forward = lambda x, h: (seen.append(tuple(x.shape)), real2(x, h))[1]
+    engine.evaluate(lstm, torch.randint(0, V, (90, 5), generator=g).to(dev), 16)
+    assert all(sh[1] == 5 for sh in seen) and len(seen) == 6
