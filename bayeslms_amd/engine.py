@@ -666,12 +666,18 @@ def evaluate(model, source, seq_len, eval_batch_size=None, rank=0, world=1, grou
     # to the order of the additions.  BLM_EVAL_WINDOWS=1 walks the windows one by one as train.py:441-458 does.
     n_full = max(0, (source.size(0) - 1) // seq_len)  # windows of exactly seq_len rows; the ragged last one goes alone
     n_win = 1
-    if hidden is None and hi > lo and not hasattr(model, "init_hidden"):
-        n_win = int(os.environ.get("BLM_EVAL_WINDOWS", "0")) or max(1, min(n_full, 16384 // max(1, seq_len * (hi - lo))))
+    if hi > lo:
+        rows = 16384 if hidden is None else 2400  # recurrent: the time loop is issued step by step, three windows of 700 rows pay, more do not
+        n_win = int(os.environ.get("BLM_EVAL_WINDOWS", "0")) or max(1, min(max(n_full, 1), rows // max(1, seq_len * (hi - lo))))
+    # A recurrent model carries its state from window to window (repackage_hidden), so G consecutive windows ARE one window of
+    # G seq_len steps: the same recurrence step for step, with the input / decoder products over G times the rows (the LSTM
+    # language models' evaluation batch gives them 700 rows per window) and the layer wavefront over a longer stretch
+    # (configs[1]'s model, 12 windows of 20 x 35: 668 k tokens/s window by window, 765 k in threes; no better and host-bound beyond).
+    stride = seq_len * (n_win if hidden is not None else 1)
     with torch.no_grad():
         try:
             i, left = 0, n_full
-            while n_win > 1 and left > 1 and hi > lo:
+            while hidden is None and n_win > 1 and left > 1 and hi > lo:
                 g = min(n_win, left)
                 starts = range(i, i + g * seq_len, seq_len)
                 data = torch.cat([mine[k:k + seq_len] for k in starts], 1)
@@ -682,10 +688,10 @@ def evaluate(model, source, seq_len, eval_batch_size=None, rank=0, world=1, grou
                 loss = out.mean() if fused else ops.cross_entropy(out.view(-1, out.shape[-1]), targets)[0]
                 total += (g * seq_len) * loss.double()  # equally sized windows: sum_k len * mean_k = G len * mean of all
                 i, left = i + g * seq_len, left - g
-            for i in range(i, source.size(0) - 1, seq_len):
+            for i in range(i, source.size(0) - 1, stride):
                 if hi <= lo:
                     break  # more ranks than columns: nothing of this stream is mine
-                data, targets = get_batch(mine, i, seq_len)
+                data, targets = get_batch(mine, i, stride)
                 if fused:
                     dec.nll_targets = targets
                 if hidden is None:

@@ -220,7 +220,8 @@ def test_evaluate_batches_the_windows_of_a_stateless_model(dev, monkeypatch):
     """evaluate() (train.py:441-458) walks the stream window by window; a Transformer carries nothing from one window to the next, so
     G full windows run as ONE batch of G x columns columns (BLM_EVAL_WINDOWS=G; default: as many as fill ~16384 rows; 1: one by one, the
     reference's walk).  Same loss to rounding for every G, fused and unfused decoder, with a ragged last window and with fewer
-    windows than G; an LSTM (carried state) is never batched."""
+    windows than G.  A recurrent model carries its state from window to window, so G of its windows are one window of G x seq_len steps:
+    the same recurrence with G times the rows in the input / decoder products (all four LSTM families)."""
     from bayeslms_amd import engine, model as M
     torch.manual_seed(6)
     V = 64
@@ -250,11 +251,22 @@ def test_evaluate_batches_the_windows_of_a_stateless_model(dev, monkeypatch):
                     assert [c[1] for c in calls] == [25, 5]           # five full windows at once, the ragged one alone
                 if G == "2" and rows == 90:
                     assert [c[1] for c in calls] == [10, 10, 5, 5]    # 2 + 2 + the fifth full window + the ragged one
-    monkeypatch.delenv("BLM_EVAL_WINDOWS")
-    monkeypatch.setenv("BLM_EVAL_FUSED_NLL", "1")
-    lstm = M.RNNModel("LSTM", V, 32, 32, 2, 0.1, True).to(dev)
-    seen = []
-    real2 = lstm.forward
-    lstm.forward = lambda x, h: (seen.append(tuple(x.shape)), real2(x, h))[1]
-    engine.evaluate(lstm, torch.randint(0, V, (90, 5), generator=g).to(dev), 16)
-    assert all(sh[1] == 5 for sh in seen) and len(seen) == 6
+    # a recurrent model carries its state across windows: G consecutive windows are ONE window of G x seq_len steps (never a wider batch)
+    for build in (lambda: M.RNNModel("LSTM", V, 32, 32, 2, 0.1, True), lambda: M.BayesRNNModel("LSTM", V, 32, 32, 2, 0.1, True, 3),
+                  lambda: M.GaussRNNModel("LSTM", V, 32, 32, 2, 0.1, True, "33"), lambda: M.VariationalRNNModel("LSTM", V, 32, 32, 2, 0.1, True, "11")):
+        lstm = build().to(dev)
+        seen = []
+        real2 = lstm.forward
+        lstm.forward = lambda x, h, real2=real2, seen=seen: (seen.append(tuple(x.shape)), real2(x, h))[1]
+        stream = torch.randint(0, V, (90, 5), generator=g).to(dev)
+        for fused in ("1", "0"):
+            monkeypatch.setenv("BLM_EVAL_FUSED_NLL", fused)
+            monkeypatch.setenv("BLM_EVAL_WINDOWS", "1")
+            del seen[:]
+            ref = engine.evaluate(lstm, stream, 16)
+            assert [sh for sh in seen] == [(16, 5)] * 5 + [(9, 5)]
+            for G, shapes in (("2", [(32, 5), (32, 5), (25, 5)]), ("0", [(80, 5), (9, 5)]), ("4", [(64, 5), (25, 5)])):
+                monkeypatch.setenv("BLM_EVAL_WINDOWS", G)
+                del seen[:]
+                got = engine.evaluate(lstm, stream, 16)
+                assert seen == shapes and abs(got - ref) <= 3e-6 * abs(ref), (type(lstm).__name__, fused, G, seen, got, ref)
