@@ -1390,12 +1390,14 @@ def main():
             ws = torch.empty(int(L.lib().blm_mfma_probe_ws_floats()), device=dev)
             fl = C.c_double(0.0)
             L.check(L.lib().blm_mfma_probe(ws.data_ptr(), 2000, C.byref(fl), L.stream()), "blm_mfma_probe")
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            L.check(L.lib().blm_mfma_probe(ws.data_ptr(), 20000, C.byref(fl), L.stream()), "blm_mfma_probe")
-            e1.record()
-            torch.cuda.synchronize()
-            tf = fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+            tf = 0.0
+            for _ in range(3):  # best of three: the first launch after the light evaluation pass can meet a relaxed clock
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                L.check(L.lib().blm_mfma_probe(ws.data_ptr(), 20000, C.byref(fl), L.stream()), "blm_mfma_probe")
+                e1.record()
+                torch.cuda.synchronize()
+                tf = max(tf, fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
             chip = {"bare_mfma_tflops": round(tf, 1), "implied_clock_ghz": round(tf * 1e12 / (256 * 4 * 64.0) / 1e9, 2),
                     "note": "v_mfma_f32_32x32x2_f32 loop without memory traffic on this box, right after the timed steps (blm_mfma_probe): "
                             "the datasheet peak assumes 2.4 GHz"}
@@ -1425,6 +1427,13 @@ def main():
                     "avg_launch_ms": round(ms, 4), "launches": kt["sampled_gemm_fwd"]["n"]}
             if chip and chip.get("bare_mfma_tflops"):
                 roof["frac_of_this_chips_bare_mfma_rate"] = round(ach / chip["bare_mfma_tflops"], 4)
+            if traffic:  # north_star: "rocprof HBM GB/s and MFMA utilisation reported against gfx950 peak" (counter bytes / this run's launch time)
+                gbps = traffic / (ms * 1e-3) / 1e9
+                roof["hbm_gbps"] = round(gbps, 1)
+                roof["hbm_frac_of_8_tbps"] = round(gbps / 8000.0, 4)
+            util = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE.replace(".json", "_mfma_util.json"))
+            if traffic and os.path.exists(util):
+                roof["mfma_pipe_utilisation_pmc"] = round(json.load(open(util)).get("mfma_pipe_utilisation", 0.0), 4) or None
         out = {
             "metric": "train_tokens_per_sec", "value": round(tokens / elapsed, 1), "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
