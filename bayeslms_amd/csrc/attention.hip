@@ -1,7 +1,7 @@
 // Fused causal self-attention, forward and backward, one workgroup per (batch column, head).
 // Scores, softmax, probability dropout and P.V never leave the CU: K/V (forward) and then Q/dO
 // (backward) tiles sit in LDS, each lane owns one query (or key) row in registers, LDS reads are
-// wave-uniform broadcasts.  T <= 128, head_dim in {4,8,16,32,64}; every other shape (head_dim up to 512, any T) goes
+// wave-uniform broadcasts.  T <= 128, head_dim in {4,8,16,32,64} (any other size up to 128: two lanes per row); every other shape (head_dim up to 512, any T) goes
 // through the untiled one-wave-per-row kernels at the end of this file.
 //
 // Replaces model.py:889-920 (MultiheadAttention.forward core: scale, bmm, +mask, softmax, dropout,
@@ -26,6 +26,7 @@ struct AttnP {
   float *dq, *dk, *dv;
   long ldd;
   int T, B, nhead;
+  int hd;  // head_dim (the templated kernels know it at compile time; the two-lanes-per-row kernels read it here)
   float scale;
   blm_rng rng;
   uint32_t thr;
@@ -230,6 +231,223 @@ __global__ __launch_bounds__(ATT_T) void attn_bwd_kernel(const AttnP p) {
 }
 
 
+// ------------------------------------------------------------------ head_dim <= 128 (T <= 128): two lanes per row
+// The tiled kernels above hold a row's whole head in registers (q / o, k / v: 2 x head_dim values per lane), which stops at 64.
+// Here a row is shared by a lane PAIR -- lane 2 i + part holds features [64 part, 64 part + 64) of row i -- so the register
+// picture per lane is the head_dim-64 kernels', a score is the sum of the pair's two half dot products (one DPP exchange), and
+// each lane updates its own half of o / dq / dk / dv.  K / V (then Q / dO) rows sit in LDS with the two halves 68 floats apart
+// (row stride 136): the pair's two broadcast addresses of a ds_read_b128 fall into different banks.  256 threads per (column, head).
+// Any head size up to 128 that has no kernel of its own runs here (p.hd = the real size: features beyond it are zeros in LDS and in
+// the registers, train.py's defaults give 100).  Measured (tools/attn_head_dim_probe.py, T 128, B 64, 4 heads x 128): 130 / 407 us
+// forward / backward against 776 / 1680 us on the one-wave-per-query kernels.
+constexpr int WIDE_HS = 64;               // features per lane
+constexpr int WIDE_HD = 2 * WIDE_HS;      // head_dim served
+constexpr int WIDE_PS = WIDE_HS + 4;      // distance of the two halves of a row in LDS
+constexpr int WIDE_RS = 2 * WIDE_PS;      // LDS row stride
+
+__device__ __forceinline__ void load_tile_wide(float* dst, const float* src, long ld, int T, int B, int b, int off, float mul, int hd) {
+  // dst[t][68 * (c / 64) + c % 64] = c < hd ? src[(t*B+b)*ld + off + c] * mul : 0
+  constexpr int Q = WIDE_HD / 4;
+  for (int i = threadIdx.x; i < T * Q; i += 2 * ATT_T) {
+    const int t = i / Q, c = (i - t * Q) * 4;
+    const float* s = src + ((long)t * B + b) * ld + off + c;
+    float4 v;
+    if (c + 3 < hd && ((reinterpret_cast<uintptr_t>(s)) & 15) == 0) v = *reinterpret_cast<const float4*>(s);
+    else v = make_float4(c < hd ? s[0] : 0.f, c + 1 < hd ? s[1] : 0.f, c + 2 < hd ? s[2] : 0.f, c + 3 < hd ? s[3] : 0.f);
+    v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+    *reinterpret_cast<float4*>(dst + t * WIDE_RS + (c >= WIDE_HS ? c + (WIDE_PS - WIDE_HS) : c)) = v;
+  }
+}
+
+__device__ __forceinline__ float pair_sum(float x) { return x + __shfl_xor(x, 1, 64); }
+
+template <bool FULL>  // FULL: head_dim 128 exactly (no tail guards: the loads and stores stay vectorised)
+__global__ __launch_bounds__(2 * ATT_T) void attn_fwd_wide_kernel(const AttnP p) {
+  constexpr int HS = WIDE_HS;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T = p.T;
+  float* Ks = sm;
+  float* Vs = sm + T * WIDE_RS;
+  const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * (FULL ? WIDE_HD : p.hd);
+  const int i = threadIdx.x >> 1, part = threadIdx.x & 1, po = part * WIDE_PS;
+  const int nloc = FULL ? HS : min(HS, max(0, p.hd - part * HS));  // this lane's real features
+  load_tile_wide(Ks, p.k, p.ld, T, p.B, b, off, 1.f, p.hd);
+  load_tile_wide(Vs, p.v, p.ld, T, p.B, b, off, 1.f, p.hd);
+  float q[HS], o[HS];
+  const bool act = i < T;
+  if (act) {
+    const float* qs = p.q + ((long)i * p.B + b) * p.ld + off + part * HS;
+#pragma unroll
+    for (int c = 0; c < HS; ++c) { q[c] = (FULL || c < nloc) ? qs[c] * p.scale : 0.f; o[c] = 0.f; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < HS; ++c) { q[c] = 0.f; o[c] = 0.f; }
+  }
+  __syncthreads();
+  float m = -INFINITY, l = 0.f;
+  const uint64_t gbase = (((uint64_t)(p.col_offset + b) * p.nhead + head) * T + i) * (uint64_t)T;
+  const int wave_last = min(T - 1, (int)(threadIdx.x | 63) >> 1);
+  for (int j = 0; j <= wave_last; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HS; c += 4) {
+      const float4 kk = *reinterpret_cast<const float4*>(Ks + j * WIDE_RS + po + c);
+      s += q[c] * kk.x + q[c + 1] * kk.y + q[c + 2] * kk.z + q[c + 3] * kk.w;
+    }
+    s = pair_sum(s);  // every lane of the wave takes part: the exchange sits outside the causal branch
+    if (act && j <= i) {
+      const float mn = fmaxf(m, s);
+      const float corr = __expf(m - mn), pe = __expf(s - mn);
+      l = l * corr + pe;
+      const float pd = p.drop ? pe * keep_at(p, gbase + j) : pe;
+#pragma unroll
+      for (int c = 0; c < HS; c += 4) {
+        const float4 vv = *reinterpret_cast<const float4*>(Vs + j * WIDE_RS + po + c);
+        o[c] = o[c] * corr + pd * vv.x; o[c + 1] = o[c + 1] * corr + pd * vv.y;
+        o[c + 2] = o[c + 2] * corr + pd * vv.z; o[c + 3] = o[c + 3] * corr + pd * vv.w;
+      }
+      m = mn;
+    }
+  }
+  if (act) {
+    const float inv = 1.f / l;
+    float* os = p.out + ((long)i * p.B + b) * ((long)p.nhead * (FULL ? WIDE_HD : p.hd)) + off + part * HS;
+#pragma unroll
+    for (int c = 0; c < HS; ++c)
+      if (FULL || c < nloc) os[c] = o[c] * inv;
+    if (p.lse && part == 0) p.lse[(long)blockIdx.x * T + i] = m + __logf(l);
+  }
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(2 * ATT_T) void attn_bwd_wide_kernel(const AttnP p) {
+  constexpr int HS = WIDE_HS;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T = p.T;
+  float* A = sm;                     // K, then Q*scale
+  float* Bf = sm + T * WIDE_RS;      // V, then dO
+  float* lse_s = sm + 2 * T * WIDE_RS;
+  float* del_s = lse_s + T;
+  const int b = blockIdx.x / p.nhead, head = blockIdx.x % p.nhead, off = head * (FULL ? WIDE_HD : p.hd);
+  const int i = threadIdx.x >> 1, part = threadIdx.x & 1, po = part * WIDE_PS;
+  const int nloc = FULL ? HS : min(HS, max(0, p.hd - part * HS));  // this lane's real features
+  const bool act = i < T;
+  const long dmodel = (long)p.nhead * (FULL ? WIDE_HD : p.hd);
+  const uint64_t bh = (uint64_t)(p.col_offset + b) * p.nhead + head;
+
+  // ---------------- phase 1: lane pair = query row -> dQ
+  load_tile_wide(A, p.k, p.ld, T, p.B, b, off, 1.f, p.hd);
+  load_tile_wide(Bf, p.v, p.ld, T, p.B, b, off, 1.f, p.hd);
+  {
+    float q[HS], dO[HS], dq[HS];
+    float lse = 0.f, delta = 0.f;
+    if (act) {
+      const float* qs = p.q + ((long)i * p.B + b) * p.ld + off + part * HS;
+      const float* ds = p.dout + ((long)i * p.B + b) * dmodel + off + part * HS;
+      const float* os = p.o_in + ((long)i * p.B + b) * dmodel + off + part * HS;
+#pragma unroll
+      for (int c = 0; c < HS; ++c) {
+        const bool in = FULL || c < nloc;
+        q[c] = in ? qs[c] * p.scale : 0.f; dO[c] = in ? ds[c] : 0.f; dq[c] = 0.f;
+        if (in) delta += ds[c] * os[c];
+      }
+      lse = p.lse[(long)blockIdx.x * T + i];
+    } else {
+#pragma unroll
+      for (int c = 0; c < HS; ++c) { q[c] = 0.f; dO[c] = 0.f; dq[c] = 0.f; }
+    }
+    delta = pair_sum(delta);
+    if (act && part == 0) { lse_s[i] = lse; del_s[i] = delta; }
+    __syncthreads();
+    const int wave_last = min(T - 1, (int)(threadIdx.x | 63) >> 1);
+    for (int j = 0; j <= wave_last; ++j) {
+      float s = 0.f, dpd = 0.f;
+#pragma unroll
+      for (int c = 0; c < HS; c += 4) {
+        const float4 kk = *reinterpret_cast<const float4*>(A + j * WIDE_RS + po + c);
+        const float4 vv = *reinterpret_cast<const float4*>(Bf + j * WIDE_RS + po + c);
+        s += q[c] * kk.x + q[c + 1] * kk.y + q[c + 2] * kk.z + q[c + 3] * kk.w;
+        dpd += dO[c] * vv.x + dO[c + 1] * vv.y + dO[c + 2] * vv.z + dO[c + 3] * vv.w;
+      }
+      s = pair_sum(s);
+      dpd = pair_sum(dpd);
+      if (act && j <= i) {
+        const float pr = __expf(s - lse);
+        const float kp = p.drop ? keep_at(p, (bh * T + i) * (uint64_t)T + j) : 1.f;
+        const float dS = pr * (dpd * kp - delta);
+#pragma unroll
+        for (int c = 0; c < HS; c += 4) {
+          const float4 kk = *reinterpret_cast<const float4*>(A + j * WIDE_RS + po + c);
+          dq[c] += dS * kk.x; dq[c + 1] += dS * kk.y; dq[c + 2] += dS * kk.z; dq[c + 3] += dS * kk.w;
+        }
+      }
+    }
+    if (act) {
+      float* o = p.dq + ((long)i * p.B + b) * p.ldd + off + part * HS;
+#pragma unroll
+      for (int c = 0; c < HS; ++c)
+        if (FULL || c < nloc) o[c] = dq[c] * p.scale;
+    }
+  }
+  __syncthreads();
+  // ---------------- phase 2: lane pair = key row -> dK, dV
+  load_tile_wide(A, p.q, p.ld, T, p.B, b, off, p.scale, p.hd);
+  load_tile_wide(Bf, p.dout, dmodel, T, p.B, b, off, 1.f, p.hd);
+  float k[HS], v[HS];
+  const int j = i;
+  if (act) {
+    const float* ks = p.k + ((long)j * p.B + b) * p.ld + off + part * HS;
+    const float* vs = p.v + ((long)j * p.B + b) * p.ld + off + part * HS;
+#pragma unroll
+    for (int c = 0; c < HS; ++c) { k[c] = (FULL || c < nloc) ? ks[c] : 0.f; v[c] = (FULL || c < nloc) ? vs[c] : 0.f; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < HS; ++c) { k[c] = 0.f; v[c] = 0.f; }
+  }
+  __syncthreads();
+  constexpr int HH = HS / 2;  // dk / dv in two passes of 32 features: the register budget of the head_dim-64 kernel
+  const int wave_first = (int)(threadIdx.x & ~63) >> 1;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float dk[HH], dv[HH];
+#pragma unroll
+    for (int c = 0; c < HH; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+    for (int qi = wave_first; qi < T; ++qi) {
+      float s = 0.f, dpd = 0.f;
+#pragma unroll
+      for (int c = 0; c < HS; c += 4) {
+        const float4 qq = *reinterpret_cast<const float4*>(A + qi * WIDE_RS + po + c);
+        const float4 dd = *reinterpret_cast<const float4*>(Bf + qi * WIDE_RS + po + c);
+        s += qq.x * k[c] + qq.y * k[c + 1] + qq.z * k[c + 2] + qq.w * k[c + 3];
+        dpd += dd.x * v[c] + dd.y * v[c + 1] + dd.z * v[c + 2] + dd.w * v[c + 3];
+      }
+      s = pair_sum(s);
+      dpd = pair_sum(dpd);
+      if (act && j <= qi) {
+        const float pr = __expf(s - lse_s[qi]);
+        const float kp = p.drop ? keep_at(p, (bh * T + qi) * (uint64_t)T + j) : 1.f;
+        const float dS = pr * (dpd * kp - del_s[qi]);
+        const float pd = pr * kp;
+#pragma unroll
+        for (int c = 0; c < HH; c += 4) {
+          const float4 qq = *reinterpret_cast<const float4*>(A + qi * WIDE_RS + po + half * HH + c);
+          const float4 dd = *reinterpret_cast<const float4*>(Bf + qi * WIDE_RS + po + half * HH + c);
+          dk[c] += dS * qq.x; dk[c + 1] += dS * qq.y; dk[c + 2] += dS * qq.z; dk[c + 3] += dS * qq.w;
+          dv[c] += pd * dd.x; dv[c + 1] += pd * dd.y; dv[c + 2] += pd * dd.z; dv[c + 3] += pd * dd.w;
+        }
+      }
+    }
+    if (act) {
+      float* ok = p.dk + ((long)j * p.B + b) * p.ldd + off + part * HS + half * HH;
+      float* ov = p.dv + ((long)j * p.B + b) * p.ldd + off + part * HS + half * HH;
+#pragma unroll
+      for (int c = 0; c < HH; ++c)
+        if (FULL || half * HH + c < nloc) { ok[c] = dk[c]; ov[c] = dv[c]; }
+    }
+  }
+}
+
+
 // ------------------------------------------------------------------ generic fallback: any head_dim <= 512, any T
 // One wave per query (forward, dQ) or per key (dK/dV): the lanes share the head's features (feature f = lane + 64 j),
 // every score is a wave reduction, softmax is online.  No LDS, no tiling: a correctness path for the shapes the
@@ -377,8 +595,9 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_generic_kernel(const AttnP p,
   }
 }
 
-static bool tiled_ok(int T, int head_dim) {  // the LDS-tiled VALU kernels: T <= 128, head_dim a power of two up to 64
-  return T <= ATT_T && (head_dim == 4 || head_dim == 8 || head_dim == 16 || head_dim == 32 || head_dim == 64);
+static bool own_kernel(int head_dim) { return head_dim == 4 || head_dim == 8 || head_dim == 16 || head_dim == 32 || head_dim == 64; }
+static bool tiled_ok(int T, int head_dim) {  // the LDS-tiled VALU kernels: T <= 128, head_dim a power of two up to 64 -- or anything up to 128 on lane pairs
+  return T <= ATT_T && head_dim <= WIDE_HD;
 }
 
 static int fill(AttnP& p, int T, int B, int nhead, int head_dim, float pdrop, const blm_rng* rng, int col_offset,
@@ -387,7 +606,7 @@ static int fill(AttnP& p, int T, int B, int nhead, int head_dim, float pdrop, co
   if (head_dim <= 0 || head_dim > 64 * GEN_MAXJ)
     return blm_fail(BLM_ERR_UNSUPPORTED, "%s: head_dim %d not in 1..%d", who, head_dim, 64 * GEN_MAXJ);
   if (pdrop > 0.f && !rng) return blm_fail(BLM_ERR_INVALID, "%s: dropout needs rng", who);
-  p.T = T; p.B = B; p.nhead = nhead;
+  p.T = T; p.B = B; p.nhead = nhead; p.hd = head_dim;
   p.scale = 1.0f / sqrtf((float)head_dim);
   p.drop = pdrop > 0.f;
   if (p.drop) p.rng = *rng;
@@ -429,6 +648,20 @@ static int launch_fwd_valu(const AttnP& p, int T, int B, int nhead, int head_dim
     BLM_HIP(hipGetLastError());
     return BLM_OK;
   }
+  if (!own_kernel(head_dim)) {  // two lanes per row; up to 136 KB of LDS
+    const size_t ldsw = (size_t)2 * T * WIDE_RS * sizeof(float);
+    const bool full = head_dim == WIDE_HD;
+    auto kern = full ? attn_fwd_wide_kernel<true> : attn_fwd_wide_kernel<false>;
+    static bool attr_f[2] = {false, false};  // benign race (idempotent)
+    if (!attr_f[full]) {
+      BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)((size_t)2 * ATT_T * WIDE_RS * sizeof(float))));
+      attr_f[full] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(B * nhead), dim3(2 * ATT_T), ldsw, st, p);
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
+  }
   const size_t lds = (size_t)2 * T * head_dim * sizeof(float);
   DISPATCH_HD(attn_fwd_kernel, lds)
   BLM_HIP(hipGetLastError());
@@ -440,6 +673,20 @@ static int launch_bwd_valu(const AttnP& p, int T, int B, int nhead, int head_dim
     hipLaunchKernelGGL(attn_bwd_dq_generic_kernel, dim3(T, B * nhead), dim3(64), 0, st, p, head_dim);
     BLM_HIP(hipGetLastError());
     hipLaunchKernelGGL(attn_bwd_dkv_generic_kernel, dim3(T, B * nhead), dim3(64), 0, st, p, head_dim);
+    BLM_HIP(hipGetLastError());
+    return BLM_OK;
+  }
+  if (!own_kernel(head_dim)) {
+    const size_t ldsw = ((size_t)2 * T * WIDE_RS + 2 * T) * sizeof(float);
+    const bool full = head_dim == WIDE_HD;
+    auto kern = full ? attn_bwd_wide_kernel<true> : attn_bwd_wide_kernel<false>;
+    static bool attr_b[2] = {false, false};
+    if (!attr_b[full]) {
+      BLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(((size_t)2 * ATT_T * WIDE_RS + 2 * ATT_T) * sizeof(float))));
+      attr_b[full] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(B * nhead), dim3(2 * ATT_T), ldsw, st, p);
     BLM_HIP(hipGetLastError());
     return BLM_OK;
   }

@@ -650,7 +650,11 @@ def test_add_dropout_ln(dev, D):
                                           (129, 2, 2, 64), (200, 1, 3, 64), (256, 2, 1, 64), (301, 1, 2, 64), (515, 1, 1, 64),
                                           # any other head size / length: the untiled one-wave-per-row kernels
                                           # (train.py's defaults give head_dim 100)
-                                          (35, 2, 2, 100), (20, 1, 3, 7), (150, 2, 2, 32), (140, 1, 1, 100), (9, 2, 1, 130)])
+                                          (35, 2, 2, 100), (20, 1, 3, 7), (150, 2, 2, 32), (140, 1, 1, 100), (9, 2, 1, 130),
+                                          # head_dim 128, T <= 128: two lanes per row (attn_*_wide_kernel); beyond 128 steps: untiled again
+                                          (128, 3, 2, 128), (1, 2, 1, 128), (37, 5, 3, 128), (100, 64, 4, 128), (127, 1, 1, 128), (129, 1, 2, 128),
+                                          # every other head size up to 128 takes the same kernels with its tail zero-filled
+                                          (128, 2, 2, 100), (64, 3, 2, 96), (33, 2, 3, 48), (50, 2, 2, 65), (17, 1, 2, 127), (40, 2, 1, 3), (128, 1, 3, 63)])
 def test_attention_matches_oracle(dev, T, B, nhead, hd):
     ops = ops_mod()
     d = nhead * hd
@@ -675,7 +679,8 @@ def test_attention_matches_oracle(dev, T, B, nhead, hd):
 
 
 @pytest.mark.parametrize("T,B,nhead,hd", [(8, 2, 2, 4), (96, 2, 2, 64), (50, 3, 1, 64), (128, 1, 2, 64), (160, 2, 1, 64),
-                                          (203, 1, 2, 64), (30, 2, 2, 100), (131, 1, 1, 32), (66, 64, 8, 64), (30, 3, 2, 64), (16, 2, 4, 64)])
+                                          (203, 1, 2, 64), (30, 2, 2, 100), (131, 1, 1, 32), (66, 64, 8, 64), (30, 3, 2, 64), (16, 2, 4, 64),
+                                          (128, 2, 2, 128), (45, 3, 1, 128), (77, 2, 2, 100)])
 def test_attention_dropout_uses_philox_mask(dev, T, B, nhead, hd):
     """Probability dropout (VALU kernels for small heads, MFMA kernels for head_dim 64; T % 4 != 0
     takes the per-element Philox path)."""
@@ -703,7 +708,7 @@ def test_attention_dropout_uses_philox_mask(dev, T, B, nhead, hd):
 
 
 @pytest.mark.parametrize("T,B,nhead,hd", [(8, 2, 2, 4), (96, 2, 2, 64), (128, 1, 2, 64), (160, 2, 1, 64), (30, 2, 2, 100), (131, 1, 1, 32),
-                                          (7, 4, 4, 4)])
+                                          (7, 4, 4, 4), (90, 2, 2, 128)])
 @pytest.mark.parametrize("window", [False, True])
 def test_attention_with_the_dropout_mask_handed_over(dev, T, B, nhead, hd, window):
     """blm_attn_fwd_keep / blm_attn_bwd_keep (``Drop.keep``): the dropout factors of the probabilities are an operand -- the
