@@ -1580,9 +1580,37 @@ class _LSTMLayer(torch.autograd.Function):
         return dx, dh, dc, dw_ih, dw_hh, db_ih, db_hh, d_noise
 
 
+def _pad_gate_blocks(t, H, Hp, cols=False):
+    """(4H, ...) -> (4Hp, ...): gate block g = rows [g H, (g + 1) H) moves to [g Hp, g Hp + H), zeros behind it (``cols``: the last
+    dimension H -> Hp as well).  Differentiable (F.pad): its backward is the slice that drops the padding's gradient."""
+    t4 = t.reshape(4, H, *t.shape[1:])
+    pad = [0, Hp - H] if t4.dim() == 2 else ([0, Hp - H if cols else 0] + [0, 0] * (t4.dim() - 3) + [0, Hp - H])
+    return torch.nn.functional.pad(t4, pad).reshape(4 * Hp, *([Hp] if cols else t.shape[1:]))
+
+
+_PAD_HIDDEN_FROM = 64  # smaller layers stay on the GEMM + cell composition (padding 8 units to 32 would quadruple them)
+
+
 def lstm_layer(x, h0, c0, w_ih, w_hh, b_ih, b_hh, noise_rows=None):
     """One LSTM layer over T steps.  ``noise_rows`` (T, H), optional: row t is added to every batch row
-    of h_t after the cell and carried into step t+1 (VLSTMCell, reference model.py:2523-2527)."""
+    of h_t after the cell and carried into step t+1 (VLSTMCell, reference model.py:2523-2527).
+
+    A hidden size that is not a multiple of 32 (the classic word-language-model sizes: 200, 650, 1500 -- train.py's own default is
+    200) does not fit the fused step kernels' tiles and used to fall back to one skinny GEMM + one cell kernel per step: 1.4-1.9 x
+    the step time of the next multiple of 32 (tools/lstm_hidden_size_probe.py).  It is zero-padded to that multiple instead: padded
+    units have zero weights and a zero bias, so their gates are (1/2, 1/2, 0, 1/2), their cell and output stay exactly 0, and they
+    feed nothing back (their columns of W_hh are zero) -- the real units compute what they computed before.  The padding and the
+    slices that undo it are torch ops: autograd routes the gradients back to the unpadded parameters."""
+    H = w_hh.shape[1]
+    B = x.shape[1] if x.dim() == 3 else 0
+    if (H % 32 and H >= _PAD_HIDDEN_FROM and x.dim() == 3 and w_hh.dim() == 2 and w_hh.shape[0] == 4 * H
+            and (torch.is_grad_enabled() or B < _UNFUSED_STEP_B)):
+        Hp = (H + 31) // 32 * 32
+        pad = torch.nn.functional.pad
+        y, hT, cT = _LSTMLayer.apply(x, pad(h0, (0, Hp - H)), pad(c0, (0, Hp - H)), _pad_gate_blocks(w_ih, H, Hp),
+                                     _pad_gate_blocks(w_hh, H, Hp, cols=True), _pad_gate_blocks(b_ih, H, Hp),
+                                     _pad_gate_blocks(b_hh, H, Hp), None if noise_rows is None else pad(noise_rows, (0, Hp - H)))
+        return y[..., :H], hT[..., :H], cT[..., :H]
     return _LSTMLayer.apply(x, h0, c0, w_ih, w_hh, b_ih, b_hh, noise_rows)
 
 
@@ -1847,7 +1875,7 @@ def lstm_stack2_ok(x, w_hh1, w_hh2, w_ih2):
         # deterministic mode keeps the stack on one stream unless the wavefront is forced on (set_lstm_wavefront(True)): with one K
         # slice per tile its per-chunk products are bit-identical to the sequential layers', which is what makes the forced form
         # a bitwise race check of the stream schedule (tests/test_gpu_deterministic.py)
-        on = B <= 32 and T >= 32 and not is_deterministic()
+        on = B <= 32 and T >= 32 and H >= 640 and not is_deterministic()
     else:
         on = _STACK2_ON
     return (on and T >= 8 and H % 32 == 0 and w_hh2.shape[1] == H and w_ih2.shape[1] == H and w_hh1.is_contiguous() and w_hh2.is_contiguous()
@@ -1861,7 +1889,10 @@ def lstm_stack2_ok(x, w_hh1, w_hh2, w_ih2):
 #   cfg2 (T 35, B 64: the kernels fill the chip, layer 2's per-chunk input GEMM of M = 320 rows and the one-chunk lag give the
 #   overlap back): 6.65 -> 6.74 ms;  cfg1 (T 35, B 20): 2.31 -> 2.21 ms with three chunks of 12 steps (2.30 with 5-step
 #   chunks, 2.31 with 16 + 16 + 3), evaluate() at T 35 / B 20 1.14 -> 1.07 ms.
-# Rule: on for B <= 32 and T >= 32; BLM_LSTM_WAVEFRONT=0|1 / set_lstm_wavefront(True | False) force it, None = rule.
+#   smaller layers (round 5, tools/lstm_hidden_size_probe.py, T 35, B 20, off / on): H 128: 528 / 421 k tokens/s, 256: 500 / 447 k,
+#   512: 465 / 441 k, 768: 362 / 361 k, 672: 349 / 386 k, 1536: 197 / 201 k -- the step kernels of a small layer are a few dozen
+#   workgroups and the step is host-bound: the second stream's events cost more than the overlap returns.
+# Rule: on for B <= 32, T >= 32 and H >= 640; BLM_LSTM_WAVEFRONT=0|1 / set_lstm_wavefront(True | False) force it, None = rule.
 _env_wf = os.environ.get("BLM_LSTM_WAVEFRONT")
 _STACK2_ON = None if _env_wf is None else _env_wf == "1"
 

@@ -66,6 +66,8 @@ def _run(rank, world, port, ret, family="tlm_ffn", T=12):
     stream = torch.randint(0, 150, (8 * (4 * T + 13),), generator=torch.Generator().manual_seed(1))
     train = D.batchify(stream, 8, dev, rank, world)
     m, kl_fn, is_rnn = _build(dev, family)
+    if is_rnn and T >= 32:
+        ops.set_lstm_wavefront(True)  # these models are 32 units wide: the measured rule (H >= 640) would keep their layers on one stream
     stack2 = []
     real_stack2 = ops.lstm_stack2
     ops.lstm_stack2 = lambda *a, **k: (stack2.append(1), real_stack2(*a, **k))[1]
