@@ -225,6 +225,31 @@ def _f32(t, name):
     return dev_tensor(t, name, torch.float32)
 
 
+def _rows2d(t, N, name):
+    """-> ((M, N) view of ``t``, its row stride).  The logits of a vocabulary that is not a multiple of 4 words (wikitext-2: 33278)
+    live in a buffer whose rows are padded to one (below): the kernels take the row stride, so such a tensor is used as it is; any
+    other layout is made contiguous first, as `_f32` does."""
+    if t.dim() >= 2 and t.shape[-1] == N and not t.is_contiguous() and t.stride(-1) == 1 and t.is_cuda and t.dtype == torch.float32:
+        try:
+            v = t.view(-1, N)  # fails if the leading dimensions are not uniformly strided
+        except RuntimeError:
+            v = None
+        if v is not None and v.stride(0) >= N and v.stride(0) % 4 == 0 and v.data_ptr() % 16 == 0:
+            dev_tensor(v[:1], name, torch.float32)  # the device checks of the product path
+            return v, v.stride(0)
+    c = _f32(t, name)
+    return c.reshape(-1, N), N
+
+
+def _padded_rows(lead_shape, N, device):
+    """An (..., N) fp32 tensor whose rows start 16 bytes aligned: a view of a buffer with the row stride rounded up to 4 floats."""
+    M = 1
+    for d in lead_shape:
+        M *= int(d)
+    Np = (N + 3) // 4 * 4
+    return torch.empty(M, Np, device=device, dtype=torch.float32)[:, :N].view(*lead_shape, N), Np
+
+
 class _P:
     """Row addresses of a contiguous tensor: ``_P(t)[i]`` == ``t[i].data_ptr()`` without building a view per time step
     (six views per LSTM step cost more host time than the 12 us kernel they feed)."""
@@ -416,8 +441,8 @@ def _gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, alpha, accumulate, epilogue, b
     check(lib().blm_gemm(C.byref(a), stream()), "blm_gemm")
 
 
-def _colsum_into(dy2, M, N, out, accumulate=True):
-    check(lib().blm_colsum(ptr(dy2), N, ptr(out), M, N, 1 if accumulate else 0, stream()), "blm_colsum")
+def _colsum_into(dy2, M, N, out, accumulate=True, ld=None):
+    check(lib().blm_colsum(ptr(dy2), N if ld is None else int(ld), ptr(out), M, N, 1 if accumulate else 0, stream()), "blm_colsum")
 
 
 # ----------------------------------------------------------------------------
@@ -429,8 +454,23 @@ class _Linear(torch.autograd.Function):
         x = _f32(x, "x")
         N, K = w.shape
         M = x.numel() // K
-        y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
-        gemm(L.GEMM_NT, x, w, y, M, N, K, K, K, N, epilogue=L.EPI_BIAS if b is not None else L.EPI_NONE, bias=b)
+        if N % 4 and N >= 64:
+            # an output width that is not a multiple of 4 (a vocabulary of 33278 words): rows of N floats are not 16-byte aligned,
+            # which took this product's epilogue, the cross entropy and BOTH backward products (the logits' gradient is their
+            # A operand) off their vector paths -- the headline step 19.9 -> 26.4 ms (tools/shape_cliff_probe.py).  The rows are
+            # padded to a multiple of 4 floats instead; what the caller sees is the (..., N) view of that buffer.
+            # The product itself runs on a copy of the weight with Np - N zero rows behind it (and a zero-padded bias): every extent
+            # a multiple of 4, the padding columns of the output exactly 0.
+            y, ldy = _padded_rows(x.shape[:-1], N, x.device)
+            pad = torch.nn.functional.pad
+            w_p = pad(w.detach(), (0, 0, 0, ldy - N))
+            b_p = pad(b.detach(), (0, ldy - N)) if b is not None else None
+            gemm(L.GEMM_NT, x, w_p, y, M, ldy, K, K, K, ldy, epilogue=L.EPI_BIAS if b is not None else L.EPI_NONE, bias=b_p)
+            ctx.w_p = w_p if (ctx.needs_input_grad[0]) else None
+        else:
+            y, ldy = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32), N
+            gemm(L.GEMM_NT, x, w, y, M, N, K, K, K, ldy, epilogue=L.EPI_BIAS if b is not None else L.EPI_NONE, bias=b)
+            ctx.w_p = None
         ctx.save_for_backward(x)
         ctx.w, ctx.b, ctx.link = w, b, link
         if link is not None and ctx.needs_input_grad[0]:
@@ -441,9 +481,13 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         w, b = ctx.w, ctx.b
-        dy = _f32(dy, "dy")
         N, K = w.shape
         M = x.numel() // K
+        dy, ldy = _rows2d(dy, N, "dy")  # the padded rows of an odd vocabulary's logits come back as they went out
+        Np = (N + 3) // 4 * 4
+        if (N % 4 and N >= 64 and ldy == Np and ctx.link is None
+                and (dy.storage_offset() + (M - 1) * Np + Np) * 4 <= dy.untyped_storage().nbytes()):
+            return _Linear._backward_padded(ctx, x, w, b, dy, M, N, Np, K)
         dx = None
         if ctx.needs_input_grad[0]:
             parked = ctx.link.take(x) if ctx.link is not None else None
@@ -451,22 +495,57 @@ class _Linear(torch.autograd.Function):
                 # this op feeds the LayerNorm directly and no dropout sits between them: the LayerNorm backward hands ONE
                 # buffer out as dx and dy, and a GEMM cannot accumulate into its own A operand
                 dx = torch.empty_like(x)
-                gemm(L.GEMM_NN, dy, w, dx, M, K, N, N, K, K)
+                gemm(L.GEMM_NN, dy, w, dx, M, K, N, ldy, K, K)
                 dx.add_(parked)
             elif parked is not None:  # residual block: add into the LayerNorm backward's dx (ResidualLink)
-                gemm(L.GEMM_NN, dy, w, parked, M, K, N, N, K, K, accumulate=True)
+                gemm(L.GEMM_NN, dy, w, parked, M, K, N, ldy, K, K, accumulate=True)
                 dx = parked
             else:
                 dx = torch.empty_like(x)
-                gemm(L.GEMM_NN, dy, w, dx, M, K, N, N, K, K)
+                gemm(L.GEMM_NN, dy, w, dx, M, K, N, ldy, K, K)
         dw = db = None
         fuse_b = w.requires_grad and b is not None and b.requires_grad and b.is_leaf
         if w.requires_grad:
             buf, acc, dw = _wgrad_target(w)
-            gemm(L.GEMM_TN, dy, x, buf, N, K, M, N, K, K, accumulate=acc, colsum_a=_grad_buf(b) if fuse_b else None)
+            gemm(L.GEMM_TN, dy, x, buf, N, K, M, ldy, K, K, accumulate=acc, colsum_a=_grad_buf(b) if fuse_b else None)
         if b is not None and b.requires_grad and not fuse_b:
             buf, acc, db = _wgrad_target(b)
-            _colsum_into(dy, M, N, buf, accumulate=acc)
+            _colsum_into(dy, M, N, buf, accumulate=acc, ld=ldy)
+        _notify(w, b)
+        return dx, dw, db, None
+
+    @staticmethod
+    def _backward_padded(ctx, x, w, b, dy, M, N, Np, K):
+        """Backward over the padded layout of an output whose width is not a multiple of 4: dy is the (M, N) window of an
+        (M, Np) buffer.  Both products take the whole buffer -- the gradient of the logits is their A operand, and its contiguous
+        extent has to be a multiple of 4 for the vector / LDS-DMA loaders -- with the padding columns zeroed (the forward left
+        zeros there and the cross entropy writes only real columns, but the buffer may be anybody's) against the zero-row padded
+        weight; the weight gradient's padding rows are dropped when it is added to ``w.grad``."""
+        full = dy.as_strided((M, Np), (Np, 1))
+        full[:, N:].zero_()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w_p = ctx.w_p if ctx.w_p is not None else torch.nn.functional.pad(w.detach(), (0, 0, 0, Np - N))
+            dx = torch.empty_like(x)
+            gemm(L.GEMM_NN, full, w_p, dx, M, K, Np, Np, K, K)
+        dw = db = None
+        want_b = b is not None and b.requires_grad
+        if w.requires_grad:
+            dw_p = torch.empty(Np, K, device=x.device, dtype=torch.float32)
+            db_p = torch.zeros(Np, device=x.device, dtype=torch.float32) if want_b else None
+            gemm(L.GEMM_TN, full, x, dw_p, Np, K, M, Np, K, K, colsum_a=db_p)
+            if w.is_leaf:
+                _grad_buf(w).add_(dw_p[:N])
+            else:
+                dw = dw_p[:N]
+            if want_b:
+                if b.is_leaf:
+                    _grad_buf(b).add_(db_p[:N])
+                else:
+                    db = db_p[:N]
+        elif want_b:
+            buf, acc, db = _wgrad_target(b)
+            _colsum_into(full, M, N, buf, accumulate=acc, ld=Np)
         _notify(w, b)
         return dx, dw, db, None
 
@@ -1074,9 +1153,12 @@ class _CrossEntropy(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, targets, unit_grad, keep=False):
-        logits = _f32(logits, "logits")
-        targets = dev_tensor(targets, "targets", torch.int64)
         V = logits.shape[-1]
+        whole = logits                      # what autograd gets back as the gradient in the fused form: the caller's tensor ...
+        logits, ld = _rows2d(logits, V, "logits")  # rows padded to 4 floats (odd vocabulary, ops._Linear) are taken as they are
+        if whole.data_ptr() != logits.data_ptr():
+            whole = logits.view(whole.shape)  # ... or the contiguous copy that had to be made of it, in its shape
+        targets = dev_tensor(targets, "targets", torch.int64)
         M = logits.numel() // V
         if targets.numel() != M:
             raise BayesLMError("cross_entropy: %d targets for %d rows" % (targets.numel(), M))
@@ -1088,24 +1170,24 @@ class _CrossEntropy(torch.autograd.Function):
         fuse = grad_mode and unit_grad and not keep
         lse = torch.empty(M, device=logits.device, dtype=torch.float32) if (grad_mode and not fuse) else None
         L.require_gfx950()
-        check(lib().blm_ce_fwd_bwd(ptr(logits), V, ptr(targets), ptr(nll), ptr(lse), ptr(loss),
+        check(lib().blm_ce_fwd_bwd(ptr(logits), ld, ptr(targets), ptr(nll), ptr(lse), ptr(loss),
                                    ptr(logits) if fuse else None, 1.0 / M, M, V, stream()), "blm_ce_fwd_bwd")
         if fuse:  # the buffer now holds the gradient: any other autograd consumer of the logits must fail, not read it
-            torch.autograd.graph.increment_version(logits)
+            torch.autograd.graph.increment_version(whole)
         inv_count = None
         if keep:  # torch's mean: over the targets that are not ignore_index (device-side count, no host synchronisation)
             inv_count = 1.0 / (targets != -100).sum().clamp_(min=1).to(torch.float32)
-            ctx.save_for_backward(logits)  # version-checked at backward
-            ctx.meta = (None, targets, lse, fuse, M, V, keep, inv_count)
+            ctx.save_for_backward(whole)  # version-checked at backward
+            ctx.meta = (None, targets, lse, fuse, M, V, keep, inv_count, ld)
         else:
-            ctx.meta = (logits, targets, lse, fuse, M, V, keep, None)
+            ctx.meta = (whole, targets, lse, fuse, M, V, keep, None, ld)
         ctx.mark_non_differentiable(nll)
         ctx.set_materialize_grads(False)  # no zero fill for the per-token NLL's (non-existent) gradient
         return (loss * inv_count if keep else loss / M), nll
 
     @staticmethod
     def backward(ctx, g, _g_nll):
-        logits, targets, lse, fuse, M, V, keep, inv_count = ctx.meta
+        logits, targets, lse, fuse, M, V, keep, inv_count, ld = ctx.meta
         if g is None:
             return None, None, None, None
         if fuse:
@@ -1114,9 +1196,15 @@ class _CrossEntropy(torch.autograd.Function):
         if keep:
             (logits,) = ctx.saved_tensors
             g = g * (inv_count * M)  # the kernel scales by 1 / M
-        # keep: the caller's logits stay what they are (a user loop may still read them after backward): the gradient gets its own buffer
-        out = torch.empty_like(logits) if keep else logits
-        check(lib().blm_ce_bwd(ptr(logits), V, ptr(targets), ptr(lse), ptr(g), 1.0 / M, ptr(out), M, V, stream()),
+        # keep: the caller's logits stay what they are (a user loop may still read them after backward): the gradient gets its own
+        # buffer, rows strided as the logits' (one stride serves both in the kernel)
+        if not keep:
+            out = logits
+        elif ld == V:
+            out = torch.empty_like(logits)
+        else:
+            out = torch.empty(M, ld, device=logits.device, dtype=torch.float32)[:, :V].view(logits.shape)
+        check(lib().blm_ce_bwd(ptr(logits), ld, ptr(targets), ptr(lse), ptr(g), 1.0 / M, ptr(out), M, V, stream()),
               "blm_ce_bwd")
         if not keep:
             torch.autograd.graph.increment_version(logits)

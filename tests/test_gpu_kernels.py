@@ -785,6 +785,50 @@ def test_cross_entropy(dev, M, V):
         assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
 
 
+@pytest.mark.parametrize("V", [33278, 1001, 67, 10002])
+def test_a_vocabulary_that_is_not_a_multiple_of_4_keeps_the_vector_paths(dev, V):
+    """wikitext-2 has 33278 words: rows of V floats are not 16-byte aligned, which used to take the decoder's epilogue, the cross
+    entropy and both backward products off their vector paths (headline step 19.9 -> 26.4 ms).  ops.linear pads the rows of such an
+    output to a multiple of 4 floats and hands out the (..., V) view; the cross entropy and the backward products take the row
+    stride.  Against torch: logits, loss (engine trainer form, the reference loop's form and `.view(-1, V)` as train.py:404 does),
+    every gradient; the padding columns are never read as data."""
+    ops = ops_mod()
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(V)
+    T, B, K = 6, 5, 32
+    x = (torch.randn(T, B, K, generator=g) * 0.5)
+    w = (torch.randn(V, K, generator=g) * 0.1)
+    b = torch.randn(V, generator=g) * 0.1
+    t = torch.randint(0, V, (T * B,), generator=g)
+    ref_leaves = [a.clone().requires_grad_(True) for a in (x, w, b)]
+    ref_logits = F.linear(*ref_leaves)
+    ref = F.cross_entropy(ref_logits.view(-1, V), t)
+    ref.backward()
+    for form in ("engine", "engine_unit", "torch_loop"):
+        xs, ws, bs = [a.to(dev).requires_grad_(True) for a in (x, w, b)]
+        y = ops.linear(xs, ws, bs)
+        assert y.shape == (T, B, V) and y.stride(-1) == 1 and y.stride(-2) % 4 == 0 and y.stride(-2) >= V and y.data_ptr() % 16 == 0
+        assert (y.stride(-2) == V) == (V % 4 == 0)
+        assert rel(y, ref_logits) < 1e-5
+        if form == "torch_loop":   # the reference's loop: nn.CrossEntropyLoss on output.view(-1, ntokens) of the model's Logits
+            y = ops.as_logits(y)
+            before = y.detach().clone()
+            loss = torch.nn.CrossEntropyLoss()(y.view(-1, V), t.to(dev))
+        else:
+            loss, nll = ops.cross_entropy(y.view(-1, V), t.to(dev), unit_grad=form == "engine_unit")
+            assert nll.shape == (T * B,)
+        assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+        loss.backward()
+        for a, r, name in zip((xs, ws, bs), ref_leaves, ("x", "w", "b")):
+            assert rel(a.grad, r.grad) < 2e-5, (form, name)
+        if form == "torch_loop":
+            assert torch.equal(y.detach().as_subclass(torch.Tensor), before)  # the caller's logits are untouched
+    # a strided tensor the helper cannot take as it is (rows not 16-byte aligned) is copied, not misread
+    odd = torch.randn(T * B, V + 1, generator=g).to(dev)[:, 1:]
+    loss2, _ = ops.cross_entropy(odd.clone().requires_grad_(True)[:, :], t.to(dev))
+    assert abs(float(loss2) - float(F.cross_entropy(odd.cpu(), t))) < 1e-5 * abs(float(loss2))
+
+
 def test_colsum_and_clip_sgd(dev):
     ops, lib = ops_mod(), L()
     g = torch.Generator().manual_seed(6)
