@@ -2381,10 +2381,33 @@ def lstm_recurrent_gpnn2(xw, h0, c0, w_hh, coef_w, coef_b, fmean, flgstd, noises
 
 
 def lstm_recurrent_gp_supported(H, w_rec):
-    return H % 32 == 0
+    return H % 32 == 0 or H >= _PAD_HIDDEN_FROM  # other sizes from 64 up are zero-padded to the next multiple of 32 (below)
+
+
+def _pad_last_gate_blocks(t, H, Hp):
+    """(..., 4H) -> (..., 4Hp), gate block g of the last dimension moved to [g Hp, g Hp + H)."""
+    return torch.nn.functional.pad(t.reshape(*t.shape[:-1], 4, H), (0, Hp - H)).reshape(*t.shape[:-1], 4 * Hp)
 
 
 def lstm_recurrent_gp(xw, h0, c0, w_rec, coef4=None, ovr=-1, rbias=None, w_cell=None):
+    """The GP-LSTM recurrence on the fused step kernels (_LSTMRecurrentGP).  A hidden size that is not a multiple of 32 is
+    zero-padded as in ``lstm_layer`` (650: 71 k -> the padded rate, tools/lstm_family_hidden_size_probe.py): with zero recurrent
+    rows / columns, zero pre-activations and ZERO mixture coefficients a padded unit's GP gate is 0 and its other gates 1/2, so its
+    cell and output stay exactly 0 whichever gate the GPNN sits on; pad and slice are torch ops (autograd undoes them)."""
+    G = xw.shape[-1]
+    H = G // 4
+    if H % 32 and H >= _PAD_HIDDEN_FROM and G == 4 * H and tuple(w_rec.shape) == (G, H):
+        Hp = (H + 31) // 32 * 32
+        pad = torch.nn.functional.pad
+        ovr = int(ovr)
+        c4 = coef4
+        if coef4 is not None and ovr >= 0:
+            c4 = _pad_last_gate_blocks(coef4, H, Hp) if coef4.shape[-1] == 4 * H else pad(coef4, (0, Hp - H))
+        rb = _pad_last_gate_blocks(rbias, H, Hp) if (rbias is not None and ovr >= 4) else rbias
+        wc = pad(w_cell, (0, Hp - H, 0, Hp - H)) if (w_cell is not None and ovr == 5) else w_cell
+        y, hT, cT = _LSTMRecurrentGP.apply(_pad_last_gate_blocks(xw, H, Hp), pad(h0, (0, Hp - H)), pad(c0, (0, Hp - H)),
+                                           _pad_gate_blocks(w_rec, H, Hp, cols=True), c4, ovr, rb, wc)
+        return y[..., :H], hT[..., :H], cT[..., :H]
     return _LSTMRecurrentGP.apply(xw, h0, c0, w_rec, coef4, ovr, rbias, w_cell)
 
 

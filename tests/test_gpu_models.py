@@ -1520,3 +1520,40 @@ def test_scorer_packed_tokens_equal_padded_layout(dev, kind, monkeypatch):
     a, b = np.asarray(out[0]), np.asarray(out[1])
     assert a.shape == b.shape and len(a) == sum(len(h) for h in nbest.values())
     np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gauss_pos", ["13", "23", "33", "43", "63", "73", "6360"])
+def test_gp_lstm_pads_a_hidden_size_that_is_not_a_multiple_of_32(gauss_pos, monkeypatch):
+    """A GP-LSTM whose hidden size is not a multiple of 32 used to leave the fused step kernels for the step-wise loop (650 units:
+    71 k tokens/s against 305 k at 672).  ops.lstm_recurrent_gp zero-pads it -- weights, pre-activations AND mixture coefficients, so a
+    padded unit's GP gate is 0, its cell and output stay 0 -- for every place the GPNN can sit (gate types 1-4, 6, 7; two cells).  The
+    padded fused path against the unpadded step-wise loop (itself pinned by the gauss_rnn fixtures): logits, carried state, every gradient."""
+    from bayeslms_amd import model as M, ops
+    dev = torch.device("cuda:0")
+    V, H, T, B = 90, 72, 6, 5
+    g = torch.Generator().manual_seed(31)
+    x = torch.randint(0, V, (T, B), generator=g).to(dev)
+    go = torch.randn(T, B, V, generator=g).to(dev)
+    res = {}
+    for padded in (True, False):
+        monkeypatch.setattr(ops, "_PAD_HIDDEN_FROM", 64 if padded else 1 << 30)
+        torch.manual_seed(17)
+        m = M.GaussRNNModel("LSTM", V, H, H, 2, 0.0, True, gauss_pos).to(dev)
+        calls = []
+        real = ops._LSTMRecurrentGP.apply
+        monkeypatch.setattr(ops._LSTMRecurrentGP, "apply", staticmethod(lambda *a: (calls.append(tuple(a[3].shape)), real(*a))[1]))
+        m.train()
+        out, hid = m(x, m.init_hidden(B))
+        (out.as_subclass(torch.Tensor) * go).sum().backward()
+        res[padded] = (out.detach().as_subclass(torch.Tensor).clone(), [h.detach().clone() for h in hid],
+                       {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, calls)
+        monkeypatch.setattr(ops._LSTMRecurrentGP, "apply", real)
+    assert res[True][3] and all(s == (4 * 96, 96) for s in res[True][3]) and not res[False][3]   # 72 -> 96 on the fused kernels / the loop
+    assert rel(res[True][0], res[False][0]) < 1e-5
+    for a, b in zip(res[True][1], res[False][1]):
+        assert a.shape == b.shape and rel(a, b) < 1e-5
+    assert set(res[True][2]) == set(res[False][2])
+    for k in res[True][2]:
+        a, b = res[True][2][k], res[False][2][k]
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 5e-5 * float(b.abs().max()) + 1e-8, k

@@ -17,7 +17,7 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     dev = torch.device("cuda:0")
     torch.manual_seed(1111)
-    V = bench.V
+    V = int(os.environ.get("V", bench.V))  # e.g. V=33278 (wikitext-2): a vocabulary that is not a multiple of 4 words
     if kind == "tlm":
         m, mtype = M.BayesTransformerModel(V, 512, 8, 4096, 6, 0.2, True, "FFN").to(dev), "Transformer"
     else:
