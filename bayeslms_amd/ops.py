@@ -241,6 +241,22 @@ def _rows2d(t, N, name):
     return c.reshape(-1, N), N
 
 
+def _row_chunks(M, ld):
+    """Row ranges of an (M, ld) fp32 operand that each stay under 2^32 bytes.  The LDS-DMA loaders of the GEMM kernels address an
+    operand with 32-bit byte offsets (include/bayeslm.h: larger operands take the guarded loaders, at roughly half the rate); the
+    logits' gradient of a 256 x 128 token batch over 33,000 words is 4.3 GB, and the 288 GB of an MI355X invite such batches
+    (tools/batch_size_probe.py: 410 k tokens/s at B 128, 353 k at B 256).  The decoder's backward products run chunk by chunk instead."""
+    lim = ((1 << 32) - 1) // (4 * max(int(ld), 1))
+    if M <= lim or lim < 256:
+        return [(0, M)]
+    n = -(-M // lim)
+    step = (-(-M // n) + 127) // 128 * 128
+    while step > lim:
+        n += 1
+        step = (-(-M // n) + 127) // 128 * 128
+    return [(r, min(M, r + step)) for r in range(0, M, step)]
+
+
 def _padded_rows(lead_shape, N, device):
     """An (..., N) fp32 tensor whose rows start 16 bytes aligned: a view of a buffer with the row stride rounded up to 4 floats."""
     M = 1
@@ -502,12 +518,17 @@ class _Linear(torch.autograd.Function):
                 dx = parked
             else:
                 dx = torch.empty_like(x)
-                gemm(L.GEMM_NN, dy, w, dx, M, K, N, ldy, K, K)
+                dx2 = dx.view(-1, K)
+                for r0, r1 in _row_chunks(M, ldy):  # one chunk unless dy is 4 GB or more
+                    gemm(L.GEMM_NN, dy[r0:r1], w, dx2[r0:r1], r1 - r0, K, N, ldy, K, K)
         dw = db = None
         fuse_b = w.requires_grad and b is not None and b.requires_grad and b.is_leaf
         if w.requires_grad:
             buf, acc, dw = _wgrad_target(w)
-            gemm(L.GEMM_TN, dy, x, buf, N, K, M, ldy, K, K, accumulate=acc, colsum_a=_grad_buf(b) if fuse_b else None)
+            x2 = x.view(-1, K)
+            for r0, r1 in _row_chunks(M, ldy):
+                gemm(L.GEMM_TN, dy[r0:r1], x2[r0:r1], buf, N, K, r1 - r0, ldy, K, K, accumulate=acc or r0 > 0,
+                     colsum_a=_grad_buf(b) if fuse_b else None)
         if b is not None and b.requires_grad and not fuse_b:
             buf, acc, db = _wgrad_target(b)
             _colsum_into(dy, M, N, buf, accumulate=acc, ld=ldy)
@@ -527,13 +548,17 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             w_p = ctx.w_p if ctx.w_p is not None else torch.nn.functional.pad(w.detach(), (0, 0, 0, Np - N))
             dx = torch.empty_like(x)
-            gemm(L.GEMM_NN, full, w_p, dx, M, K, Np, Np, K, K)
+            dx2 = dx.view(-1, K)
+            for r0, r1 in _row_chunks(M, Np):
+                gemm(L.GEMM_NN, full[r0:r1], w_p, dx2[r0:r1], r1 - r0, K, Np, Np, K, K)
         dw = db = None
         want_b = b is not None and b.requires_grad
         if w.requires_grad:
             dw_p = torch.empty(Np, K, device=x.device, dtype=torch.float32)
             db_p = torch.zeros(Np, device=x.device, dtype=torch.float32) if want_b else None
-            gemm(L.GEMM_TN, full, x, dw_p, Np, K, M, Np, K, K, colsum_a=db_p)
+            x2 = x.view(-1, K)
+            for r0, r1 in _row_chunks(M, Np):
+                gemm(L.GEMM_TN, full[r0:r1], x2[r0:r1], dw_p, Np, K, r1 - r0, Np, K, K, accumulate=r0 > 0, colsum_a=db_p)
             if w.is_leaf:
                 _grad_buf(w).add_(dw_p[:N])
             else:
