@@ -861,3 +861,42 @@ def test_gradient_slab_bookkeeping(monkeypatch):
     # switched off: plain zeros
     slab.on = False
     assert slab.take(ps[0]).untyped_storage().data_ptr() != step5[0].untyped_storage().data_ptr()
+
+
+def test_shape_helpers_of_the_off_baseline_paths():
+    """Host logic behind three round-5 fixes for shapes other than BASELINE's: the row chunks that keep a GEMM operand under the
+    LDS-DMA loaders' 2^32-byte offset limit (logits of large batches), the gate-block padding of LSTM operands whose hidden size is
+    not a multiple of 32, and the padded-row buffer / row-stride view of a vocabulary that is not a multiple of 4 words."""
+    import torch
+    from bayeslms_amd import ops
+    # --- row chunks
+    assert ops._row_chunks(8192, 33000) == [(0, 8192)]                       # the headline: one launch, as before
+    assert ops._row_chunks(32768, 33000) == [(0, 16384), (16384, 32768)]     # T 128 x B 256: 4.3 GB of logits
+    for M, ld in ((32768, 33000), (70016, 33000), (100000, 50000), (5, 1 << 31), (40000, 33280)):
+        ch = ops._row_chunks(M, ld)
+        assert ch[0][0] == 0 and ch[-1][1] == M and all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
+        if len(ch) > 1:
+            assert all((b - a) * ld * 4 < (1 << 32) and (b - a) % 128 == 0 for a, b in ch[:-1]) and (ch[-1][1] - ch[-1][0]) * ld * 4 < (1 << 32)
+    # --- gate-block padding: block g of (4H, ...) lands at rows [g Hp, g Hp + H), zeros behind it; differentiable
+    H, Hp, I = 5, 8, 3
+    w = torch.arange(4 * H * I, dtype=torch.float32).reshape(4 * H, I).requires_grad_(True)
+    wp = ops._pad_gate_blocks(w, H, Hp)
+    assert wp.shape == (4 * Hp, I) and torch.equal(wp.reshape(4, Hp, I)[:, :H], w.detach().reshape(4, H, I))
+    assert float(wp.reshape(4, Hp, I)[:, H:].abs().sum()) == 0.0
+    (wp * torch.arange(4 * Hp * I, dtype=torch.float32).reshape(4 * Hp, I)).sum().backward()
+    assert w.grad.shape == w.shape and float(w.grad[H, 0]) == float(Hp * I)   # gate block 1, unit 0 sits at padded row Hp
+    wh = torch.arange(4 * H * H, dtype=torch.float32).reshape(4 * H, H)
+    whp = ops._pad_gate_blocks(wh, H, Hp, cols=True)
+    assert whp.shape == (4 * Hp, Hp) and torch.equal(whp.reshape(4, Hp, Hp)[:, :H, :H], wh.reshape(4, H, H)) and float(whp.sum()) == float(wh.sum())
+    b = torch.arange(4 * H, dtype=torch.float32)
+    assert torch.equal(ops._pad_gate_blocks(b, H, Hp).reshape(4, Hp)[:, :H], b.reshape(4, H))
+    x = torch.arange(2 * 3 * 4 * H, dtype=torch.float32).reshape(2, 3, 4 * H)
+    xp = ops._pad_last_gate_blocks(x, H, Hp)
+    assert xp.shape == (2, 3, 4 * Hp) and torch.equal(xp.reshape(2, 3, 4, Hp)[..., :H], x.reshape(2, 3, 4, H)) and float(xp.sum()) == float(x.sum())
+    # --- padded rows: a (..., N) view whose rows start 16 bytes apart-aligned; `.view(-1, N)` (train.py:404) keeps working
+    y, ld = ops._padded_rows((6, 5), 33278, "cpu")
+    assert y.shape == (6, 5, 33278) and ld == 33280 and y.stride() == (5 * 33280, 33280, 1)
+    flat = y.view(-1, 33278)
+    assert flat.shape == (30, 33278) and flat.stride() == (33280, 1) and flat.data_ptr() == y.data_ptr()
+    y2, ld2 = ops._padded_rows((4,), 1000, "cpu")
+    assert ld2 == 1000 and y2.is_contiguous()
