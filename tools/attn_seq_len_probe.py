@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Causal attention forward / backward (one-launch backward with the dS workspace) through the C ABI at 8192 tokens, 8 heads x 64,
+dropout 0.2, against the sequence length (T 64 ... 2048): T <= 128 on the one-tile kernels, beyond on the chunked (flash-style) ones.
+One MI355X, round 5: forward 32 us (T 128) ... 276 us (T 2048, 62 TFLOP/s of causal work), backward 74 ... 1340 us; T 129 costs 117 / 341 us."""
 import os, sys, ctypes
 sys.path.insert(0, ".")
 import torch

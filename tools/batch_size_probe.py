@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Training tokens/s against the batch size: the headline Transformer at T 128, B 16 ... 256 and the configs[1] Bayesian LSTM at T 35,
+B 8 ... 256 (last column: fraction of the fp32 MFMA peak).  -> profiles/r05_batch_size_probe.txt"""
 import os, sys
 sys.path.insert(0, ".")
 import torch, bench

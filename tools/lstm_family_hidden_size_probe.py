@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""The Bayesian / GP / Variational LSTM language models at 650 against 672 hidden units (V 10000, batch 20, seq_len 35): what an odd
+hidden size costs each family.  -> profiles/r05_lstm_hidden_size_probe.txt"""
 import os, sys
 sys.path.insert(0, ".")
 import torch, bench

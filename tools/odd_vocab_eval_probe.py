@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""evaluate() of the headline Transformer and the 2 x 1024 LSTM at V = 33000 against 33278 (wikitext-2: not a multiple of 4 words, so
+the decoder cannot be fused with the cross entropy and the logits are stored -- with padded rows): 1.19 M / 735 k tokens/s either way."""
 import os, sys
 sys.path.insert(0, ".")
 import torch, bench
