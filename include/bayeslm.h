@@ -364,9 +364,13 @@ int blm_add_dropout_ln_bwd(const float* dout, const float* s, const float* gamma
 /* Fused causal self-attention for qkv packed (T, B, 3*d) [q|k|v], head index
  * = b*nhead + head, head_dim = d/nhead (model.py:876-920).  Scaling
  * head_dim^-0.5, additive causal mask, softmax, dropout p on the
- * probabilities, P.V.  Saves lse (B*nhead, T) for backward.  T <= 128,
- * head_dim <= 64 in this round.  q/k/v may also be three separate (T,B,d)
- * tensors (BayesMultiheadAttention, model.py:975-977): pass ld_qkv = d. */
+ * probabilities, P.V.  Saves lse (B*nhead, T) for backward.  Any T and any
+ * head_dim <= 512 are taken; which kernels run: head_dim 64 -- matrix cores
+ * (T <= 128 one tile, longer sequences chunked); 4 / 8 / 16 / 32 at T <= 128 --
+ * vector ALU, a query per lane; any other head_dim <= 128 at T <= 128 -- vector
+ * ALU, two lanes per row; everything else -- one wave per query, untiled.
+ * q/k/v may also be three separate (T,B,d) tensors (BayesMultiheadAttention,
+ * model.py:975-977): pass ld_qkv = d. */
 int blm_attn_fwd(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, float* lse, int T, int B,
                  int nhead, int head_dim, float p, const blm_rng* rng, int col_offset, int global_cols, void* stream);
 int blm_attn_bwd(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out, const float* dout,
