@@ -151,9 +151,9 @@ __global__ __launch_bounds__(TPB) void add_pe_dropout_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------ residual + dropout + LayerNorm
-// One wave per row; the row lives in registers (VPT float4 per lane) when D == 256*VPT, else the
-// generic kernel re-reads s from s_out.
-template <int VPT>
+// One wave per row; the row lives in registers (VPT float4 per lane) when D == 256*VPT -- or, RAG, when D is any multiple of 4 up to
+// 256*VPT (the lanes past the row carry zeros: 384, 640, train.py's default 200 ...); else the generic kernel re-reads s from s_out.
+template <int VPT, bool RAG = false>
 __global__ __launch_bounds__(TPB) void add_drop_ln_fwd_reg(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ out,
@@ -168,6 +168,7 @@ __global__ __launch_bounds__(TPB) void add_drop_ln_fwd_reg(const float* __restri
 #pragma unroll
   for (int v = 0; v < VPT; ++v) {
     const int j = (v * 64 + lane) * 4;
+    if (RAG && j >= D) { s[v] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
     const float4 a = *reinterpret_cast<const float4*>(x + row * D + j);
     const float4 c = *reinterpret_cast<const float4*>(y + row * D + j);
     const float4 kp = keep4(dk, t, b, j);
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(TPB) void add_drop_ln_fwd_reg(const float* __restri
   float var = 0.f;
 #pragma unroll
   for (int v = 0; v < VPT; ++v) {
+    if (RAG && (v * 64 + lane) * 4 >= D) continue;
     const float dx = s[v].x - mean, dy = s[v].y - mean, dz = s[v].z - mean, dw = s[v].w - mean;
     var += dx * dx + dy * dy + dz * dz + dw * dw;
   }
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(TPB) void add_drop_ln_fwd_reg(const float* __restri
 #pragma unroll
   for (int v = 0; v < VPT; ++v) {
     const int j = (v * 64 + lane) * 4;
+    if (RAG && j >= D) continue;
     const float4 g = *reinterpret_cast<const float4*>(gamma + j);
     const float4 be = *reinterpret_cast<const float4*>(beta + j);
     if (s_out) *reinterpret_cast<float4*>(s_out + row * D + j) = s[v];
@@ -234,7 +237,7 @@ constexpr int LN_BWD_BLOCKS = 256;
 
 // Each wave walks rows row = blockIdx*4 + wave + k*gridDim*4; per-lane partial dgamma/dbeta for its
 // columns stay in registers, then waves combine through LDS and the block writes one partial row.
-template <int VPT>
+template <int VPT, bool RAG = false>
 __global__ __launch_bounds__(TPB) void add_drop_ln_bwd_reg(const float* __restrict__ dout, const float* __restrict__ s,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ mean_i,
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(TPB) void add_drop_ln_bwd_reg(const float* __restri
 #pragma unroll
   for (int v = 0; v < VPT; ++v) {
     pg[v] = pb[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-    g[v] = *reinterpret_cast<const float4*>(gamma + (v * 64 + lane) * 4);
+    g[v] = (RAG && (v * 64 + lane) * 4 >= D) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(gamma + (v * 64 + lane) * 4);
   }
   for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
     const int t = (int)(row / dk.B), b = (int)(row % dk.B);
@@ -257,6 +260,7 @@ __global__ __launch_bounds__(TPB) void add_drop_ln_bwd_reg(const float* __restri
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
       const int j = (v * 64 + lane) * 4;
+      if (RAG && j >= D) { xh[v] = dxh[v] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
       const float4 d = *reinterpret_cast<const float4*>(dout + row * D + j);
       const float4 sv = *reinterpret_cast<const float4*>(s + row * D + j);
       xh[v] = make_float4((sv.x - mean) * rstd, (sv.y - mean) * rstd, (sv.z - mean) * rstd, (sv.w - mean) * rstd);
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(TPB) void add_drop_ln_bwd_reg(const float* __restri
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
       const int j = (v * 64 + lane) * 4;
+      if (RAG && j >= D) continue;
       float4 ds;
       ds.x = rstd * (dxh[v].x - m1 - xh[v].x * m2); ds.y = rstd * (dxh[v].y - m1 - xh[v].y * m2);
       ds.z = rstd * (dxh[v].z - m1 - xh[v].z * m2); ds.w = rstd * (dxh[v].w - m1 - xh[v].w * m2);
@@ -284,6 +289,7 @@ __global__ __launch_bounds__(TPB) void add_drop_ln_bwd_reg(const float* __restri
 #pragma unroll
   for (int v = 0; v < VPT; ++v) {
     const int j = (v * 64 + lane) * 4;
+    if (RAG && j >= D) continue;
     *reinterpret_cast<float4*>(sm + (wave * 2 + 0) * D + j) = pg[v];
     *reinterpret_cast<float4*>(sm + (wave * 2 + 1) * D + j) = pb[v];
   }
@@ -924,8 +930,17 @@ extern "C" int blm_add_dropout_ln_fwd(const float* x, const float* y, const floa
 #define LN_FWD(V) hipLaunchKernelGGL(add_drop_ln_fwd_reg<V>, grid, dim3(TPB), 0, ST, x, y, gamma, beta, out, s_out, mean, rstd, M, eps_ln, dk)
   if (al && D == 256) LN_FWD(1);
   else if (al && D == 512) LN_FWD(2);
-  else if (al && D == 1024) LN_FWD(4);
+  else if (al && D == 768) LN_FWD(3);   // the widths between the powers of two (768, 1280, 1536) used to take the generic kernel:
+  else if (al && D == 1024) LN_FWD(4);  // a d_model 768 model spent a sixth of its step there (tools/shape_cliff_probe.py)
+  else if (al && D == 1280) LN_FWD(5);
+  else if (al && D == 1536) LN_FWD(6);
   else if (al && D == 2048) LN_FWD(8);
+#define LN_FWD_RAG(V) hipLaunchKernelGGL((add_drop_ln_fwd_reg<V, true>), grid, dim3(TPB), 0, ST, x, y, gamma, beta, out, s_out, mean, rstd, M, eps_ln, dk)
+  else if (al && D % 4 == 0 && D < 256) LN_FWD_RAG(1);    // any other multiple of 4 up to 1024: the same kernels, the tail lanes idle
+  else if (al && D % 4 == 0 && D < 512) LN_FWD_RAG(2);
+  else if (al && D % 4 == 0 && D < 768) LN_FWD_RAG(3);
+  else if (al && D % 4 == 0 && D < 1024) LN_FWD_RAG(4);
+#undef LN_FWD_RAG
   else
     hipLaunchKernelGGL(add_drop_ln_fwd_generic, grid, dim3(TPB), 0, ST, x, y, gamma, beta, out, s_out ? s_out : out, mean,
                        rstd, M, eps_ln, dk);
@@ -957,8 +972,17 @@ extern "C" int blm_add_dropout_ln_bwd(const float* dout, const float* s, const f
 #define LN_BWD(V) hipLaunchKernelGGL(add_drop_ln_bwd_reg<V>, dim3(nblk), dim3(TPB), lds, ST, dout, s, gamma, mean, rstd, dx, dy, ws, M, dk)
   if (al && D == 256) LN_BWD(1);
   else if (al && D == 512) LN_BWD(2);
+  else if (al && D == 768) LN_BWD(3);
   else if (al && D == 1024) LN_BWD(4);
+  else if (al && D == 1280) LN_BWD(5);
+  else if (al && D == 1536) LN_BWD(6);
   else if (al && D == 2048) LN_BWD(8);
+#define LN_BWD_RAG(V) hipLaunchKernelGGL((add_drop_ln_bwd_reg<V, true>), dim3(nblk), dim3(TPB), lds, ST, dout, s, gamma, mean, rstd, dx, dy, ws, M, dk)
+  else if (al && D % 4 == 0 && D < 256) LN_BWD_RAG(1);
+  else if (al && D % 4 == 0 && D < 512) LN_BWD_RAG(2);
+  else if (al && D % 4 == 0 && D < 768) LN_BWD_RAG(3);
+  else if (al && D % 4 == 0 && D < 1024) LN_BWD_RAG(4);
+#undef LN_BWD_RAG
   else {  // four partial rows per workgroup (one per wave): a quarter of the blocks fills the same workspace
     nblk = (nblk + 3) / 4;
     BLM_HIP(hipMemsetAsync(ws, 0, (size_t)2 * 4 * nblk * D * sizeof(float), ST));

@@ -614,7 +614,7 @@ def test_dropout_mask_is_the_philox_mask_and_column_sharding(dev):
     assert torch.equal(y1, y[:, 4:])
 
 
-@pytest.mark.parametrize("D", [16, 512, 1024])
+@pytest.mark.parametrize("D", [16, 18, 100, 200, 384, 512, 640, 768, 1000, 1024, 1100, 1280, 1536])
 def test_add_dropout_ln(dev, D):
     ops = ops_mod()
     T, B = 6, 5

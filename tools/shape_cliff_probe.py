@@ -47,6 +47,10 @@ if which in ("tlm", "all"):
     tlm(33000, 768, 12, 3072)
     tlm(33000, 1024, 16, 4096)
     tlm(33000, 1000, 8, 4000)
+if which == "ln":  # the widths whose LayerNorm left the register kernels before round 5 (768) / still does (384)
+    tlm(33000, 768, 12, 3072)
+    tlm(33000, 384, 6, 1536)
+    tlm(33000, 1536, 24, 6144, L=2)
 if which in ("vocab", "all"):
     for V in (33000, 33278, 33001, 10001):
         tlm(V, 512, 8, 4096)
